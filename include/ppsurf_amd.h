@@ -1,0 +1,108 @@
+/*
+ * ppsurf_amd -- C ABI of the MI355X-native occupancy-query path of PPSurf.
+ *
+ * The reference (cg-tuwien/ppsurf) is pure Python: its seam is Python functions/classes, not an FFI
+ * (SURVEY.md 8b).  This header is the boundary a maintainer of the reference would bind (ctypes stub in
+ * INTEGRATION.md); each entry point names the reference code it replaces (paths relative to the
+ * reference root).
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer owned by the caller (PyTorch tensors), row-major, unless it is
+ *     marked [host];
+ *   - `stream` is a hipStream_t (NULL = default stream); launches are asynchronous;
+ *   - return value: 0 ok, 1 bad argument, 2 launch failure (hipGetLastError != success).  No exceptions,
+ *     no allocation inside: scratch comes from the caller;
+ *   - "point-major" means [n,3] / [n,C] with the coordinate / channel fastest.
+ */
+#ifndef PPSURF_AMD_H
+#define PPSURF_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* library / device info --------------------------------------------------------------------------- */
+int pps_abi_version(void);                       /* bumps when a signature changes */
+int pps_device_cu_count(void);                   /* multiProcessorCount of the current device, <0 on error */
+
+/* ---- spatial queries ---------------------------------------------------------------------------- */
+
+/* Exact brute-force k nearest neighbours, k <= 64.
+ * replaces: source/poco_utils.py:257-273 `knn` -> source/base/proximity.py:40-89 (pykdtree on the CPU).
+ * d2 = ((dx*dx + dy*dy) + dz*dz) in fp32 without FMA contraction; neighbours sorted by (d2, index).
+ * pts [n,3], query [m,3] point-major; out_idx int64 [m,k]; out_d2 f32 [m,k] or NULL.  Requires 1 <= k <= min(n,64). */
+int pps_knn_f32(const float* pts, int64_t n, const float* query, int64_t m, int k,
+                int64_t* out_idx, float* out_d2, void* stream);
+
+/* Gather P neighbours per query from the raw cloud, centre at the query, divide by the max neighbour distance.
+ * replaces: source/poco_utils.py:67-72 `_get_pts_local_ps` (gather + normalise part) and
+ *           source/ppsurf_data_loader.py:91-123 `normalize_patches/get_patch_radii/model_space_to_patch_space`.
+ * raw [n,3]; query [q,3]; idx int64 [q, idx_stride] (first p columns used); out f32 [q,p,3]. */
+int pps_patch_normalize_f32(const float* raw, const float* query, const int64_t* idx, int64_t idx_stride,
+                            int64_t q, int p, float* out, void* stream);
+
+/* ---- decoder weights: host-side packing into MFMA operand order --------------------------------- */
+/* All `W` are dense [out,in] row-major fp32 [host], already BatchNorm-folded / composed by the caller
+ * (ppsurf_amd/decoder.py).  Packed images are plain float arrays the caller uploads to the device. */
+
+/* size in floats of the packed image of a dense layer [out,in] (both padded to multiples of 16, out to 32) */
+size_t pps_packed_dense_floats(int out, int in);
+/* packed[ob][kb][lane][s] = W[16*ob + (lane&15)][16*kb + 4*(lane>>4) + s]  (zero padded) */
+int pps_pack_dense_f32(const float* W, int out, int in, float* packed /* [host] */);
+/* xyz layer [out,3]: packed[ob][lane] = W[16*ob + (lane&15)][lane>>4] (0 for lane>>4 == 3) */
+size_t pps_packed_xyz_floats(int out);
+int pps_pack_xyz_f32(const float* W, int out, float* packed /* [host] */);
+
+/* ---- decoder kernels (eval mode, BatchNorm folded) ---------------------------------------------- */
+
+/* out[m, n_out] = in[m, 256] * W^T + b   (one dense layer over rows; used for G = fc1[:, :256] * latent + b1).
+ * replaces: the latent part of fc1 in source/poco_model.py:400-405, hoisted from per (query,neighbour) to per point.
+ * in: element (row r, channel c) at in[r*in_row_stride + c*in_ch_stride]  (point-major: (256,1); channel-first: (1,n)).
+ * wpack: pps_pack_dense_f32 image of W [256,256]; bias f32 [256]; out point-major [m,256]. */
+int pps_rows_dense256_f32(const float* in, int64_t in_row_stride, int64_t in_ch_stride, int64_t m,
+                          const float* wpack, const float* bias, float* out, void* stream);
+
+/* Interpolation-attention branch up to the pooled feature (C = 256, heads = 64, k <= 64).
+ * replaces: source/poco_model.py:381-414 `InterpAttentionKHeadsNet.forward` (gather, fc1..fc3, fc_query,
+ *           softmax over neighbours, mean over heads, weighted sum); fc_value and fc8 are applied after the
+ *           pooling by pps_decode_tail_f32 (sum_j a_j = 1).
+ * G [n,256] (see above); pts [n,3]; query [q,3]; idx int64 [q,k];
+ * wpack = concat(xyz pack of fc1[:,256:259] [256,3], dense packs of fc2, fc3 [256,256], fc_query [64,256]);
+ * bias = concat(b2[256], b3[256], bq[64]); pooled out f32 [q,256]. */
+int pps_interp_pool_f32(const float* G, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
+                        const float* wpack, const float* bias, float* pooled, void* stream);
+
+/* PointNet branch, phase A: per patch point conv0a, conv0b, STN conv1..3, max over the patch.
+ * replaces: source/base/nn.py:323-324 and :164-170.   patches [q,p,3]; out g [q,256].
+ * wpack = concat(xyz pack conv0a [64,3], dense conv0b [64,64], stn.conv1 [64,64], stn.conv2 [128,64], stn.conv3 [256,128]);
+ * bias = concat(64,64,64,128,256). */
+int pps_pointnet_stn_rows_f32(const float* patches, int64_t q, int p, const float* wpack, const float* bias,
+                              float* g, void* stream);
+
+/* PointNet branch, phase B: STN fully connected part 256 -> 128 -> 64 -> 4096 (+identity, folded into the bias).
+ * replaces: source/base/nn.py:183-189.   g [q,256]; trans2 out [q,64,64].
+ * wpack = concat(dense fc1 [128,256], fc2 [64,128], fc3 [4096,64]); bias = concat(128,64,4096). */
+int pps_pointnet_stn_fc_f32(const float* g, int64_t q, const float* wpack, const float* bias, float* trans2, void* stream);
+
+/* PointNet branch, phase C: conv0a/0b (recomputed), feature transform, conv1..3, attention pooling weights,
+ * pooled (pre fc_value) feature.   replaces: source/base/nn.py:323-336 and :84-96 (value conv applied in the tail).
+ * patches [q,p,3]; trans2 [q,64,64]; xbar out [q,256].
+ * wpack = concat(xyz conv0a, dense conv0b [64,64], conv1 [64,64], conv2 [128,64], conv3 [256,128]);
+ * bias = concat(64,64,64,128,256, att.fc_query weight [256], att.fc_query bias [1] padded to 4). */
+int pps_pointnet_feat_rows_f32(const float* patches, const float* trans2, int64_t q, int p, const float* wpack,
+                               const float* bias, float* xbar, void* stream);
+
+/* Tail: [pooled | xbar] (512) -> 256 (ReLU) -> 256 (ReLU) -> 2 logits.
+ * replaces: fc_value+fc8 (poco_model.py:410-417), att.fc_value (nn.py:89-93), the branch sum
+ *           (source/ppsurf_model.py:100) and source/base/nn.py:415-417 `MLP.forward`, composed on the host.
+ * wpack = concat(dense Wa [256,256], Wb [256,256], L2 [256,256], L3 [2,256] (padded to 32)); bias = concat(256,256,32).
+ * logits out f32 [q,2]; occ out f32 [q] = softmax(logits)[0]-softmax(logits)[1] (poco_utils.py:78-81) or NULL. */
+int pps_decode_tail_f32(const float* pooled, const float* xbar, int64_t q, const float* wpack, const float* bias,
+                        float* logits, float* occ, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPSURF_AMD_H */

@@ -1,0 +1,56 @@
+"""ctypes binding of the C ABI declared in include/ppsurf_amd.h.
+
+The product path has NO fallback: if libppsurf_amd.so is missing or fails to load, importing an op raises.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libppsurf_amd.so')
+
+_c = ctypes
+_P, _I64, _I, _SZ = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/ppsurf_amd.h one to one
+SIGNATURES = {
+    'pps_abi_version': (_I, []),
+    'pps_device_cu_count': (_I, []),
+    'pps_knn_f32': (_I, [_P, _I64, _P, _I64, _I, _P, _P, _P]),
+    'pps_patch_normalize_f32': (_I, [_P, _P, _P, _I64, _I64, _I, _P, _P]),
+    'pps_packed_dense_floats': (_SZ, [_I, _I]),
+    'pps_pack_dense_f32': (_I, [_P, _I, _I, _P]),
+    'pps_packed_xyz_floats': (_SZ, [_I]),
+    'pps_pack_xyz_f32': (_I, [_P, _I, _P]),
+    'pps_rows_dense256_f32': (_I, [_P, _I64, _I64, _I64, _P, _P, _P, _P]),
+    'pps_interp_pool_f32': (_I, [_P, _P, _P, _P, _I64, _I, _P, _P, _P, _P]),
+    'pps_pointnet_stn_rows_f32': (_I, [_P, _I64, _I, _P, _P, _P, _P]),
+    'pps_pointnet_stn_fc_f32': (_I, [_P, _I64, _P, _P, _P, _P]),
+    'pps_pointnet_feat_rows_f32': (_I, [_P, _P, _I64, _I, _P, _P, _P, _P]),
+    'pps_decode_tail_f32': (_I, [_P, _P, _I64, _P, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class PpsError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise PpsError('{} not found: build it with `python -m ppsurf_amd.build` (hipcc, gfx950). '
+                           'There is no CPU fallback.'.format(LIB_PATH))
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise PpsError('{} failed with status {} ({})'.format(what, rc, {1: 'bad argument', 2: 'launch failure'}.get(rc, '?')))

@@ -1,0 +1,141 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) kernels of ppsurf_amd.
+//
+// Register-resident activation tiles for the f32-input MFMA `v_mfma_f32_16x16x4_f32`:
+// one wave owns a tile of 16 ROWS (neighbours / patch points / queries) x C channels and keeps it in
+// registers in the MFMA C/D layout, so that the output of one dense layer IS the B operand of the next
+// layer without any data movement (the K index of the contraction is permuted consistently in the
+// packed weights).  Block b (16 channels) is one f32x4 per lane:
+//     lane l = (n = l & 15, g = l >> 4), register r   <->   row n, channel 16*b + 4*g + r.
+// Weights are packed on the host (pps_pack.cpp) as  [ob][kb][lane][4]  floats with
+//     packed[ob][kb][l][s] = W[16*ob + (l & 15)][16*kb + 4*(l >> 4) + s]
+// so one ds_read_b128 / global_load_dwordx4 per lane feeds the A operand of 4 consecutive MFMAs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PPS_WAVE 64
+#define PPS_OK 0
+#define PPS_ERR_ARG 1
+#define PPS_ERR_LAUNCH 2
+
+// scheduling groups (llvm.amdgcn.sched.group.barrier masks)
+#define PPS_SG_MFMA 0x008
+#define PPS_SG_DSREAD 0x100
+#define PPS_SG_VALU 0x002
+
+namespace pps {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// ---- reductions over the 16 rows of a tile (lanes with equal l>>4), pure DPP ------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// after these 4 steps every lane of a 16-lane row holds the reduction over the row
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_mov<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_mov<0x141>(v));   // row_half_mirror
+    v = fmaxf(v, dpp_mov<0x140>(v));   // row_mirror
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;
+}
+
+// ---- dense layer on a register tile ------------------------------------------------------------------
+// out[ob] = act( bias + sum_kb W[ob][kb] * in[kb] ),  weights read through `w` (LDS or global, packed layout,
+// pointing at the first f32x4 of (ob = OB0, kb = 0) for this lane's chunk), two output blocks in flight.
+// ACT: 0 none, 1 relu.  INIT: 0 accumulator starts from the bias, 1 from the current contents of out[].
+template <int KB, int NOB, int ACT, int INIT = 0>
+__device__ __forceinline__ void dense_blocks(const f32x4 (&in)[KB], f32x4* out, const f32x4* __restrict__ w,
+                                             const f32x4* __restrict__ bias, int lane) {
+    static_assert(NOB % 2 == 0, "output blocks are processed in pairs");
+    const int g = lane >> 4;
+#pragma unroll
+    for (int ob = 0; ob < NOB; ob += 2) {
+        f32x4 acc0 = INIT ? out[ob] : bias[(ob) * 4 + g];
+        f32x4 acc1 = INIT ? out[ob + 1] : bias[(ob + 1) * 4 + g];
+        f32x4 n0 = w[((ob) * KB) * 64 + lane];
+        f32x4 n1 = w[((ob + 1) * KB) * 64 + lane];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const f32x4 a0 = n0, a1 = n1;
+            if (kb + 1 < KB) {
+                n0 = w[((ob) * KB + kb + 1) * 64 + lane];
+                n1 = w[((ob + 1) * KB + kb + 1) * 64 + lane];
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, in[kb].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, in[kb].x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, in[kb].y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, in[kb].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, in[kb].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, in[kb].z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, in[kb].w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, in[kb].w, acc1, 0, 0, 0);
+            // next A fragments are requested before this step's MFMAs, nothing migrates across steps
+            __builtin_amdgcn_sched_group_barrier(PPS_SG_DSREAD, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(PPS_SG_MFMA, 8, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ACT == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc0[r] = fmaxf(acc0[r], 0.f);
+                acc1[r] = fmaxf(acc1[r], 0.f);
+            }
+        }
+        out[ob] = acc0;
+        out[ob + 1] = acc1;
+    }
+}
+
+// first layer for xyz inputs (K = 3 padded to 4): B operand of lane (n,g) is coordinate g of row n (0 for g = 3).
+// wxyz packed [ob][lane]:  W[16*ob + (l & 15)][l >> 4]  (0 for l >> 4 == 3).
+template <int NOB>
+__device__ __forceinline__ void xyz_blocks(float coord, f32x4* acc, const float* __restrict__ wxyz, int lane) {
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxyz[ob * 64 + lane], coord, acc[ob], 0, 0, 0);
+}
+
+// ---- cooperative weight-chunk streaming global -> LDS (LDS-DMA, no VGPR staging) ----------------------
+// A chunk is NF4 * NTHREADS f32x4 (NF4 * NTHREADS * 16 bytes), copied verbatim with global_load_lds_dwordx4:
+// each wave instruction moves 1 KiB to a wave-uniform LDS base + lane * 16.  The copy is asynchronous; the
+// __syncthreads() that ends a pipeline step waits for it (vmcnt(0)) and publishes it to the other waves.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <int NF4, int NTHREADS>
+__device__ __forceinline__ void chunk_copy_async(const f32x4* __restrict__ src, f32x4* dst) {
+    // `src` is workgroup-uniform (SGPR base); the only per-lane part is one 32-bit byte offset
+    unsigned lane_off = threadIdx.x * 16u;
+    asm volatile("" : "+v"(lane_off));     // opaque: keeps hipcc from hoisting (and then spilling) one 64-bit address per chunk
+    const int wave_base = threadIdx.x & ~63;
+    const char* sbase = (const char*)src;
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+        f32x4* d = dst + i * NTHREADS + wave_base;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(sbase + (size_t)(i * NTHREADS * 16) + lane_off), (lds_ptr_t)(uintptr_t)d, 16, 0, 0);
+    }
+}
+
+// XCD-aware persistent tile order: workgroup b runs on XCD b % 8 (observed, speed only); each XCD walks a
+// contiguous range of tiles so neighbouring queries share its L2.
+__device__ __forceinline__ void xcd_tile_range(int ntiles, int& first, int& count, int& stride) {
+    const int nwg = gridDim.x;
+    const int b = blockIdx.x;
+    if ((nwg & 7) != 0 || nwg < 8) { first = b; stride = nwg; count = (ntiles > b) ? (ntiles - b + nwg - 1) / nwg : 0; return; }
+    const int xcd = b & 7, slot = b >> 3, per = nwg >> 3;
+    const int lo = (int)(((int64_t)ntiles * xcd) / 8), hi = (int)(((int64_t)ntiles * (xcd + 1)) / 8);
+    first = lo + slot; stride = per;
+    count = (hi - lo > slot) ? (hi - lo - slot + per - 1) / per : 0;
+}
+
+}  // namespace pps

@@ -1,0 +1,616 @@
+// Occupancy decoder of PPSurf for gfx950: interpolation-attention branch, PointNet patch branch, MLP tail.
+//
+// All kernels share one structure (pps_common.h):
+//   * a workgroup = 8 waves (512 threads, 2 waves per SIMD, <= 256 VGPRs), persistent over "tiles";
+//   * each wave owns 16 rows and keeps their activations in registers in the MFMA C/D layout of
+//     v_mfma_f32_16x16x4_f32 (exact fp32, 157 TFLOP/s peak), chaining layers without leaving registers;
+//   * the layer weights, packed on the host in A-operand order, are streamed global(L2) -> registers -> LDS
+//     in 8..32 KiB chunks, double buffered, one barrier per chunk, shared by the 8 waves.
+//
+// Reference semantics (eval mode, BatchNorm folded by the host, see ppsurf_amd/decoder.py):
+//   source/poco_model.py:381-419, source/base/nn.py:72-96,133-190,305-373,415-417, source/ppsurf_model.py:82-117.
+#include "pps_common.h"
+#include "../../include/ppsurf_amd.h"
+
+using namespace pps;
+
+#define NT 512                 // threads per workgroup
+#define CH4 2048               // f32x4 per 32 KiB weight chunk
+
+// One pipeline step: request the NEXT chunk, compute on the CURRENT one, publish the next, barrier.
+template <int NF4_NEXT, class F>
+__device__ __forceinline__ void stream_step(const f32x4* __restrict__ gnext, f32x4*& cur, f32x4*& nxt, F&& compute) {
+    chunk_copy_async<NF4_NEXT, NT>(gnext, nxt);
+    compute((const f32x4*)cur);
+    __syncthreads();
+    f32x4* t = cur; cur = nxt; nxt = t;
+}
+
+template <int NF4>
+__device__ __forceinline__ void stream_prologue(const f32x4* __restrict__ g, f32x4* buf) {
+    chunk_copy_async<NF4, NT>(g, buf);
+}
+
+__device__ __forceinline__ void lds_fill(float* dst, const float* __restrict__ src, int nfloats) {
+    for (int i = threadIdx.x; i < nfloats; i += NT) dst[i] = src[i];
+}
+
+template <int N>
+__device__ __forceinline__ void relu_blocks(f32x4* a) {
+#pragma unroll
+    for (int b = 0; b < N; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[b][r] = fmaxf(a[b][r], 0.f);
+}
+
+extern __shared__ __attribute__((aligned(16))) char pps_smem[];
+
+// =====================================================================================================
+// rows_dense256: out[m,256] = in[m,256] W^T + b
+// =====================================================================================================
+#define RD_LDS_BYTES (2 * CH4 * 16 + 256 * 4)
+
+__global__ __launch_bounds__(NT, 2) void rows_dense256_kernel(const float* __restrict__ in, int64_t rs, int64_t cs, int64_t m,
+                                                              const float* __restrict__ wpack, const float* __restrict__ bias,
+                                                              float* __restrict__ out) {
+    f32x4* buf0 = (f32x4*)pps_smem;
+    f32x4* buf1 = buf0 + CH4;
+    float* bias_l = (float*)(buf1 + CH4);
+    const f32x4* bias4 = (const f32x4*)bias_l;
+    const f32x4* wg = (const f32x4*)wpack;
+    const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+
+    lds_fill(bias_l, bias, 256);
+    stream_prologue<4>(wg, buf0);
+    __syncthreads();
+    f32x4 *cur = buf0, *nxt = buf1;
+
+    const int ntiles = (int)((m + 127) / 128);
+    int first, count, stride;
+    xcd_tile_range(ntiles, first, count, stride);
+    for (int it = 0; it < count; ++it) {
+        const int64_t row = (int64_t)(first + it * stride) * 128 + wave * 16 + n;
+        const bool rv = row < m;
+        const int64_t rc = rv ? row : m - 1;
+        f32x4 a[16];
+        if (cs == 1) {
+            const f32x4* src = (const f32x4*)(in + rc * rs) + g;
+#pragma unroll
+            for (int b = 0; b < 16; ++b) a[b] = src[4 * b];
+        } else {
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[b][r] = in[rc * rs + (int64_t)(16 * b + 4 * g + r) * cs];
+        }
+        f32x4* dst = (f32x4*)(out + rc * 256) + g;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            f32x4 o[2];
+            stream_step<4>(wg + ((c + 1) & 7) * CH4, cur, nxt,
+                           [&](const f32x4* w) { dense_blocks<16, 2, 0>(a, o, w, bias4 + 8 * c, lane); });
+            if (rv) { dst[4 * (2 * c)] = o[0]; dst[4 * (2 * c + 1)] = o[1]; }
+        }
+    }
+}
+
+// =====================================================================================================
+// interp_pool: gather(G, xyz) -> +fc1_xyz, ReLU -> fc2 -> fc3 -> fc_query -> softmax_j, mean_heads -> sum_j a_j h3_j
+// weights (floats): [xyz 1024][fc2 65536][fc3 65536][fcq 16384]   bias: [256][256][64]
+// =====================================================================================================
+#define IP_W_XYZ 1024
+#define IP_NBIAS 576
+// LDS floats: xyz 1024 | bias 576 | ms_m 512 | ms_s 512 | f 512 | part 2048
+#define IP_LDS_BYTES (2 * CH4 * 16 + (IP_W_XYZ + IP_NBIAS + 512 * 3 + 2048) * 4)
+
+__global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restrict__ G, const float* __restrict__ pts,
+                                                            const float* __restrict__ query, const int64_t* __restrict__ idx,
+                                                            int64_t Q, int k, const float* __restrict__ wpack,
+                                                            const float* __restrict__ bias, float* __restrict__ pooled) {
+    f32x4* buf0 = (f32x4*)pps_smem;
+    f32x4* buf1 = buf0 + CH4;
+    float* xyz_l = (float*)(buf1 + CH4);
+    float* bias_l = xyz_l + IP_W_XYZ;
+    float* msm = bias_l + IP_NBIAS;      // [8][64] per-wave row max of every head
+    float* mss = msm + 512;              // [8][64] per-wave sum of exp
+    float* f_l = mss + 512;              // [8][64] per-wave head factor exp(m_w - M) / (64 S)
+    float* part = f_l + 512;             // [8][256] per-wave pooled partial
+    const f32x4* bias4 = (const f32x4*)bias_l;
+    const f32x4* wg = (const f32x4*)(wpack + IP_W_XYZ);
+    const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+
+    lds_fill(xyz_l, wpack, IP_W_XYZ);
+    lds_fill(bias_l, bias, IP_NBIAS);
+    stream_prologue<4>(wg, buf0);
+    __syncthreads();
+    f32x4 *cur = buf0, *nxt = buf1;
+
+    const int ntiles = (int)((Q + 1) / 2);
+    int first, count, stride;
+    xcd_tile_range(ntiles, first, count, stride);
+    const int wq = wave & 3, wbase = wave & 4;
+    for (int it = 0; it < count; ++it) {
+        const int64_t qi = (int64_t)(first + it * stride) * 2 + (wave >> 2);
+        const bool qv = qi < Q;
+        const int64_t qc = qv ? qi : Q - 1;
+        const int row = wq * 16 + n;
+        const bool valid = row < k;
+        const int64_t i = idx[qc * k + (valid ? row : 0)];
+
+        f32x4 a[16], b[16];
+        {
+            const f32x4* grow = (const f32x4*)(G + i * 256) + g;
+#pragma unroll
+            for (int bb = 0; bb < 16; ++bb) a[bb] = grow[4 * bb];
+            const float coord = (g < 3) ? (query[qc * 3 + g] - pts[i * 3 + g]) : 0.f;   // query minus neighbour (poco_model.py:402)
+            xyz_blocks<16>(coord, a, xyz_l, lane);
+            relu_blocks<16>(a);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            stream_step<4>(wg + (c + 1) * CH4, cur, nxt,
+                           [&](const f32x4* w) { dense_blocks<16, 2, 1>(a, &b[2 * c], w, bias4 + 8 * c, lane); });
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            stream_step<4>(wg + (c + 9) * CH4, cur, nxt,
+                           [&](const f32x4* w) { dense_blocks<16, 2, 1>(b, &a[2 * c], w, bias4 + 64 + 8 * c, lane); });
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            stream_step<4>(wg + ((c + 17) % 18) * CH4, cur, nxt,
+                           [&](const f32x4* w) { dense_blocks<16, 2, 0>(a, &b[2 * c], w, bias4 + 128 + 8 * c, lane); });
+
+        // ---- softmax over the 64 neighbours (4 waves x 16 rows) for each of the 64 heads -------------
+        // lane (n,g) holds heads 16*bb + 4*g + r of row n in b[bb][r]
+        float e[16];
+        {
+            f32x4 m4[4], s4[4];
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = valid ? b[bb][r] : -INFINITY;
+                    const float mx = row16_max(v);
+                    const float ev = valid ? __expf(v - mx) : 0.f;
+                    e[bb * 4 + r] = ev;
+                    m4[bb][r] = mx;
+                    s4[bb][r] = row16_sum(ev);
+                }
+            if (n < 4) {
+                const f32x4 mm = (n == 0) ? m4[0] : (n == 1) ? m4[1] : (n == 2) ? m4[2] : m4[3];
+                const f32x4 ss = (n == 0) ? s4[0] : (n == 1) ? s4[1] : (n == 2) ? s4[2] : s4[3];
+                ((f32x4*)(msm + wave * 64))[4 * n + g] = mm;
+                ((f32x4*)(mss + wave * 64))[4 * n + g] = ss;
+            }
+        }
+        __syncthreads();
+        {
+            // lane = head: combine the 4 waves of this query
+            float mw[4], sw[4];
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) { mw[w2] = msm[(wbase + w2) * 64 + lane]; sw[w2] = mss[(wbase + w2) * 64 + lane]; }
+            const float M = fmaxf(fmaxf(mw[0], mw[1]), fmaxf(mw[2], mw[3]));
+            float S = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) S += sw[w2] * __expf(mw[w2] - M);
+            f_l[wave * 64 + lane] = __expf(mw[wq] - M) / (64.f * S);
+        }
+        __syncthreads();
+        float an = 0.f;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const f32x4 f4 = ((const f32x4*)(f_l + wave * 64))[4 * bb + g];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) an += e[bb * 4 + r] * f4[r];
+        }
+        an += __shfl_xor(an, 16);
+        an += __shfl_xor(an, 32);           // attention weight of row n (mean over the 64 heads)
+#pragma unroll
+        for (int bb = 0; bb < 16; ++bb) {
+            f32x4 p;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = row16_sum(an * a[bb][r]);
+            if (n == 0) ((f32x4*)(part + wave * 256))[4 * bb + g] = p;
+        }
+        __syncthreads();
+        if (wq == 0 && qv) {
+            f32x4 s = ((const f32x4*)(part + (wbase + 0) * 256))[lane];
+            s += ((const f32x4*)(part + (wbase + 1) * 256))[lane];
+            s += ((const f32x4*)(part + (wbase + 2) * 256))[lane];
+            s += ((const f32x4*)(part + (wbase + 3) * 256))[lane];
+            ((f32x4*)(pooled + qi * 256))[lane] = s;
+        }
+    }
+}
+
+// =====================================================================================================
+// PointNet phase A: conv0a, conv0b, stn.conv1..3 (+ReLU), max over the patch -> g[q,256]
+// weights (floats): [xyz 256][c0b 4096][s1 4096][s2 8192][s3 32768]   bias [64][64][64][128][256]
+// =====================================================================================================
+#define PA_W_XYZ 256
+#define PA_NBIAS 576
+#define PA_LDS_BYTES (2 * CH4 * 16 + (PA_W_XYZ + PA_NBIAS) * 4)
+
+__global__ __launch_bounds__(NT, 2) void pointnet_stn_rows_kernel(const float* __restrict__ patches, int64_t Q, int P,
+                                                                  const float* __restrict__ wpack, const float* __restrict__ bias,
+                                                                  float* __restrict__ gout) {
+    f32x4* buf0 = (f32x4*)pps_smem;
+    f32x4* buf1 = buf0 + CH4;
+    float* xyz_l = (float*)(buf1 + CH4);
+    float* bias_l = xyz_l + PA_W_XYZ;
+    const f32x4* bias4 = (const f32x4*)bias_l;
+    const f32x4* wg = (const f32x4*)(wpack + PA_W_XYZ);
+    const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+
+    lds_fill(xyz_l, wpack, PA_W_XYZ);
+    lds_fill(bias_l, bias, PA_NBIAS);
+    stream_prologue<2>(wg, buf0);
+    __syncthreads();
+    f32x4 *cur = buf0, *nxt = buf1;
+
+    const int nrb = (P + 15) / 16;
+    const int ntiles = (int)((Q + 7) / 8);
+    int first, count, stride;
+    xcd_tile_range(ntiles, first, count, stride);
+    for (int it = 0; it < count; ++it) {
+        const int64_t qi = (int64_t)(first + it * stride) * 8 + wave;
+        const bool qv = qi < Q;
+        const int64_t qc = qv ? qi : Q - 1;
+        f32x4 rmax[16];
+#pragma unroll
+        for (int bb = 0; bb < 16; ++bb) rmax[bb] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int rb = 0; rb < nrb; ++rb) {
+            const int row = rb * 16 + n;
+            const int rowc = row < P ? row : P - 1;           // padded rows repeat a valid point: max unaffected
+            const float coord = (g < 3) ? patches[(qc * P + rowc) * 3 + g] : 0.f;
+            f32x4 x0[4], x1[4], y[8], z[16];
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) x0[bb] = bias4[4 * bb + g];
+            xyz_blocks<4>(coord, x0, xyz_l, lane);
+            relu_blocks<4>(x0);
+            stream_step<2>(wg + 1024, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 16, lane); });
+            stream_step<4>(wg + 2048, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x1, x0, w, bias4 + 32, lane); });
+            stream_step<4>(wg + 4096, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 8, 1>(x0, y, w, bias4 + 48, lane); });
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                stream_step<4>(wg + 6144 + c * CH4, cur, nxt,
+                               [&](const f32x4* w) { dense_blocks<8, 4, 1>(y, &z[4 * c], w, bias4 + 80 + 16 * c, lane); });
+            stream_step<2>(wg, cur, nxt, [&](const f32x4* w) { dense_blocks<8, 4, 1>(y, &z[12], w, bias4 + 80 + 48, lane); });
+#pragma unroll
+            for (int bb = 0; bb < 16; ++bb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rmax[bb][r] = fmaxf(rmax[bb][r], z[bb][r]);
+        }
+#pragma unroll
+        for (int bb = 0; bb < 16; ++bb) {
+            f32x4 p;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = row16_max(rmax[bb][r]);
+            if (n == 0 && qv) ((f32x4*)(gout + qi * 256))[4 * bb + g] = p;
+        }
+    }
+}
+
+// =====================================================================================================
+// PointNet phase B: g[q,256] -> fc1(128, ReLU) -> fc2(64, ReLU) -> fc3(4096) (+I in bias) -> trans2[q,4096]
+// weights (floats): [fc1 32768][fc2 8192][fc3 262144]   bias [128][64][4096]
+// =====================================================================================================
+#define PB_NBIAS (128 + 64 + 4096)
+#define PB_LDS_BYTES (2 * CH4 * 16 + PB_NBIAS * 4)
+
+__global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_kernel(const float* __restrict__ gin, int64_t Q,
+                                                                const float* __restrict__ wpack, const float* __restrict__ bias,
+                                                                float* __restrict__ trans2) {
+    f32x4* buf0 = (f32x4*)pps_smem;
+    f32x4* buf1 = buf0 + CH4;
+    float* bias_l = (float*)(buf1 + CH4);
+    const f32x4* bias4 = (const f32x4*)bias_l;
+    const f32x4* wg = (const f32x4*)wpack;
+    const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+
+    lds_fill(bias_l, bias, PB_NBIAS);
+    stream_prologue<4>(wg, buf0);
+    __syncthreads();
+    f32x4 *cur = buf0, *nxt = buf1;
+
+    const int ntiles = (int)((Q + 127) / 128);
+    int first, count, stride;
+    xcd_tile_range(ntiles, first, count, stride);
+    for (int it = 0; it < count; ++it) {
+        const int64_t qi = (int64_t)(first + it * stride) * 128 + wave * 16 + n;
+        const bool qv = qi < Q;
+        const int64_t qc = qv ? qi : Q - 1;
+        f32x4 a[16], h[8], u[4];
+        {
+            const f32x4* src = (const f32x4*)(gin + qc * 256) + g;
+#pragma unroll
+            for (int bb = 0; bb < 16; ++bb) a[bb] = src[4 * bb];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            stream_step<4>(wg + (c + 1) * CH4, cur, nxt,
+                           [&](const f32x4* w) { dense_blocks<16, 2, 1>(a, &h[2 * c], w, bias4 + 8 * c, lane); });
+        stream_step<4>(wg + 5 * CH4, cur, nxt, [&](const f32x4* w) { dense_blocks<8, 4, 1>(h, u, w, bias4 + 32, lane); });
+        f32x4* dst = (f32x4*)(trans2 + qc * 4096) + g;
+#pragma unroll 1
+        for (int c = 0; c < 32; ++c) {
+            f32x4 o[8];
+            const f32x4* gn = (c + 1 < 32) ? wg + (6 + c) * CH4 : wg;
+            stream_step<4>(gn, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 8, 0>(u, o, w, bias4 + 48 + 32 * c, lane); });
+            if (qv) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dst[4 * (8 * c + j)] = o[j];
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// PointNet phase C: conv0a, conv0b, x <- trans2 x, conv1, conv2 (+ReLU), conv3 (no ReLU), attention pooling
+// weights (floats): [xyz 256][c0b 4096][c1 4096][c2 8192][c3 32768]   bias [64][64][64][128][256][wq 256][bq 4]
+// =====================================================================================================
+#define PC_W_XYZ 256
+#define PC_NBIAS (576 + 256 + 4)
+#define PC_LDS_BYTES (2 * CH4 * 16 + (PC_W_XYZ + PC_NBIAS) * 4)
+
+__global__ __launch_bounds__(NT, 2) void pointnet_feat_rows_kernel(const float* __restrict__ patches, const float* __restrict__ trans2,
+                                                                   int64_t Q, int P, const float* __restrict__ wpack,
+                                                                   const float* __restrict__ bias, float* __restrict__ xbar) {
+    f32x4* buf0 = (f32x4*)pps_smem;
+    f32x4* buf1 = buf0 + CH4;
+    float* xyz_l = (float*)(buf1 + CH4);
+    float* bias_l = xyz_l + PC_W_XYZ;
+    const f32x4* bias4 = (const f32x4*)bias_l;
+    const f32x4* wq4 = bias4 + 144;
+    const f32x4* wg = (const f32x4*)(wpack + PC_W_XYZ);
+    const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+
+    lds_fill(xyz_l, wpack, PC_W_XYZ);
+    lds_fill(bias_l, bias, PC_NBIAS);
+    stream_prologue<2>(wg, buf0);
+    __syncthreads();
+    f32x4 *cur = buf0, *nxt = buf1;
+    const float bq = bias_l[576 + 256];
+
+    const int nrb = (P + 15) / 16;
+    const int ntiles = (int)((Q + 7) / 8);
+    int first, count, stride;
+    xcd_tile_range(ntiles, first, count, stride);
+    for (int it = 0; it < count; ++it) {
+        const int64_t qi = (int64_t)(first + it * stride) * 8 + wave;
+        const bool qv = qi < Q;
+        const int64_t qc = qv ? qi : Q - 1;
+        const f32x4* tq = (const f32x4*)(trans2 + qc * 4096);
+        f32x4 acc[16];
+#pragma unroll
+        for (int bb = 0; bb < 16; ++bb) acc[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float mrun = -INFINITY, ssum = 0.f;
+        for (int rb = 0; rb < nrb; ++rb) {
+            const int row = rb * 16 + n;
+            const bool valid = row < P;
+            const int rowc = valid ? row : P - 1;
+            const float coord = (g < 3) ? patches[(qc * P + rowc) * 3 + g] : 0.f;
+            f32x4 x0[4], x1[4], y[8], z[16];
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) x0[bb] = bias4[4 * bb + g];
+            xyz_blocks<4>(coord, x0, xyz_l, lane);
+            relu_blocks<4>(x0);
+            stream_step<2>(wg + 1024, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 16, lane); });
+            // feature transform x0 = trans2[q] (64x64, row-major) @ x1: A operand straight from global
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) {
+                f32x4 t[4];
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) t[kb] = tq[(16 * ob + n) * 16 + 4 * kb + g];
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(t[kb].x, x1[kb].x, o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(t[kb].y, x1[kb].y, o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(t[kb].z, x1[kb].z, o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(t[kb].w, x1[kb].w, o, 0, 0, 0);
+                }
+                x0[ob] = o;
+            }
+            stream_step<4>(wg + 2048, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 32, lane); });
+            stream_step<4>(wg + 4096, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 8, 1>(x1, y, w, bias4 + 48, lane); });
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                stream_step<4>(wg + 6144 + c * CH4, cur, nxt,
+                               [&](const f32x4* w) { dense_blocks<8, 4, 0>(y, &z[4 * c], w, bias4 + 80 + 16 * c, lane); });
+            stream_step<2>(wg, cur, nxt, [&](const f32x4* w) { dense_blocks<8, 4, 0>(y, &z[12], w, bias4 + 80 + 48, lane); });
+
+            // attention logit of row n (nn.py:88), online softmax over the patch points (nn.py:91-93)
+            float s = 0.f;
+#pragma unroll
+            for (int bb = 0; bb < 16; ++bb) {
+                const f32x4 w4 = wq4[4 * bb + g];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s += w4[r] * z[bb][r];
+            }
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            s += bq;
+            const float mblk = row16_max(valid ? s : -INFINITY);
+            const float mnew = fmaxf(mrun, mblk);
+            const float scale = __expf(mrun - mnew);
+            const float en = valid ? __expf(s - mnew) : 0.f;
+            mrun = mnew;
+            ssum = ssum * scale + en;
+#pragma unroll
+            for (int bb = 0; bb < 16; ++bb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[bb][r] = acc[bb][r] * scale + en * z[bb][r];
+        }
+        const float inv = 1.f / row16_sum(ssum);
+#pragma unroll
+        for (int bb = 0; bb < 16; ++bb) {
+            f32x4 p;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = row16_sum(acc[bb][r]) * inv;
+            if (n == 0 && qv) ((f32x4*)(xbar + qi * 256))[4 * bb + g] = p;
+        }
+    }
+}
+
+// =====================================================================================================
+// Tail: [pooled | xbar] -> 256 (ReLU) -> 256 (ReLU) -> 2
+// weights (floats): [Wa 65536][Wb 65536][L2 65536][L3 8192]   bias [256][256][32]
+// =====================================================================================================
+#define TL_NBIAS (256 + 256 + 32)
+#define TL_LDS_BYTES (2 * CH4 * 16 + TL_NBIAS * 4)
+
+__global__ __launch_bounds__(NT, 2) void decode_tail_kernel(const float* __restrict__ pooled, const float* __restrict__ xbar, int64_t Q,
+                                                            const float* __restrict__ wpack, const float* __restrict__ bias,
+                                                            float* __restrict__ logits, float* __restrict__ occ) {
+    f32x4* buf0 = (f32x4*)pps_smem;
+    f32x4* buf1 = buf0 + CH4;
+    float* bias_l = (float*)(buf1 + CH4);
+    const f32x4* bias4 = (const f32x4*)bias_l;
+    const f32x4* wg = (const f32x4*)wpack;
+    const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+
+    lds_fill(bias_l, bias, TL_NBIAS);
+    stream_prologue<4>(wg, buf0);
+    __syncthreads();
+    f32x4 *cur = buf0, *nxt = buf1;
+
+    const int ntiles = (int)((Q + 127) / 128);
+    int first, count, stride;
+    xcd_tile_range(ntiles, first, count, stride);
+    for (int it = 0; it < count; ++it) {
+        const int64_t qi = (int64_t)(first + it * stride) * 128 + wave * 16 + n;
+        const bool qv = qi < Q;
+        const int64_t qc = qv ? qi : Q - 1;
+        f32x4 p[16], x[16], h[16];
+        {
+            const f32x4* sp = (const f32x4*)(pooled + qc * 256) + g;
+            const f32x4* sx = (const f32x4*)(xbar + qc * 256) + g;
+#pragma unroll
+            for (int bb = 0; bb < 16; ++bb) { p[bb] = sp[4 * bb]; x[bb] = sx[4 * bb]; }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            stream_step<4>(wg + (c + 1) * CH4, cur, nxt,
+                           [&](const f32x4* w) { dense_blocks<16, 2, 0>(p, &h[2 * c], w, bias4 + 8 * c, lane); });
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            stream_step<4>(wg + (c + 9) * CH4, cur, nxt,
+                           [&](const f32x4* w) { dense_blocks<16, 2, 1, 1>(x, &h[2 * c], w, bias4, lane); });
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            stream_step<4>(wg + (c + 17) * CH4, cur, nxt,
+                           [&](const f32x4* w) { dense_blocks<16, 2, 1>(h, &p[2 * c], w, bias4 + 64 + 8 * c, lane); });
+        f32x4 o[2];
+        stream_step<4>(wg, cur, nxt, [&](const f32x4* w) { dense_blocks<16, 2, 0>(p, o, w, bias4 + 128, lane); });
+        if (qv && g == 0) {
+            const float l0 = o[0].x, l1 = o[0].y;
+            logits[qi * 2] = l0;
+            logits[qi * 2 + 1] = l1;
+            if (occ) {
+                const float mx = fmaxf(l0, l1);
+                const float e0 = __expf(l0 - mx), e1 = __expf(l1 - mx);
+                occ[qi] = (e0 - e1) / (e0 + e1);
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+static int g_cu_count = 0;
+static int cu_count() {
+    if (g_cu_count == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        g_cu_count = prop.multiProcessorCount;
+    }
+    return g_cu_count;
+}
+
+template <class K>
+static int set_lds(K kernel, int bytes) {
+    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : 1;
+}
+
+static int grid_for(int64_t ntiles) {
+    int cus = cu_count();
+    if (cus <= 0) cus = 256;
+    return (int)(ntiles < cus ? (ntiles > 0 ? ntiles : 1) : cus);
+}
+
+#define PPS_LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH)
+
+extern "C" {
+
+int pps_abi_version(void) { return 1; }
+int pps_device_cu_count(void) { return cu_count(); }
+
+int pps_rows_dense256_f32(const float* in, int64_t rs, int64_t cs, int64_t m, const float* wpack, const float* bias,
+                          float* out, void* stream) {
+    if (!in || !wpack || !bias || !out || m < 0) return PPS_ERR_ARG;
+    if (m == 0) return PPS_OK;
+    if (cs == 1 && (rs % 4) != 0) return PPS_ERR_ARG;
+    static int once = set_lds(rows_dense256_kernel, RD_LDS_BYTES);
+    (void)once;
+    hipLaunchKernelGGL(rows_dense256_kernel, dim3(grid_for((m + 127) / 128)), dim3(NT), RD_LDS_BYTES, (hipStream_t)stream,
+                       in, rs, cs, m, wpack, bias, out);
+    return PPS_LAUNCH_CHECK();
+}
+
+int pps_interp_pool_f32(const float* G, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
+                        const float* wpack, const float* bias, float* pooled, void* stream) {
+    if (!G || !pts || !query || !idx || !wpack || !bias || !pooled || q < 0 || k < 1 || k > 64) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    static int once = set_lds(interp_pool_kernel, IP_LDS_BYTES);
+    (void)once;
+    hipLaunchKernelGGL(interp_pool_kernel, dim3(grid_for((q + 1) / 2)), dim3(NT), IP_LDS_BYTES, (hipStream_t)stream,
+                       G, pts, query, idx, q, k, wpack, bias, pooled);
+    return PPS_LAUNCH_CHECK();
+}
+
+int pps_pointnet_stn_rows_f32(const float* patches, int64_t q, int p, const float* wpack, const float* bias, float* g,
+                              void* stream) {
+    if (!patches || !wpack || !bias || !g || q < 0 || p < 1) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    static int once = set_lds(pointnet_stn_rows_kernel, PA_LDS_BYTES);
+    (void)once;
+    hipLaunchKernelGGL(pointnet_stn_rows_kernel, dim3(grid_for((q + 7) / 8)), dim3(NT), PA_LDS_BYTES, (hipStream_t)stream,
+                       patches, q, p, wpack, bias, g);
+    return PPS_LAUNCH_CHECK();
+}
+
+int pps_pointnet_stn_fc_f32(const float* g, int64_t q, const float* wpack, const float* bias, float* trans2, void* stream) {
+    if (!g || !wpack || !bias || !trans2 || q < 0) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    static int once = set_lds(pointnet_stn_fc_kernel, PB_LDS_BYTES);
+    (void)once;
+    hipLaunchKernelGGL(pointnet_stn_fc_kernel, dim3(grid_for((q + 127) / 128)), dim3(NT), PB_LDS_BYTES, (hipStream_t)stream,
+                       g, q, wpack, bias, trans2);
+    return PPS_LAUNCH_CHECK();
+}
+
+int pps_pointnet_feat_rows_f32(const float* patches, const float* trans2, int64_t q, int p, const float* wpack,
+                               const float* bias, float* xbar, void* stream) {
+    if (!patches || !trans2 || !wpack || !bias || !xbar || q < 0 || p < 1) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    static int once = set_lds(pointnet_feat_rows_kernel, PC_LDS_BYTES);
+    (void)once;
+    hipLaunchKernelGGL(pointnet_feat_rows_kernel, dim3(grid_for((q + 7) / 8)), dim3(NT), PC_LDS_BYTES, (hipStream_t)stream,
+                       patches, trans2, q, p, wpack, bias, xbar);
+    return PPS_LAUNCH_CHECK();
+}
+
+int pps_decode_tail_f32(const float* pooled, const float* xbar, int64_t q, const float* wpack, const float* bias,
+                        float* logits, float* occ, void* stream) {
+    if (!pooled || !xbar || !wpack || !bias || !logits || q < 0) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    static int once = set_lds(decode_tail_kernel, TL_LDS_BYTES);
+    (void)once;
+    hipLaunchKernelGGL(decode_tail_kernel, dim3(grid_for((q + 127) / 128)), dim3(NT), TL_LDS_BYTES, (hipStream_t)stream,
+                       pooled, xbar, q, wpack, bias, logits, occ);
+    return PPS_LAUNCH_CHECK();
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+// Exact brute-force k-nearest-neighbour search and patch normalisation for gfx950.
+//
+// replaces the CPU kd-tree of the reference: source/poco_utils.py:257-273 `knn`,
+// source/base/proximity.py:40-89, source/poco_utils.py:67-72, source/ppsurf_data_loader.py:91-123.
+//
+// Design (HBM/L2-bound integer+fp32 VALU work, no MFMA):
+//   * one wave scans the whole cloud for QW queries at a time: each lane loads ONE point per step (coalesced,
+//     the 1.2 MB cloud stays in the XCD's L2) and evaluates it against QW wave-uniform queries;
+//   * every query keeps its current k best as a SORTED list spread over the 64 lanes (lane i = i-th best) of a
+//     64-bit key (d2 bits << 32 | index): unsigned key order == (d2, index) lexicographic order;
+//   * a point is a candidate only if d2 < tau (the current k-th d2).  Scanning in ascending index order makes the
+//     strict test exact for ties.  Candidates are compacted into a small LDS buffer with ballot/mbcnt and merged
+//     into the list by a wave-wide bitonic sort + merge when the buffer fills.
+//   * d2 = ((dx*dx + dy*dy) + dz*dz) with explicit round-to-nearest mul/add (no FMA contraction) so indices are
+//     bit-identical to the CPU oracle.
+#include "pps_common.h"
+#include "../../include/ppsurf_amd.h"
+
+#define KNN_QW 8            // queries per wave pass
+#define KNN_WAVES 4         // waves per workgroup
+#define KNN_CAP 128         // candidate buffer entries per query (flush threshold 64 + one step of 64)
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
+    const int lo = __shfl_xor((int)(unsigned)v, m), hi = __shfl_xor((int)(unsigned)(v >> 32), m);
+    return ((u64)(unsigned)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
+    const int lo = __shfl((int)(unsigned)v, src), hi = __shfl((int)(unsigned)(v >> 32), src);
+    return ((u64)(unsigned)hi << 32) | (unsigned)lo;
+}
+
+// ascending bitonic sort of one key per lane over the 64 lanes
+__device__ __forceinline__ u64 wave_sort64(u64 key, int lane) {
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+        for (int st = size >> 1; st > 0; st >>= 1) {
+            const u64 other = shfl_xor_u64(key, st);
+            const bool up = ((lane & size) == 0);          // ascending block
+            const bool lower = ((lane & st) == 0);
+            const bool take_min = (up == lower);
+            const u64 mn = key < other ? key : other, mx = key < other ? other : key;
+            key = take_min ? mn : mx;
+        }
+    }
+    return key;
+}
+// `key` is bitonic over the 64 lanes -> ascending
+__device__ __forceinline__ u64 wave_bitonic_merge64(u64 key, int lane) {
+#pragma unroll
+    for (int st = 32; st > 0; st >>= 1) {
+        const u64 other = shfl_xor_u64(key, st);
+        const bool lower = ((lane & st) == 0);
+        const u64 mn = key < other ? key : other, mx = key < other ? other : key;
+        key = lower ? mn : mx;
+    }
+    return key;
+}
+
+// merge `cnt` buffered candidates into the sorted list; returns the new list
+__device__ __forceinline__ u64 knn_flush(u64 list, const u64* cand, int cnt, int lane) {
+    while (cnt > 0) {
+        const int c = cnt < 64 ? cnt : 64;
+        u64 ck = (lane < c) ? cand[cnt - c + lane] : ~0ull;
+        ck = wave_sort64(ck, lane);
+        const u64 rev = shfl_u64(ck, 63 - lane);
+        list = wave_bitonic_merge64(list < rev ? list : rev, lane);
+        cnt -= c;
+    }
+    return list;
+}
+
+__global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(const float* __restrict__ pts, int n, const float* __restrict__ query,
+                                                             int64_t m, int k, int64_t* __restrict__ out_idx,
+                                                             float* __restrict__ out_d2) {
+    __shared__ u64 cand_all[KNN_WAVES][KNN_QW][KNN_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t ntask = (m + KNN_QW - 1) / KNN_QW;
+    for (int64_t task = (int64_t)blockIdx.x * KNN_WAVES + wave; task < ntask; task += (int64_t)gridDim.x * KNN_WAVES) {
+        const int64_t q0 = task * KNN_QW;
+        float qx[KNN_QW], qy[KNN_QW], qz[KNN_QW], tau[KNN_QW];
+        u64 list[KNN_QW];
+        int cnt[KNN_QW];
+#pragma unroll
+        for (int j = 0; j < KNN_QW; ++j) {
+            const int64_t qq = (q0 + j < m) ? q0 + j : m - 1;
+            qx[j] = __builtin_nontemporal_load(query + qq * 3);
+            qy[j] = query[qq * 3 + 1];
+            qz[j] = query[qq * 3 + 2];
+            qx[j] = __shfl(qx[j], 0); qy[j] = __shfl(qy[j], 0); qz[j] = __shfl(qz[j], 0);
+            tau[j] = INFINITY;
+            list[j] = ~0ull;
+            cnt[j] = 0;
+        }
+        for (int base = 0; base < n; base += 64) {
+            const int p = base + lane;
+            const bool pv = p < n;
+            const int pc = pv ? p : n - 1;
+            const float px = pts[3 * pc], py = pts[3 * pc + 1], pz = pts[3 * pc + 2];
+#pragma unroll
+            for (int j = 0; j < KNN_QW; ++j) {
+                const float dx = __fsub_rn(qx[j], px), dy = __fsub_rn(qy[j], py), dz = __fsub_rn(qz[j], pz);
+                const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                const bool pass = pv && (d2 < tau[j]);
+                const u64 mask = __ballot(pass);
+                if (mask != 0ull) {
+                    u64* cand = cand_all[wave][j];
+                    const int pos = cnt[j] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                    if (pass) cand[pos] = ((u64)__float_as_uint(d2) << 32) | (unsigned)p;
+                    cnt[j] += __popcll(mask);
+                    if (cnt[j] > KNN_CAP - 64) {
+                        list[j] = knn_flush(list[j], cand, cnt[j], lane);
+                        cnt[j] = 0;
+                        tau[j] = __uint_as_float((unsigned)(shfl_u64(list[j], k - 1) >> 32));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KNN_QW; ++j) {
+            list[j] = knn_flush(list[j], cand_all[wave][j], cnt[j], lane);
+            if (q0 + j < m && lane < k) {
+                out_idx[(q0 + j) * k + lane] = (int64_t)(unsigned)(list[j] & 0xffffffffull);
+                if (out_d2) out_d2[(q0 + j) * k + lane] = __uint_as_float((unsigned)(list[j] >> 32));
+            }
+        }
+    }
+}
+
+// one wave per query: lane j < P handles neighbour j
+__global__ __launch_bounds__(256) void patch_normalize_kernel(const float* __restrict__ raw, const float* __restrict__ query,
+                                                              const int64_t* __restrict__ idx, int64_t idx_stride, int64_t Q, int P,
+                                                              float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= Q) return;
+    const float qx = query[qi * 3], qy = query[qi * 3 + 1], qz = query[qi * 3 + 2];
+    float mx = 0.f;
+    for (int j = lane; j < P; j += 64) {
+        const int64_t i = idx[qi * idx_stride + j];
+        const float dx = __fsub_rn(raw[i * 3], qx), dy = __fsub_rn(raw[i * 3 + 1], qy), dz = __fsub_rn(raw[i * 3 + 2], qz);
+        mx = fmaxf(mx, __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
+    const float radius = __fsqrt_rn(mx);       // max_j ||p_j - q||  (ppsurf_data_loader.py:107-109)
+    for (int j = lane; j < P; j += 64) {
+        const int64_t i = idx[qi * idx_stride + j];
+        float* o = out + (qi * P + j) * 3;
+        o[0] = __fdiv_rn(__fsub_rn(raw[i * 3], qx), radius);
+        o[1] = __fdiv_rn(__fsub_rn(raw[i * 3 + 1], qy), radius);
+        o[2] = __fdiv_rn(__fsub_rn(raw[i * 3 + 2], qz), radius);
+    }
+}
+
+extern "C" {
+
+int pps_knn_f32(const float* pts, int64_t n, const float* query, int64_t m, int k, int64_t* out_idx, float* out_d2,
+                void* stream) {
+    if (n < 1 || m < 0 || k < 1 || k > 64 || k > n || n > 0x7fffffff) return PPS_ERR_ARG;
+    if (m == 0) return PPS_OK;
+    if (!pts || !query || !out_idx) return PPS_ERR_ARG;
+    const int64_t ntask = (m + KNN_QW - 1) / KNN_QW;
+    int64_t blocks = (ntask + KNN_WAVES - 1) / KNN_WAVES;
+    int cus = pps_device_cu_count();
+    if (cus <= 0) cus = 256;
+    if (blocks > (int64_t)cus * 8) blocks = (int64_t)cus * 8;
+    hipLaunchKernelGGL(knn_kernel, dim3((unsigned)blocks), dim3(KNN_WAVES * 64), 0, (hipStream_t)stream, pts, (int)n, query, m, k,
+                       out_idx, out_d2);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+int pps_patch_normalize_f32(const float* raw, const float* query, const int64_t* idx, int64_t idx_stride, int64_t q, int p,
+                            float* out, void* stream) {
+    if (!raw || !query || !idx || !out || q < 0 || p < 1 || idx_stride < p) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    hipLaunchKernelGGL(patch_normalize_kernel, dim3((unsigned)((q + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw, query, idx,
+                       idx_stride, q, p, out);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+}  // extern "C"

@@ -1,0 +1,42 @@
+// Host-side packing of dense layer weights into the A-operand order of v_mfma_f32_16x16x4_f32 used by the
+// register-tile kernels (layout documented in pps_common.h).  Plain C++, no device code.
+#include <cstddef>
+#include <cstring>
+#include "../../include/ppsurf_amd.h"
+
+static inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+extern "C" {
+
+size_t pps_packed_dense_floats(int out, int in) {
+    if (out <= 0 || in <= 0) return 0;
+    return (size_t)pad_to(out, 32) * (size_t)pad_to(in, 16);
+}
+
+int pps_pack_dense_f32(const float* W, int out, int in, float* packed) {
+    if (!W || !packed || out <= 0 || in <= 0) return 1;
+    const int OB = pad_to(out, 32) / 16, KB = pad_to(in, 16) / 16;
+    for (int ob = 0; ob < OB; ++ob)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int l = 0; l < 64; ++l)
+                for (int s = 0; s < 4; ++s) {
+                    const int o = 16 * ob + (l & 15), c = 16 * kb + 4 * (l >> 4) + s;
+                    packed[(((size_t)ob * KB + kb) * 64 + l) * 4 + s] = (o < out && c < in) ? W[(size_t)o * in + c] : 0.f;
+                }
+    return 0;
+}
+
+size_t pps_packed_xyz_floats(int out) { return out <= 0 ? 0 : (size_t)pad_to(out, 16) * 4; }
+
+int pps_pack_xyz_f32(const float* W, int out, float* packed) {
+    if (!W || !packed || out <= 0) return 1;
+    const int OB = pad_to(out, 16) / 16;
+    for (int ob = 0; ob < OB; ++ob)
+        for (int l = 0; l < 64; ++l) {
+            const int o = 16 * ob + (l & 15), c = l >> 4;
+            packed[ob * 64 + l] = (o < out && c < 3) ? W[o * 3 + c] : 0.f;
+        }
+    return 0;
+}
+
+}  // extern "C"

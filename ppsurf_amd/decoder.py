@@ -1,0 +1,179 @@
+"""Host side of the fused occupancy decoder (PPSurfNetwork.from_latent, source/ppsurf_model.py:82-117).
+
+`DecoderPlan` turns the reference's state dict (names 'projection.*', 'point_net.*', 'mlp.*') into the packed
+weight images the HIP kernels consume, once per set of weights, in fp64 on the host:
+
+  * eval-mode BatchNorm is folded into the preceding conv / linear (source/base/nn.py:164-166,183-184,323-336,415);
+  * fc1 (poco_model.py:368,405) is split: its latent part is hoisted from every (query, neighbour) pair to every
+    POINT (`G = latents @ W1[:, :C]^T + b1`, pps_rows_dense256_f32), its xyz part stays per pair;
+  * softmax weights sum to one, so fc_value/fc8 (poco_model.py:410-417) and the PointNet attention value conv
+    (nn.py:89-93) commute with the pooling; together with the first MLP layer they compose into one 512->256
+    layer evaluated once per query (pps_decode_tail_f32).
+
+All of this is algebraically exact; results differ from the reference by fp32 re-association only
+(tests/test_decoder_gpu.py, tolerance 1e-4 on the logits).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+BN_EPS = 1e-5
+C = 256          # latent size the kernels are specialised for (configs/ppsurf.yaml:7)
+HEADS = 64       # poco_model.py:374
+
+
+def _np64(t):
+    if isinstance(t, torch.Tensor):
+        t = t.detach().cpu().numpy()
+    return np.asarray(t, dtype=np.float64)
+
+
+def _fold_bn(w, b, sd, bn):
+    """(W [out,in], b [out]) followed by eval BatchNorm `bn` -> equivalent (W', b')."""
+    scale = _np64(sd[bn + '.weight']) / np.sqrt(_np64(sd[bn + '.running_var']) + BN_EPS)
+    return w * scale[:, None], (b - _np64(sd[bn + '.running_mean'])) * scale + _np64(sd[bn + '.bias'])
+
+
+def _wb(sd, name):
+    w = _np64(sd[name + '.weight'])
+    return w.reshape(w.shape[0], -1), _np64(sd[name + '.bias'])
+
+
+def pack_dense(w):
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    out = np.empty(_lib.lib().pps_packed_dense_floats(w.shape[0], w.shape[1]), dtype=np.float32)
+    _lib.check(_lib.lib().pps_pack_dense_f32(w.ctypes.data, w.shape[0], w.shape[1], out.ctypes.data), 'pps_pack_dense_f32')
+    return out
+
+
+def pack_xyz(w):
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    out = np.empty(_lib.lib().pps_packed_xyz_floats(w.shape[0]), dtype=np.float32)
+    _lib.check(_lib.lib().pps_pack_xyz_f32(w.ctypes.data, w.shape[0], out.ctypes.data), 'pps_pack_xyz_f32')
+    return out
+
+
+def _pad(v, n):
+    out = np.zeros(n, dtype=np.float32)
+    out[:v.shape[0]] = v
+    return out
+
+
+class DecoderPlan:
+    """Packed, device-resident weights of the eval-mode PPSurf decoder."""
+
+    def __init__(self, sd, device, prefix=''):
+        p = prefix
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        # ---- interpolation branch (poco_model.py:364-419) ------------------------------------------------
+        w1, b1 = _wb(sd, p + 'projection.fc1')
+        if w1.shape != (C, C + 3):
+            raise NotImplementedError('the HIP decoder is specialised for latent size {} (got fc1 {})'.format(C, w1.shape))
+        w2, b2 = _wb(sd, p + 'projection.fc2')
+        w3, b3 = _wb(sd, p + 'projection.fc3')
+        wq, bq = _wb(sd, p + 'projection.fc_query')
+        wv, bv = _wb(sd, p + 'projection.fc_value')
+        w8, b8 = _wb(sd, p + 'projection.fc8')
+        if wq.shape[0] != HEADS or w8.shape[0] != C:
+            raise NotImplementedError('unexpected projection head sizes {} {}'.format(wq.shape, w8.shape))
+        host = {
+            'g_w': pack_dense(w1[:, :C]), 'g_b': f32(b1),
+            'ip_w': np.concatenate([pack_xyz(w1[:, C:]), pack_dense(w2), pack_dense(w3), pack_dense(wq)]),
+            'ip_b': f32(np.concatenate([b2, b3, bq])),
+        }
+        # ---- PointNet branch (nn.py:255-373 with use_point_stn=False, use_feat_stn=True, sym_op='att') ---
+        pn = p + 'point_net.'
+        c0a = _fold_bn(*_wb(sd, pn + 'conv0a'), sd, pn + 'bn0a')
+        c0b = _fold_bn(*_wb(sd, pn + 'conv0b'), sd, pn + 'bn0b')
+        s1 = _fold_bn(*_wb(sd, pn + 'stn2.conv1'), sd, pn + 'stn2.bn1')
+        s2 = _fold_bn(*_wb(sd, pn + 'stn2.conv2'), sd, pn + 'stn2.bn2')
+        s3 = _fold_bn(*_wb(sd, pn + 'stn2.conv3'), sd, pn + 'stn2.bn3')
+        f1 = _fold_bn(*_wb(sd, pn + 'stn2.fc1'), sd, pn + 'stn2.bn4')
+        f2 = _fold_bn(*_wb(sd, pn + 'stn2.fc2'), sd, pn + 'stn2.bn5')
+        f3w, f3b = _wb(sd, pn + 'stn2.fc3')
+        if s3[0].shape != (256, 128) or f3w.shape != (4096, 64) or c0a[0].shape != (64, 3):
+            raise NotImplementedError('the HIP PointNet is specialised for net_size_max=256, feature STN dim 64')
+        c1 = _fold_bn(*_wb(sd, pn + 'conv1'), sd, pn + 'bn1')
+        c2 = _fold_bn(*_wb(sd, pn + 'conv2'), sd, pn + 'bn2')
+        c3 = _fold_bn(*_wb(sd, pn + 'conv3'), sd, pn + 'bn3')
+        aq_w, aq_b = _wb(sd, pn + 'att.fc_query')
+        av_w, av_b = _wb(sd, pn + 'att.fc_value')
+        host['pa_w'] = np.concatenate([pack_xyz(c0a[0]), pack_dense(c0b[0]), pack_dense(s1[0]), pack_dense(s2[0]), pack_dense(s3[0])])
+        host['pa_b'] = f32(np.concatenate([c0a[1], c0b[1], s1[1], s2[1], s3[1]]))
+        host['pb_w'] = np.concatenate([pack_dense(f1[0]), pack_dense(f2[0]), pack_dense(f3w)])
+        host['pb_b'] = f32(np.concatenate([f1[1], f2[1], f3b + np.eye(64).reshape(-1)]))        # + identity (nn.py:187-188)
+        host['pc_w'] = np.concatenate([pack_xyz(c0a[0]), pack_dense(c0b[0]), pack_dense(c1[0]), pack_dense(c2[0]), pack_dense(c3[0])])
+        host['pc_b'] = f32(np.concatenate([c0a[1], c0b[1], c1[1], c2[1], c3[1], aq_w.reshape(-1), _pad(aq_b, 4)]))
+        # ---- tail: fc_value . fc8 | att.fc_value, branch sum (ppsurf_model.py:100), MLP (nn.py:376-417) --
+        m = p + 'mlp.layers.'
+        l1 = _fold_bn(*_wb(sd, m + '0.0'), sd, m + '0.1')
+        l2 = _fold_bn(*_wb(sd, m + '1.0'), sd, m + '1.1')
+        l3w, l3b = _wb(sd, m + '2.0')
+        if l3w.shape[0] != 2:
+            raise NotImplementedError('occupancy head must have 2 outputs')
+        wa = l1[0] @ w8 @ wv
+        wb = l1[0] @ av_w
+        ba = l1[0] @ (w8 @ bv + b8 + av_b) + l1[1]
+        host['tl_w'] = np.concatenate([pack_dense(wa), pack_dense(wb), pack_dense(l2[0]), pack_dense(l3w)])
+        host['tl_b'] = f32(np.concatenate([ba, l2[1], _pad(l3b, 32)]))
+        expect = {'g_w': 65536, 'ip_w': 1024 + 65536 * 2 + 16384, 'ip_b': 576, 'pa_w': 256 + 4096 * 2 + 8192 + 32768,
+                  'pa_b': 576, 'pb_w': 32768 + 8192 + 262144, 'pb_b': 128 + 64 + 4096, 'pc_w': 256 + 4096 * 2 + 8192 + 32768,
+                  'pc_b': 576 + 256 + 4, 'tl_w': 65536 * 3 + 8192, 'tl_b': 544}
+        for k, n in expect.items():
+            assert host[k].shape == (n,), (k, host[k].shape, n)
+        self.device = torch.device(device)
+        self.w = {k: torch.from_numpy(v).to(self.device) for k, v in host.items()}
+        self._scratch = {}
+
+    # ---- scratch management: caller-owned buffers, reused across chunks -------------------------------------
+    def scratch(self, name, shape, dtype=torch.float32):
+        t = self._scratch.get(name)
+        n = int(np.prod(shape))
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+            self._scratch[name] = t
+        return t[:n].view(shape)
+
+    # ---- kernels ---------------------------------------------------------------------------------------------
+    def point_table(self, latents_cn):
+        """G [N,256] = fc1_latent(latents) + b1.  `latents_cn` has SHAPE [C,N] like the reference's data['latents'][b]
+        (source/ppsurf_model.py:78); a transposed view of point-major storage is read in place (strides decide)."""
+        latents = latents_cn
+        assert latents.dim() == 2 and latents.shape[0] == C and latents.dtype == torch.float32 and latents.device == self.device
+        n, rs, cs = latents.shape[1], latents.stride(1), latents.stride(0)
+        if cs == 1 and rs % 4 != 0:
+            raise ValueError('point-major latents need a row stride that is a multiple of 4 floats')
+        out = torch.empty((n, C), dtype=torch.float32, device=self.device)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().pps_rows_dense256_f32(latents.data_ptr(), rs, cs, n, self.w['g_w'].data_ptr(),
+                                                    self.w['g_b'].data_ptr(), out.data_ptr(), st), 'pps_rows_dense256_f32')
+        return out
+
+    def decode(self, table, pts, query, idx, patches, want_occ=True):
+        """table G [N,256]; pts [N,3]; query [Q,3]; idx int64 [Q,k]; patches [Q,P,3] -> (logits [Q,2], occ [Q] | None)."""
+        L = _lib.lib()
+        q, k, p = query.shape[0], idx.shape[1], patches.shape[1]
+        for t in (table, pts, query, idx, patches):
+            assert t.is_contiguous() and t.device == self.device
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        pooled = self.scratch('pooled', (q, C))
+        g = self.scratch('g', (q, C))
+        trans2 = self.scratch('trans2', (q, 4096))
+        xbar = self.scratch('xbar', (q, C))
+        logits = torch.empty((q, 2), dtype=torch.float32, device=self.device)
+        occ = torch.empty((q,), dtype=torch.float32, device=self.device) if want_occ else None
+        w = self.w
+        _lib.check(L.pps_interp_pool_f32(table.data_ptr(), pts.data_ptr(), query.data_ptr(), idx.data_ptr(), q, k,
+                                         w['ip_w'].data_ptr(), w['ip_b'].data_ptr(), pooled.data_ptr(), st), 'pps_interp_pool_f32')
+        _lib.check(L.pps_pointnet_stn_rows_f32(patches.data_ptr(), q, p, w['pa_w'].data_ptr(), w['pa_b'].data_ptr(),
+                                               g.data_ptr(), st), 'pps_pointnet_stn_rows_f32')
+        _lib.check(L.pps_pointnet_stn_fc_f32(g.data_ptr(), q, w['pb_w'].data_ptr(), w['pb_b'].data_ptr(), trans2.data_ptr(), st),
+                   'pps_pointnet_stn_fc_f32')
+        _lib.check(L.pps_pointnet_feat_rows_f32(patches.data_ptr(), trans2.data_ptr(), q, p, w['pc_w'].data_ptr(),
+                                                w['pc_b'].data_ptr(), xbar.data_ptr(), st), 'pps_pointnet_feat_rows_f32')
+        _lib.check(L.pps_decode_tail_f32(pooled.data_ptr(), xbar.data_ptr(), q, w['tl_w'].data_ptr(), w['tl_b'].data_ptr(),
+                                         logits.data_ptr(), occ.data_ptr() if want_occ else None, st), 'pps_decode_tail_f32')
+        return logits, occ

@@ -1,0 +1,121 @@
+"""GPU parity of the fused occupancy decoder (C ABI) vs the golden fixture produced by the reference and vs the oracle.
+Tolerance: 1e-4 absolute on the fp32 logits (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import load_golden, filled_sd
+from oracle import ppsurf_oracle as O
+from ppsurf_amd import ops
+from ppsurf_amd.decoder import DecoderPlan
+from ppsurf_amd.synthetic import make_cloud, make_band_queries, make_latents
+import emulate
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+_plan = None
+
+
+def plan():
+    global _plan
+    if _plan is None:
+        _plan = DecoderPlan(filled_sd('', key='ppsurf'), DEV)
+    return _plan
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_point_table_both_layouts():
+    pl = plan()
+    lat = make_latents(256, 1000, seed=3)[0]                      # [256,N] channel-first like data['latents'][0]
+    w = emulate.unpack_dense(pl.w['g_w'].cpu().numpy(), 256, 256)
+    ref = lat.T.astype(np.float64) @ w.T + pl.w['g_b'].cpu().numpy()
+    g_cf = pl.point_table(dev(lat)).cpu().numpy()
+    g_pm = pl.point_table(dev(lat.T.copy()).t()).cpu().numpy()    # transposed view of point-major storage
+    np.testing.assert_allclose(g_cf, ref, rtol=1e-5, atol=1e-5)
+    assert np.array_equal(g_cf, g_pm)
+
+
+def test_decoder_stages_vs_emulation():
+    """Each kernel on its own against the float64 replay of the packed weights (localises a failure)."""
+    import ctypes
+    from ppsurf_amd import _lib
+    pl = plan()
+    rng = np.random.default_rng(5)
+    cloud = make_cloud(3000, seed=8)
+    qry = make_band_queries(cloud, 203, resolution=65, seed=2)     # odd count: exercises the tile tails
+    ids = O.knn_point_major(cloud, qry, 64)
+    patches = O.normalize_patches(cloud[ids[:, :50]], qry)
+    lat = make_latents(256, cloud.shape[0], seed=9)[0]
+    w = {k: v.cpu().numpy() for k, v in pl.w.items()}
+    ref_logits, ref_trans2 = emulate.decode(w, lat, cloud, qry, ids, patches)
+    table = pl.point_table(dev(lat))
+    logits, occ = pl.decode(table, dev(cloud), dev(qry), dev(ids), dev(patches))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(pl.scratch('trans2', (203, 4096)).cpu().numpy().reshape(-1, 64, 64), ref_trans2, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(logits.cpu().numpy(), ref_logits, rtol=1e-4, atol=1e-4)
+    ref_occ = np.tanh((ref_logits[:, 0] - ref_logits[:, 1]) / 2)
+    np.testing.assert_allclose(occ.cpu().numpy(), ref_occ, rtol=1e-4, atol=1e-4)
+
+
+def test_decoder_matches_reference_golden():
+    g = load_golden('ppsurf_from_latent')
+    pl = plan()
+    cloud, qry = g['cloud'], g['query']
+    pts = dev(cloud)
+    idx = ops.knn_point_major(pts, dev(qry), 64)
+    assert np.array_equal(idx.cpu().numpy(), g['proj_ids'][0])
+    patches = ops.patch_normalize(pts, dev(qry), idx, 50)
+    np.testing.assert_allclose(patches.cpu().numpy(), g['patches'], rtol=1e-5, atol=1e-6)
+    table = pl.point_table(dev(make_latents(256, cloud.shape[0], 77)[0]))
+    logits, occ = pl.decode(table, pts, dev(qry), idx, patches)
+    np.testing.assert_allclose(logits.cpu().numpy(), g['logits'][0].T, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(occ.cpu().numpy(), g['occ'], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize('p,k,q', [(50, 64, 1), (10, 64, 77), (25, 16, 130), (50, 64, 1031)])
+def test_decoder_vs_oracle_shapes(p, k, q):
+    """P in the ablation set of configs/ppsurf_*nn.yaml, small k (clamped kNN), ragged query counts."""
+    sd = filled_sd('', key='ppsurf')
+    pl = plan()
+    n = 1500 if k == 64 else k                                   # k clamps to the number of points (poco_utils.py:259-260)
+    cloud = make_cloud(max(n, p), seed=p + k)[:max(n, p)]
+    cloud_lat = cloud[:n] if k != 64 else cloud
+    qry = make_band_queries(cloud, q, resolution=33, seed=q)
+    ids = O.knn_point_major(cloud_lat, qry, min(k, cloud_lat.shape[0]))
+    pid = O.knn_point_major(cloud, qry, p)
+    patches = O.normalize_patches(cloud[pid], qry)
+    lat = make_latents(256, cloud_lat.shape[0], seed=q)
+    data = {'latents': torch.from_numpy(lat), 'pts': torch.from_numpy(cloud_lat.T.copy()).unsqueeze(0),
+            'pts_query': torch.from_numpy(qry).unsqueeze(0), 'pts_local_ps': torch.from_numpy(patches).unsqueeze(0)}
+    ref = O.ppsurf_from_latent(sd, data, k=k)[0].T.numpy()
+    table = pl.point_table(dev(lat[0]))
+    logits, _ = pl.decode(table, dev(cloud_lat), dev(qry), dev(ids), dev(patches.astype(np.float32)))
+    np.testing.assert_allclose(logits.cpu().numpy(), ref, rtol=0, atol=1e-4)
+
+
+def test_decoder_full_chunk_properties():
+    """BASELINE chunk (N=100k, Q=50k, k=64, P=50): finite outputs, permutation equivariance over queries, and a
+    sampled comparison with the oracle."""
+    sd = filled_sd('', key='ppsurf')
+    pl = plan()
+    cloud = make_cloud(100_000, seed=42)
+    qry = make_band_queries(cloud, 50_000, resolution=257, seed=1)
+    pts, qd = dev(cloud), dev(qry)
+    lat = make_latents(256, cloud.shape[0], seed=77)
+    table = pl.point_table(dev(lat[0]))
+    idx = ops.knn_point_major(pts, qd, 64)
+    patches = ops.patch_normalize(pts, qd, idx, 50)
+    logits, occ = pl.decode(table, pts, qd, idx, patches)
+    lg = logits.cpu().numpy()
+    assert np.isfinite(lg).all() and (np.abs(occ.cpu().numpy()) <= 1).all()
+    perm = torch.randperm(50_000, device=DEV)
+    lg2, _ = pl.decode(table, pts, qd[perm].contiguous(), idx[perm].contiguous(), patches[perm].contiguous())
+    assert torch.equal(lg2, logits[perm])                         # each query is independent of its tile neighbours
+    sel = np.random.default_rng(1).choice(50_000, 64, replace=False)
+    data = {'latents': torch.from_numpy(lat), 'pts': torch.from_numpy(cloud.T.copy()).unsqueeze(0),
+            'pts_query': torch.from_numpy(qry[sel]).unsqueeze(0), 'pts_local_ps': patches[torch.from_numpy(sel).to(DEV)].cpu().unsqueeze(0)}
+    ref = O.ppsurf_from_latent(sd, data, k=64)[0].T.numpy()
+    np.testing.assert_allclose(lg[sel], ref, rtol=0, atol=1e-4)

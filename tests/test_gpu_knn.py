@@ -1,0 +1,100 @@
+"""GPU parity: brute-force kNN and patch normalisation through the C ABI vs the CPU oracle (bit-exact indices)."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import load_golden
+from oracle import ppsurf_oracle as O
+from ppsurf_amd import ops
+from ppsurf_amd.synthetic import make_cloud, make_band_queries
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _knn_gpu(pts, qry, k, d2=False):
+    r = ops.knn_point_major(torch.from_numpy(pts).to(DEV), torch.from_numpy(qry).to(DEV), k, return_d2=d2)
+    torch.cuda.synchronize()
+    return (r[0].cpu().numpy(), r[1].cpu().numpy()) if d2 else r.cpu().numpy()
+
+
+def test_knn_golden_fixture():
+    g = load_golden('knn')
+    for b in range(2):
+        p = np.ascontiguousarray(g['pts'][b].T)
+        q = np.ascontiguousarray(g['query'][b].T)
+        for key, k in (('ids16', 16), ('ids64', 64), ('ids1', 1)):
+            assert np.array_equal(_knn_gpu(p, q, k), g[key].reshape(2, 90, k)[b])
+
+
+@pytest.mark.parametrize('n,m,k', [(64, 5, 64), (65, 33, 7), (1000, 257, 16), (5000, 1000, 50), (20000, 3000, 64), (39, 156, 1), (9, 4, 9)])
+def test_knn_bit_exact_vs_oracle(n, m, k):
+    rng = np.random.default_rng(n + m + k)
+    pts = rng.uniform(-0.5, 0.5, (n, 3)).astype(np.float32)
+    qry = rng.uniform(-0.5, 0.5, (m, 3)).astype(np.float32)
+    idx, d2 = _knn_gpu(pts, qry, k, d2=True)
+    ref_idx, ref_d2 = O.knn_point_major(pts, qry, k, return_d2=True)
+    assert np.array_equal(idx, ref_idx)
+    assert np.array_equal(d2, ref_d2)
+
+
+def test_knn_ties_quantised_grid():
+    # points on a coarse lattice: many exactly equal distances -> order must be (d2, index)
+    rng = np.random.default_rng(3)
+    pts = (rng.integers(0, 6, (4000, 3)) / 8.0).astype(np.float32)
+    qry = (rng.integers(0, 6, (300, 3)) / 8.0).astype(np.float32)
+    assert np.array_equal(_knn_gpu(pts, qry, 64), O.knn_point_major(pts, qry, 64))
+
+
+def test_knn_duplicates_and_self_queries():
+    rng = np.random.default_rng(4)
+    pts = rng.uniform(-0.5, 0.5, (700, 3)).astype(np.float32)
+    pts[100:200] = pts[0:100]
+    idx = _knn_gpu(pts, pts, 16)
+    assert np.array_equal(idx, O.knn_point_major(pts, pts, 16))
+    d = np.linalg.norm(pts[idx[:, 0]] - pts, axis=1)
+    assert (d == 0).all()
+
+
+def test_knn_full_size_properties():
+    """BASELINE size (100k points, a 50k-query chunk, k=64): size-independent properties + a sampled oracle check."""
+    cloud = make_cloud(100_000, seed=42)
+    qry = make_band_queries(cloud, 50_000, resolution=257, seed=1)
+    idx, d2 = _knn_gpu(cloud, qry, 64, d2=True)
+    assert idx.min() >= 0 and idx.max() < cloud.shape[0]
+    assert (np.diff(d2, axis=1) >= 0).all()                       # ascending distances
+    srt = np.sort(idx, axis=1)
+    assert (np.diff(srt, axis=1) > 0).all()                       # no index twice
+    rel = cloud[idx] - qry[:, None, :]
+    chk = (rel[..., 0] * rel[..., 0] + rel[..., 1] * rel[..., 1]) + rel[..., 2] * rel[..., 2]
+    assert np.array_equal(chk.astype(np.float32), d2)             # reported d2 is the d2 of the reported index
+    sel = np.random.default_rng(0).choice(qry.shape[0], 400, replace=False)
+    ref_idx = O.knn_point_major(cloud, qry[sel], 64)
+    assert np.array_equal(idx[sel], ref_idx)
+    assert np.array_equal(idx[:, :50], _knn_gpu(cloud, qry, 50))  # the 50-NN is a prefix of the 64-NN
+
+
+def test_knn_rejects_bad_arguments():
+    from ppsurf_amd._lib import PpsError
+    pts = torch.zeros((10, 3), device=DEV)
+    with pytest.raises(PpsError):
+        ops.knn_point_major(pts, pts, 11)          # k > n
+    with pytest.raises(PpsError):
+        ops.knn_point_major(pts, pts, 0)
+    with pytest.raises(PpsError):
+        ops.knn_point_major(pts.cpu(), pts.cpu(), 3)   # no CPU fallback
+    assert ops.knn_point_major(pts, pts[:0], 3).shape == (0, 3)
+
+
+@pytest.mark.parametrize('p', [10, 50, 64, 200])
+def test_patch_normalize_vs_oracle(p):
+    cloud = make_cloud(5000, seed=2)
+    qry = make_band_queries(cloud, 333, resolution=65, seed=5)
+    kk = min(p, 64)
+    ids = O.knn_point_major(cloud, qry, kk)
+    if p > 64:
+        ids = np.concatenate([ids] * 4, axis=1)[:, :p].copy()
+    out = ops.patch_normalize(torch.from_numpy(cloud).to(DEV), torch.from_numpy(qry).to(DEV), torch.from_numpy(ids).to(DEV), p)
+    ref = O.normalize_patches(cloud[ids], qry)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-7)
+    assert abs(np.linalg.norm(out.cpu().numpy(), axis=2).max(axis=1) - 1.0).max() < 1e-6
