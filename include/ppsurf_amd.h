@@ -102,6 +102,32 @@ int pps_pointnet_feat_rows_f32(const float* patches, const float* trans2, int64_
 int pps_decode_tail_f32(const float* pooled, const float* xbar, int64_t q, const float* wpack, const float* bias,
                         float* logits, float* occ, void* stream);
 
+/* ---- FKAConv encoder (eval mode), point-major activations, one batch item per call ----------------- */
+
+/* number of floats of the packed small parameters of one FKAConv layer:
+ * [norm_radius, alpha, beta, act(1 relu | 2 silu), fc1[16][3], fc2[16][32], fc3[16][32], bn1.w[16], bn1.b[16], bn2.w[16], bn2.b[16]] */
+size_t pps_fkaconv_geo_floats(void);
+/* bytes of workspace for a layer with m support points (per-block partial InstanceNorm statistics, double) */
+size_t pps_fkaconv_ws_bytes(int64_t m);
+
+/* One FKAConv layer.   replaces: source/base/nn.py:592-652 `FKAConvLayer.forward` (eval: norm_radius fixed).
+ * x [n,cin], pts [n,3], sup [m,3], idx int64 [m,k] (k <= 16; InstanceNorms skipped when k == 1, nn.py:627-638);
+ * wt [cin*16, cout]: cv.weight[o,c,0,t] stored at wt[(c*16+t)*cout + o] (a following BatchNorm may be folded in);
+ * bias [cout] or NULL; act_out 0 none | 1 ReLU; out [m,cout]; ws: pps_fkaconv_ws_bytes(m) bytes. */
+int pps_fkaconv_fwd_f32(const float* x, const float* pts, const float* sup, const int64_t* idx, int64_t n, int64_t m, int k,
+                        int cin, int cout, const float* geo, const float* wt, const float* bias, int act_out, float* out,
+                        void* ws, void* stream);
+
+/* out[m,o] = act(bias[o] + sum_c A[m,c] wt[c,o] + residual[m,o]),  A[m] = [in1[idx1[m]] (c1) | in2[idx2[m]] (c2)].
+ * replaces: Conv1d(k=1) + BatchNorm1d (folded) + ReLU, torch.cat, nearest-neighbour `interpolate` (nn.py:684-697, K=1)
+ *           and the residual add of nn.py:440-448, 532-548.   idx1/idx2 int64 [m] or NULL (identity); in2 NULL if c2 == 0. */
+int pps_rows_linear_f32(const float* in1, const int64_t* idx1, int c1, const float* in2, const int64_t* idx2, int c2,
+                        const float* wt, const float* bias, const float* residual, int act, int64_t m, int cout, float* out,
+                        void* stream);
+
+/* out[m,c] = max_j x[idx[m,j], c].   replaces: source/base/nn.py:677-680 `max_pool` and the global max of :531. */
+int pps_gather_max_f32(const float* x, const int64_t* idx, int64_t m, int k, int c, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

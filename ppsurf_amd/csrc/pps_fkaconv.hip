@@ -1,0 +1,373 @@
+// FKAConv point-convolution encoder kernels for gfx950 (eval mode), point-major activations.
+//
+// replaces: source/base/nn.py:592-652 `FKAConvLayer.forward` (~25 ATen launches + two InstanceNorms per layer),
+//           :655-697 batch_gather / max_pool / interpolate, and the 1x1 Conv1d + BatchNorm1d + ReLU + residual
+//           glue of ResidualBlock / FKAConvNetwork (:438-450, :508-554).
+//
+// One FKAConv layer = 3 launches (the two InstanceNorm2d are GLOBAL reductions over all (support point, neighbour)
+// pairs, nn.py:586-587,630,638):
+//   phase 1: geometry -> fc1                      -> per-block partial sums of IN1 statistics
+//   phase 2: ... IN1, act, max-pool over K, fc2   -> per-block partial sums of IN2 statistics
+//   phase 3: ... IN2, act, max-pool, fc3 * dw     -> m3[m][j][16] in LDS, F = sum_j x[idx] (x) m3, out = Wcv . F
+// Geometry and the tiny MLPs are recomputed in every phase instead of being stored (HBM traffic stays at the
+// compulsory x/pts/idx reads).  Statistics are reduced in double, in a fixed order (deterministic).
+// 16 lanes (one DPP row) handle the K <= 16 neighbours of one support point.
+#include "pps_common.h"
+#include "../../include/ppsurf_amd.h"
+
+using namespace pps;
+
+#define FK_TM 16                        // support points per workgroup (16 lanes each)
+#define FK_NT 256
+
+// packed small parameters of a layer ("geo" array, floats)
+#define GEO_RADIUS 0
+#define GEO_ALPHA 1
+#define GEO_BETA 2
+#define GEO_ACT 3                       // 1 relu, 2 silu
+#define GEO_FC1 4                       // [16][3]
+#define GEO_FC2 (GEO_FC1 + 48)          // [16][32]
+#define GEO_FC3 (GEO_FC2 + 512)         // [16][32]
+#define GEO_IN1W (GEO_FC3 + 512)
+#define GEO_IN1B (GEO_IN1W + 16)
+#define GEO_IN2W (GEO_IN1B + 16)
+#define GEO_IN2B (GEO_IN2W + 16)
+#define GEO_FLOATS (GEO_IN2B + 16)      // 1140
+
+__device__ __forceinline__ float act_fn(float v, int act) {
+    if (act == 2) return v / (1.f + __expf(-v));       // SiLU (ppsurf_model.py:49-50)
+    return fmaxf(v, 0.f);
+}
+
+struct Geo {
+    float dw;        // normalised distance weight of this neighbour (nn.py:619-624)
+    float pn[3];     // neighbour offset / norm_radius (nn.py:601,616)
+    bool valid;
+};
+
+__device__ __forceinline__ Geo geometry(const float* __restrict__ pts, const float* __restrict__ sup, const int64_t* __restrict__ idx,
+                                        int64_t m, int64_t M, int j, int K, const float* geo) {
+    Geo r;
+    r.valid = (m < M) && (j < K);
+    float d = 0.f;
+    r.pn[0] = r.pn[1] = r.pn[2] = 0.f;
+    if (r.valid) {
+        const int64_t i = idx[m * K + j];
+        const float px = pts[i * 3] - sup[m * 3], py = pts[i * 3 + 1] - sup[m * 3 + 1], pz = pts[i * 3 + 2] - sup[m * 3 + 2];
+        d = sqrtf(px * px + py * py + pz * pz);
+        const float rad = geo[GEO_RADIUS];
+        r.pn[0] = px / rad; r.pn[1] = py / rad; r.pn[2] = pz / rad;
+    }
+    const float w = r.valid ? 1.f / (1.f + __expf(-(-geo[GEO_ALPHA] * d + geo[GEO_BETA]))) : 0.f;
+    float s = row16_sum(w);
+    s = s + (s == 0.f ? 1.f : 0.f) + 1e-6f;
+    r.dw = w / s * (float)K;
+    return r;
+}
+
+__device__ __forceinline__ void fc1_raw(const Geo& g, const float* geo, float (&o)[16]) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+        o[t] = geo[GEO_FC1 + t * 3] * g.pn[0] + geo[GEO_FC1 + t * 3 + 1] * g.pn[1] + geo[GEO_FC1 + t * 3 + 2] * g.pn[2];
+}
+
+// act(IN(raw)) then [m ; max_j(m*dw)] -> fc (16x32)
+__device__ __forceinline__ void norm_act_pool(float (&v)[16], const Geo& g, const float* geo, const float* stat /* [16][2] mean,rstd */,
+                                              int wofs, int bofs, int K, float (&mp)[16]) {
+    const int act = (int)geo[GEO_ACT];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        float x = v[t];
+        if (K > 1) x = (x - stat[2 * t]) * stat[2 * t + 1] * geo[wofs + t] + geo[bofs + t];     // nn.py:627-630
+        x = act_fn(x, act);
+        v[t] = x;
+        mp[t] = row16_max(g.valid ? x * g.dw : -INFINITY);
+    }
+}
+
+__device__ __forceinline__ void fc32(const float (&a)[16], const float (&b)[16], const float* w /* [16][32] */, float (&o)[16]) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) s += w[t * 32 + c] * a[c];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) s += w[t * 32 + 16 + c] * b[c];
+        o[t] = s;
+    }
+}
+
+// block partial sums (double) of v[t], v[t]^2 over valid lanes -> part[blockIdx.x][16][2]
+__device__ __forceinline__ void block_stats(const float (&v)[16], bool valid, double* __restrict__ part, double* red /* LDS [4][32] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        double s = valid ? (double)v[t] : 0.0, q = valid ? (double)v[t] * (double)v[t] : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+        if (lane == 0) { red[wave * 32 + 2 * t] = s; red[wave * 32 + 2 * t + 1] = q; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32)
+        part[(int64_t)blockIdx.x * 32 + threadIdx.x] = red[threadIdx.x] + red[32 + threadIdx.x] + red[64 + threadIdx.x] + red[96 + threadIdx.x];
+}
+
+// mean / rstd (biased variance, eps 1e-5) from the per-block partials, fixed summation order -> LDS stat[16][2]
+__device__ __forceinline__ void finish_stats(const double* __restrict__ part, int nblk, double count, float* stat) {
+    if (threadIdx.x < 16) {
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < nblk; ++b) { s += part[(int64_t)b * 32 + 2 * threadIdx.x]; q += part[(int64_t)b * 32 + 2 * threadIdx.x + 1]; }
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stat[2 * threadIdx.x] = (float)mean;
+        stat[2 * threadIdx.x + 1] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+}
+
+template <int PHASE>
+__global__ __launch_bounds__(FK_NT) void fka_stats_kernel(const float* __restrict__ pts, const float* __restrict__ sup,
+                                                          const int64_t* __restrict__ idx, int64_t M, int K,
+                                                          const float* __restrict__ geo_g, const double* __restrict__ part1,
+                                                          double* __restrict__ part_out) {
+    __shared__ float geo[GEO_FLOATS];
+    __shared__ float stat1[32];
+    __shared__ double red[128];
+    for (int i = threadIdx.x; i < GEO_FLOATS; i += FK_NT) geo[i] = geo_g[i];
+    if (PHASE == 2) finish_stats(part1, gridDim.x, (double)M * K, stat1);
+    __syncthreads();
+    const int j = threadIdx.x & 15;
+    const int64_t m = (int64_t)blockIdx.x * FK_TM + (threadIdx.x >> 4);
+    const Geo g = geometry(pts, sup, idx, m, M, j, K, geo);
+    float v[16];
+    fc1_raw(g, geo, v);
+    if (PHASE == 2) {
+        float mp[16], o[16];
+        norm_act_pool(v, g, geo, stat1, GEO_IN1W, GEO_IN1B, K, mp);
+        fc32(v, mp, geo + GEO_FC2, o);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = o[t];
+    }
+    block_stats(v, g.valid, part_out, red);
+}
+
+// phase 3 + feature aggregation + (1,16) convolution.  wt [Cin*16][Cout] (k = c*16 + t), out [M][Cout].
+__global__ __launch_bounds__(FK_NT) void fka_conv_kernel(const float* __restrict__ x, const float* __restrict__ pts,
+                                                         const float* __restrict__ sup, const int64_t* __restrict__ idx, int64_t M, int K,
+                                                         int Cin, int Cout, const float* __restrict__ geo_g,
+                                                         const double* __restrict__ part1, const double* __restrict__ part2,
+                                                         const float* __restrict__ wt, const float* __restrict__ bias, int act_out,
+                                                         float* __restrict__ out) {
+    __shared__ float geo[GEO_FLOATS];
+    __shared__ float stat1[32], stat2[32];
+    __shared__ float m3[FK_TM][16][17];          // [m][j][t], padded
+    __shared__ int nb[FK_TM][16];                // neighbour row (or -1)
+    __shared__ float F[FK_TM][16 * 16 + 1];      // feature chunk: 16 channels x 16 t per support point
+    for (int i = threadIdx.x; i < GEO_FLOATS; i += FK_NT) geo[i] = geo_g[i];
+    finish_stats(part1, gridDim.x, (double)M * K, stat1);
+    if (threadIdx.x >= 64 && threadIdx.x < 80) {
+        // second statistic by another wave (same fixed order)
+        const int t = threadIdx.x - 64;
+        double s = 0.0, q = 0.0;
+        for (int b = 0; b < (int)gridDim.x; ++b) { s += part2[(int64_t)b * 32 + 2 * t]; q += part2[(int64_t)b * 32 + 2 * t + 1]; }
+        const double cnt = (double)M * K, mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stat2[2 * t] = (float)mean;
+        stat2[2 * t + 1] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+    const int j = threadIdx.x & 15, ml = threadIdx.x >> 4;
+    const int64_t m0 = (int64_t)blockIdx.x * FK_TM;
+    {
+        const int64_t m = m0 + ml;
+        const Geo g = geometry(pts, sup, idx, m, M, j, K, geo);
+        float v[16], mp[16], o[16];
+        fc1_raw(g, geo, v);
+        norm_act_pool(v, g, geo, stat1, GEO_IN1W, GEO_IN1B, K, mp);
+        fc32(v, mp, geo + GEO_FC2, o);
+        norm_act_pool(o, g, geo, stat2, GEO_IN2W, GEO_IN2B, K, mp);
+        fc32(o, mp, geo + GEO_FC3, v);
+        const int act = (int)geo[GEO_ACT];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) m3[ml][j][t] = g.valid ? act_fn(v[t], act) * g.dw : 0.f;     // nn.py:643
+        nb[ml][j] = g.valid ? (int)idx[m * K + j] : -1;
+    }
+    __syncthreads();
+
+    // output ownership: thread -> (output o, group of support points)
+    const int OT = Cout < FK_NT ? Cout : FK_NT;                     // threads along the output axis
+    const int MG = (FK_NT / OT) < FK_TM ? (FK_NT / OT) : FK_TM;     // support-point groups
+    const int mper = (FK_TM + MG - 1) / MG;                         // support points per thread
+    const int og = threadIdx.x % OT, mg = threadIdx.x / OT;
+    const bool active = mg < MG && mg * mper < FK_TM;
+    for (int o0 = 0; o0 < Cout; o0 += FK_NT) {
+        const int o = o0 + og;
+        float acc[FK_TM];
+#pragma unroll
+        for (int i = 0; i < FK_TM; ++i) acc[i] = 0.f;
+        for (int c0 = 0; c0 < Cin; c0 += 16) {
+            __syncthreads();
+            // F[m][cl*16 + t] = sum_j x[nb[m][j]][c0+cl] * m3[m][j][t]   (thread = (m, cl))
+            {
+                const int cl = threadIdx.x & 15, mm = threadIdx.x >> 4;
+                float f[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) f[t] = 0.f;
+                if (c0 + cl < Cin) {
+                    for (int jj = 0; jj < K; ++jj) {
+                        const int r = nb[mm][jj];
+                        if (r >= 0) {
+                            const float xv = x[(int64_t)r * Cin + c0 + cl];
+#pragma unroll
+                            for (int t = 0; t < 16; ++t) f[t] += xv * m3[mm][jj][t];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 16; ++t) F[mm][cl * 16 + t] = f[t];
+            }
+            __syncthreads();
+            if (active && o < Cout) {
+                const int kmax = (Cin - c0 < 16 ? Cin - c0 : 16) * 16;
+                const float* wrow = wt + (int64_t)c0 * 16 * Cout + o;
+                for (int k = 0; k < kmax; ++k) {
+                    const float w = wrow[(int64_t)k * Cout];
+#pragma unroll
+                    for (int i = 0; i < FK_TM; ++i)
+                        if (i < mper && mg * mper + i < FK_TM) acc[i] += w * F[mg * mper + i][k];
+                }
+            }
+        }
+        if (active && o < Cout) {
+            for (int i = 0; i < mper && mg * mper + i < FK_TM; ++i) {
+                const int64_t m = m0 + mg * mper + i;
+                if (m < M) {
+                    float v = acc[i] + (bias ? bias[o] : 0.f);
+                    if (act_out == 1) v = fmaxf(v, 0.f);
+                    out[m * Cout + o] = v;
+                }
+            }
+        }
+    }
+}
+
+// out[m][o] = act( bias[o] + sum_c A[m][c] * wt[c][o] + residual[m][o] ),  A = [in1[idx1[m]] | in2[idx2[m]]]
+#define RL_TM 32
+#define RL_TN 64
+#define RL_TK 32
+__global__ __launch_bounds__(256) void rows_linear_kernel(const float* __restrict__ in1, const int64_t* __restrict__ idx1, int C1,
+                                                          const float* __restrict__ in2, const int64_t* __restrict__ idx2, int C2,
+                                                          const float* __restrict__ wt, const float* __restrict__ bias,
+                                                          const float* __restrict__ residual, int act, int64_t M, int Cout,
+                                                          float* __restrict__ out) {
+    __shared__ float As[RL_TM][RL_TK + 1];
+    __shared__ float Ws[RL_TK][RL_TN + 1];
+    __shared__ int64_t r1[RL_TM], r2[RL_TM];
+    const int64_t m0 = (int64_t)blockIdx.x * RL_TM;
+    const int o0 = blockIdx.y * RL_TN;
+    if (threadIdx.x < RL_TM) {
+        const int64_t m = m0 + threadIdx.x;
+        const int64_t mc = m < M ? m : M - 1;
+        r1[threadIdx.x] = idx1 ? idx1[mc] : mc;
+        r2[threadIdx.x] = in2 ? (idx2 ? idx2[mc] : mc) : 0;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // outputs 4*tx.., rows 2*ty..
+    float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int Ct = C1 + C2;
+    for (int k0 = 0; k0 < Ct; k0 += RL_TK) {
+        for (int e = threadIdx.x; e < RL_TM * RL_TK; e += 256) {
+            const int r = e / RL_TK, kk = e % RL_TK, c = k0 + kk;
+            float v = 0.f;
+            if (c < C1) v = in1[r1[r] * C1 + c];
+            else if (c < Ct) v = in2[r2[r] * C2 + (c - C1)];
+            As[r][kk] = v;
+        }
+        for (int e = threadIdx.x; e < RL_TK * RL_TN; e += 256) {
+            const int kk = e / RL_TN, oo = e % RL_TN;
+            Ws[kk][oo] = (k0 + kk < Ct && o0 + oo < Cout) ? wt[(int64_t)(k0 + kk) * Cout + o0 + oo] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < RL_TK; ++kk) {
+            const float a0 = As[2 * ty][kk], a1 = As[2 * ty + 1][kk];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float w = Ws[kk][4 * tx + i];
+                acc[0][i] += a0 * w;
+                acc[1][i] += a1 * w;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int64_t m = m0 + 2 * ty + rr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = o0 + 4 * tx + i;
+            if (o >= Cout) continue;
+            float v = acc[rr][i] + (bias ? bias[o] : 0.f);
+            if (residual) v += residual[m * Cout + o];
+            if (act == 1) v = fmaxf(v, 0.f);
+            out[m * Cout + o] = v;
+        }
+    }
+}
+
+// out[m][c] = max_j x[idx[m][j]][c]   (nn.py:677-680; K arbitrary; also the global max of nn.py:531 with one row of idx)
+__global__ __launch_bounds__(256) void gather_max_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx, int64_t M, int K, int C,
+                                                         float* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= M * C) return;
+    const int64_t m = e / C;
+    const int c = (int)(e % C);
+    float v = -INFINITY;
+    for (int j = 0; j < K; ++j) v = fmaxf(v, x[idx[m * K + j] * C + c]);
+    out[e] = v;
+}
+
+extern "C" {
+
+size_t pps_fkaconv_geo_floats(void) { return GEO_FLOATS; }
+
+size_t pps_fkaconv_ws_bytes(int64_t M) {
+    const int64_t nblk = (M + FK_TM - 1) / FK_TM;
+    return (size_t)nblk * 32 * sizeof(double) * 2;
+}
+
+int pps_fkaconv_fwd_f32(const float* x, const float* pts, const float* sup, const int64_t* idx, int64_t n, int64_t m, int k,
+                        int cin, int cout, const float* geo, const float* wt, const float* bias, int act_out, float* out,
+                        void* ws, void* stream) {
+    if (!x || !pts || !sup || !idx || !geo || !wt || !out || !ws || n < 1 || m < 1 || k < 1 || k > 16 || cin < 1 || cout < 1)
+        return PPS_ERR_ARG;
+    const int nblk = (int)((m + FK_TM - 1) / FK_TM);
+    double* part1 = (double*)ws;
+    double* part2 = part1 + (size_t)nblk * 32;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(fka_stats_kernel<1>, dim3(nblk), dim3(FK_NT), 0, st, pts, sup, idx, m, k, geo, (const double*)nullptr, part1);
+    hipLaunchKernelGGL(fka_stats_kernel<2>, dim3(nblk), dim3(FK_NT), 0, st, pts, sup, idx, m, k, geo, (const double*)part1, part2);
+    hipLaunchKernelGGL(fka_conv_kernel, dim3(nblk), dim3(FK_NT), 0, st, x, pts, sup, idx, m, k, cin, cout, geo, (const double*)part1,
+                       (const double*)part2, wt, bias, act_out, out);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+int pps_rows_linear_f32(const float* in1, const int64_t* idx1, int c1, const float* in2, const int64_t* idx2, int c2,
+                        const float* wt, const float* bias, const float* residual, int act, int64_t m, int cout, float* out,
+                        void* stream) {
+    if (!in1 || !wt || !out || m < 1 || c1 < 1 || c2 < 0 || cout < 1 || (c2 > 0 && !in2)) return PPS_ERR_ARG;
+    dim3 grid((unsigned)((m + RL_TM - 1) / RL_TM), (unsigned)((cout + RL_TN - 1) / RL_TN));
+    hipLaunchKernelGGL(rows_linear_kernel, grid, dim3(256), 0, (hipStream_t)stream, in1, idx1, c1, c2 > 0 ? in2 : nullptr, idx2, c2, wt,
+                       bias, residual, act, m, cout, out);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+int pps_gather_max_f32(const float* x, const int64_t* idx, int64_t m, int k, int c, float* out, void* stream) {
+    if (!x || !idx || !out || m < 1 || k < 1 || c < 1) return PPS_ERR_ARG;
+    hipLaunchKernelGGL(gather_max_kernel, dim3((unsigned)((m * c + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, idx, m, k, c, out);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+}  // extern "C"

@@ -152,8 +152,9 @@ class DecoderPlan:
                                                     self.w['g_b'].data_ptr(), out.data_ptr(), st), 'pps_rows_dense256_f32')
         return out
 
-    def decode(self, table, pts, query, idx, patches, want_occ=True):
-        """table G [N,256]; pts [N,3]; query [Q,3]; idx int64 [Q,k]; patches [Q,P,3] -> (logits [Q,2], occ [Q] | None)."""
+    def decode(self, table, pts, query, idx, patches, want_occ=True, interp_events=None):
+        """table G [N,256]; pts [N,3]; query [Q,3]; idx int64 [Q,k]; patches [Q,P,3] -> (logits [Q,2], occ [Q] | None).
+        interp_events: optional (start, end) torch.cuda.Event pair recorded around the dominant kernel (bench.py)."""
         L = _lib.lib()
         q, k, p = query.shape[0], idx.shape[1], patches.shape[1]
         for t in (table, pts, query, idx, patches):
@@ -166,8 +167,12 @@ class DecoderPlan:
         logits = torch.empty((q, 2), dtype=torch.float32, device=self.device)
         occ = torch.empty((q,), dtype=torch.float32, device=self.device) if want_occ else None
         w = self.w
+        if interp_events is not None:
+            interp_events[0].record()
         _lib.check(L.pps_interp_pool_f32(table.data_ptr(), pts.data_ptr(), query.data_ptr(), idx.data_ptr(), q, k,
                                          w['ip_w'].data_ptr(), w['ip_b'].data_ptr(), pooled.data_ptr(), st), 'pps_interp_pool_f32')
+        if interp_events is not None:
+            interp_events[1].record()
         _lib.check(L.pps_pointnet_stn_rows_f32(patches.data_ptr(), q, p, w['pa_w'].data_ptr(), w['pa_b'].data_ptr(),
                                                g.data_ptr(), st), 'pps_pointnet_stn_rows_f32')
         _lib.check(L.pps_pointnet_stn_fc_f32(g.data_ptr(), q, w['pb_w'].data_ptr(), w['pb_b'].data_ptr(), trans2.data_ptr(), st),
