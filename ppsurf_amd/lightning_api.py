@@ -1,0 +1,256 @@
+"""PocoModel / PPSurfModel with the reference's constructor and Lightning hook signatures.
+
+Mirrors source/poco_model.py:19-329 and source/ppsurf_model.py:10-36: `training_step(batch, batch_idx)`,
+`validation_step`, `test_step`, `predict_step(batch, batch_idx, dataloader_idx=0)`, `compute_loss`, `calc_metrics`,
+`self.network` with `.encoder/.projection/.point_net/.mlp` (state-dict names).  Works under pytorch_lightning when it is
+installed and as a plain torch.nn.Module otherwise (ppsurf_amd.runner drives the hooks then).
+"""
+import math
+import numbers
+import os
+import typing
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import spatial
+from .modules import _Base, PocoNetwork, PPSurfNetwork
+
+
+def calc_accuracy(num_true, num_predictions):
+    return float('NaN') if num_predictions == 0 else num_true / num_predictions
+
+
+def calc_precision(tp, fp):
+    return float('NaN') if tp + fp == 0 else tp / (tp + fp)
+
+
+def calc_recall(tp, fn):
+    return float('NaN') if tp + fn == 0 else tp / (tp + fn)
+
+
+def calc_f1(precision, recall):
+    if math.isnan(precision) or math.isnan(recall) or precision + recall == 0:
+        return float('NaN')
+    return 2.0 * (precision * recall) / (precision + recall)
+
+
+def compare_predictions_binary_tensors(ground_truth, predicted, prediction_name):
+    """source/base/metrics.py:41-84: confusion counts and accuracy / precision / recall / F1 of two {0,1} tensors."""
+    if ground_truth.shape != predicted.shape:
+        raise ValueError('The ground truth matrix and the predicted matrix have different sizes!')
+    if not isinstance(ground_truth, torch.Tensor) or not isinstance(predicted, torch.Tensor):
+        raise ValueError('Both matrices must be dense of type torch.tensor!')
+    gt, pr = ground_truth > 0.0, predicted > 0.0
+    res = {} if prediction_name is None else {'comp_name': prediction_name}
+    n = float(gt.numel())
+    tp, fp, fn = float((pr & gt).sum()), float((pr & ~gt).sum()), float((~pr & gt).sum())
+    tn = n - tp - fp - fn
+    res.update({'predictions': n, 'pred_gt': n, 'positives': tp + fp, 'pos_gt': tp + fn, 'true_neg': tn, 'negatives': n - tp - fp,
+                'neg_gt': n - tp - fn, 'true_pos': tp, 'true': tp + tn, 'false_pos': fp, 'false_neg': fn, 'false': fp + fn})
+    res['accuracy'] = calc_accuracy(res['true'], n)
+    res['precision'] = calc_precision(tp, fp)
+    res['recall'] = calc_recall(tp, fn)
+    res['f1_score'] = calc_f1(res['precision'], res['recall'])
+    return res
+
+
+def in_file_is_dataset(in_file: str):
+    return os.path.splitext(in_file)[1].lower() == '.txt'
+
+
+def get_results_dir(out_dir: str, name: str, in_file: str):
+    return os.path.join(out_dir, name, os.path.basename(os.path.dirname(in_file)))
+
+
+class PocoModel(_Base):
+
+    def __init__(self, output_names, in_channels, out_channels, k, lambda_l1, debug, in_file, results_dir, padding_factor, name,
+                 network_latent_size, gen_subsample_manifold_iter, gen_subsample_manifold, gen_resolution_global, rec_batch_size,
+                 gen_refine_iter, workers):
+        super().__init__()
+        self.output_names, self.in_channels, self.out_channels, self.k = output_names, in_channels, out_channels, k
+        self.lambda_l1, self.network_latent_size = lambda_l1, network_latent_size
+        self.gen_subsample_manifold_iter, self.gen_subsample_manifold = gen_subsample_manifold_iter, gen_subsample_manifold
+        self.gen_resolution_global, self.gen_resolution_metric, self.num_pts_local = gen_resolution_global, None, None
+        self.rec_batch_size, self.gen_refine_iter, self.workers = rec_batch_size, gen_refine_iter, workers
+        self.in_file, self.results_dir, self.padding_factor = in_file, results_dir, padding_factor
+        self.debug, self.show_unused_params, self.name = debug, debug, name
+        self.network = self._make_network()
+        self.test_step_outputs = []
+        self.last_prediction = None                 # (verts, faces) of the most recent predict_step, for callers/tests
+
+    def _make_network(self):
+        return PocoNetwork(in_channels=self.in_channels, latent_size=self.network_latent_size, out_channels=self.out_channels, k=self.k)
+
+    # ---- progress bar / logging shims ---------------------------------------------------------------------------
+    def get_prog_bar(self):
+        trainer = getattr(self, '_trainer', None) or getattr(self, 'trainer_', None)
+        try:
+            trainer = self.trainer
+        except Exception:
+            pass
+        return getattr(trainer, 'progress_bar_callback', None) if trainer is not None else None
+
+    def _log(self, *args, **kwargs):
+        if hasattr(super(), 'log'):
+            try:
+                return super().log(*args, **kwargs)
+            except Exception:
+                return None
+        return None
+
+    def on_after_backward(self):
+        if self.show_unused_params:
+            for name, param in self.named_parameters():
+                if param.grad is None:
+                    print('Unused param {}'.format(name))
+            self.show_unused_params = False
+
+    # ---- loss / metrics (poco_model.py:75-118) ------------------------------------------------------------------
+    def compute_loss(self, pred, batch_data):
+        occ_loss = nn.functional.cross_entropy(input=pred, target=batch_data['occ'], reduction='none')
+        loss_components = torch.stack([occ_loss])
+        loss_components_mean = torch.stack([torch.mean(occ_loss)])
+        return loss_components_mean.mean(), loss_components_mean, loss_components
+
+    def calc_metrics(self, pred, gt_data):
+        pred_labels = torch.argmax(pred, dim=1).to(torch.float32)
+        eval_dict = compare_predictions_binary_tensors(ground_truth=gt_data['occ'].squeeze(), predicted=pred_labels.squeeze(),
+                                                       prediction_name=None)
+        eval_dict['abs_dist_rms'] = np.nan
+        return eval_dict
+
+    def get_loss_and_metrics(self, pred, batch):
+        loss, mean, comps = self.compute_loss(pred=pred, batch_data=batch)
+        return loss, mean, comps, self.calc_metrics(pred=pred, gt_data=batch)
+
+    def default_step_dict(self, batch):
+        pred = self.network.forward(batch)
+        loss, mean, comps, metrics = self.get_loss_and_metrics(pred, batch)
+        if self.lambda_l1 != 0.0:
+            raise NotImplementedError('lambda_l1 != 0 calls a regulariser that does not exist in the reference (poco_model.py:112-113)')
+        return loss, mean, comps, metrics
+
+    def training_step(self, batch, batch_idx):
+        loss, mean, comps, metrics = self.default_step_dict(batch=batch)
+        self.do_logging(loss, mean, log_type='train', output_names=self.output_names, metrics_dict=metrics, f1_in_prog_bar=False,
+                        keys_to_log=frozenset({'accuracy', 'precision', 'recall', 'f1_score'}))
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        loss, mean, comps, metrics = self.default_step_dict(batch=batch)
+        self.do_logging(loss, mean, log_type='val', output_names=self.output_names, metrics_dict=metrics, f1_in_prog_bar=True,
+                        keys_to_log=frozenset({'accuracy', 'precision', 'recall', 'f1_score'}))
+        return loss
+
+    def test_step(self, batch, batch_idx):
+        pred = self.network.forward(batch)
+        if batch['shape_id'].shape[0] != 1:
+            raise NotImplementedError('batch size > 1 not supported')
+        loss, mean, comps = self.compute_loss(pred=pred, batch_data=batch)
+        metrics = self.calc_metrics(pred=pred, gt_data=batch)
+        results = {'shape_id': batch['shape_id'].squeeze(0), 'pc_file_in': batch['pc_file_in'][0], 'loss': loss,
+                   'loss_components_mean': mean.squeeze(0), 'loss_components': comps.squeeze(0), 'metrics_dict': metrics}
+        self.test_step_outputs.append(results)
+        bar = self.get_prog_bar()
+        if bar is not None and getattr(bar, 'test_progress_bar', None) is not None:
+            bar.test_progress_bar.set_postfix_str('pc_file: {}'.format(os.path.basename(results['pc_file_in'])), refresh=True)
+        return results
+
+    def do_logging(self, loss_total, loss_components, log_type: str, output_names: list, metrics_dict: dict,
+                   keys_to_log=frozenset({'abs_dist_rms', 'accuracy', 'precision', 'recall', 'f1_score'}), f1_in_prog_bar=True,
+                   on_step=True, on_epoch=False):
+        self._log('loss/{}/00_all'.format(log_type), loss_total, on_step=on_step, on_epoch=on_epoch)
+        if len(loss_components) > 1:
+            for li, l in enumerate(loss_components):
+                self._log('loss/{}/{}_{}'.format(log_type, li, output_names[li]), l, on_step=on_step, on_epoch=on_epoch)
+        for key, value in metrics_dict.items():
+            if key in keys_to_log and isinstance(value, numbers.Number):
+                self._log('metrics/{}/{}'.format(log_type, key), 0.0 if math.isnan(value) else value, on_step=on_step, on_epoch=on_epoch)
+        self._log('metrics/{}/{}'.format(log_type, 'F1'), metrics_dict['f1_score'], on_step=on_step, on_epoch=on_epoch, logger=False,
+                  prog_bar=f1_in_prog_bar)
+
+    # ---- reconstruction (poco_model.py:183-273) -----------------------------------------------------------------
+    @torch.no_grad()
+    def encode_latents(self, pts_cf: torch.Tensor, progress=None) -> torch.Tensor:
+        """Latent loop of poco_model.py:203-236 for one cloud.  pts_cf [3,N] on the device -> latents POINT-MAJOR [N,C]:
+        coverage-balanced random subsets of gen_subsample_manifold points until every point has been encoded
+        gen_subsample_manifold_iter times; latents are averaged."""
+        n, dev = pts_cf.shape[1], pts_cf.device
+        latent = torch.zeros((n, self.network_latent_size), dtype=torch.float32, device=dev)
+        counts = torch.zeros((n,), dtype=torch.float32, device=dev)
+        m = self.gen_subsample_manifold
+        iteration = 0
+        for current_value in range(self.gen_subsample_manifold_iter):
+            while float(counts.min()) < current_value + 1:
+                if n >= m:
+                    valid_ids = torch.nonzero(counts == current_value)[:, 0]
+                    ids = valid_ids[torch.randperm(valid_ids.shape[0], device=dev)[:m]]
+                    if ids.shape[0] < m:
+                        ids = torch.cat([ids, torch.randperm(n, device=dev)[:m - ids.shape[0]]], dim=0)
+                    assert ids.shape[0] == m
+                else:
+                    ids = torch.arange(n, device=dev)
+                data_partial = {'pts': pts_cf[:, ids].unsqueeze(0)}
+                data_partial.update(spatial.get_fkaconv_ids(data_partial))
+                latent[ids] += self.network.encoder.forward_point_major(data_partial, 0)    # duplicates: last write wins, like the reference
+                counts[ids] += 1
+                iteration += 1
+                if progress is not None:
+                    progress('get_latent iter: {}'.format(iteration))
+        return latent / counts.unsqueeze(1)
+
+    @torch.no_grad()
+    def predict_step(self, batch: dict, batch_idx, dataloader_idx=0):
+        from . import reconstruct, meshio
+        if batch['pts_ms'].shape[0] > 1:
+            raise NotImplementedError('batch size > 1 not supported')
+        self.network.eval()
+        bar = self.get_prog_bar()
+        progress = None
+        if bar is not None and getattr(bar, 'predict_progress_bar', None) is not None:
+            progress = lambda s: bar.predict_progress_bar.set_postfix_str(s, refresh=True)
+        pc_file_in = batch['pc_file_in'][0]
+        if in_file_is_dataset(self.in_file):
+            out_file_rec = os.path.join(get_results_dir(self.results_dir, self.name, self.in_file), 'meshes', os.path.basename(pc_file_in))
+        else:
+            out_file_rec = os.path.join(self.results_dir, os.path.basename(pc_file_in), os.path.basename(pc_file_in) + '.ply')
+        dev = next(self.network.parameters()).device
+        pts_cf = torch.transpose(batch['pts_ms'], -1, -2)[0].to(dev).float()          # [3,N]   (get_data_poco, poco_data_loader.py:247)
+        latent_pm = self.encode_latents(pts_cf, progress)
+        shape = {'pts': pts_cf.unsqueeze(0), 'latents': latent_pm.t().unsqueeze(0)}     # [1,C,N] view of point-major storage
+        mesh = reconstruct.export_mesh_and_refine_vertices_region_growing_v3(
+            network=self.network, latent=shape, pts_raw_ms=batch['pts_raw_ms'] if 'pts_raw_ms' in batch else None,
+            resolution=self.gen_resolution_global, padding=1, mc_value=0, num_pts=self.rec_batch_size, num_pts_local=self.num_pts_local,
+            input_points=pts_cf.t().cpu().numpy(), refine_iter=self.gen_refine_iter, out_value=1, prog_bar=bar, pc_file_in=pc_file_in)
+        self.last_prediction = mesh
+        if mesh is not None:
+            verts, faces = mesh
+            if not in_file_is_dataset(self.in_file):               # de-normalise single files (poco_model.py:256-265)
+                raw = meshio.load_pts(pc_file_in)[:, :3]
+                bb_min, bb_max = raw.min(axis=0), raw.max(axis=0)
+                verts = verts * (np.max(bb_max - bb_min) * (1.0 + self.padding_factor)) + (bb_min + bb_max) * 0.5
+            meshio.write_ply_mesh(out_file_rec, verts, faces)
+        else:
+            print('No reconstruction for {}'.format(pc_file_in))
+        return 0
+
+
+class PPSurfModel(PocoModel):
+
+    def __init__(self, pointnet_latent_size, output_names, in_channels, out_channels, k, lambda_l1, debug, in_file, results_dir,
+                 padding_factor, name, network_latent_size, gen_subsample_manifold_iter, gen_subsample_manifold, gen_resolution_global,
+                 num_pts_local, rec_batch_size, gen_refine_iter, workers):
+        self._pps = (num_pts_local, pointnet_latent_size)
+        super().__init__(output_names=output_names, in_channels=in_channels, out_channels=out_channels, k=k, lambda_l1=lambda_l1,
+                         debug=debug, in_file=in_file, results_dir=results_dir, padding_factor=padding_factor, name=name,
+                         workers=workers, rec_batch_size=rec_batch_size, gen_refine_iter=gen_refine_iter,
+                         gen_subsample_manifold=gen_subsample_manifold, gen_resolution_global=gen_resolution_global,
+                         gen_subsample_manifold_iter=gen_subsample_manifold_iter, network_latent_size=network_latent_size)
+        self.num_pts_local, self.pointnet_latent_size = num_pts_local, pointnet_latent_size
+
+    def _make_network(self):
+        return PPSurfNetwork(in_channels=self.in_channels, latent_size=self.network_latent_size, out_channels=self.out_channels, k=self.k,
+                             num_pts_local=self._pps[0], pointnet_latent_size=self._pps[1])

@@ -1,0 +1,144 @@
+"""Marching Cubes and mesh clean-up in numpy (host post-processing of the occupancy volume).
+
+Stands in for `skimage.measure.marching_cubes` (source/poco_utils.py:96) and the trimesh clean-up of
+source/base/mesh.py:7-38 (merge vertices, drop degenerate / duplicate faces, drop connected components with <= 6 faces);
+neither package exists in the build image and the reference pins no output for them ("parity unpinned").
+
+The 256-case triangle table is DERIVED at import instead of being typed in: for every corner-sign pattern the crossing
+points of each cube face are joined by segments (an ambiguous face always cuts off its inside corners, a rule that only
+depends on the face's own corners, so neighbouring cubes agree and the surface has no cracks), the segments chain into
+closed loops, and each loop is fan-triangulated.  Vertices sit on grid edges (one fractional coordinate), which is what
+the bisection refinement of the reference relies on (poco_utils.py:111-119).
+"""
+import numpy as np
+
+# corner c has offset (c & 1, (c >> 1) & 1, (c >> 2) & 1); an edge is a pair of corners differing in one bit
+_CORNERS = np.array([[c & 1, (c >> 1) & 1, (c >> 2) & 1] for c in range(8)], dtype=np.int64)
+_EDGES = [(a, a | (1 << ax)) for ax in range(3) for a in range(8) if not a & (1 << ax)]          # 12 edges
+_EDGE_ID = {e: i for i, e in enumerate(_EDGES)}
+_EDGE_AXIS = np.array([int(np.log2(b - a)) for a, b in _EDGES], dtype=np.int64)
+_EDGE_ORIGIN = _CORNERS[[a for a, _ in _EDGES]]
+
+
+def _face_cycles():
+    """For each of the 6 faces: its 4 corners in counter-clockwise order seen from OUTSIDE the cube."""
+    faces = []
+    for ax in range(3):
+        u, v = (ax + 1) % 3, (ax + 2) % 3
+        for side in (0, 1):
+            def corner(a, b):
+                c = [0, 0, 0]
+                c[ax], c[u], c[v] = side, a, b
+                return c[0] | (c[1] << 1) | (c[2] << 2)
+            cyc = [corner(0, 0), corner(1, 0), corner(1, 1), corner(0, 1)]     # CCW around +ax
+            faces.append(cyc if side == 1 else cyc[::-1])
+    return faces
+
+
+def _build_table():
+    faces = _face_cycles()
+    table = []
+    for case in range(256):
+        inside = [(case >> c) & 1 for c in range(8)]
+        nxt = {}                                        # directed segments between edge ids (inside on the left, seen from outside)
+        for cyc in faces:
+            for i in range(4):
+                c0, c1, c2 = cyc[i - 1], cyc[i], cyc[(i + 1) % 4]
+                # walking CCW: entering the inside region on edge (c0->c1) and leaving it on a later edge
+                if not inside[c0] and inside[c1]:
+                    j = i
+                    while inside[cyc[(j + 1) % 4]] and (j + 1) % 4 != (i - 1) % 4:
+                        j += 1
+                    e_in = _EDGE_ID[tuple(sorted((c0, c1)))]
+                    e_out = _EDGE_ID[tuple(sorted((cyc[j % 4], cyc[(j + 1) % 4])))]
+                    nxt[e_out] = e_in
+        tris, seen = [], set()
+        for start in sorted(nxt):
+            if start in seen:
+                continue
+            loop, e = [], start
+            while e not in seen:
+                seen.add(e)
+                loop.append(e)
+                e = nxt[e]
+            for t in range(1, len(loop) - 1):
+                tris.append((loop[0], loop[t + 1], loop[t]))        # winding: normals point towards LOWER values
+        table.append(tris)
+    width = max(len(t) for t in table)
+    out = np.full((256, width, 3), -1, dtype=np.int64)
+    for i, t in enumerate(table):
+        if t:
+            out[i, :len(t)] = np.array(t)
+    return out
+
+
+_TRI_TABLE = _build_table()
+
+
+def marching_cubes(volume: np.ndarray, level: float = 0.0):
+    """volume [X,Y,Z] (NaN = unknown: cubes touching a NaN are skipped) -> (verts float64 [V,3] in index space,
+    faces int64 [F,3]).  'Inside' is value > level; triangles are oriented with normals towards lower values."""
+    vol = np.asarray(volume, dtype=np.float64)
+    nx, ny, nz = vol.shape
+    corner_vals = [vol[dx:nx - 1 + dx, dy:ny - 1 + dy, dz:nz - 1 + dz] for dx, dy, dz in _CORNERS]
+    finite = np.ones(corner_vals[0].shape, dtype=bool)
+    case = np.zeros(corner_vals[0].shape, dtype=np.int64)
+    for c, v in enumerate(corner_vals):
+        finite &= ~np.isnan(v)
+        with np.errstate(invalid='ignore'):
+            case |= (v > level).astype(np.int64) << c
+    active = finite & (case != 0) & (case != 255)
+    cx, cy, cz = np.nonzero(active)
+    if cx.size == 0:
+        return np.zeros((0, 3)), np.zeros((0, 3), dtype=np.int64)
+    tris = _TRI_TABLE[case[cx, cy, cz]]                             # [n, W, 3] local edge ids
+    valid = tris[:, :, 0] >= 0
+    cube_of = np.broadcast_to(np.arange(cx.size)[:, None], valid.shape)[valid]
+    e = tris[valid]                                                  # [T,3]
+    base = np.stack([cx, cy, cz], axis=1)[cube_of]                   # [T,3]
+    origin = base[:, None, :] + _EDGE_ORIGIN[e]                      # [T,3(verts),3]
+    axis = _EDGE_AXIS[e]
+    key = ((origin[..., 0] * ny + origin[..., 1]) * nz + origin[..., 2]) * 3 + axis
+    ukey, faces = np.unique(key.reshape(-1), return_inverse=True)
+    faces = faces.reshape(-1, 3)
+    ax = ukey % 3
+    lin = ukey // 3
+    o = np.stack([lin // (ny * nz), (lin // nz) % ny, lin % nz], axis=1)
+    o2 = o.copy()
+    o2[np.arange(o.shape[0]), ax] += 1
+    va = vol[o[:, 0], o[:, 1], o[:, 2]]
+    vb = vol[o2[:, 0], o2[:, 1], o2[:, 2]]
+    t = (level - va) / (vb - va)
+    verts = o.astype(np.float64)
+    verts[np.arange(o.shape[0]), ax] += t
+    return verts, faces.astype(np.int64)
+
+
+def clean_mesh(verts: np.ndarray, faces: np.ndarray, min_component_faces=6, digits=8):
+    """merge vertices by position, drop degenerate and duplicate faces, keep connected components with MORE than
+    `min_component_faces` faces (mesh.py:7-38), drop unreferenced vertices."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    if faces.shape[0] == 0:
+        return verts, faces
+    _, first, inv = np.unique(np.round(verts, digits), axis=0, return_index=True, return_inverse=True)
+    verts = verts[first]
+    faces = inv.reshape(-1)[faces]
+    ok = (faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2])
+    faces = faces[ok]
+    _, keep = np.unique(np.sort(faces, axis=1), axis=0, return_index=True)
+    faces = faces[np.sort(keep)]
+    if faces.shape[0] and min_component_faces is not None:
+        nf = faces.shape[0]
+        edges = np.sort(np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]]), axis=1)
+        owner = np.tile(np.arange(nf), 3)
+        order = np.lexsort((edges[:, 1], edges[:, 0]))
+        es, ow = edges[order], owner[order]
+        same = (es[1:] == es[:-1]).all(axis=1)
+        a, b = ow[:-1][same], ow[1:][same]
+        graph = coo_matrix((np.ones(a.shape[0]), (a, b)), shape=(nf, nf))
+        _, label = connected_components(graph, directed=False)
+        size = np.bincount(label)
+        faces = faces[size[label] > min_component_faces]
+    used, inv = np.unique(faces.reshape(-1), return_inverse=True)
+    return verts[used], inv.reshape(-1, 3).astype(np.int64)

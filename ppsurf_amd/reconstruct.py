@@ -1,0 +1,162 @@
+"""Iso-surface driver around the HIP decoder: region-growing volume, Marching Cubes, vertex refinement.
+
+Mirrors source/poco_utils.py:26-254 `export_mesh_and_refine_vertices_region_growing_v3` / `_create_volume`:
+same grid geometry (scalar min/max of the cloud, step = (max-min)/(R-1), padding 1), same +-2 dilation band, same frontier
+rule, same float64 volume with NaN = unseen and `out_value` borders, same 10 bisection rounds.
+
+What is different by design (MI355X-first):
+  * the cloud, the latent table, the query lists and the volume live on the GPU; per chunk there is no host round trip
+    (the reference goes device -> host -> device for the kd-tree and the patches, poco_utils.py:67-72,261-273);
+  * one 64-NN search per chunk serves both the interpolation ids and the 50-NN patches (same cloud in predict:
+    source/occupancy_data_module.py:227-253, manifold_points=None);
+  * dilation is a separable max-filter on the device instead of a Python loop over points;
+  * already evaluated voxels of the band are NOT re-evaluated in later growth rounds (the reference re-evaluates them,
+    `volume[mask] = z`, poco_utils.py:232); the decoder is deterministic, so the volume is identical.
+"""
+import typing
+
+import numpy as np
+import torch
+
+from . import ops, mcubes
+
+
+def _dilate(mask: torch.Tensor, r: int) -> torch.Tensor:
+    """Binary dilation with a (2r+1)^3 box, clipped at the volume border (poco_utils.py:181-196)."""
+    m = mask[None, None].float()
+    m = torch.nn.functional.max_pool3d(m, kernel_size=2 * r + 1, stride=1, padding=r)
+    return m[0, 0] > 0
+
+
+class OccupancyField:
+    """occ(q) for arbitrary query points of ONE shape: kNN + patches + decoder on the GPU, chunked by rec_batch_size."""
+
+    def __init__(self, network, latent: dict, pts_raw_ms: torch.Tensor, num_pts: int, num_pts_local: typing.Optional[int]):
+        self.net = network
+        pts = latent['pts']
+        pts = pts if pts.shape[1] == 3 else pts.transpose(1, 2)
+        self.dev = pts.device
+        self.pts = pts[0].t().contiguous().float()                        # [N,3]
+        self.raw = pts_raw_ms[0].to(self.dev).contiguous().float() if pts_raw_ms is not None else self.pts
+        self.same_cloud = self.raw.shape == self.pts.shape and bool(torch.equal(self.raw, self.pts))
+        self.plan = network.decoder_plan(self.dev)
+        self.table = network.point_table(latent['latents'][0], self.plan)
+        self.k = min(network.projection.k, self.pts.shape[0])
+        self.p = num_pts_local
+        self.chunk = int(num_pts)
+        self.n_queries = 0
+
+    @torch.no_grad()
+    def __call__(self, queries: torch.Tensor) -> torch.Tensor:
+        """queries [q,3] float32 on the device -> occ [q] float32 (= softmax(logits)[0] - softmax(logits)[1])."""
+        out = []
+        for s in range(0, queries.shape[0], self.chunk):
+            q = queries[s:s + self.chunk].contiguous()
+            idx = ops.knn_point_major(self.pts, q, self.k)
+            if self.same_cloud and self.p <= self.k:
+                patches = ops.patch_normalize(self.raw, q, idx, self.p)     # the P nearest are a prefix of the k nearest
+            else:
+                patches = ops.patch_normalize(self.raw, q, ops.knn_point_major(self.raw, q, self.p), self.p)
+            _, occ = self.plan.decode(self.table, self.pts, q, idx, patches, want_occ=True)
+            out.append(occ)
+            self.n_queries += q.shape[0]
+        return torch.cat(out) if out else torch.empty((0,), device=self.dev)
+
+
+def create_volume(field, pts_ids: torch.Tensor, resolution: int, step: float, bmin_pad: float, padding=1, dilation_size=2,
+                  out_value=1.0, progress=None):
+    """Region growing (poco_utils.py:178-254).  pts_ids int64 [n,3] voxel ids of the input points (device).
+    Returns the float64 volume (device) with NaN = never evaluated."""
+    dev = pts_ids.device
+    n = resolution + 2 * padding
+    volume = torch.full((n, n, n), float('nan'), dtype=torch.float64, device=dev)
+    to_see = torch.ones((n, n, n), dtype=torch.bool, device=dev)
+    it = 0
+    while pts_ids.shape[0] > 0:
+        seeds = torch.zeros((n, n, n), dtype=torch.bool, device=dev)
+        seeds[pts_ids[:, 0], pts_ids[:, 1], pts_ids[:, 2]] = True
+        band = _dilate(seeds, dilation_size)
+        todo = band & torch.isnan(volume)                                  # skip voxels already evaluated
+        coords = torch.nonzero(todo)
+        if coords.shape[0] > 0:
+            q = coords.to(torch.float32) * np.float32(step) + np.float32(bmin_pad)      # :212-213 (float32 arithmetic)
+            volume[todo] = field(q).to(torch.float64)
+        to_see[pts_ids[:, 0], pts_ids[:, 1], pts_ids[:, 2]] = False
+        v = volume[pts_ids[:, 0], pts_ids[:, 1], pts_ids[:, 2]]
+        neg_seeds = torch.zeros_like(seeds)
+        pos_seeds = torch.zeros_like(seeds)
+        s = pts_ids[v <= 0]
+        neg_seeds[s[:, 0], s[:, 1], s[:, 2]] = True
+        s = pts_ids[v >= 0]
+        pos_seeds[s[:, 0], s[:, 1], s[:, 2]] = True
+        new_mask = (_dilate(neg_seeds, dilation_size) & (volume >= 0) & to_see) | (_dilate(pos_seeds, dilation_size) & (volume <= 0) & to_see)
+        pts_ids = torch.nonzero(new_mask)
+        it += 1
+        if progress is not None:
+            progress('occ_batch round {}'.format(it))
+    p = padding
+    volume[:p] = out_value; volume[-p:] = out_value
+    volume[:, :p] = out_value; volume[:, -p:] = out_value
+    volume[:, :, :p] = out_value; volume[:, :, -p:] = out_value
+    return volume
+
+
+def export_mesh_and_refine_vertices_region_growing_v3(network, latent: dict, pts_raw_ms, resolution: int, padding=0, mc_value=0,
+                                                      num_pts=50000, num_pts_local=None, refine_iter=10, input_points=None,
+                                                      out_value=np.nan, dilation_size=2, prog_bar=None, pc_file_in: str = 'unknown'):
+    """poco_utils.py:26-175.  Returns (vertices float32 [V,3], faces int64 [F,3]) in model space, or None when the occupancy
+    never crosses `mc_value`.  (The reference wraps the same arrays into a trimesh.Trimesh; ppsurf_amd.meshio writes PLY.)"""
+    if latent['pts'].shape[0] != 1:
+        raise ValueError('Reconstruction must be done with batch size = 0!')     # message kept from poco_utils.py:50
+    if num_pts_local is None:
+        raise NotImplementedError('the HIP decoder is the PPSurf decoder: num_pts_local is required')
+    progress = None
+    if prog_bar is not None and getattr(prog_bar, 'predict_progress_bar', None) is not None:
+        progress = lambda s: prog_bar.predict_progress_bar.set_postfix_str('{}, {}'.format(pc_file_in[-24:], s), refresh=True)
+    field = OccupancyField(network, latent, pts_raw_ms, num_pts, num_pts_local)
+    dev = field.dev
+    input_points = np.asarray(input_points)
+    bmin, bmax = input_points.min(), input_points.max()
+    step = (bmax - bmin) / (resolution - 1)
+    bmin_pad = bmin - padding * step
+    pts_ids = torch.from_numpy(((input_points - bmin) / step + padding).astype(np.int32).astype(np.int64)).to(dev)
+    volume = create_volume(field, pts_ids, resolution, step, bmin_pad, padding, dilation_size, out_value, progress)
+
+    seen = volume[~torch.isnan(volume)]
+    if not (float(seen.max()) > mc_value > float(seen.min())):
+        return None
+    vol_np = volume.cpu().numpy()
+    verts, faces = mcubes.marching_cubes(vol_np, mc_value)
+    verts, faces = mcubes.clean_mesh(verts, faces, min_component_faces=6)
+    if refine_iter > 0 and verts.shape[0] > 0:
+        frac = ((verts - np.floor(verts)) > 0).astype(verts.dtype)
+        mask = np.logical_and(frac.sum(axis=1) > 0, frac.sum(axis=1) < 2)
+        v = verts[mask]
+        v1i = np.floor(v).astype(int)
+        v2i = (np.floor(v) + frac[mask]).astype(int)
+        p1 = vol_np[v1i[:, 0], v1i[:, 1], v1i[:, 2]]
+        p2 = vol_np[v2i[:, 0], v2i[:, 1], v2i[:, 2]]
+        v1 = v1i.astype(np.float32) * step + bmin_pad
+        v2 = v2i.astype(np.float32) * step + bmin_pad
+        ok = ~np.isnan(p1) & ~np.isnan(p2)
+        v, v1, v2, p1, p2 = v[ok], v1[ok], v2[ok], p1[ok], p2[ok]
+        mask[mask] = ok
+        verts = verts * step + bmin_pad
+        v = v * step + bmin_pad
+        v_d = torch.from_numpy(v).to(dev, torch.float32)
+        v1_d, v2_d = torch.from_numpy(v1).to(dev, torch.float32), torch.from_numpy(v2).to(dev, torch.float32)
+        p1_d, p2_d = torch.from_numpy(p1).to(dev), torch.from_numpy(p2).to(dev)
+        for it in range(refine_iter):                                       # bisection on the device (poco_utils.py:146-165)
+            pr = field(v_d).to(torch.float64)
+            m1 = (pr * p1_d) > 0
+            v1_d[m1] = v_d[m1]; p1_d[m1] = pr[m1]
+            m2 = (pr * p2_d) > 0
+            v2_d[m2] = v_d[m2]; p2_d[m2] = pr[m2]
+            v_d = (v2_d + v1_d) / 2
+            if progress is not None:
+                progress('refine iter {}'.format(it))
+        verts[mask] = v_d.cpu().numpy()
+    else:
+        verts = verts * step + bmin_pad
+    verts, faces = mcubes.clean_mesh(verts, faces, min_component_faces=6)
+    return verts.astype(np.float32), faces

@@ -1,0 +1,169 @@
+"""Spatial queries and neighbourhood assembly on the GPU, behind the reference's free-function API.
+
+  knn                -> source/poco_utils.py:257-273            (CPU kd-tree per call in the reference)
+  sampling_quantized -> source/poco_data_loader.py:59-134      (torch_geometric voxel_grid + consecutive_cluster)
+  get_fkaconv_ids    -> source/poco_data_loader.py:137-209
+  get_proj_ids       -> source/poco_data_loader.py:212-240
+  get_data_poco      -> source/poco_data_loader.py:243-270
+  normalize_patches / get_pts_local_ps -> source/ppsurf_data_loader.py:91-123, source/poco_utils.py:67-72
+
+Tensors keep the reference's channel-first [B,3,N] layout at this boundary; the kernels work point-major.
+"""
+import math
+import random
+
+import torch
+
+from . import ops
+
+
+def _point_major(t):
+    """[3,N] (or [N,3] view) -> contiguous [N,3] float32."""
+    return t.transpose(0, 1).contiguous().float()
+
+
+def knn(points: torch.Tensor, support_points: torch.Tensor, k: int, workers: int = 1) -> torch.Tensor:
+    """points [B,3,N], support_points [B,3,M] -> int64 [B,M,k] on the device of `points`; k clamps to N
+    (poco_utils.py:259-260).  `workers` is accepted and ignored, as the reference ignores it for pykdtree."""
+    k = min(int(k), points.shape[2])
+    out = [ops.knn_point_major(_point_major(points[b]), _point_major(support_points[b]), k) for b in range(points.shape[0])]
+    return torch.stack(out, dim=0)
+
+
+def _rotation(axis: int) -> torch.Tensor:
+    """Random rotation about one axis by U(-180, 180) degrees (torch_geometric RandomRotate semantics, python `random`)."""
+    a = math.pi * random.uniform(-180.0, 180.0) / 180.0
+    s, c = math.sin(a), math.cos(a)
+    if axis == 0:
+        m = [[1, 0, 0], [0, c, s], [0, -s, c]]
+    elif axis == 1:
+        m = [[c, 0, -s], [0, 1, 0], [s, 0, c]]
+    else:
+        m = [[c, s, 0], [-s, c, 0], [0, 0, 1]]
+    return torch.tensor(m, dtype=torch.float32)
+
+
+def _one_per_voxel(pos: torch.Tensor, size: float) -> torch.Tensor:
+    """Index of one representative point per occupied voxel of edge `size` (grid anchored at the bbox minimum)."""
+    start = pos.min(dim=0)[0]
+    cell = torch.floor((pos - start) / size).to(torch.int64)
+    dims = cell.max(dim=0)[0] + 1
+    key = (cell[:, 2] * dims[1] + cell[:, 1]) * dims[0] + cell[:, 0]
+    skey, order = torch.sort(key, stable=True)
+    first = torch.ones_like(skey, dtype=torch.bool)
+    first[1:] = skey[1:] != skey[:-1]
+    return order[first]
+
+
+def sampling_quantized(pts_batch, ratio=None, n_support=None, support_points=None, support_points_ids=None):
+    """Voxel-stratified random sub-sampling to exactly max(1, int(N*ratio)) points (poco_data_loader.py:59-134):
+    voxel edge = bbox diagonal / sqrt(n), random 3-axis rotation, one point per occupied voxel, remove, halve, repeat;
+    the last round is truncated at random.  Stochastic (python `random`, torch RNG) like the reference."""
+    if support_points is not None:
+        return support_points, support_points_ids
+    assert (ratio is None) != (n_support is None)
+    b, _, n = pts_batch.shape
+    target = max(1, int(n * ratio)) if ratio is not None else n_support
+    if target == n:
+        ids = torch.arange(n, dtype=torch.long, device=pts_batch.device).unsqueeze(0).expand(b, n)
+        return pts_batch, ids
+    if not 0 < target < n:
+        raise ValueError('Search Quantized - ratio value error {} should be in ]0,1]'.format(ratio))
+    extent = pts_batch.max(dim=2)[0] - pts_batch.min(dim=2)[0]
+    vox0 = (extent.norm(2, dim=1) / math.sqrt(target)).tolist()
+    all_ids = []
+    for i in range(b):
+        pts = pts_batch[i].transpose(0, 1)
+        ids = torch.arange(pts.shape[0], device=pts.device)
+        vox, count, picked = vox0[i], 0, []
+        while True:
+            rot = (_rotation(2) @ _rotation(1) @ _rotation(0)).to(pts.device)
+            perm = _one_per_voxel(pts @ rot.t(), vox)
+            if count + perm.shape[0] < target:
+                picked.append(ids[perm])
+                count += perm.shape[0]
+                keep = torch.ones(ids.shape[0], dtype=torch.bool, device=pts.device)
+                keep[perm] = False
+                pts, ids = pts[keep], ids[keep]
+                vox = vox / 2
+            else:
+                sel = torch.randperm(perm.shape[0], device=pts.device)[:target - count]
+                picked.append(ids[perm[sel]])
+                break
+        all_ids.append(torch.cat(picked))
+    ids = torch.stack(all_ids, dim=0)
+    support = torch.gather(pts_batch, 2, ids.unsqueeze(1).expand(b, 3, ids.shape[1]))
+    return support, ids
+
+
+def get_fkaconv_ids(data, segmentation: bool = True):
+    """4 support levels (ratio 0.25) and the 13 kNN tables of poco_data_loader.py:137-209."""
+    pts = data['pts'].clone()
+    unbatched = pts.dim() == 2
+    if unbatched:
+        pts = pts.unsqueeze(0)
+    levels = [pts]
+    for _ in range(4):
+        levels.append(sampling_quantized(levels[-1], 0.25)[0])
+    ret = {}
+    squeeze = (lambda t: t.squeeze(0)) if unbatched else (lambda t: t)
+    for a in range(5):
+        ret['ids{}{}'.format(a, a)] = squeeze(knn(levels[a], levels[a], 16))
+        if a < 4:
+            ret['ids{}{}'.format(a, a + 1)] = squeeze(knn(levels[a], levels[a + 1], 16))
+            if segmentation:
+                ret['ids{}{}'.format(a + 1, a)] = squeeze(knn(levels[a + 1], levels[a], 1))
+    for a in range(1, 5):
+        ret['support{}'.format(a)] = squeeze(levels[a])
+    return ret
+
+
+def get_proj_ids(data, k: int):
+    """poco_data_loader.py:212-240: accepts [B,3,N] or [B,N,3], batched or not."""
+    pts, ptq = data['pts'], data['pts_query']
+    unb_p, unb_q = pts.dim() == 2, ptq.dim() == 2
+    if unb_p:
+        pts = pts.unsqueeze(0)
+    if unb_q:
+        ptq = ptq.unsqueeze(0)
+    if pts.shape[1] != 3:
+        pts = pts.transpose(1, 2)
+    if ptq.shape[1] != 3:
+        ptq = ptq.transpose(1, 2)
+    ids = knn(pts, ptq.to(pts.device), k, -1)
+    if unb_p or unb_q:
+        ids = ids.squeeze(0)
+    return {'proj_ids': ids}
+
+
+def get_data_poco(batch_data: dict):
+    """poco_data_loader.py:243-270 (k=64 is hard-coded there, :261)."""
+    fk = {'pts': torch.transpose(batch_data['pts_ms'], -1, -2), 'pts_query': torch.transpose(batch_data['pts_query_ms'], -1, -2)}
+    if 'imp_surf_dist_ms' in batch_data:
+        occ = torch.zeros_like(batch_data['imp_surf_dist_ms'], dtype=torch.int64)
+        occ[torch.sign(batch_data['imp_surf_dist_ms']) > 0.0] = 1
+        fk['occ'] = occ
+    else:
+        fk['occ'] = torch.zeros(fk['pts_query'].shape[:1])
+    with torch.no_grad():
+        net = get_fkaconv_ids(fk)
+        net['proj_ids'] = get_proj_ids(fk, k=64)['proj_ids']
+    batch_data.update(fk)
+    batch_data.update(net)
+    return batch_data
+
+
+def normalize_patches(pts_local_ms, pts_query_ms):
+    """ppsurf_data_loader.py:91-123 on device tensors: [Q,P,3], [Q,3] -> [Q,P,3]."""
+    q, p = pts_local_ms.shape[0], pts_local_ms.shape[1]
+    flat = pts_local_ms.reshape(q * p, 3).contiguous().float()
+    idx = torch.arange(q * p, dtype=torch.int64, device=flat.device).view(q, p)
+    return ops.patch_normalize(flat, pts_query_ms, idx, p)
+
+
+def get_pts_local_ps(pts_raw_ms, pts_query, num_pts_local, idx=None):
+    """poco_utils.py:67-72 on the GPU: P nearest raw points of each query, centred and scaled -> [Q,P,3].
+    `idx` may carry an already computed neighbour table whose first P columns are the P nearest (same cloud)."""
+    if idx is None:
+        idx = ops.knn_point_major(pts_raw_ms, pts_query, num_pts_local)
+    return ops.patch_normalize(pts_raw_ms, pts_query, idx, num_pts_local)

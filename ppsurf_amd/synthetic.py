@@ -18,6 +18,9 @@ _LINEAR_OUT = ('fc_query.weight', 'fc_value.weight', 'fc8.weight', 'point_net.co
                'mlp.layers.2.0.weight', 'MLP.layers.2.0.weight')
 
 
+_FKA_GAIN = 0.0015
+
+
 def _rng(name: str, salt: int = 0) -> np.random.Generator:
     return np.random.default_rng(zlib.crc32(name.encode()) + 7919 * salt)
 
@@ -46,6 +49,8 @@ def fill_param(name: str, shape, salt: int = 0) -> np.ndarray:
         gain = 2.0                                   # He: layers followed by a ReLU/SiLU keep O(1) activations
         if name.endswith('stn2.fc3.weight'):
             gain = 0.005                             # feature transform stays near identity (as trained STNs do)
+        elif name.endswith('.cv.weight') and len(shape) == 4:
+            gain = _FKA_GAIN                         # FKAConv kernel: the 16 neighbour weights add up, keep the U-Net O(1)
         elif any(name.endswith(e) for e in _LINEAR_OUT):
             gain = 1.0
         return (rng.standard_normal(shape) * np.sqrt(gain / fan_in)).astype(np.float32)

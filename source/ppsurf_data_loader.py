@@ -1,0 +1,1 @@
+from ppsurf_amd.spatial import normalize_patches, get_pts_local_ps  # noqa: F401

@@ -1,0 +1,135 @@
+"""GPU end-to-end tests through the reference-shaped Python API (modules -> C ABI -> HIP)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import load_golden, filled_sd
+from oracle import ppsurf_oracle as O
+from ppsurf_amd.synthetic import make_cloud, make_latents
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+_net = None
+
+
+def network():
+    global _net
+    if _net is None:
+        from source.ppsurf_model import PPSurfNetwork
+        net = PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=50, pointnet_latent_size=256)
+        net.load_state_dict(filled_sd('', key='ppsurf'))
+        _net = net.to(DEV).eval()
+    return _net
+
+
+def test_knn_api_shapes_and_clamp():
+    from source.poco_utils import knn
+    g = load_golden('knn')
+    pts, qry = torch.from_numpy(g['pts']).to(DEV), torch.from_numpy(g['query']).to(DEV)
+    ids = knn(pts, qry, 16)
+    assert ids.dtype == torch.int64 and ids.device.type == 'cuda' and tuple(ids.shape) == (2, 90, 16)
+    assert np.array_equal(ids.cpu().numpy(), g['ids16'])
+    assert np.array_equal(knn(pts, qry, 1).cpu().numpy(), g['ids1'].reshape(2, 90, 1))
+    assert np.array_equal(knn(pts[:, :, :9], qry, 16).cpu().numpy(), g['ids_clamp'])       # k clamps to N
+
+
+def test_from_latent_api_matches_reference_golden():
+    g = load_golden('ppsurf_from_latent')
+    net = network()
+    data = {'latents': torch.from_numpy(make_latents(256, g['cloud'].shape[0], 77)).to(DEV),
+            'pts': torch.from_numpy(g['cloud'].T.copy()).unsqueeze(0).to(DEV),
+            'pts_query': torch.from_numpy(g['query']).unsqueeze(0),                          # [B,Q,3] on the CPU like the MC driver
+            'pts_local_ps': torch.from_numpy(g['patches']).unsqueeze(0).to(DEV)}
+    out = net.from_latent(data)
+    assert tuple(out.shape) == (1, 2, 96)
+    np.testing.assert_allclose(out.cpu().numpy(), g['logits'], rtol=0, atol=1e-4)
+    assert np.array_equal(data['proj_ids'].cpu().numpy(), g['proj_ids'])                     # side effect kept (ppsurf_model.py:83)
+    data['pts_query'] = data['pts_query'].transpose(1, 2).contiguous()                       # [B,3,Q] is accepted as well
+    np.testing.assert_allclose(net.from_latent(data).cpu().numpy(), g['logits'], rtol=0, atol=1e-4)
+
+
+def test_forward_with_precomputed_ids_vs_oracle():
+    """network.forward (encoder spectral_only=True + from_latent) on a fit-shaped batch item vs the oracle."""
+    net = network()
+    sd = filled_sd('', key='ppsurf')
+    rng = np.random.default_rng(3)
+    cloud = make_cloud(1200, seed=4)
+    pts = torch.from_numpy(cloud.T.copy()).unsqueeze(0)
+    sups, cur = [], pts
+    for _ in range(4):
+        sel = torch.from_numpy(np.sort(rng.choice(cur.shape[2], max(1, int(cur.shape[2] * 0.25)), replace=False)))
+        cur = cur[:, :, sel].contiguous()
+        sups.append(cur)
+    data = {'pts': pts}
+    data.update(O.fkaconv_ids_from_supports(pts, sups))
+    qry = (cloud[rng.choice(1200, 150)] + rng.normal(0, 0.01, (150, 3))).astype(np.float32)
+    patches = O.get_pts_local_ps(cloud, qry, 50)
+    data['pts_query'] = torch.from_numpy(qry.T.copy()).unsqueeze(0)
+    data['pts_local_ps'] = torch.from_numpy(patches).unsqueeze(0)
+    ref_lat = O.fkaconv_network(sd, 'encoder', data, act='silu', fixed=True)
+    ref = O.ppsurf_from_latent(sd, dict(data, latents=ref_lat), k=64)
+    gdata = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in data.items()}
+    out = net.forward(gdata)
+    np.testing.assert_allclose(gdata['latents'].cpu().numpy(), ref_lat.numpy(), rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-4)
+
+
+def test_get_latent_builds_neighbourhoods_on_device():
+    net = network()
+    torch.manual_seed(0)
+    cloud = make_cloud(2000, seed=6)
+    data = net.get_latent({'pts': torch.from_numpy(cloud.T.copy()).unsqueeze(0).to(DEV)})
+    assert tuple(data['latents'].shape) == (1, 256, 2000) and data['proj_correction'] is None
+    assert tuple(data['support1'].shape) == (1, 3, 500) and tuple(data['support4'].shape) == (1, 3, 7)
+    assert tuple(data['ids00'].shape) == (1, 2000, 16) and tuple(data['ids44'].shape) == (1, 7, 7) and tuple(data['ids10'].shape) == (1, 2000, 1)
+    # the id tables are exact kNN of the sampled levels
+    ref = O.knn(data['pts'].cpu(), data['support1'].cpu(), 16)
+    assert torch.equal(data['ids01'].cpu(), ref)
+    assert torch.isfinite(data['latents']).all()
+
+
+def test_reconstruction_volume_matches_oracle_driver_and_writes_ply(tmp_path):
+    """predict_step on a small cloud (R=17): the GPU region-growing volume equals the reference driver's volume when
+    the latter is fed by the oracle network on the SAME latents; a PLY mesh is written."""
+    from source.ppsurf_model import PPSurfModel
+    from ppsurf_amd import reconstruct, meshio
+    torch.manual_seed(1)
+    np.save(str(tmp_path / 'cloud.npy'), make_cloud(700, seed=12))
+    model = PPSurfModel(pointnet_latent_size=256, output_names=['imp_surf_sign'], in_channels=3, out_channels=2, k=64, lambda_l1=0.0,
+                        debug=False, in_file=str(tmp_path / 'cloud.npy'), results_dir=str(tmp_path / 'res'), padding_factor=0.05,
+                        name='t', network_latent_size=256, gen_subsample_manifold_iter=2, gen_subsample_manifold=10000,
+                        gen_resolution_global=17, num_pts_local=50, rec_batch_size=3000, gen_refine_iter=2, workers=1)
+    model.network.load_state_dict(filled_sd('', key='ppsurf'))
+    model = model.to(DEV).eval()
+    cloud = make_cloud(700, seed=12)
+    batch = {'pts_ms': torch.from_numpy(cloud).unsqueeze(0), 'pts_raw_ms': torch.from_numpy(cloud).unsqueeze(0),
+             'pc_file_in': [str(tmp_path / 'cloud.npy')]}
+    # volume parity on fixed latents
+    pts_cf = torch.from_numpy(cloud.T.copy()).to(DEV)
+    lat = model.encode_latents(pts_cf)                                   # [N,256] point-major
+    shape = {'pts': pts_cf.unsqueeze(0), 'latents': lat.t().unsqueeze(0)}
+    field = reconstruct.OccupancyField(model.network, shape, batch['pts_raw_ms'], 3000, 50)
+    bmin, bmax = cloud.min(), cloud.max()
+    step = (bmax - bmin) / 16
+    ids = ((cloud - bmin) / step + 1).astype(np.int32)
+    vol = reconstruct.create_volume(field, torch.from_numpy(ids.astype(np.int64)).to(DEV), 17, step, bmin - step).cpu().numpy()
+    sd = filled_sd('', key='ppsurf')
+    lat_cf = lat.t().unsqueeze(0).cpu()
+
+    def oracle_occ(q):
+        data = {'latents': lat_cf, 'pts': torch.from_numpy(cloud.T.copy()).unsqueeze(0), 'pts_query': torch.from_numpy(q).unsqueeze(0),
+                'pts_local_ps': torch.from_numpy(O.get_pts_local_ps(cloud, q, 50)).unsqueeze(0)}
+        return O.predict_from_latent(O.ppsurf_from_latent(sd, data, k=64)).numpy()
+
+    ref, n_eval = O.create_volume(oracle_occ, ids, 17, step, bmin - step, 3000)
+    assert np.array_equal(np.isnan(vol), np.isnan(ref))
+    np.testing.assert_allclose(np.nan_to_num(vol, nan=7.0), np.nan_to_num(ref, nan=7.0), rtol=0, atol=1e-4)
+    assert field.n_queries <= n_eval                                     # no voxel is decoded twice on the GPU path
+    # the Lightning hook end to end
+    assert model.predict_step(batch, 0) == 0
+    out = os.path.join(str(tmp_path / 'res'), 'cloud.npy', 'cloud.npy.ply')
+    if model.last_prediction is not None:
+        v = meshio.read_ply_vertices(out)
+        assert v.shape[0] == model.last_prediction[0].shape[0] and np.isfinite(v).all()
