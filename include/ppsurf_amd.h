@@ -107,16 +107,23 @@ int pps_decode_tail_f32(const float* pooled, const float* xbar, int64_t q, const
 /* number of floats of the packed small parameters of one FKAConv layer:
  * [norm_radius, alpha, beta, act(1 relu | 2 silu), fc1[16][3], fc2[16][32], fc3[16][32], bn1.w[16], bn1.b[16], bn2.w[16], bn2.b[16]] */
 size_t pps_fkaconv_geo_floats(void);
-/* bytes of workspace for a layer with m support points (per-block partial InstanceNorm statistics, double) */
-size_t pps_fkaconv_ws_bytes(int64_t m);
+/* bytes of workspace for a layer with m support points and cin input channels
+ * (per-block partial InstanceNorm statistics in double + the aggregated features F [m, cin*16]) */
+size_t pps_fkaconv_ws_bytes(int64_t m, int cin);
 
 /* One FKAConv layer.   replaces: source/base/nn.py:592-652 `FKAConvLayer.forward` (eval: norm_radius fixed).
  * x [n,cin], pts [n,3], sup [m,3], idx int64 [m,k] (k <= 16; InstanceNorms skipped when k == 1, nn.py:627-638);
- * wt [cin*16, cout]: cv.weight[o,c,0,t] stored at wt[(c*16+t)*cout + o] (a following BatchNorm may be folded in);
- * bias [cout] or NULL; act_out 0 none | 1 ReLU; out [m,cout]; ws: pps_fkaconv_ws_bytes(m) bytes. */
+ * wpack: pps_pack_dense_f32 image of W [cout, cin*16] with W[o][c*16+t] = cv.weight[o,c,0,t] (a following BatchNorm may be
+ * folded in); bias [cout] or NULL; act_out 0 none | 1 ReLU; out [m,cout]; ws: pps_fkaconv_ws_bytes(m, cin) bytes. */
 int pps_fkaconv_fwd_f32(const float* x, const float* pts, const float* sup, const int64_t* idx, int64_t n, int64_t m, int k,
-                        int cin, int cout, const float* geo, const float* wt, const float* bias, int act_out, float* out,
+                        int cin, int cout, const float* geo, const float* wpack, const float* bias, int act_out, float* out,
                         void* ws, void* stream);
+
+/* Same contract as pps_rows_linear_f32 on the fp32 matrix cores; needs c1 % 16 == 0 and c2 % 16 == 0.
+ * wpack: pps_pack_dense_f32 image of W [cout, c1+c2]. */
+int pps_rows_gemm_f32(const float* in1, const int64_t* idx1, int c1, const float* in2, const int64_t* idx2, int c2,
+                      const float* wpack, const float* bias, const float* residual, int act, int64_t m, int cout, float* out,
+                      void* stream);
 
 /* out[m,o] = act(bias[o] + sum_c A[m,c] wt[c,o] + residual[m,o]),  A[m] = [in1[idx1[m]] (c1) | in2[idx2[m]] (c2)].
  * replaces: Conv1d(k=1) + BatchNorm1d (folded) + ReLU, torch.cat, nearest-neighbour `interpolate` (nn.py:684-697, K=1)

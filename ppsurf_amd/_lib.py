@@ -28,9 +28,10 @@ SIGNATURES = {
     'pps_pointnet_feat_rows_f32': (_I, [_P, _P, _I64, _I, _P, _P, _P, _P]),
     'pps_decode_tail_f32': (_I, [_P, _P, _I64, _P, _P, _P, _P, _P]),
     'pps_fkaconv_geo_floats': (_SZ, []),
-    'pps_fkaconv_ws_bytes': (_SZ, [_I64]),
+    'pps_fkaconv_ws_bytes': (_SZ, [_I64, _I]),
     'pps_fkaconv_fwd_f32': (_I, [_P, _P, _P, _P, _I64, _I64, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),
     'pps_rows_linear_f32': (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I64, _I, _P, _P]),
+    'pps_rows_gemm_f32': (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I64, _I, _P, _P]),
     'pps_gather_max_f32': (_I, [_P, _P, _I64, _I, _I, _P, _P]),
 }
 

@@ -151,23 +151,20 @@ __global__ __launch_bounds__(FK_NT) void fka_stats_kernel(const float* __restric
     block_stats(v, g.valid, part_out, red);
 }
 
-// phase 3 + feature aggregation + (1,16) convolution.  wt [Cin*16][Cout] (k = c*16 + t), out [M][Cout].
-__global__ __launch_bounds__(FK_NT) void fka_conv_kernel(const float* __restrict__ x, const float* __restrict__ pts,
+// phase 3 + feature aggregation: F[m][c*16 + t] = sum_j x[idx[m][j]][c] * m3[m][j][t]   (nn.py:643-649)
+// The (1,16) convolution that follows (nn.py:650) is the dense product F[M, Cin*16] x W^T, done by rows_gemm_kernel.
+__global__ __launch_bounds__(FK_NT) void fka_feat_kernel(const float* __restrict__ x, const float* __restrict__ pts,
                                                          const float* __restrict__ sup, const int64_t* __restrict__ idx, int64_t M, int K,
-                                                         int Cin, int Cout, const float* __restrict__ geo_g,
-                                                         const double* __restrict__ part1, const double* __restrict__ part2,
-                                                         const float* __restrict__ wt, const float* __restrict__ bias, int act_out,
-                                                         float* __restrict__ out) {
+                                                         int Cin, const float* __restrict__ geo_g, const double* __restrict__ part1,
+                                                         const double* __restrict__ part2, float* __restrict__ F) {
     __shared__ float geo[GEO_FLOATS];
     __shared__ float stat1[32], stat2[32];
     __shared__ float m3[FK_TM][16][17];          // [m][j][t], padded
     __shared__ int nb[FK_TM][16];                // neighbour row (or -1)
-    __shared__ float F[FK_TM][16 * 16 + 1];      // feature chunk: 16 channels x 16 t per support point
     for (int i = threadIdx.x; i < GEO_FLOATS; i += FK_NT) geo[i] = geo_g[i];
     finish_stats(part1, gridDim.x, (double)M * K, stat1);
     if (threadIdx.x >= 64 && threadIdx.x < 80) {
-        // second statistic by another wave (same fixed order)
-        const int t = threadIdx.x - 64;
+        const int t = threadIdx.x - 64;          // second statistic by another wave (same fixed order)
         double s = 0.0, q = 0.0;
         for (int b = 0; b < (int)gridDim.x; ++b) { s += part2[(int64_t)b * 32 + 2 * t]; q += part2[(int64_t)b * 32 + 2 * t + 1]; }
         const double cnt = (double)M * K, mean = s / cnt;
@@ -194,59 +191,78 @@ __global__ __launch_bounds__(FK_NT) void fka_conv_kernel(const float* __restrict
         nb[ml][j] = g.valid ? (int)idx[m * K + j] : -1;
     }
     __syncthreads();
-
-    // output ownership: thread -> (output o, group of support points)
-    const int OT = Cout < FK_NT ? Cout : FK_NT;                     // threads along the output axis
-    const int MG = (FK_NT / OT) < FK_TM ? (FK_NT / OT) : FK_TM;     // support-point groups
-    const int mper = (FK_TM + MG - 1) / MG;                         // support points per thread
-    const int og = threadIdx.x % OT, mg = threadIdx.x / OT;
-    const bool active = mg < MG && mg * mper < FK_TM;
-    for (int o0 = 0; o0 < Cout; o0 += FK_NT) {
-        const int o = o0 + og;
-        float acc[FK_TM];
+    // thread = (support point mm, channel lane cl); 16 consecutive channels per pass -> coalesced x reads, 64 B F writes
+    const int cl = threadIdx.x & 15, mm = threadIdx.x >> 4;
+    if (m0 + mm >= M) return;
+    float* frow = F + (m0 + mm) * (int64_t)Cin * 16;
+    for (int c = cl; c < Cin; c += 16) {
+        float f[16];
 #pragma unroll
-        for (int i = 0; i < FK_TM; ++i) acc[i] = 0.f;
-        for (int c0 = 0; c0 < Cin; c0 += 16) {
-            __syncthreads();
-            // F[m][cl*16 + t] = sum_j x[nb[m][j]][c0+cl] * m3[m][j][t]   (thread = (m, cl))
-            {
-                const int cl = threadIdx.x & 15, mm = threadIdx.x >> 4;
-                float f[16];
+        for (int t = 0; t < 16; ++t) f[t] = 0.f;
+        for (int jj = 0; jj < K; ++jj) {
+            const int r = nb[mm][jj];
+            if (r >= 0) {
+                const float xv = x[(int64_t)r * Cin + c];
 #pragma unroll
-                for (int t = 0; t < 16; ++t) f[t] = 0.f;
-                if (c0 + cl < Cin) {
-                    for (int jj = 0; jj < K; ++jj) {
-                        const int r = nb[mm][jj];
-                        if (r >= 0) {
-                            const float xv = x[(int64_t)r * Cin + c0 + cl];
-#pragma unroll
-                            for (int t = 0; t < 16; ++t) f[t] += xv * m3[mm][jj][t];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < 16; ++t) F[mm][cl * 16 + t] = f[t];
-            }
-            __syncthreads();
-            if (active && o < Cout) {
-                const int kmax = (Cin - c0 < 16 ? Cin - c0 : 16) * 16;
-                const float* wrow = wt + (int64_t)c0 * 16 * Cout + o;
-                for (int k = 0; k < kmax; ++k) {
-                    const float w = wrow[(int64_t)k * Cout];
-#pragma unroll
-                    for (int i = 0; i < FK_TM; ++i)
-                        if (i < mper && mg * mper + i < FK_TM) acc[i] += w * F[mg * mper + i][k];
-                }
+                for (int t = 0; t < 16; ++t) f[t] += xv * m3[mm][jj][t];
             }
         }
-        if (active && o < Cout) {
-            for (int i = 0; i < mper && mg * mper + i < FK_TM; ++i) {
-                const int64_t m = m0 + mg * mper + i;
-                if (m < M) {
-                    float v = acc[i] + (bias ? bias[o] : 0.f);
-                    if (act_out == 1) v = fmaxf(v, 0.f);
-                    out[m * Cout + o] = v;
-                }
+        f32x4* dst = (f32x4*)(frow + (int64_t)c * 16);
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) dst[t4] = f32x4{f[4 * t4], f[4 * t4 + 1], f[4 * t4 + 2], f[4 * t4 + 3]};
+    }
+}
+
+// out[m][o] = act(bias[o] + sum_k A[m][k] W[o][k] + residual[m][o]),  A[m] = [in1[idx1[m]] (c1) | in2[idx2[m]] (c2)], c1, c2 % 16 == 0.
+// fp32 MFMA (v_mfma_f32_16x16x4_f32): one wave = 16 rows x (16*NOB) outputs, both operands straight from global/L2:
+// A fragments from the packed weight image (pps_pack_dense_f32, 1 KiB contiguous per wave load), B fragments as one
+// float4 of the (gathered) input row per lane.  grid = (row tiles of 64, output tiles of 16*NOB).
+template <int NOB>
+__global__ __launch_bounds__(256) void rows_gemm_kernel(const float* __restrict__ in1, const int64_t* __restrict__ idx1, int C1,
+                                                        const float* __restrict__ in2, const int64_t* __restrict__ idx2, int C2,
+                                                        const f32x4* __restrict__ wpack, const float* __restrict__ bias,
+                                                        const float* __restrict__ residual, int act, int64_t M, int N,
+                                                        float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * 16 + n;
+    const int64_t rc = row < M ? row : M - 1;
+    const int64_t r1 = idx1 ? idx1[rc] : rc;
+    const int64_t r2 = in2 ? (idx2 ? idx2[rc] : rc) : 0;
+    const int KB1 = C1 >> 4, KB = (C1 + C2) >> 4;
+    const int ob0 = blockIdx.y * NOB;
+    const f32x4* a1 = (const f32x4*)(in1 + r1 * C1) + g;
+    const f32x4* a2 = in2 ? (const f32x4*)(in2 + r2 * C2) + g : a1;
+    f32x4 acc[NOB];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        const int o = 16 * (ob0 + ob) + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ob][r] = (bias && o + r < N) ? bias[o + r] : 0.f;
+    }
+    const f32x4* w = wpack + (int64_t)ob0 * KB * 64 + lane;
+#pragma unroll 4
+    for (int kb = 0; kb < KB; ++kb) {
+        const f32x4 b = kb < KB1 ? a1[4 * kb] : a2[4 * (kb - KB1)];
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+            const f32x4 a = w[((int64_t)ob * KB + kb) * 64];
+            acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[ob], 0, 0, 0);
+            acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[ob], 0, 0, 0);
+            acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[ob], 0, 0, 0);
+            acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[ob], 0, 0, 0);
+        }
+    }
+    if (row >= M) return;
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) {
+        const int o = 16 * (ob0 + ob) + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (o + r < N) {
+                float v = acc[ob][r];
+                if (residual) v += residual[row * N + o + r];
+                if (act == 1) v = fmaxf(v, 0.f);
+                out[row * N + o + r] = v;
             }
         }
     }
@@ -333,25 +349,49 @@ extern "C" {
 
 size_t pps_fkaconv_geo_floats(void) { return GEO_FLOATS; }
 
-size_t pps_fkaconv_ws_bytes(int64_t M) {
+size_t pps_fkaconv_ws_bytes(int64_t M, int cin) {
     const int64_t nblk = (M + FK_TM - 1) / FK_TM;
-    return (size_t)nblk * 32 * sizeof(double) * 2;
+    return (size_t)nblk * 32 * sizeof(double) * 2 + (size_t)M * cin * 16 * sizeof(float);
+}
+
+static int launch_rows_gemm(const float* in1, const int64_t* idx1, int c1, const float* in2, const int64_t* idx2, int c2,
+                            const float* wpack, const float* bias, const float* residual, int act, int64_t m, int n, float* out,
+                            hipStream_t st) {
+    const int obt = ((n + 31) / 32) * 2;                    // packed output blocks (out padded to 32)
+    const unsigned gx = (unsigned)((m + 63) / 64);
+    // few row tiles -> narrow output tiles so that the weight stream is spread over more CUs
+    if (gx * (obt / 4) >= 256 && obt % 4 == 0)
+        hipLaunchKernelGGL(rows_gemm_kernel<4>, dim3(gx, obt / 4), dim3(256), 0, st, in1, idx1, c1, in2, idx2, c2, (const f32x4*)wpack,
+                           bias, residual, act, m, n, out);
+    else
+        hipLaunchKernelGGL(rows_gemm_kernel<2>, dim3(gx, obt / 2), dim3(256), 0, st, in1, idx1, c1, in2, idx2, c2, (const f32x4*)wpack,
+                           bias, residual, act, m, n, out);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 
 int pps_fkaconv_fwd_f32(const float* x, const float* pts, const float* sup, const int64_t* idx, int64_t n, int64_t m, int k,
-                        int cin, int cout, const float* geo, const float* wt, const float* bias, int act_out, float* out,
+                        int cin, int cout, const float* geo, const float* wpack, const float* bias, int act_out, float* out,
                         void* ws, void* stream) {
-    if (!x || !pts || !sup || !idx || !geo || !wt || !out || !ws || n < 1 || m < 1 || k < 1 || k > 16 || cin < 1 || cout < 1)
+    if (!x || !pts || !sup || !idx || !geo || !wpack || !out || !ws || n < 1 || m < 1 || k < 1 || k > 16 || cin < 1 || cout < 1)
         return PPS_ERR_ARG;
     const int nblk = (int)((m + FK_TM - 1) / FK_TM);
     double* part1 = (double*)ws;
     double* part2 = part1 + (size_t)nblk * 32;
+    float* F = (float*)(part2 + (size_t)nblk * 32);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(fka_stats_kernel<1>, dim3(nblk), dim3(FK_NT), 0, st, pts, sup, idx, m, k, geo, (const double*)nullptr, part1);
     hipLaunchKernelGGL(fka_stats_kernel<2>, dim3(nblk), dim3(FK_NT), 0, st, pts, sup, idx, m, k, geo, (const double*)part1, part2);
-    hipLaunchKernelGGL(fka_conv_kernel, dim3(nblk), dim3(FK_NT), 0, st, x, pts, sup, idx, m, k, cin, cout, geo, (const double*)part1,
-                       (const double*)part2, wt, bias, act_out, out);
-    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+    hipLaunchKernelGGL(fka_feat_kernel, dim3(nblk), dim3(FK_NT), 0, st, x, pts, sup, idx, m, k, cin, geo, (const double*)part1,
+                       (const double*)part2, F);
+    if (hipGetLastError() != hipSuccess) return PPS_ERR_LAUNCH;
+    return launch_rows_gemm(F, nullptr, cin * 16, nullptr, nullptr, 0, wpack, bias, nullptr, act_out, m, cout, out, st);
+}
+
+int pps_rows_gemm_f32(const float* in1, const int64_t* idx1, int c1, const float* in2, const int64_t* idx2, int c2,
+                      const float* wpack, const float* bias, const float* residual, int act, int64_t m, int cout, float* out,
+                      void* stream) {
+    if (!in1 || !wpack || !out || m < 1 || c1 < 16 || (c1 & 15) || c2 < 0 || (c2 & 15) || cout < 1 || (c2 > 0 && !in2)) return PPS_ERR_ARG;
+    return launch_rows_gemm(in1, idx1, c1, c2 > 0 ? in2 : nullptr, idx2, c2, wpack, bias, residual, act, m, cout, out, (hipStream_t)stream);
 }
 
 int pps_rows_linear_f32(const float* in1, const int64_t* idx1, int c1, const float* in2, const int64_t* idx2, int c2,

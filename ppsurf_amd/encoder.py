@@ -34,11 +34,11 @@ class FKAConvParams:
     def __init__(self, sd, p, device, act, bn=None, relu_out=False):
         w = _np64(sd[p + '.cv.weight'])                       # [Cout, Cin, 1, 16]
         self.cout, self.cin = w.shape[0], w.shape[1]
-        wt = w[:, :, 0, :].transpose(1, 2, 0).reshape(self.cin * 16, self.cout)     # [(c,t), o]
+        wd = w[:, :, 0, :].reshape(self.cout, self.cin * 16)                      # W[o][c*16+t]
         bias = None
         if bn is not None:
             scale, shift = _bn_scale_shift(sd, bn)
-            wt = wt * scale[None, :]
+            wd = wd * scale[:, None]
             bias = shift
         geo = np.zeros(_lib.lib().pps_fkaconv_geo_floats(), dtype=np.float64)
         geo[0] = _np64(sd[p + '.norm_radius']).reshape(-1)[0]
@@ -53,7 +53,8 @@ class FKAConvParams:
             geo[o:o + n] = v
             o += n
         f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
-        self.geo, self.wt = f(geo), f(wt)
+        from .decoder import pack_dense
+        self.geo, self.wpack = f(geo), torch.from_numpy(pack_dense(wd)).to(device)
         self.bias = f(bias) if bias is not None else None
         self.act_out = 1 if relu_out else 0
 
@@ -63,9 +64,9 @@ class FKAConvParams:
         assert x.shape[1] == self.cin and x.is_contiguous() and pts.is_contiguous() and sup.is_contiguous() and idx.is_contiguous()
         L = _lib.lib()
         out = torch.empty((m, self.cout), dtype=torch.float32, device=x.device)
-        ws = torch.empty((L.pps_fkaconv_ws_bytes(m),), dtype=torch.uint8, device=x.device)
+        ws = torch.empty((L.pps_fkaconv_ws_bytes(m, self.cin),), dtype=torch.uint8, device=x.device)
         _lib.check(L.pps_fkaconv_fwd_f32(x.data_ptr(), pts.data_ptr(), sup.data_ptr(), idx.data_ptr(), n, m, k, self.cin, self.cout,
-                                         self.geo.data_ptr(), self.wt.data_ptr(), self.bias.data_ptr() if self.bias is not None else None,
+                                         self.geo.data_ptr(), self.wpack.data_ptr(), self.bias.data_ptr() if self.bias is not None else None,
                                          self.act_out, out.data_ptr(), ws.data_ptr(), _stream(x)), 'pps_fkaconv_fwd_f32')
         return out
 
@@ -82,8 +83,10 @@ class LinearParams:
             w = w * scale[:, None]
             b = b * scale + shift
         f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+        from .decoder import pack_dense
         self.cin, self.cout = w.shape[1], w.shape[0]
-        self.wt, self.bias = f(w.T), f(b)
+        self.wt, self.bias = f(w.T), f(b)                     # VALU kernel operand (any channel counts)
+        self.wpack = torch.from_numpy(pack_dense(w)).to(device)   # MFMA kernel operand (c1, c2 multiples of 16)
 
     def __call__(self, in1, idx1=None, in2=None, idx2=None, residual=None, relu=False, m=None):
         c1 = in1.shape[1]
@@ -93,9 +96,14 @@ class LinearParams:
             m = idx1.shape[0] if idx1 is not None else in1.shape[0]
         out = torch.empty((m, self.cout), dtype=torch.float32, device=in1.device)
         p = lambda t: t.data_ptr() if t is not None else None
-        _lib.check(_lib.lib().pps_rows_linear_f32(in1.data_ptr(), p(idx1), c1, p(in2), p(idx2), c2, self.wt.data_ptr(), self.bias.data_ptr(),
-                                                  p(residual), 1 if relu else 0, m, self.cout, out.data_ptr(), _stream(in1)),
-                   'pps_rows_linear_f32')
+        if c1 % 16 == 0 and c2 % 16 == 0:
+            _lib.check(_lib.lib().pps_rows_gemm_f32(in1.data_ptr(), p(idx1), c1, p(in2), p(idx2), c2, self.wpack.data_ptr(),
+                                                    self.bias.data_ptr(), p(residual), 1 if relu else 0, m, self.cout, out.data_ptr(),
+                                                    _stream(in1)), 'pps_rows_gemm_f32')
+        else:
+            _lib.check(_lib.lib().pps_rows_linear_f32(in1.data_ptr(), p(idx1), c1, p(in2), p(idx2), c2, self.wt.data_ptr(),
+                                                      self.bias.data_ptr(), p(residual), 1 if relu else 0, m, self.cout, out.data_ptr(),
+                                                      _stream(in1)), 'pps_rows_linear_f32')
         return out
 
 
