@@ -119,10 +119,8 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from ppsurf_amd import sharding
+    dt = sharding.max_over_ranks(dt, dev)
     assert bool(torch.isfinite(occ).all())
 
     if rank == 0:

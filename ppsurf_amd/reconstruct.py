@@ -18,7 +18,7 @@ import typing
 import numpy as np
 import torch
 
-from . import ops, mcubes
+from . import ops, mcubes, sharding
 
 
 def _dilate(mask: torch.Tensor, r: int) -> torch.Tensor:
@@ -80,7 +80,7 @@ def create_volume(field, pts_ids: torch.Tensor, resolution: int, step: float, bm
         coords = torch.nonzero(todo)
         if coords.shape[0] > 0:
             q = coords.to(torch.float32) * np.float32(step) + np.float32(bmin_pad)      # :212-213 (float32 arithmetic)
-            volume[todo] = field(q).to(torch.float64)
+            volume[todo] = sharding.sharded_map(field, q).to(torch.float64)    # query blocks sharded over the ranks, if any
         to_see[pts_ids[:, 0], pts_ids[:, 1], pts_ids[:, 2]] = False
         v = volume[pts_ids[:, 0], pts_ids[:, 1], pts_ids[:, 2]]
         neg_seeds = torch.zeros_like(seeds)

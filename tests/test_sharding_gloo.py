@@ -1,0 +1,57 @@
+"""N>1 path on CPU: 2 processes over gloo.  The sharded region growing must produce exactly the single-process volume
+(the reference driver's golden volume), and the helper collectives must agree across ranks."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from golden_util import REPO, load_golden
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ppsurf_amd import sharding
+    from ppsurf_amd.reconstruct import create_volume
+    g = load_golden('create_volume')
+    seen = []
+
+    def field(q):
+        seen.append(q.shape[0])
+        return (0.4 - torch.linalg.norm(q.double(), dim=1)).float()
+
+    vol = create_volume(field, torch.from_numpy(g['pts_ids'].astype(np.int64)), int(g['resolution']), float(g['step']),
+                        float(g['bmin_pad'])).numpy()
+    t = sharding.max_over_ranks(1.0 + rank, 'cpu')
+    lat = torch.full((5, 3), float(rank + 1))
+    cnt = torch.ones(5)
+    sharding.allreduce_latents(lat, cnt)
+    ids = torch.arange(11, dtype=torch.float32)
+    gathered = sharding.sharded_map(lambda x: x * 2, ids)
+    np.savez(os.path.join(out_dir, 'r{}.npz'.format(rank)), vol=vol, t=t, lat=lat.numpy(), cnt=cnt.numpy(), gathered=gathered.numpy(),
+             seen=np.array(seen).sum())
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_region_growing(tmp_path):
+    from ppsurf_amd.sharding import shard_range
+    assert [shard_range(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+    assert [shard_range(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
+    port = 29000 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    ref = load_golden('create_volume')['volume']
+    r0, r1 = np.load(tmp_path / 'r0.npz'), np.load(tmp_path / 'r1.npz')
+    for r in (r0, r1):
+        assert np.array_equal(np.isnan(r['vol']), np.isnan(ref))
+        np.testing.assert_allclose(np.nan_to_num(r['vol'], nan=7.0), np.nan_to_num(ref, nan=7.0), rtol=0, atol=2e-7)
+        assert r['t'] == 2.0 and (r['lat'] == 3.0).all() and (r['cnt'] == 2.0).all()
+        assert np.array_equal(r['gathered'], np.arange(11) * 2.0)
+    total = int((~np.isnan(ref[1:-1, 1:-1, 1:-1])).sum())
+    assert abs(int(r0['seen']) - int(r1['seen'])) <= 64 and int(r0['seen']) + int(r1['seen']) <= int((~np.isnan(ref)).sum())
