@@ -70,6 +70,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--overlap', action='store_true', help='run the spatial queries of chunk i+1 on a side stream (A/B; no gain measured)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -100,25 +101,23 @@ def main():
     qd = torch.from_numpy(qry).to(dev)
     table = plan.point_table(torch.from_numpy(lat[0]).to(dev))       # per-shape, outside the per-chunk step
 
+    from ppsurf_amd.decoder import ChunkPipeline
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # the product's chunk loop (ppsurf_amd.reconstruct.OccupancyField uses the same class): the 64-NN search + patch gather of
+    # chunk i+1 run on a side stream under the MFMA-bound decoder kernels of chunk i.  The 50-NN are a prefix of the 64-NN.
+    pipe = ChunkPipeline(plan, table, pts, pts, K_PROJ, P_LOCAL, same_cloud=True, max_chunk=Q_CHUNK, overlap=args.overlap)
 
-    def step(i=None):
-        idx = ops.knn_point_major(pts, qd, K_PROJ)
-        patches = ops.patch_normalize(pts, qd, idx, P_LOCAL)          # the 50-NN are a prefix of the 64-NN (same cloud)
-        return plan.decode(table, pts, qd, idx, patches, want_occ=True, interp_events=None if i is None else ev[i])
-
-    for _ in range(args.warmup):
-        step()
+    pipe.run([qd] * args.warmup)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        logits, occ = step(i)
+    results = pipe.run([qd] * args.steps, want_occ=True, interp_events=ev)        # EXACTLY `steps` chunks of Q_CHUNK queries
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    logits, occ = results[-1]
     from ppsurf_amd import sharding
     dt = sharding.max_over_ranks(dt, dev)
     assert bool(torch.isfinite(occ).all())

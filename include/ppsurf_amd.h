@@ -36,6 +36,14 @@ int pps_device_cu_count(void);                   /* multiProcessorCount of the c
 int pps_knn_f32(const float* pts, int64_t n, const float* query, int64_t m, int k,
                 int64_t* out_idx, float* out_d2, void* stream);
 
+/* Same search, same results (bit-identical indices and d2), over a cloud pre-arranged in blocks of 64 points with
+ * bounding boxes so that whole blocks are rejected against the running k-th distance (exact: the box bound is evaluated in
+ * the same rounding order as d2).  Built once per cloud by the caller (ppsurf_amd/ops.py `KnnBlocks`):
+ * pts_blocked [nb*64,3] (points in block order, tail padded), orig_idx int32 [nb*64] (original index, -1 for padding),
+ * bbox [nb,6] (min xyz, max xyz of the valid points of the block), n = number of valid points ((nb-1)*64 < n <= nb*64). */
+int pps_knn_blocked_f32(const float* pts_blocked, const int32_t* orig_idx, const float* bbox, int64_t nb, int64_t n,
+                        const float* query, int64_t m, int k, int64_t* out_idx, float* out_d2, void* stream);
+
 /* Gather P neighbours per query from the raw cloud, centre at the query, divide by the max neighbour distance.
  * replaces: source/poco_utils.py:67-72 `_get_pts_local_ps` (gather + normalise part) and
  *           source/ppsurf_data_loader.py:91-123 `normalize_patches/get_patch_radii/model_space_to_patch_space`.

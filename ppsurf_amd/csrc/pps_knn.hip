@@ -129,6 +129,108 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(const float* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Blocked variant: the same exhaustive search over a cloud that was reordered along a space-filling curve and cut into
+// blocks of 64 points with axis-aligned bounding boxes.  A block is skipped for a query when its box lower bound
+// near2 = ((gx*gx + gy*gy) + gz*gz)  (g = per-axis gap, evaluated with the SAME rounding order as d2, hence never above
+// the d2 of a point inside the box: rounding is monotonic) exceeds the current k-th distance tau.  tau starts from a box
+// UPPER bound: the farthest-corner distance of any full block bounds the k-th distance (k <= 64 points lie inside).
+// Results are bit-identical to knn_kernel: candidates are tested with d2 <= tau and ordered by the full (d2, original
+// index) key in the merge network.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(KNN_WAVES * 64) void knn_blocked_kernel(const float* __restrict__ pts, const int* __restrict__ orig,
+                                                                     const float* __restrict__ bbox, int nb, int nb_full,
+                                                                     const float* __restrict__ query, int64_t m, int k,
+                                                                     int64_t* __restrict__ out_idx, float* __restrict__ out_d2) {
+    __shared__ u64 cand_all[KNN_WAVES][KNN_QW][KNN_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t ntask = (m + KNN_QW - 1) / KNN_QW;
+    for (int64_t task = (int64_t)blockIdx.x * KNN_WAVES + wave; task < ntask; task += (int64_t)gridDim.x * KNN_WAVES) {
+        const int64_t q0 = task * KNN_QW;
+        float qx[KNN_QW], qy[KNN_QW], qz[KNN_QW], tau[KNN_QW];
+        u64 list[KNN_QW];
+        int cnt[KNN_QW];
+#pragma unroll
+        for (int j = 0; j < KNN_QW; ++j) {
+            const int64_t qq = (q0 + j < m) ? q0 + j : m - 1;
+            qx[j] = __shfl(query[qq * 3], 0); qy[j] = __shfl(query[qq * 3 + 1], 0); qz[j] = __shfl(query[qq * 3 + 2], 0);
+            tau[j] = INFINITY;
+            list[j] = ~0ull;
+            cnt[j] = 0;
+        }
+        // ---- initial tau: min over full blocks of the farthest-corner distance -------------------------------------
+        for (int b0 = 0; b0 < nb_full; b0 += 64) {
+            const int b = b0 + lane;
+            const bool bv = b < nb_full;
+            const float* bb = bbox + (int64_t)(bv ? b : 0) * 6;
+            const float lx = bb[0], ly = bb[1], lz = bb[2], hx = bb[3], hy = bb[4], hz = bb[5];
+#pragma unroll
+            for (int j = 0; j < KNN_QW; ++j) {
+                const float fx = fmaxf(fabsf(__fsub_rn(qx[j], lx)), fabsf(__fsub_rn(qx[j], hx)));
+                const float fy = fmaxf(fabsf(__fsub_rn(qy[j], ly)), fabsf(__fsub_rn(qy[j], hy)));
+                const float fz = fmaxf(fabsf(__fsub_rn(qz[j], lz)), fabsf(__fsub_rn(qz[j], hz)));
+                float far2 = bv ? __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz)) : INFINITY;
+#pragma unroll
+                for (int s = 32; s > 0; s >>= 1) far2 = fminf(far2, __shfl_xor(far2, s));
+                tau[j] = fminf(tau[j], far2);
+            }
+        }
+        // ---- scan: 64 boxes per culling step, surviving blocks point by point ---------------------------------------
+        for (int b0 = 0; b0 < nb; b0 += 64) {
+            const int b = b0 + lane;
+            const bool bv = b < nb;
+            const float* bb = bbox + (int64_t)(bv ? b : 0) * 6;
+            const float lx = bb[0], ly = bb[1], lz = bb[2], hx = bb[3], hy = bb[4], hz = bb[5];
+            u64 need[KNN_QW];
+            u64 any = 0ull;
+#pragma unroll
+            for (int j = 0; j < KNN_QW; ++j) {
+                const float gx = fmaxf(fmaxf(__fsub_rn(lx, qx[j]), __fsub_rn(qx[j], hx)), 0.f);
+                const float gy = fmaxf(fmaxf(__fsub_rn(ly, qy[j]), __fsub_rn(qy[j], hy)), 0.f);
+                const float gz = fmaxf(fmaxf(__fsub_rn(lz, qz[j]), __fsub_rn(qz[j], hz)), 0.f);
+                const float near2 = __fadd_rn(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)), __fmul_rn(gz, gz));
+                need[j] = __ballot(bv && near2 <= tau[j]);
+                any |= need[j];
+            }
+            while (any != 0ull) {
+                const int bit = __builtin_ctzll(any);
+                any &= any - 1ull;
+                const int p = (b0 + bit) * 64 + lane;
+                const float px = pts[3 * p], py = pts[3 * p + 1], pz = pts[3 * p + 2];
+                const int oi = orig[p];
+                const bool pv = oi >= 0;
+#pragma unroll
+                for (int j = 0; j < KNN_QW; ++j) {
+                    if (((need[j] >> bit) & 1ull) == 0ull) continue;
+                    const float dx = __fsub_rn(qx[j], px), dy = __fsub_rn(qy[j], py), dz = __fsub_rn(qz[j], pz);
+                    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                    const bool pass = pv && (d2 <= tau[j]);
+                    const u64 mask = __ballot(pass);
+                    if (mask != 0ull) {
+                        u64* cand = cand_all[wave][j];
+                        const int pos = cnt[j] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                        if (pass) cand[pos] = ((u64)__float_as_uint(d2) << 32) | (unsigned)oi;
+                        cnt[j] += __popcll(mask);
+                        if (cnt[j] > KNN_CAP - 64) {
+                            list[j] = knn_flush(list[j], cand, cnt[j], lane);
+                            cnt[j] = 0;
+                            tau[j] = fminf(tau[j], __uint_as_float((unsigned)(shfl_u64(list[j], k - 1) >> 32)));
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KNN_QW; ++j) {
+            list[j] = knn_flush(list[j], cand_all[wave][j], cnt[j], lane);
+            if (q0 + j < m && lane < k) {
+                out_idx[(q0 + j) * k + lane] = (int64_t)(unsigned)(list[j] & 0xffffffffull);
+                if (out_d2) out_d2[(q0 + j) * k + lane] = __uint_as_float((unsigned)(list[j] >> 32));
+            }
+        }
+    }
+}
+
 // one wave per query: lane j < P handles neighbour j
 __global__ __launch_bounds__(256) void patch_normalize_kernel(const float* __restrict__ raw, const float* __restrict__ query,
                                                               const int64_t* __restrict__ idx, int64_t idx_stride, int64_t Q, int P,
@@ -169,6 +271,21 @@ int pps_knn_f32(const float* pts, int64_t n, const float* query, int64_t m, int 
     if (blocks > (int64_t)cus * 8) blocks = (int64_t)cus * 8;
     hipLaunchKernelGGL(knn_kernel, dim3((unsigned)blocks), dim3(KNN_WAVES * 64), 0, (hipStream_t)stream, pts, (int)n, query, m, k,
                        out_idx, out_d2);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+int pps_knn_blocked_f32(const float* pts_blocked, const int32_t* orig_idx, const float* bbox, int64_t nb, int64_t n,
+                        const float* query, int64_t m, int k, int64_t* out_idx, float* out_d2, void* stream) {
+    if (n < 1 || nb < 1 || nb * 64 < n || (nb - 1) * 64 >= n || m < 0 || k < 1 || k > 64 || k > n || nb > 0x1ffffff) return PPS_ERR_ARG;
+    if (m == 0) return PPS_OK;
+    if (!pts_blocked || !orig_idx || !bbox || !query || !out_idx) return PPS_ERR_ARG;
+    const int64_t ntask = (m + KNN_QW - 1) / KNN_QW;
+    int64_t blocks = (ntask + KNN_WAVES - 1) / KNN_WAVES;
+    int cus = pps_device_cu_count();
+    if (cus <= 0) cus = 256;
+    if (blocks > (int64_t)cus * 8) blocks = (int64_t)cus * 8;
+    hipLaunchKernelGGL(knn_blocked_kernel, dim3((unsigned)blocks), dim3(KNN_WAVES * 64), 0, (hipStream_t)stream, pts_blocked, orig_idx,
+                       bbox, (int)nb, (int)(n / 64), query, m, k, out_idx, out_d2);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 

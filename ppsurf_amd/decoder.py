@@ -182,3 +182,57 @@ class DecoderPlan:
         _lib.check(L.pps_decode_tail_f32(pooled.data_ptr(), xbar.data_ptr(), q, w['tl_w'].data_ptr(), w['tl_b'].data_ptr(),
                                          logits.data_ptr(), occ.data_ptr() if want_occ else None, st), 'pps_decode_tail_f32')
         return logits, occ
+
+
+class ChunkPipeline:
+    """Decodes a sequence of query chunks of ONE shape with the spatial queries of chunk i+1 (kNN + patch gather: fp32 VALU,
+    L2-resident) running on a side HIP stream underneath the MFMA-bound decoder kernels of chunk i.  Double-buffered
+    neighbour tables / patches; events order the two streams.  replaces the chunk loops of source/poco_utils.py:218-223,146-153."""
+
+    def __init__(self, plan: DecoderPlan, table, pts, raw, k: int, p: int, same_cloud: bool, max_chunk: int, overlap: bool = False):
+        from . import ops
+        self.ops, self.plan, self.table, self.pts, self.raw = ops, plan, table, pts, raw
+        self.k, self.p, self.same_cloud, self.overlap = int(k), int(p), bool(same_cloud), bool(overlap)
+        dev = plan.device
+        self.idx = [torch.empty((max_chunk, self.k), dtype=torch.int64, device=dev) for _ in range(2)]
+        self.pidx = None if (same_cloud and p <= k) else [torch.empty((max_chunk, self.p), dtype=torch.int64, device=dev) for _ in range(2)]
+        self.patches = [torch.empty((max_chunk, self.p, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+        # the cloud is searched thousands of times per shape: arrange it once for the block-culling search
+        self.blocks = self.ops.KnnBlocks(pts)
+        self.raw_blocks = None if self.pidx is None else self.ops.KnnBlocks(raw)
+        self.side = torch.cuda.Stream(device=dev) if overlap else None
+        self.ready = [torch.cuda.Event() for _ in range(2)]
+        self.free = [torch.cuda.Event() for _ in range(2)]
+        self.n = 0
+
+    def _spatial(self, q, b):
+        m = q.shape[0]
+        idx = self.idx[b][:m]
+        self.blocks.query(q, self.k, out=idx)
+        src = idx
+        if self.pidx is not None:
+            src = self.pidx[b][:m]
+            self.raw_blocks.query(q, self.p, out=src)
+        self.ops.patch_normalize(self.raw, q, src, self.p, out=self.patches[b][:m])
+
+    def run(self, chunks, want_occ=True, interp_events=None):
+        """chunks: list of contiguous float32 [q_i,3] device tensors -> list of (logits, occ)."""
+        main = torch.cuda.current_stream(self.plan.device)
+        out = []
+        for i, q in enumerate(chunks):
+            b = (self.n + i) & 1
+            if self.side is not None:
+                self.side.wait_stream(main) if i == 0 else None
+                with torch.cuda.stream(self.side):
+                    self.side.wait_event(self.free[b])
+                    self._spatial(q, b)
+                    self.ready[b].record(self.side)
+                main.wait_event(self.ready[b])
+            else:
+                self._spatial(q, b)
+            m = q.shape[0]
+            ev = interp_events[i] if interp_events is not None else None
+            out.append(self.plan.decode(self.table, self.pts, q, self.idx[b][:m], self.patches[b][:m], want_occ=want_occ, interp_events=ev))
+            self.free[b].record(main)
+        self.n += len(chunks)
+        return out

@@ -8,27 +8,73 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-def knn_point_major(pts: torch.Tensor, query: torch.Tensor, k: int, return_d2: bool = False):
-    """pts [n,3], query [m,3] float32 contiguous on the GPU -> int64 [m,k] (sorted by (d2, index)); k <= min(n, 64)."""
+def knn_point_major(pts: torch.Tensor, query: torch.Tensor, k: int, return_d2: bool = False, out: torch.Tensor = None):
+    """pts [n,3], query [m,3] float32 contiguous on the GPU -> int64 [m,k] (sorted by (d2, index)); k <= min(n, 64).
+    `out`: optional preallocated int64 [m,k] (stream-pipelined callers)."""
     if not (pts.is_cuda and query.is_cuda):
         raise _lib.PpsError('pps_knn_f32 needs device tensors; there is no CPU fallback')
     pts = pts.contiguous().float()
     query = query.contiguous().float()
     m = query.shape[0]
-    idx = torch.empty((m, k), dtype=torch.int64, device=pts.device)
+    idx = out if out is not None else torch.empty((m, k), dtype=torch.int64, device=pts.device)
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and tuple(idx.shape) == (m, k)
     d2 = torch.empty((m, k), dtype=torch.float32, device=pts.device) if return_d2 else None
     _lib.check(_lib.lib().pps_knn_f32(pts.data_ptr(), pts.shape[0], query.data_ptr(), m, int(k), idx.data_ptr(),
                                       d2.data_ptr() if return_d2 else None, _stream(pts)), 'pps_knn_f32')
     return (idx, d2) if return_d2 else idx
 
 
-def patch_normalize(raw: torch.Tensor, query: torch.Tensor, idx: torch.Tensor, p: int) -> torch.Tensor:
+def patch_normalize(raw: torch.Tensor, query: torch.Tensor, idx: torch.Tensor, p: int, out: torch.Tensor = None) -> torch.Tensor:
     """raw [n,3], query [q,3], idx int64 [q,>=p] -> patches [q,p,3] in patch space (ppsurf_data_loader.py:91-123)."""
     raw = raw.contiguous().float()
     query = query.contiguous().float()
     assert idx.dtype == torch.int64 and idx.stride(1) == 1
     q = query.shape[0]
-    out = torch.empty((q, p, 3), dtype=torch.float32, device=raw.device)
+    if out is None:
+        out = torch.empty((q, p, 3), dtype=torch.float32, device=raw.device)
+    assert out.is_contiguous() and tuple(out.shape) == (q, p, 3)
     _lib.check(_lib.lib().pps_patch_normalize_f32(raw.data_ptr(), query.data_ptr(), idx.data_ptr(), idx.stride(0), q, int(p),
                                                   out.data_ptr(), _stream(raw)), 'pps_patch_normalize_f32')
     return out
+
+
+class KnnBlocks:
+    """A cloud arranged for pps_knn_blocked_f32: points sorted along a Morton curve, cut into blocks of 64 with bounding
+    boxes.  Built once per cloud with a handful of torch device ops; queries return the ORIGINAL indices, bit-identical
+    to knn_point_major."""
+
+    def __init__(self, pts: torch.Tensor):
+        if not pts.is_cuda:
+            raise _lib.PpsError('KnnBlocks needs a device tensor; there is no CPU fallback')
+        pts = pts.contiguous().float()
+        n = pts.shape[0]
+        lo = pts.min(dim=0)[0]
+        span = (pts.max(dim=0)[0] - lo).max().clamp_min(1e-20)
+        cell = ((pts - lo) / span * 1023.0).to(torch.int64).clamp_(0, 1023)
+
+        def spread(v):                                   # 10 bits -> every third bit
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            return (v | (v << 2)) & 0x09249249
+        code = spread(cell[:, 0]) | (spread(cell[:, 1]) << 1) | (spread(cell[:, 2]) << 2)
+        order = torch.sort(code, stable=True)[1]
+        nb = (n + 63) // 64
+        pad = nb * 64 - n
+        sorted_pts = pts[order]
+        self.n, self.nb = n, nb
+        self.pts = torch.cat([sorted_pts, sorted_pts[-1:].expand(pad, 3)], dim=0).contiguous()
+        self.orig = torch.cat([order.to(torch.int32), torch.full((pad,), -1, dtype=torch.int32, device=pts.device)]).contiguous()
+        blk = self.pts.view(nb, 64, 3)                   # padding repeats the last valid point: boxes stay tight
+        self.bbox = torch.cat([blk.min(dim=1)[0], blk.max(dim=1)[0]], dim=1).contiguous()
+
+    def query(self, query: torch.Tensor, k: int, return_d2: bool = False, out: torch.Tensor = None):
+        query = query.contiguous().float()
+        m = query.shape[0]
+        idx = out if out is not None else torch.empty((m, k), dtype=torch.int64, device=query.device)
+        assert idx.dtype == torch.int64 and idx.is_contiguous() and tuple(idx.shape) == (m, k)
+        d2 = torch.empty((m, k), dtype=torch.float32, device=query.device) if return_d2 else None
+        _lib.check(_lib.lib().pps_knn_blocked_f32(self.pts.data_ptr(), self.orig.data_ptr(), self.bbox.data_ptr(), self.nb, self.n,
+                                                  query.data_ptr(), m, int(k), idx.data_ptr(), d2.data_ptr() if return_d2 else None,
+                                                  _stream(query)), 'pps_knn_blocked_f32')
+        return (idx, d2) if return_d2 else idx

@@ -45,22 +45,17 @@ class OccupancyField:
         self.p = num_pts_local
         self.chunk = int(num_pts)
         self.n_queries = 0
+        from .decoder import ChunkPipeline
+        self.pipe = ChunkPipeline(self.plan, self.table, self.pts, self.raw, self.k, self.p, self.same_cloud, self.chunk)
 
     @torch.no_grad()
     def __call__(self, queries: torch.Tensor) -> torch.Tensor:
         """queries [q,3] float32 on the device -> occ [q] float32 (= softmax(logits)[0] - softmax(logits)[1])."""
-        out = []
-        for s in range(0, queries.shape[0], self.chunk):
-            q = queries[s:s + self.chunk].contiguous()
-            idx = ops.knn_point_major(self.pts, q, self.k)
-            if self.same_cloud and self.p <= self.k:
-                patches = ops.patch_normalize(self.raw, q, idx, self.p)     # the P nearest are a prefix of the k nearest
-            else:
-                patches = ops.patch_normalize(self.raw, q, ops.knn_point_major(self.raw, q, self.p), self.p)
-            _, occ = self.plan.decode(self.table, self.pts, q, idx, patches, want_occ=True)
-            out.append(occ)
-            self.n_queries += q.shape[0]
-        return torch.cat(out) if out else torch.empty((0,), device=self.dev)
+        if queries.shape[0] == 0:
+            return torch.empty((0,), device=self.dev)
+        chunks = [queries[s:s + self.chunk].contiguous() for s in range(0, queries.shape[0], self.chunk)]
+        self.n_queries += queries.shape[0]
+        return torch.cat([occ for _, occ in self.pipe.run(chunks, want_occ=True)])
 
 
 def create_volume(field, pts_ids: torch.Tensor, resolution: int, step: float, bmin_pad: float, padding=1, dilation_size=2,

@@ -98,3 +98,29 @@ def test_patch_normalize_vs_oracle(p):
     ref = O.normalize_patches(cloud[ids], qry)
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-7)
     assert abs(np.linalg.norm(out.cpu().numpy(), axis=2).max(axis=1) - 1.0).max() < 1e-6
+
+
+@pytest.mark.parametrize('n,m,k', [(9, 4, 9), (63, 10, 5), (64, 70, 64), (65, 33, 7), (1000, 257, 16), (20000, 3000, 64), (100_000, 5000, 64)])
+def test_blocked_knn_is_bit_identical_to_brute_force(n, m, k):
+    rng = np.random.default_rng(n * 7 + m)
+    if n >= 20000:
+        pts = make_cloud(n, seed=n)
+        qry = make_band_queries(pts, m, resolution=257, seed=m)
+    else:
+        pts = rng.uniform(-0.5, 0.5, (n, 3)).astype(np.float32)
+        qry = rng.uniform(-0.6, 0.6, (m, 3)).astype(np.float32)
+    dp, dq = torch.from_numpy(pts).to(DEV), torch.from_numpy(qry).to(DEV)
+    blocks = ops.KnnBlocks(dp)
+    idx, d2 = blocks.query(dq, k, return_d2=True)
+    ref_idx, ref_d2 = ops.knn_point_major(dp, dq, k, return_d2=True)
+    assert torch.equal(idx, ref_idx) and torch.equal(d2, ref_d2)
+    assert np.array_equal(idx.cpu().numpy(), O.knn_point_major(pts, qry, k))
+
+
+def test_blocked_knn_ties_and_far_queries():
+    rng = np.random.default_rng(11)
+    pts = (rng.integers(0, 6, (4000, 3)) / 8.0).astype(np.float32)          # lattice: many exact distance ties
+    qry = np.concatenate([(rng.integers(0, 6, (200, 3)) / 8.0), rng.uniform(-30, 30, (50, 3))]).astype(np.float32)
+    dp, dq = torch.from_numpy(pts).to(DEV), torch.from_numpy(qry).to(DEV)
+    idx = ops.KnnBlocks(dp).query(dq, 64)
+    assert np.array_equal(idx.cpu().numpy(), O.knn_point_major(pts, qry, 64))

@@ -34,6 +34,9 @@ t_tab = timeit('point_table (N rows)', lambda: pl.point_table(lat))
 table = pl.point_table(lat)
 t_knn = timeit('knn k=64', lambda: ops.knn_point_major(pts, qd, 64))
 idx = ops.knn_point_major(pts, qd, 64)
+blocks = ops.KnnBlocks(pts)
+t_kb = timeit('knn blocked k=64', lambda: blocks.query(qd, 64))
+t_bld = timeit('KnnBlocks build', lambda: ops.KnnBlocks(pts))
 t_pat = timeit('patch_normalize P=50', lambda: ops.patch_normalize(pts, qd, idx, 50))
 patches = ops.patch_normalize(pts, qd, idx, 50)
 from ppsurf_amd import _lib
