@@ -63,14 +63,22 @@ __device__ __forceinline__ void dense_blocks(const f32x4 (&in)[KB], f32x4* out, 
     for (int ob = 0; ob < NOB; ob += 2) {
         f32x4 acc0 = INIT ? out[ob] : bias[(ob) * 4 + g];
         f32x4 acc1 = INIT ? out[ob + 1] : bias[(ob + 1) * 4 + g];
-        f32x4 n0 = w[((ob) * KB) * 64 + lane];
-        f32x4 n1 = w[((ob + 1) * KB) * 64 + lane];
+        // A fragments are requested TWO k-steps ahead: the pair consumed by step kb was issued during step kb-2, so the
+        // wait in front of its first MFMA is a counted lgkmcnt with the newer pair still in flight (no exposed LDS latency)
+        f32x4 p0 = w[((ob) * KB) * 64 + lane];
+        f32x4 p1 = w[((ob + 1) * KB) * 64 + lane];
+        f32x4 q0 = p0, q1 = p1;
+        if (KB > 1) {
+            q0 = w[((ob) * KB + 1) * 64 + lane];
+            q1 = w[((ob + 1) * KB + 1) * 64 + lane];
+        }
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
-            const f32x4 a0 = n0, a1 = n1;
-            if (kb + 1 < KB) {
-                n0 = w[((ob) * KB + kb + 1) * 64 + lane];
-                n1 = w[((ob + 1) * KB + kb + 1) * 64 + lane];
+            const f32x4 a0 = p0, a1 = p1;
+            p0 = q0; p1 = q1;
+            if (kb + 2 < KB) {
+                q0 = w[((ob) * KB + kb + 2) * 64 + lane];
+                q1 = w[((ob + 1) * KB + kb + 2) * 64 + lane];
             }
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, in[kb].x, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, in[kb].x, acc1, 0, 0, 0);
@@ -80,7 +88,6 @@ __device__ __forceinline__ void dense_blocks(const f32x4 (&in)[KB], f32x4* out, 
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, in[kb].z, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, in[kb].w, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, in[kb].w, acc1, 0, 0, 0);
-            // next A fragments are requested before this step's MFMAs, nothing migrates across steps
             __builtin_amdgcn_sched_group_barrier(PPS_SG_DSREAD, 2, 0);
             __builtin_amdgcn_sched_group_barrier(PPS_SG_MFMA, 8, 0);
             __builtin_amdgcn_sched_barrier(0);

@@ -14,16 +14,27 @@
 
 using namespace pps;
 
-#define NT 512                 // threads per workgroup
+#ifndef NT
+#define NT 256                 // threads per workgroup (4 waves); 2 workgroups per CU run decoupled
+#endif
+#define NW (NT / 64)            // waves per workgroup
+#define WG_PER_CU (512 / NT)
 #define CH4 2048               // f32x4 per 32 KiB weight chunk
 
 // One pipeline step: request the NEXT chunk, compute on the CURRENT one, publish the next, barrier.
+// PPS_ABL_* macros are ablation switches for tools/ablate_interp.sh (never defined in the product build)
 template <int NF4_NEXT, class F>
 __device__ __forceinline__ void stream_step(const f32x4* __restrict__ gnext, f32x4*& cur, f32x4*& nxt, F&& compute) {
+#ifndef PPS_ABL_NOSTREAM
     chunk_copy_async<NF4_NEXT, NT>(gnext, nxt);
+#endif
     compute((const f32x4*)cur);
+#ifndef PPS_ABL_NOBARRIER
     __syncthreads();
+#endif
+#ifndef PPS_ABL_NOSTREAM
     f32x4* t = cur; cur = nxt; nxt = t;
+#endif
 }
 
 template <int NF4>
@@ -45,6 +56,7 @@ __device__ __forceinline__ void relu_blocks(f32x4* a) {
 
 extern __shared__ __attribute__((aligned(16))) char pps_smem[];
 
+
 // =====================================================================================================
 // rows_dense256: out[m,256] = in[m,256] W^T + b
 // =====================================================================================================
@@ -61,15 +73,15 @@ __global__ __launch_bounds__(NT, 2) void rows_dense256_kernel(const float* __res
     const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
 
     lds_fill(bias_l, bias, 256);
-    stream_prologue<4>(wg, buf0);
+    stream_prologue<CH4 / NT>(wg, buf0);
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 
-    const int ntiles = (int)((m + 127) / 128);
+    const int ntiles = (int)((m + NW * 16 - 1) / (NW * 16));
     int first, count, stride;
     xcd_tile_range(ntiles, first, count, stride);
     for (int it = 0; it < count; ++it) {
-        const int64_t row = (int64_t)(first + it * stride) * 128 + wave * 16 + n;
+        const int64_t row = (int64_t)(first + it * stride) * (NW * 16) + wave * 16 + n;
         const bool rv = row < m;
         const int64_t rc = rv ? row : m - 1;
         f32x4 a[16];
@@ -87,7 +99,7 @@ __global__ __launch_bounds__(NT, 2) void rows_dense256_kernel(const float* __res
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             f32x4 o[2];
-            stream_step<4>(wg + ((c + 1) & 7) * CH4, cur, nxt,
+            stream_step<CH4 / NT>(wg + ((c + 1) & 7) * CH4, cur, nxt,
                            [&](const f32x4* w) { dense_blocks<16, 2, 0>(a, o, w, bias4 + 8 * c, lane); });
             if (rv) { dst[4 * (2 * c)] = o[0]; dst[4 * (2 * c + 1)] = o[1]; }
         }
@@ -100,8 +112,8 @@ __global__ __launch_bounds__(NT, 2) void rows_dense256_kernel(const float* __res
 // =====================================================================================================
 #define IP_W_XYZ 1024
 #define IP_NBIAS 576
-// LDS floats: xyz 1024 | bias 576 | ms_m 512 | ms_s 512 | f 512 | part 2048
-#define IP_LDS_BYTES (2 * CH4 * 16 + (IP_W_XYZ + IP_NBIAS + 512 * 3 + 2048) * 4)
+// LDS floats: xyz 1024 | bias 576 | ms_m NW*64 | ms_s NW*64 | f NW*64 | part NW*256
+#define IP_LDS_BYTES (2 * CH4 * 16 + (IP_W_XYZ + IP_NBIAS + NW * 64 * 3 + NW * 256) * 4)
 
 __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restrict__ G, const float* __restrict__ pts,
                                                             const float* __restrict__ query, const int64_t* __restrict__ idx,
@@ -112,25 +124,25 @@ __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restr
     float* xyz_l = (float*)(buf1 + CH4);
     float* bias_l = xyz_l + IP_W_XYZ;
     float* msm = bias_l + IP_NBIAS;      // [8][64] per-wave row max of every head
-    float* mss = msm + 512;              // [8][64] per-wave sum of exp
-    float* f_l = mss + 512;              // [8][64] per-wave head factor exp(m_w - M) / (64 S)
-    float* part = f_l + 512;             // [8][256] per-wave pooled partial
+    float* mss = msm + NW * 64;          // [NW][64] per-wave sum of exp
+    float* f_l = mss + NW * 64;          // [NW][64] per-wave head factor exp(m_w - M) / (64 S)
+    float* part = f_l + NW * 64;         // [NW][256] per-wave pooled partial
     const f32x4* bias4 = (const f32x4*)bias_l;
     const f32x4* wg = (const f32x4*)(wpack + IP_W_XYZ);
     const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
 
     lds_fill(xyz_l, wpack, IP_W_XYZ);
     lds_fill(bias_l, bias, IP_NBIAS);
-    stream_prologue<4>(wg, buf0);
+    stream_prologue<CH4 / NT>(wg, buf0);
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 
-    const int ntiles = (int)((Q + 1) / 2);
+    const int ntiles = (int)((Q + NW / 4 - 1) / (NW / 4));       // 4 waves (64 neighbours) per query
     int first, count, stride;
     xcd_tile_range(ntiles, first, count, stride);
-    const int wq = wave & 3, wbase = wave & 4;
+    const int wq = wave & 3, wbase = wave & ~3;
     for (int it = 0; it < count; ++it) {
-        const int64_t qi = (int64_t)(first + it * stride) * 2 + (wave >> 2);
+        const int64_t qi = (int64_t)(first + it * stride) * (NW / 4) + (wave >> 2);
         const bool qv = qi < Q;
         const int64_t qc = qv ? qi : Q - 1;
         const int row = wq * 16 + n;
@@ -139,7 +151,11 @@ __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restr
 
         f32x4 a[16], b[16];
         {
+#ifdef PPS_ABL_NOGATHER
+            const f32x4* grow = (const f32x4*)(G + (int64_t)(lane & 15) * 256) + g;
+#else
             const f32x4* grow = (const f32x4*)(G + i * 256) + g;
+#endif
 #pragma unroll
             for (int bb = 0; bb < 16; ++bb) a[bb] = grow[4 * bb];
             const float coord = (g < 3) ? (query[qc * 3 + g] - pts[i * 3 + g]) : 0.f;   // query minus neighbour (poco_model.py:402)
@@ -148,17 +164,21 @@ __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restr
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c)
-            stream_step<4>(wg + (c + 1) * CH4, cur, nxt,
+            stream_step<CH4 / NT>(wg + (c + 1) * CH4, cur, nxt,
                            [&](const f32x4* w) { dense_blocks<16, 2, 1>(a, &b[2 * c], w, bias4 + 8 * c, lane); });
 #pragma unroll
         for (int c = 0; c < 8; ++c)
-            stream_step<4>(wg + (c + 9) * CH4, cur, nxt,
+            stream_step<CH4 / NT>(wg + (c + 9) * CH4, cur, nxt,
                            [&](const f32x4* w) { dense_blocks<16, 2, 1>(b, &a[2 * c], w, bias4 + 64 + 8 * c, lane); });
 #pragma unroll
         for (int c = 0; c < 2; ++c)
-            stream_step<4>(wg + ((c + 17) % 18) * CH4, cur, nxt,
+            stream_step<CH4 / NT>(wg + ((c + 17) % 18) * CH4, cur, nxt,
                            [&](const f32x4* w) { dense_blocks<16, 2, 0>(a, &b[2 * c], w, bias4 + 128 + 8 * c, lane); });
 
+#ifdef PPS_ABL_NOSOFTMAX
+        if (qv && wq == 0 && lane < 64) { f32x4 s4 = a[0] + b[0]; for (int bb = 1; bb < 16; ++bb) s4 += a[bb]; ((f32x4*)(pooled + qi * 256))[lane] = s4; }
+        continue;
+#endif
         // ---- softmax over the 64 neighbours (4 waves x 16 rows) for each of the 64 heads -------------
         // lane (n,g) holds heads 16*bb + 4*g + r of row n in b[bb][r]
         float e[16];
@@ -243,16 +263,16 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_rows_kernel(const float* _
 
     lds_fill(xyz_l, wpack, PA_W_XYZ);
     lds_fill(bias_l, bias, PA_NBIAS);
-    stream_prologue<2>(wg, buf0);
+    stream_prologue<1024 / NT>(wg, buf0);
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 
     const int nrb = (P + 15) / 16;
-    const int ntiles = (int)((Q + 7) / 8);
+    const int ntiles = (int)((Q + NW - 1) / NW);
     int first, count, stride;
     xcd_tile_range(ntiles, first, count, stride);
     for (int it = 0; it < count; ++it) {
-        const int64_t qi = (int64_t)(first + it * stride) * 8 + wave;
+        const int64_t qi = (int64_t)(first + it * stride) * NW + wave;
         const bool qv = qi < Q;
         const int64_t qc = qv ? qi : Q - 1;
         f32x4 rmax[16];
@@ -267,14 +287,14 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_rows_kernel(const float* _
             for (int bb = 0; bb < 4; ++bb) x0[bb] = bias4[4 * bb + g];
             xyz_blocks<4>(coord, x0, xyz_l, lane);
             relu_blocks<4>(x0);
-            stream_step<2>(wg + 1024, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 16, lane); });
-            stream_step<4>(wg + 2048, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x1, x0, w, bias4 + 32, lane); });
-            stream_step<4>(wg + 4096, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 8, 1>(x0, y, w, bias4 + 48, lane); });
+            stream_step<1024 / NT>(wg + 1024, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 16, lane); });
+            stream_step<CH4 / NT>(wg + 2048, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x1, x0, w, bias4 + 32, lane); });
+            stream_step<CH4 / NT>(wg + 4096, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 8, 1>(x0, y, w, bias4 + 48, lane); });
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                stream_step<4>(wg + 6144 + c * CH4, cur, nxt,
+                stream_step<CH4 / NT>(wg + 6144 + c * CH4, cur, nxt,
                                [&](const f32x4* w) { dense_blocks<8, 4, 1>(y, &z[4 * c], w, bias4 + 80 + 16 * c, lane); });
-            stream_step<2>(wg, cur, nxt, [&](const f32x4* w) { dense_blocks<8, 4, 1>(y, &z[12], w, bias4 + 80 + 48, lane); });
+            stream_step<1024 / NT>(wg, cur, nxt, [&](const f32x4* w) { dense_blocks<8, 4, 1>(y, &z[12], w, bias4 + 80 + 48, lane); });
 #pragma unroll
             for (int bb = 0; bb < 16; ++bb)
 #pragma unroll
@@ -308,15 +328,15 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_kernel(const float* __r
     const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
 
     lds_fill(bias_l, bias, PB_NBIAS);
-    stream_prologue<4>(wg, buf0);
+    stream_prologue<CH4 / NT>(wg, buf0);
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 
-    const int ntiles = (int)((Q + 127) / 128);
+    const int ntiles = (int)((Q + NW * 16 - 1) / (NW * 16));
     int first, count, stride;
     xcd_tile_range(ntiles, first, count, stride);
     for (int it = 0; it < count; ++it) {
-        const int64_t qi = (int64_t)(first + it * stride) * 128 + wave * 16 + n;
+        const int64_t qi = (int64_t)(first + it * stride) * (NW * 16) + wave * 16 + n;
         const bool qv = qi < Q;
         const int64_t qc = qv ? qi : Q - 1;
         f32x4 a[16], h[8], u[4];
@@ -327,15 +347,15 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_kernel(const float* __r
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            stream_step<4>(wg + (c + 1) * CH4, cur, nxt,
+            stream_step<CH4 / NT>(wg + (c + 1) * CH4, cur, nxt,
                            [&](const f32x4* w) { dense_blocks<16, 2, 1>(a, &h[2 * c], w, bias4 + 8 * c, lane); });
-        stream_step<4>(wg + 5 * CH4, cur, nxt, [&](const f32x4* w) { dense_blocks<8, 4, 1>(h, u, w, bias4 + 32, lane); });
+        stream_step<CH4 / NT>(wg + 5 * CH4, cur, nxt, [&](const f32x4* w) { dense_blocks<8, 4, 1>(h, u, w, bias4 + 32, lane); });
         f32x4* dst = (f32x4*)(trans2 + qc * 4096) + g;
 #pragma unroll 1
         for (int c = 0; c < 32; ++c) {
             f32x4 o[8];
             const f32x4* gn = (c + 1 < 32) ? wg + (6 + c) * CH4 : wg;
-            stream_step<4>(gn, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 8, 0>(u, o, w, bias4 + 48 + 32 * c, lane); });
+            stream_step<CH4 / NT>(gn, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 8, 0>(u, o, w, bias4 + 48 + 32 * c, lane); });
             if (qv) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dst[4 * (8 * c + j)] = o[j];
@@ -366,17 +386,17 @@ __global__ __launch_bounds__(NT, 2) void pointnet_feat_rows_kernel(const float* 
 
     lds_fill(xyz_l, wpack, PC_W_XYZ);
     lds_fill(bias_l, bias, PC_NBIAS);
-    stream_prologue<2>(wg, buf0);
+    stream_prologue<1024 / NT>(wg, buf0);
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
     const float bq = bias_l[576 + 256];
 
     const int nrb = (P + 15) / 16;
-    const int ntiles = (int)((Q + 7) / 8);
+    const int ntiles = (int)((Q + NW - 1) / NW);
     int first, count, stride;
     xcd_tile_range(ntiles, first, count, stride);
     for (int it = 0; it < count; ++it) {
-        const int64_t qi = (int64_t)(first + it * stride) * 8 + wave;
+        const int64_t qi = (int64_t)(first + it * stride) * NW + wave;
         const bool qv = qi < Q;
         const int64_t qc = qv ? qi : Q - 1;
         const f32x4* tq = (const f32x4*)(trans2 + qc * 4096);
@@ -394,7 +414,7 @@ __global__ __launch_bounds__(NT, 2) void pointnet_feat_rows_kernel(const float* 
             for (int bb = 0; bb < 4; ++bb) x0[bb] = bias4[4 * bb + g];
             xyz_blocks<4>(coord, x0, xyz_l, lane);
             relu_blocks<4>(x0);
-            stream_step<2>(wg + 1024, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 16, lane); });
+            stream_step<1024 / NT>(wg + 1024, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 16, lane); });
             // feature transform x0 = trans2[q] (64x64, row-major) @ x1: A operand straight from global
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) {
@@ -411,13 +431,13 @@ __global__ __launch_bounds__(NT, 2) void pointnet_feat_rows_kernel(const float* 
                 }
                 x0[ob] = o;
             }
-            stream_step<4>(wg + 2048, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 32, lane); });
-            stream_step<4>(wg + 4096, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 8, 1>(x1, y, w, bias4 + 48, lane); });
+            stream_step<CH4 / NT>(wg + 2048, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 32, lane); });
+            stream_step<CH4 / NT>(wg + 4096, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 8, 1>(x1, y, w, bias4 + 48, lane); });
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                stream_step<4>(wg + 6144 + c * CH4, cur, nxt,
+                stream_step<CH4 / NT>(wg + 6144 + c * CH4, cur, nxt,
                                [&](const f32x4* w) { dense_blocks<8, 4, 0>(y, &z[4 * c], w, bias4 + 80 + 16 * c, lane); });
-            stream_step<2>(wg, cur, nxt, [&](const f32x4* w) { dense_blocks<8, 4, 0>(y, &z[12], w, bias4 + 80 + 48, lane); });
+            stream_step<1024 / NT>(wg, cur, nxt, [&](const f32x4* w) { dense_blocks<8, 4, 0>(y, &z[12], w, bias4 + 80 + 48, lane); });
 
             // attention logit of row n (nn.py:88), online softmax over the patch points (nn.py:91-93)
             float s = 0.f;
@@ -470,15 +490,15 @@ __global__ __launch_bounds__(NT, 2) void decode_tail_kernel(const float* __restr
     const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
 
     lds_fill(bias_l, bias, TL_NBIAS);
-    stream_prologue<4>(wg, buf0);
+    stream_prologue<CH4 / NT>(wg, buf0);
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 
-    const int ntiles = (int)((Q + 127) / 128);
+    const int ntiles = (int)((Q + NW * 16 - 1) / (NW * 16));
     int first, count, stride;
     xcd_tile_range(ntiles, first, count, stride);
     for (int it = 0; it < count; ++it) {
-        const int64_t qi = (int64_t)(first + it * stride) * 128 + wave * 16 + n;
+        const int64_t qi = (int64_t)(first + it * stride) * (NW * 16) + wave * 16 + n;
         const bool qv = qi < Q;
         const int64_t qc = qv ? qi : Q - 1;
         f32x4 p[16], x[16], h[16];
@@ -490,18 +510,18 @@ __global__ __launch_bounds__(NT, 2) void decode_tail_kernel(const float* __restr
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c)
-            stream_step<4>(wg + (c + 1) * CH4, cur, nxt,
+            stream_step<CH4 / NT>(wg + (c + 1) * CH4, cur, nxt,
                            [&](const f32x4* w) { dense_blocks<16, 2, 0>(p, &h[2 * c], w, bias4 + 8 * c, lane); });
 #pragma unroll
         for (int c = 0; c < 8; ++c)
-            stream_step<4>(wg + (c + 9) * CH4, cur, nxt,
+            stream_step<CH4 / NT>(wg + (c + 9) * CH4, cur, nxt,
                            [&](const f32x4* w) { dense_blocks<16, 2, 1, 1>(x, &h[2 * c], w, bias4, lane); });
 #pragma unroll
         for (int c = 0; c < 8; ++c)
-            stream_step<4>(wg + (c + 17) * CH4, cur, nxt,
+            stream_step<CH4 / NT>(wg + (c + 17) * CH4, cur, nxt,
                            [&](const f32x4* w) { dense_blocks<16, 2, 1>(h, &p[2 * c], w, bias4 + 64 + 8 * c, lane); });
         f32x4 o[2];
-        stream_step<4>(wg, cur, nxt, [&](const f32x4* w) { dense_blocks<16, 2, 0>(p, o, w, bias4 + 128, lane); });
+        stream_step<CH4 / NT>(wg, cur, nxt, [&](const f32x4* w) { dense_blocks<16, 2, 0>(p, o, w, bias4 + 128, lane); });
         if (qv && g == 0) {
             const float l0 = o[0].x, l1 = o[0].y;
             logits[qi * 2] = l0;
@@ -537,6 +557,7 @@ static int set_lds(K kernel, int bytes) {
 static int grid_for(int64_t ntiles) {
     int cus = cu_count();
     if (cus <= 0) cus = 256;
+    cus *= WG_PER_CU;
     return (int)(ntiles < cus ? (ntiles > 0 ? ntiles : 1) : cus);
 }
 
@@ -545,6 +566,15 @@ static int grid_for(int64_t ntiles) {
 extern "C" {
 
 int pps_abi_version(void) { return 1; }
+
+// development aid (not part of the public header): resident workgroups per CU of the decoder kernels
+int pps_debug_occupancy(int which) {
+    int n = -1;
+    if (which == 0) { set_lds(interp_pool_kernel, IP_LDS_BYTES); hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, interp_pool_kernel, NT, IP_LDS_BYTES); }
+    if (which == 1) { set_lds(pointnet_stn_rows_kernel, PA_LDS_BYTES); hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pointnet_stn_rows_kernel, NT, PA_LDS_BYTES); }
+    if (which == 2) { set_lds(pointnet_feat_rows_kernel, PC_LDS_BYTES); hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pointnet_feat_rows_kernel, NT, PC_LDS_BYTES); }
+    return n;
+}
 int pps_device_cu_count(void) { return cu_count(); }
 
 int pps_rows_dense256_f32(const float* in, int64_t rs, int64_t cs, int64_t m, const float* wpack, const float* bias,
@@ -554,7 +584,7 @@ int pps_rows_dense256_f32(const float* in, int64_t rs, int64_t cs, int64_t m, co
     if (cs == 1 && (rs % 4) != 0) return PPS_ERR_ARG;
     static int once = set_lds(rows_dense256_kernel, RD_LDS_BYTES);
     (void)once;
-    hipLaunchKernelGGL(rows_dense256_kernel, dim3(grid_for((m + 127) / 128)), dim3(NT), RD_LDS_BYTES, (hipStream_t)stream,
+    hipLaunchKernelGGL(rows_dense256_kernel, dim3(grid_for((m + NW * 16 - 1) / (NW * 16))), dim3(NT), RD_LDS_BYTES, (hipStream_t)stream,
                        in, rs, cs, m, wpack, bias, out);
     return PPS_LAUNCH_CHECK();
 }
@@ -565,7 +595,7 @@ int pps_interp_pool_f32(const float* G, const float* pts, const float* query, co
     if (q == 0) return PPS_OK;
     static int once = set_lds(interp_pool_kernel, IP_LDS_BYTES);
     (void)once;
-    hipLaunchKernelGGL(interp_pool_kernel, dim3(grid_for((q + 1) / 2)), dim3(NT), IP_LDS_BYTES, (hipStream_t)stream,
+    hipLaunchKernelGGL(interp_pool_kernel, dim3(grid_for((q + NW / 4 - 1) / (NW / 4))), dim3(NT), IP_LDS_BYTES, (hipStream_t)stream,
                        G, pts, query, idx, q, k, wpack, bias, pooled);
     return PPS_LAUNCH_CHECK();
 }
@@ -576,7 +606,7 @@ int pps_pointnet_stn_rows_f32(const float* patches, int64_t q, int p, const floa
     if (q == 0) return PPS_OK;
     static int once = set_lds(pointnet_stn_rows_kernel, PA_LDS_BYTES);
     (void)once;
-    hipLaunchKernelGGL(pointnet_stn_rows_kernel, dim3(grid_for((q + 7) / 8)), dim3(NT), PA_LDS_BYTES, (hipStream_t)stream,
+    hipLaunchKernelGGL(pointnet_stn_rows_kernel, dim3(grid_for((q + NW - 1) / NW)), dim3(NT), PA_LDS_BYTES, (hipStream_t)stream,
                        patches, q, p, wpack, bias, g);
     return PPS_LAUNCH_CHECK();
 }
@@ -586,7 +616,7 @@ int pps_pointnet_stn_fc_f32(const float* g, int64_t q, const float* wpack, const
     if (q == 0) return PPS_OK;
     static int once = set_lds(pointnet_stn_fc_kernel, PB_LDS_BYTES);
     (void)once;
-    hipLaunchKernelGGL(pointnet_stn_fc_kernel, dim3(grid_for((q + 127) / 128)), dim3(NT), PB_LDS_BYTES, (hipStream_t)stream,
+    hipLaunchKernelGGL(pointnet_stn_fc_kernel, dim3(grid_for((q + NW * 16 - 1) / (NW * 16))), dim3(NT), PB_LDS_BYTES, (hipStream_t)stream,
                        g, q, wpack, bias, trans2);
     return PPS_LAUNCH_CHECK();
 }
@@ -597,7 +627,7 @@ int pps_pointnet_feat_rows_f32(const float* patches, const float* trans2, int64_
     if (q == 0) return PPS_OK;
     static int once = set_lds(pointnet_feat_rows_kernel, PC_LDS_BYTES);
     (void)once;
-    hipLaunchKernelGGL(pointnet_feat_rows_kernel, dim3(grid_for((q + 7) / 8)), dim3(NT), PC_LDS_BYTES, (hipStream_t)stream,
+    hipLaunchKernelGGL(pointnet_feat_rows_kernel, dim3(grid_for((q + NW - 1) / NW)), dim3(NT), PC_LDS_BYTES, (hipStream_t)stream,
                        patches, trans2, q, p, wpack, bias, xbar);
     return PPS_LAUNCH_CHECK();
 }
@@ -608,7 +638,7 @@ int pps_decode_tail_f32(const float* pooled, const float* xbar, int64_t q, const
     if (q == 0) return PPS_OK;
     static int once = set_lds(decode_tail_kernel, TL_LDS_BYTES);
     (void)once;
-    hipLaunchKernelGGL(decode_tail_kernel, dim3(grid_for((q + 127) / 128)), dim3(NT), TL_LDS_BYTES, (hipStream_t)stream,
+    hipLaunchKernelGGL(decode_tail_kernel, dim3(grid_for((q + NW * 16 - 1) / (NW * 16))), dim3(NT), TL_LDS_BYTES, (hipStream_t)stream,
                        pooled, xbar, q, wpack, bias, logits, occ);
     return PPS_LAUNCH_CHECK();
 }
