@@ -50,6 +50,29 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Sum over the 16 rows of EVERY channel of a 16-block tile (64 registers) in 240 instead of 576 VALU ops: a butterfly in
+// which each step halves the number of live registers (lanes with the step's bit set keep the upper half of the blocks and
+// hand the lower half to their partner, and vice versa).  On return lane (n,g) holds in v[0] the sums of block n:
+// channels 16*n + 4*g + r, r = 0..3 -> one contiguous ds_write_b128 / global store per lane.
+template <int CTRL>
+__device__ __forceinline__ f32x4 dpp_mov4(f32x4 v) { return f32x4{dpp_mov<CTRL>(v.x), dpp_mov<CTRL>(v.y), dpp_mov<CTRL>(v.z), dpp_mov<CTRL>(v.w)}; }
+
+template <int HALF, int CTRL>
+__device__ __forceinline__ void butterfly_step(f32x4* v, bool upper) {
+#pragma unroll
+    for (int b = 0; b < HALF; ++b) {
+        const f32x4 keep = upper ? v[b + HALF] : v[b];
+        const f32x4 send = upper ? v[b] : v[b + HALF];
+        v[b] = keep + dpp_mov4<CTRL>(send);
+    }
+}
+__device__ __forceinline__ void rows16_sum_transposed(f32x4 (&v)[16], int lane) {
+    butterfly_step<8, 0x128>(v, (lane & 8) != 0);    // row_ror:8   partner n ^ 8
+    butterfly_step<4, 0x141>(v, (lane & 4) != 0);    // row_half_mirror   partner flips bits 0..2
+    butterfly_step<2, 0x4E>(v, (lane & 2) != 0);     // quad_perm [2,3,0,1]   partner n ^ 2
+    butterfly_step<1, 0xB1>(v, (lane & 1) != 0);     // quad_perm [1,0,3,2]   partner n ^ 1
+}
+
 // ---- dense layer on a register tile ------------------------------------------------------------------
 // out[ob] = act( bias + sum_kb W[ob][kb] * in[kb] ),  weights read through `w` (LDS or global, packed layout,
 // pointing at the first f32x4 of (ob = OB0, kb = 0) for this lane's chunk), two output blocks in flight.

@@ -225,12 +225,9 @@ __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restr
         an += __shfl_xor(an, 16);
         an += __shfl_xor(an, 32);           // attention weight of row n (mean over the 64 heads)
 #pragma unroll
-        for (int bb = 0; bb < 16; ++bb) {
-            f32x4 p;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) p[r] = row16_sum(an * a[bb][r]);
-            if (n == 0) ((f32x4*)(part + wave * 256))[4 * bb + g] = p;
-        }
+        for (int bb = 0; bb < 16; ++bb) a[bb] *= an;
+        rows16_sum_transposed(a, lane);                     // lane (n,g): a[0] = sum over the 16 rows of block n
+        ((f32x4*)(part + wave * 256))[4 * n + g] = a[0];
         __syncthreads();
         if (wq == 0 && qv) {
             f32x4 s = ((const f32x4*)(part + (wbase + 0) * 256))[lane];
