@@ -9,6 +9,7 @@
 //
 // Reference semantics (eval mode, BatchNorm folded by the host, see ppsurf_amd/decoder.py):
 //   source/poco_model.py:381-419, source/base/nn.py:72-96,133-190,305-373,415-417, source/ppsurf_model.py:82-117.
+#include <cstdlib>
 #include "pps_common.h"
 #include "../../include/ppsurf_amd.h"
 
@@ -23,10 +24,11 @@ using namespace pps;
 
 // One pipeline step: request the NEXT chunk, compute on the CURRENT one, publish the next, barrier.
 // PPS_ABL_* macros are ablation switches for tools/ablate_interp.sh (never defined in the product build)
-template <int NF4_NEXT, class F>
+// CHUNK_F4_NEXT: size of the next chunk in f32x4; NTH: threads of the workgroup (all of them copy)
+template <int CHUNK_F4_NEXT, int NTH = NT, class F>
 __device__ __forceinline__ void stream_step(const f32x4* __restrict__ gnext, f32x4*& cur, f32x4*& nxt, F&& compute) {
 #ifndef PPS_ABL_NOSTREAM
-    chunk_copy_async<NF4_NEXT, NT>(gnext, nxt);
+    chunk_copy_async<CHUNK_F4_NEXT / NTH, NTH>(gnext, nxt);
 #endif
     compute((const f32x4*)cur);
 #ifndef PPS_ABL_NOBARRIER
@@ -37,13 +39,27 @@ __device__ __forceinline__ void stream_step(const f32x4* __restrict__ gnext, f32
 #endif
 }
 
-template <int NF4>
+template <int CHUNK_F4, int NTH = NT>
 __device__ __forceinline__ void stream_prologue(const f32x4* __restrict__ g, f32x4* buf) {
-    chunk_copy_async<NF4, NT>(g, buf);
+    chunk_copy_async<CHUNK_F4 / NTH, NTH>(g, buf);
 }
 
 __device__ __forceinline__ void lds_fill(float* dst, const float* __restrict__ src, int nfloats) {
-    for (int i = threadIdx.x; i < nfloats; i += NT) dst[i] = src[i];
+    for (int i = threadIdx.x; i < nfloats; i += blockDim.x) dst[i] = src[i];
+}
+
+// reductions over aligned groups of LO in {1,2,4,8} adjacent rows (lanes n): every lane of a group gets the result
+__device__ __forceinline__ float group_max(float v, int lo) {
+    if (lo >= 2) v = fmaxf(v, dpp_mov<0xB1>(v));
+    if (lo >= 4) v = fmaxf(v, dpp_mov<0x4E>(v));
+    if (lo >= 8) v = fmaxf(v, dpp_mov<0x141>(v));
+    return v;
+}
+__device__ __forceinline__ float group_sum(float v, int lo) {
+    if (lo >= 2) v += dpp_mov<0xB1>(v);
+    if (lo >= 4) v += dpp_mov<0x4E>(v);
+    if (lo >= 8) v += dpp_mov<0x141>(v);
+    return v;
 }
 
 template <int N>
@@ -73,7 +89,7 @@ __global__ __launch_bounds__(NT, 2) void rows_dense256_kernel(const float* __res
     const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
 
     lds_fill(bias_l, bias, 256);
-    stream_prologue<CH4 / NT>(wg, buf0);
+    stream_prologue<CH4>(wg, buf0);
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 
@@ -99,7 +115,7 @@ __global__ __launch_bounds__(NT, 2) void rows_dense256_kernel(const float* __res
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             f32x4 o[2];
-            stream_step<CH4 / NT>(wg + ((c + 1) & 7) * CH4, cur, nxt,
+            stream_step<CH4>(wg + ((c + 1) & 7) * CH4, cur, nxt,
                            [&](const f32x4* w) { dense_blocks<16, 2, 0>(a, o, w, bias4 + 8 * c, lane); });
             if (rv) { dst[4 * (2 * c)] = o[0]; dst[4 * (2 * c + 1)] = o[1]; }
         }
@@ -133,7 +149,7 @@ __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restr
 
     lds_fill(xyz_l, wpack, IP_W_XYZ);
     lds_fill(bias_l, bias, IP_NBIAS);
-    stream_prologue<CH4 / NT>(wg, buf0);
+    stream_prologue<CH4>(wg, buf0);
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 
@@ -164,15 +180,15 @@ __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restr
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c)
-            stream_step<CH4 / NT>(wg + (c + 1) * CH4, cur, nxt,
+            stream_step<CH4>(wg + (c + 1) * CH4, cur, nxt,
                            [&](const f32x4* w) { dense_blocks<16, 2, 1>(a, &b[2 * c], w, bias4 + 8 * c, lane); });
 #pragma unroll
         for (int c = 0; c < 8; ++c)
-            stream_step<CH4 / NT>(wg + (c + 9) * CH4, cur, nxt,
+            stream_step<CH4>(wg + (c + 9) * CH4, cur, nxt,
                            [&](const f32x4* w) { dense_blocks<16, 2, 1>(b, &a[2 * c], w, bias4 + 64 + 8 * c, lane); });
 #pragma unroll
         for (int c = 0; c < 2; ++c)
-            stream_step<CH4 / NT>(wg + ((c + 17) % 18) * CH4, cur, nxt,
+            stream_step<CH4>(wg + ((c + 17) % 18) * CH4, cur, nxt,
                            [&](const f32x4* w) { dense_blocks<16, 2, 0>(a, &b[2 * c], w, bias4 + 128 + 8 * c, lane); });
 
 #ifdef PPS_ABL_NOSOFTMAX
@@ -242,67 +258,121 @@ __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restr
 // =====================================================================================================
 // PointNet phase A: conv0a, conv0b, stn.conv1..3 (+ReLU), max over the patch -> g[q,256]
 // weights (floats): [xyz 256][c0b 4096][s1 4096][s2 8192][s3 32768]   bias [64][64][64][128][256]
+//
+// Row packing (both PointNet row kernels): a patch has P = 16*FB + LO rows.  When LO is 2, 4 or 8 (P = 50, 100, 200 of
+// configs/ppsurf_*nn.yaml) a wave owns QG = 16/LO queries at a time and evaluates their LO left-over rows TOGETHER in
+// one 16-row tile (group-reduced per query and parked in LDS), then the FB full tiles of each query: no padded rows
+// (P = 50: 25 tiles per 8 queries instead of 32).  Any other P falls back to ceil(P/16) tiles per query with the
+// padding rows repeating a valid point (max) / masked (softmax).
 // =====================================================================================================
+#define PNT 512                // threads of the PointNet row kernels (8 waves, one workgroup per CU)
+#define PNW (PNT / 64)
+#define PN_ROWF 260            // floats per parked left-over row (256 + pad against bank conflicts)
 #define PA_W_XYZ 256
 #define PA_NBIAS 576
-#define PA_LDS_BYTES (2 * CH4 * 16 + (PA_W_XYZ + PA_NBIAS) * 4)
+#define PN_PARK_ROWS 8         // parked rows per wave = max queries per wave group
+#define PA_LDS_BYTES (2 * CH4 * 16 + (PA_W_XYZ + PA_NBIAS + PNW * PN_PARK_ROWS * PN_ROWF) * 4)
 
-__global__ __launch_bounds__(NT, 2) void pointnet_stn_rows_kernel(const float* __restrict__ patches, int64_t Q, int P,
-                                                                  const float* __restrict__ wpack, const float* __restrict__ bias,
-                                                                  float* __restrict__ gout) {
+struct PatchPacking {
+    int fb, lo, qg, tiles_per_query;      // full tiles, left-over rows, queries per wave group, tiles evaluated per query
+    bool packed;
+};
+__host__ __device__ inline PatchPacking patch_packing(int P, bool allow = true) {
+    PatchPacking k;
+    const int lo = P & 15;
+    k.packed = allow && (P >= 16) && (lo == 2 || lo == 4 || lo == 8);
+    k.fb = k.packed ? P / 16 : (P + 15) / 16;
+    k.lo = k.packed ? lo : 0;
+    k.qg = k.packed ? 16 / lo : 1;
+    k.tiles_per_query = k.fb;
+    return k;
+}
+
+// conv0a .. stn.conv3 on one 16-row tile; z = 256 channels
+__device__ __forceinline__ void stn_chain(float coord, f32x4 (&z)[16], const float* xyz_l, const f32x4* bias4, const f32x4* wg,
+                                          f32x4*& cur, f32x4*& nxt, int lane) {
+    const int g = lane >> 4;
+    f32x4 x0[4], x1[4], y[8];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) x0[bb] = bias4[4 * bb + g];
+    xyz_blocks<4>(coord, x0, xyz_l, lane);
+    relu_blocks<4>(x0);
+    stream_step<1024, PNT>(wg + 1024, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 16, lane); });
+    stream_step<CH4, PNT>(wg + 2048, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x1, x0, w, bias4 + 32, lane); });
+    stream_step<CH4, PNT>(wg + 4096, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 8, 1>(x0, y, w, bias4 + 48, lane); });
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        stream_step<CH4, PNT>(wg + 6144 + c * CH4, cur, nxt,
+                              [&](const f32x4* w) { dense_blocks<8, 4, 1>(y, &z[4 * c], w, bias4 + 80 + 16 * c, lane); });
+    stream_step<1024, PNT>(wg, cur, nxt, [&](const f32x4* w) { dense_blocks<8, 4, 1>(y, &z[12], w, bias4 + 80 + 48, lane); });
+}
+
+__global__ __launch_bounds__(PNT, 2) void pointnet_stn_rows_kernel(const float* __restrict__ patches, int64_t Q, int P, int pack,
+                                                                   const float* __restrict__ wpack, const float* __restrict__ bias,
+                                                                   float* __restrict__ gout) {
     f32x4* buf0 = (f32x4*)pps_smem;
     f32x4* buf1 = buf0 + CH4;
     float* xyz_l = (float*)(buf1 + CH4);
     float* bias_l = xyz_l + PA_W_XYZ;
+    float* park = bias_l + PA_NBIAS;                       // [PNW][PN_PARK_ROWS][PN_ROWF] per-query left-over maxima
     const f32x4* bias4 = (const f32x4*)bias_l;
     const f32x4* wg = (const f32x4*)(wpack + PA_W_XYZ);
     const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    float* mypark = park + wave * PN_PARK_ROWS * PN_ROWF;
 
     lds_fill(xyz_l, wpack, PA_W_XYZ);
     lds_fill(bias_l, bias, PA_NBIAS);
-    stream_prologue<1024 / NT>(wg, buf0);
+    stream_prologue<1024, PNT>(wg, buf0);
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 
-    const int nrb = (P + 15) / 16;
-    const int ntiles = (int)((Q + NW - 1) / NW);
+    const PatchPacking pk = patch_packing(P, pack != 0);
+    const int64_t ngroups = (Q + pk.qg - 1) / pk.qg;
+    const int ntiles = (int)((ngroups + PNW - 1) / PNW);
     int first, count, stride;
     xcd_tile_range(ntiles, first, count, stride);
     for (int it = 0; it < count; ++it) {
-        const int64_t qi = (int64_t)(first + it * stride) * NW + wave;
-        const bool qv = qi < Q;
-        const int64_t qc = qv ? qi : Q - 1;
-        f32x4 rmax[16];
+        const int64_t q0 = ((int64_t)(first + it * stride) * PNW + wave) * pk.qg;
+        f32x4 z[16];
+        if (pk.packed) {
+            // the LO left-over rows of the QG queries of this wave, one tile
+            const int ql = n / pk.lo;
+            const int64_t qq = (q0 + ql < Q) ? q0 + ql : Q - 1;
+            const float coord = (g < 3) ? patches[(qq * P + pk.fb * 16 + (n % pk.lo)) * 3 + g] : 0.f;
+            stn_chain(coord, z, xyz_l, bias4, wg, cur, nxt, lane);
 #pragma unroll
-        for (int bb = 0; bb < 16; ++bb) rmax[bb] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        for (int rb = 0; rb < nrb; ++rb) {
-            const int row = rb * 16 + n;
-            const int rowc = row < P ? row : P - 1;           // padded rows repeat a valid point: max unaffected
-            const float coord = (g < 3) ? patches[(qc * P + rowc) * 3 + g] : 0.f;
-            f32x4 x0[4], x1[4], y[8], z[16];
+            for (int bb = 0; bb < 16; ++bb) {
+                f32x4 m;
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb) x0[bb] = bias4[4 * bb + g];
-            xyz_blocks<4>(coord, x0, xyz_l, lane);
-            relu_blocks<4>(x0);
-            stream_step<1024 / NT>(wg + 1024, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 16, lane); });
-            stream_step<CH4 / NT>(wg + 2048, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x1, x0, w, bias4 + 32, lane); });
-            stream_step<CH4 / NT>(wg + 4096, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 8, 1>(x0, y, w, bias4 + 48, lane); });
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                stream_step<CH4 / NT>(wg + 6144 + c * CH4, cur, nxt,
-                               [&](const f32x4* w) { dense_blocks<8, 4, 1>(y, &z[4 * c], w, bias4 + 80 + 16 * c, lane); });
-            stream_step<1024 / NT>(wg, cur, nxt, [&](const f32x4* w) { dense_blocks<8, 4, 1>(y, &z[12], w, bias4 + 80 + 48, lane); });
+                for (int r = 0; r < 4; ++r) m[r] = group_max(z[bb][r], pk.lo);
+                if ((n % pk.lo) == 0) ((f32x4*)(mypark + ql * PN_ROWF))[4 * bb + g] = m;
+            }
+        }
+        for (int qi = 0; qi < pk.qg; ++qi) {
+            const int64_t q = q0 + qi;
+            const bool qv = q < Q;
+            const int64_t qc = qv ? q : Q - 1;
+            f32x4 rmax[16];
 #pragma unroll
             for (int bb = 0; bb < 16; ++bb)
+                rmax[bb] = pk.packed ? ((const f32x4*)(mypark + qi * PN_ROWF))[4 * bb + g] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            for (int rb = 0; rb < pk.fb; ++rb) {
+                const int row = rb * 16 + n;
+                const int rowc = row < P ? row : P - 1;       // padded rows repeat a valid point: max unaffected
+                const float coord = (g < 3) ? patches[(qc * P + rowc) * 3 + g] : 0.f;
+                stn_chain(coord, z, xyz_l, bias4, wg, cur, nxt, lane);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) rmax[bb][r] = fmaxf(rmax[bb][r], z[bb][r]);
-        }
+                for (int bb = 0; bb < 16; ++bb)
 #pragma unroll
-        for (int bb = 0; bb < 16; ++bb) {
-            f32x4 p;
+                    for (int r = 0; r < 4; ++r) rmax[bb][r] = fmaxf(rmax[bb][r], z[bb][r]);
+            }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) p[r] = row16_max(rmax[bb][r]);
-            if (n == 0 && qv) ((f32x4*)(gout + qi * 256))[4 * bb + g] = p;
+            for (int bb = 0; bb < 16; ++bb) {
+                f32x4 p;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[r] = row16_max(rmax[bb][r]);
+                if (n == 0 && qv) ((f32x4*)(gout + q * 256))[4 * bb + g] = p;
+            }
         }
     }
 }
@@ -325,7 +395,7 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_kernel(const float* __r
     const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
 
     lds_fill(bias_l, bias, PB_NBIAS);
-    stream_prologue<CH4 / NT>(wg, buf0);
+    stream_prologue<CH4>(wg, buf0);
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 
@@ -344,15 +414,15 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_kernel(const float* __r
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            stream_step<CH4 / NT>(wg + (c + 1) * CH4, cur, nxt,
+            stream_step<CH4>(wg + (c + 1) * CH4, cur, nxt,
                            [&](const f32x4* w) { dense_blocks<16, 2, 1>(a, &h[2 * c], w, bias4 + 8 * c, lane); });
-        stream_step<CH4 / NT>(wg + 5 * CH4, cur, nxt, [&](const f32x4* w) { dense_blocks<8, 4, 1>(h, u, w, bias4 + 32, lane); });
+        stream_step<CH4>(wg + 5 * CH4, cur, nxt, [&](const f32x4* w) { dense_blocks<8, 4, 1>(h, u, w, bias4 + 32, lane); });
         f32x4* dst = (f32x4*)(trans2 + qc * 4096) + g;
 #pragma unroll 1
         for (int c = 0; c < 32; ++c) {
             f32x4 o[8];
             const f32x4* gn = (c + 1 < 32) ? wg + (6 + c) * CH4 : wg;
-            stream_step<CH4 / NT>(gn, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 8, 0>(u, o, w, bias4 + 48 + 32 * c, lane); });
+            stream_step<CH4>(gn, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 8, 0>(u, o, w, bias4 + 48 + 32 * c, lane); });
             if (qv) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dst[4 * (8 * c + j)] = o[j];
@@ -364,107 +434,157 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_kernel(const float* __r
 // =====================================================================================================
 // PointNet phase C: conv0a, conv0b, x <- trans2 x, conv1, conv2 (+ReLU), conv3 (no ReLU), attention pooling
 // weights (floats): [xyz 256][c0b 4096][c1 4096][c2 8192][c3 32768]   bias [64][64][64][128][256][wq 256][bq 4]
+// Row packing as in phase A; the left-over tile parks, per query, the softmax partials (max m, sum S, weighted sum A[256]).
 // =====================================================================================================
 #define PC_W_XYZ 256
 #define PC_NBIAS (576 + 256 + 4)
-#define PC_LDS_BYTES (2 * CH4 * 16 + (PC_W_XYZ + PC_NBIAS) * 4)
+#define PC_LDS_BYTES (2 * CH4 * 16 + (PC_W_XYZ + PC_NBIAS + PNW * PN_PARK_ROWS * PN_ROWF) * 4)
 
-__global__ __launch_bounds__(NT, 2) void pointnet_feat_rows_kernel(const float* __restrict__ patches, const float* __restrict__ trans2,
-                                                                   int64_t Q, int P, const float* __restrict__ wpack,
-                                                                   const float* __restrict__ bias, float* __restrict__ xbar) {
+// conv0a .. conv3 on one 16-row tile of query `tq` (per-row feature transform), then the attention logit of each row
+// rows_per_query = 16 and nq = 1 for a tile of one query; a left-over tile holds nq queries x rows_per_query rows
+__device__ __forceinline__ float feat_chain(float coord, const float* __restrict__ trans2, int64_t q0, int64_t Q, int nq, int rows_per_query,
+                                            f32x4 (&z)[16], const float* xyz_l, const f32x4* bias4, const f32x4* wq4, float bq,
+                                            const f32x4* wg, f32x4*& cur, f32x4*& nxt, int lane) {
+    const int n = lane & 15, g = lane >> 4;
+    f32x4 x0[4], x1[4], y[8];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) x0[bb] = bias4[4 * bb + g];
+    xyz_blocks<4>(coord, x0, xyz_l, lane);
+    relu_blocks<4>(x0);
+    stream_step<1024, PNT>(wg + 1024, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 16, lane); });
+    // feature transform x0 = trans2[q] (64x64, row-major) @ x1, A operand straight from global.  The A operand is shared by
+    // the 16 columns of an MFMA, so a tile holding rows of nq different queries is done as nq accumulating products with
+    // the columns of the other queries zeroed (nq = 1 for the full tiles: one product, no masking cost).
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) x0[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int qi = 0; qi < nq; ++qi) {
+        const int64_t qq = (q0 + qi < Q) ? q0 + qi : Q - 1;
+        const f32x4* tq = (const f32x4*)(trans2 + qq * 4096);
+        const bool mine = (n / rows_per_query) == qi;
+        f32x4 xm[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) xm[kb] = mine ? x1[kb] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            f32x4 t[4];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) t[kb] = tq[(16 * ob + n) * 16 + 4 * kb + g];
+            f32x4 o = x0[ob];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(t[kb].x, xm[kb].x, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(t[kb].y, xm[kb].y, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(t[kb].z, xm[kb].z, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x4f32(t[kb].w, xm[kb].w, o, 0, 0, 0);
+            }
+            x0[ob] = o;
+        }
+    }
+    stream_step<CH4, PNT>(wg + 2048, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 32, lane); });
+    stream_step<CH4, PNT>(wg + 4096, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 8, 1>(x1, y, w, bias4 + 48, lane); });
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        stream_step<CH4, PNT>(wg + 6144 + c * CH4, cur, nxt,
+                              [&](const f32x4* w) { dense_blocks<8, 4, 0>(y, &z[4 * c], w, bias4 + 80 + 16 * c, lane); });
+    stream_step<1024, PNT>(wg, cur, nxt, [&](const f32x4* w) { dense_blocks<8, 4, 0>(y, &z[12], w, bias4 + 80 + 48, lane); });
+    float s = 0.f;                                   // attention logit of row n (nn.py:88)
+#pragma unroll
+    for (int bb = 0; bb < 16; ++bb) {
+        const f32x4 w4 = wq4[4 * bb + g];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += w4[r] * z[bb][r];
+    }
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    return s + bq;
+}
+
+__global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float* __restrict__ patches, const float* __restrict__ trans2,
+                                                                    int64_t Q, int P, int pack, const float* __restrict__ wpack,
+                                                                    const float* __restrict__ bias, float* __restrict__ xbar) {
     f32x4* buf0 = (f32x4*)pps_smem;
     f32x4* buf1 = buf0 + CH4;
     float* xyz_l = (float*)(buf1 + CH4);
     float* bias_l = xyz_l + PC_W_XYZ;
+    float* park = bias_l + PC_NBIAS;                   // [PNW][PN_PARK_ROWS][PN_ROWF]: A[256], m, S of the left-over rows
     const f32x4* bias4 = (const f32x4*)bias_l;
     const f32x4* wq4 = bias4 + 144;
     const f32x4* wg = (const f32x4*)(wpack + PC_W_XYZ);
     const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    float* mypark = park + wave * PN_PARK_ROWS * PN_ROWF;
 
     lds_fill(xyz_l, wpack, PC_W_XYZ);
     lds_fill(bias_l, bias, PC_NBIAS);
-    stream_prologue<1024 / NT>(wg, buf0);
+    stream_prologue<1024, PNT>(wg, buf0);
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
     const float bq = bias_l[576 + 256];
 
-    const int nrb = (P + 15) / 16;
-    const int ntiles = (int)((Q + NW - 1) / NW);
+    const PatchPacking pk = patch_packing(P, pack != 0);
+    const int64_t ngroups = (Q + pk.qg - 1) / pk.qg;
+    const int ntiles = (int)((ngroups + PNW - 1) / PNW);
     int first, count, stride;
     xcd_tile_range(ntiles, first, count, stride);
     for (int it = 0; it < count; ++it) {
-        const int64_t qi = (int64_t)(first + it * stride) * NW + wave;
-        const bool qv = qi < Q;
-        const int64_t qc = qv ? qi : Q - 1;
-        const f32x4* tq = (const f32x4*)(trans2 + qc * 4096);
-        f32x4 acc[16];
-#pragma unroll
-        for (int bb = 0; bb < 16; ++bb) acc[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float mrun = -INFINITY, ssum = 0.f;
-        for (int rb = 0; rb < nrb; ++rb) {
-            const int row = rb * 16 + n;
-            const bool valid = row < P;
-            const int rowc = valid ? row : P - 1;
-            const float coord = (g < 3) ? patches[(qc * P + rowc) * 3 + g] : 0.f;
-            f32x4 x0[4], x1[4], y[8], z[16];
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) x0[bb] = bias4[4 * bb + g];
-            xyz_blocks<4>(coord, x0, xyz_l, lane);
-            relu_blocks<4>(x0);
-            stream_step<1024 / NT>(wg + 1024, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 16, lane); });
-            // feature transform x0 = trans2[q] (64x64, row-major) @ x1: A operand straight from global
-#pragma unroll
-            for (int ob = 0; ob < 4; ++ob) {
-                f32x4 t[4];
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) t[kb] = tq[(16 * ob + n) * 16 + 4 * kb + g];
-                f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(t[kb].x, x1[kb].x, o, 0, 0, 0);
-                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(t[kb].y, x1[kb].y, o, 0, 0, 0);
-                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(t[kb].z, x1[kb].z, o, 0, 0, 0);
-                    o = __builtin_amdgcn_mfma_f32_16x16x4f32(t[kb].w, x1[kb].w, o, 0, 0, 0);
-                }
-                x0[ob] = o;
-            }
-            stream_step<CH4 / NT>(wg + 2048, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 32, lane); });
-            stream_step<CH4 / NT>(wg + 4096, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 8, 1>(x1, y, w, bias4 + 48, lane); });
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                stream_step<CH4 / NT>(wg + 6144 + c * CH4, cur, nxt,
-                               [&](const f32x4* w) { dense_blocks<8, 4, 0>(y, &z[4 * c], w, bias4 + 80 + 16 * c, lane); });
-            stream_step<1024 / NT>(wg, cur, nxt, [&](const f32x4* w) { dense_blocks<8, 4, 0>(y, &z[12], w, bias4 + 80 + 48, lane); });
-
-            // attention logit of row n (nn.py:88), online softmax over the patch points (nn.py:91-93)
-            float s = 0.f;
+        const int64_t q0 = ((int64_t)(first + it * stride) * PNW + wave) * pk.qg;
+        f32x4 z[16];
+        if (pk.packed) {
+            const int ql = n / pk.lo;
+            const int64_t qq = (q0 + ql < Q) ? q0 + ql : Q - 1;
+            const float coord = (g < 3) ? patches[(qq * P + pk.fb * 16 + (n % pk.lo)) * 3 + g] : 0.f;
+            const float s = feat_chain(coord, trans2, q0, Q, pk.qg, pk.lo, z, xyz_l, bias4, wq4, bq, wg, cur, nxt, lane);
+            const float m = group_max(s, pk.lo);
+            const float e = __expf(s - m);
+            const float S = group_sum(e, pk.lo);
+            float* row = mypark + ql * PN_ROWF;
 #pragma unroll
             for (int bb = 0; bb < 16; ++bb) {
-                const f32x4 w4 = wq4[4 * bb + g];
+                f32x4 a4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s += w4[r] * z[bb][r];
+                for (int r = 0; r < 4; ++r) a4[r] = group_sum(e * z[bb][r], pk.lo);
+                if ((n % pk.lo) == 0) ((f32x4*)row)[4 * bb + g] = a4;
             }
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            s += bq;
-            const float mblk = row16_max(valid ? s : -INFINITY);
-            const float mnew = fmaxf(mrun, mblk);
-            const float scale = __expf(mrun - mnew);
-            const float en = valid ? __expf(s - mnew) : 0.f;
-            mrun = mnew;
-            ssum = ssum * scale + en;
-#pragma unroll
-            for (int bb = 0; bb < 16; ++bb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[bb][r] = acc[bb][r] * scale + en * z[bb][r];
+            if ((n % pk.lo) == 0 && g == 0) { row[256] = m; row[257] = S; }
         }
-        const float inv = 1.f / row16_sum(ssum);
+        for (int qi = 0; qi < pk.qg; ++qi) {
+            const int64_t q = q0 + qi;
+            const bool qv = q < Q;
+            const int64_t qc = qv ? q : Q - 1;
+            const float* row = mypark + qi * PN_ROWF;
+            // per-lane (unreduced) online-softmax state; the parked left-over partials seed lane n == 0
+            f32x4 acc[16];
+            float mrun = -INFINITY, ssum = 0.f;
+            if (pk.packed) {
+                mrun = row[256];
+                ssum = (n == 0) ? row[257] : 0.f;
+            }
 #pragma unroll
-        for (int bb = 0; bb < 16; ++bb) {
-            f32x4 p;
+            for (int bb = 0; bb < 16; ++bb) {
+                const f32x4 a4 = pk.packed ? ((const f32x4*)row)[4 * bb + g] : f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[bb] = (pk.packed && n == 0) ? a4 : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            for (int rb = 0; rb < pk.fb; ++rb) {
+                const int rowi = rb * 16 + n;
+                const bool valid = rowi < P;
+                const int rowc = valid ? rowi : P - 1;
+                const float coord = (g < 3) ? patches[(qc * P + rowc) * 3 + g] : 0.f;
+                const float s = feat_chain(coord, trans2, qc, Q, 1, 16, z, xyz_l, bias4, wq4, bq, wg, cur, nxt, lane);
+                // online softmax over the patch points (nn.py:91-93)
+                const float mblk = row16_max(valid ? s : -INFINITY);
+                const float mnew = fmaxf(mrun, mblk);
+                const float scale = __expf(mrun - mnew);
+                const float en = valid ? __expf(s - mnew) : 0.f;
+                mrun = mnew;
+                ssum = ssum * scale + en;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) p[r] = row16_sum(acc[bb][r]) * inv;
-            if (n == 0 && qv) ((f32x4*)(xbar + qi * 256))[4 * bb + g] = p;
+                for (int bb = 0; bb < 16; ++bb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[bb][r] = acc[bb][r] * scale + en * z[bb][r];
+            }
+            const float inv = 1.f / row16_sum(ssum);
+            rows16_sum_transposed(acc, lane);             // lane (n,g): acc[0] = sum over the 16 lanes of block n
+            if (qv) ((f32x4*)(xbar + q * 256))[4 * n + g] = acc[0] * inv;
         }
     }
 }
@@ -487,7 +607,7 @@ __global__ __launch_bounds__(NT, 2) void decode_tail_kernel(const float* __restr
     const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
 
     lds_fill(bias_l, bias, TL_NBIAS);
-    stream_prologue<CH4 / NT>(wg, buf0);
+    stream_prologue<CH4>(wg, buf0);
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 
@@ -507,18 +627,18 @@ __global__ __launch_bounds__(NT, 2) void decode_tail_kernel(const float* __restr
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c)
-            stream_step<CH4 / NT>(wg + (c + 1) * CH4, cur, nxt,
+            stream_step<CH4>(wg + (c + 1) * CH4, cur, nxt,
                            [&](const f32x4* w) { dense_blocks<16, 2, 0>(p, &h[2 * c], w, bias4 + 8 * c, lane); });
 #pragma unroll
         for (int c = 0; c < 8; ++c)
-            stream_step<CH4 / NT>(wg + (c + 9) * CH4, cur, nxt,
+            stream_step<CH4>(wg + (c + 9) * CH4, cur, nxt,
                            [&](const f32x4* w) { dense_blocks<16, 2, 1, 1>(x, &h[2 * c], w, bias4, lane); });
 #pragma unroll
         for (int c = 0; c < 8; ++c)
-            stream_step<CH4 / NT>(wg + (c + 17) * CH4, cur, nxt,
+            stream_step<CH4>(wg + (c + 17) * CH4, cur, nxt,
                            [&](const f32x4* w) { dense_blocks<16, 2, 1>(h, &p[2 * c], w, bias4 + 64 + 8 * c, lane); });
         f32x4 o[2];
-        stream_step<CH4 / NT>(wg, cur, nxt, [&](const f32x4* w) { dense_blocks<16, 2, 0>(p, o, w, bias4 + 128, lane); });
+        stream_step<CH4>(wg, cur, nxt, [&](const f32x4* w) { dense_blocks<16, 2, 0>(p, o, w, bias4 + 128, lane); });
         if (qv && g == 0) {
             const float l0 = o[0].x, l1 = o[0].y;
             logits[qi * 2] = l0;
@@ -558,6 +678,24 @@ static int grid_for(int64_t ntiles) {
     return (int)(ntiles < cus ? (ntiles > 0 ? ntiles : 1) : cus);
 }
 
+// PointNet row kernels: one 8-wave workgroup per CU.  Packed wave groups (qg queries, no padded rows) are used for as many
+// FULL rounds over all waves of the chip as the query count allows; the remainder runs one query per wave so that the last
+// round is short instead of a whole packed group (Q = 50000, P = 50: 3 x 25 + 4 tiles per wave instead of 100).
+struct PnSplit { int64_t q_packed; int grid_packed, grid_rest; };
+static PnSplit pn_split(int64_t q, int p) {
+    int cus = cu_count();
+    if (cus <= 0) cus = 256;
+    const PatchPacking pk = patch_packing(p);
+    PnSplit sp;
+    const int64_t per_round = (int64_t)cus * PNW * pk.qg;
+    sp.q_packed = pk.packed ? (q / per_round) * per_round : 0;
+    if (pk.packed && getenv("PPS_PN_FORCE_PACK")) sp.q_packed = q;      // test hook: packed path for any query count
+    sp.grid_packed = cus;
+    const int64_t rest_tiles = (q - sp.q_packed + PNW - 1) / PNW;
+    sp.grid_rest = (int)(rest_tiles < cus ? rest_tiles : cus);
+    return sp;
+}
+
 #define PPS_LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH)
 
 extern "C" {
@@ -568,8 +706,8 @@ int pps_abi_version(void) { return 1; }
 int pps_debug_occupancy(int which) {
     int n = -1;
     if (which == 0) { set_lds(interp_pool_kernel, IP_LDS_BYTES); hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, interp_pool_kernel, NT, IP_LDS_BYTES); }
-    if (which == 1) { set_lds(pointnet_stn_rows_kernel, PA_LDS_BYTES); hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pointnet_stn_rows_kernel, NT, PA_LDS_BYTES); }
-    if (which == 2) { set_lds(pointnet_feat_rows_kernel, PC_LDS_BYTES); hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pointnet_feat_rows_kernel, NT, PC_LDS_BYTES); }
+    if (which == 1) { set_lds(pointnet_stn_rows_kernel, PA_LDS_BYTES); hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pointnet_stn_rows_kernel, PNT, PA_LDS_BYTES); }
+    if (which == 2) { set_lds(pointnet_feat_rows_kernel, PC_LDS_BYTES); hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pointnet_feat_rows_kernel, PNT, PC_LDS_BYTES); }
     return n;
 }
 int pps_device_cu_count(void) { return cu_count(); }
@@ -603,8 +741,13 @@ int pps_pointnet_stn_rows_f32(const float* patches, int64_t q, int p, const floa
     if (q == 0) return PPS_OK;
     static int once = set_lds(pointnet_stn_rows_kernel, PA_LDS_BYTES);
     (void)once;
-    hipLaunchKernelGGL(pointnet_stn_rows_kernel, dim3(grid_for((q + NW - 1) / NW)), dim3(NT), PA_LDS_BYTES, (hipStream_t)stream,
-                       patches, q, p, wpack, bias, g);
+    const PnSplit sp = pn_split(q, p);
+    if (sp.q_packed > 0)
+        hipLaunchKernelGGL(pointnet_stn_rows_kernel, dim3(sp.grid_packed), dim3(PNT), PA_LDS_BYTES, (hipStream_t)stream, patches,
+                           sp.q_packed, p, 1, wpack, bias, g);
+    if (q > sp.q_packed)
+        hipLaunchKernelGGL(pointnet_stn_rows_kernel, dim3(sp.grid_rest), dim3(PNT), PA_LDS_BYTES, (hipStream_t)stream,
+                           patches + sp.q_packed * p * 3, q - sp.q_packed, p, 0, wpack, bias, g + sp.q_packed * 256);
     return PPS_LAUNCH_CHECK();
 }
 
@@ -624,8 +767,14 @@ int pps_pointnet_feat_rows_f32(const float* patches, const float* trans2, int64_
     if (q == 0) return PPS_OK;
     static int once = set_lds(pointnet_feat_rows_kernel, PC_LDS_BYTES);
     (void)once;
-    hipLaunchKernelGGL(pointnet_feat_rows_kernel, dim3(grid_for((q + NW - 1) / NW)), dim3(NT), PC_LDS_BYTES, (hipStream_t)stream,
-                       patches, trans2, q, p, wpack, bias, xbar);
+    const PnSplit sp = pn_split(q, p);
+    if (sp.q_packed > 0)
+        hipLaunchKernelGGL(pointnet_feat_rows_kernel, dim3(sp.grid_packed), dim3(PNT), PC_LDS_BYTES, (hipStream_t)stream, patches,
+                           trans2, sp.q_packed, p, 1, wpack, bias, xbar);
+    if (q > sp.q_packed)
+        hipLaunchKernelGGL(pointnet_feat_rows_kernel, dim3(sp.grid_rest), dim3(PNT), PC_LDS_BYTES, (hipStream_t)stream,
+                           patches + sp.q_packed * p * 3, trans2 + sp.q_packed * 4096, q - sp.q_packed, p, 0, wpack, bias,
+                           xbar + sp.q_packed * 256);
     return PPS_LAUNCH_CHECK();
 }
 

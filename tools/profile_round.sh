@@ -14,7 +14,7 @@ rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.l
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -d $OUT/pmc_mfma -o pmc -- $BENCH > $OUT/pmc_mfma.log 2>&1
 cd - > /dev/null
-find $OUT -name "*.csv" | head -30
-# keep the merge small: drop the big per-dispatch traces, keep stats + counter csv
-find $OUT -name "*kernel_trace.csv" -size +8M -delete
+# summarise on the box, then drop the rocpd databases (tens of MB) so that the merge back stays small
+python tools/rocpd_summary.py $OUT $OUT/summary > /dev/null
+find $OUT -name "*.db" -delete
 du -sh $OUT
