@@ -40,9 +40,12 @@ int pps_knn_f32(const float* pts, int64_t n, const float* query, int64_t m, int 
  * bounding boxes so that whole blocks are rejected against the running k-th distance (exact: the box bound is evaluated in
  * the same rounding order as d2).  Built once per cloud by the caller (ppsurf_amd/ops.py `KnnBlocks`):
  * pts_blocked [nb*64,3] (points in block order, tail padded), orig_idx int32 [nb*64] (original index, -1 for padding),
- * bbox [nb,6] (min xyz, max xyz of the valid points of the block), n = number of valid points ((nb-1)*64 < n <= nb*64). */
+ * bbox [nb,6] (min xyz, max xyz of the valid points of the block), n = number of valid points ((nb-1)*64 < n <= nb*64);
+ * win_bbox [n_win,6]: boxes of windows of ceil(k/64) consecutive FULL blocks (each holds >= k points: their farthest
+ * corner bounds the k-th distance from above; n_win may be 0).  Here k <= min(n, 256). */
 int pps_knn_blocked_f32(const float* pts_blocked, const int32_t* orig_idx, const float* bbox, int64_t nb, int64_t n,
-                        const float* query, int64_t m, int k, int64_t* out_idx, float* out_d2, void* stream);
+                        const float* win_bbox, int64_t n_win, const float* query, int64_t m, int k, int64_t* out_idx,
+                        float* out_d2, void* stream);
 
 /* Gather P neighbours per query from the raw cloud, centre at the query, divide by the max neighbour distance.
  * replaces: source/poco_utils.py:67-72 `_get_pts_local_ps` (gather + normalise part) and

@@ -138,31 +138,56 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(const float* __rest
 // Results are bit-identical to knn_kernel: candidates are tested with d2 <= tau and ordered by the full (d2, original
 // index) key in the merge network.
 // ---------------------------------------------------------------------------------------------------------------
+// two sorted 64-lists -> lower (returned in a) and upper (returned in b) sorted halves of their union
+__device__ __forceinline__ void wave_merge2(u64& a, u64& b, int lane) {
+    const u64 rev = shfl_u64(b, 63 - lane);
+    const u64 lo = a < rev ? a : rev, hi = a < rev ? rev : a;
+    a = wave_bitonic_merge64(lo, lane);
+    b = wave_bitonic_merge64(hi, lane);
+}
+
+// sorted list of 64*R keys, element e = r*64 + lane; merge the buffered candidates, keep the 64*R smallest
+template <int R>
+__device__ __forceinline__ void knn_flush_r(u64 (&list)[R], const u64* cand, int cnt, int lane) {
+    while (cnt > 0) {
+        const int c = cnt < 64 ? cnt : 64;
+        u64 carry = (lane < c) ? cand[cnt - c + lane] : ~0ull;
+        carry = wave_sort64(carry, lane);
+#pragma unroll
+        for (int r = 0; r < R; ++r) wave_merge2(list[r], carry, lane);
+        cnt -= c;
+    }
+}
+
+template <int R>
 __global__ __launch_bounds__(KNN_WAVES * 64) void knn_blocked_kernel(const float* __restrict__ pts, const int* __restrict__ orig,
-                                                                     const float* __restrict__ bbox, int nb, int nb_full,
+                                                                     const float* __restrict__ bbox, int nb,
+                                                                     const float* __restrict__ win_bbox, int n_win,
                                                                      const float* __restrict__ query, int64_t m, int k,
                                                                      int64_t* __restrict__ out_idx, float* __restrict__ out_d2) {
     __shared__ u64 cand_all[KNN_WAVES][KNN_QW][KNN_CAP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kr = (k - 1) >> 6, kl = (k - 1) & 63;          // register / lane of the k-th key
     const int64_t ntask = (m + KNN_QW - 1) / KNN_QW;
     for (int64_t task = (int64_t)blockIdx.x * KNN_WAVES + wave; task < ntask; task += (int64_t)gridDim.x * KNN_WAVES) {
         const int64_t q0 = task * KNN_QW;
         float qx[KNN_QW], qy[KNN_QW], qz[KNN_QW], tau[KNN_QW];
-        u64 list[KNN_QW];
+        u64 list[KNN_QW][R];
         int cnt[KNN_QW];
 #pragma unroll
         for (int j = 0; j < KNN_QW; ++j) {
             const int64_t qq = (q0 + j < m) ? q0 + j : m - 1;
             qx[j] = __shfl(query[qq * 3], 0); qy[j] = __shfl(query[qq * 3 + 1], 0); qz[j] = __shfl(query[qq * 3 + 2], 0);
             tau[j] = INFINITY;
-            list[j] = ~0ull;
+#pragma unroll
+            for (int r = 0; r < R; ++r) list[j][r] = ~0ull;
             cnt[j] = 0;
         }
-        // ---- initial tau: min over full blocks of the farthest-corner distance -------------------------------------
-        for (int b0 = 0; b0 < nb_full; b0 += 64) {
+        // ---- initial tau: min over windows of R full blocks (>= k points) of the farthest-corner distance ------------
+        for (int b0 = 0; b0 < n_win; b0 += 64) {
             const int b = b0 + lane;
-            const bool bv = b < nb_full;
-            const float* bb = bbox + (int64_t)(bv ? b : 0) * 6;
+            const bool bv = b < n_win;
+            const float* bb = win_bbox + (int64_t)(bv ? b : 0) * 6;
             const float lx = bb[0], ly = bb[1], lz = bb[2], hx = bb[3], hy = bb[4], hz = bb[5];
 #pragma unroll
             for (int j = 0; j < KNN_QW; ++j) {
@@ -212,9 +237,9 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_blocked_kernel(const float
                         if (pass) cand[pos] = ((u64)__float_as_uint(d2) << 32) | (unsigned)oi;
                         cnt[j] += __popcll(mask);
                         if (cnt[j] > KNN_CAP - 64) {
-                            list[j] = knn_flush(list[j], cand, cnt[j], lane);
+                            knn_flush_r<R>(list[j], cand, cnt[j], lane);
                             cnt[j] = 0;
-                            tau[j] = fminf(tau[j], __uint_as_float((unsigned)(shfl_u64(list[j], k - 1) >> 32)));
+                            tau[j] = fminf(tau[j], __uint_as_float((unsigned)(shfl_u64(list[j][kr < R ? kr : R - 1], kl) >> 32)));
                         }
                     }
                 }
@@ -222,10 +247,16 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_blocked_kernel(const float
         }
 #pragma unroll
         for (int j = 0; j < KNN_QW; ++j) {
-            list[j] = knn_flush(list[j], cand_all[wave][j], cnt[j], lane);
-            if (q0 + j < m && lane < k) {
-                out_idx[(q0 + j) * k + lane] = (int64_t)(unsigned)(list[j] & 0xffffffffull);
-                if (out_d2) out_d2[(q0 + j) * k + lane] = __uint_as_float((unsigned)(list[j] >> 32));
+            knn_flush_r<R>(list[j], cand_all[wave][j], cnt[j], lane);
+            if (q0 + j < m) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int e = r * 64 + lane;
+                    if (e < k) {
+                        out_idx[(q0 + j) * k + e] = (int64_t)(unsigned)(list[j][r] & 0xffffffffull);
+                        if (out_d2) out_d2[(q0 + j) * k + e] = __uint_as_float((unsigned)(list[j][r] >> 32));
+                    }
+                }
             }
         }
     }
@@ -275,17 +306,27 @@ int pps_knn_f32(const float* pts, int64_t n, const float* query, int64_t m, int 
 }
 
 int pps_knn_blocked_f32(const float* pts_blocked, const int32_t* orig_idx, const float* bbox, int64_t nb, int64_t n,
-                        const float* query, int64_t m, int k, int64_t* out_idx, float* out_d2, void* stream) {
-    if (n < 1 || nb < 1 || nb * 64 < n || (nb - 1) * 64 >= n || m < 0 || k < 1 || k > 64 || k > n || nb > 0x1ffffff) return PPS_ERR_ARG;
+                        const float* win_bbox, int64_t n_win, const float* query, int64_t m, int k, int64_t* out_idx, float* out_d2,
+                        void* stream) {
+    if (n < 1 || nb < 1 || nb * 64 < n || (nb - 1) * 64 >= n || m < 0 || k < 1 || k > 256 || k > n || nb > 0x1ffffff || n_win < 0)
+        return PPS_ERR_ARG;
     if (m == 0) return PPS_OK;
-    if (!pts_blocked || !orig_idx || !bbox || !query || !out_idx) return PPS_ERR_ARG;
+    if (!pts_blocked || !orig_idx || !bbox || !query || !out_idx || (n_win > 0 && !win_bbox)) return PPS_ERR_ARG;
     const int64_t ntask = (m + KNN_QW - 1) / KNN_QW;
     int64_t blocks = (ntask + KNN_WAVES - 1) / KNN_WAVES;
     int cus = pps_device_cu_count();
     if (cus <= 0) cus = 256;
     if (blocks > (int64_t)cus * 8) blocks = (int64_t)cus * 8;
-    hipLaunchKernelGGL(knn_blocked_kernel, dim3((unsigned)blocks), dim3(KNN_WAVES * 64), 0, (hipStream_t)stream, pts_blocked, orig_idx,
-                       bbox, (int)nb, (int)(n / 64), query, m, k, out_idx, out_d2);
+    const dim3 grid((unsigned)blocks), block(KNN_WAVES * 64);
+    hipStream_t st = (hipStream_t)stream;
+    const int r = (k + 63) / 64;
+#define PPS_KNN_LAUNCH(R) hipLaunchKernelGGL(knn_blocked_kernel<R>, grid, block, 0, st, pts_blocked, orig_idx, bbox, (int)nb, win_bbox, \
+                                             (int)n_win, query, m, k, out_idx, out_d2)
+    if (r == 1) PPS_KNN_LAUNCH(1);
+    else if (r == 2) PPS_KNN_LAUNCH(2);
+    else if (r == 3) PPS_KNN_LAUNCH(3);
+    else PPS_KNN_LAUNCH(4);
+#undef PPS_KNN_LAUNCH
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 

@@ -67,6 +67,20 @@ class KnnBlocks:
         self.orig = torch.cat([order.to(torch.int32), torch.full((pad,), -1, dtype=torch.int32, device=pts.device)]).contiguous()
         blk = self.pts.view(nb, 64, 3)                   # padding repeats the last valid point: boxes stay tight
         self.bbox = torch.cat([blk.min(dim=1)[0], blk.max(dim=1)[0]], dim=1).contiguous()
+        self._win = {}
+
+    def _windows(self, r: int):
+        """Boxes of r consecutive FULL blocks (>= 64*r points each): upper bounds of the k-th distance for k <= 64*r."""
+        if r not in self._win:
+            nfull = self.n // 64
+            if nfull < r:
+                self._win[r] = None
+            else:
+                lo, hi = self.bbox[:nfull, :3], self.bbox[:nfull, 3:]
+                wl = lo.unfold(0, r, 1).min(dim=2)[0]
+                wh = hi.unfold(0, r, 1).max(dim=2)[0]
+                self._win[r] = torch.cat([wl, wh], dim=1).contiguous()
+        return self._win[r]
 
     def query(self, query: torch.Tensor, k: int, return_d2: bool = False, out: torch.Tensor = None):
         query = query.contiguous().float()
@@ -74,7 +88,9 @@ class KnnBlocks:
         idx = out if out is not None else torch.empty((m, k), dtype=torch.int64, device=query.device)
         assert idx.dtype == torch.int64 and idx.is_contiguous() and tuple(idx.shape) == (m, k)
         d2 = torch.empty((m, k), dtype=torch.float32, device=query.device) if return_d2 else None
+        win = self._windows((int(k) + 63) // 64) if 1 <= int(k) <= 256 else None
         _lib.check(_lib.lib().pps_knn_blocked_f32(self.pts.data_ptr(), self.orig.data_ptr(), self.bbox.data_ptr(), self.nb, self.n,
+                                                  win.data_ptr() if win is not None else None, win.shape[0] if win is not None else 0,
                                                   query.data_ptr(), m, int(k), idx.data_ptr(), d2.data_ptr() if return_d2 else None,
                                                   _stream(query)), 'pps_knn_blocked_f32')
         return (idx, d2) if return_d2 else idx

@@ -26,7 +26,10 @@ def knn(points: torch.Tensor, support_points: torch.Tensor, k: int, workers: int
     """points [B,3,N], support_points [B,3,M] -> int64 [B,M,k] on the device of `points`; k clamps to N
     (poco_utils.py:259-260).  `workers` is accepted and ignored, as the reference ignores it for pykdtree."""
     k = min(int(k), points.shape[2])
-    out = [ops.knn_point_major(_point_major(points[b]), _point_major(support_points[b]), k) for b in range(points.shape[0])]
+    if k <= 64:
+        out = [ops.knn_point_major(_point_major(points[b]), _point_major(support_points[b]), k) for b in range(points.shape[0])]
+    else:                                   # 64 < k <= 256 (100NN / 200NN patches): block-culling search, same results
+        out = [ops.KnnBlocks(_point_major(points[b])).query(_point_major(support_points[b]), k) for b in range(points.shape[0])]
     return torch.stack(out, dim=0)
 
 
@@ -165,5 +168,6 @@ def get_pts_local_ps(pts_raw_ms, pts_query, num_pts_local, idx=None):
     """poco_utils.py:67-72 on the GPU: P nearest raw points of each query, centred and scaled -> [Q,P,3].
     `idx` may carry an already computed neighbour table whose first P columns are the P nearest (same cloud)."""
     if idx is None:
-        idx = ops.knn_point_major(pts_raw_ms, pts_query, num_pts_local)
+        idx = (ops.knn_point_major(pts_raw_ms, pts_query, num_pts_local) if num_pts_local <= 64
+               else ops.KnnBlocks(pts_raw_ms).query(pts_query, num_pts_local))
     return ops.patch_normalize(pts_raw_ms, pts_query, idx, num_pts_local)

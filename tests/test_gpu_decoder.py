@@ -96,7 +96,7 @@ def test_decoder_vs_oracle_shapes(p, k, q):
     np.testing.assert_allclose(logits.cpu().numpy(), ref, rtol=0, atol=1e-4)
 
 
-@pytest.mark.parametrize('p,q', [(50, 203), (18, 45), (20, 133), (24, 64), (50, 8), (50, 1)])
+@pytest.mark.parametrize('p,q', [(50, 203), (18, 45), (20, 133), (24, 64), (50, 8), (50, 1), (100, 37), (200, 21)])
 def test_packed_pointnet_tiles_match_oracle(p, q, monkeypatch):
     """Left-over rows of 16/LO queries share one tile (LO = P % 16 in {2,4,8}); forced on for small query counts."""
     monkeypatch.setenv('PPS_PN_FORCE_PACK', '1')

@@ -124,3 +124,23 @@ def test_blocked_knn_ties_and_far_queries():
     dp, dq = torch.from_numpy(pts).to(DEV), torch.from_numpy(qry).to(DEV)
     idx = ops.KnnBlocks(dp).query(dq, 64)
     assert np.array_equal(idx.cpu().numpy(), O.knn_point_major(pts, qry, 64))
+
+
+@pytest.mark.parametrize('n,m,k', [(300, 40, 200), (5000, 333, 65), (5000, 333, 100), (20000, 1000, 128), (100_000, 2000, 200), (3000, 100, 256)])
+def test_blocked_knn_large_k_vs_oracle(n, m, k):
+    """k up to 256 (the 100NN / 200NN patch searches of configs/ppsurf_100nn.yaml, ppsurf_200nn.yaml)."""
+    pts = make_cloud(n, seed=k)
+    qry = make_band_queries(pts, m, resolution=129, seed=n)
+    idx, d2 = ops.KnnBlocks(torch.from_numpy(pts).to(DEV)).query(torch.from_numpy(qry).to(DEV), k, return_d2=True)
+    ref_idx, ref_d2 = O.knn_point_major(pts, qry, k, return_d2=True)
+    assert np.array_equal(idx.cpu().numpy(), ref_idx)
+    assert np.array_equal(d2.cpu().numpy(), ref_d2)
+
+
+def test_knn_api_routes_large_k():
+    from ppsurf_amd.spatial import knn
+    pts = make_cloud(2000, seed=3)
+    p = torch.from_numpy(pts.T.copy()).unsqueeze(0).to(DEV)
+    ids = knn(p, p[:, :, :50], 200)
+    assert tuple(ids.shape) == (1, 50, 200)
+    assert np.array_equal(ids[0].cpu().numpy(), O.knn_point_major(pts, pts[:50], 200))

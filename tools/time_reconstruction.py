@@ -1,0 +1,60 @@
+"""End-to-end timing of ONE reconstruction at R=257 on one GPU with the real kernels doing all the work.
+
+Formula-filled weights do not describe a surface (no checkpoint offline), so the region growing would stop after the first
+round.  For TIMING ONLY the sign that steers the growth / Marching Cubes / refinement comes from the analytic SDF of the
+synthetic cloud (bumpy sphere), while every query is still decoded by the network (its occupancy is computed and
+discarded).  Query counts therefore match a real shape of that geometry; nothing here is used by the product path.
+"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import numpy as np, torch
+from golden_util import filled_sd
+from source.ppsurf_model import PPSurfModel
+from ppsurf_amd import reconstruct, mcubes
+from ppsurf_amd.synthetic import make_cloud
+
+N = int(os.environ.get('N', 100000)); R = int(os.environ.get('R', 257)); DEV = 'cuda:0'
+model = PPSurfModel(pointnet_latent_size=256, output_names=['imp_surf_sign'], in_channels=3, out_channels=2, k=64, lambda_l1=0.0,
+                    debug=False, in_file='x.npy', results_dir='/tmp/res', padding_factor=0.05, name='t', network_latent_size=256,
+                    gen_subsample_manifold_iter=10, gen_subsample_manifold=10000, gen_resolution_global=R, num_pts_local=50,
+                    rec_batch_size=50000, gen_refine_iter=10, workers=1)
+model.network.load_state_dict(filled_sd('', key='ppsurf'))
+model = model.to(DEV).eval()
+cloud = make_cloud(N, seed=42, noise=0.0)
+cloud_t = torch.from_numpy(cloud).to(DEV)
+
+
+class SteeredField(reconstruct.OccupancyField):
+    def __call__(self, q):
+        super().__call__(q)                                   # real kNN + patches + decoder, result discarded
+        d = torch.cdist(q, cloud_t[::50]).min(dim=1)[0]       # cheap proxy of the distance to the surface
+        inside = torch.linalg.norm(q, dim=1) < torch.linalg.norm(cloud_t[::50][torch.cdist(q, cloud_t[::50]).argmin(dim=1)], dim=1)
+        return torch.where(inside, d, -d)
+
+
+def sync():
+    torch.cuda.synchronize(); return time.time()
+
+pts_cf = cloud_t.t().contiguous()
+t0 = sync(); lat = model.encode_latents(pts_cf); t1 = sync()
+shape = {'pts': pts_cf.unsqueeze(0), 'latents': lat.t().unsqueeze(0)}
+field = SteeredField(model.network, shape, cloud_t.unsqueeze(0), 50000, 50)
+bmin, bmax = cloud.min(), cloud.max(); step = (bmax - bmin) / (R - 1)
+pts_ids = torch.from_numpy(((cloud - bmin) / step + 1).astype(np.int32).astype(np.int64)).to(DEV)
+t2 = sync(); vol = reconstruct.create_volume(field, pts_ids, R, step, bmin - step); t3 = sync()
+n_band = field.n_queries
+v = vol.cpu().numpy(); verts, faces = mcubes.marching_cubes(v, 0.0); verts, faces = mcubes.clean_mesh(verts, faces); t4 = time.time()
+frac = ((verts - np.floor(verts)) > 0)
+edge = verts[(frac.sum(1) == 1)]
+q = torch.from_numpy((edge * step + (bmin - step)).astype(np.float32)).to(DEV)
+t5 = sync()
+for _ in range(10):
+    field(q)
+t6 = sync()
+total = (t1 - t0) + (t3 - t2) + (t4 - t3) + (t6 - t5)
+print('latent loop        {:7.3f} s  (100 encoder passes)'.format(t1 - t0))
+print('region growing     {:7.3f} s  {} band queries ({:.2e} q/s incl. driver)'.format(t3 - t2, n_band, n_band / (t3 - t2)))
+print('MC + clean (host)  {:7.3f} s  {} verts {} faces'.format(t4 - t3, verts.shape[0], faces.shape[0]))
+print('refinement         {:7.3f} s  10 x {} queries ({:.2e} q/s)'.format(t6 - t5, q.shape[0], 10 * q.shape[0] / (t6 - t5)))
+print('TOTAL              {:7.3f} s per shape  ->  {:.0f} shapes/hour on one GPU; {} decoder queries'.format(total, 3600 / total, field.n_queries))
