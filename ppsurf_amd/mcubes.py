@@ -142,3 +142,94 @@ def clean_mesh(verts: np.ndarray, faces: np.ndarray, min_component_faces=6, digi
         faces = faces[size[label] > min_component_faces]
     used, inv = np.unique(faces.reshape(-1), return_inverse=True)
     return verts[used], inv.reshape(-1, 3).astype(np.int64)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# torch twins (run on the device that holds the volume; identical results to the numpy functions above)
+# ---------------------------------------------------------------------------------------------------------------------
+def marching_cubes_torch(volume, level: float = 0.0):
+    """Same as marching_cubes for a torch tensor on any device -> (verts float64 [V,3], faces int64 [F,3]) on that device."""
+    import torch
+    vol = volume.to(torch.float64)
+    dev = vol.device
+    nx, ny, nz = vol.shape
+    corners = _CORNERS.tolist()
+    finite = None
+    case = torch.zeros((nx - 1, ny - 1, nz - 1), dtype=torch.int64, device=dev)
+    for c, (dx, dy, dz) in enumerate(corners):
+        v = vol[dx:nx - 1 + dx, dy:ny - 1 + dy, dz:nz - 1 + dz]
+        ok = ~torch.isnan(v)
+        finite = ok if finite is None else (finite & ok)
+        case |= (v > level).to(torch.int64) << c
+    active = finite & (case != 0) & (case != 255)
+    cubes = torch.nonzero(active)
+    if cubes.shape[0] == 0:
+        return torch.zeros((0, 3), dtype=torch.float64, device=dev), torch.zeros((0, 3), dtype=torch.int64, device=dev)
+    table = torch.from_numpy(_TRI_TABLE).to(dev)
+    tris = table[case[cubes[:, 0], cubes[:, 1], cubes[:, 2]]]          # [n, W, 3]
+    valid = tris[:, :, 0] >= 0
+    cube_of = torch.arange(cubes.shape[0], device=dev)[:, None].expand_as(valid)[valid]
+    e = tris[valid]                                                     # [T,3]
+    origin = cubes[cube_of][:, None, :] + torch.from_numpy(_EDGE_ORIGIN).to(dev)[e]
+    axis = torch.from_numpy(_EDGE_AXIS).to(dev)[e]
+    key = ((origin[..., 0] * ny + origin[..., 1]) * nz + origin[..., 2]) * 3 + axis
+    ukey, faces = torch.unique(key.reshape(-1), return_inverse=True)
+    faces = faces.reshape(-1, 3)
+    ax = ukey % 3
+    lin = torch.div(ukey, 3, rounding_mode='floor')
+    o = torch.stack([torch.div(lin, ny * nz, rounding_mode='floor'), torch.div(lin, nz, rounding_mode='floor') % ny, lin % nz], dim=1)
+    ar = torch.arange(o.shape[0], device=dev)
+    o2 = o.clone()
+    o2[ar, ax] += 1
+    va = vol[o[:, 0], o[:, 1], o[:, 2]]
+    vb = vol[o2[:, 0], o2[:, 1], o2[:, 2]]
+    verts = o.to(torch.float64)
+    verts[ar, ax] += (level - va) / (vb - va)
+    return verts, faces
+
+
+def clean_mesh_torch(verts, faces, min_component_faces=6, digits=8):
+    """Same as clean_mesh on torch tensors (connected components by min-label propagation with pointer jumping)."""
+    import torch
+    if faces.shape[0] == 0:
+        return verts, faces
+    dev = verts.device
+    scale = 10.0 ** digits
+    _, inv = torch.unique(torch.round(verts * scale), dim=0, return_inverse=True)
+    first = torch.full((int(inv.max()) + 1,), verts.shape[0], dtype=torch.int64, device=dev)
+    first.scatter_reduce_(0, inv, torch.arange(verts.shape[0], device=dev), reduce='amin')
+    verts = verts[first]
+    faces = inv[faces]
+    ok = (faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2])
+    faces = faces[ok]
+    srt = torch.sort(faces, dim=1)[0]
+    nv = verts.shape[0]
+    fkey = (srt[:, 0] * nv + srt[:, 1]) * nv + srt[:, 2] if nv < 2_000_000 else None
+    if fkey is not None:
+        _, finv = torch.unique(fkey, return_inverse=True)
+        keep = torch.full((int(finv.max()) + 1,), faces.shape[0], dtype=torch.int64, device=dev)
+        keep.scatter_reduce_(0, finv, torch.arange(faces.shape[0], device=dev), reduce='amin')
+        faces = faces[torch.sort(keep)[0]]
+    if faces.shape[0] and min_component_faces is not None:
+        nf = faces.shape[0]
+        e = torch.cat([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]])
+        e = torch.sort(e, dim=1)[0]
+        ekey = e[:, 0] * nv + e[:, 1]
+        owner = torch.arange(nf, device=dev).repeat(3)
+        skey, order = torch.sort(ekey, stable=True)
+        ow = owner[order]
+        same = skey[1:] == skey[:-1]
+        a, b = ow[:-1][same], ow[1:][same]
+        label = torch.arange(nf, device=dev)
+        while True:
+            new = label.clone()
+            new.scatter_reduce_(0, a, label[b], reduce='amin')
+            new.scatter_reduce_(0, b, label[a], reduce='amin')
+            new = new[new]
+            if torch.equal(new, label):
+                break
+            label = new
+        size = torch.bincount(label, minlength=nf)
+        faces = faces[size[label] > min_component_faces]
+    used, finv = torch.unique(faces.reshape(-1), return_inverse=True)
+    return verts[used], finv.reshape(-1, 3)

@@ -120,38 +120,35 @@ def export_mesh_and_refine_vertices_region_growing_v3(network, latent: dict, pts
     seen = volume[~torch.isnan(volume)]
     if not (float(seen.max()) > mc_value > float(seen.min())):
         return None
-    vol_np = volume.cpu().numpy()
-    verts, faces = mcubes.marching_cubes(vol_np, mc_value)
-    verts, faces = mcubes.clean_mesh(verts, faces, min_component_faces=6)
+    # Marching Cubes, clean-up and the bisection refinement stay on the device (poco_utils.py:96-168)
+    verts, faces = mcubes.marching_cubes_torch(volume, mc_value)
+    verts, faces = mcubes.clean_mesh_torch(verts, faces, min_component_faces=6)
     if refine_iter > 0 and verts.shape[0] > 0:
-        frac = ((verts - np.floor(verts)) > 0).astype(verts.dtype)
-        mask = np.logical_and(frac.sum(axis=1) > 0, frac.sum(axis=1) < 2)
-        v = verts[mask]
-        v1i = np.floor(v).astype(int)
-        v2i = (np.floor(v) + frac[mask]).astype(int)
-        p1 = vol_np[v1i[:, 0], v1i[:, 1], v1i[:, 2]]
-        p2 = vol_np[v2i[:, 0], v2i[:, 1], v2i[:, 2]]
-        v1 = v1i.astype(np.float32) * step + bmin_pad
-        v2 = v2i.astype(np.float32) * step + bmin_pad
-        ok = ~np.isnan(p1) & ~np.isnan(p2)
-        v, v1, v2, p1, p2 = v[ok], v1[ok], v2[ok], p1[ok], p2[ok]
-        mask[mask] = ok
+        frac = (verts - torch.floor(verts)) > 0
+        nfrac = frac.sum(dim=1)
+        sel = torch.nonzero((nfrac > 0) & (nfrac < 2))[:, 0]               # vertices on a grid edge
+        v = verts[sel]
+        v1i = torch.floor(v).to(torch.int64)
+        v2i = v1i + frac[sel].to(torch.int64)
+        p1 = volume[v1i[:, 0], v1i[:, 1], v1i[:, 2]]
+        p2 = volume[v2i[:, 0], v2i[:, 1], v2i[:, 2]]
+        ok = ~torch.isnan(p1) & ~torch.isnan(p2)
+        sel, v, v1i, v2i, p1, p2 = sel[ok], v[ok], v1i[ok], v2i[ok], p1[ok], p2[ok]
+        v1 = v1i.to(torch.float32) * np.float32(step) + np.float32(bmin_pad)
+        v2 = v2i.to(torch.float32) * np.float32(step) + np.float32(bmin_pad)
         verts = verts * step + bmin_pad
-        v = v * step + bmin_pad
-        v_d = torch.from_numpy(v).to(dev, torch.float32)
-        v1_d, v2_d = torch.from_numpy(v1).to(dev, torch.float32), torch.from_numpy(v2).to(dev, torch.float32)
-        p1_d, p2_d = torch.from_numpy(p1).to(dev), torch.from_numpy(p2).to(dev)
-        for it in range(refine_iter):                                       # bisection on the device (poco_utils.py:146-165)
-            pr = field(v_d).to(torch.float64)
-            m1 = (pr * p1_d) > 0
-            v1_d[m1] = v_d[m1]; p1_d[m1] = pr[m1]
-            m2 = (pr * p2_d) > 0
-            v2_d[m2] = v_d[m2]; p2_d[m2] = pr[m2]
-            v_d = (v2_d + v1_d) / 2
+        vq = (v * step + bmin_pad).to(torch.float32)
+        for it in range(refine_iter):                                       # bisection (poco_utils.py:146-165)
+            pr = field(vq).to(torch.float64)
+            m1 = (pr * p1) > 0
+            v1[m1] = vq[m1]; p1[m1] = pr[m1]
+            m2 = (pr * p2) > 0
+            v2[m2] = vq[m2]; p2[m2] = pr[m2]
+            vq = (v2 + v1) / 2
             if progress is not None:
                 progress('refine iter {}'.format(it))
-        verts[mask] = v_d.cpu().numpy()
+        verts[sel] = vq.to(verts.dtype)
     else:
         verts = verts * step + bmin_pad
-    verts, faces = mcubes.clean_mesh(verts, faces, min_component_faces=6)
-    return verts.astype(np.float32), faces
+    verts, faces = mcubes.clean_mesh_torch(verts, faces, min_component_faces=6)
+    return verts.to(torch.float32).cpu().numpy(), faces.cpu().numpy()
