@@ -86,11 +86,12 @@ class PocoModel(_Base):
 
     # ---- progress bar / logging shims ---------------------------------------------------------------------------
     def get_prog_bar(self):
-        trainer = getattr(self, '_trainer', None) or getattr(self, 'trainer_', None)
-        try:
-            trainer = self.trainer
-        except Exception:
-            pass
+        trainer = self.__dict__.get('_runner_trainer')
+        if trainer is None:
+            try:
+                trainer = self.trainer
+            except Exception:
+                trainer = None
         return getattr(trainer, 'progress_bar_callback', None) if trainer is not None else None
 
     def _log(self, *args, **kwargs):

@@ -76,3 +76,14 @@ def write_ply_mesh(path, verts: np.ndarray, faces: np.ndarray):
         f.write(header.encode('ascii'))
         f.write(verts.tobytes())
         f.write(rec.tobytes())
+
+
+def write_ply_points(path, pts: np.ndarray):
+    """Binary little-endian PLY with float x/y/z vertices and zero faces (layout of datasets/*/04_pts_vis/*.xyz.ply)."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    pts = np.asarray(pts, dtype='<f4')
+    header = ('ply\nformat binary_little_endian 1.0\ncomment ppsurf_amd\nelement vertex {}\nproperty float x\nproperty float y\n'
+              'property float z\nelement face 0\nproperty list uchar int vertex_indices\nend_header\n').format(pts.shape[0])
+    with open(path, 'wb') as f:
+        f.write(header.encode('ascii'))
+        f.write(pts.tobytes())

@@ -118,3 +118,26 @@ def make_band_queries(pts: np.ndarray, m: int, resolution: int = 257, seed: int 
 def make_latents(c: int, n: int, seed: int = 77) -> np.ndarray:
     """Seeded N(0,1) latent table, channel-first [1,c,n] float32 (decoder cost is value independent)."""
     return np.random.default_rng(seed).standard_normal((1, c, n)).astype(np.float32)
+
+
+def write_dataset(root: str, n_shapes: int = 3, n_pts: int = 3000, n_query: int = 2000, seed: int = 0):
+    """Synthetic dataset in the reference's directory layout (source/occupancy_data_module.py:34-71): `04_pts_vis/<name>.xyz.ply`,
+    `05_query_pts|05_query_dist/<name>.ply.npy` ((n_query,3) / (n_query,) float32, signed distance > 0 outside), and
+    train/val/test set lists.  Returns the path of testset.txt."""
+    import os
+    from . import meshio
+    rng = np.random.default_rng(seed)
+    names = ['synth_{:03d}'.format(i) for i in range(n_shapes)]
+    for i, name in enumerate(names):
+        cloud = make_cloud(n_pts, seed=seed + i)
+        meshio.write_ply_points(os.path.join(root, '04_pts_vis', name + '.xyz.ply'), cloud)
+        q = (cloud[rng.integers(0, n_pts, n_query)] + rng.normal(0, 0.02, (n_query, 3))).astype(np.float32)
+        near = cloud[np.argmin(((q[:, None, :] - cloud[None, ::8, :]) ** 2).sum(-1), axis=1) * 8]
+        dist = (np.linalg.norm(q, axis=1) - np.linalg.norm(near, axis=1)).astype(np.float32)     # radial proxy of the signed distance
+        for sub, arr in (('05_query_pts', q), ('05_query_dist', dist)):
+            os.makedirs(os.path.join(root, sub), exist_ok=True)
+            np.save(os.path.join(root, sub, name + '.ply.npy'), arr)
+    for fname in ('trainset.txt', 'valset.txt', 'testset.txt'):
+        with open(os.path.join(root, fname), 'w') as f:
+            f.write('\n'.join(names) + '\n')
+    return os.path.join(root, 'testset.txt')
