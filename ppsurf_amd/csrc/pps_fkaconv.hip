@@ -112,13 +112,20 @@ __device__ __forceinline__ void block_stats(const float (&v)[16], bool valid, do
         part[(int64_t)blockIdx.x * 32 + threadIdx.x] = red[threadIdx.x] + red[32 + threadIdx.x] + red[64 + threadIdx.x] + red[96 + threadIdx.x];
 }
 
-// mean / rstd (biased variance, eps 1e-5) from the per-block partials, fixed summation order -> LDS stat[16][2]
-__device__ __forceinline__ void finish_stats(const double* __restrict__ part, int nblk, double count, float* stat) {
+// mean / rstd (biased variance, eps 1e-5) of the 16 channels from the per-block partials: ONE workgroup, fixed summation order
+// (thread t sums the partials of statistic t%32 over the blocks b = t/32 (mod 8), then the 8 sub-sums are added in order).
+__global__ __launch_bounds__(256) void fka_finalize_kernel(const double* __restrict__ part, int nblk, double count, float* __restrict__ stat) {
+    __shared__ double sub[8][32];
+    const int s = threadIdx.x & 31, c = threadIdx.x >> 5;
+    double acc = 0.0;
+    for (int b = c; b < nblk; b += 8) acc += part[(int64_t)b * 32 + s];
+    sub[c][s] = acc;
+    __syncthreads();
     if (threadIdx.x < 16) {
-        double s = 0.0, q = 0.0;
-        for (int b = 0; b < nblk; ++b) { s += part[(int64_t)b * 32 + 2 * threadIdx.x]; q += part[(int64_t)b * 32 + 2 * threadIdx.x + 1]; }
-        const double mean = s / count;
-        double var = q / count - mean * mean;
+        double sm = 0.0, sq = 0.0;
+        for (int i = 0; i < 8; ++i) { sm += sub[i][2 * threadIdx.x]; sq += sub[i][2 * threadIdx.x + 1]; }
+        const double mean = sm / count;
+        double var = sq / count - mean * mean;
         if (var < 0.0) var = 0.0;
         stat[2 * threadIdx.x] = (float)mean;
         stat[2 * threadIdx.x + 1] = (float)(1.0 / sqrt(var + 1e-5));
@@ -128,14 +135,12 @@ __device__ __forceinline__ void finish_stats(const double* __restrict__ part, in
 template <int PHASE>
 __global__ __launch_bounds__(FK_NT) void fka_stats_kernel(const float* __restrict__ pts, const float* __restrict__ sup,
                                                           const int64_t* __restrict__ idx, int64_t M, int K,
-                                                          const float* __restrict__ geo_g, const double* __restrict__ part1,
+                                                          const float* __restrict__ geo_g, const float* __restrict__ stat1,
                                                           double* __restrict__ part_out) {
-    __shared__ float geo[GEO_FLOATS];
-    __shared__ float stat1[32];
+    // the small per-layer parameters are read straight from the kernel-argument array with wave-uniform indices:
+    // scalar loads (s_load) feeding SGPR operands instead of 1100 LDS broadcast reads per lane
+    const float* __restrict__ geo = geo_g;
     __shared__ double red[128];
-    for (int i = threadIdx.x; i < GEO_FLOATS; i += FK_NT) geo[i] = geo_g[i];
-    if (PHASE == 2) finish_stats(part1, gridDim.x, (double)M * K, stat1);
-    __syncthreads();
     const int j = threadIdx.x & 15;
     const int64_t m = (int64_t)blockIdx.x * FK_TM + (threadIdx.x >> 4);
     const Geo g = geometry(pts, sup, idx, m, M, j, K, geo);
@@ -155,25 +160,11 @@ __global__ __launch_bounds__(FK_NT) void fka_stats_kernel(const float* __restric
 // The (1,16) convolution that follows (nn.py:650) is the dense product F[M, Cin*16] x W^T, done by rows_gemm_kernel.
 __global__ __launch_bounds__(FK_NT) void fka_feat_kernel(const float* __restrict__ x, const float* __restrict__ pts,
                                                          const float* __restrict__ sup, const int64_t* __restrict__ idx, int64_t M, int K,
-                                                         int Cin, const float* __restrict__ geo_g, const double* __restrict__ part1,
-                                                         const double* __restrict__ part2, float* __restrict__ F) {
-    __shared__ float geo[GEO_FLOATS];
-    __shared__ float stat1[32], stat2[32];
+                                                         int Cin, const float* __restrict__ geo_g, const float* __restrict__ stat1,
+                                                         const float* __restrict__ stat2, float* __restrict__ F) {
+    const float* __restrict__ geo = geo_g;
     __shared__ float m3[FK_TM][16][17];          // [m][j][t], padded
     __shared__ int nb[FK_TM][16];                // neighbour row (or -1)
-    for (int i = threadIdx.x; i < GEO_FLOATS; i += FK_NT) geo[i] = geo_g[i];
-    finish_stats(part1, gridDim.x, (double)M * K, stat1);
-    if (threadIdx.x >= 64 && threadIdx.x < 80) {
-        const int t = threadIdx.x - 64;          // second statistic by another wave (same fixed order)
-        double s = 0.0, q = 0.0;
-        for (int b = 0; b < (int)gridDim.x; ++b) { s += part2[(int64_t)b * 32 + 2 * t]; q += part2[(int64_t)b * 32 + 2 * t + 1]; }
-        const double cnt = (double)M * K, mean = s / cnt;
-        double var = q / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        stat2[2 * t] = (float)mean;
-        stat2[2 * t + 1] = (float)(1.0 / sqrt(var + 1e-5));
-    }
-    __syncthreads();
     const int j = threadIdx.x & 15, ml = threadIdx.x >> 4;
     const int64_t m0 = (int64_t)blockIdx.x * FK_TM;
     {
@@ -351,7 +342,7 @@ size_t pps_fkaconv_geo_floats(void) { return GEO_FLOATS; }
 
 size_t pps_fkaconv_ws_bytes(int64_t M, int cin) {
     const int64_t nblk = (M + FK_TM - 1) / FK_TM;
-    return (size_t)nblk * 32 * sizeof(double) * 2 + (size_t)M * cin * 16 * sizeof(float);
+    return (size_t)nblk * 32 * sizeof(double) * 2 + 64 * sizeof(float) + (size_t)M * cin * 16 * sizeof(float);
 }
 
 static int launch_rows_gemm(const float* in1, const int64_t* idx1, int c1, const float* in2, const int64_t* idx2, int c2,
@@ -377,12 +368,17 @@ int pps_fkaconv_fwd_f32(const float* x, const float* pts, const float* sup, cons
     const int nblk = (int)((m + FK_TM - 1) / FK_TM);
     double* part1 = (double*)ws;
     double* part2 = part1 + (size_t)nblk * 32;
-    float* F = (float*)(part2 + (size_t)nblk * 32);
+    float* stat1 = (float*)(part2 + (size_t)nblk * 32);
+    float* stat2 = stat1 + 32;
+    float* F = stat2 + 32;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(fka_stats_kernel<1>, dim3(nblk), dim3(FK_NT), 0, st, pts, sup, idx, m, k, geo, (const double*)nullptr, part1);
-    hipLaunchKernelGGL(fka_stats_kernel<2>, dim3(nblk), dim3(FK_NT), 0, st, pts, sup, idx, m, k, geo, (const double*)part1, part2);
-    hipLaunchKernelGGL(fka_feat_kernel, dim3(nblk), dim3(FK_NT), 0, st, x, pts, sup, idx, m, k, cin, geo, (const double*)part1,
-                       (const double*)part2, F);
+    const double count = (double)m * k;
+    hipLaunchKernelGGL(fka_stats_kernel<1>, dim3(nblk), dim3(FK_NT), 0, st, pts, sup, idx, m, k, geo, (const float*)nullptr, part1);
+    hipLaunchKernelGGL(fka_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)part1, nblk, count, stat1);
+    hipLaunchKernelGGL(fka_stats_kernel<2>, dim3(nblk), dim3(FK_NT), 0, st, pts, sup, idx, m, k, geo, (const float*)stat1, part2);
+    hipLaunchKernelGGL(fka_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)part2, nblk, count, stat2);
+    hipLaunchKernelGGL(fka_feat_kernel, dim3(nblk), dim3(FK_NT), 0, st, x, pts, sup, idx, m, k, cin, geo, (const float*)stat1,
+                       (const float*)stat2, F);
     if (hipGetLastError() != hipSuccess) return PPS_ERR_LAUNCH;
     return launch_rows_gemm(F, nullptr, cin * 16, nullptr, nullptr, 0, wpack, bias, nullptr, act_out, m, cout, out, st);
 }
