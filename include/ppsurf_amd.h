@@ -47,6 +47,21 @@ int pps_knn_blocked_f32(const float* pts_blocked, const int32_t* orig_idx, const
                         const float* win_bbox, int64_t n_win, const float* query, int64_t m, int k, int64_t* out_idx,
                         float* out_d2, void* stream);
 
+/* The neighbourhood tables of one encoder pass in a single launch (k <= 64 each, ntasks <= 16); arrays are [host] arrays of
+ * device pointers / sizes.   replaces: the 13 `knn` calls of source/poco_data_loader.py:155-168. */
+int pps_knn_multi_f32(int ntasks, const float* const* pts, const int64_t* n, const float* const* query, const int64_t* m,
+                      const int* k, int64_t* const* out_idx, void* stream);
+
+/* Voxel-stratified sub-sampling of one cloud to exactly `target` unique points, all rounds in one workgroup.
+ * replaces: source/poco_data_loader.py:59-134 `sampling_quantized` (per batch item): per round a rotation rots[r] (row-major
+ * 3x3, drawn by the caller), one representative (smallest index) per occupied voxel of edge `vox` anchored at the rotated
+ * bbox minimum, accept all and halve `vox` while fewer than `target` were taken, else a random subset (hash of `seed`).
+ * vox <= 0 selects the reference's default edge, bbox diagonal / sqrt(target) (:85-88), computed in the kernel.
+ * pts [n,3], 2 <= n <= pps_voxel_sample_max_points(), 1 <= target < n; out_ids int64 [target] ascending; out_rounds int32 or NULL. */
+int pps_voxel_sample_max_points(void);
+int pps_voxel_sample_f32(const float* pts, int64_t n, int64_t target, float vox, const float* rots, int nrot, uint32_t seed,
+                         int64_t* out_ids, int32_t* out_rounds, void* stream);
+
 /* Gather P neighbours per query from the raw cloud, centre at the query, divide by the max neighbour distance.
  * replaces: source/poco_utils.py:67-72 `_get_pts_local_ps` (gather + normalise part) and
  *           source/ppsurf_data_loader.py:91-123 `normalize_patches/get_patch_radii/model_space_to_patch_space`.

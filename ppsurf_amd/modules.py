@@ -174,9 +174,12 @@ class FKAConvNetwork(_Base):
         pm = lambda t: t[b].t().contiguous()
         ids = {}
         for k, v in data.items():
-            if k.startswith('ids'):
+            if k.startswith('ids') and torch.is_tensor(v):
                 t = v[b] if v.dim() == 3 else v
                 ids[k] = t.reshape(-1).contiguous() if k in ('ids43', 'ids32', 'ids21', 'ids10') else t.contiguous()
+        cached = data.get('_levels_point_major')
+        if cached is not None:                                    # levels already point-major (spatial.get_fkaconv_ids)
+            return plan.forward(cached[b][0], cached[b][1:], ids)
         sups = [pm(data['support{}'.format(i)]) for i in (1, 2, 3, 4)]
         return plan.forward(pm(data['pts']), sups, ids)
 

@@ -9,12 +9,15 @@
 
 Tensors keep the reference's channel-first [B,3,N] layout at this boundary; the kernels work point-major.
 """
+import ctypes
 import math
 import random
 
 import torch
 
-from . import ops
+from . import ops, _lib
+
+N_ROT = 12          # rotations drawn per sampling level (rounds beyond that would need 2^-12 of the initial voxel edge)
 
 
 def _point_major(t):
@@ -58,10 +61,30 @@ def _one_per_voxel(pos: torch.Tensor, size: float) -> torch.Tensor:
     return order[first]
 
 
-def sampling_quantized(pts_batch, ratio=None, n_support=None, support_points=None, support_points_ids=None):
+def draw_rotations(n: int = N_ROT) -> torch.Tensor:
+    """n composed random rotations Rz Ry Rx (python `random`, like torch_geometric's RandomRotate) -> float32 [n,3,3] on the CPU."""
+    return torch.stack([_rotation(2) @ _rotation(1) @ _rotation(0) for _ in range(n)])
+
+
+def voxel_sample_point_major(pts_pm: torch.Tensor, target: int, rotations: torch.Tensor = None, seed: int = None) -> torch.Tensor:
+    """One cloud [n,3] on the GPU -> int64 [target] ascending, through pps_voxel_sample_f32 (all rounds in one launch)."""
+    n = pts_pm.shape[0]
+    rot = (draw_rotations() if rotations is None else rotations).to(torch.float32).reshape(-1, 9).contiguous().to(pts_pm.device, non_blocking=True)
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    out = torch.empty((target,), dtype=torch.int64, device=pts_pm.device)
+    _lib.check(_lib.lib().pps_voxel_sample_f32(pts_pm.data_ptr(), n, int(target), ctypes.c_float(-1.0), rot.data_ptr(), rot.shape[0],
+                                               ctypes.c_uint32(seed & 0xffffffff), out.data_ptr(), None,
+                                               torch.cuda.current_stream(pts_pm.device).cuda_stream), 'pps_voxel_sample_f32')
+    return out
+
+
+def sampling_quantized(pts_batch, ratio=None, n_support=None, support_points=None, support_points_ids=None, _rotations=None):
     """Voxel-stratified random sub-sampling to exactly max(1, int(N*ratio)) points (poco_data_loader.py:59-134):
     voxel edge = bbox diagonal / sqrt(n), random 3-axis rotation, one point per occupied voxel, remove, halve, repeat;
-    the last round is truncated at random.  Stochastic (python `random`, torch RNG) like the reference."""
+    the last round is truncated at random.  Stochastic (python `random`, torch RNG) like the reference.
+    GPU clouds of up to pps_voxel_sample_max_points() points go through the HIP kernel; anything else through the
+    equivalent torch-op loop below (`_rotations`: test hook, one [R,3,3] tensor of rotations shared by both paths)."""
     if support_points is not None:
         return support_points, support_points_ids
     assert (ratio is None) != (n_support is None)
@@ -72,6 +95,9 @@ def sampling_quantized(pts_batch, ratio=None, n_support=None, support_points=Non
         return pts_batch, ids
     if not 0 < target < n:
         raise ValueError('Search Quantized - ratio value error {} should be in ]0,1]'.format(ratio))
+    if pts_batch.is_cuda and 2 <= n <= _lib.lib().pps_voxel_sample_max_points():
+        ids = torch.stack([voxel_sample_point_major(_point_major(pts_batch[i]), target, _rotations) for i in range(b)], dim=0)
+        return torch.gather(pts_batch, 2, ids.unsqueeze(1).expand(b, 3, target)), ids
     extent = pts_batch.max(dim=2)[0] - pts_batch.min(dim=2)[0]
     vox0 = (extent.norm(2, dim=1) / math.sqrt(target)).tolist()
     all_ids = []
@@ -79,8 +105,10 @@ def sampling_quantized(pts_batch, ratio=None, n_support=None, support_points=Non
         pts = pts_batch[i].transpose(0, 1)
         ids = torch.arange(pts.shape[0], device=pts.device)
         vox, count, picked = vox0[i], 0, []
+        rnd = 0
         while True:
-            rot = (_rotation(2) @ _rotation(1) @ _rotation(0)).to(pts.device)
+            rot = ((_rotation(2) @ _rotation(1) @ _rotation(0)) if _rotations is None else _rotations[rnd]).to(pts.device)
+            rnd += 1
             perm = _one_per_voxel(pts @ rot.t(), vox)
             if count + perm.shape[0] < target:
                 picked.append(ids[perm])
@@ -99,12 +127,53 @@ def sampling_quantized(pts_batch, ratio=None, n_support=None, support_points=Non
     return support, ids
 
 
+def _tables_point_major(levels_pm, segmentation=True):
+    """The 9 (+4) kNN tables of one cloud from its 5 point-major levels in ONE launch (pps_knn_multi_f32)."""
+    tasks = []
+    for a in range(5):
+        tasks.append(('ids{}{}'.format(a, a), levels_pm[a], levels_pm[a], 16))
+        if a < 4:
+            tasks.append(('ids{}{}'.format(a, a + 1), levels_pm[a], levels_pm[a + 1], 16))
+            if segmentation:
+                tasks.append(('ids{}{}'.format(a + 1, a), levels_pm[a + 1], levels_pm[a], 1))
+    dev = levels_pm[0].device
+    outs, nt = {}, len(tasks)
+    P, I64, I = ctypes.c_void_p * nt, ctypes.c_int64 * nt, ctypes.c_int * nt
+    pts, qry, out, ns, ms, ks = P(), P(), P(), I64(), I64(), I()
+    for t, (name, p, q, k) in enumerate(tasks):
+        k = min(k, p.shape[0])
+        o = torch.empty((q.shape[0], k), dtype=torch.int64, device=dev)
+        outs[name] = o
+        pts[t], qry[t], out[t], ns[t], ms[t], ks[t] = p.data_ptr(), q.data_ptr(), o.data_ptr(), p.shape[0], q.shape[0], k
+    _lib.check(_lib.lib().pps_knn_multi_f32(nt, pts, ns, qry, ms, ks, out, torch.cuda.current_stream(dev).cuda_stream), 'pps_knn_multi_f32')
+    return outs
+
+
 def get_fkaconv_ids(data, segmentation: bool = True):
     """4 support levels (ratio 0.25) and the 13 kNN tables of poco_data_loader.py:137-209."""
     pts = data['pts'].clone()
     unbatched = pts.dim() == 2
     if unbatched:
         pts = pts.unsqueeze(0)
+    if pts.is_cuda and 4 <= pts.shape[2] <= _lib.lib().pps_voxel_sample_max_points():
+        # fused GPU path: 4 sampling launches + 1 launch for all tables per cloud, everything point-major
+        per_item = []
+        for b in range(pts.shape[0]):
+            lv = [_point_major(pts[b])]
+            for _ in range(4):
+                n = lv[-1].shape[0]
+                target = max(1, int(n * 0.25))
+                lv.append(lv[-1] if target == n else lv[-1][voxel_sample_point_major(lv[-1], target)] if n >= 2 else lv[-1])
+            per_item.append((lv, _tables_point_major(lv, segmentation)))
+        ret = {}
+        for name in per_item[0][1]:
+            t = torch.stack([it[1][name] for it in per_item], dim=0)
+            ret[name] = t.squeeze(0) if unbatched else t
+        for a in range(1, 5):
+            t = torch.stack([it[0][a].t() for it in per_item], dim=0)
+            ret['support{}'.format(a)] = t.squeeze(0) if unbatched else t
+        ret['_levels_point_major'] = [it[0] for it in per_item]      # reused by FKAConvNetwork.forward_point_major
+        return ret
     levels = [pts]
     for _ in range(4):
         levels.append(sampling_quantized(levels[-1], 0.25)[0])
