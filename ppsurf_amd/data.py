@@ -107,7 +107,7 @@ class TestDataset(ReconstructionDataset):
 
 def _collate1(item):
     """default_collate for batch size 1."""
-    return {k: (v.unsqueeze(0) if torch.is_tensor(v) else [v]) for k, v in item.items()}
+    return {k: (v if k.startswith('_') else v.unsqueeze(0) if torch.is_tensor(v) else [v]) for k, v in item.items()}
 
 
 class PocoDataModule:
