@@ -714,8 +714,9 @@ int pps_device_cu_count(void) { return cu_count(); }
 
 int pps_rows_dense256_f32(const float* in, int64_t rs, int64_t cs, int64_t m, const float* wpack, const float* bias,
                           float* out, void* stream) {
-    if (!in || !wpack || !bias || !out || m < 0) return PPS_ERR_ARG;
+    if (m < 0) return PPS_ERR_ARG;
     if (m == 0) return PPS_OK;
+    if (!in || !wpack || !bias || !out) return PPS_ERR_ARG;
     if (cs == 1 && (rs % 4) != 0) return PPS_ERR_ARG;
     static int once = set_lds(rows_dense256_kernel, RD_LDS_BYTES);
     (void)once;
@@ -726,8 +727,9 @@ int pps_rows_dense256_f32(const float* in, int64_t rs, int64_t cs, int64_t m, co
 
 int pps_interp_pool_f32(const float* G, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
                         const float* wpack, const float* bias, float* pooled, void* stream) {
-    if (!G || !pts || !query || !idx || !wpack || !bias || !pooled || q < 0 || k < 1 || k > 64) return PPS_ERR_ARG;
+    if (q < 0 || k < 1 || k > 64) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
+    if (!G || !pts || !query || !idx || !wpack || !bias || !pooled) return PPS_ERR_ARG;
     static int once = set_lds(interp_pool_kernel, IP_LDS_BYTES);
     (void)once;
     hipLaunchKernelGGL(interp_pool_kernel, dim3(grid_for((q + NW / 4 - 1) / (NW / 4))), dim3(NT), IP_LDS_BYTES, (hipStream_t)stream,
@@ -737,8 +739,9 @@ int pps_interp_pool_f32(const float* G, const float* pts, const float* query, co
 
 int pps_pointnet_stn_rows_f32(const float* patches, int64_t q, int p, const float* wpack, const float* bias, float* g,
                               void* stream) {
-    if (!patches || !wpack || !bias || !g || q < 0 || p < 1) return PPS_ERR_ARG;
+    if (q < 0 || p < 1) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
+    if (!patches || !wpack || !bias || !g) return PPS_ERR_ARG;
     static int once = set_lds(pointnet_stn_rows_kernel, PA_LDS_BYTES);
     (void)once;
     const PnSplit sp = pn_split(q, p);
@@ -752,8 +755,9 @@ int pps_pointnet_stn_rows_f32(const float* patches, int64_t q, int p, const floa
 }
 
 int pps_pointnet_stn_fc_f32(const float* g, int64_t q, const float* wpack, const float* bias, float* trans2, void* stream) {
-    if (!g || !wpack || !bias || !trans2 || q < 0) return PPS_ERR_ARG;
+    if (q < 0) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
+    if (!g || !wpack || !bias || !trans2) return PPS_ERR_ARG;
     static int once = set_lds(pointnet_stn_fc_kernel, PB_LDS_BYTES);
     (void)once;
     hipLaunchKernelGGL(pointnet_stn_fc_kernel, dim3(grid_for((q + NW * 16 - 1) / (NW * 16))), dim3(NT), PB_LDS_BYTES, (hipStream_t)stream,
@@ -763,8 +767,9 @@ int pps_pointnet_stn_fc_f32(const float* g, int64_t q, const float* wpack, const
 
 int pps_pointnet_feat_rows_f32(const float* patches, const float* trans2, int64_t q, int p, const float* wpack,
                                const float* bias, float* xbar, void* stream) {
-    if (!patches || !trans2 || !wpack || !bias || !xbar || q < 0 || p < 1) return PPS_ERR_ARG;
+    if (q < 0 || p < 1) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
+    if (!patches || !trans2 || !wpack || !bias || !xbar) return PPS_ERR_ARG;
     static int once = set_lds(pointnet_feat_rows_kernel, PC_LDS_BYTES);
     (void)once;
     const PnSplit sp = pn_split(q, p);
@@ -780,8 +785,9 @@ int pps_pointnet_feat_rows_f32(const float* patches, const float* trans2, int64_
 
 int pps_decode_tail_f32(const float* pooled, const float* xbar, int64_t q, const float* wpack, const float* bias,
                         float* logits, float* occ, void* stream) {
-    if (!pooled || !xbar || !wpack || !bias || !logits || q < 0) return PPS_ERR_ARG;
+    if (q < 0) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
+    if (!pooled || !xbar || !wpack || !bias || !logits) return PPS_ERR_ARG;
     static int once = set_lds(decode_tail_kernel, TL_LDS_BYTES);
     (void)once;
     hipLaunchKernelGGL(decode_tail_kernel, dim3(grid_for((q + NW * 16 - 1) / (NW * 16))), dim3(NT), TL_LDS_BYTES, (hipStream_t)stream,

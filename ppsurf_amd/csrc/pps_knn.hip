@@ -332,8 +332,9 @@ int pps_knn_blocked_f32(const float* pts_blocked, const int32_t* orig_idx, const
 
 int pps_patch_normalize_f32(const float* raw, const float* query, const int64_t* idx, int64_t idx_stride, int64_t q, int p,
                             float* out, void* stream) {
-    if (!raw || !query || !idx || !out || q < 0 || p < 1 || idx_stride < p) return PPS_ERR_ARG;
+    if (q < 0 || p < 1) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
+    if (!raw || !query || !idx || !out || idx_stride < p) return PPS_ERR_ARG;
     hipLaunchKernelGGL(patch_normalize_kernel, dim3((unsigned)((q + 3) / 4)), dim3(256), 0, (hipStream_t)stream, raw, query, idx,
                        idx_stride, q, p, out);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;

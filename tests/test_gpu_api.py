@@ -133,3 +133,41 @@ def test_reconstruction_volume_matches_oracle_driver_and_writes_ply(tmp_path):
     if model.last_prediction is not None:
         v = meshio.read_ply_vertices(out)
         assert v.shape[0] == model.last_prediction[0].shape[0] and np.isfinite(v).all()
+
+
+def test_from_latent_batch_of_two_and_empty_queries():
+    """B > 1 (fit / validation batches) and degenerate query counts."""
+    net = network()
+    sd = filled_sd('', key='ppsurf')
+    rng = np.random.default_rng(8)
+    clouds = [make_cloud(900, seed=s) for s in (1, 2)]
+    qry = [(c[rng.choice(900, 70)] + rng.normal(0, 0.01, (70, 3))).astype(np.float32) for c in clouds]
+    lat = np.concatenate([make_latents(256, 900, seed=s) for s in (1, 2)], axis=0)
+    patches = np.stack([O.get_pts_local_ps(c, q, 50) for c, q in zip(clouds, qry)])
+    data = {'latents': torch.from_numpy(lat), 'pts': torch.from_numpy(np.stack([c.T for c in clouds]).copy()),
+            'pts_query': torch.from_numpy(np.stack(qry)), 'pts_local_ps': torch.from_numpy(patches)}
+    ref = O.ppsurf_from_latent(sd, data, k=64).numpy()
+    out = net.from_latent({k: v.to(DEV) for k, v in data.items()})
+    assert tuple(out.shape) == (2, 2, 70)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=1e-4)
+    empty = {'latents': torch.from_numpy(lat[:1]).to(DEV), 'pts': data['pts'][:1].to(DEV), 'pts_query': torch.zeros((1, 0, 3), device=DEV),
+             'pts_local_ps': torch.zeros((1, 0, 50, 3), device=DEV)}
+    assert tuple(net.from_latent(empty).shape) == (1, 2, 0)
+
+
+def test_tiny_cloud_clamps_k_everywhere():
+    """A cloud with fewer points than k=64 / 16: every table clamps (poco_utils.py:259-260) and the decoder masks the
+    missing neighbours."""
+    net = network()
+    sd = filled_sd('', key='ppsurf')
+    cloud = make_cloud(50, seed=21)
+    qry = (cloud[:9] + 0.01).astype(np.float32)
+    lat = make_latents(256, 50, seed=4)
+    patches = O.get_pts_local_ps(cloud, qry, 50)
+    data = {'latents': torch.from_numpy(lat), 'pts': torch.from_numpy(cloud.T.copy()).unsqueeze(0), 'pts_query': torch.from_numpy(qry).unsqueeze(0),
+            'pts_local_ps': torch.from_numpy(patches).unsqueeze(0)}
+    ref = O.ppsurf_from_latent(sd, data, k=64).numpy()
+    gd = {k: v.to(DEV) for k, v in data.items()}
+    out = net.from_latent(gd)
+    assert tuple(gd['proj_ids'].shape) == (1, 9, 50)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=1e-4)
