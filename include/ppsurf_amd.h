@@ -100,6 +100,14 @@ int pps_rows_dense256_f32(const float* in, int64_t in_row_stride, int64_t in_ch_
 int pps_interp_pool_f32(const float* G, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
                         const float* wpack, const float* bias, float* pooled, void* stream);
 
+/* The whole POCO projection head for small latent sizes (c in {32,64}; configs/poco.yaml: c = 32, nout = 2).
+ * replaces: source/poco_model.py:381-419 `InterpAttentionKHeadsNet.forward` incl. fc8 (POCO's `from_latent`, :357-359).
+ * G [n,c] = fc1[:, :c] latent + b1 (pps_rows_gemm_f32); wpack = concat(xyz pack fc1[:,c:c+3], dense packs fc2, fc3 [c,c],
+ * fc_query [64,c]); bias = concat(b2, b3, bq[64]); wtail = concat(fc8.fc_value composed [nout,c] row-major, bias [nout]);
+ * out f32 [q,nout], nout <= 8. */
+int pps_interp_small_f32(const float* G, const float* pts, const float* query, const int64_t* idx, int64_t q, int k, int c,
+                         const float* wpack, const float* bias, const float* wtail, int nout, float* out, void* stream);
+
 /* PointNet branch, phase A: per patch point conv0a, conv0b, STN conv1..3, max over the patch.
  * replaces: source/base/nn.py:323-324 and :164-170.   patches [q,p,3]; out g [q,256].
  * wpack = concat(xyz pack conv0a [64,3], dense conv0b [64,64], stn.conv1 [64,64], stn.conv2 [128,64], stn.conv3 [256,128]);

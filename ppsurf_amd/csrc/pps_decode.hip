@@ -256,6 +256,110 @@ __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restr
 }
 
 // =====================================================================================================
+// interp_small: the POCO projection head (source/poco_model.py:362-419 with latent_size C = 16*CB <= 64 and a handful of
+// output channels, configs/poco.yaml:47-48: C = 32, out = 2).  Same register-tile chain as interp_pool; all weights
+// (a few KiB) stay resident in LDS, and fc8 . fc_value (composed on the host) is applied to the pooled feature in place.
+// weights (floats): [xyz 64*CB][fc2 256*CB*CB][fc3 256*CB*CB][fcq 1024*CB]   bias: [16CB][16CB][64]   tail: [NOUT][16CB] + [NOUT]
+// =====================================================================================================
+#define IS_NT 256
+#define IS_MAX_OUT 8
+template <int CB>
+__global__ __launch_bounds__(IS_NT) void interp_small_kernel(const float* __restrict__ G, const float* __restrict__ pts,
+                                                             const float* __restrict__ query, const int64_t* __restrict__ idx,
+                                                             int64_t Q, int k, const float* __restrict__ wpack,
+                                                             const float* __restrict__ bias, const float* __restrict__ wtail, int nout,
+                                                             float* __restrict__ out) {
+    constexpr int C = 16 * CB, NWX = 64 * CB, NW2 = 256 * CB * CB, NWQ = 1024 * CB, NB = 2 * C + 64;
+    __shared__ __attribute__((aligned(16))) float lds[NWX + 2 * NW2 + NWQ + NB + 4 * 64 * 3 + 4 * C + IS_MAX_OUT * (C + 1)];
+    float* xyz_l = lds;
+    const f32x4* w2 = (const f32x4*)(lds + NWX);
+    const f32x4* w3 = (const f32x4*)(lds + NWX + NW2);
+    const f32x4* wq = (const f32x4*)(lds + NWX + 2 * NW2);
+    float* bias_l = lds + NWX + 2 * NW2 + NWQ;
+    float* msm = bias_l + NB;
+    float* mss = msm + 256;
+    float* f_l = mss + 256;
+    float* part = f_l + 256;                 // [4][C]
+    float* tail_l = part + 4 * C;            // [nout][C] then [nout]
+    const f32x4* bias4 = (const f32x4*)bias_l;
+    const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    for (int i = threadIdx.x; i < NWX + 2 * NW2 + NWQ; i += IS_NT) lds[i] = wpack[i];
+    for (int i = threadIdx.x; i < NB; i += IS_NT) bias_l[i] = bias[i];
+    for (int i = threadIdx.x; i < nout * (C + 1); i += IS_NT) tail_l[i] = wtail[i];
+    __syncthreads();
+    for (int64_t qi = blockIdx.x; qi < Q; qi += gridDim.x) {
+        const int row = wave * 16 + n;
+        const bool valid = row < k;
+        const int64_t i = idx[qi * k + (valid ? row : 0)];
+        f32x4 a[CB], h[CB], b[4];
+        const f32x4* grow = (const f32x4*)(G + i * C) + g;
+#pragma unroll
+        for (int bb = 0; bb < CB; ++bb) a[bb] = grow[4 * bb];
+        const float coord = (g < 3) ? (query[qi * 3 + g] - pts[i * 3 + g]) : 0.f;
+        xyz_blocks<CB>(coord, a, xyz_l, lane);
+        relu_blocks<CB>(a);
+        dense_blocks<CB, CB, 1>(a, h, w2, bias4, lane);
+        dense_blocks<CB, CB, 1>(h, a, w3, bias4 + 4 * CB, lane);
+        dense_blocks<CB, 4, 0>(a, b, wq, bias4 + 8 * CB, lane);           // 64 heads
+        float e[16];
+        {
+            f32x4 m4[4], s4[4];
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = valid ? b[bb][r] : -INFINITY;
+                    const float mx = row16_max(v);
+                    const float ev = valid ? __expf(v - mx) : 0.f;
+                    e[bb * 4 + r] = ev;
+                    m4[bb][r] = mx;
+                    s4[bb][r] = row16_sum(ev);
+                }
+            if (n < 4) {
+                const f32x4 mm = (n == 0) ? m4[0] : (n == 1) ? m4[1] : (n == 2) ? m4[2] : m4[3];
+                const f32x4 ss = (n == 0) ? s4[0] : (n == 1) ? s4[1] : (n == 2) ? s4[2] : s4[3];
+                ((f32x4*)(msm + wave * 64))[4 * n + g] = mm;
+                ((f32x4*)(mss + wave * 64))[4 * n + g] = ss;
+            }
+        }
+        __syncthreads();
+        {
+            float mw[4], sw[4];
+#pragma unroll
+            for (int w2i = 0; w2i < 4; ++w2i) { mw[w2i] = msm[w2i * 64 + lane]; sw[w2i] = mss[w2i * 64 + lane]; }
+            const float M = fmaxf(fmaxf(mw[0], mw[1]), fmaxf(mw[2], mw[3]));
+            float S = 0.f;
+#pragma unroll
+            for (int w2i = 0; w2i < 4; ++w2i) S += sw[w2i] * __expf(mw[w2i] - M);
+            f_l[wave * 64 + lane] = __expf(mw[wave] - M) / (64.f * S);
+        }
+        __syncthreads();
+        float an = 0.f;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const f32x4 f4 = ((const f32x4*)(f_l + wave * 64))[4 * bb + g];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) an += e[bb * 4 + r] * f4[r];
+        }
+        an += __shfl_xor(an, 16);
+        an += __shfl_xor(an, 32);
+#pragma unroll
+        for (int bb = 0; bb < CB; ++bb) {
+            f32x4 p;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = row16_sum(an * a[bb][r]);
+            if (n == 0) ((f32x4*)(part + wave * C))[4 * bb + g] = p;
+        }
+        __syncthreads();
+        if (threadIdx.x < nout) {
+            float acc = tail_l[nout * C + threadIdx.x];
+            for (int c = 0; c < C; ++c) acc += tail_l[threadIdx.x * C + c] * (part[c] + part[C + c] + part[2 * C + c] + part[3 * C + c]);
+            out[qi * nout + threadIdx.x] = acc;
+        }
+    }
+}
+
+// =====================================================================================================
 // PointNet phase A: conv0a, conv0b, stn.conv1..3 (+ReLU), max over the patch -> g[q,256]
 // weights (floats): [xyz 256][c0b 4096][s1 4096][s2 8192][s3 32768]   bias [64][64][64][128][256]
 //
@@ -734,6 +838,20 @@ int pps_interp_pool_f32(const float* G, const float* pts, const float* query, co
     (void)once;
     hipLaunchKernelGGL(interp_pool_kernel, dim3(grid_for((q + NW / 4 - 1) / (NW / 4))), dim3(NT), IP_LDS_BYTES, (hipStream_t)stream,
                        G, pts, query, idx, q, k, wpack, bias, pooled);
+    return PPS_LAUNCH_CHECK();
+}
+
+int pps_interp_small_f32(const float* G, const float* pts, const float* query, const int64_t* idx, int64_t q, int k, int c,
+                         const float* wpack, const float* bias, const float* wtail, int nout, float* out, void* stream) {
+    if (q < 0 || k < 1 || k > 64 || (c != 32 && c != 64) || nout < 1 || nout > IS_MAX_OUT) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    if (!G || !pts || !query || !idx || !wpack || !bias || !wtail || !out) return PPS_ERR_ARG;
+    int cus = cu_count();
+    if (cus <= 0) cus = 256;
+    const int grid = (int)(q < (int64_t)cus * 8 ? q : (int64_t)cus * 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (c == 32) hipLaunchKernelGGL(interp_small_kernel<2>, dim3(grid), dim3(IS_NT), 0, st, G, pts, query, idx, q, k, wpack, bias, wtail, nout, out);
+    else hipLaunchKernelGGL(interp_small_kernel<4>, dim3(grid), dim3(IS_NT), 0, st, G, pts, query, idx, q, k, wpack, bias, wtail, nout, out);
     return PPS_LAUNCH_CHECK();
 }
 

@@ -236,3 +236,47 @@ class ChunkPipeline:
             self.free[b].record(main)
         self.n += len(chunks)
         return out
+
+
+class PocoDecoderPlan:
+    """Packed weights of POCO's projection head (source/poco_model.py:362-419; latent size 32 or 64, few output channels).
+    fc1 is split like in DecoderPlan (per-point table G), fc8 . fc_value is composed on the host and applied after pooling."""
+
+    def __init__(self, sd, device, prefix='projection'):
+        p = prefix
+        w1, b1 = _wb(sd, p + '.fc1')
+        c = w1.shape[0]
+        if c not in (32, 64) or w1.shape[1] != c + 3:
+            raise NotImplementedError('the small-latent HIP decoder handles latent sizes 32 and 64 (got fc1 {})'.format(w1.shape))
+        w2, b2 = _wb(sd, p + '.fc2')
+        w3, b3 = _wb(sd, p + '.fc3')
+        wq, bq = _wb(sd, p + '.fc_query')
+        wv, bv = _wb(sd, p + '.fc_value')
+        w8, b8 = _wb(sd, p + '.fc8')
+        if wq.shape[0] != HEADS or w8.shape[0] > 8:
+            raise NotImplementedError('unexpected projection head sizes {} {}'.format(wq.shape, w8.shape))
+        f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+        self.c, self.nout, self.device = c, w8.shape[0], torch.device(device)
+        self.g_w, self.g_b = f32(pack_dense(w1[:, :c])), f32(b1)
+        self.w = f32(np.concatenate([pack_xyz(w1[:, c:]), pack_dense(w2), pack_dense(w3), pack_dense(wq)]))
+        self.b = f32(np.concatenate([b2, b3, bq]))
+        self.tail = f32(np.concatenate([(w8 @ wv).reshape(-1), w8 @ bv + b8]))
+
+    def point_table(self, latents_cn):
+        """G [N,c] from latents of SHAPE [c,N] (any strides)."""
+        lat = latents_cn.t().contiguous().float()
+        out = torch.empty_like(lat)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().pps_rows_gemm_f32(lat.data_ptr(), None, self.c, None, None, 0, self.g_w.data_ptr(), self.g_b.data_ptr(), None, 0,
+                                                lat.shape[0], self.c, out.data_ptr(), st), 'pps_rows_gemm_f32')
+        return out
+
+    def decode(self, table, pts, query, idx):
+        """table [N,c]; pts [N,3]; query [Q,3]; idx int64 [Q,k] -> logits [Q,nout]."""
+        q, k = query.shape[0], idx.shape[1]
+        out = torch.empty((q, self.nout), dtype=torch.float32, device=self.device)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().pps_interp_small_f32(table.data_ptr(), pts.data_ptr(), query.data_ptr(), idx.data_ptr(), q, k, self.c,
+                                                   self.w.data_ptr(), self.b.data_ptr(), self.tail.data_ptr(), self.nout, out.data_ptr(), st),
+                   'pps_interp_small_f32')
+        return out

@@ -18,7 +18,7 @@ import torch
 from torch import nn
 
 from . import spatial
-from .decoder import DecoderPlan
+from .decoder import DecoderPlan, PocoDecoderPlan
 from .encoder import EncoderPlan, FKAConvParams, ResidualBlockParams, gather_max
 
 try:                                                    # Lightning is optional (absent in the build image)
@@ -342,16 +342,30 @@ class PPSurfNetwork(_Base):
 
 
 class PocoNetwork(_Base):
-    """source/poco_model.py:332-359.  The encoder runs on the HIP path; the POCO projection head (latent size 32, 2 output
-    channels straight from fc8) has no native decoder kernel in this round."""
+    """source/poco_model.py:332-359: FKAConv encoder (ReLU, cv5 discarded) + the interpolation-attention head straight to logits."""
 
     def __init__(self, in_channels, latent_size, out_channels, k):
         super().__init__()
         self.encoder = FKAConvNetwork(in_channels, latent_size, segmentation=True, dropout=0, x4d_bug_fixed=False)
         self.projection = InterpAttentionKHeadsNet(latent_size, out_channels, k)
         self.lcp_preprocess = True
+        self._dec = None
+        self._table = None
         print('Network -- backbone -- {} parameters'.format(count_parameters(self.encoder)))
         print('Network -- projection -- {} parameters'.format(count_parameters(self.projection)))
+
+    def decoder_plan(self, device) -> PocoDecoderPlan:
+        ver = _params_version(self.projection) + (self.training,)
+        if self._dec is None or self._dec[0] != ver or self._dec[1].device != torch.device(device):
+            self._dec = (ver, PocoDecoderPlan({'projection.' + k: v for k, v in _sd(self.projection).items()}, device))
+            self._table = None
+        return self._dec[1]
+
+    def point_table(self, latents_b, plan):
+        key = (latents_b.data_ptr(), latents_b._version, tuple(latents_b.shape), tuple(latents_b.stride()), id(plan))
+        if self._table is None or self._table[0] != key:
+            self._table = (key, plan.point_table(latents_b))
+        return self._table[1]
 
     def get_latent(self, data):
         data['latents'] = self.encoder.forward(data, spectral_only=False)
@@ -359,9 +373,28 @@ class PocoNetwork(_Base):
         return data
 
     def forward(self, data):
+        """poco_model.py:345-349: encoder with the precomputed tables, projection with the PRECOMPUTED proj_ids."""
         data['latents'] = self.encoder.forward(data, spectral_only=True)
-        return self.from_latent(data)
+        return self._project(data, has_proj_ids=True)
 
     def from_latent(self, data):
-        raise NotImplementedError('POCO projection head (latent_size != 256 / out_channels != latent_size) has no HIP kernel yet; '
-                                  'the PPSurf decoder (PPSurfNetwork.from_latent) is the native path')
+        """poco_model.py:357-359: proj_ids are recomputed (has_proj_ids defaults to False, :381-387)."""
+        return self._project(data, has_proj_ids=False)
+
+    def _project(self, data, has_proj_ids):
+        from . import ops
+        _require_eval(self)
+        pts = _channel_first(data['pts'])
+        dev = pts.device
+        ptq = _channel_first(data['pts_query'].to(dev))
+        plan = self.decoder_plan(dev)
+        k = min(self.projection.k, pts.shape[2])
+        logits, ids_all = [], []
+        for b in range(pts.shape[0]):
+            pts_pm, q_pm = pts[b].t().contiguous().float(), ptq[b].t().contiguous().float()
+            idx = data['proj_ids'][b].contiguous() if has_proj_ids else ops.knn_point_major(pts_pm, q_pm, k)
+            logits.append(plan.decode(self.point_table(data['latents'][b], plan), pts_pm, q_pm, idx).t())
+            ids_all.append(idx)
+        if not has_proj_ids:
+            data['proj_ids'] = torch.stack(ids_all, dim=0)
+        return torch.stack(logits, dim=0)

@@ -29,7 +29,8 @@ def _dilate(mask: torch.Tensor, r: int) -> torch.Tensor:
 
 
 class OccupancyField:
-    """occ(q) for arbitrary query points of ONE shape: kNN + patches + decoder on the GPU, chunked by rec_batch_size."""
+    """occ(q) for arbitrary query points of ONE shape on the GPU, chunked by rec_batch_size.
+    PPSurf networks (with `point_net`): kNN + patches + fused decoder.  POCO networks: kNN + projection head."""
 
     def __init__(self, network, latent: dict, pts_raw_ms: torch.Tensor, num_pts: int, num_pts_local: typing.Optional[int]):
         self.net = network
@@ -37,25 +38,36 @@ class OccupancyField:
         pts = pts if pts.shape[1] == 3 else pts.transpose(1, 2)
         self.dev = pts.device
         self.pts = pts[0].t().contiguous().float()                        # [N,3]
-        self.raw = pts_raw_ms[0].to(self.dev).contiguous().float() if pts_raw_ms is not None else self.pts
-        self.same_cloud = self.raw.shape == self.pts.shape and bool(torch.equal(self.raw, self.pts))
         self.plan = network.decoder_plan(self.dev)
         self.table = network.point_table(latent['latents'][0], self.plan)
         self.k = min(network.projection.k, self.pts.shape[0])
-        self.p = num_pts_local
         self.chunk = int(num_pts)
         self.n_queries = 0
-        from .decoder import ChunkPipeline
-        self.pipe = ChunkPipeline(self.plan, self.table, self.pts, self.raw, self.k, self.p, self.same_cloud, self.chunk)
+        self.ppsurf = hasattr(network, 'point_net')
+        if self.ppsurf:
+            if num_pts_local is None:
+                raise ValueError('PPSurf networks need num_pts_local')
+            self.raw = pts_raw_ms[0].to(self.dev).contiguous().float() if pts_raw_ms is not None else self.pts
+            same = self.raw.shape == self.pts.shape and bool(torch.equal(self.raw, self.pts))
+            from .decoder import ChunkPipeline
+            self.pipe = ChunkPipeline(self.plan, self.table, self.pts, self.raw, self.k, num_pts_local, same, self.chunk)
+        else:
+            self.blocks = ops.KnnBlocks(self.pts)
 
     @torch.no_grad()
     def __call__(self, queries: torch.Tensor) -> torch.Tensor:
-        """queries [q,3] float32 on the device -> occ [q] float32 (= softmax(logits)[0] - softmax(logits)[1])."""
+        """queries [q,3] float32 on the device -> occ [q] float32 (= softmax(logits)[0] - softmax(logits)[1], poco_utils.py:78-81)."""
         if queries.shape[0] == 0:
             return torch.empty((0,), device=self.dev)
         chunks = [queries[s:s + self.chunk].contiguous() for s in range(0, queries.shape[0], self.chunk)]
         self.n_queries += queries.shape[0]
-        return torch.cat([occ for _, occ in self.pipe.run(chunks, want_occ=True)])
+        if self.ppsurf:
+            return torch.cat([occ for _, occ in self.pipe.run(chunks, want_occ=True)])
+        out = []
+        for q in chunks:
+            pr = torch.softmax(self.plan.decode(self.table, self.pts, q, self.blocks.query(q, self.k)), dim=1)
+            out.append(pr[:, 0] - pr[:, 1])
+        return torch.cat(out)
 
 
 def create_volume(field, pts_ids: torch.Tensor, resolution: int, step: float, bmin_pad: float, padding=1, dilation_size=2,
@@ -103,8 +115,6 @@ def export_mesh_and_refine_vertices_region_growing_v3(network, latent: dict, pts
     never crosses `mc_value`.  (The reference wraps the same arrays into a trimesh.Trimesh; ppsurf_amd.meshio writes PLY.)"""
     if latent['pts'].shape[0] != 1:
         raise ValueError('Reconstruction must be done with batch size = 0!')     # message kept from poco_utils.py:50
-    if num_pts_local is None:
-        raise NotImplementedError('the HIP decoder is the PPSurf decoder: num_pts_local is required')
     progress = None
     if prog_bar is not None and getattr(prog_bar, 'predict_progress_bar', None) is not None:
         progress = lambda s: prog_bar.predict_progress_bar.set_postfix_str('{}, {}'.format(pc_file_in[-24:], s), refresh=True)

@@ -171,3 +171,35 @@ def test_tiny_cloud_clamps_k_everywhere():
     out = net.from_latent(gd)
     assert tuple(gd['proj_ids'].shape) == (1, 9, 50)
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=1e-4)
+
+
+def test_poco_projection_head_and_network():
+    """POCO (configs/poco.yaml: latent 32, 2 output channels): projection head vs the reference golden, PocoNetwork API."""
+    from ppsurf_amd.decoder import PocoDecoderPlan
+    g = load_golden('interp_attention')
+    sd = filled_sd('IA_c32.')
+    plan = PocoDecoderPlan({k.replace('IA_c32.', 'projection.'): v for k, v in sd.items()}, DEV)
+    pts, q = g['c32_pts'][0], g['c32_query'][0]
+    lat = make_latents(32, pts.shape[1], seed=32)[0]
+    table = plan.point_table(torch.from_numpy(lat).to(DEV))
+    out = plan.decode(table, torch.from_numpy(pts.T.copy()).to(DEV), torch.from_numpy(q.T.copy()).to(DEV), torch.from_numpy(g['c32_ids'][0]).to(DEV))
+    np.testing.assert_allclose(out.cpu().numpy().T, g['c32_out'][0], rtol=0, atol=1e-4)      # k = 16 < 64: masked neighbours
+
+    from source.poco_model import PocoNetwork
+    from golden_util import manifest
+    from ppsurf_amd.synthetic import fill_param
+    net = PocoNetwork(in_channels=3, latent_size=32, out_channels=2, k=64)
+    psd = {k: torch.from_numpy(fill_param(k, s)) for k, s in manifest('poco')}
+    net.load_state_dict(psd)
+    net = net.to(DEV).eval()
+    cloud = make_cloud(1500, seed=2)
+    qry = (cloud[:80] + 0.01).astype(np.float32)
+    data = {'pts': torch.from_numpy(cloud.T.copy()).unsqueeze(0).to(DEV), 'pts_query': torch.from_numpy(qry).unsqueeze(0).to(DEV)}
+    torch.manual_seed(0)
+    data = net.get_latent(data)
+    assert tuple(data['latents'].shape) == (1, 32, 1500)
+    out = net.from_latent(data)
+    ref = O.interp_attention(psd, 'projection', data['latents'].cpu().contiguous(), O.knn(data['pts'].cpu(), data['pts_query'].cpu().transpose(1, 2), 64),
+                             data['pts'].cpu(), data['pts_query'].cpu().transpose(1, 2))
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-4)
+    assert tuple(data['proj_ids'].shape) == (1, 80, 64)

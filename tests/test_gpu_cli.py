@@ -69,3 +69,18 @@ def test_rec_rewrite_fit_and_cpu_are_refused(tmp_path):
         runner.main(['pps.py', 'fit'] + _configs(tmp_path, 'x.txt'))
     with pytest.raises(RuntimeError, match='no CPU path'):
         runner.main(['pps.py', 'predict'] + _configs(tmp_path, 'x.txt') + ['--trainer.accelerator', 'cpu'])
+
+
+def test_poco_model_predict_through_the_cli(tmp_path, capsys):
+    """configs/poco.yaml alone selects PocoModel / PocoDataModule (latent 32, no patches): predict runs natively too."""
+    from ppsurf_amd import runner
+    from ppsurf_amd.synthetic import write_dataset
+    in_file = write_dataset(str(tmp_path / 'ds'), n_shapes=1, n_pts=2000, n_query=100)
+    base = str(tmp_path / 'poco.yaml')
+    yaml.safe_dump(BASE, open(base, 'w'))
+    model = runner.main(['pps.py', 'predict', '-c', base, '--data.init_args.in_file', in_file, '--model.init_args.gen_resolution_global', '17',
+                         '--model.init_args.results_dir', str(tmp_path / 'res'), '--model.init_args.rec_batch_size', '2000'])
+    assert type(model).__name__ == 'PocoModel' and model.num_pts_local is None and model.network_latent_size == 32
+    out = capsys.readouterr().out
+    mesh_dir = tmp_path / 'res' / 'poco' / 'ds' / 'meshes'
+    assert (len(list(mesh_dir.glob('*.ply'))) if mesh_dir.exists() else 0) + out.count('No reconstruction for') == 1
