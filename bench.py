@@ -70,6 +70,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1 ('nccl' = RCCL; 'gloo' only for single-GPU rehearsals)")
+    ap.add_argument('--same-gpu', action='store_true', help='rehearsal: every rank uses cuda:0 (needs --backend gloo)')
     ap.add_argument('--overlap', action='store_true', help='run the spatial queries of chunk i+1 on a side stream (A/B; no gain measured)')
     args = ap.parse_args()
 
@@ -78,13 +80,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit('--gpus {} needs torch.distributed.run with {} ranks (WORLD_SIZE={})'.format(args.gpus, args.gpus, world))
+    if args.same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from golden_util import filled_sd
     from ppsurf_amd import ops
@@ -119,7 +126,7 @@ def main():
     dt = time.perf_counter() - t0
     logits, occ = results[-1]
     from ppsurf_amd import sharding
-    dt = sharding.max_over_ranks(dt, dev)
+    dt = sharding.max_over_ranks(dt, dev if args.backend == 'nccl' else 'cpu')
     assert bool(torch.isfinite(occ).all())
 
     if rank == 0:
