@@ -19,7 +19,9 @@ using namespace pps;
 #define NT 256                 // threads per workgroup (4 waves); 2 workgroups per CU run decoupled
 #endif
 #define NW (NT / 64)            // waves per workgroup
+#ifndef WG_PER_CU
 #define WG_PER_CU (512 / NT)
+#endif
 #define CH4 2048               // f32x4 per 32 KiB weight chunk
 
 // One pipeline step: request the NEXT chunk, compute on the CURRENT one, publish the next, barrier.
