@@ -14,7 +14,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import spatial
+from . import spatial, sharding
 from .modules import _Base, PocoNetwork, PPSurfNetwork
 
 
@@ -178,26 +178,55 @@ class PocoModel(_Base):
     def encode_latents(self, pts_cf: torch.Tensor, progress=None) -> torch.Tensor:
         """Latent loop of poco_model.py:203-236 for one cloud.  pts_cf [3,N] on the device -> latents POINT-MAJOR [N,C]:
         coverage-balanced random subsets of gen_subsample_manifold points until every point has been encoded
-        gen_subsample_manifold_iter times; latents are averaged."""
+        gen_subsample_manifold_iter times; latents are averaged.
+
+        With torch.distributed initialised and `shard_queries` set, the encoder passes of each coverage round are dealt
+        round-robin to the ranks (the subset selection comes from a generator seeded identically on every rank) and the
+        partial sums / counts are all-reduced once per round."""
         n, dev = pts_cf.shape[1], pts_cf.device
         latent = torch.zeros((n, self.network_latent_size), dtype=torch.float32, device=dev)
         counts = torch.zeros((n,), dtype=torch.float32, device=dev)
         m = self.gen_subsample_manifold
+        rank, world = sharding.world() if getattr(self, 'shard_queries', False) else (0, 1)
+        gen = None
+        if world > 1:
+            gen = torch.Generator(device='cpu')
+            gen.manual_seed(int(n) * 1000003 + 12345)
+
+        def randperm(k):
+            return torch.randperm(k, device=dev) if gen is None else torch.randperm(k, generator=gen).to(dev)
+
         iteration = 0
         for current_value in range(self.gen_subsample_manifold_iter):
             while float(counts.min()) < current_value + 1:
-                if n >= m:
-                    valid_ids = torch.nonzero(counts == current_value)[:, 0]
-                    ids = valid_ids[torch.randperm(valid_ids.shape[0], device=dev)[:m]]
-                    if ids.shape[0] < m:
-                        ids = torch.cat([ids, torch.randperm(n, device=dev)[:m - ids.shape[0]]], dim=0)
-                    assert ids.shape[0] == m
-                else:
-                    ids = torch.arange(n, device=dev)
-                data_partial = {'pts': pts_cf[:, ids].unsqueeze(0)}
-                data_partial.update(spatial.get_fkaconv_ids(data_partial))
-                latent[ids] += self.network.encoder.forward_point_major(data_partial, 0)    # duplicates: last write wins, like the reference
-                counts[ids] += 1
+                # one "wave" of passes: with one rank exactly the reference's loop body; with several ranks every rank draws
+                # the same `world` consecutive subsets of the still uncovered points and encodes the one it owns
+                part = torch.zeros_like(latent) if world > 1 else latent
+                cnt = torch.zeros_like(counts) if world > 1 else counts
+                covered = counts.clone()
+                for r in range(world):
+                    if n >= m:
+                        valid_ids = torch.nonzero(covered == current_value)[:, 0]
+                        if valid_ids.shape[0] == 0 and r > 0:
+                            break
+                        ids = valid_ids[randperm(valid_ids.shape[0])[:m]]
+                        if ids.shape[0] < m:
+                            ids = torch.cat([ids, randperm(n)[:m - ids.shape[0]]], dim=0)
+                        assert ids.shape[0] == m
+                    else:
+                        ids = torch.arange(n, device=dev)
+                    covered[ids] += 1
+                    if r == rank:
+                        data_partial = {'pts': pts_cf[:, ids].unsqueeze(0)}
+                        data_partial.update(spatial.get_fkaconv_ids(data_partial))
+                        part[ids] += self.network.encoder.forward_point_major(data_partial, 0)   # duplicates: last write wins, like the reference
+                        cnt[ids] += 1
+                    if n < m:
+                        break
+                if world > 1:
+                    sharding.allreduce_latents(part, cnt)
+                    latent += part
+                    counts += cnt
                 iteration += 1
                 if progress is not None:
                     progress('get_latent iter: {}'.format(iteration))
@@ -227,6 +256,8 @@ class PocoModel(_Base):
             resolution=self.gen_resolution_global, padding=1, mc_value=0, num_pts=self.rec_batch_size, num_pts_local=self.num_pts_local,
             input_points=pts_cf.t().cpu().numpy(), refine_iter=self.gen_refine_iter, out_value=1, prog_bar=bar, pc_file_in=pc_file_in)
         self.last_prediction = mesh
+        if getattr(self, 'shard_queries', False) and sharding.world()[0] != 0:
+            return 0                                                   # every rank holds the same mesh; rank 0 writes it
         if mesh is not None:
             verts, faces = mesh
             if not in_file_is_dataset(self.in_file):               # de-normalise single files (poco_model.py:256-265)

@@ -149,7 +149,7 @@ def export_mesh_and_refine_vertices_region_growing_v3(network, latent: dict, pts
         verts = verts * step + bmin_pad
         vq = (v * step + bmin_pad).to(torch.float32)
         for it in range(refine_iter):                                       # bisection (poco_utils.py:146-165)
-            pr = field(vq).to(torch.float64)
+            pr = sharding.sharded_map(field, vq).to(torch.float64)
             m1 = (pr * p1) > 0
             v1[m1] = vq[m1]; p1[m1] = pr[m1]
             m2 = (pr * p2) > 0

@@ -137,9 +137,23 @@ def main(argv=None):
         state = torch.load(ckpt, map_location='cpu')
         model.load_state_dict(state.get('state_dict', state))
     model.__dict__['_runner_trainer'] = _Trainer()
+    # multi-GPU predict (launched with torch.distributed.run, one rank per GPU, RCCL): PPS_SHARD=shapes (default) deals the
+    # shapes of the test set round-robin to the ranks, no communication; PPS_SHARD=queries shards the query blocks and the
+    # encoder passes of every shape over all ranks (latent all-reduce + per-round all-gather of occupancies).
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    shard = os.environ.get('PPS_SHARD', 'shapes')
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group(os.environ.get('PPS_BACKEND', 'nccl'), rank=rank, world_size=world)
+        model.shard_queries = shard == 'queries'
+        from . import sharding
+        sharding.set_query_sharding(model.shard_queries)
     with torch.no_grad():
         if sub == 'predict':
             for i, batch in enumerate(data.predict_dataloader()):
+                if world > 1 and shard == 'shapes' and i % world != rank:
+                    continue
                 model.predict_step(batch, i)
         else:
             for i, batch in enumerate(data.test_dataloader()):

@@ -6,6 +6,16 @@ single exchange per growth round: a variable-length all-gather of 4 bytes per qu
 import torch
 
 
+_QUERY_SHARDING = False
+
+
+def set_query_sharding(on: bool):
+    """Query-block sharding inside one shape is opt-in: with shape-level sharding the ranks work on different shapes and
+    must not meet in a collective."""
+    global _QUERY_SHARDING
+    _QUERY_SHARDING = bool(on)
+
+
 def world():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
@@ -26,7 +36,7 @@ def sharded_map(fn, items: torch.Tensor) -> torch.Tensor:
     import torch.distributed as dist
     rank, ws = world()
     n = items.shape[0]
-    if ws == 1:
+    if ws == 1 or not _QUERY_SHARDING:
         return fn(items)
     lo, hi = shard_range(n, rank, ws)
     local = fn(items[lo:hi]).to(torch.float32).contiguous()

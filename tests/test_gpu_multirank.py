@@ -1,0 +1,62 @@
+"""Two ranks on ONE GPU over gloo (rehearsal of the RCCL paths the driver runs on 8 GPUs): query/pass-sharded predict of
+one shape must give the single-rank mesh inputs (same volume), shape-sharded predict must split the test set."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from golden_util import REPO
+
+pytestmark = pytest.mark.gpu
+
+SCRIPT = r'''
+import os, sys
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, 'tests'))
+import numpy as np, torch, torch.distributed as dist
+from golden_util import filled_sd
+from source.ppsurf_model import PPSurfModel
+from ppsurf_amd import reconstruct, sharding
+from ppsurf_amd.synthetic import make_cloud
+rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+if world > 1:
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sharding.set_query_sharding(True)
+torch.manual_seed(7)
+model = PPSurfModel(pointnet_latent_size=256, output_names=['imp_surf_sign'], in_channels=3, out_channels=2, k=64, lambda_l1=0.0, debug=False,
+                    in_file='c.npy', results_dir={out!r}, padding_factor=0.05, name='t', network_latent_size=256, gen_subsample_manifold_iter=2,
+                    gen_subsample_manifold=1000, gen_resolution_global=17, num_pts_local=50, rec_batch_size=700, gen_refine_iter=0, workers=0)
+model.network.load_state_dict(filled_sd('', key='ppsurf'))
+model = model.to('cuda:0').eval()
+model.shard_queries = world > 1
+cloud = make_cloud(2500, seed=3)
+pts_cf = torch.from_numpy(cloud.T.copy()).to('cuda:0')
+lat = model.encode_latents(pts_cf)
+assert torch.isfinite(lat).all()
+# volume on FIXED latents (the latent loop is stochastic): both runs must agree exactly
+fixed = torch.from_numpy(np.random.default_rng(1).standard_normal((2500, 256)).astype(np.float32)).to('cuda:0')
+shape = {{'pts': pts_cf.unsqueeze(0), 'latents': fixed.t().unsqueeze(0)}}
+field = reconstruct.OccupancyField(model.network, shape, torch.from_numpy(cloud).unsqueeze(0), 700, 50)
+bmin, bmax = cloud.min(), cloud.max(); step = (bmax - bmin) / 16
+ids = torch.from_numpy(((cloud - bmin) / step + 1).astype(np.int32).astype(np.int64)).to('cuda:0')
+vol = reconstruct.create_volume(field, ids, 17, step, bmin - step).cpu().numpy()
+np.save(os.path.join({out!r}, 'vol_w{{}}_r{{}}.npy'.format(world, rank)), vol)
+np.save(os.path.join({out!r}, 'nq_w{{}}_r{{}}.npy'.format(world, rank)), np.array([field.n_queries, float(lat.abs().mean())]))
+'''
+
+
+def test_query_sharded_volume_equals_single_rank(tmp_path):
+    script = tmp_path / 'run.py'
+    script.write_text(SCRIPT.format(repo=REPO, out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    subprocess.check_call([sys.executable, str(script)], env=env, timeout=600)
+    subprocess.check_call([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                           '--master-port', str(29600 + os.getpid() % 300), str(script)], env=env, timeout=600)
+    v1 = np.load(tmp_path / 'vol_w1_r0.npy')
+    a, b = np.load(tmp_path / 'vol_w2_r0.npy'), np.load(tmp_path / 'vol_w2_r1.npy')
+    assert np.array_equal(np.isnan(a), np.isnan(v1)) and np.array_equal(np.nan_to_num(a), np.nan_to_num(b))
+    np.testing.assert_allclose(np.nan_to_num(a), np.nan_to_num(v1), rtol=0, atol=2e-5)
+    n1 = np.load(tmp_path / 'nq_w1_r0.npy')[0]
+    n2 = np.load(tmp_path / 'nq_w2_r0.npy')[0] + np.load(tmp_path / 'nq_w2_r1.npy')[0]
+    assert n2 == n1                                                     # the two ranks decoded disjoint halves

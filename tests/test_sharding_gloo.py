@@ -20,6 +20,7 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from ppsurf_amd import sharding
     from ppsurf_amd.reconstruct import create_volume
+    sharding.set_query_sharding(True)
     g = load_golden('create_volume')
     seen = []
 
