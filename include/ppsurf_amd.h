@@ -169,6 +169,38 @@ int pps_rows_linear_f32(const float* in1, const int64_t* idx1, int c1, const flo
 /* out[m,c] = max_j x[idx[m,j], c].   replaces: source/base/nn.py:677-680 `max_pool` and the global max of :531. */
 int pps_gather_max_f32(const float* x, const int64_t* idx, int64_t m, int k, int c, float* out, void* stream);
 
+/* ---- training step: neighbourhood gathers with hand-written backward ------------------------------------------------ */
+/* Scatter-adds (the transposes of the gathers) use no atomics: the caller passes the CSR of the id table,
+ *   order   int64 [entries]  entry numbers (m*k + j, or the row number r for a flat table) stably sorted by target row,
+ *   offsets int64 [n+1]      entries of target row i are order[offsets[i] .. offsets[i+1]),
+ * and every target row adds its contributions in that fixed order (bit-reproducible gradients). */
+
+/* out[r,:] = x[idx[r],:].   replaces: source/base/nn.py:655-674 `batch_gather` for the latent gather of
+ * source/poco_model.py:400 and the nearest-neighbour up-sampling of nn.py:684-697. */
+int pps_gather_rows_f32(const float* x, const int64_t* idx, int64_t r, int c, float* out, void* stream);
+
+/* out[i,:] = sum_{e in offsets[i]..offsets[i+1]} vals[order[e],:]  (vals [entries,c], out [n,c]): backward of
+ * pps_gather_rows_f32 and second half of the backward of pps_neighbour_contract_fwd_f32. */
+int pps_segment_sum_rows_f32(const float* vals, const int64_t* order, const int64_t* offsets, int64_t n, int c, float* out,
+                             void* stream);
+
+/* FKAConv feature aggregation, out[m, ch*16+t] = sum_j x[idx[m,j], ch] * g[m,j,t]  (x [n,c], idx int64 [m,k], g [m,k,16],
+ * out [m, c*16] in the (channel, kernel-column) order of cv.weight[Cout, Cin, 1, 16]).
+ * replaces: source/base/nn.py:598,647-649 (batch_gather of the features + the two transposes around torch.matmul). */
+int pps_neighbour_contract_fwd_f32(const float* x, const int64_t* idx, const float* g, int64_t m, int k, int c, float* out,
+                                   void* stream);
+/* its backward: dxg [m,k,c] = per-entry gradient of the gathered rows (NULL to skip; reduce it to x rows with
+ * pps_segment_sum_rows_f32), dg [m,k,16] (NULL to skip). */
+int pps_neighbour_contract_bwd_f32(const float* x, const int64_t* idx, const float* g, const float* dout, int64_t m, int k, int c,
+                                   float* dxg, float* dg, void* stream);
+
+/* Neighbourhood max-pool that also records the winning neighbour: out [m,c], arg int32 [m,c] (first j attaining the max).
+ * replaces: source/base/nn.py:677-680 `max_pool` in training. */
+int pps_gather_max_arg_f32(const float* x, const int64_t* idx, int64_t m, int k, int c, float* out, int32_t* arg, void* stream);
+/* its backward: dx [n,c] from dout [m,c], arg and the CSR of idx. */
+int pps_gather_max_bwd_f32(const float* dout, const int32_t* arg, const int64_t* order, const int64_t* offsets, int64_t n, int k,
+                           int c, float* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

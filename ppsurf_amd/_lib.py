@@ -38,6 +38,12 @@ SIGNATURES = {
     'pps_rows_linear_f32': (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I64, _I, _P, _P]),
     'pps_rows_gemm_f32': (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I64, _I, _P, _P]),
     'pps_gather_max_f32': (_I, [_P, _P, _I64, _I, _I, _P, _P]),
+    'pps_gather_rows_f32': (_I, [_P, _P, _I64, _I, _P, _P]),
+    'pps_segment_sum_rows_f32': (_I, [_P, _P, _P, _I64, _I, _P, _P]),
+    'pps_neighbour_contract_fwd_f32': (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
+    'pps_neighbour_contract_bwd_f32': (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _P, _P]),
+    'pps_gather_max_arg_f32': (_I, [_P, _P, _I64, _I, _I, _P, _P, _P]),
+    'pps_gather_max_bwd_f32': (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _P]),
 }
 
 _lib = None

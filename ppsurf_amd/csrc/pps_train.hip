@@ -1,0 +1,221 @@
+// Neighbourhood gather / scatter kernels of the TRAINING step, forward and backward (gfx950).
+//
+// The dense layers of a fit step are library GEMMs over all rows of the batch; what is specific to this network is the
+// neighbourhood traffic: gather x rows through an id table, contract with the 16x16 kernel weights of the FKAConv layer,
+// max-pool over a neighbourhood, gather latent rows for the interpolation head -- and the transposes of all of these in the
+// backward pass, which are scatter-adds.  Scatter-adds are done WITHOUT atomics: the caller sorts the id table once per step
+// (stable sort -> `order`, `offsets`: CSR of "which (m,j) entries point at row n") and every output row sums its own
+// contributions in a fixed order, so gradients are bit-reproducible from run to run.
+//
+// All kernels are HBM/L2-bandwidth bound streaming kernels: one thread per (row, channel) with the channel fastest, so every
+// row access is a contiguous C*4-byte segment; id tables are read as wave-wide broadcasts.
+//
+// replaces (reference, under autograd): source/base/nn.py:655-674 `batch_gather` (+ its index_add backward), :677-680
+// `max_pool`, :647-649 the FKAConv feature aggregation, source/poco_model.py:400 the latent gather of the interpolation head.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ppsurf_amd.h"
+
+namespace {
+
+constexpr int TB = 256;
+constexpr int KT = 16;          // FKAConv kernel size (columns of the weighting matrix)
+
+inline int launch_status() { return hipGetLastError() == hipSuccess ? 0 : 2; }
+inline unsigned blocks_for(int64_t threads) { return (unsigned)((threads + TB - 1) / TB); }
+
+__device__ __forceinline__ void vadd(float4& a, const float4& v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+__device__ __forceinline__ void vadd(float& a, const float& v) { a += v; }
+__device__ __forceinline__ void vzero(float4& a) { a = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void vzero(float& a) { a = 0.f; }
+
+// out[r, :] = x[idx[r], :]           (V = float4 when C % 4 == 0, else float; c4 = row length in units of V)
+template <typename V>
+__global__ void __launch_bounds__(TB) gather_rows_kernel(const V* __restrict__ x, const int64_t* __restrict__ idx,
+                                                         int64_t r, int c4, V* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (t >= r * c4) return;
+    const int64_t row = t / c4;
+    const int col = (int)(t - row * c4);
+    out[t] = x[idx[row] * c4 + col];
+}
+
+// out[n, :] = sum over e in [offsets[n], offsets[n+1]) of vals[order[e], :]   (fixed order: deterministic)
+template <typename V>
+__global__ void __launch_bounds__(TB) segment_sum_rows_kernel(const V* __restrict__ vals, const int64_t* __restrict__ order,
+                                                              const int64_t* __restrict__ offsets, int64_t n, int c4,
+                                                              V* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (t >= n * c4) return;
+    const int64_t row = t / c4;
+    const int col = (int)(t - row * c4);
+    V acc;
+    vzero(acc);
+    const int64_t e1 = offsets[row + 1];
+    for (int64_t e = offsets[row]; e < e1; ++e) vadd(acc, vals[order[e] * c4 + col]);
+    out[t] = acc;
+}
+
+// FKAConv feature aggregation: out[m, c*16 + t] = sum_j x[idx[m,j], c] * g[m,j,t]
+__global__ void __launch_bounds__(TB) contract_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
+                                                          const float* __restrict__ g, int64_t m, int k, int c,
+                                                          float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (t >= m * c) return;
+    const int64_t row = t / c;
+    const int ch = (int)(t - row * c);
+    float acc[KT];
+#pragma unroll
+    for (int i = 0; i < KT; ++i) acc[i] = 0.f;
+    const float4* gm = (const float4*)(g + row * k * KT);
+    for (int j = 0; j < k; ++j) {
+        const float xv = x[idx[row * k + j] * c + ch];
+#pragma unroll
+        for (int i = 0; i < KT / 4; ++i) {
+            const float4 w = gm[j * (KT / 4) + i];
+            acc[4 * i + 0] += xv * w.x; acc[4 * i + 1] += xv * w.y; acc[4 * i + 2] += xv * w.z; acc[4 * i + 3] += xv * w.w;
+        }
+    }
+    float4* o = (float4*)(out + t * KT);
+#pragma unroll
+    for (int i = 0; i < KT / 4; ++i) o[i] = make_float4(acc[4 * i], acc[4 * i + 1], acc[4 * i + 2], acc[4 * i + 3]);
+}
+
+// backward, part 1: per gathered entry  dxg[m,j,c] = sum_t dout[m, c*16+t] * g[m,j,t]   (scattered to x rows by segment_sum)
+__global__ void __launch_bounds__(TB) contract_bwd_x_kernel(const float* __restrict__ dout, const float* __restrict__ g,
+                                                            int64_t m, int k, int c, float* __restrict__ dxg) {
+    const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (t >= m * c) return;
+    const int64_t row = t / c;
+    const int ch = (int)(t - row * c);
+    float d[KT];
+    const float4* dp = (const float4*)(dout + t * KT);
+#pragma unroll
+    for (int i = 0; i < KT / 4; ++i) { const float4 v = dp[i]; d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w; }
+    const float4* gm = (const float4*)(g + row * k * KT);
+    for (int j = 0; j < k; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < KT / 4; ++i) {
+            const float4 w = gm[j * (KT / 4) + i];
+            s += d[4 * i] * w.x + d[4 * i + 1] * w.y + d[4 * i + 2] * w.z + d[4 * i + 3] * w.w;
+        }
+        dxg[(row * k + j) * c + ch] = s;
+    }
+}
+
+// backward, part 2: dg[m,j,t] = sum_c dout[m, c*16+t] * x[idx[m,j], c]      one thread per (m, j, t), t fastest
+__global__ void __launch_bounds__(TB) contract_bwd_g_kernel(const float* __restrict__ dout, const float* __restrict__ x,
+                                                            const int64_t* __restrict__ idx, int64_t m, int k, int c,
+                                                            float* __restrict__ dg) {
+    const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (t >= m * k * KT) return;
+    const int tt = (int)(t % KT);
+    const int64_t mj = t / KT;
+    const int64_t row = mj / k;
+    const float* xr = x + idx[mj] * c;
+    const float* dr = dout + row * c * KT + tt;
+    float s = 0.f;
+    for (int ch = 0; ch < c; ++ch) s += dr[ch * KT] * xr[ch];
+    dg[t] = s;
+}
+
+// out[m,c] = max_j x[idx[m,j], c], arg[m,c] = first j attaining it
+__global__ void __launch_bounds__(TB) gather_max_arg_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
+                                                            int64_t m, int k, int c, float* __restrict__ out,
+                                                            int32_t* __restrict__ arg) {
+    const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (t >= m * c) return;
+    const int64_t row = t / c;
+    const int ch = (int)(t - row * c);
+    float best = x[idx[row * k] * c + ch];
+    int bj = 0;
+    for (int j = 1; j < k; ++j) {
+        const float v = x[idx[row * k + j] * c + ch];
+        if (v > best) { best = v; bj = j; }
+    }
+    out[t] = best;
+    arg[t] = bj;
+}
+
+// dx[n,c] = sum over entries e=(m,j) pointing at n (CSR order) of dout[m,c] * [arg[m,c] == j]
+__global__ void __launch_bounds__(TB) gather_max_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ arg,
+                                                            const int64_t* __restrict__ order, const int64_t* __restrict__ offsets,
+                                                            int64_t n, int k, int c, float* __restrict__ dx) {
+    const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (t >= n * c) return;
+    const int64_t row = t / c;
+    const int ch = (int)(t - row * c);
+    float acc = 0.f;
+    const int64_t e1 = offsets[row + 1];
+    for (int64_t e = offsets[row]; e < e1; ++e) {
+        const int64_t mj = order[e];
+        const int64_t mm = mj / k;
+        const int j = (int)(mj - mm * k);
+        if (arg[mm * c + ch] == j) acc += dout[mm * c + ch];
+    }
+    dx[t] = acc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pps_gather_rows_f32(const float* x, const int64_t* idx, int64_t r, int c, float* out, void* stream) {
+    if (r < 0 || c < 1) return 1;
+    if (r == 0) return 0;
+    if (!x || !idx || !out) return 1;
+    if (c & 3) gather_rows_kernel<float><<<blocks_for(r * c), TB, 0, (hipStream_t)stream>>>(x, idx, r, c, out);
+    else gather_rows_kernel<float4><<<blocks_for(r * (c / 4)), TB, 0, (hipStream_t)stream>>>((const float4*)x, idx, r, c / 4, (float4*)out);
+    return launch_status();
+}
+
+int pps_segment_sum_rows_f32(const float* vals, const int64_t* order, const int64_t* offsets, int64_t n, int c, float* out,
+                             void* stream) {
+    if (n < 0 || c < 1) return 1;
+    if (n == 0) return 0;
+    if (!order || !offsets || !out) return 1;          /* vals may be NULL only when there are no entries at all */
+    if (c & 3) segment_sum_rows_kernel<float><<<blocks_for(n * c), TB, 0, (hipStream_t)stream>>>(vals, order, offsets, n, c, out);
+    else segment_sum_rows_kernel<float4><<<blocks_for(n * (c / 4)), TB, 0, (hipStream_t)stream>>>((const float4*)vals, order, offsets, n,
+                                                                                              c / 4, (float4*)out);
+    return launch_status();
+}
+
+int pps_neighbour_contract_fwd_f32(const float* x, const int64_t* idx, const float* g, int64_t m, int k, int c, float* out,
+                                   void* stream) {
+    if (m < 0 || k < 1 || c < 1) return 1;
+    if (m == 0) return 0;
+    if (!x || !idx || !g || !out) return 1;
+    contract_fwd_kernel<<<blocks_for(m * c), TB, 0, (hipStream_t)stream>>>(x, idx, g, m, k, c, out);
+    return launch_status();
+}
+
+int pps_neighbour_contract_bwd_f32(const float* x, const int64_t* idx, const float* g, const float* dout, int64_t m, int k, int c,
+                                   float* dxg, float* dg, void* stream) {
+    if (m < 0 || k < 1 || c < 1) return 1;
+    if (m == 0) return 0;
+    if (!x || !idx || !g || !dout || (!dxg && !dg)) return 1;
+    if (dxg) contract_bwd_x_kernel<<<blocks_for(m * c), TB, 0, (hipStream_t)stream>>>(dout, g, m, k, c, dxg);
+    if (dg) contract_bwd_g_kernel<<<blocks_for(m * k * KT), TB, 0, (hipStream_t)stream>>>(dout, x, idx, m, k, c, dg);
+    return launch_status();
+}
+
+int pps_gather_max_arg_f32(const float* x, const int64_t* idx, int64_t m, int k, int c, float* out, int32_t* arg, void* stream) {
+    if (m < 0 || k < 1 || c < 1) return 1;
+    if (m == 0) return 0;
+    if (!x || !idx || !out || !arg) return 1;
+    gather_max_arg_kernel<<<blocks_for(m * c), TB, 0, (hipStream_t)stream>>>(x, idx, m, k, c, out, arg);
+    return launch_status();
+}
+
+int pps_gather_max_bwd_f32(const float* dout, const int32_t* arg, const int64_t* order, const int64_t* offsets, int64_t n, int k,
+                           int c, float* dx, void* stream) {
+    if (n < 0 || k < 1 || c < 1) return 1;
+    if (n == 0) return 0;
+    if (!order || !offsets || !dx) return 1;
+    gather_max_bwd_kernel<<<blocks_for(n * c), TB, 0, (hipStream_t)stream>>>(dout, arg, order, offsets, n, k, c, dx);
+    return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,260 @@
+"""Train-mode forward of the networks as an autograd graph (fit / training_step path).
+
+The inference path (ppsurf_amd/decoder.py, encoder.py) folds eval-mode BatchNorm into packed weights and never leaves
+registers; training cannot do that: every BatchNorm needs statistics over the whole batch before the next layer starts, the
+activations are needed again by the backward pass, and the weights change every step.  So the training step is organised
+differently: POINT-MAJOR activations `[rows, C]` that stay resident in HBM (a fit batch is ~3 GB of activations on a 288 GB
+part), dense layers as plain library GEMMs over all rows of the batch at once, and the neighbourhood work -- kNN tables, patch
+search, gathers, per-neighbourhood pooling -- as HIP kernels with hand-written backward (ppsurf_amd/train_ops.py).  The id
+tables are built on the device inside the step (spatial.get_data_poco), not by DataLoader worker processes.
+
+The parameter holders of ppsurf_amd/modules.py are used directly (same state-dict names as the reference, so the optimizer
+classes named in configs/poco.yaml work on `model.parameters()` and checkpoints stay interchangeable).
+
+Semantics restated from the reference, train() mode:
+  FKAConvLayer       source/base/nn.py:592-652  (norm_radius EMA :608-613, InstanceNorm skipped when K == 1 :627-638)
+  ResidualBlock      source/base/nn.py:438-450
+  FKAConvNetwork     source/base/nn.py:508-554  (x4d_bug_fixed :531-534)
+  InterpAttention    source/poco_model.py:381-419
+  STN / PointNetfeat source/base/nn.py:162-190, 305-373 ; AttentionPoco :84-96 ; MLP :376-417
+  networks           source/ppsurf_model.py:70-117, source/poco_model.py:345-359
+Parity: tests/test_train_graph_cpu.py and tests/test_gpu_train.py against tests/golden/train_*.npz (outputs, loss, updated
+buffers and parameter gradients recorded from the reference itself).
+"""
+import torch
+import torch.nn.functional as F
+
+from . import train_ops
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# small layers on [rows, C]
+# ---------------------------------------------------------------------------------------------------------------------
+def _w2d(layer):
+    w = layer.weight
+    return w.reshape(w.shape[0], -1)
+
+
+def dense(layer, x):
+    """1x1 Conv1d / Conv2d / Linear holder applied to rows."""
+    return F.linear(x, _w2d(layer), layer.bias)
+
+
+def batch_norm(bn, x):
+    """BatchNorm1d holder on [rows, C]: batch statistics + running-stat update in train(), running stats in eval()."""
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
+
+
+def _act(name):
+    return F.silu if name == 'silu' else F.relu
+
+
+def _instance_norm(inorm, m):
+    """InstanceNorm2d(affine, no running stats) on [B, M, K, C]: statistics over (M, K) per batch item and channel."""
+    mean = m.mean(dim=(1, 2), keepdim=True)
+    var = m.var(dim=(1, 2), unbiased=False, keepdim=True)
+    return (m - mean) * torch.rsqrt(var + inorm.eps) * inorm.weight + inorm.bias
+
+
+_flat_cache = {}
+
+
+def _flat_ids(ids, n):
+    """[B, M, K] ids into a batch item -> flat row numbers into [B*n, C].  Memoised per table (a table serves several
+    layers, and the CSR used by the backward kernels is cached on the flat tensor)."""
+    key = (ids.data_ptr(), ids._version, tuple(ids.shape), n)
+    hit = _flat_cache.get(key)
+    if hit is not None:
+        return hit[1]
+    b = ids.shape[0]
+    flat = (ids + torch.arange(b, device=ids.device).view(b, 1, 1) * n).reshape(-1)
+    if len(_flat_cache) > 64:
+        _flat_cache.clear()
+    _flat_cache[key] = (ids, flat)
+    return flat
+
+
+def release_step_caches():
+    """Drop the id-table caches (call once per optimisation step, after backward)."""
+    _flat_cache.clear()
+    train_ops.clear_cache()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# encoder
+# ---------------------------------------------------------------------------------------------------------------------
+def fkaconv_layer(layer, x, pts, sup, ids):
+    """x [B,N,Cin], pts [B,N,3], sup [B,M,3], ids int64 [B,M,K] -> [B,M,Cout]."""
+    act = _act('silu' if isinstance(layer.activation, torch.nn.SiLU) else 'relu')
+    b, n, cin = x.shape
+    m, k = ids.shape[1], ids.shape[2]
+    flat = _flat_ids(ids, n)
+    pn = pts.reshape(b * n, 3)[flat].view(b, m, k, 3) - sup.unsqueeze(2)
+    dist = torch.sqrt((pn.detach() ** 2).sum(-1))                                        # [B,M,K], no gradient (:605)
+    if layer.training:
+        with torch.no_grad():
+            mom = layer.norm_radius_momentum
+            layer.norm_radius.data = layer.norm_radius.data * (1 - mom) + dist.max(2)[0].mean() * mom
+    pn = pn / layer.norm_radius
+    dw = torch.sigmoid(-layer.alpha * dist + layer.beta)
+    s = dw.sum(2, keepdim=True)
+    s = s + (s == 0) + 1e-6
+    dw = (dw / s * k).unsqueeze(-1)                                                      # [B,M,K,1]
+    g = F.linear(pn, _w2d(layer.fc1))
+    g = act(g if k == 1 else _instance_norm(layer.bn1, g))
+    mp = (g * dw).max(dim=2, keepdim=True)[0].expand(-1, -1, k, -1)
+    g = F.linear(torch.cat([g, mp], dim=-1), _w2d(layer.fc2))
+    g = act(g if k == 1 else _instance_norm(layer.bn2, g))
+    mp = (g * dw).max(dim=2, keepdim=True)[0].expand(-1, -1, k, -1)
+    g = act(F.linear(torch.cat([g, mp], dim=-1), _w2d(layer.fc3))) * dw                  # [B,M,K,16]
+    feat = train_ops.neighbour_contract(x.reshape(b * n, cin), flat.view(b * m, k), g.reshape(b * m, k, -1))   # [B*M, Cin*16]
+    return F.linear(feat, _w2d(layer.cv)).view(b, m, -1)                                 # Conv2d (1,16): (c,t) -> c*16+t
+
+
+def residual_block(blk, x, pts, sup, ids):
+    """[B,N,Cin] -> [B,M,Cout]."""
+    b, n, cin = x.shape
+    m = ids.shape[1]
+    h = F.relu(batch_norm(blk.bn0, dense(blk.cv0, x.reshape(b * n, cin)))).view(b, n, -1)
+    h = fkaconv_layer(blk.cv1, h, pts, sup, ids)
+    h = F.relu(batch_norm(blk.bn1, h.reshape(b * m, -1)))
+    h = batch_norm(blk.bn2, dense(blk.cv2, h))
+    sc = x.reshape(b * n, cin)
+    if not isinstance(blk.shortcut, torch.nn.Identity):
+        sc = batch_norm(blk.bn_shortcut, dense(blk.shortcut, sc))
+    if n != m:
+        sc = train_ops.neighbour_max(sc, _flat_ids(ids, n).view(b * m, -1))
+    return F.relu(h + sc).view(b, m, -1)
+
+
+def _upsample(x, ids_up, n_coarse):
+    """nearest-neighbour interpolation (nn.py:684-697 with K == 1): x [B,Nc,C], ids_up [B,Nf,1] -> [B,Nf,C]."""
+    b, nf = ids_up.shape[0], ids_up.shape[1]
+    ids_up = torch.where(ids_up > -1, ids_up, torch.zeros_like(ids_up))
+    return train_ops.gather_rows(x.reshape(b * n_coarse, -1), _flat_ids(ids_up, n_coarse)).view(b, nf, -1)
+
+
+def encoder(enc, data):
+    """FKAConvNetwork.forward(data, spectral_only=True): data['pts'] [B,3,N] + supports / id tables -> latents [B,N,C]."""
+    pm = lambda t: t.transpose(1, 2).contiguous()
+    pts = pm(data['pts'])
+    s1, s2, s3, s4 = (pm(data['support{}'.format(i)]) for i in (1, 2, 3, 4))
+    b = pts.shape[0]
+    x = torch.ones_like(pts)                                                             # input features are all-ones (:517)
+    x0 = fkaconv_layer(enc.cv0, x, pts, pts, data['ids00'])
+    x0 = F.relu(batch_norm(enc.bn0, x0.reshape(b * pts.shape[1], -1))).view(b, pts.shape[1], -1)
+    x0 = residual_block(enc.resnetb01, x0, pts, pts, data['ids00'])
+    x1 = residual_block(enc.resnetb10, x0, pts, s1, data['ids01'])
+    x1 = residual_block(enc.resnetb11, x1, s1, s1, data['ids11'])
+    x2 = residual_block(enc.resnetb20, x1, s1, s2, data['ids12'])
+    x2 = residual_block(enc.resnetb21, x2, s2, s2, data['ids22'])
+    x3 = residual_block(enc.resnetb30, x2, s2, s3, data['ids23'])
+    x3 = residual_block(enc.resnetb31, x3, s3, s3, data['ids33'])
+    x4 = residual_block(enc.resnetb40, x3, s3, s4, data['ids34'])
+    x4 = residual_block(enc.resnetb41, x4, s4, s4, data['ids44'])
+
+    def head(cv, bn, coarse, ids_up, skip):
+        z = torch.cat([_upsample(coarse, ids_up, coarse.shape[1]), skip], dim=-1)
+        return F.relu(batch_norm(bn, dense(cv, z.reshape(-1, z.shape[-1])))).view(b, skip.shape[1], -1)
+
+    x4d = x4
+    if enc.fixed or enc.training:                                                        # :531-534
+        # without x4d_bug_fixed (POCO) the reference still evaluates cv5/bn5 and throws the result away: in train() that
+        # updates bn5's running statistics, which end up in the checkpoint
+        x5 = x4.max(dim=1, keepdim=True)[0].expand_as(x4)
+        z = torch.cat([x4, x5], dim=-1)
+        z = F.relu(batch_norm(enc.bn5, dense(enc.cv5, z.reshape(-1, z.shape[-1])))).view(b, x4.shape[1], -1)
+        if enc.fixed:
+            x4d = z
+    x3d = head(enc.cv3d, enc.bn3d, x4d, data['ids43'], x3)
+    x2d = head(enc.cv2d, enc.bn2d, x3d, data['ids32'], x2)
+    x1d = head(enc.cv1d, enc.bn1d, x2d, data['ids21'], x1)
+    xo = head(enc.cv0d, enc.bn0d, x1d, data['ids10'], x0)
+    xo = enc.dropout(xo)
+    return dense(enc.fcout, xo.reshape(-1, xo.shape[-1])).view(b, pts.shape[1], -1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# decoder
+# ---------------------------------------------------------------------------------------------------------------------
+def interp_attention(proj, latents, pts, query, ids, last_layer=True):
+    """latents [B,N,C], pts [B,N,3], query [B,Q,3], ids [B,Q,k] -> [B,Q,Cout] (poco_model.py:400-417)."""
+    b, n, c = latents.shape
+    q, k = ids.shape[1], ids.shape[2]
+    flat = _flat_ids(ids, n)
+    lat = train_ops.gather_rows(latents.reshape(b * n, c), flat)                         # [B*Q*k, C]
+    rel = (query.unsqueeze(2) - pts.reshape(b * n, 3)[flat].view(b, q, k, 3)).reshape(-1, 3)     # query minus neighbour
+    h = F.relu(dense(proj.fc1, torch.cat([lat, rel], dim=-1)))
+    h = F.relu(dense(proj.fc2, h))
+    h = F.relu(dense(proj.fc3, h))
+    att = torch.softmax(dense(proj.fc_query, h).view(b * q, k, -1), dim=1).mean(dim=2)  # softmax over neighbours, mean of heads
+    val = dense(proj.fc_value, h).view(b * q, k, -1)
+    out = (att.unsqueeze(-1) * val).sum(dim=1)
+    if last_layer:
+        out = dense(proj.fc8, out)
+    return out.view(b, q, -1)
+
+
+def stn(t, h, nq, p):
+    """h [nq*p, dim] -> [nq, dim, dim]."""
+    d = t.dim
+    z = F.relu(batch_norm(t.bn1, dense(t.conv1, h)))
+    z = F.relu(batch_norm(t.bn2, dense(t.conv2, z)))
+    z = F.relu(batch_norm(t.bn3, dense(t.conv3, z)))
+    z = z.view(nq, p, -1).max(dim=1)[0]
+    z = F.relu(batch_norm(t.bn4, dense(t.fc1, z)))
+    z = F.relu(batch_norm(t.bn5, dense(t.fc2, z)))
+    z = dense(t.fc3, z) + torch.eye(d, dtype=z.dtype, device=z.device).reshape(1, d * d)
+    return z.view(nq, d, d)
+
+
+def pointnet(pn, patches):
+    """patches [Q', P, 3] -> (feat [Q', C], trans2 [Q', 64, 64])."""
+    nq, p, _ = patches.shape
+    h = F.relu(batch_norm(pn.bn0a, dense(pn.conv0a, patches.reshape(nq * p, 3))))
+    h = F.relu(batch_norm(pn.bn0b, dense(pn.conv0b, h)))
+    trans2 = stn(pn.stn2, h, nq, p)
+    h = torch.bmm(h.view(nq, p, -1), trans2.transpose(1, 2)).reshape(nq * p, -1)         # channel-first: trans2 @ x
+    h = F.relu(batch_norm(pn.bn1, dense(pn.conv1, h)))
+    h = F.relu(batch_norm(pn.bn2, dense(pn.conv2, h)))
+    h = batch_norm(pn.bn3, dense(pn.conv3, h))
+    w = torch.softmax(dense(pn.att.fc_query, h).view(nq, p), dim=1)
+    v = dense(pn.att.fc_value, h).view(nq, p, -1)
+    return (w.unsqueeze(-1) * v).sum(dim=1), trans2
+
+
+def mlp(m, x):
+    for i, block in enumerate(m.layers):
+        x = dense(block[0], x)
+        if i < len(m.layers) - 1:
+            x = block[3](F.relu(batch_norm(block[1], x)))                                # Dropout holder, active in train()
+    return x
+
+
+def _point_major(t):
+    """[B,3,N] or [B,N,3] -> [B,N,3]."""
+    return t.transpose(1, 2) if t.shape[1] == 3 and t.shape[2] != 3 else t
+
+
+def ppsurf_from_latent(net, latents, data, proj_ids):
+    """latents [B,N,C] point-major; data{pts, pts_query, pts_local_ps [B,Q,P,3]}; proj_ids [B,Q,k] -> logits [B,2,Q]."""
+    pts = _point_major(data['pts']).contiguous()
+    query = _point_major(data['pts_query']).contiguous()
+    b, q = query.shape[0], query.shape[1]
+    feat_proj = interp_attention(net.projection, latents, pts, query, proj_ids)
+    pl = data['pts_local_ps']
+    feat_pn, _ = pointnet(net.point_net, pl.reshape(b * q, pl.shape[2], 3))
+    out = mlp(net.mlp, feat_proj.reshape(b * q, -1) + feat_pn)
+    return out.view(b, q, -1).transpose(1, 2)
+
+
+def ppsurf_forward(net, data, proj_ids):
+    return ppsurf_from_latent(net, encoder(net.encoder, data), data, proj_ids)
+
+
+def poco_forward(net, data, proj_ids):
+    pts = _point_major(data['pts']).contiguous()
+    query = _point_major(data['pts_query']).contiguous()
+    return interp_attention(net.projection, encoder(net.encoder, data), pts, query, proj_ids).transpose(1, 2)

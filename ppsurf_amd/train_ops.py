@@ -1,0 +1,154 @@
+"""Autograd ops of the training step backed by the HIP kernels of csrc/pps_train.hip (forward AND backward hand-written).
+
+    gather_rows(x [n,c], idx [r])                     -> [r,c]          (latent gather, nearest up-sampling)
+    neighbour_max(x [n,c], idx [m,k])                 -> [m,c]          (nn.py:677-680 max_pool)
+    neighbour_contract(x [n,c], idx [m,k], g [m,k,16])-> [m, c*16]      (nn.py:598,647-649 FKAConv feature aggregation)
+
+Device tensors only: there is no CPU implementation in the product (tests/train_ref_ops.py holds the torch twins the CPU
+suite patches in to check the surrounding graph).  Backward scatter-adds are atomics-free and bit-reproducible: the id table
+is sorted once (`csr`, cached per table and step) and each target row sums its contributions in a fixed order.
+All ops compute in fp32 (inputs are up-cast under autocast).
+"""
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise _lib.PpsError('ppsurf_amd.train_ops runs on the GPU only (got a {} tensor): there is no CPU path'.format(t.device))
+
+
+_csr_cache = {}
+
+
+def csr(idx_flat: torch.Tensor, n: int):
+    """(order, offsets) of a flat id table: entries stably sorted by target row, offsets int64 [n+1].  Cached per table."""
+    key = (idx_flat.data_ptr(), idx_flat._version, idx_flat.numel(), n)
+    hit = _csr_cache.get(key)                       # the cached entry keeps the table alive, so the address cannot be reused
+    if hit is not None:
+        return hit[1], hit[2]
+    order = torch.sort(idx_flat, stable=True)[1].contiguous()
+    counts = torch.bincount(idx_flat, minlength=n)
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=idx_flat.device)
+    torch.cumsum(counts, 0, out=offsets[1:])
+    if len(_csr_cache) > 64:
+        _csr_cache.clear()
+    _csr_cache[key] = (idx_flat, order, offsets)
+    return order, offsets
+
+
+def clear_cache():
+    _csr_cache.clear()
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, x, idx):
+        _need_cuda(x, idx)
+        x = x.contiguous()
+        idx = idx.contiguous()
+        out = torch.empty((idx.numel(), x.shape[1]), device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().pps_gather_rows_f32(x.data_ptr(), idx.data_ptr(), idx.numel(), x.shape[1], out.data_ptr(), _stream()),
+                   'pps_gather_rows_f32')
+        ctx.save_for_backward(idx)
+        ctx.n = x.shape[0]
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, dout):
+        idx, = ctx.saved_tensors
+        order, offsets = csr(idx, ctx.n)
+        dout = dout.contiguous().float()
+        dx = torch.empty((ctx.n, dout.shape[1]), device=dout.device, dtype=torch.float32)
+        _lib.check(_lib.lib().pps_segment_sum_rows_f32(dout.data_ptr(), order.data_ptr(), offsets.data_ptr(), ctx.n, dout.shape[1],
+                                                       dx.data_ptr(), _stream()), 'pps_segment_sum_rows_f32')
+        return dx, None
+
+
+class _NeighbourMax(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, x, idx):
+        _need_cuda(x, idx)
+        x = x.contiguous()
+        idx = idx.contiguous()
+        m, k = idx.shape
+        c = x.shape[1]
+        out = torch.empty((m, c), device=x.device, dtype=torch.float32)
+        arg = torch.empty((m, c), device=x.device, dtype=torch.int32)
+        _lib.check(_lib.lib().pps_gather_max_arg_f32(x.data_ptr(), idx.data_ptr(), m, k, c, out.data_ptr(), arg.data_ptr(), _stream()),
+                   'pps_gather_max_arg_f32')
+        ctx.save_for_backward(idx, arg)
+        ctx.n = x.shape[0]
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, dout):
+        idx, arg = ctx.saved_tensors
+        order, offsets = csr(idx.view(-1), ctx.n)
+        dout = dout.contiguous().float()
+        c = dout.shape[1]
+        dx = torch.empty((ctx.n, c), device=dout.device, dtype=torch.float32)
+        _lib.check(_lib.lib().pps_gather_max_bwd_f32(dout.data_ptr(), arg.data_ptr(), order.data_ptr(), offsets.data_ptr(), ctx.n,
+                                                     idx.shape[1], c, dx.data_ptr(), _stream()), 'pps_gather_max_bwd_f32')
+        return dx, None
+
+
+class _NeighbourContract(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, x, idx, g):
+        _need_cuda(x, idx, g)
+        x, idx, g = x.contiguous(), idx.contiguous(), g.contiguous()
+        m, k = idx.shape
+        c = x.shape[1]
+        if g.shape != (m, k, 16):
+            raise ValueError('neighbour_contract: g must be [m, k, 16], got {}'.format(tuple(g.shape)))
+        out = torch.empty((m, c * 16), device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().pps_neighbour_contract_fwd_f32(x.data_ptr(), idx.data_ptr(), g.data_ptr(), m, k, c, out.data_ptr(),
+                                                             _stream()), 'pps_neighbour_contract_fwd_f32')
+        ctx.save_for_backward(x, idx, g)
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, dout):
+        x, idx, g = ctx.saved_tensors
+        m, k = idx.shape
+        n, c = x.shape
+        dout = dout.contiguous().float()
+        need_x, _, need_g = ctx.needs_input_grad
+        dxg = torch.empty((m * k, c), device=x.device, dtype=torch.float32) if need_x else None
+        dg = torch.empty((m, k, 16), device=x.device, dtype=torch.float32) if need_g else None
+        if need_x or need_g:
+            _lib.check(_lib.lib().pps_neighbour_contract_bwd_f32(x.data_ptr(), idx.data_ptr(), g.data_ptr(), dout.data_ptr(), m, k, c,
+                                                                 dxg.data_ptr() if need_x else None, dg.data_ptr() if need_g else None,
+                                                                 _stream()), 'pps_neighbour_contract_bwd_f32')
+        dx = None
+        if need_x:
+            order, offsets = csr(idx.view(-1), n)
+            dx = torch.empty((n, c), device=x.device, dtype=torch.float32)
+            _lib.check(_lib.lib().pps_segment_sum_rows_f32(dxg.data_ptr(), order.data_ptr(), offsets.data_ptr(), n, c, dx.data_ptr(),
+                                                           _stream()), 'pps_segment_sum_rows_f32')
+        return dx, None, dg
+
+
+def gather_rows(x, idx):
+    return _GatherRows.apply(x, idx)
+
+
+def neighbour_max(x, idx):
+    return _NeighbourMax.apply(x, idx)
+
+
+def neighbour_contract(x, idx, g):
+    return _NeighbourContract.apply(x, idx, g)

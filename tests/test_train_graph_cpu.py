@@ -1,0 +1,199 @@
+"""Training graph (ppsurf_amd/train_graph.py) against the reference's train-mode fixtures, on the CPU.
+
+The three HIP neighbourhood ops are replaced by their torch twins (tests/train_ref_ops.py); everything else -- layer order,
+BatchNorm batch statistics and running-stat updates, InstanceNorm, norm_radius EMA, dropout, the loss -- is the product code.
+Outputs / loss / buffers are compared with the reference's fp32 run (<= 5e-5 of the output scale).  Gradients are compared with
+the reference's float64 run twice: with this graph evaluated in float64 (<= 1e-7: the graph is the same function) and in fp32
+(the precision the product trains in; tolerance stated per test)."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from golden_util import load_golden, filled_sd, sd_digest
+from train_ref_ops import patched
+from ppsurf_amd import modules, train_graph as tg
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _load(module, prefix, key=None, digest=None):
+    sd = filled_sd(prefix, key)
+    if digest is not None:
+        assert sd_digest(sd) == str(digest)
+    module.load_state_dict({k[len(prefix):]: v for k, v in sd.items()})
+    return module.train()
+
+
+def _close(a, b, rtol, what, floor=0.0, flips=False):
+    """max |a-b| <= rtol * max(max|b|, floor).  `floor` = scale of the largest gradient of the module: biases in front of a
+    train-mode BatchNorm have an analytically ZERO gradient, what is recorded for them is rounding noise of that scale."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = max(np.abs(b).max(), floor, 1e-30)
+    err = np.abs(a - b) / scale
+    if flips:
+        # a ReLU whose pre-activation is within rounding of 0 takes the other branch in one of the two fp32 evaluations
+        # (fp64 replay sides with this graph): allow <= 0.5 % of the entries (one flip touches a whole row) to be off by a few percent of the scale
+        assert (err > rtol).mean() <= 5e-3 and err.max() <= 5e-2, '{}: {} entries off, max {:.3e}'.format(what, int((err > rtol).sum()), err.max())
+        return
+    assert err.max() <= rtol, '{}: max err {:.3e} of scale {:.3e}'.format(what, err.max(), scale)
+
+
+def _sig(t):
+    t = t.detach().double().reshape(-1)
+    head = torch.zeros(32, dtype=torch.float64)
+    head[:min(32, t.numel())] = t[:32]
+    return torch.cat([torch.stack([t.sum(), t.abs().sum(), t.norm()]), head]).numpy()
+
+
+def _check_sigs(named, names, sigs, rtol, what, noise=1e-6, sigs32=None):
+    """Signatures [sum, sum|.|, l2, first 32 entries] of every tensor against the reference's float64 evaluation.
+    Tolerance per tensor: `rtol` relative, plus an absolute floor of `noise` x the largest l2 norm of the set (biases in front
+    of a train-mode BatchNorm have an analytically ZERO gradient), and -- when the fixture also holds the reference's own fp32
+    signatures -- 3x the deviation of the reference's fp32 run from its fp64 run (an fp32 backward through ~60 layers is only
+    that accurate; this graph is held to the same accuracy as the reference itself)."""
+    named = dict(named)
+    floor = noise * max(float(s[2]) for s in sigs)
+    for i, (k, ref) in enumerate(zip(names, sigs)):
+        t = named[str(k)]
+        got = _sig(t)
+        own = np.abs(sigs32[i] - ref) * 3 if sigs32 is not None else np.zeros_like(ref)
+        assert abs(got[1] - ref[1]) <= rtol * ref[1] + floor * np.sqrt(t.numel()) + own[1], '{} {}: sum|.| {} vs {}'.format(what, k, got[1], ref[1])
+        assert abs(got[2] - ref[2]) <= rtol * ref[2] + floor + own[2], '{} {}: l2 {} vs {}'.format(what, k, got[2], ref[2])
+        rms = ref[2] / np.sqrt(t.numel())
+        assert np.abs(got[3:] - ref[3:]).max() <= 4 * rtol * max(np.abs(ref[3:]).max(), rms) + floor + own[3:].max(), \
+            '{} {}: leading entries differ'.format(what, k)
+
+
+@pytest.mark.parametrize('act', ['relu', 'silu'])
+def test_fkaconv_layer_train(act):
+    g = load_golden('train_fkaconv_layer')
+    layer = _load(modules.FKAConvLayer(8, 16, 16, activation=nn.SiLU() if act == 'silu' else nn.ReLU()), 'L_{}.'.format(act),
+                  digest=g['digest_' + act])
+    x = _t(g['x']).transpose(1, 2).contiguous().requires_grad_(True)
+    pts, sup = _t(g['pts']).transpose(1, 2).contiguous(), _t(g['sup']).transpose(1, 2).contiguous()
+    with patched():
+        out = tg.fkaconv_layer(layer, x, pts, sup, _t(g['ids']))
+        (out * _t(g['r']).transpose(1, 2)).sum().backward()
+    _close(out.detach().transpose(1, 2), g['out_' + act], 2e-5, 'out')
+    _close(layer.norm_radius, g['norm_radius_' + act], 1e-6, 'norm_radius')
+    _close(x.grad.transpose(1, 2), g['gx_' + act], 1e-4, 'grad x')
+    for k, p in layer.named_parameters():
+        _close(p.grad, g['g_{}_{}'.format(act, k)], 1e-4, 'grad ' + k)
+
+
+def test_residual_block_train():
+    g = load_golden('train_residual_block')
+    blk = _load(modules.ResidualBlock(16, 32, 16, activation=nn.SiLU()), 'RB_down.', digest=g['digest'])
+    x = _t(g['x']).transpose(1, 2).contiguous().requires_grad_(True)
+    pts, sup = _t(g['pts']).transpose(1, 2).contiguous(), _t(g['sup']).transpose(1, 2).contiguous()
+    with patched():
+        out = tg.residual_block(blk, x, pts, sup, _t(g['ids']))
+        (out * _t(g['r']).transpose(1, 2)).sum().backward()
+    _close(out.detach().transpose(1, 2), g['out'], 2e-5, 'out')
+    _close(x.grad.transpose(1, 2), g['gx'], 1e-4, 'grad x')
+    top = max(np.abs(g['g_' + k]).max() for k, _ in blk.named_parameters())
+    for k, p in blk.named_parameters():
+        _close(p.grad, g['g_' + k], 2e-4, 'grad ' + k, floor=1e-2 * top)
+    for k, b in blk.named_buffers():
+        _close(b.double(), g['b_' + k], 1e-5, 'buffer ' + k)
+
+
+@pytest.mark.parametrize('p', [10, 50])
+def test_pointnet_train(p):
+    g = load_golden('train_pointnet')
+    net = _load(modules.PointNetfeat(net_size_max=256, num_points=p, use_point_stn=False, use_feat_stn=True, output_size=256,
+                                     sym_op='att', dim=3), 'PN_p{}.'.format(p), digest=g['digest_p{}'.format(p)])
+    x = _t(g['p{}_x'.format(p)]).transpose(1, 2).contiguous().requires_grad_(True)
+    feat, trans2 = tg.pointnet(net, x)
+    (feat * _t(g['p{}_r'.format(p)])).sum().backward()
+    _close(feat.detach(), g['p{}_feat'.format(p)], 2e-5, 'feat')
+    _close(trans2[:4].detach(), g['p{}_trans2'.format(p)], 2e-5, 'trans2')
+    _close(x.grad.transpose(1, 2), g['p{}_gx'.format(p)], 2e-4, 'grad x')
+    _check_sigs([(k, v.grad) for k, v in net.named_parameters()], g['p{}_gnames'.format(p)], g['p{}_gsigs'.format(p)], 2e-4, 'grad')
+    _check_sigs([(k, v.float()) for k, v in net.named_buffers()], g['p{}_bnames'.format(p)], g['p{}_bsigs'.format(p)], 1e-5, 'buffer')
+
+
+@pytest.mark.parametrize('tag,c,cout,k', [('c32', 32, 2, 16), ('c256', 256, 256, 64)])
+def test_interp_attention_grads(tag, c, cout, k):
+    from ppsurf_amd.synthetic import make_latents
+    g = load_golden('train_interp_attention')
+    net = _load(modules.InterpAttentionKHeadsNet(c, cout, k), 'IA_{}.'.format(tag), digest=g['digest_' + tag])
+    n = g[tag + '_pts'].shape[2]
+    lat = _t(make_latents(c, n, seed=c)).transpose(1, 2).contiguous().requires_grad_(True)
+    pts, q = _t(g[tag + '_pts']).transpose(1, 2).contiguous(), _t(g[tag + '_query']).transpose(1, 2).contiguous()
+    with patched():
+        out = tg.interp_attention(net, lat, pts, q, _t(g[tag + '_ids']))
+        (out * _t(g[tag + '_r']).transpose(1, 2)).sum().backward()
+    _close(out.detach().transpose(1, 2), g[tag + '_out'], 2e-5, 'out')
+    _close(lat.grad.transpose(1, 2), g[tag + '_glat'], 1e-4, 'grad latents', flips=True)
+    _check_sigs([(k_, v.grad) for k_, v in net.named_parameters()], g[tag + '_gnames'], g[tag + '_gsigs'], 1e-4, 'grad')
+
+
+def _step_inputs(g, dt=torch.float32):
+    data = {k[3:]: _t(v) for k, v in g.items() if k.startswith('in_')}
+    data = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in data.items()}
+    return data, data['occ']
+
+
+def _ppsurf(dt):
+    g = load_golden('train_ppsurf')
+    net = _load(modules.PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=50,
+                                      pointnet_latent_size=256), '', key='ppsurf', digest=g['digest']).to(dt)
+    for m in net.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+    return g, net
+
+
+def _poco(dt):
+    g = load_golden('train_poco')
+    net = _load(modules.PocoNetwork(in_channels=3, latent_size=32, out_channels=2, k=64), 'POCO.', key='poco', digest=g['digest']).to(dt)
+    return g, net
+
+
+def _run_step(forward, net, dt):
+    data, occ = _step_inputs(load_golden('train_ppsurf'), dt)
+    with patched():
+        logits = forward(net, data, data['proj_ids'])
+        loss = nn.functional.cross_entropy(logits, occ, reduction='none').mean()
+        loss.backward()
+    return logits.detach(), float(loss.detach())
+
+
+@pytest.mark.parametrize('which', ['ppsurf', 'poco'])
+def test_training_step_fp32(which):
+    """One training step's forward/backward in fp32: logits, loss, updated buffers vs the reference's fp32 run; gradients vs
+    its fp64 run within 1 % per tensor (+ the self-calibrating terms of _check_sigs): fp32 summation noise of a ~60-layer
+    backward pass -- the exactness of the graph is established by the float64 test below."""
+    g, net = (_ppsurf if which == 'ppsurf' else _poco)(torch.float32)
+    logits, loss = _run_step(tg.ppsurf_forward if which == 'ppsurf' else tg.poco_forward, net, torch.float32)
+    _close(logits, g['logits'], 5e-5, 'logits')
+    assert abs(loss - float(g['loss'])) < 1e-5
+    assert [k for k, p in net.named_parameters() if p.grad is None] == [str(k) for k in g['unused']]
+    _check_sigs([(k, v.grad) for k, v in net.named_parameters()], g['gnames'], g['gsigs'], 1e-2, 'grad', sigs32=g['gsigs32'])
+    _check_sigs([(k, v.float()) for k, v in net.named_buffers()], g['bnames'], g['bsigs'], 2e-5, 'buffer')
+
+
+@pytest.mark.parametrize('which', ['ppsurf', 'poco'])
+def test_training_step_fp64_is_the_same_function(which):
+    g, net = (_ppsurf if which == 'ppsurf' else _poco)(torch.float64)
+    logits, loss = _run_step(tg.ppsurf_forward if which == 'ppsurf' else tg.poco_forward, net, torch.float64)
+    _close(logits, g['logits'], 5e-5, 'logits')                      # recorded in fp32
+    _check_sigs([(k, v.grad) for k, v in net.named_parameters()], g['gnames'], g['gsigs'], 1e-7, 'grad', noise=1e-10)
+
+
+def test_ppsurf_training_step_dropout_same_generator():
+    """With the CPU generator seeded like the recording run, F.dropout draws the same masks (same shapes, same order)."""
+    g = load_golden('train_ppsurf')
+    net = _load(modules.PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=50,
+                                      pointnet_latent_size=256), '', key='ppsurf')
+    data, occ = _step_inputs(g)
+    with patched():
+        torch.manual_seed(123)
+        logits = tg.ppsurf_forward(net, data, data['proj_ids'])
+    loss = nn.functional.cross_entropy(logits, occ, reduction='none').mean()
+    _close(logits.detach(), g['logits_dropout'], 5e-5, 'logits')
+    assert abs(float(loss.detach()) - float(g['loss_dropout'])) < 1e-5
