@@ -10,14 +10,15 @@ Mirrors (names, constructor arguments, tensor conventions):
 The torch.nn layers created here only HOLD parameters (so `state_dict()` matches the reference's 455 entries and its
 checkpoints load unchanged); they are never called.  forward() builds a *plan* (BatchNorm-folded, packed weights on the
 device; ppsurf_amd/encoder.py, ppsurf_amd/decoder.py), cached until a parameter changes, and launches the kernels.
-Only eval mode is executed natively in this round; train-mode forward raises NotImplementedError.
+That is eval() mode.  In train() mode forward() runs the autograd graph of ppsurf_amd/train_graph.py instead (batch-statistics
+BatchNorm, dropout, norm_radius EMA; HIP gather/scatter ops with hand-written backward) on the same parameter tensors.
 """
 import typing
 
 import torch
 from torch import nn
 
-from . import spatial
+from . import spatial, train_graph
 from .decoder import DecoderPlan, PocoDecoderPlan
 from .encoder import EncoderPlan, FKAConvParams, ResidualBlockParams, gather_max
 
@@ -40,10 +41,9 @@ def _sd(module):
     return {k: v.detach() for k, v in module.state_dict().items()}
 
 
-def _require_eval(module):
-    if module.training:
-        raise NotImplementedError('{}: train-mode forward (batch-statistics BatchNorm, dropout, norm_radius EMA) is not '
-                                  'implemented on the HIP path yet; call .eval()'.format(type(module).__name__))
+def _pm(t):
+    """[B,C,N] -> contiguous point-major [B,N,C]."""
+    return t.transpose(1, 2).contiguous()
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -99,7 +99,8 @@ class FKAConvLayer(_Base):
         """x [B,Cin,N], pts [B,3,N], support_points [B,3,M], neighbors_indices [B,M,K] -> [B,Cout,M]."""
         if x is None:
             return None
-        _require_eval(self)
+        if self.training:
+            return train_graph.fkaconv_layer(self, _pm(x), _pm(pts), _pm(support_points), neighbors_indices).transpose(1, 2)
         ver = _params_version(self)
         if self._plan is None or self._plan[0] != ver:
             sd = {'L.' + k: v for k, v in _sd(self).items()}
@@ -125,7 +126,8 @@ class ResidualBlock(_Base):
         self._plan = None
 
     def forward(self, x, pts, support_points, neighbors_indices):
-        _require_eval(self)
+        if self.training:
+            return train_graph.residual_block(self, _pm(x), _pm(pts), _pm(support_points), neighbors_indices).transpose(1, 2)
         ver = _params_version(self)
         if self._plan is None or self._plan[0] != ver:
             sd = {'R.' + k: v for k, v in _sd(self).items()}
@@ -185,10 +187,11 @@ class FKAConvNetwork(_Base):
 
     def forward(self, data, spectral_only=False):
         """nn.py:508-554.  data['pts'] [B,3,N] (+ supports / ids unless spectral_only=False) -> [B,C,N]."""
-        _require_eval(self)
         if not spectral_only:
             for key, value in spatial.get_fkaconv_ids(data).items():
                 data[key] = value
+        if self.training:
+            return train_graph.encoder(self, data).transpose(1, 2)
         if self.dropout.p != 0:
             raise NotImplementedError('encoder dropout != 0 is not used by POCO / PPSurf')
         out = [self.forward_point_major(data, b).t() for b in range(data['pts'].shape[0])]
@@ -320,10 +323,13 @@ class PPSurfNetwork(_Base):
     def from_latent(self, data: typing.Dict[str, torch.Tensor]):
         """source/ppsurf_model.py:82-117: data{latents [B,C,N], pts [B,3,N], pts_query [B,Q,3]|[B,3,Q], pts_local_ps [B,Q,P,3]}
         -> logits [B,2,Q]; sets data['proj_ids'] (int64 [B,Q,k]) like the reference (has_proj_ids=False, :83)."""
-        _require_eval(self)
         pts = _channel_first(data['pts'])
         dev = pts.device
         ptq = _channel_first(data['pts_query'].to(dev))
+        if self.training:
+            with torch.no_grad():
+                data['proj_ids'] = spatial.knn(pts, ptq, self.projection.k)
+            return train_graph.ppsurf_from_latent(self, _pm(data['latents']), data, data['proj_ids'])
         plan = self.decoder_plan(dev)
         k = min(self.projection.k, pts.shape[2])
         logits, ids_all = [], []
@@ -383,10 +389,14 @@ class PocoNetwork(_Base):
 
     def _project(self, data, has_proj_ids):
         from . import ops
-        _require_eval(self)
         pts = _channel_first(data['pts'])
         dev = pts.device
         ptq = _channel_first(data['pts_query'].to(dev))
+        if self.training:
+            if not has_proj_ids:
+                with torch.no_grad():
+                    data['proj_ids'] = spatial.knn(pts, ptq, self.projection.k)
+            return train_graph.interp_attention(self.projection, _pm(data['latents']), _pm(pts), _pm(ptq), data['proj_ids']).transpose(1, 2)
         plan = self.decoder_plan(dev)
         k = min(self.projection.k, pts.shape[2])
         logits, ids_all = [], []

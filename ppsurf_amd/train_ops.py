@@ -65,6 +65,8 @@ class _GatherRows(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, dout):
         idx, = ctx.saved_tensors
+        if idx.numel() == 0:
+            return torch.zeros((ctx.n, dout.shape[1]), device=dout.device, dtype=torch.float32), None
         order, offsets = csr(idx, ctx.n)
         dout = dout.contiguous().float()
         dx = torch.empty((ctx.n, dout.shape[1]), device=dout.device, dtype=torch.float32)

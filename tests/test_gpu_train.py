@@ -1,0 +1,165 @@
+"""Training path on the GPU: HIP gather/scatter ops (forward + hand-written backward) against their torch twins, and the
+training graph with those ops against the reference's train-mode fixtures."""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from golden_util import load_golden, filled_sd
+import train_ref_ops as ref
+from test_train_graph_cpu import _close, _check_sigs, _load, _t, _step_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _rand_table(rng, m, k, n):
+    return torch.from_numpy(np.stack([rng.choice(n, k, replace=False) for _ in range(m)]).astype(np.int64)).to(DEV)
+
+
+@pytest.mark.parametrize('n,c,r', [(1000, 256, 5000), (37, 32, 400), (50, 3, 120), (10, 8, 0)])
+def test_gather_rows_fwd_bwd(n, c, r):
+    from ppsurf_amd import train_ops
+    rng = np.random.default_rng(n)
+    x = torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32)).to(DEV).requires_grad_(True)
+    idx = torch.from_numpy(rng.integers(0, n, r).astype(np.int64)).to(DEV)
+    w = torch.from_numpy(rng.standard_normal((r, c)).astype(np.float32)).to(DEV)
+    out = train_ops.gather_rows(x, idx)
+    assert torch.equal(out, x.detach()[idx])
+    (out * w).sum().backward()
+    got = x.grad.clone()
+    x.grad = None
+    (ref.gather_rows(x, idx) * w).sum().backward()
+    torch.testing.assert_close(got, x.grad, rtol=1e-5, atol=1e-5)
+    # atomics-free backward: bit-identical from run to run
+    x.grad = None
+    (train_ops.gather_rows(x, idx) * w).sum().backward()
+    assert torch.equal(got, x.grad)
+
+
+@pytest.mark.parametrize('n,m,k,c', [(800, 200, 16, 64), (300, 300, 16, 32), (64, 16, 4, 128), (40, 160, 1, 8)])
+def test_neighbour_max_fwd_bwd(n, m, k, c):
+    from ppsurf_amd import train_ops
+    rng = np.random.default_rng(m)
+    x = torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32)).to(DEV).requires_grad_(True)
+    idx = _rand_table(rng, m, k, n)
+    w = torch.from_numpy(rng.standard_normal((m, c)).astype(np.float32)).to(DEV)
+    out = train_ops.neighbour_max(x, idx)
+    assert torch.equal(out, ref.neighbour_max(x.detach(), idx))
+    (out * w).sum().backward()
+    got = x.grad.clone()
+    x.grad = None
+    (ref.neighbour_max(x, idx) * w).sum().backward()
+    torch.testing.assert_close(got, x.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('n,m,k,c,xgrad', [(800, 200, 16, 32, True), (300, 300, 16, 3, False), (64, 16, 4, 256, True), (40, 160, 1, 8, True)])
+def test_neighbour_contract_fwd_bwd(n, m, k, c, xgrad):
+    from ppsurf_amd import train_ops
+    rng = np.random.default_rng(c)
+    x = torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32)).to(DEV).requires_grad_(xgrad)
+    g = torch.from_numpy(rng.standard_normal((m, k, 16)).astype(np.float32)).to(DEV).requires_grad_(True)
+    idx = _rand_table(rng, m, k, n)
+    w = torch.from_numpy(rng.standard_normal((m, c * 16)).astype(np.float32)).to(DEV)
+    out = train_ops.neighbour_contract(x, idx, g)
+    want = ref.neighbour_contract(x.double(), idx, g.double())
+    torch.testing.assert_close(out.double(), want, rtol=1e-5, atol=1e-5)
+    (out * w).sum().backward()
+    gx, gg = (x.grad.clone() if xgrad else None), g.grad.clone()
+    x.grad, g.grad = None, None
+    (ref.neighbour_contract(x, idx, g) * w).sum().backward()
+    torch.testing.assert_close(gg, g.grad, rtol=1e-4, atol=1e-4)
+    if xgrad:
+        torch.testing.assert_close(gx, x.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_ops_refuse_cpu_tensors():
+    from ppsurf_amd import train_ops
+    from ppsurf_amd._lib import PpsError
+    with pytest.raises(PpsError, match='no CPU'):
+        train_ops.gather_rows(torch.zeros(4, 8), torch.zeros(2, dtype=torch.int64))
+
+
+@pytest.mark.parametrize('act', ['relu', 'silu'])
+def test_fkaconv_layer_train_gpu(act):
+    from ppsurf_amd import modules, train_graph as tg
+    g = load_golden('train_fkaconv_layer')
+    layer = _load(modules.FKAConvLayer(8, 16, 16, activation=nn.SiLU() if act == 'silu' else nn.ReLU()), 'L_{}.'.format(act)).to(DEV)
+    x = _t(g['x']).to(DEV).requires_grad_(True)                                   # channel-first module API
+    out = layer(x, _t(g['pts']).to(DEV), _t(g['sup']).to(DEV), _t(g['ids']).to(DEV))
+    (out * _t(g['r']).to(DEV)).sum().backward()
+    _close(out.detach().cpu(), g['out_' + act], 2e-5, 'out')
+    _close(layer.norm_radius.cpu(), g['norm_radius_' + act], 1e-6, 'norm_radius')
+    _close(x.grad.cpu(), g['gx_' + act], 2e-4, 'grad x')
+    for k, p in layer.named_parameters():
+        _close(p.grad.cpu(), g['g_{}_{}'.format(act, k)], 2e-4, 'grad ' + k)
+
+
+def test_residual_block_train_gpu():
+    from ppsurf_amd import modules
+    g = load_golden('train_residual_block')
+    blk = _load(modules.ResidualBlock(16, 32, 16, activation=nn.SiLU()), 'RB_down.').to(DEV)
+    x = _t(g['x']).to(DEV).requires_grad_(True)
+    out = blk(x, _t(g['pts']).to(DEV), _t(g['sup']).to(DEV), _t(g['ids']).to(DEV))
+    (out * _t(g['r']).to(DEV)).sum().backward()
+    _close(out.detach().cpu(), g['out'], 2e-5, 'out')
+    _close(x.grad.cpu(), g['gx'], 2e-4, 'grad x')
+    top = max(np.abs(g['g_' + k]).max() for k, _ in blk.named_parameters())
+    for k, p in blk.named_parameters():
+        _close(p.grad.cpu(), g['g_' + k], 5e-4, 'grad ' + k, floor=1e-2 * top)
+    for k, b in blk.named_buffers():
+        _close(b.double().cpu(), g['b_' + k], 1e-5, 'buffer ' + k)
+
+
+@pytest.mark.parametrize('which', ['ppsurf', 'poco'])
+def test_training_step_gpu(which):
+    """network.forward(batch) in train() on the GPU (HIP kNN for the projection ids, HIP gather/scatter ops, library GEMMs):
+    logits / loss / buffers vs the reference's fp32 run, gradients vs its fp64 run (tolerances as in the CPU twin test)."""
+    from ppsurf_amd import modules
+    g = load_golden('train_' + which)
+    gin = load_golden('train_ppsurf')
+    if which == 'ppsurf':
+        net = _load(modules.PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=50,
+                                          pointnet_latent_size=256), '', key='ppsurf')
+    else:
+        net = _load(modules.PocoNetwork(in_channels=3, latent_size=32, out_channels=2, k=64), 'POCO.', key='poco')
+    for m in net.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+    net = net.to(DEV)
+    data, occ = _step_inputs(gin)
+    data = {k: v.to(DEV) for k, v in data.items()}
+    want_ids = data['proj_ids'].clone()
+    if which == 'ppsurf':
+        del data['proj_ids']                                       # PPSurf recomputes them (ppsurf_model.py:83)
+    logits = net.forward(data)
+    assert torch.equal(data['proj_ids'], want_ids)
+    loss = nn.functional.cross_entropy(logits, data['occ'], reduction='none').mean()
+    loss.backward()
+    _close(logits.detach().cpu(), g['logits'], 5e-5, 'logits')
+    assert abs(float(loss.detach()) - float(g['loss'])) < 1e-5
+    assert [k for k, p in net.named_parameters() if p.grad is None] == [str(k) for k in g['unused']]
+    _check_sigs([(k, v.grad.cpu()) for k, v in net.named_parameters() if v.grad is not None], g['gnames'], g['gsigs'], 1e-2, 'grad',
+                sigs32=g['gsigs32'])
+    _check_sigs([(k, v.float().cpu()) for k, v in net.named_buffers()], g['bnames'], g['bsigs'], 2e-5, 'buffer')
+
+
+def test_a_few_adamw_steps_reduce_the_loss_bf16():
+    from ppsurf_amd import modules
+    gin = load_golden('train_ppsurf')
+    net = _load(modules.PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=50,
+                                      pointnet_latent_size=256), '', key='ppsurf').to(DEV)
+    data, _ = _step_inputs(gin)
+    data = {k: v.to(DEV) for k, v in data.items()}
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, eps=1e-5, weight_decay=1e-2)
+    losses = []
+    torch.manual_seed(0)
+    for _ in range(8):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            logits = net.forward(dict(data))
+            loss = nn.functional.cross_entropy(logits.float(), data['occ'], reduction='none').mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

@@ -41,8 +41,9 @@ def test_model_constructor_surface_and_errors():
     assert model.num_pts_local == 50 and model.rec_batch_size == 25000
     with pytest.raises(NotImplementedError, match='batch size > 1 not supported'):
         model.predict_step({'pts_ms': torch.zeros(2, 10, 3), 'pc_file_in': ['a', 'b']}, 0)
-    model.train()
-    with pytest.raises(NotImplementedError):
+    model.train()                                   # train() runs the autograd graph; its kNN / gather ops are HIP-only
+    from ppsurf_amd._lib import PpsError
+    with pytest.raises(PpsError, match='no CPU'):
         model.network.from_latent({'pts': torch.zeros(1, 3, 4), 'pts_query': torch.zeros(1, 2, 3), 'latents': torch.zeros(1, 256, 4),
                                    'pts_local_ps': torch.zeros(1, 2, 50, 3)})
 

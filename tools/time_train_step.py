@@ -1,0 +1,95 @@
+"""Time one fit step at the BASELINE configuration (#3): B shapes x 10k points, 2000 queries per shape, P = 50.
+    python tools/time_train_step.py [--batch 10] [--bf16] [--steps 5] [--poco]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
+from ppsurf_amd import modules, spatial, synthetic  # noqa: E402
+from golden_util import filled_sd  # noqa: E402
+
+
+def make_batch(b, n, q, p, dev, seed=0):
+    rng = np.random.default_rng(seed)
+    pts, qry, dist = [], [], []
+    for i in range(b):
+        c = synthetic.make_cloud(n, seed=seed * 100 + i)
+        qq = (c[rng.choice(n, q)] + rng.normal(0, 0.02, (q, 3))).astype(np.float32)
+        pts.append(c); qry.append(qq); dist.append((0.4 - np.linalg.norm(qq, axis=1)).astype(np.float32))
+    batch = {'pts_ms': torch.from_numpy(np.stack(pts)).to(dev), 'pts_query_ms': torch.from_numpy(np.stack(qry)).to(dev),
+             'imp_surf_dist_ms': torch.from_numpy(np.stack(dist)).to(dev)}
+    return batch
+
+
+def prepare(batch, p):
+    """device-side equivalent of the dataset's per-shape work: patches, supports, id tables."""
+    b = batch['pts_ms'].shape[0]
+    if p:
+        batch['pts_local_ps'] = torch.stack([spatial.get_pts_local_ps(batch['pts_ms'][i].contiguous(), batch['pts_query_ms'][i].contiguous(), p)
+                                             for i in range(b)])
+    return spatial.get_data_poco(batch)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--bf16', action='store_true')
+    ap.add_argument('--poco', action='store_true')
+    ap.add_argument('--profile', action='store_true')
+    a = ap.parse_args()
+    dev = torch.device('cuda')
+    if a.poco:
+        net = modules.PocoNetwork(in_channels=3, latent_size=32, out_channels=2, k=64)
+        sd = filled_sd('POCO.', 'poco')
+        net.load_state_dict({k[5:]: v for k, v in sd.items()})
+    else:
+        net = modules.PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=50, pointnet_latent_size=256)
+        net.load_state_dict(filled_sd('', 'ppsurf'))
+    net = net.to(dev).train()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, eps=1e-5, weight_decay=1e-2)
+
+    def step(i, times=None):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev[0].record()
+        batch = prepare(make_batch_cached[i % len(make_batch_cached)].copy(), 0 if a.poco else 50)
+        ev[1].record()
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=a.bf16):
+            logits = net.forward(batch)
+            loss = torch.nn.functional.cross_entropy(logits.float(), batch['occ'], reduction='none').mean()
+        ev[2].record()
+        loss.backward()
+        ev[3].record()
+        opt.step()
+        ev[4].record()
+        torch.cuda.synchronize()
+        if times is not None:
+            times.append([ev[j].elapsed_time(ev[j + 1]) for j in range(4)])
+        return float(loss)
+
+    make_batch_cached = [make_batch(a.batch, 10000, 2000, 50, dev, seed=s) for s in range(2)]
+    for i in range(2):
+        step(i)
+    times = []
+    t0 = time.time()
+    for i in range(a.steps):
+        l = step(i, times)
+    wall = (time.time() - t0) / a.steps * 1e3
+    t = np.array(times).mean(0)
+    print('batch {} {}: id tables+patches {:.1f} ms, forward {:.1f} ms, backward {:.1f} ms, AdamW {:.1f} ms, wall {:.1f} ms/step, loss {:.4f}, '
+          'peak mem {:.1f} GB'.format(a.batch, 'bf16' if a.bf16 else 'fp32', t[0], t[1], t[2], t[3], wall, l, torch.cuda.max_memory_allocated() / 1e9))
+    if a.profile:
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+            step(0)
+        print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=30))
+
+
+if __name__ == '__main__':
+    main()
