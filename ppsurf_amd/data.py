@@ -1,11 +1,13 @@
-"""Datasets / data module of the predict and test paths, without trimesh / Lightning.
+"""Datasets / data module (predict, test, fit) without trimesh / Lightning.
 
 Mirrors the parts of source/occupancy_data_module.py:18-253, source/poco_data_loader.py:273-412 and
 source/ppsurf_data_loader.py:11-141 that feed `predict_step` / `test_step`: dataset directory layout
 (`04_pts_vis/<shape>.xyz.ply`, `05_query_pts|05_query_dist/<shape>.ply.npy`, `testset.txt`), single-file inputs with
 bbox normalisation (source/base/math.py:111-126), the batch dictionary keys, batch size 1.
-The patch search of the test path runs on the GPU (ppsurf_amd.spatial) in the main process instead of a CPU kd-tree in
-DataLoader workers.  Training datasets (augmentation, sub-sampling, DDP sampler) are not built in this round.
+The patch search runs on the GPU (ppsurf_amd.spatial) in the main process instead of a CPU kd-tree in DataLoader workers.
+Fit batches are assembled the same way: the dataset items are plain arrays (sub-sampled cloud, augmented queries), and one
+`collate_on_device` call per batch does patches, support levels and the 13 id tables of every shape on the device -- the work
+the reference spreads over `workers` CPU processes (configs/device_server.yaml uses 48 of them for 4 GPUs).
 """
 import os
 
@@ -105,6 +107,107 @@ class TestDataset(ReconstructionDataset):
         return spatial.get_data_poco(item)
 
 
+def random_rotation_matrix(rand3) -> np.ndarray:
+    """Uniform random rotation from three uniform numbers (Shoemake's method; the algorithm behind
+    trimesh.transformations.random_rotation_matrix(rand), used at poco_data_loader.py:333 / ppsurf_data_loader.py:66;
+    trimesh itself is not in the image) -> 3x3 float64."""
+    r1, r2 = np.sqrt(1.0 - rand3[0]), np.sqrt(rand3[0])
+    t1, t2 = 2.0 * np.pi * rand3[1], 2.0 * np.pi * rand3[2]
+    w, x, y, z = np.cos(t2) * r2, np.sin(t1) * r1, np.cos(t1) * r1, np.sin(t2) * r2
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+class TrainDataset(ReconstructionDataset):
+    """PocoDataset / PPSurfDataset for fit and validation (poco_data_loader.py:273-396, ppsurf_data_loader.py:48-81):
+    cloud sub-sampled to `manifold_points` (with replacement when it is smaller), ground-truth queries + signed distances,
+    `patches_per_shape` random queries only under DDP (:384-389), random rotation of cloud, normals and queries when
+    augmenting.  Like the reference, patches are searched in the UNROTATED raw cloud with the rotated queries
+    (ppsurf_data_loader.py:62-73).  Items are host arrays; `collate_on_device` finishes a batch on the GPU."""
+
+    def __init__(self, in_file, padding_factor, seed, use_ddp, manifold_points, patches_per_shape, do_data_augmentation, num_pts_local):
+        super().__init__(in_file, padding_factor, with_raw=False)
+        self.manifold_points, self.patches_per_shape = manifold_points, patches_per_shape
+        self.do_data_augmentation, self.num_pts_local = do_data_augmentation, num_pts_local
+        if seed is None:
+            seed = int(np.random.randint(0, 2 ** 31 - 1))
+        self.ddp = bool(use_ddp) and torch.cuda.device_count() > 1
+        if self.ddp:
+            import torch.distributed as dist
+            if not dist.is_available() or not dist.is_initialized():
+                raise RuntimeError('Requires distributed package to be available')
+            seed += dist.get_rank()                                            # per-rank stream (:297-298)
+        self.rng = np.random.RandomState(seed)
+
+    def __getitem__(self, i):
+        data = load_shape_data_pc(self.in_file, self.padding_factor, self.shape_names[i], normalize=not in_file_is_dataset(self.in_file))
+        raw = data['pts_ms']
+        pts, normals = raw, data['normals_ms']
+        if self.manifold_points is not None:
+            sel = self.rng.choice(np.arange(raw.shape[0]), size=self.manifold_points, replace=raw.shape[0] < self.manifold_points)
+            pts, normals = raw[sel], normals[sel]
+        q, dist_ = self._queries(self.shape_names[i])
+        if self.ddp and self.patches_per_shape is not None and self.patches_per_shape > 0:
+            sel = self.rng.choice(np.arange(q.shape[0]), self.patches_per_shape)
+            q, dist_ = q[sel], dist_[sel]
+        if self.do_data_augmentation:
+            rot = random_rotation_matrix(self.rng.rand(3))
+            pts = (pts @ rot.T).astype(np.float32)
+            normals = (normals @ rot.T).astype(np.float32)
+            q = (q @ rot.T).astype(np.float32)
+        return {'pts_ms': pts, 'normals_ms': normals, 'pts_query_ms': q, 'imp_surf_dist_ms': dist_, 'pts_raw_ms': raw,
+                'pc_file_in': data['pc_file_in'], 'shape_id': i}
+
+    def collate_on_device(self, items, device):
+        """default_collate + the per-shape work of the reference's __getitem__ (patches, get_data_poco), on the device."""
+        batch = {k: torch.from_numpy(np.stack([it[k] for it in items])).to(device, non_blocking=True)
+                 for k in ('pts_ms', 'normals_ms', 'pts_query_ms', 'imp_surf_dist_ms')}
+        batch['shape_id'] = torch.tensor([it['shape_id'] for it in items], device=device)
+        batch['pc_file_in'] = [it['pc_file_in'] for it in items]
+        if self.num_pts_local is not None:
+            batch['pts_local_ps'] = torch.stack([
+                spatial.get_pts_local_ps(torch.from_numpy(it['pts_raw_ms']).to(device), batch['pts_query_ms'][b].contiguous(), self.num_pts_local)
+                for b, it in enumerate(items)])
+        return spatial.get_data_poco(batch)
+
+
+class DeviceBatchLoader:
+    """DataLoader stand-in for fit / validation: shuffling like torch's RandomSampler (non-DDP) or DistributedSampler
+    (seed 0 + epoch, padded to a multiple of the world size, rank-strided; occupancy_data_module.py:108-137), batches built by
+    TrainDataset.collate_on_device.  `set_epoch` has DistributedSampler semantics."""
+
+    def __init__(self, dataset, batch_size, shuffle, device, rank=0, world_size=1):
+        self.dataset, self.batch_size, self.shuffle, self.device = dataset, int(batch_size), shuffle, device
+        self.rank, self.world_size, self.epoch = rank, world_size, 0
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def _indices(self):
+        n = len(self.dataset)
+        if self.world_size > 1:
+            if self.shuffle:
+                g = torch.Generator()
+                g.manual_seed(0 + self.epoch)
+                idx = torch.randperm(n, generator=g).tolist()
+            else:
+                idx = list(range(n))
+            total = -(-n // self.world_size) * self.world_size
+            idx += idx[:total - n]
+            return idx[self.rank:total:self.world_size]
+        return torch.randperm(n).tolist() if self.shuffle else list(range(n))
+
+    def __len__(self):
+        n = len(self.dataset) if self.world_size == 1 else -(-len(self.dataset) // self.world_size)
+        return -(-n // self.batch_size)
+
+    def __iter__(self):
+        idx = self._indices()
+        for s in range(0, len(idx), self.batch_size):
+            yield self.dataset.collate_on_device([self.dataset[i] for i in idx[s:s + self.batch_size]], self.device)
+
+
 def _collate1(item):
     """default_collate for batch size 1."""
     return {k: (v if k.startswith('_') else v.unsqueeze(0) if torch.is_tensor(v) else [v]) for k, v in item.items()}
@@ -128,10 +231,18 @@ class PocoDataModule:
         ds = TestDataset(self.testset, self.padding_factor, self.num_pts_local, self.manifold_points, self.seed, self.device)
         return (_collate1(ds[i]) for i in range(len(ds)))
 
-    def train_dataloader(self):
-        raise NotImplementedError('training data pipeline (augmentation, DDP sampler) is not built in this round')
+    def _fit_loader(self, set_file, augment, shuffle):
+        import torch.distributed as dist
+        ddp = bool(self.use_ddp) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        ds = TrainDataset(set_file, self.padding_factor, self.seed, self.use_ddp, self.manifold_points, self.patches_per_shape, augment,
+                          self.num_pts_local)
+        return DeviceBatchLoader(ds, self.batch_size, shuffle, self.device, dist.get_rank() if ddp else 0, dist.get_world_size() if ddp else 1)
 
-    val_dataloader = train_dataloader
+    def train_dataloader(self):
+        return self._fit_loader(self.trainset, self.do_data_augmentation, True)
+
+    def val_dataloader(self):
+        return self._fit_loader(self.valset, False, False)
 
 
 class PPSurfDataModule(PocoDataModule):

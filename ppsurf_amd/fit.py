@@ -1,0 +1,145 @@
+"""`fit` subcommand without Lightning: the training loop the reference delegates to pytorch_lightning.Trainer
+(configs/poco.yaml:4-25,60-77; source/poco_model.py:56-132), one process per GPU.
+
+  * optimizer / lr scheduler are instantiated from the YAML `class_path`s (torch.optim.AdamW, MultiStepLR stepped per epoch);
+  * trainer.precision: '16-mixed' (fp16 autocast + loss scaling, the reference default), 'bf16-mixed', or '32';
+  * every step: device-side batch assembly (data.DeviceBatchLoader) -> model.training_step -> backward -> bucketed gradient
+    all-reduce over RCCL overlapped with the backward pass (sharding.GradBuckets) -> optimizer step;
+  * BatchNorm / norm_radius buffers follow DDP semantics: broadcast from rank 0 at start (and stay rank-local afterwards);
+  * validation every `check_val_every_n_epoch` epochs in eval() mode -- that is the fused HIP inference path;
+  * ModelCheckpoint(save_last) -> models/<name>/version_0/checkpoints/last.ckpt with Lightning's key layout
+    ({'state_dict': {'network.<...>': tensor}, 'epoch', 'global_step', 'optimizer_states', 'lr_schedulers'}), so checkpoints
+    are interchangeable with the reference; metrics go to models/<name>/version_0/metrics.jsonl.
+"""
+import contextlib
+import importlib
+import json
+import os
+import time
+
+import torch
+
+from . import sharding, train_graph
+
+
+def _instantiate(spec, *args):
+    mod, cls = spec['class_path'].rsplit('.', 1)
+    return getattr(importlib.import_module(mod), cls)(*args, **spec.get('init_args', {}))
+
+
+class _MetricLog:
+    """Collects what the model logs through LightningModule.log during a step."""
+
+    def __init__(self):
+        self.values = {}
+
+    def __call__(self, name, value, **_kw):
+        self.values[name] = float(value.detach()) if torch.is_tensor(value) else float(value)
+
+
+def autocast_context(precision, device_type='cuda'):
+    precision = str(precision)
+    if precision in ('16-mixed', '16'):
+        return torch.autocast(device_type, dtype=torch.float16), True
+    if precision in ('bf16-mixed', 'bf16'):
+        return torch.autocast(device_type, dtype=torch.bfloat16), False
+    if precision in ('32', '32-true'):
+        return contextlib.nullcontext(), False
+    raise ValueError('unsupported trainer.precision {!r}'.format(precision))
+
+
+def save_checkpoint(path, model, optimizer, scheduler, epoch, global_step):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    tmp = path + '.tmp'
+    torch.save({'state_dict': model.state_dict(), 'epoch': epoch, 'global_step': global_step,
+                'optimizer_states': [optimizer.state_dict()], 'lr_schedulers': [scheduler.state_dict()] if scheduler is not None else [],
+                'pytorch-lightning_version': 'ppsurf_amd'}, tmp)
+    os.replace(tmp, path)
+
+
+def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
+    rank, world = sharding.world()
+    tcfg = cfg.get('trainer', {})
+    max_epochs = int(tcfg.get('max_epochs', 150))
+    max_steps = int(tcfg.get('max_steps', -1))
+    val_every = int(tcfg.get('check_val_every_n_epoch', 1))
+    ctx, use_scaler = autocast_context(tcfg.get('precision', '16-mixed'), torch.device(device).type)
+    params = [p for p in model.parameters() if p.requires_grad]
+    optimizer = _instantiate(cfg['optimizer'], params)
+    scheduler = _instantiate(cfg['lr_scheduler'], optimizer) if cfg.get('lr_scheduler') else None
+    scaler = torch.amp.GradScaler(torch.device(device).type, enabled=use_scaler)
+    start_epoch, global_step = 0, 0
+    if ckpt_path is not None:
+        state = torch.load(ckpt_path, map_location='cpu')
+        model.load_state_dict(state['state_dict'])
+        if state.get('optimizer_states'):
+            optimizer.load_state_dict(state['optimizer_states'][0])
+        if scheduler is not None and state.get('lr_schedulers'):
+            scheduler.load_state_dict(state['lr_schedulers'][0])
+        start_epoch, global_step = int(state.get('epoch', -1)) + 1, int(state.get('global_step', 0))
+    if world > 1:
+        import torch.distributed as dist
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=0)
+    buckets = sharding.GradBuckets(params)
+    out_dir = os.path.join('models', str(getattr(model, 'name', 'model')), 'version_0')
+    ckpt_file = os.path.join(out_dir, 'checkpoints', 'last.ckpt')
+    metrics = _MetricLog()
+    model.__dict__['_fit_log'] = metrics
+    train_loader, val_loader = data.train_dataloader(), data.val_dataloader()
+    mfile = None
+    if rank == 0:
+        os.makedirs(out_dir, exist_ok=True)
+        mfile = open(os.path.join(out_dir, 'metrics.jsonl'), 'a')
+    history = []
+    done = False
+    for epoch in range(start_epoch, max_epochs):
+        model.train()
+        train_loader.set_epoch(epoch)
+        t0 = time.time()
+        for bi, batch in enumerate(train_loader):
+            buckets.zero()
+            metrics.values = {}
+            with ctx:
+                loss = model.training_step(batch, bi)
+            scaler.scale(loss).backward()
+            model.on_after_backward()
+            buckets.finish()
+            scaler.step(optimizer)
+            scaler.update()
+            train_graph.release_step_caches()
+            global_step += 1
+            rec = dict(metrics.values, epoch=epoch, step=global_step, lr=optimizer.param_groups[0]['lr'])
+            history.append(rec)
+            if mfile is not None:
+                mfile.write(json.dumps(rec) + '\n')
+            if 0 < max_steps <= global_step:
+                done = True
+                break
+        if scheduler is not None:
+            scheduler.step()
+        msg = 'epoch {} ({} steps, {:.1f} s): train loss {:.4f}'.format(epoch, global_step, time.time() - t0,
+                                                                      history[-1].get('loss/train/00_all', float('nan')))
+        if val_every > 0 and (epoch + 1) % val_every == 0 and len(val_loader.dataset) > 0:
+            model.eval()
+            metrics.values = {}
+            vals = []
+            with torch.no_grad():
+                for bi, batch in enumerate(val_loader):
+                    vals.append(float(model.validation_step(batch, bi)))
+            vloss = sum(vals) / max(len(vals), 1)
+            if world > 1:
+                vloss = sharding.mean_over_ranks(vloss, device)
+            msg += ', val loss {:.4f}'.format(vloss)
+            if mfile is not None:
+                mfile.write(json.dumps({'epoch': epoch, 'loss/val/00_all': vloss, 'metrics/val/F1': metrics.values.get('metrics/val/F1')}) + '\n')
+        if rank == 0:
+            save_checkpoint(ckpt_file, model, optimizer, scheduler, epoch, global_step)
+            mfile.flush()
+            log(msg)
+        if done:
+            break
+    if mfile is not None:
+        mfile.close()
+    model.__dict__.pop('_fit_log', None)
+    return history

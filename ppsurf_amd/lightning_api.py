@@ -95,6 +95,9 @@ class PocoModel(_Base):
         return getattr(trainer, 'progress_bar_callback', None) if trainer is not None else None
 
     def _log(self, *args, **kwargs):
+        sink = self.__dict__.get('_fit_log')          # ppsurf_amd.fit collects the step's values here
+        if sink is not None:
+            return sink(*args, **kwargs)
         if hasattr(super(), 'log'):
             try:
                 return super().log(*args, **kwargs)

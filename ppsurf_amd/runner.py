@@ -8,7 +8,7 @@
 Stacked `-c` YAML files (later overrides earlier), dotted overrides, `class_path` / `init_args` instantiation and the
 argument links of poco.py:16-20 / pps.py:25.  Used when pytorch_lightning is not installed; with Lightning present the
 reference's own LightningCLI can drive the same classes through the `source.*` import paths.
-Subcommands: predict, test.  `fit` needs the training path, which is not built in this round.
+Subcommands: fit (ppsurf_amd/fit.py), test, predict.
 """
 import copy
 import importlib
@@ -116,8 +116,6 @@ class _Trainer:
 def main(argv=None):
     argv = list(sys.argv if argv is None else argv)
     sub, cfg, ckpt = parse(argv)
-    if sub == 'fit':
-        raise NotImplementedError('`fit` needs train-mode kernels (batch-statistics BatchNorm, backward), not built in this round')
     if cfg.get('seed_everything') is not None:
         import random
         import numpy as np
@@ -127,25 +125,34 @@ def main(argv=None):
     accel = str(cfg.get('trainer', {}).get('accelerator', 'gpu'))
     if accel == 'cpu' or not torch.cuda.is_available():
         raise RuntimeError('ppsurf_amd runs on an MI355X (gfx950) only: there is no CPU path (trainer.accelerator={})'.format(accel))
-    device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
+    # one process per GPU; more ranks than GPUs (2-rank rehearsals on a 1-GPU box) wrap around
+    device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)) % torch.cuda.device_count())
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(device)
+        if not dist.is_initialized():
+            dist.init_process_group(os.environ.get('PPS_BACKEND', 'nccl'), rank=rank, world_size=world)
     model = _instantiate(cfg['model']).to(device).eval()
     dspec = dict(cfg['data'])
     dspec['class_path'] = _DATA_CLASSES.get(dspec['class_path'], dspec['class_path'])
     data = _instantiate(dspec)
     data.device = device
+    model.__dict__['_runner_trainer'] = _Trainer()
+    if sub == 'fit':
+        # data-parallel over shapes: every rank runs its own batches, gradients are averaged over RCCL (ppsurf_amd/fit.py);
+        # data.init_args.use_ddp selects the DistributedSampler semantics like in the reference
+        from . import fit as fit_mod
+        fit_mod.fit(model, data, cfg, ckpt_path=ckpt, device=device)
+        return model
     if ckpt is not None:
         state = torch.load(ckpt, map_location='cpu')
         model.load_state_dict(state.get('state_dict', state))
-    model.__dict__['_runner_trainer'] = _Trainer()
     # multi-GPU predict (launched with torch.distributed.run, one rank per GPU, RCCL): PPS_SHARD=shapes (default) deals the
     # shapes of the test set round-robin to the ranks, no communication; PPS_SHARD=queries shards the query blocks and the
     # encoder passes of every shape over all ranks (latent all-reduce + per-round all-gather of occupancies).
-    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     shard = os.environ.get('PPS_SHARD', 'shapes')
     if world > 1:
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            dist.init_process_group(os.environ.get('PPS_BACKEND', 'nccl'), rank=rank, world_size=world)
         model.shard_queries = shard == 'queries'
         from . import sharding
         sharding.set_query_sharding(model.shard_queries)

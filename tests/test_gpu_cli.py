@@ -57,7 +57,7 @@ def test_predict_and_test_subcommands(tmp_path, capsys):
     assert out.count('loss') == 2 and 'nan' not in out.split('loss')[1][:12]
 
 
-def test_rec_rewrite_fit_and_cpu_are_refused(tmp_path):
+def test_rec_rewrite_and_cpu_is_refused(tmp_path):
     from ppsurf_amd import runner
     cloud = tmp_path / 'c.npy'
     np.save(cloud, np.zeros((10, 3), np.float32))
@@ -65,8 +65,6 @@ def test_rec_rewrite_fit_and_cpu_are_refused(tmp_path):
     assert rec[1] == 'predict' and 'configs/ppsurf_50nn.yaml' in rec and rec[-2:] == ['--model.init_args.rec_batch_size', '25000']
     with pytest.raises(ValueError):
         runner.handle_rec_subcommand(['pps.py', 'rec', str(tmp_path / 'missing.ply'), 'out'])
-    with pytest.raises(NotImplementedError):
-        runner.main(['pps.py', 'fit'] + _configs(tmp_path, 'x.txt'))
     with pytest.raises(RuntimeError, match='no CPU path'):
         runner.main(['pps.py', 'predict'] + _configs(tmp_path, 'x.txt') + ['--trainer.accelerator', 'cpu'])
 
@@ -84,3 +82,61 @@ def test_poco_model_predict_through_the_cli(tmp_path, capsys):
     out = capsys.readouterr().out
     mesh_dir = tmp_path / 'res' / 'poco' / 'ds' / 'meshes'
     assert (len(list(mesh_dir.glob('*.ply'))) if mesh_dir.exists() else 0) + out.count('No reconstruction for') == 1
+
+
+OPT = {'optimizer': {'class_path': 'torch.optim.AdamW', 'init_args': {'lr': 0.001, 'betas': [0.9, 0.999], 'eps': 1e-5, 'weight_decay': 1e-2,
+                                                                       'amsgrad': False}},
+       'lr_scheduler': {'class_path': 'torch.optim.lr_scheduler.MultiStepLR', 'init_args': {'milestones': [1, 125], 'gamma': 0.1}}}
+
+
+def _fit_args(tmp_path, in_file, extra=()):
+    opt = str(tmp_path / 'opt.yaml')
+    yaml.safe_dump(OPT, open(opt, 'w'))
+    return (['pps.py', 'fit'] + _configs(tmp_path, in_file) + ['-c', opt, '--trainer.max_epochs', '2', '--data.init_args.batch_size', '2',
+                                                               '--data.init_args.manifold_points', '1200'] + list(extra))
+
+
+@pytest.mark.parametrize('precision', ['16-mixed', 'bf16-mixed', '32'])
+def test_fit_subcommand_writes_a_reference_layout_checkpoint(tmp_path, monkeypatch, capsys, precision):
+    """pps.py fit on a synthetic dataset: 2 epochs x 2 steps (3 shapes, batch 2), AdamW + MultiStepLR from the YAML, validation
+    through the HIP inference path, last.ckpt with the reference's 455 state-dict names under 'network.'; predict loads it."""
+    import json
+    from ppsurf_amd import runner
+    from ppsurf_amd.synthetic import write_dataset
+    from golden_util import manifest
+    monkeypatch.chdir(tmp_path)
+    in_file = write_dataset(str(tmp_path / 'ds'), n_shapes=3, n_pts=2500, n_query=300)
+    model = runner.main(_fit_args(tmp_path, in_file, ['--trainer.precision', precision]))
+    ckpt = tmp_path / 'models' / 'ppsurf_mini' / 'version_0' / 'checkpoints' / 'last.ckpt'
+    state = torch.load(ckpt, map_location='cpu')
+    assert sorted(state['state_dict'].keys()) == sorted('network.' + k for k, _ in manifest('ppsurf'))
+    assert state['epoch'] == 1 and state['global_step'] == 4
+    assert abs(state['optimizer_states'][0]['param_groups'][0]['lr'] - 1e-4) < 1e-12         # MultiStepLR milestone at epoch 1
+    recs = [json.loads(l) for l in open(tmp_path / 'models' / 'ppsurf_mini' / 'version_0' / 'metrics.jsonl')]
+    steps = [r for r in recs if 'step' in r]
+    assert len(steps) == 4 and all(np.isfinite(r['loss/train/00_all']) for r in steps) and 'metrics/train/accuracy' in steps[0]
+    vals = [r for r in recs if 'loss/val/00_all' in r]
+    assert len(vals) == 2 and all(np.isfinite(r['loss/val/00_all']) for r in vals)
+    # buffers moved (train-mode side effects) and are finite
+    nr = state['state_dict']['network.encoder.cv0.norm_radius']
+    assert torch.isfinite(nr).all() and float(nr) != 1.0
+    assert int(state['state_dict']['network.mlp.layers.0.1.num_batches_tracked']) == 4
+    capsys.readouterr()
+    runner.main(['pps.py', 'predict'] + _configs(tmp_path, in_file) + ['--ckpt_path', str(ckpt), '--model.init_args.gen_resolution_global', '17',
+                                                                       '--model.init_args.results_dir', str(tmp_path / 'res')])
+    out = capsys.readouterr().out
+    mesh_dir = tmp_path / 'res' / 'ppsurf_mini' / 'ds' / 'meshes'
+    assert (len(list(mesh_dir.glob('*.ply'))) if mesh_dir.exists() else 0) + out.count('No reconstruction for') == 3
+
+
+def test_fit_resumes_from_a_checkpoint(tmp_path, monkeypatch):
+    from ppsurf_amd import runner
+    from ppsurf_amd.synthetic import write_dataset
+    monkeypatch.chdir(tmp_path)
+    in_file = write_dataset(str(tmp_path / 'ds'), n_shapes=2, n_pts=2000, n_query=200)
+    runner.main(_fit_args(tmp_path, in_file, ['--trainer.max_epochs', '1', '--trainer.precision', '32']))
+    ckpt = tmp_path / 'models' / 'ppsurf_mini' / 'version_0' / 'checkpoints' / 'last.ckpt'
+    assert torch.load(ckpt, map_location='cpu')['epoch'] == 0
+    runner.main(_fit_args(tmp_path, in_file, ['--trainer.max_epochs', '3', '--trainer.precision', '32', '--ckpt_path', str(ckpt)]))
+    state = torch.load(ckpt, map_location='cpu')
+    assert state['epoch'] == 2 and state['global_step'] == 3

@@ -60,3 +60,35 @@ def test_query_sharded_volume_equals_single_rank(tmp_path):
     n1 = np.load(tmp_path / 'nq_w1_r0.npy')[0]
     n2 = np.load(tmp_path / 'nq_w2_r0.npy')[0] + np.load(tmp_path / 'nq_w2_r1.npy')[0]
     assert n2 == n1                                                     # the two ranks decoded disjoint halves
+
+
+def test_two_rank_fit_keeps_the_replicas_identical(tmp_path):
+    """pps.py fit launched as 2 ranks (gloo on one GPU here, RCCL on the 8-GPU node): shapes sharded by the DistributedSampler
+    rule, bucketed gradient all-reduce; after training both replicas hold bit-identical parameters."""
+    import yaml
+    import torch
+    from ppsurf_amd.synthetic import write_dataset
+    from test_gpu_cli import BASE, PPS, OPT
+    in_file = write_dataset(str(tmp_path / 'ds'), n_shapes=4, n_pts=2000, n_query=200)
+    cfg = dict(BASE); cfg.update(OPT)
+    paths = []
+    for name, c in (('poco', cfg), ('pps', PPS), ('mini', {'model': {'init_args': {'name': 'ppsurf_mini'}},
+                                                          'data': {'init_args': {'in_file': in_file, 'batch_size': 1, 'use_ddp': True,
+                                                                                 'manifold_points': 1000}},
+                                                          'trainer': {'max_epochs': 2, 'precision': 'bf16-mixed'}})):
+        paths += ['-c', str(tmp_path / (name + '.yaml'))]
+        yaml.safe_dump(c, open(paths[-1], 'w'))
+    script = tmp_path / 'run.py'
+    script.write_text("import os, sys, torch\nsys.path.insert(0, {r!r})\nfrom ppsurf_amd import runner\n"
+                      "m = runner.main(['pps.py', 'fit'] + {a!r})\n"
+                      "torch.save({{k: v.cpu() for k, v in m.state_dict().items()}}, os.path.join({o!r}, 'sd_r' + os.environ['RANK'] + '.pt'))\n"
+                      .format(r=REPO, a=paths, o=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', PPS_BACKEND='gloo')
+    subprocess.check_call([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                           '--master-port', str(29900 + os.getpid() % 90), str(script)], env=env, cwd=str(tmp_path), timeout=900)
+    a, b = torch.load(tmp_path / 'sd_r0.pt'), torch.load(tmp_path / 'sd_r1.pt')
+    params = [k for k in a if 'running_' not in k and 'num_batches' not in k and 'norm_radius' not in k]
+    assert all(torch.equal(a[k], b[k]) for k in params)                    # same parameters on both replicas
+    assert any(not torch.equal(a[k], b[k]) for k in a if 'running_mean' in k)     # buffers are rank-local (different shapes)
+    state = torch.load(tmp_path / 'models' / 'ppsurf_mini' / 'version_0' / 'checkpoints' / 'last.ckpt', map_location='cpu')
+    assert state['global_step'] == 4                                       # 4 shapes / 2 ranks / batch 1 x 2 epochs

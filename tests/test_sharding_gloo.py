@@ -56,3 +56,51 @@ def test_two_rank_sharded_region_growing(tmp_path):
         assert np.array_equal(r['gathered'], np.arange(11) * 2.0)
     total = int((~np.isnan(ref[1:-1, 1:-1, 1:-1])).sum())
     assert abs(int(r0['seen']) - int(r1['seen'])) <= 64 and int(r0['seen']) + int(r1['seen']) <= int((~np.isnan(ref)).sum())
+
+
+def _grad_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ppsurf_amd.sharding import GradBuckets
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 2))
+    unused = torch.nn.Linear(3, 3)                                   # never part of the graph (POCO's cv5/bn5)
+    params = list(net.parameters()) + list(unused.parameters())
+    buckets = GradBuckets(params, n_buckets=3)
+    x = torch.from_numpy(np.random.default_rng(5).standard_normal((8, 6)).astype(np.float32))
+    y = torch.from_numpy(np.random.default_rng(6).integers(0, 2, 8))
+    opt = torch.optim.AdamW(params, lr=1e-2, weight_decay=0.1)
+    out = {}
+    for step in range(2):
+        buckets.zero()
+        lo, hi = rank * 4, rank * 4 + 4                              # each rank sees half of the batch
+        torch.nn.functional.cross_entropy(net(x[lo:hi]), y[lo:hi]).backward()
+        buckets.finish()
+        out['g{}'.format(step)] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy().copy()
+        out['unused_none{}'.format(step)] = np.array([p.grad is None for p in unused.parameters()])
+        opt.step()
+    out['w'] = torch.cat([p.detach().reshape(-1) for p in params]).numpy()
+    np.savez(os.path.join(out_dir, 'g{}.npz'.format(rank)), **out)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_buckets_equal_full_batch_gradients(tmp_path):
+    """Shapes sharded over 2 ranks + bucketed all-reduce == the gradient of the mean loss over the whole batch; a parameter
+    that takes no part in the graph keeps grad None (the optimizer must not touch it)."""
+    port = 31000 + os.getpid() % 2000
+    mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / 'g0.npz'), np.load(tmp_path / 'g1.npz')
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 2))
+    unused = torch.nn.Linear(3, 3)
+    w_unused0 = torch.cat([p.detach().reshape(-1) for p in unused.parameters()]).numpy().copy()
+    x = torch.from_numpy(np.random.default_rng(5).standard_normal((8, 6)).astype(np.float32))
+    y = torch.from_numpy(np.random.default_rng(6).integers(0, 2, 8))
+    torch.nn.functional.cross_entropy(net(x), y).backward()
+    full = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy()
+    np.testing.assert_allclose(r0['g0'], full, rtol=1e-5, atol=1e-7)
+    assert np.array_equal(r0['g0'], r1['g0']) and np.array_equal(r0['g1'], r1['g1']) and np.array_equal(r0['w'], r1['w'])
+    assert r0['unused_none0'].all() and r0['unused_none1'].all()
+    assert np.array_equal(r0['w'][-w_unused0.size:], w_unused0)              # untouched by AdamW's weight decay
