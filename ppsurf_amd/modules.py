@@ -327,8 +327,13 @@ class PPSurfNetwork(_Base):
         dev = pts.device
         ptq = _channel_first(data['pts_query'].to(dev))
         if self.training:
-            with torch.no_grad():
-                data['proj_ids'] = spatial.knn(pts, ptq, self.projection.k)
+            k = min(self.projection.k, pts.shape[2])
+            have = data.get('proj_ids')
+            if not (torch.is_tensor(have) and tuple(have.shape) == (pts.shape[0], ptq.shape[2], k)):
+                # the reference always recomputes them here with self.k (ppsurf_model.py:83); the dataset's table
+                # (get_data_poco, k = 64) is the same search whenever the sizes agree, so it is reused
+                with torch.no_grad():
+                    data['proj_ids'] = spatial.knn(pts, ptq, k)
             return train_graph.ppsurf_from_latent(self, _pm(data['latents']), data, data['proj_ids'])
         plan = self.decoder_plan(dev)
         k = min(self.projection.k, pts.shape[2])

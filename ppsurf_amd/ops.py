@@ -24,6 +24,26 @@ def knn_point_major(pts: torch.Tensor, query: torch.Tensor, k: int, return_d2: b
     return (idx, d2) if return_d2 else idx
 
 
+def knn_batch_point_major(pts_list, query_list, k_list):
+    """Up to 16 independent searches (k <= 64 each) per launch through pps_knn_multi_f32: the shapes of a fit batch, or the
+    tables of one encoder pass.  pts_list[i] [n_i,3], query_list[i] [m_i,3] contiguous float32 on the GPU -> list of int64 [m_i,k_i]."""
+    import ctypes
+    outs = []
+    for s in range(0, len(pts_list), 16):
+        ps, qs, ks = pts_list[s:s + 16], query_list[s:s + 16], k_list[s:s + 16]
+        nt = len(ps)
+        P, I64, I = ctypes.c_void_p * nt, ctypes.c_int64 * nt, ctypes.c_int * nt
+        pts, qry, out, ns, ms, kk = P(), P(), P(), I64(), I64(), I()
+        for t in range(nt):
+            if not (ps[t].is_cuda and qs[t].is_cuda):
+                raise _lib.PpsError('pps_knn_multi_f32 needs device tensors; there is no CPU fallback')
+            o = torch.empty((qs[t].shape[0], ks[t]), dtype=torch.int64, device=ps[t].device)
+            outs.append(o)
+            pts[t], qry[t], out[t], ns[t], ms[t], kk[t] = ps[t].data_ptr(), qs[t].data_ptr(), o.data_ptr(), ps[t].shape[0], qs[t].shape[0], ks[t]
+        _lib.check(_lib.lib().pps_knn_multi_f32(nt, pts, ns, qry, ms, kk, out, _stream(ps[0])), 'pps_knn_multi_f32')
+    return outs
+
+
 def patch_normalize(raw: torch.Tensor, query: torch.Tensor, idx: torch.Tensor, p: int, out: torch.Tensor = None) -> torch.Tensor:
     """raw [n,3], query [q,3], idx int64 [q,>=p] -> patches [q,p,3] in patch space (ppsurf_data_loader.py:91-123)."""
     raw = raw.contiguous().float()

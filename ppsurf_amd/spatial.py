@@ -29,7 +29,11 @@ def knn(points: torch.Tensor, support_points: torch.Tensor, k: int, workers: int
     """points [B,3,N], support_points [B,3,M] -> int64 [B,M,k] on the device of `points`; k clamps to N
     (poco_utils.py:259-260).  `workers` is accepted and ignored, as the reference ignores it for pykdtree."""
     k = min(int(k), points.shape[2])
-    if k <= 64:
+    nb = points.shape[0]
+    if k <= 64 and nb > 1 and points.is_cuda:          # a fit batch: all shapes in one launch
+        out = ops.knn_batch_point_major([_point_major(points[b]) for b in range(nb)], [_point_major(support_points[b]) for b in range(nb)],
+                                        [k] * nb)
+    elif k <= 64:
         out = [ops.knn_point_major(_point_major(points[b]), _point_major(support_points[b]), k) for b in range(points.shape[0])]
     else:                                   # 64 < k <= 256 (100NN / 200NN patches): block-culling search, same results
         out = [ops.KnnBlocks(_point_major(points[b])).query(_point_major(support_points[b]), k) for b in range(points.shape[0])]

@@ -190,8 +190,10 @@ def interp_attention(proj, latents, pts, query, ids, last_layer=True):
     h = F.relu(dense(proj.fc2, h))
     h = F.relu(dense(proj.fc3, h))
     att = torch.softmax(dense(proj.fc_query, h).view(b * q, k, -1), dim=1).mean(dim=2)  # softmax over neighbours, mean of heads
-    val = dense(proj.fc_value, h).view(b * q, k, -1)
-    out = (att.unsqueeze(-1) * val).sum(dim=1)
+    # sum_j a_j (W_v h_j + b_v) = W_v (sum_j a_j h_j) + b_v because the weights of a query sum to 1 (:412-414): fc_value runs on
+    # Q rows instead of Q*k (same identity as the inference kernel); autograd differentiates the pooled form
+    pooled = torch.bmm(att.unsqueeze(1).to(h.dtype), h.view(b * q, k, -1)).squeeze(1)
+    out = dense(proj.fc_value, pooled)
     if last_layer:
         out = dense(proj.fc8, out)
     return out.view(b, q, -1)
@@ -221,8 +223,8 @@ def pointnet(pn, patches):
     h = F.relu(batch_norm(pn.bn2, dense(pn.conv2, h)))
     h = batch_norm(pn.bn3, dense(pn.conv3, h))
     w = torch.softmax(dense(pn.att.fc_query, h).view(nq, p), dim=1)
-    v = dense(pn.att.fc_value, h).view(nq, p, -1)
-    return (w.unsqueeze(-1) * v).sum(dim=1), trans2
+    pooled = torch.bmm(w.unsqueeze(1).to(h.dtype), h.view(nq, p, -1)).squeeze(1)          # pool first: the weights sum to 1
+    return dense(pn.att.fc_value, pooled), trans2
 
 
 def mlp(m, x):
