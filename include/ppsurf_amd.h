@@ -201,6 +201,23 @@ int pps_gather_max_arg_f32(const float* x, const int64_t* idx, int64_t m, int k,
 int pps_gather_max_bwd_f32(const float* dout, const int32_t* arg, const int64_t* order, const int64_t* offsets, int64_t n, int k,
                            int c, float* dx, void* stream);
 
+/* FKAConv geometry branch in train() mode, forward and backward (the part of FKAConvLayer.forward that turns neighbour
+ * offsets into the [M,K,16] kernel-weighting matrix).   replaces: source/base/nn.py:601-643 under autograd.
+ * A batch of b shapes with m support points each: pts [rows,3], sup [b*m,3], idx int64 [b*m,k] = row numbers into pts
+ * (batch offsets included), k <= 16.  geo_w [pps_fkaconv_geo_floats()] = the layer's packed small parameters (layout of
+ * pps_fkaconv_fwd_f32: norm_radius, alpha, beta, activation, fc1/fc2/fc3 weights, InstanceNorm affine parameters);
+ * momentum > 0 first updates geo_w[0] (norm_radius) in place with the EMA of nn.py:608-613 and then uses the new value.
+ * g_out [b*m, k, 16];  stat [2][b][32] receives (mean, rstd) of the two InstanceNorms per shape (input of the backward).
+ * The InstanceNorms (statistics per shape over all (point, neighbour) pairs) are skipped when k == 1 (nn.py:627-638). */
+size_t pps_fka_train_ws_bytes(int64_t b, int64_t m, int k);
+int pps_fka_geometry_fwd_f32(const float* pts, const float* sup, const int64_t* idx, int64_t b, int64_t m, int k, float* geo_w,
+                             float momentum, float* g_out, float* stat, void* ws, void* stream);
+/* backward: dg [b*m,k,16] -> dgeo [pps_fkaconv_geo_floats()] (gradients of alpha, beta, fc1/fc2/fc3, InstanceNorm affine
+ * parameters in the geo layout; entries of norm_radius / activation are 0).  Recomputes the branch (nothing but `stat` is
+ * kept from the forward); deterministic (fixed-order reductions, no atomics). */
+int pps_fka_geometry_bwd_f32(const float* pts, const float* sup, const int64_t* idx, int64_t b, int64_t m, int k, const float* geo_w,
+                             const float* stat, const float* dg, float* dgeo, void* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,17 +47,6 @@ def batch_norm(bn, x):
     return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
 
 
-def _act(name):
-    return F.silu if name == 'silu' else F.relu
-
-
-def _instance_norm(inorm, m):
-    """InstanceNorm2d(affine, no running stats) on [B, M, K, C]: statistics over (M, K) per batch item and channel."""
-    mean = m.mean(dim=(1, 2), keepdim=True)
-    var = m.var(dim=(1, 2), unbiased=False, keepdim=True)
-    return (m - mean) * torch.rsqrt(var + inorm.eps) * inorm.weight + inorm.bias
-
-
 _flat_cache = {}
 
 
@@ -85,31 +74,28 @@ def release_step_caches():
 # ---------------------------------------------------------------------------------------------------------------------
 # encoder
 # ---------------------------------------------------------------------------------------------------------------------
+def pack_geo(layer):
+    """The layer's small parameters as ONE differentiable vector in the layout of the HIP kernels (pps_fka_common.h):
+    [norm_radius, alpha, beta, activation (1 relu / 2 silu), fc1 [16,3], fc2 [16,32], fc3 [16,32], bn1 w, bn1 b, bn2 w, bn2 b]."""
+    act = 2.0 if isinstance(layer.activation, torch.nn.SiLU) else 1.0
+    head = torch.tensor([act], dtype=layer.alpha.dtype, device=layer.alpha.device)
+    parts = [layer.norm_radius.detach().reshape(1), layer.alpha.reshape(1), layer.beta.reshape(1), head, layer.fc1.weight.reshape(-1),
+             layer.fc2.weight.reshape(-1), layer.fc3.weight.reshape(-1), layer.bn1.weight, layer.bn1.bias, layer.bn2.weight, layer.bn2.bias]
+    return torch.cat([p.to(layer.alpha.dtype) for p in parts])
+
+
 def fkaconv_layer(layer, x, pts, sup, ids):
-    """x [B,N,Cin], pts [B,N,3], sup [B,M,3], ids int64 [B,M,K] -> [B,M,Cout]."""
-    act = _act('silu' if isinstance(layer.activation, torch.nn.SiLU) else 'relu')
+    """x [B,N,Cin], pts [B,N,3], sup [B,M,3], ids int64 [B,M,K] -> [B,M,Cout].
+    Geometry branch (nn.py:601-643, incl. the norm_radius EMA in train()) and feature aggregation (:647-649) are HIP ops with
+    hand-written backward; the (1,16) convolution is one GEMM over all support points of the batch."""
     b, n, cin = x.shape
     m, k = ids.shape[1], ids.shape[2]
-    flat = _flat_ids(ids, n)
-    pn = pts.reshape(b * n, 3)[flat].view(b, m, k, 3) - sup.unsqueeze(2)
-    dist = torch.sqrt((pn.detach() ** 2).sum(-1))                                        # [B,M,K], no gradient (:605)
+    flat = _flat_ids(ids, n).view(b * m, k)
+    momentum = layer.norm_radius_momentum if layer.training else 0.0
+    g, radius = train_ops.fka_geometry(pack_geo(layer), pts.reshape(b * n, 3), sup.reshape(b * m, 3), flat, b, m, momentum)
     if layer.training:
-        with torch.no_grad():
-            mom = layer.norm_radius_momentum
-            layer.norm_radius.data = layer.norm_radius.data * (1 - mom) + dist.max(2)[0].mean() * mom
-    pn = pn / layer.norm_radius
-    dw = torch.sigmoid(-layer.alpha * dist + layer.beta)
-    s = dw.sum(2, keepdim=True)
-    s = s + (s == 0) + 1e-6
-    dw = (dw / s * k).unsqueeze(-1)                                                      # [B,M,K,1]
-    g = F.linear(pn, _w2d(layer.fc1))
-    g = act(g if k == 1 else _instance_norm(layer.bn1, g))
-    mp = (g * dw).max(dim=2, keepdim=True)[0].expand(-1, -1, k, -1)
-    g = F.linear(torch.cat([g, mp], dim=-1), _w2d(layer.fc2))
-    g = act(g if k == 1 else _instance_norm(layer.bn2, g))
-    mp = (g * dw).max(dim=2, keepdim=True)[0].expand(-1, -1, k, -1)
-    g = act(F.linear(torch.cat([g, mp], dim=-1), _w2d(layer.fc3))) * dw                  # [B,M,K,16]
-    feat = train_ops.neighbour_contract(x.reshape(b * n, cin), flat.view(b * m, k), g.reshape(b * m, k, -1))   # [B*M, Cin*16]
+        layer.norm_radius.data = radius.reshape(layer.norm_radius.shape).to(layer.norm_radius.dtype)
+    feat = train_ops.neighbour_contract(x.reshape(b * n, cin), flat, g)                  # [B*M, Cin*16]
     return F.linear(feat, _w2d(layer.cv)).view(b, m, -1)                                 # Conv2d (1,16): (c,t) -> c*16+t
 
 

@@ -3,6 +3,7 @@
     gather_rows(x [n,c], idx [r])                     -> [r,c]          (latent gather, nearest up-sampling)
     neighbour_max(x [n,c], idx [m,k])                 -> [m,c]          (nn.py:677-680 max_pool)
     neighbour_contract(x [n,c], idx [m,k], g [m,k,16])-> [m, c*16]      (nn.py:598,647-649 FKAConv feature aggregation)
+    fka_geometry(geo [1140], pts, sup, idx, b, m, momentum) -> (g [b*m,k,16], norm_radius')   (nn.py:601-643, pps_fka_train.hip)
 
 Device tensors only: there is no CPU implementation in the product (tests/train_ref_ops.py holds the torch twins the CPU
 suite patches in to check the surrounding graph).  Backward scatter-adds are atomics-free and bit-reproducible: the id table
@@ -142,6 +143,52 @@ class _NeighbourContract(torch.autograd.Function):
             _lib.check(_lib.lib().pps_segment_sum_rows_f32(dxg.data_ptr(), order.data_ptr(), offsets.data_ptr(), n, c, dx.data_ptr(),
                                                            _stream()), 'pps_segment_sum_rows_f32')
         return dx, None, dg
+
+
+GEO_FLOATS = 1140          # pps_fkaconv_geo_floats(): radius, alpha, beta, act, fc1 [16,3], fc2 [16,32], fc3 [16,32], IN1 w/b, IN2 w/b
+
+
+class _FkaGeometry(torch.autograd.Function):
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, geo, pts, sup, idx, b, m, momentum):
+        _need_cuda(geo, pts, sup, idx)
+        pts, sup, idx = pts.contiguous(), sup.contiguous(), idx.contiguous()
+        k = idx.shape[1]
+        if geo.numel() != GEO_FLOATS or idx.shape[0] != b * m or sup.shape[0] != b * m:
+            raise ValueError('fka_geometry: inconsistent sizes')
+        geo_w = geo.detach().clone().contiguous()
+        g = torch.empty((b * m, k, 16), device=pts.device, dtype=torch.float32)
+        stat = torch.empty((2, b, 32), device=pts.device, dtype=torch.float32)
+        ws = torch.empty((_lib.lib().pps_fka_train_ws_bytes(b, m, k),), device=pts.device, dtype=torch.uint8)
+        _lib.check(_lib.lib().pps_fka_geometry_fwd_f32(pts.data_ptr(), sup.data_ptr(), idx.data_ptr(), b, m, k, geo_w.data_ptr(),
+                                                       float(momentum), g.data_ptr(), stat.data_ptr(), ws.data_ptr(), _stream()),
+                   'pps_fka_geometry_fwd_f32')
+        ctx.save_for_backward(pts, sup, idx, geo_w, stat)
+        ctx.dims = (b, m, k)
+        radius = geo_w[0:1].clone()
+        ctx.mark_non_differentiable(radius)
+        return g, radius
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, dg, _dradius):
+        pts, sup, idx, geo_w, stat = ctx.saved_tensors
+        b, m, k = ctx.dims
+        dg = dg.contiguous().float()
+        dgeo = torch.empty((GEO_FLOATS,), device=dg.device, dtype=torch.float32)
+        ws = torch.empty((_lib.lib().pps_fka_train_ws_bytes(b, m, k),), device=dg.device, dtype=torch.uint8)
+        _lib.check(_lib.lib().pps_fka_geometry_bwd_f32(pts.data_ptr(), sup.data_ptr(), idx.data_ptr(), b, m, k, geo_w.data_ptr(),
+                                                       stat.data_ptr(), dg.data_ptr(), dgeo.data_ptr(), ws.data_ptr(), _stream()),
+                   'pps_fka_geometry_bwd_f32')
+        return dgeo, None, None, None, None, None, None
+
+
+def fka_geometry(geo, pts, sup, idx, b, m, momentum):
+    """geo: packed small parameters of the layer (differentiable); pts [rows,3], sup [b*m,3], idx int64 [b*m,k] rows of pts.
+    momentum > 0: train() -- norm_radius is first moved towards the mean neighbourhood radius, the new value is used and
+    returned.  -> (g [b*m,k,16], norm_radius [1])."""
+    return _FkaGeometry.apply(geo, pts, sup, idx, b, m, momentum)
 
 
 def gather_rows(x, idx):

@@ -73,6 +73,46 @@ def test_neighbour_contract_fwd_bwd(n, m, k, c, xgrad):
         torch.testing.assert_close(gx, x.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('act,b,n,m,k,mom', [(2.0, 3, 400, 150, 16, 0.1), (1.0, 1, 200, 200, 16, 0.0), (2.0, 2, 90, 37, 4, 0.1),
+                                             (1.0, 2, 64, 256, 1, 0.1), (2.0, 10, 2000, 500, 16, 0.1)])
+def test_fka_geometry_fwd_bwd(act, b, n, m, k, mom):
+    """Fused geometry branch (3 forward phases, 3 backward passes, recomputation) against the torch restatement under autograd:
+    g, the updated norm_radius, and the gradient of every small parameter of the layer."""
+    from ppsurf_amd import train_ops
+    from ppsurf_amd.synthetic import fill_param
+    rng = np.random.default_rng(int(b * 1000 + m + k))
+    pts = torch.from_numpy(rng.uniform(-0.5, 0.5, (b * n, 3)).astype(np.float32)).to(DEV)
+    sup_rows = torch.from_numpy(np.stack([rng.choice(n, m, replace=m > n) + i * n for i in range(b)]).reshape(-1)).to(DEV)
+    sup = pts[sup_rows].contiguous()
+    from ppsurf_amd import ops
+    idx = torch.cat([ops.knn_point_major(pts[i * n:(i + 1) * n].contiguous(), sup[i * m:(i + 1) * m].contiguous(), k) + i * n for i in range(b)])
+    geo0 = np.concatenate([[0.2, 1.3, 0.7, act], fill_param('T.fc1.weight', (16, 3, 1, 1)).reshape(-1) * 3,
+                           fill_param('T.fc2.weight', (16, 32, 1, 1)).reshape(-1), fill_param('T.fc3.weight', (16, 32, 1, 1)).reshape(-1),
+                           1 + 0.2 * rng.standard_normal(16), 0.2 * rng.standard_normal(16), 1 + 0.2 * rng.standard_normal(16),
+                           0.2 * rng.standard_normal(16)]).astype(np.float32)
+    w = torch.from_numpy(rng.standard_normal((b * m, k, 16)).astype(np.float32)).to(DEV)
+    res = []
+    for fn, dt in ((train_ops.fka_geometry, torch.float32), (ref.fka_geometry, torch.float64)):
+        geo = torch.from_numpy(geo0).to(DEV).to(dt).requires_grad_(True)
+        g, radius = fn(geo, pts.to(dt), sup.to(dt), idx, b, m, mom)
+        (g * w.to(dt)).sum().backward()
+        res.append((g.detach().double(), radius.detach().double(), geo.grad.double()))
+    (g1, r1, d1), (g2, r2, d2) = res
+    assert abs(float(r1) - float(r2)) <= 1e-6 * float(r2)
+    torch.testing.assert_close(g1, g2, rtol=2e-4, atol=2e-5 * float(g2.abs().max()))
+    assert float(d1[0]) == 0.0 and float(d1[3]) == 0.0                              # norm_radius, activation id: no gradient
+    for name, sl in (('alpha/beta', slice(1, 3)), ('fc1', slice(4, 52)), ('fc2', slice(52, 564)), ('fc3', slice(564, 1076)),
+                     ('IN affine', slice(1076, 1140))):
+        scale = float(d2[sl].abs().max())
+        err = float((d1[sl] - d2[sl]).abs().max())
+        assert err <= 2e-3 * max(scale, 1e-6), '{}: max err {:.3e} of scale {:.3e}'.format(name, err, scale)
+    # deterministic: same bits twice
+    geo = torch.from_numpy(geo0).to(DEV).requires_grad_(True)
+    g, _ = train_ops.fka_geometry(geo, pts, sup, idx, b, m, mom)
+    (g * w).sum().backward()
+    assert torch.equal(geo.grad.double(), d1) and torch.equal(g.double(), g1)
+
+
 def test_ops_refuse_cpu_tensors():
     from ppsurf_amd import train_ops
     from ppsurf_amd._lib import PpsError
