@@ -430,27 +430,30 @@ __global__ __launch_bounds__(FT_NT) void fka_bwd_kernel(const float* __restrict_
     }
 }
 
-// dgeo[1140] from the per-block partials (fixed order) and the InstanceNorm sums
+// dgeo[1140] from the per-block partials and the InstanceNorm sums: one wave per entry, lanes stride over the blocks and
+// the 64 sub-sums are combined by a fixed butterfly (deterministic)
 __global__ __launch_bounds__(256) void fka_fin_grad_kernel(const float* __restrict__ pw3, const float* __restrict__ pw2, const float* __restrict__ pw1,
                                                            const double* __restrict__ pab, int nblk, const float* __restrict__ gm2,
                                                            const float* __restrict__ gm1, int B, double count, int K, float* __restrict__ dgeo) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (e >= GEO_FLOATS) return;
     double s = 0.0;
     if (e >= GEO_FC3 && e < GEO_FC3 + 512) {
-        for (int b = 0; b < nblk; ++b) s += (double)pw3[(int64_t)b * 512 + (e - GEO_FC3)];
+        for (int b = lane; b < nblk; b += 64) s += (double)pw3[(int64_t)b * 512 + (e - GEO_FC3)];
     } else if (e >= GEO_FC2 && e < GEO_FC2 + 512) {
-        for (int b = 0; b < nblk; ++b) s += (double)pw2[(int64_t)b * 512 + (e - GEO_FC2)];
+        for (int b = lane; b < nblk; b += 64) s += (double)pw2[(int64_t)b * 512 + (e - GEO_FC2)];
     } else if (e >= GEO_FC1 && e < GEO_FC1 + 48) {
-        for (int b = 0; b < nblk; ++b) s += (double)pw1[(int64_t)b * 48 + (e - GEO_FC1)];
+        for (int b = lane; b < nblk; b += 64) s += (double)pw1[(int64_t)b * 48 + (e - GEO_FC1)];
     } else if (e == GEO_ALPHA || e == GEO_BETA) {
-        for (int b = 0; b < nblk; ++b) s += pab[(int64_t)b * 2 + (e == GEO_BETA ? 1 : 0)];
+        for (int b = lane; b < nblk; b += 64) s += pab[(int64_t)b * 2 + (e == GEO_BETA ? 1 : 0)];
     } else if (e >= GEO_IN1W && K > 1) {                       // affine parameters of the InstanceNorms: sum over the shapes
         const int t = (e - GEO_IN1W) & 15, which = (e - GEO_IN1W) >> 4;   // 0: IN1 weight, 1: IN1 bias, 2: IN2 weight, 3: IN2 bias
         const float* gm = which < 2 ? gm1 : gm2;
-        for (int b = 0; b < B; ++b) s += (double)gm[b * 32 + 2 * t + ((which & 1) ? 0 : 1)] * count;
+        for (int b = lane; b < B; b += 64) s += (double)gm[b * 32 + 2 * t + ((which & 1) ? 0 : 1)] * count;
     }
-    dgeo[e] = (float)s;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) dgeo[e] = (float)s;
 }
 
 inline int grid_g(int64_t M) {
@@ -530,7 +533,7 @@ int pps_fka_geometry_bwd_f32(const float* pts, const float* sup, const int64_t* 
     hipLaunchKernelGGL(fka_fin_stat_kernel<1>, dim3((unsigned)b), dim3(256), 0, st, (const double*)part_s, G, count, gm1);
     hipLaunchKernelGGL(fka_bwd_kernel<3>, grid, dim3(FT_NT), 0, st, pts, sup, idx, m, k, geo_w, stat1, stat2, (const float*)gm1, dg, dyb, ddwb,
                        part_s, pw1, part_ab);
-    hipLaunchKernelGGL(fka_fin_grad_kernel, dim3((GEO_FLOATS + 255) / 256), dim3(256), 0, st, (const float*)pw3, (const float*)pw2,
+    hipLaunchKernelGGL(fka_fin_grad_kernel, dim3((GEO_FLOATS + 3) / 4), dim3(256), 0, st, (const float*)pw3, (const float*)pw2,
                        (const float*)pw1, (const double*)part_ab, (int)nblk, (const float*)gm2, (const float*)gm1, (int)b, count, k, dgeo);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }

@@ -166,9 +166,8 @@ class TrainDataset(ReconstructionDataset):
         batch['shape_id'] = torch.tensor([it['shape_id'] for it in items], device=device)
         batch['pc_file_in'] = [it['pc_file_in'] for it in items]
         if self.num_pts_local is not None:
-            batch['pts_local_ps'] = torch.stack([
-                spatial.get_pts_local_ps(torch.from_numpy(it['pts_raw_ms']).to(device), batch['pts_query_ms'][b].contiguous(), self.num_pts_local)
-                for b, it in enumerate(items)])
+            raws = [torch.from_numpy(it['pts_raw_ms']).to(device, non_blocking=True) for it in items]
+            batch['pts_local_ps'] = spatial.get_pts_local_ps_batch(raws, batch['pts_query_ms'], self.num_pts_local)
         return spatial.get_data_poco(batch)
 
 

@@ -244,3 +244,16 @@ def get_pts_local_ps(pts_raw_ms, pts_query, num_pts_local, idx=None):
         idx = (ops.knn_point_major(pts_raw_ms, pts_query, num_pts_local) if num_pts_local <= 64
                else ops.KnnBlocks(pts_raw_ms).query(pts_query, num_pts_local))
     return ops.patch_normalize(pts_raw_ms, pts_query, idx, num_pts_local)
+
+
+def get_pts_local_ps_batch(raws, queries, num_pts_local):
+    """Patches of a fit batch: raws = list of B raw clouds [n_b,3] (sizes may differ), queries [B,Q,3] -> [B,Q,P,3].
+    The B patch searches are one launch (pps_knn_multi_f32) when P <= 64."""
+    b = len(raws)
+    raws = [r.contiguous().float() for r in raws]
+    qs = [queries[i].contiguous().float() for i in range(b)]
+    if num_pts_local <= 64:
+        ids = ops.knn_batch_point_major(raws, qs, [min(num_pts_local, r.shape[0]) for r in raws])
+    else:
+        ids = [ops.KnnBlocks(r).query(q, num_pts_local) for r, q in zip(raws, qs)]
+    return torch.stack([ops.patch_normalize(raws[i], qs[i], ids[i], num_pts_local) for i in range(b)])

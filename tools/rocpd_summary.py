@@ -10,7 +10,8 @@ import sys
 
 
 def short(name):
-    return name.split('(')[0].replace('void ', '')[:60]
+    name = name.replace('(anonymous namespace)::', '').replace('void ', '')
+    return name.split('(')[0][:60]
 
 
 def main(src, dst):

@@ -30,8 +30,7 @@ def prepare(batch, p):
     """device-side equivalent of the dataset's per-shape work: patches, supports, id tables."""
     b = batch['pts_ms'].shape[0]
     if p:
-        batch['pts_local_ps'] = torch.stack([spatial.get_pts_local_ps(batch['pts_ms'][i].contiguous(), batch['pts_query_ms'][i].contiguous(), p)
-                                             for i in range(b)])
+        batch['pts_local_ps'] = spatial.get_pts_local_ps_batch([batch['pts_ms'][i] for i in range(b)], batch['pts_query_ms'], p)
     return spatial.get_data_poco(batch)
 
 
