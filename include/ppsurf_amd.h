@@ -218,6 +218,18 @@ int pps_fka_geometry_fwd_f32(const float* pts, const float* sup, const int64_t* 
 int pps_fka_geometry_bwd_f32(const float* pts, const float* sup, const int64_t* idx, int64_t b, int64_t m, int k, const float* geo_w,
                              const float* stat, const float* dg, float* dgeo, void* ws, void* stream);
 
+/* BatchNorm1d in train() mode with the ReLU fused, on point-major activations x [rows, c] (c % 4 == 0, 256 % (c/4) == 0,
+ * c <= 1024), storage dtype 0 = fp32, 1 = bf16 (x, y, dy, dx share it), fp32 arithmetic.
+ * replaces: activation(bn(conv(x))) of source/base/nn.py:438-450,508-554,162-190,323-336,376-417 under autograd.
+ * forward: batch statistics (biased variance) -> save [2][c] (mean, rstd); running_mean/var (NULL or both) updated in place with
+ * `momentum` and the unbiased variance like torch.nn.BatchNorm1d; y = relu? max(0, .) : . of the normalised, affine output.
+ * backward: dx, dgamma [c], dbeta [c] from x, dy and `save` (the ReLU mask is recomputed from x).  Deterministic. */
+size_t pps_bn_train_ws_bytes(int64_t rows, int c);
+int pps_bn_train_fwd(const void* x, int64_t rows, int c, int dtype, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, float momentum, float eps, int relu, void* y, float* save, void* ws, void* stream);
+int pps_bn_train_bwd(const void* x, const void* dy, int64_t rows, int c, int dtype, const float* gamma, const float* beta, const float* save,
+                     int relu, void* dx, float* dgamma, float* dbeta, void* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

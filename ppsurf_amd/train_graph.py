@@ -71,12 +71,12 @@ class _RowsLinear(torch.autograd.Function):
             s = 256 if rows >= 256 * 1024 else 64
             rs = rows // s
             main = rs * s
-            dw = torch.bmm(g[:main].view(s, rs, -1).transpose(1, 2), xc[:main].view(s, rs, -1)).to(acc).sum(0)
+            dw = torch.bmm(g[:main].view(s, rs, -1).transpose(1, 2), xc[:main].view(s, rs, -1)).sum(0, dtype=acc)
             if main < rows:
                 dw = dw + (g[main:].t() @ xc[main:]).to(acc)
             dw = dw.to(wdt)
         if bdt is not None and ctx.needs_input_grad[2]:
-            db = g.to(acc).sum(0).to(bdt)
+            db = g.sum(0, dtype=acc).to(bdt)
         return dx, dw, db
 
 
@@ -91,11 +91,15 @@ def dense(layer, x):
     return rows_linear(x, _w2d(layer), layer.bias)
 
 
-def batch_norm(bn, x):
-    """BatchNorm1d holder on [rows, C]: batch statistics + running-stat update in train(), running stats in eval()."""
+def batch_norm(bn, x, relu=False):
+    """BatchNorm1d holder on [rows, C] (+ fused ReLU): batch statistics + running-stat update in train() through the fused HIP
+    op (2 + 2 streaming passes instead of torch's 7, train_ops.bn_act), running statistics in eval()."""
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
+    if bn.training and train_ops.bn_supported(x.shape[0], x.shape[1]):
+        return train_ops.bn_act(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu)
+    y = F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training, bn.momentum, bn.eps)
+    return F.relu(y) if relu else y
 
 
 _flat_cache = {}
@@ -154,9 +158,9 @@ def residual_block(blk, x, pts, sup, ids):
     """[B,N,Cin] -> [B,M,Cout]."""
     b, n, cin = x.shape
     m = ids.shape[1]
-    h = F.relu(batch_norm(blk.bn0, dense(blk.cv0, x.reshape(b * n, cin)))).view(b, n, -1)
+    h = batch_norm(blk.bn0, dense(blk.cv0, x.reshape(b * n, cin)), relu=True).view(b, n, -1)
     h = fkaconv_layer(blk.cv1, h, pts, sup, ids)
-    h = F.relu(batch_norm(blk.bn1, h.reshape(b * m, -1)))
+    h = batch_norm(blk.bn1, h.reshape(b * m, -1), relu=True)
     h = batch_norm(blk.bn2, dense(blk.cv2, h))
     sc = x.reshape(b * n, cin)
     if not isinstance(blk.shortcut, torch.nn.Identity):
@@ -181,7 +185,7 @@ def encoder(enc, data):
     b = pts.shape[0]
     x = torch.ones_like(pts)                                                             # input features are all-ones (:517)
     x0 = fkaconv_layer(enc.cv0, x, pts, pts, data['ids00'])
-    x0 = F.relu(batch_norm(enc.bn0, x0.reshape(b * pts.shape[1], -1))).view(b, pts.shape[1], -1)
+    x0 = batch_norm(enc.bn0, x0.reshape(b * pts.shape[1], -1), relu=True).view(b, pts.shape[1], -1)
     x0 = residual_block(enc.resnetb01, x0, pts, pts, data['ids00'])
     x1 = residual_block(enc.resnetb10, x0, pts, s1, data['ids01'])
     x1 = residual_block(enc.resnetb11, x1, s1, s1, data['ids11'])
@@ -194,7 +198,7 @@ def encoder(enc, data):
 
     def head(cv, bn, coarse, ids_up, skip):
         z = torch.cat([_upsample(coarse, ids_up, coarse.shape[1]), skip], dim=-1)
-        return F.relu(batch_norm(bn, dense(cv, z.reshape(-1, z.shape[-1])))).view(b, skip.shape[1], -1)
+        return batch_norm(bn, dense(cv, z.reshape(-1, z.shape[-1])), relu=True).view(b, skip.shape[1], -1)
 
     x4d = x4
     if enc.fixed or enc.training:                                                        # :531-534
@@ -202,7 +206,7 @@ def encoder(enc, data):
         # updates bn5's running statistics, which end up in the checkpoint
         x5 = x4.max(dim=1, keepdim=True)[0].expand_as(x4)
         z = torch.cat([x4, x5], dim=-1)
-        z = F.relu(batch_norm(enc.bn5, dense(enc.cv5, z.reshape(-1, z.shape[-1])))).view(b, x4.shape[1], -1)
+        z = batch_norm(enc.bn5, dense(enc.cv5, z.reshape(-1, z.shape[-1])), relu=True).view(b, x4.shape[1], -1)
         if enc.fixed:
             x4d = z
     x3d = head(enc.cv3d, enc.bn3d, x4d, data['ids43'], x3)
@@ -239,12 +243,12 @@ def interp_attention(proj, latents, pts, query, ids, last_layer=True):
 def stn(t, h, nq, p):
     """h [nq*p, dim] -> [nq, dim, dim]."""
     d = t.dim
-    z = F.relu(batch_norm(t.bn1, dense(t.conv1, h)))
-    z = F.relu(batch_norm(t.bn2, dense(t.conv2, z)))
-    z = F.relu(batch_norm(t.bn3, dense(t.conv3, z)))
+    z = batch_norm(t.bn1, dense(t.conv1, h), relu=True)
+    z = batch_norm(t.bn2, dense(t.conv2, z), relu=True)
+    z = batch_norm(t.bn3, dense(t.conv3, z), relu=True)
     z = z.view(nq, p, -1).max(dim=1)[0]
-    z = F.relu(batch_norm(t.bn4, dense(t.fc1, z)))
-    z = F.relu(batch_norm(t.bn5, dense(t.fc2, z)))
+    z = batch_norm(t.bn4, dense(t.fc1, z), relu=True)
+    z = batch_norm(t.bn5, dense(t.fc2, z), relu=True)
     z = dense(t.fc3, z) + torch.eye(d, dtype=z.dtype, device=z.device).reshape(1, d * d)
     return z.view(nq, d, d)
 
@@ -252,12 +256,12 @@ def stn(t, h, nq, p):
 def pointnet(pn, patches):
     """patches [Q', P, 3] -> (feat [Q', C], trans2 [Q', 64, 64])."""
     nq, p, _ = patches.shape
-    h = F.relu(batch_norm(pn.bn0a, dense(pn.conv0a, patches.reshape(nq * p, 3))))
-    h = F.relu(batch_norm(pn.bn0b, dense(pn.conv0b, h)))
+    h = batch_norm(pn.bn0a, dense(pn.conv0a, patches.reshape(nq * p, 3)), relu=True)
+    h = batch_norm(pn.bn0b, dense(pn.conv0b, h), relu=True)
     trans2 = stn(pn.stn2, h, nq, p)
     h = torch.bmm(h.view(nq, p, -1), trans2.transpose(1, 2)).reshape(nq * p, -1)         # channel-first: trans2 @ x
-    h = F.relu(batch_norm(pn.bn1, dense(pn.conv1, h)))
-    h = F.relu(batch_norm(pn.bn2, dense(pn.conv2, h)))
+    h = batch_norm(pn.bn1, dense(pn.conv1, h), relu=True)
+    h = batch_norm(pn.bn2, dense(pn.conv2, h), relu=True)
     h = batch_norm(pn.bn3, dense(pn.conv3, h))
     w = torch.softmax(dense(pn.att.fc_query, h).view(nq, p), dim=1)
     pooled = torch.bmm(w.unsqueeze(1).to(h.dtype), h.view(nq, p, -1)).squeeze(1)          # pool first: the weights sum to 1
@@ -268,7 +272,7 @@ def mlp(m, x):
     for i, block in enumerate(m.layers):
         x = dense(block[0], x)
         if i < len(m.layers) - 1:
-            x = block[3](F.relu(batch_norm(block[1], x)))                                # Dropout holder, active in train()
+            x = block[3](batch_norm(block[1], x, relu=True))                                # Dropout holder, active in train()
     return x
 
 

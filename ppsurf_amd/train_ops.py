@@ -4,6 +4,7 @@
     neighbour_max(x [n,c], idx [m,k])                 -> [m,c]          (nn.py:677-680 max_pool)
     neighbour_contract(x [n,c], idx [m,k], g [m,k,16])-> [m, c*16]      (nn.py:598,647-649 FKAConv feature aggregation)
     fka_geometry(geo [1140], pts, sup, idx, b, m, momentum) -> (g [b*m,k,16], norm_radius')   (nn.py:601-643, pps_fka_train.hip)
+    bn_act(x [rows,c], weight, bias, running_mean, running_var, momentum, eps, relu) -> [rows,c]   (train-mode BatchNorm1d + ReLU)
 
 Device tensors only: there is no CPU implementation in the product (tests/train_ref_ops.py holds the torch twins the CPU
 suite patches in to check the surrounding graph).  Backward scatter-adds are atomics-free and bit-reproducible: the id table
@@ -189,6 +190,55 @@ def fka_geometry(geo, pts, sup, idx, b, m, momentum):
     momentum > 0: train() -- norm_radius is first moved towards the mean neighbourhood radius, the new value is used and
     returned.  -> (g [b*m,k,16], norm_radius [1])."""
     return _FkaGeometry.apply(geo, pts, sup, idx, b, m, momentum)
+
+
+class _BnAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
+        _need_cuda(x, weight, bias)
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        x = x.contiguous()
+        rows, c = x.shape
+        w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        y = torch.empty_like(x)
+        save = torch.empty((2, c), device=x.device, dtype=torch.float32)
+        nbytes = _lib.lib().pps_bn_train_ws_bytes(rows, c)
+        if nbytes == 0 and rows > 0:
+            raise ValueError('bn_act: unsupported shape [{}, {}]'.format(rows, c))
+        ws = torch.empty((max(nbytes, 1),), device=x.device, dtype=torch.uint8)
+        _lib.check(_lib.lib().pps_bn_train_fwd(x.data_ptr(), rows, c, 1 if x.dtype == torch.bfloat16 else 0, w32.data_ptr(), b32.data_ptr(),
+                                               running_mean.data_ptr() if running_mean is not None else None,
+                                               running_var.data_ptr() if running_var is not None else None, float(momentum), float(eps),
+                                               int(bool(relu)), y.data_ptr(), save.data_ptr(), ws.data_ptr(), _stream()), 'pps_bn_train_fwd')
+        ctx.save_for_backward(x, w32, b32, save)
+        ctx.relu = bool(relu)
+        ctx.dtypes = (weight.dtype, bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w32, b32, save = ctx.saved_tensors
+        rows, c = x.shape
+        dy = dy.to(x.dtype).contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.empty((c,), device=x.device, dtype=torch.float32)
+        dbeta = torch.empty((c,), device=x.device, dtype=torch.float32)
+        ws = torch.empty((max(_lib.lib().pps_bn_train_ws_bytes(rows, c), 1),), device=x.device, dtype=torch.uint8)
+        _lib.check(_lib.lib().pps_bn_train_bwd(x.data_ptr(), dy.data_ptr(), rows, c, 1 if x.dtype == torch.bfloat16 else 0, w32.data_ptr(),
+                                               b32.data_ptr(), save.data_ptr(), int(ctx.relu), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                               ws.data_ptr(), _stream()), 'pps_bn_train_bwd')
+        return dx, dgamma.to(ctx.dtypes[0]), dbeta.to(ctx.dtypes[1]), None, None, None, None, None
+
+
+def bn_supported(rows, c):
+    return c % 4 == 0 and c <= 1024 and 256 % (c // 4) == 0
+
+
+def bn_act(x, weight, bias, running_mean, running_var, momentum, eps, relu):
+    """Train-mode BatchNorm1d over the rows of x [rows, c] (batch statistics, running statistics updated in place) with an
+    optional fused ReLU; x fp32 or bf16 (kept), statistics and gradients of the affine parameters in fp32."""
+    return _BnAct.apply(x, weight, bias, running_mean, running_var, momentum, eps, relu)
 
 
 def gather_rows(x, idx):

@@ -113,6 +113,39 @@ def test_fka_geometry_fwd_bwd(act, b, n, m, k, mom):
     assert torch.equal(geo.grad.double(), d1) and torch.equal(g.double(), g1)
 
 
+@pytest.mark.parametrize('rows,c,relu,dt', [(5000, 64, True, torch.float32), (777, 256, False, torch.float32), (40000, 32, True, torch.bfloat16),
+                                            (3, 1024, True, torch.float32), (100000, 128, True, torch.bfloat16), (1, 16, False, torch.float32)])
+def test_bn_act_fwd_bwd(rows, c, relu, dt):
+    """Fused train-mode BatchNorm1d(+ReLU) against torch (float64): output, running statistics, dx, dgamma, dbeta."""
+    from ppsurf_amd import train_ops
+    rng = np.random.default_rng(rows + c)
+    x0 = torch.from_numpy((rng.standard_normal((rows, c)) * rng.uniform(0.5, 2, c) + rng.uniform(-3, 3, c)).astype(np.float32)).to(DEV).to(dt)
+    w0 = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)).to(DEV)
+    b0 = torch.from_numpy(rng.uniform(-0.5, 0.5, c).astype(np.float32)).to(DEV)
+    r = torch.from_numpy(rng.standard_normal((rows, c)).astype(np.float32)).to(DEV)
+    res = []
+    for fn, cdt in ((train_ops.bn_act, dt), (ref.bn_act, torch.float64)):
+        x = x0.detach().clone().to(cdt).requires_grad_(True)
+        pdt = torch.float64 if cdt == torch.float64 else torch.float32
+        w, b = w0.detach().clone().to(pdt).requires_grad_(True), b0.detach().clone().to(pdt).requires_grad_(True)
+        rm = torch.zeros(c, device=DEV, dtype=w.dtype); rv = torch.ones(c, device=DEV, dtype=w.dtype)
+        if rows == 1 and fn is ref.bn_act:
+            res.append(None)                                   # torch refuses one value per channel in training
+            continue
+        y = fn(x, w, b, rm, rv, 0.1, 1e-5, relu)
+        (y.double() * r.double()).sum().backward()
+        res.append([t.detach().double() for t in (y, rm, rv, x.grad, w.grad, b.grad)])
+    got, want = res
+    if want is None:
+        assert torch.isfinite(got[0]).all()
+        return
+    tol = 2e-2 if dt == torch.bfloat16 else 2e-4
+    for name, a, b_ in zip(('y', 'running_mean', 'running_var', 'dx', 'dgamma', 'dbeta'), got, want):
+        scale = float(b_.abs().max()) + 1e-6
+        rel = tol * (8 if name in ('dgamma', 'dbeta') and dt == torch.bfloat16 else 1)
+        assert float((a - b_).abs().max()) <= rel * scale, '{}: err {:.3e} of {:.3e}'.format(name, float((a - b_).abs().max()), scale)
+
+
 def test_ops_refuse_cpu_tensors():
     from ppsurf_amd import train_ops
     from ppsurf_amd._lib import PpsError

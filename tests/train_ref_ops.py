@@ -56,7 +56,17 @@ def fka_geometry(geo, pts, sup, idx, b, m, momentum):
     return g.reshape(b * m, k, 16), radius.reshape(1)
 
 
-_NAMES = ('gather_rows', 'neighbour_max', 'neighbour_contract', 'fka_geometry')
+def bn_act(x, weight, bias, running_mean, running_var, momentum, eps, relu):
+    import torch.nn.functional as F
+    y = F.batch_norm(x, running_mean, running_var, weight, bias, True, momentum, eps)
+    return F.relu(y) if relu else y
+
+
+def bn_supported(rows, c):
+    return True
+
+
+_NAMES = ('gather_rows', 'neighbour_max', 'neighbour_contract', 'fka_geometry', 'bn_act', 'bn_supported')
 
 
 @contextlib.contextmanager
