@@ -47,7 +47,7 @@ int pps_knn_blocked_f32(const float* pts_blocked, const int32_t* orig_idx, const
                         const float* win_bbox, int64_t n_win, const float* query, int64_t m, int k, int64_t* out_idx,
                         float* out_d2, void* stream);
 
-/* The neighbourhood tables of one encoder pass in a single launch (k <= 64 each, ntasks <= 16); arrays are [host] arrays of
+/* The neighbourhood tables of one encoder pass (or of several shapes of a fit batch) in a single launch (k <= 64 each, ntasks <= 64); arrays are [host] arrays of
  * device pointers / sizes.   replaces: the 13 `knn` calls of source/poco_data_loader.py:155-168. */
 int pps_knn_multi_f32(int ntasks, const float* const* pts, const int64_t* n, const float* const* query, const int64_t* m,
                       const int* k, int64_t* const* out_idx, void* stream);
@@ -61,6 +61,10 @@ int pps_knn_multi_f32(int ntasks, const float* const* pts, const int64_t* n, con
 int pps_voxel_sample_max_points(void);
 int pps_voxel_sample_f32(const float* pts, int64_t n, int64_t target, float vox, const float* rots, int nrot, uint32_t seed,
                          int64_t* out_ids, int32_t* out_rounds, void* stream);
+/* The same for a batch of b equally sized clouds pts [b,n,3] in ONE launch (one workgroup per cloud; default voxel edge;
+ * rots [b,nrot,9]; cloud i uses seed + i * 0x9e3779b9): out_ids int64 [b,target], out_rounds int32 [b] or NULL. */
+int pps_voxel_sample_batch_f32(const float* pts, int64_t b, int64_t n, int64_t target, const float* rots, int nrot, uint32_t seed,
+                               int64_t* out_ids, int32_t* out_rounds, void* stream);
 
 /* Gather P neighbours per query from the raw cloud, centre at the query, divide by the max neighbour distance.
  * replaces: source/poco_utils.py:67-72 `_get_pts_local_ps` (gather + normalise part) and

@@ -43,9 +43,16 @@ __device__ __forceinline__ float block_min_float(float v, float* red) {
 }
 
 // pts [n,3]; rots [nrot][9] row-major rotation per round (p' = R p); out_ids int64 [target] ascending per round of selection
-__global__ __launch_bounds__(VS_NT) void voxel_sample_kernel(const float* __restrict__ pts, int n, int target, float vox,
-                                                             const float* __restrict__ rots, int nrot, unsigned seed,
-                                                             int64_t* __restrict__ out_ids, int* __restrict__ out_rounds) {
+// One workgroup per cloud: blockIdx.x selects cloud b of a batch of equally sized clouds (pts + b*n*3, rots + b*nrot*9,
+// out_ids + b*target, seed + b).
+__global__ __launch_bounds__(VS_NT) void voxel_sample_kernel(const float* __restrict__ pts_all, int n, int target, float vox,
+                                                             const float* __restrict__ rots_all, int nrot, unsigned seed0,
+                                                             int64_t* __restrict__ out_ids_all, int* __restrict__ out_rounds_all) {
+    const float* __restrict__ pts = pts_all + (size_t)blockIdx.x * n * 3;
+    const float* __restrict__ rots = rots_all + (size_t)blockIdx.x * nrot * 9;
+    int64_t* __restrict__ out_ids = out_ids_all + (size_t)blockIdx.x * target;
+    int* __restrict__ out_rounds = out_rounds_all ? out_rounds_all + blockIdx.x : nullptr;
+    const unsigned seed = seed0 + blockIdx.x * 0x9e3779b9u;
     __shared__ unsigned tkey[VS_TABLE];
     __shared__ unsigned trep[VS_TABLE];
     __shared__ unsigned char state[VS_MAXN];     // bit0 alive, bit1 representative of this round, bit2 selected
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(VS_NT) void voxel_sample_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------------------------
 // batched exhaustive kNN (same selection code as knn_kernel of pps_knn.hip, one wave per 8 queries of some table)
 // ---------------------------------------------------------------------------------------------------------------
-#define KM_MAX_TASKS 16
+#define KM_MAX_TASKS 64
 struct KnnMultiArgs {
     const float* pts[KM_MAX_TASKS];
     const float* query[KM_MAX_TASKS];
@@ -284,6 +291,15 @@ int pps_voxel_sample_f32(const float* pts, int64_t n, int64_t target, float vox,
     if (!pts || !rots || !out_ids || n < 2 || n > VS_MAXN || target < 1 || target >= n || nrot < 1) return PPS_ERR_ARG;
     hipLaunchKernelGGL(voxel_sample_kernel, dim3(1), dim3(VS_NT), 0, (hipStream_t)stream, pts, (int)n, (int)target, vox, rots, nrot, seed,
                        out_ids, out_rounds);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+int pps_voxel_sample_batch_f32(const float* pts, int64_t b, int64_t n, int64_t target, const float* rots, int nrot, uint32_t seed,
+                               int64_t* out_ids, int32_t* out_rounds, void* stream) {
+    if (b == 0) return PPS_OK;
+    if (!pts || !rots || !out_ids || b < 0 || n < 2 || n > VS_MAXN || target < 1 || target >= n || nrot < 1) return PPS_ERR_ARG;
+    hipLaunchKernelGGL(voxel_sample_kernel, dim3((unsigned)b), dim3(VS_NT), 0, (hipStream_t)stream, pts, (int)n, (int)target, -1.f, rots, nrot,
+                       seed, out_ids, out_rounds);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 

@@ -25,12 +25,12 @@ def knn_point_major(pts: torch.Tensor, query: torch.Tensor, k: int, return_d2: b
 
 
 def knn_batch_point_major(pts_list, query_list, k_list):
-    """Up to 16 independent searches (k <= 64 each) per launch through pps_knn_multi_f32: the shapes of a fit batch, or the
+    """Up to 64 independent searches (k <= 64 each) per launch through pps_knn_multi_f32: the shapes of a fit batch, or the
     tables of one encoder pass.  pts_list[i] [n_i,3], query_list[i] [m_i,3] contiguous float32 on the GPU -> list of int64 [m_i,k_i]."""
     import ctypes
     outs = []
-    for s in range(0, len(pts_list), 16):
-        ps, qs, ks = pts_list[s:s + 16], query_list[s:s + 16], k_list[s:s + 16]
+    for s in range(0, len(pts_list), 64):
+        ps, qs, ks = pts_list[s:s + 64], query_list[s:s + 64], k_list[s:s + 64]
         nt = len(ps)
         P, I64, I = ctypes.c_void_p * nt, ctypes.c_int64 * nt, ctypes.c_int * nt
         pts, qry, out, ns, ms, kk = P(), P(), P(), I64(), I64(), I()

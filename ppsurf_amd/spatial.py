@@ -65,9 +65,19 @@ def _one_per_voxel(pos: torch.Tensor, size: float) -> torch.Tensor:
     return order[first]
 
 
-def draw_rotations(n: int = N_ROT) -> torch.Tensor:
-    """n composed random rotations Rz Ry Rx (python `random`, like torch_geometric's RandomRotate) -> float32 [n,3,3] on the CPU."""
-    return torch.stack([_rotation(2) @ _rotation(1) @ _rotation(0) for _ in range(n)])
+def draw_rotations(n: int = N_ROT, batch: int = None) -> torch.Tensor:
+    """n composed random rotations Rz Ry Rx (angles from python `random`, U(-180,180) degrees per axis like torch_geometric's
+    RandomRotate; drawn in the order x, y, z per rotation) -> float32 [n,3,3] ([batch,n,3,3]) on the CPU.  Vectorised."""
+    import numpy as np
+    total = n * (batch or 1)
+    ang = np.array([[random.uniform(-180.0, 180.0) for _ in range(3)] for _ in range(total)]) * (math.pi / 180.0)
+    s, c = np.sin(ang), np.cos(ang)
+    rx, ry, rz = (np.zeros((total, 3, 3)) for _ in range(3))
+    rx[:, 0, 0] = 1; rx[:, 1, 1] = c[:, 0]; rx[:, 1, 2] = s[:, 0]; rx[:, 2, 1] = -s[:, 0]; rx[:, 2, 2] = c[:, 0]
+    ry[:, 1, 1] = 1; ry[:, 0, 0] = c[:, 1]; ry[:, 0, 2] = -s[:, 1]; ry[:, 2, 0] = s[:, 1]; ry[:, 2, 2] = c[:, 1]
+    rz[:, 2, 2] = 1; rz[:, 0, 0] = c[:, 2]; rz[:, 0, 1] = s[:, 2]; rz[:, 1, 0] = -s[:, 2]; rz[:, 1, 1] = c[:, 2]
+    r = torch.from_numpy((rz @ ry @ rx).astype(np.float32))
+    return r.view(batch, n, 3, 3) if batch else r
 
 
 def voxel_sample_point_major(pts_pm: torch.Tensor, target: int, rotations: torch.Tensor = None, seed: int = None) -> torch.Tensor:
@@ -80,6 +90,18 @@ def voxel_sample_point_major(pts_pm: torch.Tensor, target: int, rotations: torch
     _lib.check(_lib.lib().pps_voxel_sample_f32(pts_pm.data_ptr(), n, int(target), ctypes.c_float(-1.0), rot.data_ptr(), rot.shape[0],
                                                ctypes.c_uint32(seed & 0xffffffff), out.data_ptr(), None,
                                                torch.cuda.current_stream(pts_pm.device).cuda_stream), 'pps_voxel_sample_f32')
+    return out
+
+
+def voxel_sample_batch_point_major(pts_bpm: torch.Tensor, target: int) -> torch.Tensor:
+    """A batch of equally sized clouds [b,n,3] on the GPU -> int64 [b,target], one launch (one workgroup per cloud)."""
+    b, n = pts_bpm.shape[0], pts_bpm.shape[1]
+    rot = draw_rotations(batch=b).reshape(b, -1, 9).contiguous().to(pts_bpm.device, non_blocking=True)
+    seed = random.getrandbits(31)
+    out = torch.empty((b, target), dtype=torch.int64, device=pts_bpm.device)
+    _lib.check(_lib.lib().pps_voxel_sample_batch_f32(pts_bpm.data_ptr(), b, n, int(target), rot.data_ptr(), rot.shape[1],
+                                                     ctypes.c_uint32(seed & 0xffffffff), out.data_ptr(), None,
+                                                     torch.cuda.current_stream(pts_bpm.device).cuda_stream), 'pps_voxel_sample_batch_f32')
     return out
 
 
@@ -153,6 +175,23 @@ def _tables_point_major(levels_pm, segmentation=True):
     return outs
 
 
+def _tables_point_major_batch(per_lv, segmentation=True):
+    """_tables_point_major for several clouds: their searches share launches (up to 64 per pps_knn_multi_f32 call)."""
+    names, ps, qs, ks = [], [], [], []
+    for lv in per_lv:
+        for a in range(5):
+            todo = [('ids{}{}'.format(a, a), lv[a], lv[a], 16)]
+            if a < 4:
+                todo.append(('ids{}{}'.format(a, a + 1), lv[a], lv[a + 1], 16))
+                if segmentation:
+                    todo.append(('ids{}{}'.format(a + 1, a), lv[a + 1], lv[a], 1))
+            for name, p, q, k in todo:
+                names.append(name); ps.append(p); qs.append(q); ks.append(min(k, p.shape[0]))
+    outs = ops.knn_batch_point_major(ps, qs, ks)
+    per = len(names) // len(per_lv)
+    return [dict(zip(names[i * per:(i + 1) * per], outs[i * per:(i + 1) * per])) for i in range(len(per_lv))]
+
+
 def get_fkaconv_ids(data, segmentation: bool = True):
     """4 support levels (ratio 0.25) and the 13 kNN tables of poco_data_loader.py:137-209."""
     pts = data['pts'].clone()
@@ -160,15 +199,22 @@ def get_fkaconv_ids(data, segmentation: bool = True):
     if unbatched:
         pts = pts.unsqueeze(0)
     if pts.is_cuda and 4 <= pts.shape[2] <= _lib.lib().pps_voxel_sample_max_points():
-        # fused GPU path: 4 sampling launches + 1 launch for all tables per cloud, everything point-major
-        per_item = []
-        for b in range(pts.shape[0]):
-            lv = [_point_major(pts[b])]
-            for _ in range(4):
-                n = lv[-1].shape[0]
-                target = max(1, int(n * 0.25))
-                lv.append(lv[-1] if target == n else lv[-1][voxel_sample_point_major(lv[-1], target)] if n >= 2 else lv[-1])
-            per_item.append((lv, _tables_point_major(lv, segmentation)))
+        # fused GPU path, everything point-major: 4 sampling launches for the whole batch (one workgroup per cloud and level),
+        # the 13 tables of up to 4 clouds per kNN launch
+        nb = pts.shape[0]
+        levels = [pts.transpose(1, 2).contiguous().float()]                  # [B,n,3]
+        for _ in range(4):
+            cur = levels[-1]
+            n = cur.shape[1]
+            target = max(1, int(n * 0.25))
+            if target == n or n < 2:
+                levels.append(cur)
+            else:
+                ids = voxel_sample_batch_point_major(cur, target)
+                levels.append(torch.gather(cur, 1, ids.unsqueeze(-1).expand(nb, target, 3)).contiguous())
+        per_lv = [[levels[a][b] for a in range(5)] for b in range(nb)]
+        tables = _tables_point_major_batch(per_lv, segmentation)
+        per_item = list(zip(per_lv, tables))
         ret = {}
         for name in per_item[0][1]:
             t = torch.stack([it[1][name] for it in per_item], dim=0)
