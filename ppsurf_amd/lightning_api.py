@@ -185,7 +185,12 @@ class PocoModel(_Base):
 
         With torch.distributed initialised and `shard_queries` set, the encoder passes of each coverage round are dealt
         round-robin to the ranks (the subset selection comes from a generator seeded identically on every rank) and the
-        partial sums / counts are all-reduced once per round."""
+        partial sums / counts are all-reduced once per round.
+
+        Single rank: which points a pass covers depends only on the coverage COUNTS, never on latents, so up to
+        `latent_batch` (default 10) consecutive subsets are drawn exactly like the reference draws them one after the other and
+        then encoded as ONE batch (batched sampling / kNN tables / FKAConv kernels, GEMMs over all subsets at once): a 10k-point
+        pass alone cannot fill 256 CUs."""
         n, dev = pts_cf.shape[1], pts_cf.device
         latent = torch.zeros((n, self.network_latent_size), dtype=torch.float32, device=dev)
         counts = torch.zeros((n,), dtype=torch.float32, device=dev)
@@ -200,6 +205,31 @@ class PocoModel(_Base):
             return torch.randperm(k, device=dev) if gen is None else torch.randperm(k, generator=gen).to(dev)
 
         iteration = 0
+        batch = int(getattr(self, 'latent_batch', 10))
+        if world == 1 and batch > 1 and n >= m:
+            from . import train_graph
+            enc = self.network.encoder
+            assert not enc.training
+            for current_value in range(self.gen_subsample_manifold_iter):
+                while float(counts.min()) < current_value + 1:
+                    covered, subsets = counts.clone(), []
+                    while len(subsets) < batch and (not subsets or float(covered.min()) < current_value + 1):
+                        valid_ids = torch.nonzero(covered == current_value)[:, 0]
+                        ids = valid_ids[randperm(valid_ids.shape[0])[:m]]
+                        if ids.shape[0] < m:
+                            ids = torch.cat([ids, randperm(n)[:m - ids.shape[0]]], dim=0)
+                        covered[ids] += 1
+                        subsets.append(ids)
+                    data_partial = {'pts': torch.stack([pts_cf[:, ids] for ids in subsets])}
+                    data_partial.update(spatial.get_fkaconv_ids(data_partial))
+                    lat_b = train_graph.encoder(enc, data_partial)                      # [B, m, C], eval mode (running statistics)
+                    for i, ids in enumerate(subsets):
+                        latent[ids] += lat_b[i].float()                                # duplicates: last write wins, like the reference
+                        counts[ids] += 1
+                    iteration += len(subsets)
+                    if progress is not None:
+                        progress('get_latent iter: {}'.format(iteration))
+            return latent / counts.unsqueeze(1)
         for current_value in range(self.gen_subsample_manifold_iter):
             while float(counts.min()) < current_value + 1:
                 # one "wave" of passes: with one rank exactly the reference's loop body; with several ranks every rank draws

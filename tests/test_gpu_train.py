@@ -236,3 +236,22 @@ def test_a_few_adamw_steps_reduce_the_loss_bf16():
         opt.step()
         losses.append(float(loss.detach()))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_batched_eval_encoder_equals_the_per_cloud_hip_encoder():
+    """The latent loop encodes several subsets as one batch through the training graph in eval() mode (running statistics,
+    no side effects); it must agree with the per-cloud fused inference encoder on the same id tables."""
+    from ppsurf_amd import modules, spatial, train_graph as tg
+    from ppsurf_amd.synthetic import make_cloud
+    net = _load(modules.PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=50,
+                                      pointnet_latent_size=256), '', key='ppsurf').to(DEV).eval()
+    pts = torch.from_numpy(np.stack([make_cloud(3000, seed=s).T for s in (1, 2, 3)])).to(DEV)
+    data = {'pts': pts}
+    data.update(spatial.get_fkaconv_ids(data))
+    before = {k: v.clone() for k, v in net.encoder.state_dict().items()}
+    with torch.no_grad():
+        got = tg.encoder(net.encoder, data)                                         # [B,N,C]
+        want = net.encoder.forward(dict(data), spectral_only=True).transpose(1, 2)
+    assert all(torch.equal(before[k], v) for k, v in net.encoder.state_dict().items())          # eval: no buffer moved
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-4 * scale, float((got - want).abs().max()) / scale
