@@ -188,6 +188,10 @@ int pps_gather_rows_f32(const float* x, const int64_t* idx, int64_t r, int c, fl
 int pps_segment_sum_rows_f32(const float* vals, const int64_t* order, const int64_t* offsets, int64_t n, int c, float* out,
                              void* stream);
 
+/* the same with bf16 values (c % 4 == 0), fp32 accumulation and output */
+int pps_segment_sum_rows_bf16(const void* vals, const int64_t* order, const int64_t* offsets, int64_t n, int c, float* out,
+                              void* stream);
+
 /* FKAConv feature aggregation, out[m, ch*16+t] = sum_j x[idx[m,j], ch] * g[m,j,t]  (x [n,c], idx int64 [m,k], g [m,k,16],
  * out [m, c*16] in the (channel, kernel-column) order of cv.weight[Cout, Cin, 1, 16]).
  * replaces: source/base/nn.py:598,647-649 (batch_gather of the features + the two transposes around torch.matmul). */

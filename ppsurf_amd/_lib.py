@@ -41,6 +41,7 @@ SIGNATURES = {
     'pps_gather_max_f32': (_I, [_P, _P, _I64, _I, _I, _P, _P]),
     'pps_gather_rows_f32': (_I, [_P, _P, _I64, _I, _P, _P]),
     'pps_segment_sum_rows_f32': (_I, [_P, _P, _P, _I64, _I, _P, _P]),
+    'pps_segment_sum_rows_bf16': (_I, [_P, _P, _P, _I64, _I, _P, _P]),
     'pps_neighbour_contract_fwd_f32': (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
     'pps_neighbour_contract_bwd_f32': (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _P, _P]),
     'pps_gather_max_arg_f32': (_I, [_P, _P, _I64, _I, _I, _P, _P, _P]),

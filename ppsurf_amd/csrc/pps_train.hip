@@ -57,6 +57,24 @@ __global__ void __launch_bounds__(TB) segment_sum_rows_kernel(const V* __restric
     out[t] = acc;
 }
 
+// the same with bf16 values (4 channels = 8 bytes per thread), fp32 accumulation and output
+__global__ void __launch_bounds__(TB) segment_sum_rows_bf16_kernel(const uint2* __restrict__ vals, const int64_t* __restrict__ order,
+                                                                   const int64_t* __restrict__ offsets, int64_t n, int c4,
+                                                                   float4* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (t >= n * c4) return;
+    const int64_t row = t / c4;
+    const int col = (int)(t - row * c4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t e1 = offsets[row + 1];
+    for (int64_t e = offsets[row]; e < e1; ++e) {
+        const uint2 v = vals[order[e] * c4 + col];
+        acc.x += __uint_as_float(v.x << 16); acc.y += __uint_as_float(v.x & 0xffff0000u);
+        acc.z += __uint_as_float(v.y << 16); acc.w += __uint_as_float(v.y & 0xffff0000u);
+    }
+    out[t] = acc;
+}
+
 // FKAConv feature aggregation: out[m, c*16 + t] = sum_j x[idx[m,j], c] * g[m,j,t]
 __global__ void __launch_bounds__(TB) contract_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
                                                           const float* __restrict__ g, int64_t m, int k, int c,
@@ -179,6 +197,16 @@ int pps_segment_sum_rows_f32(const float* vals, const int64_t* order, const int6
     if (c & 3) segment_sum_rows_kernel<float><<<blocks_for(n * c), TB, 0, (hipStream_t)stream>>>(vals, order, offsets, n, c, out);
     else segment_sum_rows_kernel<float4><<<blocks_for(n * (c / 4)), TB, 0, (hipStream_t)stream>>>((const float4*)vals, order, offsets, n,
                                                                                               c / 4, (float4*)out);
+    return launch_status();
+}
+
+int pps_segment_sum_rows_bf16(const void* vals, const int64_t* order, const int64_t* offsets, int64_t n, int c, float* out,
+                              void* stream) {
+    if (n < 0 || c < 4 || (c & 3)) return 1;
+    if (n == 0) return 0;
+    if (!order || !offsets || !out) return 1;
+    segment_sum_rows_bf16_kernel<<<blocks_for(n * (c / 4)), TB, 0, (hipStream_t)stream>>>((const uint2*)vals, order, offsets, n, c / 4,
+                                                                                          (float4*)out);
     return launch_status();
 }
 

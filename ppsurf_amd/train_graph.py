@@ -225,9 +225,12 @@ def interp_attention(proj, latents, pts, query, ids, last_layer=True):
     b, n, c = latents.shape
     q, k = ids.shape[1], ids.shape[2]
     flat = _flat_ids(ids, n)
-    lat = train_ops.gather_rows(latents.reshape(b * n, c), flat)                         # [B*Q*k, C]
+    # fc1 is linear in [latent ; q - p]: its latent part is evaluated once per POINT (B*N rows instead of B*Q*k) and gathered --
+    # the per-point table G of the inference kernels (identity 1); autograd differentiates this form
+    w1 = _w2d(proj.fc1)
+    table = rows_linear(latents.reshape(b * n, c), w1[:, :c], proj.fc1.bias)             # [B*N, C]
     rel = (query.unsqueeze(2) - pts.reshape(b * n, 3)[flat].view(b, q, k, 3)).reshape(-1, 3)     # query minus neighbour
-    h = F.relu(dense(proj.fc1, torch.cat([lat, rel], dim=-1)))
+    h = F.relu(train_ops.gather_rows(table, flat) + F.linear(rel, w1[:, c:]).to(table.dtype))
     h = F.relu(dense(proj.fc2, h))
     h = F.relu(dense(proj.fc3, h))
     att = torch.softmax(dense(proj.fc_query, h).view(b * q, k, -1), dim=1).mean(dim=2)  # softmax over neighbours, mean of heads

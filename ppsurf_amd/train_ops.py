@@ -50,31 +50,41 @@ def clear_cache():
 
 
 class _GatherRows(torch.autograd.Function):
+    """Row gather; a pure copy, so bf16 rows travel as they are (viewed as half as many 4-byte words).  The backward
+    (segmented sum over the rows pointing at each source row) accumulates in fp32."""
+
     @staticmethod
-    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, x, idx):
         _need_cuda(x, idx)
+        if x.dtype not in (torch.float32, torch.bfloat16) or (x.dtype == torch.bfloat16 and x.shape[1] % 2):
+            x = x.float()
         x = x.contiguous()
         idx = idx.contiguous()
-        out = torch.empty((idx.numel(), x.shape[1]), device=x.device, dtype=torch.float32)
-        _lib.check(_lib.lib().pps_gather_rows_f32(x.data_ptr(), idx.data_ptr(), idx.numel(), x.shape[1], out.data_ptr(), _stream()),
+        out = torch.empty((idx.numel(), x.shape[1]), device=x.device, dtype=x.dtype)
+        words = x.shape[1] if x.dtype == torch.float32 else x.shape[1] // 2
+        _lib.check(_lib.lib().pps_gather_rows_f32(x.data_ptr(), idx.data_ptr(), idx.numel(), words, out.data_ptr(), _stream()),
                    'pps_gather_rows_f32')
         ctx.save_for_backward(idx)
         ctx.n = x.shape[0]
+        ctx.dtype = x.dtype
         return out
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, dout):
         idx, = ctx.saved_tensors
         if idx.numel() == 0:
-            return torch.zeros((ctx.n, dout.shape[1]), device=dout.device, dtype=torch.float32), None
+            return torch.zeros((ctx.n, dout.shape[1]), device=dout.device, dtype=ctx.dtype), None
         order, offsets = csr(idx, ctx.n)
-        dout = dout.contiguous().float()
+        dout = dout.contiguous()
         dx = torch.empty((ctx.n, dout.shape[1]), device=dout.device, dtype=torch.float32)
-        _lib.check(_lib.lib().pps_segment_sum_rows_f32(dout.data_ptr(), order.data_ptr(), offsets.data_ptr(), ctx.n, dout.shape[1],
-                                                       dx.data_ptr(), _stream()), 'pps_segment_sum_rows_f32')
-        return dx, None
+        if dout.dtype == torch.bfloat16 and dout.shape[1] % 4 == 0:
+            _lib.check(_lib.lib().pps_segment_sum_rows_bf16(dout.data_ptr(), order.data_ptr(), offsets.data_ptr(), ctx.n, dout.shape[1],
+                                                            dx.data_ptr(), _stream()), 'pps_segment_sum_rows_bf16')
+        else:
+            dout = dout.float()
+            _lib.check(_lib.lib().pps_segment_sum_rows_f32(dout.data_ptr(), order.data_ptr(), offsets.data_ptr(), ctx.n, dout.shape[1],
+                                                           dx.data_ptr(), _stream()), 'pps_segment_sum_rows_f32')
+        return dx.to(ctx.dtype), None
 
 
 class _NeighbourMax(torch.autograd.Function):

@@ -146,6 +146,19 @@ def test_bn_act_fwd_bwd(rows, c, relu, dt):
         assert float((a - b_).abs().max()) <= rel * scale, '{}: err {:.3e} of {:.3e}'.format(name, float((a - b_).abs().max()), scale)
 
 
+def test_gather_rows_bf16_keeps_the_dtype():
+    from ppsurf_amd import train_ops
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.standard_normal((300, 64)).astype(np.float32)).to(DEV).bfloat16().requires_grad_(True)
+    idx = torch.from_numpy(rng.integers(0, 300, 5000).astype(np.int64)).to(DEV)
+    w = torch.from_numpy(rng.standard_normal((5000, 64)).astype(np.float32)).to(DEV).bfloat16()
+    out = train_ops.gather_rows(x, idx)
+    assert out.dtype == torch.bfloat16 and torch.equal(out, x.detach()[idx])
+    (out * w).sum().backward()
+    want = torch.zeros(300, 64, device=DEV, dtype=torch.float64).index_add_(0, idx, w.double())
+    torch.testing.assert_close(x.grad.double(), want, rtol=1e-2, atol=1e-2 * float(want.abs().max()))
+
+
 def test_ops_refuse_cpu_tensors():
     from ppsurf_amd import train_ops
     from ppsurf_amd._lib import PpsError
