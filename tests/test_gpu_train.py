@@ -268,3 +268,52 @@ def test_batched_eval_encoder_equals_the_per_cloud_hip_encoder():
     assert all(torch.equal(before[k], v) for k, v in net.encoder.state_dict().items())          # eval: no buffer moved
     scale = float(want.abs().max())
     assert float((got - want).abs().max()) <= 2e-4 * scale, float((got - want).abs().max()) / scale
+
+
+@pytest.mark.parametrize('n,q,p', [(300, 20, 10), (2500, 33, 50)])
+def test_small_cloud_training_step_hip_ops_vs_torch_twins(n, q, p):
+    """Small clouds clamp K below 16 on the coarse levels (K = 4 and K = 1 at N = 300: InstanceNorm skipped, nn.py:627-638) and
+    give row counts that are no multiple of any tile: the whole step with the HIP ops must match the same graph on torch twins
+    (both fp32: with 1-point levels the train-mode BatchNorm normalises 2 samples, so the step is ill-conditioned and only
+    like-for-like precision is comparable; single tensors such as encoder.cv0.cv.weight -- three identical all-ones input
+    channels -- carry percent-level fp32 noise in EITHER evaluation, see make_golden_train.py)."""
+    from ppsurf_amd import modules, spatial, train_graph as tg
+    from ppsurf_amd.synthetic import make_cloud
+    import random
+    random.seed(n); torch.manual_seed(n)                       # the support sampling draws from both
+    rng = np.random.default_rng(n)
+    clouds = [make_cloud(n, seed=40 + i) for i in range(2)]
+    batch = {'pts_ms': torch.from_numpy(np.stack(clouds)).to(DEV)}
+    qs = np.stack([(c[rng.choice(n, q)] + rng.normal(0, 0.02, (q, 3))).astype(np.float32) for c in clouds])
+    batch['pts_query_ms'] = torch.from_numpy(qs).to(DEV)
+    batch['imp_surf_dist_ms'] = torch.from_numpy((0.4 - np.linalg.norm(qs, axis=2)).astype(np.float32)).to(DEV)
+    batch['pts_local_ps'] = spatial.get_pts_local_ps_batch([batch['pts_ms'][i] for i in range(2)], batch['pts_query_ms'], p)
+    batch = spatial.get_data_poco(batch)
+    assert batch['ids44'].shape[2] == min(16, max(1, int(int(int(int(n * .25) * .25) * .25) * .25)))
+    res = []
+    for use_twins, dt in ((False, torch.float32), (True, torch.float32), (True, torch.float64)):
+        net = _load(modules.PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=p,
+                                          pointnet_latent_size=256), '', key='ppsurf').to(DEV).to(dt)
+        for m in net.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = 0.0
+        data = {k: ((v.to(dt) if v.is_floating_point() else v.clone()) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        ctx = ref.patched() if use_twins else __import__('contextlib').nullcontext()
+        with ctx:
+            logits = tg.ppsurf_forward(net, data, data['proj_ids'])
+            loss = nn.functional.cross_entropy(logits, data['occ'], reduction='none').mean()
+            loss.backward()
+        res.append((logits.detach().double(), {k: v.grad.double() for k, v in net.named_parameters() if v.grad is not None},
+                    {k: v.double() for k, v in net.named_buffers()}))
+    (l1, g1, b1), (l2, g2, b2), (l3, g3, b3) = res               # HIP fp32, twins fp32, twins fp64 (= the truth)
+    # the HIP step must be as close to the float64 truth as the torch-op step of the same precision is (x3), or within 2e-4 / 5e-3
+    assert float((l1 - l3).abs().max()) <= max(3 * float((l2 - l3).abs().max()), 2e-4)
+    assert sorted(g1) == sorted(g3)
+    top = max(float(v.norm()) for v in g3.values())
+    for k in g3:
+        mine, theirs = float((g1[k] - g3[k]).norm()), float((g2[k] - g3[k]).norm())
+        assert mine <= max(5 * theirs, 2e-2 * float(g3[k].norm()) + 1e-5 * top), '{}: {:.3e} (torch fp32 {:.3e}) of {:.3e}'.format(
+            k, mine, theirs, float(g3[k].norm()))
+    for k in b3:
+        mine, theirs = float((b1[k] - b3[k]).abs().max()), float((b2[k] - b3[k]).abs().max())
+        assert mine <= max(3 * theirs, 1e-5 + 1e-4 * float(b3[k].abs().max())), '{}: {:.3e} (torch fp32 {:.3e})'.format(k, mine, theirs)
