@@ -110,8 +110,9 @@ def main():
 
     from ppsurf_amd.decoder import ChunkPipeline
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    # the product's chunk loop (ppsurf_amd.reconstruct.OccupancyField uses the same class): the 64-NN search + patch gather of
-    # chunk i+1 run on a side stream under the MFMA-bound decoder kernels of chunk i.  The 50-NN are a prefix of the 64-NN.
+    # the product's chunk loop (ppsurf_amd.reconstruct.OccupancyField uses the same class): 64-NN search, patch gather (the
+    # 50-NN are a prefix of the 64-NN), decoder kernels, all on one stream; --overlap moves the spatial queries of chunk i+1 to
+    # a side stream (measured: no gain, the decoder kernels own every CU).
     pipe = ChunkPipeline(plan, table, pts, pts, K_PROJ, P_LOCAL, same_cloud=True, max_chunk=Q_CHUNK, overlap=args.overlap)
 
     pipe.run([qd] * args.warmup)
