@@ -203,7 +203,8 @@ __global__ __launch_bounds__(FT_NT) void fka_fwd_kernel(const float* __restrict_
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // the 1140 parameters do not fit the SGPR file; the compiler hoists their scalar loads out of the tile loop and parks them
         // in VGPR lanes (v_readlane per use).  Forcing a reload per tile instead was measured 1.9x SLOWER (exposed s_load latency
-        // at 2 waves/SIMD), so the hoisting is left alone.
+        // at 2 waves/SIMD), and a copy in LDS 2x slower (the ds_reads get hoisted too: 256 VGPRs + 1.5 KB/lane of scratch), so the
+        // hoisting is left alone.
         const float* geo = geo_g;
         const Tile tl = tile_of(tile, M);
         const Geo g = geometry(pts, sup, idx, tl.mg, tl.lim, tl.j, K, geo);
