@@ -230,7 +230,7 @@ def interp_attention(proj, latents, pts, query, ids, last_layer=True):
     w1 = _w2d(proj.fc1)
     table = rows_linear(latents.reshape(b * n, c), w1[:, :c], proj.fc1.bias)             # [B*N, C]
     rel = (query.unsqueeze(2) - pts.reshape(b * n, 3)[flat].view(b, q, k, 3)).reshape(-1, 3)     # query minus neighbour
-    h = F.relu(train_ops.gather_rows(table, flat) + F.linear(rel, w1[:, c:]).to(table.dtype))
+    h = F.relu(train_ops.gather_rows(table, flat) + rows_linear(rel, w1[:, c:]).to(table.dtype))
     h = F.relu(dense(proj.fc2, h))
     h = F.relu(dense(proj.fc3, h))
     att = torch.softmax(dense(proj.fc_query, h).view(b * q, k, -1), dim=1).mean(dim=2)  # softmax over neighbours, mean of heads
