@@ -171,6 +171,42 @@ class TrainDataset(ReconstructionDataset):
         return spatial.get_data_poco(batch)
 
 
+class PocoDataset(TrainDataset):
+    """source/poco_data_loader.py:273-341 by name: fit / validation items without patches."""
+
+    def __init__(self, in_file, padding_factor, seed, use_ddp, manifold_points, patches_per_shape, do_data_augmentation=True):
+        super().__init__(in_file, padding_factor, seed, use_ddp, manifold_points, patches_per_shape, do_data_augmentation, None)
+
+
+class PPSurfDataset(TrainDataset):
+    """source/ppsurf_data_loader.py:48-123 by name, including its static patch helpers (device tensors or numpy arrays)."""
+
+    def __init__(self, in_file, num_pts_local, padding_factor, seed, use_ddp, manifold_points, patches_per_shape, do_data_augmentation=True):
+        super().__init__(in_file, padding_factor, seed, use_ddp, manifold_points, patches_per_shape, do_data_augmentation, num_pts_local)
+
+    @staticmethod
+    def get_patch_radii(pts_patch, query_pts):
+        """:100-110: largest distance of a patch point from its query -> [Q]."""
+        t = torch.as_tensor(pts_patch) - torch.as_tensor(query_pts).unsqueeze(1)
+        r = torch.sqrt((t * t).sum(-1)).max(dim=1)[0]
+        return r if torch.is_tensor(pts_patch) else r.numpy()
+
+    @staticmethod
+    def model_space_to_patch_space(pts_to_convert_ms, pts_patch_center_ms, patch_radius_ms):
+        """:112-123: (p - centre) / radius."""
+        p, c, r = torch.as_tensor(pts_to_convert_ms), torch.as_tensor(pts_patch_center_ms), torch.as_tensor(patch_radius_ms)
+        out = (p - c.unsqueeze(1)) / r.reshape(-1, 1, 1)
+        return out if torch.is_tensor(pts_to_convert_ms) else out.numpy()
+
+    @staticmethod
+    def normalize_patches(pts_local_ms, pts_query_ms):
+        """:91-97.  CUDA tensors go through pps_patch_normalize_f32, anything else through the two helpers above."""
+        if torch.is_tensor(pts_local_ms) and pts_local_ms.is_cuda:
+            return spatial.normalize_patches(pts_local_ms, pts_query_ms)
+        radius = PPSurfDataset.get_patch_radii(pts_local_ms, pts_query_ms)
+        return PPSurfDataset.model_space_to_patch_space(pts_local_ms, pts_query_ms, radius)
+
+
 class DeviceBatchLoader:
     """DataLoader stand-in for fit / validation: shuffling like torch's RandomSampler (non-DDP) or DistributedSampler
     (seed 0 + epoch, padded to a multiple of the world size, rank-strided; occupancy_data_module.py:108-137), batches built by

@@ -133,3 +133,29 @@ def test_ply_reader_writer_roundtrip(tmp_path):
     assert np.array_equal(meshio.read_ply_vertices(p).astype(np.float32), v)
     np.save(str(tmp_path / 'c.npy'), v)
     assert np.array_equal(meshio.load_pts(str(tmp_path / 'c.npy')), v)
+
+
+def test_reference_import_paths_resolve():
+    """Everything SURVEY 8(b) lists as a reference surface is importable under the reference's own module paths."""
+    import importlib
+    for mod, names in (('source.poco_model', ['PocoModel', 'PocoNetwork', 'InterpAttentionKHeadsNet']),
+                       ('source.ppsurf_model', ['PPSurfModel', 'PPSurfNetwork']),
+                       ('source.poco_data_loader', ['PocoDataModule', 'PocoDataset', 'sampling_quantized', 'get_fkaconv_ids', 'get_proj_ids', 'get_data_poco']),
+                       ('source.ppsurf_data_loader', ['PPSurfDataModule', 'PPSurfDataset']),
+                       ('source.poco_utils', ['knn', 'export_mesh_and_refine_vertices_region_growing_v3']),
+                       ('source.occupancy_data_module', ['in_file_is_dataset', 'get_set_files', 'read_shape_list', 'load_pts']),
+                       ('source.base.nn', ['FKAConvLayer', 'ResidualBlock', 'FKAConvNetwork', 'PointNetfeat', 'STN', 'MLP', 'batch_gather', 'max_pool', 'interpolate']),
+                       ('source.base.metrics', ['compare_predictions_binary_tensors']),
+                       ('source.cli', ['PPSProgressBar', 'PPSProfiler'])):
+        m = importlib.import_module(mod)
+        for n in names:
+            assert hasattr(m, n), '{}.{}'.format(mod, n)
+
+
+def test_normalize_patches_static_method_matches_reference_fixture():
+    from source.ppsurf_data_loader import PPSurfDataset
+    g = load_golden('ppsurf_from_latent')
+    local = g['cloud'][g['patch_ids']]
+    got = PPSurfDataset.normalize_patches(pts_local_ms=local, pts_query_ms=g['query'])
+    np.testing.assert_allclose(got, g['patches'], rtol=1e-6, atol=1e-6)
+    assert np.abs(np.linalg.norm(got, axis=2).max(axis=1) - 1.0).max() < 1e-5          # farthest point on the unit sphere
