@@ -163,6 +163,45 @@ class PocoModel(_Base):
             bar.test_progress_bar.set_postfix_str('pc_file: {}'.format(os.path.basename(results['pc_file_in'])), refresh=True)
         return results
 
+    def on_test_epoch_end(self):
+        """poco_model.py:164-181: per-shape table + means of the test metrics.  The reference writes an .xlsx through
+        openpyxl (source/base/evaluation.py, not in the image); the same rows go to metrics_<name>.csv here."""
+        from .data import read_shape_list
+        if not self.test_step_outputs:
+            return
+        results_dir = get_results_dir(out_dir=self.results_dir, name=self.name, in_file=self.in_file)
+        os.makedirs(results_dir, exist_ok=True)
+        names = read_shape_list(self.in_file) if in_file_is_dataset(self.in_file) else [self.in_file]
+        keys = ['accuracy', 'precision', 'recall', 'f1_score', 'abs_dist_rms']
+        rows = []
+        for out in self.test_step_outputs:
+            sid = int(out['shape_id'])
+            rows.append([names[sid] if sid < len(names) else str(sid), float(out['loss'])] + [float(out['metrics_dict'][k]) for k in keys])
+        with open(os.path.join(results_dir, 'metrics_{}.csv'.format(self.name)), 'w') as f:
+            f.write(','.join(['shape', 'loss'] + keys) + '\n')
+            for r in rows:
+                f.write(','.join([r[0]] + ['{:.6g}'.format(v) for v in r[1:]]) + '\n')
+        arr = np.array([r[1:] for r in rows], dtype=np.float64)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', category=RuntimeWarning)             # abs_dist_rms is NaN for every shape
+            mean = np.nanmean(arr, axis=0)
+        print('Test results (mean): Loss={}, RMSE={}, F1={}'.format(mean[0], mean[5], mean[4]))
+        self.test_step_outputs.clear()
+
+    def on_predict_epoch_end(self):
+        """poco_model.py:275-300: after reconstructing a DATASET the reference compares the meshes with ground truth
+        (source/base/evaluation.py: Chamfer distance, IoU, normal error through trimesh/pysdf in worker processes).  That
+        evaluation is outside the occupancy-query path; the guards are kept, the comparison is left to the reference's tools."""
+        if not in_file_is_dataset(self.in_file):
+            return
+        gt_meshes_dir = os.path.join(os.path.dirname(self.in_file), '03_meshes')
+        if not os.path.exists(gt_meshes_dir):
+            print('Warning: {} not found. Skipping evaluation.'.format(gt_meshes_dir))
+            return
+        print('{}: meshes written to {}; quantitative comparison with {} is not part of ppsurf_amd (use the reference\'s '
+              'source/base/evaluation.py on these files)'.format(self.name, get_results_dir(self.results_dir, self.name, self.in_file), gt_meshes_dir))
+
     def do_logging(self, loss_total, loss_components, log_type: str, output_names: list, metrics_dict: dict,
                    keys_to_log=frozenset({'abs_dist_rms', 'accuracy', 'precision', 'recall', 'f1_score'}), f1_in_prog_bar=True,
                    on_step=True, on_epoch=False):

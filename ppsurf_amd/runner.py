@@ -162,10 +162,12 @@ def main(argv=None):
                 if world > 1 and shard == 'shapes' and i % world != rank:
                     continue
                 model.predict_step(batch, i)
+            model.on_predict_epoch_end()
         else:
             for i, batch in enumerate(data.test_dataloader()):
                 out = model.test_step(batch, i)
                 print('{}: loss {:.6f} f1 {:.4f}'.format(os.path.basename(out['pc_file_in']), float(out['loss']), out['metrics_dict']['f1_score']))
+            model.on_test_epoch_end()
     return model
 
 

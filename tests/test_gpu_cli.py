@@ -52,9 +52,12 @@ def test_predict_and_test_subcommands(tmp_path, capsys):
     mesh_dir = tmp_path / 'res' / 'ppsurf_mini' / 'ds' / 'meshes'
     n_mesh = len(list(mesh_dir.glob('*.ply'))) if mesh_dir.exists() else 0
     assert n_mesh + out.count('No reconstruction for') == 2
-    runner.main(['pps.py', 'test'] + _configs(tmp_path, in_file) + ['--ckpt_path', ckpt])
+    runner.main(['pps.py', 'test'] + _configs(tmp_path, in_file) + ['--ckpt_path', ckpt, '--model.init_args.results_dir', str(tmp_path / 'res')])
     out = capsys.readouterr().out
-    assert out.count('loss') == 2 and 'nan' not in out.split('loss')[1][:12]
+    assert out.count('loss ') == 2 and 'nan' not in out.split('loss ')[1][:12]
+    assert 'Test results (mean): Loss=' in out                           # on_test_epoch_end (poco_model.py:164-181)
+    rows = open(tmp_path / 'res' / 'ppsurf_mini' / 'ds' / 'metrics_ppsurf_mini.csv').read().strip().split('\n')
+    assert rows[0].startswith('shape,loss,accuracy') and len(rows) == 3
 
 
 def test_rec_rewrite_and_cpu_is_refused(tmp_path):
