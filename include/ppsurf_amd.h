@@ -140,6 +140,17 @@ int pps_pointnet_feat_rows_f32(const float* patches, const float* trans2, int64_
 int pps_decode_tail_f32(const float* pooled, const float* xbar, int64_t q, const float* wpack, const float* bias,
                         float* logits, float* occ, void* stream);
 
+/* The decoder of one query chunk in ONE call (= the five launches above, in order, on `stream`).
+ * replaces: source/ppsurf_model.py:82-117 `PPSurfNetwork.from_latent` (+ the occupancy of source/poco_utils.py:78-81) given the
+ * per-point table G (pps_rows_dense256_f32) and the neighbour table.
+ * table [n,256]; pts [n,3]; query [q,3]; idx int64 [q,k]; patches [q,p,3];
+ * weights [host] array of 10 device pointers: interp (wpack, bias), stn_rows (wpack, bias), stn_fc (wpack, bias),
+ * feat_rows (wpack, bias), tail (wpack, bias) -- layouts as documented at the single entry points;
+ * logits out [q,2]; occ out [q] or NULL; ws: pps_decode_ws_bytes(q) bytes of device scratch. */
+size_t pps_decode_ws_bytes(int64_t q);
+int pps_decode_fwd_f32(const float* table, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
+                       const float* patches, int p, const float* const* weights, float* logits, float* occ, void* ws, void* stream);
+
 /* ---- FKAConv encoder (eval mode), point-major activations, one batch item per call ----------------- */
 
 /* number of floats of the packed small parameters of one FKAConv layer:

@@ -915,4 +915,26 @@ int pps_decode_tail_f32(const float* pooled, const float* xbar, int64_t q, const
     return PPS_LAUNCH_CHECK();
 }
 
+/* The whole decoder of one query chunk in one call: the five launches above on `stream`, intermediates in caller scratch. */
+size_t pps_decode_ws_bytes(int64_t q) { return q < 0 ? 0 : (size_t)q * (256 + 256 + 4096 + 256) * sizeof(float); }
+
+int pps_decode_fwd_f32(const float* table, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
+                       const float* patches, int p, const float* const* weights, float* logits, float* occ, void* ws, void* stream) {
+    if (q < 0) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    if (!weights || !ws || !logits) return PPS_ERR_ARG;
+    for (int i = 0; i < 10; ++i)
+        if (!weights[i]) return PPS_ERR_ARG;
+    float* pooled = (float*)ws;
+    float* g = pooled + q * 256;
+    float* trans2 = g + q * 256;
+    float* xbar = trans2 + q * 4096;
+    int rc = pps_interp_pool_f32(table, pts, query, idx, q, k, weights[0], weights[1], pooled, stream);
+    if (rc == PPS_OK) rc = pps_pointnet_stn_rows_f32(patches, q, p, weights[2], weights[3], g, stream);
+    if (rc == PPS_OK) rc = pps_pointnet_stn_fc_f32(g, q, weights[4], weights[5], trans2, stream);
+    if (rc == PPS_OK) rc = pps_pointnet_feat_rows_f32(patches, trans2, q, p, weights[6], weights[7], xbar, stream);
+    if (rc == PPS_OK) rc = pps_decode_tail_f32(pooled, xbar, q, weights[8], weights[9], logits, occ, stream);
+    return rc;
+}
+
 }  // extern "C"

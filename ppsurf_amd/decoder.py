@@ -137,6 +137,17 @@ class DecoderPlan:
             self._scratch[name] = t
         return t[:n].view(shape)
 
+    def intermediates(self, q):
+        """Views of the last decode() call's scratch (layout of pps_decode_fwd_f32): pooled [q,256], g [q,256],
+        trans2 [q,4096], xbar [q,256] -- for tests and debugging."""
+        ws = self.scratch('decode_ws', (_lib.lib().pps_decode_ws_bytes(q) // 4,))
+        sizes = (('pooled', C), ('g', C), ('trans2', 4096), ('xbar', C))
+        out, off = {}, 0
+        for name, width in sizes:
+            out[name] = ws[off:off + q * width].view(q, width)
+            off += q * width
+        return out
+
     # ---- kernels ---------------------------------------------------------------------------------------------
     def point_table(self, latents_cn):
         """G [N,256] = fc1_latent(latents) + b1.  `latents_cn` has SHAPE [C,N] like the reference's data['latents'][b]
@@ -160,6 +171,18 @@ class DecoderPlan:
         for t in (table, pts, query, idx, patches):
             assert t.is_contiguous() and t.device == self.device
         st = torch.cuda.current_stream(self.device).cuda_stream
+        if interp_events is None:                                   # product path: the whole chunk in one C call
+            import ctypes
+            logits = torch.empty((q, 2), dtype=torch.float32, device=self.device)
+            occ = torch.empty((q,), dtype=torch.float32, device=self.device) if want_occ else None
+            ws = self.scratch('decode_ws', (L.pps_decode_ws_bytes(q) // 4,))
+            if getattr(self, '_wptrs', None) is None:
+                self._wptrs = (ctypes.c_void_p * 10)(*[self.w[n].data_ptr() for n in ('ip_w', 'ip_b', 'pa_w', 'pa_b', 'pb_w', 'pb_b', 'pc_w',
+                                                                                      'pc_b', 'tl_w', 'tl_b')])
+            _lib.check(L.pps_decode_fwd_f32(table.data_ptr(), pts.data_ptr(), query.data_ptr(), idx.data_ptr(), q, k, patches.data_ptr(), p,
+                                            self._wptrs, logits.data_ptr(), occ.data_ptr() if want_occ else None, ws.data_ptr(), st),
+                       'pps_decode_fwd_f32')
+            return logits, occ
         pooled = self.scratch('pooled', (q, C))
         g = self.scratch('g', (q, C))
         trans2 = self.scratch('trans2', (q, 4096))

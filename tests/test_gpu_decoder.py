@@ -54,7 +54,7 @@ def test_decoder_stages_vs_emulation():
     table = pl.point_table(dev(lat))
     logits, occ = pl.decode(table, dev(cloud), dev(qry), dev(ids), dev(patches))
     torch.cuda.synchronize()
-    np.testing.assert_allclose(pl.scratch('trans2', (203, 4096)).cpu().numpy().reshape(-1, 64, 64), ref_trans2, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(pl.intermediates(203)['trans2'].cpu().numpy().reshape(-1, 64, 64), ref_trans2, rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(logits.cpu().numpy(), ref_logits, rtol=1e-4, atol=1e-4)
     ref_occ = np.tanh((ref_logits[:, 0] - ref_logits[:, 1]) / 2)
     np.testing.assert_allclose(occ.cpu().numpy(), ref_occ, rtol=1e-4, atol=1e-4)
