@@ -65,6 +65,8 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
     val_every = int(tcfg.get('check_val_every_n_epoch', 1))
     ctx, use_scaler = autocast_context(tcfg.get('precision', '16-mixed'), torch.device(device).type)
     params = [p for p in model.parameters() if p.requires_grad]
+    if not cfg.get('optimizer'):
+        raise ValueError('fit needs an `optimizer:` section (class_path / init_args), as in configs/poco.yaml:60-69')
     optimizer = _instantiate(cfg['optimizer'], params)
     scheduler = _instantiate(cfg['lr_scheduler'], optimizer) if cfg.get('lr_scheduler') else None
     scaler = torch.amp.GradScaler(torch.device(device).type, enabled=use_scaler)
@@ -118,8 +120,9 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
                 break
         if scheduler is not None:
             scheduler.step()
+        last = history[-1] if history else {}
         msg = 'epoch {} ({} steps, {:.1f} s): train loss {:.4f}'.format(epoch, global_step, time.time() - t0,
-                                                                      history[-1].get('loss/train/00_all', float('nan')))
+                                                                      last.get('loss/train/00_all', float('nan')))
         if val_every > 0 and (epoch + 1) % val_every == 0 and len(val_loader.dataset) > 0:
             model.eval()
             metrics.values = {}
