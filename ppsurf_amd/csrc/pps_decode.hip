@@ -22,6 +22,9 @@ using namespace pps;
 #ifndef WG_PER_CU
 #define WG_PER_CU (512 / NT)
 #endif
+#ifndef PPS_PRIO
+#define PPS_PRIO 1
+#endif
 #define CH4 2048               // f32x4 per 32 KiB weight chunk
 
 // One pipeline step: request the NEXT chunk, compute on the CURRENT one, publish the next, barrier.
@@ -180,6 +183,9 @@ __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restr
             xyz_blocks<16>(coord, a, xyz_l, lane);
             relu_blocks<16>(a);
         }
+        // two waves share a SIMD: the one in its MFMA phase gets the issue slots first, so the matrix pipe is not left idle
+        // behind the other wave's gather / softmax VALU work (+1.8 % measured)
+        __builtin_amdgcn_s_setprio(PPS_PRIO);
 #pragma unroll
         for (int c = 0; c < 8; ++c)
             stream_step<CH4>(wg + (c + 1) * CH4, cur, nxt,
@@ -193,6 +199,7 @@ __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restr
             stream_step<CH4>(wg + ((c + 17) % 18) * CH4, cur, nxt,
                            [&](const f32x4* w) { dense_blocks<16, 2, 0>(a, &b[2 * c], w, bias4 + 128 + 8 * c, lane); });
 
+        __builtin_amdgcn_s_setprio(0);
 #ifdef PPS_ABL_NOSOFTMAX
         if (qv && wq == 0 && lane < 64) { f32x4 s4 = a[0] + b[0]; for (int bb = 1; bb < 16; ++bb) s4 += a[bb]; ((f32x4*)(pooled + qi * 256))[lane] = s4; }
         continue;
