@@ -5,7 +5,8 @@
   * trainer.precision: '16-mixed' (fp16 autocast + loss scaling, the reference default), 'bf16-mixed', or '32';
   * every step: device-side batch assembly (data.DeviceBatchLoader) -> model.training_step -> backward -> bucketed gradient
     all-reduce over RCCL overlapped with the backward pass (sharding.GradBuckets) -> optimizer step;
-  * BatchNorm / norm_radius buffers follow DDP semantics: broadcast from rank 0 at start (and stay rank-local afterwards);
+  * BatchNorm / norm_radius buffers follow DDP semantics (`broadcast_buffers=True`): rank 0's values are broadcast, coalesced
+    into one message, at the start of every step; between two steps they are rank-local;
   * validation every `check_val_every_n_epoch` epochs in eval() mode -- that is the fused HIP inference path;
   * ModelCheckpoint(save_last) -> models/<name>/version_0/checkpoints/last.ckpt with Lightning's key layout
     ({'state_dict': {'network.<...>': tensor}, 'epoch', 'global_step', 'optimizer_states', 'lr_schedulers'}), so checkpoints
@@ -102,6 +103,7 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
         for bi, batch in enumerate(train_loader):
             buckets.zero()
             metrics.values = {}
+            sharding.broadcast_buffers(model)
             with ctx:
                 loss = model.training_step(batch, bi)
             scaler.scale(loss).backward()

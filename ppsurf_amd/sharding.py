@@ -79,6 +79,23 @@ def allreduce_latents(latent_sum: torch.Tensor, counts: torch.Tensor):
     return latent_sum, counts
 
 
+def broadcast_buffers(module, src: int = 0):
+    """torch DDP's `broadcast_buffers=True` (the Lightning default): at the start of every step the floating-point buffers
+    (BatchNorm running statistics, FKAConv norm_radius -- the latter is read by the train-mode forward) are overwritten with
+    rank `src`'s values, coalesced into ONE broadcast."""
+    import torch.distributed as dist
+    _, ws = world()
+    bufs = [b for b in module.buffers() if b.is_floating_point()]
+    if ws == 1 or not bufs:
+        return
+    flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+    dist.broadcast(flat, src=src)
+    off = 0
+    for b in bufs:
+        b.data.copy_(flat[off:off + b.numel()].view_as(b))
+        off += b.numel()
+
+
 class GradBuckets:
     """Data-parallel gradient averaging for fit (one process per GPU, shapes sharded over the ranks).
 

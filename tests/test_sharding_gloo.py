@@ -68,6 +68,11 @@ def _grad_worker(rank, world, port, out_dir):
     net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 2))
     unused = torch.nn.Linear(3, 3)                                   # never part of the graph (POCO's cv5/bn5)
     params = list(net.parameters()) + list(unused.parameters())
+    from ppsurf_amd.sharding import broadcast_buffers
+    bn = torch.nn.BatchNorm1d(4)
+    bn.running_mean.fill_(float(rank + 1)); bn.num_batches_tracked.fill_(rank + 5)
+    broadcast_buffers(bn)
+    assert float(bn.running_mean[0]) == 1.0 and int(bn.num_batches_tracked) == rank + 5      # float buffers from rank 0, ints untouched
     buckets = GradBuckets(params, n_buckets=3)
     x = torch.from_numpy(np.random.default_rng(5).standard_normal((8, 6)).astype(np.float32))
     y = torch.from_numpy(np.random.default_rng(6).integers(0, 2, 8))
