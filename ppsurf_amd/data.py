@@ -238,9 +238,18 @@ class DeviceBatchLoader:
         return -(-n // self.batch_size)
 
     def __iter__(self):
+        """Host side of batch i+1 (file reads, sub-sampling, augmentation -- one background thread, items in order, so the
+        dataset's random stream is consumed exactly as in a sequential loop) overlaps the device work of batch i."""
+        import concurrent.futures
         idx = self._indices()
-        for s in range(0, len(idx), self.batch_size):
-            yield self.dataset.collate_on_device([self.dataset[i] for i in idx[s:s + self.batch_size]], self.device)
+        starts = list(range(0, len(idx), self.batch_size))
+        load = lambda s: [self.dataset[i] for i in idx[s:s + self.batch_size]]
+        with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:
+            nxt = pool.submit(load, starts[0]) if starts else None
+            for k, s in enumerate(starts):
+                items = nxt.result()
+                nxt = pool.submit(load, starts[k + 1]) if k + 1 < len(starts) else None
+                yield self.dataset.collate_on_device(items, self.device)
 
 
 def _collate1(item):
