@@ -35,7 +35,10 @@ class _MetricLog:
         self.values = {}
 
     def __call__(self, name, value, **_kw):
-        self.values[name] = float(value.detach()) if torch.is_tensor(value) else float(value)
+        self.values[name] = value.detach() if torch.is_tensor(value) else float(value)      # tensors are read at the end of the step
+
+    def read(self):
+        return {k: (float(v) if torch.is_tensor(v) else v) for k, v in self.values.items()}
 
 
 def autocast_context(precision, device_type='cuda'):
@@ -96,6 +99,17 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
         mfile = open(os.path.join(out_dir, 'metrics.jsonl'), 'a')
     history = []
     done = False
+    pending = None
+
+    def flush(item):
+        if item is None:
+            return
+        values, extra = item
+        rec = dict({k: (float(v) if torch.is_tensor(v) else v) for k, v in values.items()}, **extra)
+        history.append(rec)
+        if mfile is not None:
+            mfile.write(json.dumps(rec) + '\n')
+
     for epoch in range(start_epoch, max_epochs):
         model.train()
         train_loader.set_epoch(epoch)
@@ -113,17 +127,19 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
             scaler.update()
             train_graph.release_step_caches()
             global_step += 1
-            rec = dict(metrics.values, epoch=epoch, step=global_step, lr=optimizer.param_groups[0]['lr'])
-            history.append(rec)
-            if mfile is not None:
-                mfile.write(json.dumps(rec) + '\n')
+            # the step's logged values are still device tensors: they are read one step LATER (when they are long finished), so
+            # the host never waits for the GPU inside the loop and keeps queueing the next step's launches
+            flush(pending)
+            pending = (metrics.values, dict(epoch=epoch, step=global_step, lr=optimizer.param_groups[0]['lr']))
             if 0 < max_steps <= global_step:
                 done = True
                 break
+        flush(pending)
+        pending = None
         if scheduler is not None:
             scheduler.step()
         last = history[-1] if history else {}
-        msg = 'epoch {} ({} steps, {:.1f} s): train loss {:.4f}'.format(epoch, global_step, time.time() - t0,
+        msg = 'epoch {} ({} steps, {:.2f} s): train loss {:.4f}'.format(epoch, global_step, time.time() - t0,
                                                                       last.get('loss/train/00_all', float('nan')))
         if val_every > 0 and (epoch + 1) % val_every == 0 and len(val_loader.dataset) > 0:
             model.eval()
@@ -137,7 +153,7 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
                 vloss = sharding.mean_over_ranks(vloss, device)
             msg += ', val loss {:.4f}'.format(vloss)
             if mfile is not None:
-                mfile.write(json.dumps({'epoch': epoch, 'loss/val/00_all': vloss, 'metrics/val/F1': metrics.values.get('metrics/val/F1')}) + '\n')
+                mfile.write(json.dumps({'epoch': epoch, 'loss/val/00_all': vloss, 'metrics/val/F1': metrics.read().get('metrics/val/F1')}) + '\n')
         if rank == 0:
             save_checkpoint(ckpt_file, model, optimizer, scheduler, epoch, global_step)
             mfile.flush()

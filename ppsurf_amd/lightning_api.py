@@ -56,6 +56,20 @@ def compare_predictions_binary_tensors(ground_truth, predicted, prediction_name)
     return res
 
 
+def binary_metrics_on_device(ground_truth, predicted):
+    """accuracy / precision / recall / F1 of compare_predictions_binary_tensors as 0-dim DEVICE tensors (NaN where the
+    reference returns NaN): no host synchronisation, for per-step logging inside the fit loop."""
+    gt, pr = ground_truth > 0.0, predicted > 0.0
+    n = float(gt.numel())
+    tp, fp, fn = (pr & gt).sum().float(), (pr & ~gt).sum().float(), (~pr & gt).sum().float()
+    nan = torch.full_like(tp, float('nan'))
+    precision = torch.where(tp + fp == 0, nan, tp / (tp + fp))
+    recall = torch.where(tp + fn == 0, nan, tp / (tp + fn))
+    f1 = torch.where(torch.isnan(precision) | torch.isnan(recall) | (precision + recall == 0), nan, 2.0 * precision * recall / (precision + recall))
+    accuracy = (n - fp - fn) / n if n > 0 else nan
+    return {'accuracy': accuracy, 'precision': precision, 'recall': recall, 'f1_score': f1, 'abs_dist_rms': float('nan')}
+
+
 def in_file_is_dataset(in_file: str):
     return os.path.splitext(in_file)[1].lower() == '.txt'
 
@@ -132,7 +146,13 @@ class PocoModel(_Base):
 
     def default_step_dict(self, batch):
         pred = self.network.forward(batch)
-        loss, mean, comps, metrics = self.get_loss_and_metrics(pred, batch)
+        if self.__dict__.get('_fit_log') is not None and self.training:
+            # inside ppsurf_amd.fit: keep the step free of host synchronisation (the reference's metric code calls .item()
+            # several times between forward and backward); the values are read once, after the optimizer step is queued
+            loss, mean, comps = self.compute_loss(pred=pred, batch_data=batch)
+            metrics = binary_metrics_on_device(batch['occ'].squeeze(), torch.argmax(pred, dim=1).to(torch.float32).squeeze())
+        else:
+            loss, mean, comps, metrics = self.get_loss_and_metrics(pred, batch)
         if self.lambda_l1 != 0.0:
             raise NotImplementedError('lambda_l1 != 0 calls a regulariser that does not exist in the reference (poco_model.py:112-113)')
         return loss, mean, comps, metrics
@@ -210,7 +230,9 @@ class PocoModel(_Base):
             for li, l in enumerate(loss_components):
                 self._log('loss/{}/{}_{}'.format(log_type, li, output_names[li]), l, on_step=on_step, on_epoch=on_epoch)
         for key, value in metrics_dict.items():
-            if key in keys_to_log and isinstance(value, numbers.Number):
+            if key in keys_to_log and torch.is_tensor(value):
+                self._log('metrics/{}/{}'.format(log_type, key), torch.nan_to_num(value, nan=0.0), on_step=on_step, on_epoch=on_epoch)
+            elif key in keys_to_log and isinstance(value, numbers.Number):
                 self._log('metrics/{}/{}'.format(log_type, key), 0.0 if math.isnan(value) else value, on_step=on_step, on_epoch=on_epoch)
         self._log('metrics/{}/{}'.format(log_type, 'F1'), metrics_dict['f1_score'], on_step=on_step, on_epoch=on_epoch, logger=False,
                   prog_bar=f1_in_prog_bar)
