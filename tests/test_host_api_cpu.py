@@ -159,3 +159,18 @@ def test_normalize_patches_static_method_matches_reference_fixture():
     got = PPSurfDataset.normalize_patches(pts_local_ms=local, pts_query_ms=g['query'])
     np.testing.assert_allclose(got, g['patches'], rtol=1e-6, atol=1e-6)
     assert np.abs(np.linalg.norm(got, axis=2).max(axis=1) - 1.0).max() < 1e-5          # farthest point on the unit sphere
+
+
+def test_device_metrics_equal_the_reference_metrics():
+    """The sync-free per-step metrics of the fit loop are the same numbers (NaN where the reference returns NaN)."""
+    from ppsurf_amd.lightning_api import binary_metrics_on_device, compare_predictions_binary_tensors
+    rng = np.random.default_rng(3)
+    cases = [(rng.integers(0, 2, 500), rng.integers(0, 2, 500)), (np.zeros(40), np.zeros(40)), (np.ones(40), np.zeros(40)),
+             (np.zeros(40), np.ones(40)), (np.ones(7), np.ones(7))]
+    for gt, pr in cases:
+        gt, pr = torch.from_numpy(gt.astype(np.int64)), torch.from_numpy(pr.astype(np.float32))
+        want = compare_predictions_binary_tensors(gt, pr, None)
+        got = binary_metrics_on_device(gt, pr)
+        for k in ('accuracy', 'precision', 'recall', 'f1_score'):
+            a, b = float(got[k]), float(want[k])
+            assert (np.isnan(a) and np.isnan(b)) or abs(a - b) < 1e-6, (k, a, b)
