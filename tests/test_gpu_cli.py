@@ -143,3 +143,36 @@ def test_fit_resumes_from_a_checkpoint(tmp_path, monkeypatch):
     runner.main(_fit_args(tmp_path, in_file, ['--trainer.max_epochs', '3', '--trainer.precision', '32', '--ckpt_path', str(ckpt)]))
     state = torch.load(ckpt, map_location='cpu')
     assert state['epoch'] == 2 and state['global_step'] == 3
+
+
+def test_fit_batch_dictionary_layout(tmp_path):
+    """Keys / shapes / dtypes of a fit batch as the reference's dataset + default_collate produce them (SURVEY 8a a2, a11, a17;
+    source/poco_data_loader.py:243-270,327-341; source/ppsurf_data_loader.py:61-81): B shapes, 1000-point sub-samples, P = 50."""
+    from ppsurf_amd.data import PPSurfDataModule
+    from ppsurf_amd.synthetic import write_dataset
+    in_file = write_dataset(str(tmp_path / 'ds'), n_shapes=3, n_pts=2200, n_query=120)
+    dm = PPSurfDataModule(num_pts_local=50, in_file=in_file, workers=0, use_ddp=False, padding_factor=0.05, seed=42, manifold_points=1000,
+                          patches_per_shape=-1, do_data_augmentation=True, batch_size=3)
+    dm.device = torch.device('cuda', 0)
+    batch = next(iter(dm.train_dataloader()))
+    b, n, q = 3, 1000, 120
+    want = {'pts_ms': ((b, n, 3), torch.float32), 'normals_ms': ((b, n, 3), torch.float32), 'pts_query_ms': ((b, q, 3), torch.float32),
+            'imp_surf_dist_ms': ((b, q), torch.float32), 'pts_local_ps': ((b, q, 50, 3), torch.float32), 'shape_id': ((b,), torch.int64),
+            'pts': ((b, 3, n), torch.float32), 'pts_query': ((b, 3, q), torch.float32), 'occ': ((b, q), torch.int64),
+            'proj_ids': ((b, q, 64), torch.int64)}
+    sizes = [n, 250, 62, 15, 3]
+    for a in range(5):
+        want['ids{}{}'.format(a, a)] = ((b, sizes[a], min(16, sizes[a])), torch.int64)
+        if a < 4:
+            want['support{}'.format(a + 1)] = ((b, 3, sizes[a + 1]), torch.float32)
+            want['ids{}{}'.format(a, a + 1)] = ((b, sizes[a + 1], min(16, sizes[a])), torch.int64)
+            want['ids{}{}'.format(a + 1, a)] = ((b, sizes[a], 1), torch.int64)
+    for k, (shape, dt) in want.items():
+        assert k in batch, k
+        assert tuple(batch[k].shape) == shape and batch[k].dtype == dt, (k, tuple(batch[k].shape), batch[k].dtype)
+    assert isinstance(batch['pc_file_in'], list) and len(batch['pc_file_in']) == b
+    assert set(batch['occ'].unique().tolist()) <= {0, 1}
+    r = torch.linalg.norm(batch['pts_local_ps'], dim=-1).max(dim=-1)[0]
+    assert float((r - 1).abs().max()) < 1e-4                                   # patches are normalised to the unit ball
+    # augmentation rotates cloud and queries together (poco_data_loader.py:317-325): the patch search used the UNROTATED raw cloud
+    assert float(torch.linalg.norm(batch['pts_ms'], dim=-1).max()) < 0.9
