@@ -174,3 +174,22 @@ def test_device_metrics_equal_the_reference_metrics():
         for k in ('accuracy', 'precision', 'recall', 'f1_score'):
             a, b = float(got[k]), float(want[k])
             assert (np.isnan(a) and np.isnan(b)) or abs(a - b) < 1e-6, (k, a, b)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/datasets/abc_minimal'), reason='reference dataset only exists in the build container')
+def test_readers_on_the_reference_dataset_files():
+    """The reference's own abc_minimal files (trimesh-written binary PLY with a comment line, float32 .npy queries / distances,
+    set lists) through this package's readers and the reconstruction dataset (source/occupancy_data_module.py:34-71,174-253)."""
+    from ppsurf_amd import data
+    in_file = '/root/reference/datasets/abc_minimal/testset.txt'
+    names = data.read_shape_list(in_file)
+    train, val, test = data.get_set_files(in_file)
+    assert len(names) == 3 and len(data.read_shape_list(train)) == 7 and len(data.read_shape_list(val)) == 3 and test == in_file
+    ds = data.ReconstructionDataset(in_file, 0.05)
+    for i in range(len(ds)):
+        it = ds[i]
+        n = it['pts_ms'].shape[0]
+        assert n > 10000 and it['pts_ms'].dtype == torch.float32 and tuple(it['pts_ms'].shape) == (n, 3)
+        assert float(it['pts_ms'].abs().max()) < 0.75                      # dataset clouds are already normalised
+        assert tuple(it['pts_query_ms'].shape) == (2000, 3) and tuple(it['imp_surf_dist_ms'].shape) == (2000,)
+        assert it['pc_file_in'].endswith(names[i] + '.xyz.ply')
