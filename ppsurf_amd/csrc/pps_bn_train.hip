@@ -14,7 +14,7 @@
 
 namespace {
 
-constexpr int NT = 256;
+constexpr int BNT = 256;
 constexpr int MAXBLK = 1024;
 
 struct F4 { float v[4]; };
@@ -46,7 +46,7 @@ struct Map {
 __device__ __forceinline__ Map map_of(int C) {
     Map m;
     m.tpr = C >> 2;
-    m.rpb = NT / m.tpr;
+    m.rpb = BNT / m.tpr;
     m.cg = threadIdx.x % m.tpr;
     m.rl = threadIdx.x / m.tpr;
     return m;
@@ -55,7 +55,7 @@ __device__ __forceinline__ Map map_of(int C) {
 // per-block partial sums over a slab of rows: part[blk][C][2] doubles
 //   MODE 0: (x - pivot), (x - pivot)^2            MODE 1: dyh, dyh * xhat   with dyh = dy * [act mask]
 template <typename T, int MODE>
-__global__ __launch_bounds__(NT) void bn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t rows, int C,
+__global__ __launch_bounds__(BNT) void bn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t rows, int C,
                                                        const float* __restrict__ save /* mean[C], rstd[C] (MODE 1) */,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
                                                        double* __restrict__ part) {
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(NT) void bn_reduce_kernel(const T* __restrict__ x, 
         }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 2 * C; e += NT) {
+    for (int e = threadIdx.x; e < 2 * C; e += BNT) {
         double s = 0.0;
         for (int r = 0; r < m.rpb; ++r) s += red[(int64_t)r * 2 * C + e];
         part[(int64_t)blockIdx.x * 2 * C + e] = s;
@@ -111,11 +111,11 @@ __global__ __launch_bounds__(NT) void bn_reduce_kernel(const T* __restrict__ x, 
 // MODE 0: mean / rstd + running statistics;  MODE 1: dgamma = S2, dbeta = S1, and the means S1/n, S2/n for the elementwise pass.
 // One wave per channel: lanes stride over the block partials, fixed butterfly at the end (deterministic).
 template <typename T, int MODE>
-__global__ __launch_bounds__(NT) void bn_finalize_kernel(const double* __restrict__ part, int nblk, int64_t rows, int C, const T* __restrict__ x,
+__global__ __launch_bounds__(BNT) void bn_finalize_kernel(const double* __restrict__ part, int nblk, int64_t rows, int C, const T* __restrict__ x,
                                                          float eps, float momentum, float* __restrict__ running_mean,
                                                          float* __restrict__ running_var, float* __restrict__ out /* [2][C] */,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * (NT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (BNT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
     for (int b = lane; b < nblk; b += 64) { s1 += part[((int64_t)b * C + c) * 2]; s2 += part[((int64_t)b * C + c) * 2 + 1]; }
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(NT) void bn_finalize_kernel(const double* __restric
 // MODE 0: y = act((x - mean) * rstd * gamma + beta);  MODE 1: dx = gamma * rstd * (dyh - m1 - xhat * m2)
 // Same thread -> (channel group, row lane) map as the reductions: the per-channel coefficients live in registers.
 template <typename T, int MODE>
-__global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t rows, int C,
+__global__ __launch_bounds__(BNT) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t rows, int C,
                                                       const float* __restrict__ save, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, const float* __restrict__ gmeans, int relu,
                                                       T* __restrict__ out) {
@@ -183,17 +183,17 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, c
 }
 
 inline int reduce_blocks(int64_t rows, int C) {
-    const int rpb = NT / (C >> 2);
+    const int rpb = BNT / (C >> 2);
     int64_t nb = (rows + (int64_t)rpb * 8 - 1) / ((int64_t)rpb * 8);          // >= 8 iterations per thread
     if (nb < 1) nb = 1;
     return (int)(nb > MAXBLK ? MAXBLK : nb);
 }
 inline int apply_blocks(int64_t rows, int C) {
-    const int rpb = NT / (C >> 2);
+    const int rpb = BNT / (C >> 2);
     const int64_t nb = (rows + (int64_t)rpb * 4 - 1) / ((int64_t)rpb * 4);          // ~4 rows per thread
     return (int)(nb < 1 ? 1 : nb > 8192 ? 8192 : nb);
 }
-inline bool ok_shape(int64_t rows, int c) { return rows >= 1 && c >= 4 && c <= 1024 && (c & 3) == 0 && (NT % (c >> 2)) == 0; }
+inline bool ok_shape(int64_t rows, int c) { return rows >= 1 && c >= 4 && c <= 1024 && (c & 3) == 0 && (BNT % (c >> 2)) == 0; }
 inline char* al(char* p) { return (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255); }
 
 template <typename T>
@@ -201,13 +201,13 @@ int fwd_t(const T* x, int64_t rows, int c, const float* gamma, const float* beta
           T* y, float* save, void* ws, hipStream_t st) {
     const int nb = reduce_blocks(rows, c);
     double* part = (double*)al((char*)ws);
-    const size_t lds = (size_t)(NT / (c >> 2)) * c * 2 * sizeof(double);
-    hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(nb), dim3(NT), lds, st, x, (const T*)nullptr, rows, c, (const float*)nullptr,
+    const size_t lds = (size_t)(BNT / (c >> 2)) * c * 2 * sizeof(double);
+    hipLaunchKernelGGL((bn_reduce_kernel<T, 0>), dim3(nb), dim3(BNT), lds, st, x, (const T*)nullptr, rows, c, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, 0, part);
-    hipLaunchKernelGGL((bn_finalize_kernel<T, 0>), dim3((c + 3) / 4), dim3(NT), 0, st, (const double*)part, nb, rows, c, x, eps, momentum,
+    hipLaunchKernelGGL((bn_finalize_kernel<T, 0>), dim3((c + 3) / 4), dim3(BNT), 0, st, (const double*)part, nb, rows, c, x, eps, momentum,
                        rm, rv, save, (float*)nullptr, (float*)nullptr);
     const int grid = apply_blocks(rows, c);
-    hipLaunchKernelGGL((bn_apply_kernel<T, 0>), dim3(grid), dim3(NT), 0, st, x, (const T*)nullptr, rows, c, (const float*)save, gamma, beta,
+    hipLaunchKernelGGL((bn_apply_kernel<T, 0>), dim3(grid), dim3(BNT), 0, st, x, (const T*)nullptr, rows, c, (const float*)save, gamma, beta,
                        (const float*)nullptr, relu, y);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
@@ -218,12 +218,12 @@ int bwd_t(const T* x, const T* dy, int64_t rows, int c, const float* gamma, cons
     const int nb = reduce_blocks(rows, c);
     double* part = (double*)al((char*)ws);
     float* gmeans = (float*)al((char*)(part + (size_t)nb * 2 * c));
-    const size_t lds = (size_t)(NT / (c >> 2)) * c * 2 * sizeof(double);
-    hipLaunchKernelGGL((bn_reduce_kernel<T, 1>), dim3(nb), dim3(NT), lds, st, x, dy, rows, c, save, gamma, beta, relu, part);
-    hipLaunchKernelGGL((bn_finalize_kernel<T, 1>), dim3((c + 3) / 4), dim3(NT), 0, st, (const double*)part, nb, rows, c, x, 0.f, 0.f,
+    const size_t lds = (size_t)(BNT / (c >> 2)) * c * 2 * sizeof(double);
+    hipLaunchKernelGGL((bn_reduce_kernel<T, 1>), dim3(nb), dim3(BNT), lds, st, x, dy, rows, c, save, gamma, beta, relu, part);
+    hipLaunchKernelGGL((bn_finalize_kernel<T, 1>), dim3((c + 3) / 4), dim3(BNT), 0, st, (const double*)part, nb, rows, c, x, 0.f, 0.f,
                        (float*)nullptr, (float*)nullptr, gmeans, dgamma, dbeta);
     const int grid = apply_blocks(rows, c);
-    hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(grid), dim3(NT), 0, st, x, dy, rows, c, save, gamma, beta, (const float*)gmeans, relu, dx);
+    hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(grid), dim3(BNT), 0, st, x, dy, rows, c, save, gamma, beta, (const float*)gmeans, relu, dx);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
