@@ -25,6 +25,9 @@ using namespace pps;
 #ifndef PPS_PRIO
 #define PPS_PRIO 1
 #endif
+#ifndef PPS_PRIO_PN
+#define PPS_PRIO_PN 1
+#endif
 #define CH4 2048               // f32x4 per 32 KiB weight chunk
 
 // One pipeline step: request the NEXT chunk, compute on the CURRENT one, publish the next, barrier.
@@ -378,13 +381,27 @@ __global__ __launch_bounds__(IS_NT) void interp_small_kernel(const float* __rest
 // (P = 50: 25 tiles per 8 queries instead of 32).  Any other P falls back to ceil(P/16) tiles per query with the
 // padding rows repeating a valid point (max) / masked (softmax).
 // =====================================================================================================
-#define PNT 512                // threads of the PointNet row kernels (8 waves, one workgroup per CU)
+// Two INDEPENDENT 4-wave workgroups per CU (16 KiB weight chunks so that both fit the LDS next to the parked rows) instead of
+// one 8-wave workgroup with 32 KiB chunks: the two waves of a SIMD then belong to different workgroups, drift out of phase and --
+// with the wave priority raised for the MFMA phase -- keep the matrix pipe fed while the other one reduces / parks
+// (stn_rows 2.00 -> 1.95 ms, feat_rows 2.47 -> 2.30 ms per 50000 queries; PNT=512 / PCH4=2048 is the old configuration).
+#ifndef PNT
+#define PNT 256                // threads of the PointNet row kernels
+#endif
+#ifndef PCH4
+#define PCH4 1024              // f32x4 per streamed weight chunk of the PointNet row kernels (1024 = 16 KiB)
+#endif
 #define PNW (PNT / 64)
+#define PN_WG_PER_CU (512 / PNT)
+#define PN_C2N (2048 / PCH4)   // chunks of conv2 (64 -> 128: 2048 f32x4) and of conv3 (128 -> 256: 8192 f32x4)
+#define PN_C3N (8192 / PCH4)
+#define PN_C2OB (8 / PN_C2N)   // output blocks per chunk
+#define PN_C3OB (16 / PN_C3N)
 #define PN_ROWF 260            // floats per parked left-over row (256 + pad against bank conflicts)
 #define PA_W_XYZ 256
 #define PA_NBIAS 576
 #define PN_PARK_ROWS 8         // parked rows per wave = max queries per wave group
-#define PA_LDS_BYTES (2 * CH4 * 16 + (PA_W_XYZ + PA_NBIAS + PNW * PN_PARK_ROWS * PN_ROWF) * 4)
+#define PA_LDS_BYTES (2 * PCH4 * 16 + (PA_W_XYZ + PA_NBIAS + PNW * PN_PARK_ROWS * PN_ROWF) * 4)
 
 struct PatchPacking {
     int fb, lo, qg, tiles_per_query;      // full tiles, left-over rows, queries per wave group, tiles evaluated per query
@@ -410,22 +427,28 @@ __device__ __forceinline__ void stn_chain(float coord, f32x4 (&z)[16], const flo
     for (int bb = 0; bb < 4; ++bb) x0[bb] = bias4[4 * bb + g];
     xyz_blocks<4>(coord, x0, xyz_l, lane);
     relu_blocks<4>(x0);
+    __builtin_amdgcn_s_setprio(PPS_PRIO_PN);
     stream_step<1024, PNT>(wg + 1024, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 16, lane); });
-    stream_step<CH4, PNT>(wg + 2048, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x1, x0, w, bias4 + 32, lane); });
-    stream_step<CH4, PNT>(wg + 4096, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 8, 1>(x0, y, w, bias4 + 48, lane); });
+    stream_step<PCH4, PNT>(wg + 2048, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x1, x0, w, bias4 + 32, lane); });
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-        stream_step<CH4, PNT>(wg + 6144 + c * CH4, cur, nxt,
-                              [&](const f32x4* w) { dense_blocks<8, 4, 1>(y, &z[4 * c], w, bias4 + 80 + 16 * c, lane); });
-    stream_step<1024, PNT>(wg, cur, nxt, [&](const f32x4* w) { dense_blocks<8, 4, 1>(y, &z[12], w, bias4 + 80 + 48, lane); });
+    for (int h = 0; h < PN_C2N; ++h)
+        stream_step<PCH4, PNT>(wg + 2048 + (h + 1) * PCH4, cur, nxt,
+                               [&](const f32x4* w) { dense_blocks<4, PN_C2OB, 1>(x0, &y[PN_C2OB * h], w, bias4 + 48 + 4 * PN_C2OB * h, lane); });
+#pragma unroll
+    for (int c = 0; c < PN_C3N - 1; ++c)
+        stream_step<PCH4, PNT>(wg + 4096 + (c + 1) * PCH4, cur, nxt,
+                               [&](const f32x4* w) { dense_blocks<8, PN_C3OB, 1>(y, &z[PN_C3OB * c], w, bias4 + 80 + 4 * PN_C3OB * c, lane); });
+    stream_step<1024, PNT>(wg, cur, nxt, [&](const f32x4* w) {
+        dense_blocks<8, PN_C3OB, 1>(y, &z[PN_C3OB * (PN_C3N - 1)], w, bias4 + 80 + 4 * PN_C3OB * (PN_C3N - 1), lane); });
+    __builtin_amdgcn_s_setprio(0);
 }
 
 __global__ __launch_bounds__(PNT, 2) void pointnet_stn_rows_kernel(const float* __restrict__ patches, int64_t Q, int P, int pack,
                                                                    const float* __restrict__ wpack, const float* __restrict__ bias,
                                                                    float* __restrict__ gout) {
     f32x4* buf0 = (f32x4*)pps_smem;
-    f32x4* buf1 = buf0 + CH4;
-    float* xyz_l = (float*)(buf1 + CH4);
+    f32x4* buf1 = buf0 + PCH4;
+    float* xyz_l = (float*)(buf1 + PCH4);
     float* bias_l = xyz_l + PA_W_XYZ;
     float* park = bias_l + PA_NBIAS;                       // [PNW][PN_PARK_ROWS][PN_ROWF] per-query left-over maxima
     const f32x4* bias4 = (const f32x4*)bias_l;
@@ -551,7 +574,7 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_kernel(const float* __r
 // =====================================================================================================
 #define PC_W_XYZ 256
 #define PC_NBIAS (576 + 256 + 4)
-#define PC_LDS_BYTES (2 * CH4 * 16 + (PC_W_XYZ + PC_NBIAS + PNW * PN_PARK_ROWS * PN_ROWF) * 4)
+#define PC_LDS_BYTES (2 * PCH4 * 16 + (PC_W_XYZ + PC_NBIAS + PNW * PN_PARK_ROWS * PN_ROWF) * 4)
 
 // conv0a .. conv3 on one 16-row tile of query `tq` (per-row feature transform), then the attention logit of each row
 // rows_per_query = 16 and nq = 1 for a tile of one query; a left-over tile holds nq queries x rows_per_query rows
@@ -564,6 +587,7 @@ __device__ __forceinline__ float feat_chain(float coord, const float* __restrict
     for (int bb = 0; bb < 4; ++bb) x0[bb] = bias4[4 * bb + g];
     xyz_blocks<4>(coord, x0, xyz_l, lane);
     relu_blocks<4>(x0);
+    __builtin_amdgcn_s_setprio(PPS_PRIO_PN);
     stream_step<1024, PNT>(wg + 1024, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 16, lane); });
     // feature transform x0 = trans2[q] (64x64, row-major) @ x1, A operand straight from global.  The A operand is shared by
     // the 16 columns of an MFMA, so a tile holding rows of nq different queries is done as nq accumulating products with
@@ -594,13 +618,18 @@ __device__ __forceinline__ float feat_chain(float coord, const float* __restrict
             x0[ob] = o;
         }
     }
-    stream_step<CH4, PNT>(wg + 2048, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 32, lane); });
-    stream_step<CH4, PNT>(wg + 4096, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 8, 1>(x1, y, w, bias4 + 48, lane); });
+    stream_step<PCH4, PNT>(wg + 2048, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 32, lane); });
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-        stream_step<CH4, PNT>(wg + 6144 + c * CH4, cur, nxt,
-                              [&](const f32x4* w) { dense_blocks<8, 4, 0>(y, &z[4 * c], w, bias4 + 80 + 16 * c, lane); });
-    stream_step<1024, PNT>(wg, cur, nxt, [&](const f32x4* w) { dense_blocks<8, 4, 0>(y, &z[12], w, bias4 + 80 + 48, lane); });
+    for (int h = 0; h < PN_C2N; ++h)
+        stream_step<PCH4, PNT>(wg + 2048 + (h + 1) * PCH4, cur, nxt,
+                               [&](const f32x4* w) { dense_blocks<4, PN_C2OB, 1>(x1, &y[PN_C2OB * h], w, bias4 + 48 + 4 * PN_C2OB * h, lane); });
+#pragma unroll
+    for (int c = 0; c < PN_C3N - 1; ++c)
+        stream_step<PCH4, PNT>(wg + 4096 + (c + 1) * PCH4, cur, nxt,
+                               [&](const f32x4* w) { dense_blocks<8, PN_C3OB, 0>(y, &z[PN_C3OB * c], w, bias4 + 80 + 4 * PN_C3OB * c, lane); });
+    stream_step<1024, PNT>(wg, cur, nxt, [&](const f32x4* w) {
+        dense_blocks<8, PN_C3OB, 0>(y, &z[PN_C3OB * (PN_C3N - 1)], w, bias4 + 80 + 4 * PN_C3OB * (PN_C3N - 1), lane); });
+    __builtin_amdgcn_s_setprio(0);
     float s = 0.f;                                   // attention logit of row n (nn.py:88)
 #pragma unroll
     for (int bb = 0; bb < 16; ++bb) {
@@ -617,8 +646,8 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float*
                                                                     int64_t Q, int P, int pack, const float* __restrict__ wpack,
                                                                     const float* __restrict__ bias, float* __restrict__ xbar) {
     f32x4* buf0 = (f32x4*)pps_smem;
-    f32x4* buf1 = buf0 + CH4;
-    float* xyz_l = (float*)(buf1 + CH4);
+    f32x4* buf1 = buf0 + PCH4;
+    float* xyz_l = (float*)(buf1 + PCH4);
     float* bias_l = xyz_l + PC_W_XYZ;
     float* park = bias_l + PC_NBIAS;                   // [PNW][PN_PARK_ROWS][PN_ROWF]: A[256], m, S of the left-over rows
     const f32x4* bias4 = (const f32x4*)bias_l;
@@ -791,7 +820,7 @@ static int grid_for(int64_t ntiles) {
     return (int)(ntiles < cus ? (ntiles > 0 ? ntiles : 1) : cus);
 }
 
-// PointNet row kernels: one 8-wave workgroup per CU.  Packed wave groups (qg queries, no padded rows) are used for as many
+// PointNet row kernels: PN_WG_PER_CU workgroups of PNW waves per CU.  Packed wave groups (qg queries, no padded rows) are used for as many
 // FULL rounds over all waves of the chip as the query count allows; the remainder runs one query per wave so that the last
 // round is short instead of a whole packed group (Q = 50000, P = 50: 3 x 25 + 4 tiles per wave instead of 100).
 struct PnSplit { int64_t q_packed; int grid_packed, grid_rest; };
@@ -800,12 +829,13 @@ static PnSplit pn_split(int64_t q, int p) {
     if (cus <= 0) cus = 256;
     const PatchPacking pk = patch_packing(p);
     PnSplit sp;
-    const int64_t per_round = (int64_t)cus * PNW * pk.qg;
+    const int wgs = cus * PN_WG_PER_CU;
+    const int64_t per_round = (int64_t)wgs * PNW * pk.qg;
     sp.q_packed = pk.packed ? (q / per_round) * per_round : 0;
     if (pk.packed && getenv("PPS_PN_FORCE_PACK")) sp.q_packed = q;      // test hook: packed path for any query count
-    sp.grid_packed = cus;
+    sp.grid_packed = wgs;
     const int64_t rest_tiles = (q - sp.q_packed + PNW - 1) / PNW;
-    sp.grid_rest = (int)(rest_tiles < cus ? rest_tiles : cus);
+    sp.grid_rest = (int)(rest_tiles < wgs ? rest_tiles : wgs);
     return sp;
 }
 
