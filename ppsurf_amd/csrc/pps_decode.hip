@@ -519,6 +519,9 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_stn_rows_kernel(const float* 
 // =====================================================================================================
 #define PB_NBIAS (128 + 64 + 4096)
 #define PB_LDS_BYTES (2 * CH4 * 16 + PB_NBIAS * 4)
+#ifndef PB_T
+#define PB_T 1                 // 16-query tiles a wave carries through fc3 together (2: no gain, 3: slower -- measured)
+#endif
 
 __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_kernel(const float* __restrict__ gin, int64_t Q,
                                                                 const float* __restrict__ wpack, const float* __restrict__ bias,
@@ -535,33 +538,53 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_kernel(const float* __r
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 
-    const int ntiles = (int)((Q + NW * 16 - 1) / (NW * 16));
+    // A wave carries PB_T tiles of 16 queries through the last layer together: its 1 MiB of weights is the bulk of the stream,
+    // and with one tile per wave the two workgroups of a CU would need 16 B/clk of LDS-DMA to keep the MFMA pipe busy (9.8 TB/s
+    // chip-wide, above what the path delivers); fc1 / fc2 (0.16 MiB) are simply streamed once per tile.
+    const int ntiles = (int)((Q + NW * 16 * PB_T - 1) / (NW * 16 * PB_T));
     int first, count, stride;
     xcd_tile_range(ntiles, first, count, stride);
     for (int it = 0; it < count; ++it) {
-        const int64_t qi = (int64_t)(first + it * stride) * (NW * 16) + wave * 16 + n;
-        const bool qv = qi < Q;
-        const int64_t qc = qv ? qi : Q - 1;
-        f32x4 a[16], h[8], u[4];
-        {
-            const f32x4* src = (const f32x4*)(gin + qc * 256) + g;
+        f32x4 u[PB_T][4];
+        int64_t qcs[PB_T];
+        bool qvs[PB_T];
 #pragma unroll
-            for (int bb = 0; bb < 16; ++bb) a[bb] = src[4 * bb];
+        for (int t = 0; t < PB_T; ++t) {
+            const int64_t qi = (int64_t)(first + it * stride) * (NW * 16 * PB_T) + (wave * PB_T + t) * 16 + n;
+            qvs[t] = qi < Q;
+            qcs[t] = qvs[t] ? qi : Q - 1;
+            f32x4 a[16], h[8];
+            {
+                const f32x4* src = (const f32x4*)(gin + qcs[t] * 256) + g;
+#pragma unroll
+                for (int bb = 0; bb < 16; ++bb) a[bb] = src[4 * bb];
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                stream_step<CH4>(wg + (c + 1) * CH4, cur, nxt,
+                               [&](const f32x4* w) { dense_blocks<16, 2, 1>(a, &h[2 * c], w, bias4 + 8 * c, lane); });
+            stream_step<CH4>(t + 1 < PB_T ? wg : wg + 5 * CH4, cur, nxt,
+                           [&](const f32x4* w) { dense_blocks<8, 4, 1>(h, u[t], w, bias4 + 32, lane); });
         }
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            stream_step<CH4>(wg + (c + 1) * CH4, cur, nxt,
-                           [&](const f32x4* w) { dense_blocks<16, 2, 1>(a, &h[2 * c], w, bias4 + 8 * c, lane); });
-        stream_step<CH4>(wg + 5 * CH4, cur, nxt, [&](const f32x4* w) { dense_blocks<8, 4, 1>(h, u, w, bias4 + 32, lane); });
-        f32x4* dst = (f32x4*)(trans2 + qc * 4096) + g;
 #pragma unroll 1
         for (int c = 0; c < 32; ++c) {
-            f32x4 o[8];
+            f32x4 o[PB_T][8];
             const f32x4* gn = (c + 1 < 32) ? wg + (6 + c) * CH4 : wg;
-            stream_step<CH4>(gn, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 8, 0>(u, o, w, bias4 + 48 + 32 * c, lane); });
-            if (qv) {
+            stream_step<CH4>(gn, cur, nxt, [&](const f32x4* w) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) dst[4 * (8 * c + j)] = o[j];
+                for (int t = 0; t < PB_T; ++t) dense_blocks<4, 8, 0>(u[t], o[t], w, bias4 + 48 + 32 * c, lane);
+            });
+#pragma unroll
+            for (int t = 0; t < PB_T; ++t) {
+#ifdef PPS_ABL_NOSTORE
+                if (qvs[t] && o[t][0].x == 123.456f) {
+#else
+                if (qvs[t]) {
+#endif
+                    f32x4* dst = (f32x4*)(trans2 + qcs[t] * 4096) + g;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dst[4 * (8 * c + j)] = o[t][j];
+                }
             }
         }
     }
@@ -917,7 +940,7 @@ int pps_pointnet_stn_fc_f32(const float* g, int64_t q, const float* wpack, const
     if (!g || !wpack || !bias || !trans2) return PPS_ERR_ARG;
     static int once = set_lds(pointnet_stn_fc_kernel, PB_LDS_BYTES);
     (void)once;
-    hipLaunchKernelGGL(pointnet_stn_fc_kernel, dim3(grid_for((q + NW * 16 - 1) / (NW * 16))), dim3(NT), PB_LDS_BYTES, (hipStream_t)stream,
+    hipLaunchKernelGGL(pointnet_stn_fc_kernel, dim3(grid_for((q + NW * 16 * PB_T - 1) / (NW * 16 * PB_T))), dim3(NT), PB_LDS_BYTES, (hipStream_t)stream,
                        g, q, wpack, bias, trans2);
     return PPS_LAUNCH_CHECK();
 }
