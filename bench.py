@@ -72,7 +72,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1 ('nccl' = RCCL; 'gloo' only for single-GPU rehearsals)")
     ap.add_argument('--same-gpu', action='store_true', help='rehearsal: every rank uses cuda:0 (needs --backend gloo)')
-    ap.add_argument('--overlap', action='store_true', help='run the spatial queries of chunk i+1 on a side stream (A/B; no gain measured)')
+    ap.add_argument('--overlap', action='store_true', help='A/B only: spatial queries of chunk i+1 on a side stream -- SLOWER (16.8 vs 12.7 ms/step): a resident kNN block '
+                         'keeps one of the two persistent decoder workgroups of its CU from starting')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -112,7 +113,7 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     # the product's chunk loop (ppsurf_amd.reconstruct.OccupancyField uses the same class): 64-NN search, patch gather (the
     # 50-NN are a prefix of the 64-NN), decoder kernels, all on one stream; --overlap moves the spatial queries of chunk i+1 to
-    # a side stream (measured: no gain, the decoder kernels own every CU).
+    # a side stream (measured: slower, the persistent decoder kernels are sized to own every CU).
     pipe = ChunkPipeline(plan, table, pts, pts, K_PROJ, P_LOCAL, same_cloud=True, max_chunk=Q_CHUNK, overlap=args.overlap)
 
     pipe.run([qd] * args.warmup)
