@@ -15,10 +15,11 @@ from ppsurf_amd import reconstruct, mcubes
 from ppsurf_amd.synthetic import make_cloud
 
 N = int(os.environ.get('N', 100000)); R = int(os.environ.get('R', 257)); DEV = 'cuda:0'
+P = int(os.environ.get('P', 50)); QB = int(os.environ.get('QB', 50000))       # config 5: N=250000 R=513 P=200 QB=25000
 model = PPSurfModel(pointnet_latent_size=256, output_names=['imp_surf_sign'], in_channels=3, out_channels=2, k=64, lambda_l1=0.0,
                     debug=False, in_file='x.npy', results_dir='/tmp/res', padding_factor=0.05, name='t', network_latent_size=256,
-                    gen_subsample_manifold_iter=10, gen_subsample_manifold=10000, gen_resolution_global=R, num_pts_local=50,
-                    rec_batch_size=50000, gen_refine_iter=10, workers=1)
+                    gen_subsample_manifold_iter=10, gen_subsample_manifold=10000, gen_resolution_global=R, num_pts_local=P,
+                    rec_batch_size=QB, gen_refine_iter=10, workers=1)
 model.network.load_state_dict(filled_sd('', key='ppsurf'))
 model = model.to(DEV).eval()
 cloud = make_cloud(N, seed=42, noise=0.0)
@@ -41,7 +42,7 @@ model.network.encoder.plan(DEV); model.network.decoder_plan(DEV)          # one-
 for rep in range(int(os.environ.get('REPS', 2))):                          # the last repetition is reported (warm allocator / code objects)
     t0 = sync(); lat = model.encode_latents(pts_cf); t1 = sync()
     shape = {'pts': pts_cf.unsqueeze(0), 'latents': lat.t().unsqueeze(0)}
-    field = SteeredField(model.network, shape, cloud_t.unsqueeze(0), 50000, 50)
+    field = SteeredField(model.network, shape, cloud_t.unsqueeze(0), QB, P)
     bmin, bmax = cloud.min(), cloud.max(); step = (bmax - bmin) / (R - 1)
     pts_ids = torch.from_numpy(((cloud - bmin) / step + 1).astype(np.int32).astype(np.int64)).to(DEV)
     t2 = sync(); vol = reconstruct.create_volume(field, pts_ids, R, step, bmin - step); t3 = sync()
@@ -55,7 +56,7 @@ for rep in range(int(os.environ.get('REPS', 2))):                          # the
         field(q)
     t6 = sync()
     total = (t1 - t0) + (t3 - t2) + (t4 - t3) + (t6 - t5)
-    print('latent loop        {:7.3f} s  (100 encoder passes)'.format(t1 - t0))
+    print('latent loop        {:7.3f} s  ({} encoder passes)'.format(t1 - t0, 10 * max(1, N // 10000)))
     print('region growing     {:7.3f} s  {} band queries ({:.2e} q/s incl. driver)'.format(t3 - t2, n_band, n_band / (t3 - t2)))
     print('MC + clean (GPU)   {:7.3f} s  {} verts {} faces'.format(t4 - t3, verts.shape[0], faces.shape[0]))
     print('refinement         {:7.3f} s  10 x {} queries ({:.2e} q/s)'.format(t6 - t5, q.shape[0], 10 * q.shape[0] / (t6 - t5)))
