@@ -36,6 +36,7 @@ def _w2d(layer):
 
 
 SPLITK_MIN_ROWS = 32768
+SPLITK_SLABS = 128           # row slabs of the split-K weight gradient (64 / 128 / 256 measured within 3 % of each other)
 
 
 class _RowsLinear(torch.autograd.Function):
@@ -43,7 +44,7 @@ class _RowsLinear(torch.autograd.Function):
 
     The forward and the input gradient are bandwidth-bound library GEMMs (0.33 ms for 1.28 M x 256 x 256 in bf16).  The weight
     gradient dW = g^T x contracts over the ROWS; hipBLASLt runs that shape 6-20x off its bandwidth bound (1.9 ms), so it is
-    computed split-K: the rows are cut into S slabs, one batched GEMM produces S partial [N, K] products with fp32
+    computed split-K: the rows are cut into S = 128 slabs, one batched GEMM produces S partial [N, K] products with fp32
     accumulation and the partials are summed in fp32 (0.33 ms; 0.06 ms instead of 1.3 ms for the 64-channel PointNet layers)."""
 
     @staticmethod
@@ -68,7 +69,7 @@ class _RowsLinear(torch.autograd.Function):
             dx = (g @ wc).to(xdt)
         if ctx.needs_input_grad[1]:
             rows = g.shape[0]
-            s = 256 if rows >= 256 * 1024 else 64
+            s = SPLITK_SLABS if rows >= SPLITK_SLABS * 1024 else 64
             rs = rows // s
             main = rs * s
             dw = torch.bmm(g[:main].view(s, rs, -1).transpose(1, 2), xc[:main].view(s, rs, -1)).sum(0, dtype=acc)
