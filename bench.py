@@ -151,8 +151,10 @@ def main():
                          'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
                          'traffic': traffic, 'avg_kernel_ms': k_ms,
                          'executed_tflops': INTERP_EXEC_FLOP_PER_QUERY * Q_CHUNK / (k_ms * 1e-3) / 1e12,
-                         'note': 'achieved counts the reference\'s ALGORITHMIC flops the kernel replaces; '
-                                 'executed_tflops counts MFMA flops actually issued (fc1/fc_value hoisted, DESIGN.md)'},
+                         'frac_executed': INTERP_EXEC_FLOP_PER_QUERY * Q_CHUNK / (k_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         'note': 'achieved / frac count the reference\'s ALGORITHMIC flops the kernel replaces (frac > 1 because two exact '
+                                 'identities remove work); executed_tflops / frac_executed count the MFMA flops actually issued = '
+                                 'utilisation of the fp32 matrix pipe (DESIGN.md 4.1)'},
             'whole_path_algorithmic_tflops': ALG_MFLOP_PER_QUERY * 1e6 * value / world / 1e12,
         }
         if world == 1 and not args.no_cpu_baseline:
