@@ -71,6 +71,28 @@ class FKAConvParams:
         return out
 
 
+    def batch(self, x, pts, sup, idx, b):
+        """The same layer for a batch of b equally sized clouds stacked along the rows (x [b*n,cin], sup [b*m,3], idx int64
+        [b*m,k] = ROW numbers into x / pts): batched geometry kernels (InstanceNorm statistics per cloud), feature
+        aggregation, then the (1,16) convolution with folded BatchNorm / ReLU as one MFMA GEMM over all rows."""
+        mt, k = idx.shape
+        L = _lib.lib()
+        geo_w = self.geo.clone()
+        g = torch.empty((mt, k, 16), dtype=torch.float32, device=x.device)
+        stat = torch.empty((2, b, 32), dtype=torch.float32, device=x.device)
+        ws = torch.empty((L.pps_fka_train_ws_bytes(b, mt // b, k),), dtype=torch.uint8, device=x.device)
+        _lib.check(L.pps_fka_geometry_fwd_f32(pts.data_ptr(), sup.data_ptr(), idx.data_ptr(), b, mt // b, k, geo_w.data_ptr(), 0.0,
+                                              g.data_ptr(), stat.data_ptr(), ws.data_ptr(), _stream(x)), 'pps_fka_geometry_fwd_f32')
+        feat = torch.empty((mt, self.cin * 16), dtype=torch.float32, device=x.device)
+        _lib.check(L.pps_neighbour_contract_fwd_f32(x.data_ptr(), idx.data_ptr(), g.data_ptr(), mt, k, self.cin, feat.data_ptr(),
+                                                    _stream(x)), 'pps_neighbour_contract_fwd_f32')
+        out = torch.empty((mt, self.cout), dtype=torch.float32, device=x.device)
+        _lib.check(L.pps_rows_gemm_f32(feat.data_ptr(), None, self.cin * 16, None, None, 0, self.wpack.data_ptr(),
+                                       self.bias.data_ptr() if self.bias is not None else None, None, self.act_out, mt, self.cout,
+                                       out.data_ptr(), _stream(x)), 'pps_rows_gemm_f32')
+        return out
+
+
 class LinearParams:
     """1x1 convolution (+ folded BatchNorm) as wt [Cin, Cout] + bias."""
 
@@ -131,6 +153,14 @@ class ResidualBlockParams:
             sc = gather_max(sc, idx)                          # nn.py:445-446
         return self.cv2(h, residual=sc, relu=True)
 
+    def batch(self, x, pts, sup, idx, b):
+        h = self.cv0(x, relu=True)
+        h = self.cv1.batch(h, pts, sup, idx, b)
+        sc = self.shortcut(x) if self.shortcut is not None else x
+        if sc.shape[0] != sup.shape[0]:
+            sc = gather_max(sc, idx)
+        return self.cv2(h, residual=sc, relu=True)
+
 
 class EncoderPlan:
     """Device-resident, BatchNorm-folded parameters of FKAConvNetwork (segmentation=True, dropout 0)."""
@@ -178,3 +208,34 @@ class EncoderPlan:
         x1d = self.cv1d(x2d, idx1=ids['ids21'], in2=x1, relu=True)
         xo = self.cv0d(x1d, idx1=ids['ids10'], in2=x0, relu=True)
         return self.fcout(xo)                                 # dropout p=0 (nn.py:547-548)
+
+    def forward_batch(self, levels, ids, b):
+        """The same for a batch of b equally sized clouds, everything stacked along the rows: levels = [pts, s1..s4] with
+        shapes [b*n_l,3]; ids: tables of ROW numbers (the batch offsets b_i*n_l already added), 'ids00'.. int64 [b*m,k],
+        up-sampling tables int64 [b*n_fine] -> latents [b*n, out].  All launches cover the whole batch: a single 10k-point
+        cloud cannot fill 256 CUs, ten of them (one coverage wave of the latent loop) can."""
+        pts, s1, s2, s3, s4 = levels
+        bl = self.blocks
+        x = torch.ones_like(pts)
+        x0 = self.cv0.batch(x, pts, pts, ids['ids00'], b)
+        x0 = bl['01'].batch(x0, pts, pts, ids['ids00'], b)
+        x1 = bl['10'].batch(x0, pts, s1, ids['ids01'], b)
+        x1 = bl['11'].batch(x1, s1, s1, ids['ids11'], b)
+        x2 = bl['20'].batch(x1, s1, s2, ids['ids12'], b)
+        x2 = bl['21'].batch(x2, s2, s2, ids['ids22'], b)
+        x3 = bl['30'].batch(x2, s2, s3, ids['ids23'], b)
+        x3 = bl['31'].batch(x3, s3, s3, ids['ids33'], b)
+        x4 = bl['40'].batch(x3, s3, s4, ids['ids34'], b)
+        x4 = bl['41'].batch(x4, s4, s4, ids['ids44'], b)
+        if self.fixed:
+            n4 = x4.shape[0] // b
+            rows = torch.arange(b * n4, dtype=torch.int64, device=x4.device)
+            x5 = gather_max(x4, rows.view(b, n4))             # per-cloud global max over the coarsest level (nn.py:531)
+            x4d = self.cv5(x4, in2=x5, idx2=rows // n4, relu=True)
+        else:
+            x4d = x4
+        x3d = self.cv3d(x4d, idx1=ids['ids43'], in2=x3, relu=True)
+        x2d = self.cv2d(x3d, idx1=ids['ids32'], in2=x2, relu=True)
+        x1d = self.cv1d(x2d, idx1=ids['ids21'], in2=x1, relu=True)
+        xo = self.cv0d(x1d, idx1=ids['ids10'], in2=x0, relu=True)
+        return self.fcout(xo)

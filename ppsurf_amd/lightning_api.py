@@ -250,8 +250,8 @@ class PocoModel(_Base):
 
         Single rank: which points a pass covers depends only on the coverage COUNTS, never on latents, so up to
         `latent_batch` (default 10) consecutive subsets are drawn exactly like the reference draws them one after the other and
-        then encoded as ONE batch (batched sampling / kNN tables / FKAConv kernels, GEMMs over all subsets at once): a 10k-point
-        pass alone cannot fill 256 CUs."""
+        then encoded as ONE batch (batched sampling / kNN tables / FKAConv geometry and aggregation kernels, MFMA GEMMs with the
+        folded BatchNorm over the rows of all subsets at once): a 10k-point pass alone cannot fill 256 CUs."""
         n, dev = pts_cf.shape[1], pts_cf.device
         latent = torch.zeros((n, self.network_latent_size), dtype=torch.float32, device=dev)
         counts = torch.zeros((n,), dtype=torch.float32, device=dev)
@@ -268,7 +268,6 @@ class PocoModel(_Base):
         iteration = 0
         batch = int(getattr(self, 'latent_batch', 10))
         if world == 1 and batch > 1 and n >= m:
-            from . import train_graph
             enc = self.network.encoder
             assert not enc.training
             for current_value in range(self.gen_subsample_manifold_iter):
@@ -283,7 +282,7 @@ class PocoModel(_Base):
                         subsets.append(ids)
                     data_partial = {'pts': torch.stack([pts_cf[:, ids] for ids in subsets])}
                     data_partial.update(spatial.get_fkaconv_ids(data_partial))
-                    lat_b = train_graph.encoder(enc, data_partial)                      # [B, m, C], eval mode (running statistics)
+                    lat_b = enc.forward_batch_point_major(data_partial)                 # [B, m, C]: batched HIP launches, folded BatchNorm
                     for i, ids in enumerate(subsets):
                         latent[ids] += lat_b[i].float()                                # duplicates: last write wins, like the reference
                         counts[ids] += 1

@@ -185,6 +185,26 @@ class FKAConvNetwork(_Base):
         sups = [pm(data['support{}'.format(i)]) for i in (1, 2, 3, 4)]
         return plan.forward(pm(data['pts']), sups, ids)
 
+    def forward_batch_point_major(self, data):
+        """Eval-mode encoder pass of ALL batch items in batched launches (equally sized clouds): -> latents [B, N, C] point-major.
+        data as produced by spatial.get_fkaconv_ids ([B,3,N] supports, [B,M,K] tables of per-cloud indices)."""
+        assert not self.training
+        plan = self.plan(data['pts'].device)
+        b = data['pts'].shape[0]
+        flat = lambda t: t.transpose(1, 2).reshape(-1, 3).contiguous().float()
+        levels = [flat(data['pts'])] + [flat(data['support{}'.format(i)]) for i in (1, 2, 3, 4)]
+        sizes = [lv.shape[0] // b for lv in levels]
+        ids = {}
+        for a in range(5):
+            for c in (a - 1, a, a + 1):
+                key = 'ids{}{}'.format(a, c)
+                if key in data and torch.is_tensor(data[key]):
+                    t = data[key]                                        # rows of level c, indices into level a
+                    off = (torch.arange(b, device=t.device) * sizes[a]).view(b, 1, 1)
+                    t = (t + off).reshape(b * t.shape[1], t.shape[2])
+                    ids[key] = t.reshape(-1).contiguous() if c == a - 1 else t.contiguous()
+        return plan.forward_batch(levels, ids, b).view(b, sizes[0], -1)
+
     def forward(self, data, spectral_only=False):
         """nn.py:508-554.  data['pts'] [B,3,N] (+ supports / ids unless spectral_only=False) -> [B,C,N]."""
         if not spectral_only:

@@ -263,11 +263,13 @@ def test_batched_eval_encoder_equals_the_per_cloud_hip_encoder():
     data.update(spatial.get_fkaconv_ids(data))
     before = {k: v.clone() for k, v in net.encoder.state_dict().items()}
     with torch.no_grad():
-        got = tg.encoder(net.encoder, data)                                         # [B,N,C]
-        want = net.encoder.forward(dict(data), spectral_only=True).transpose(1, 2)
+        got = tg.encoder(net.encoder, data)                                         # [B,N,C]: autograd graph in eval mode
+        got_hip = net.encoder.forward_batch_point_major(data)                       # [B,N,C]: batched HIP launches (latent loop)
+        want = net.encoder.forward(dict(data), spectral_only=True).transpose(1, 2)  # per-cloud fused HIP encoder
     assert all(torch.equal(before[k], v) for k, v in net.encoder.state_dict().items())          # eval: no buffer moved
     scale = float(want.abs().max())
     assert float((got - want).abs().max()) <= 2e-4 * scale, float((got - want).abs().max()) / scale
+    assert float((got_hip - want).abs().max()) <= 2e-5 * scale, float((got_hip - want).abs().max()) / scale
 
 
 @pytest.mark.parametrize('n,q,p', [(300, 20, 10), (2500, 33, 50)])
