@@ -214,6 +214,8 @@ class FKAConvNetwork(_Base):
             return train_graph.encoder(self, data).transpose(1, 2)
         if self.dropout.p != 0:
             raise NotImplementedError('encoder dropout != 0 is not used by POCO / PPSurf')
+        if data['pts'].shape[0] > 1:                      # several clouds (validation batches): batched launches
+            return self.forward_batch_point_major(data).transpose(1, 2)
         out = [self.forward_point_major(data, b).t() for b in range(data['pts'].shape[0])]
         return torch.stack(out, dim=0)          # [B,C,N] as transposed views of point-major storage
 
