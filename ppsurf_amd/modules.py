@@ -359,6 +359,19 @@ class PPSurfNetwork(_Base):
             return train_graph.ppsurf_from_latent(self, _pm(data['latents']), data, data['proj_ids'])
         plan = self.decoder_plan(dev)
         k = min(self.projection.k, pts.shape[2])
+        if pts.shape[0] > 1:
+            # several shapes (validation batches): one kNN launch and one decoder call over the rows of all shapes, the
+            # per-point tables stacked and the neighbour ids offset into the stack
+            b, n, q = pts.shape[0], pts.shape[2], ptq.shape[2]
+            ids = spatial.knn(pts, ptq, k)                                            # [B,Q,k]
+            flat = (ids + (torch.arange(b, device=dev) * n).view(b, 1, 1)).reshape(b * q, k).contiguous()
+            table = torch.cat([plan.point_table(data['latents'][i]) for i in range(b)])
+            pts_pm = pts.transpose(1, 2).reshape(b * n, 3).contiguous().float()
+            q_pm = ptq.transpose(1, 2).reshape(b * q, 3).contiguous().float()
+            patches = data['pts_local_ps'].to(dev).reshape(b * q, -1, 3).contiguous().float()
+            lg, _ = plan.decode(table, pts_pm, q_pm, flat, patches, want_occ=False)
+            data['proj_ids'] = ids
+            return lg.view(b, q, 2).transpose(1, 2)
         logits, ids_all = [], []
         for b in range(pts.shape[0]):
             pts_pm = pts[b].t().contiguous().float()
