@@ -439,6 +439,15 @@ class PocoNetwork(_Base):
             return train_graph.interp_attention(self.projection, _pm(data['latents']), _pm(pts), _pm(ptq), data['proj_ids']).transpose(1, 2)
         plan = self.decoder_plan(dev)
         k = min(self.projection.k, pts.shape[2])
+        if pts.shape[0] > 1:                               # validation batches: all shapes stacked along the rows, one decoder call
+            b, n, q = pts.shape[0], pts.shape[2], ptq.shape[2]
+            ids = data['proj_ids'] if has_proj_ids else spatial.knn(pts, ptq, k)
+            flat = (ids + (torch.arange(b, device=dev) * n).view(b, 1, 1)).reshape(b * q, -1).contiguous()
+            table = torch.cat([plan.point_table(data['latents'][i]) for i in range(b)])
+            lg = plan.decode(table, pts.transpose(1, 2).reshape(b * n, 3).contiguous().float(),
+                             ptq.transpose(1, 2).reshape(b * q, 3).contiguous().float(), flat)
+            data['proj_ids'] = ids
+            return lg.view(b, q, -1).transpose(1, 2)
         logits, ids_all = [], []
         for b in range(pts.shape[0]):
             pts_pm, q_pm = pts[b].t().contiguous().float(), ptq[b].t().contiguous().float()
