@@ -67,8 +67,8 @@ def cpu_baseline(sd, cloud, qry, lat, n_sample=8192, chunk=1024, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1 ('nccl' = RCCL; 'gloo' only for single-GPU rehearsals)")
     ap.add_argument('--same-gpu', action='store_true', help='rehearsal: every rank uses cuda:0 (needs --backend gloo)')
