@@ -53,18 +53,22 @@ int pps_knn_multi_f32(int ntasks, const float* const* pts, const int64_t* n, con
                       const int* k, int64_t* const* out_idx, void* stream);
 
 /* Voxel-stratified sub-sampling of one cloud to exactly `target` unique points, all rounds in one workgroup.
- * replaces: source/poco_data_loader.py:59-134 `sampling_quantized` (per batch item): per round a rotation rots[r] (row-major
- * 3x3, drawn by the caller), one representative (smallest index) per occupied voxel of edge `vox` anchored at the rotated
- * bbox minimum, accept all and halve `vox` while fewer than `target` were taken, else a random subset (hash of `seed`).
+ * replaces: source/poco_data_loader.py:59-134 `sampling_quantized` (per batch item) with the semantics of its CPU execution
+ * (restated and pinned in oracle/driver_oracle.py): per round the three axis rotations rots[r][0..2] (row-major 3x3 each, x
+ * then y then z, drawn by the caller) applied one after the other in float32, one representative (LARGEST index) per occupied
+ * voxel of edge `vox` anchored at the rotated bbox minimum, accept all and halve `vox` while fewer than `target` were taken,
+ * else a random subset: the representatives with the smallest `priority[i]` (uint32 [n], ties to the lower index), or ranked by a
+ * hash of `seed` when priority is NULL.
  * vox <= 0 selects the reference's default edge, bbox diagonal / sqrt(target) (:85-88), computed in the kernel.
- * pts [n,3], 2 <= n <= pps_voxel_sample_max_points(), 1 <= target < n; out_ids int64 [target] ascending; out_rounds int32 or NULL. */
+ * pts [n,3], 2 <= n <= pps_voxel_sample_max_points(), 1 <= target < n; rots [nrot,3,9]; out_ids int64 [target] ascending;
+ * out_rounds int32 or NULL. */
 int pps_voxel_sample_max_points(void);
 int pps_voxel_sample_f32(const float* pts, int64_t n, int64_t target, float vox, const float* rots, int nrot, uint32_t seed,
-                         int64_t* out_ids, int32_t* out_rounds, void* stream);
+                         const uint32_t* priority, int64_t* out_ids, int32_t* out_rounds, void* stream);
 /* The same for a batch of b equally sized clouds pts [b,n,3] in ONE launch (one workgroup per cloud; default voxel edge;
- * rots [b,nrot,9]; cloud i uses seed + i * 0x9e3779b9): out_ids int64 [b,target], out_rounds int32 [b] or NULL. */
+ * rots [b,nrot,3,9]; priority [b,n] or NULL; cloud i uses seed + i * 0x9e3779b9): out_ids int64 [b,target], out_rounds int32 [b] or NULL. */
 int pps_voxel_sample_batch_f32(const float* pts, int64_t b, int64_t n, int64_t target, const float* rots, int nrot, uint32_t seed,
-                               int64_t* out_ids, int32_t* out_rounds, void* stream);
+                               const uint32_t* priority, int64_t* out_ids, int32_t* out_rounds, void* stream);
 
 /* Gather P neighbours per query from the raw cloud, centre at the query, divide by the max neighbour distance.
  * replaces: source/poco_utils.py:67-72 `_get_pts_local_ps` (gather + normalise part) and

@@ -866,7 +866,7 @@ static PnSplit pn_split(int64_t q, int p) {
 
 extern "C" {
 
-int pps_abi_version(void) { return 1; }
+int pps_abi_version(void) { return 2; }
 
 // development aid (not part of the public header): resident workgroups per CU of the decoder kernels
 int pps_debug_occupancy(int which) {

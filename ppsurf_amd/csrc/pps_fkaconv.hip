@@ -141,13 +141,15 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const float* __restrict_
     const int ob0 = blockIdx.y * NOB;
     const f32x4* a1 = (const f32x4*)(in1 + r1 * C1) + g;
     const f32x4* a2 = in2 ? (const f32x4*)(in2 + r2 * C2) + g : a1;
-    f32x4 acc[NOB];
+    // FOUR independent accumulation chains per output block (k-steps 4kb, 4kb+1, 4kb+2, 4kb+3 of every 16-wide block), added
+    // pairwise at the end: the contraction runs over up to K = 8192 (resnetb41.cv1), a single sequential fp32 chain of K/4 MFMAs
+    // accumulates about twice the rounding error of the reference's blocked CPU GEMM (tools/enc_error_bisect.py); chains of K/16
+    // halve it, and back-to-back MFMAs no longer wait on each other's result.
+    f32x4 acc[NOB][4];
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) {
-        const int o = 16 * (ob0 + ob) + 4 * g;
+    for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[ob][r] = (bias && o + r < N) ? bias[o + r] : 0.f;
-    }
+        for (int c = 0; c < 4; ++c) acc[ob][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4* w = wpack + (int64_t)ob0 * KB * 64 + lane;
 #pragma unroll 4
     for (int kb = 0; kb < KB; ++kb) {
@@ -155,10 +157,10 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const float* __restrict_
 #pragma unroll
         for (int ob = 0; ob < NOB; ++ob) {
             const f32x4 a = w[((int64_t)ob * KB + kb) * 64];
-            acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[ob], 0, 0, 0);
-            acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[ob], 0, 0, 0);
-            acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[ob], 0, 0, 0);
-            acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[ob], 0, 0, 0);
+            acc[ob][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[ob][0], 0, 0, 0);
+            acc[ob][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[ob][1], 0, 0, 0);
+            acc[ob][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[ob][2], 0, 0, 0);
+            acc[ob][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[ob][3], 0, 0, 0);
         }
     }
     if (row >= M) return;
@@ -168,7 +170,8 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (o + r < N) {
-                float v = acc[ob][r];
+                float v = (acc[ob][0][r] + acc[ob][1][r]) + (acc[ob][2][r] + acc[ob][3][r]);
+                if (bias) v += bias[o + r];
                 if (residual) v += residual[row * N + o + r];
                 if (act == 1) v = fmaxf(v, 0.f);
                 out[row * N + o + r] = v;

@@ -12,7 +12,6 @@
 #define VS_NT 1024
 #define VS_TABLE 16384                 // hash slots (power of two); the kernel accepts n <= VS_MAXN points
 #define VS_MAXN 10240
-#define VS_EMPTY 0xffffffffu
 
 __device__ __forceinline__ unsigned vs_hash(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -42,19 +41,41 @@ __device__ __forceinline__ float block_min_float(float v, float* red) {
     return t;
 }
 
-// pts [n,3]; rots [nrot][9] row-major rotation per round (p' = R p); out_ids int64 [target] ascending per round of selection
-// One workgroup per cloud: blockIdx.x selects cloud b of a batch of equally sized clouds (pts + b*n*3, rots + b*nrot*9,
-// out_ids + b*target, seed + b).
+// pts [n,3]; rots [nrot][3][9]: per round the THREE row-major axis rotations in application order (x, y, z), each applied as
+// p' = M p in float32 exactly like the reference's `pos @ matrix.t()` (one fp32 GEMM per axis, K = 3 evaluated by the GEMM
+// microkernel as fma(p2, m2, fma(p1, m1, p0*m0)); oracle/driver_oracle.py rotate_f32, pinned by tests/golden/sampling.npz);
+// prio: optional uint32 [n] -- the last round keeps the representatives with the smallest priority (ties: lower index)
+// instead of ranking them by an internal hash ("truncation given the permutation", poco_data_loader.py:123);
+// out_ids int64 [target] ascending.
+// One workgroup per cloud: blockIdx.x selects cloud b of a batch of equally sized clouds (pts + b*n*3, rots + b*nrot*27,
+// prio + b*n, out_ids + b*target, seed + b).
+__device__ __forceinline__ void vs_rotate3(const float* __restrict__ R, float& x, float& y, float& z) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float* M = R + 9 * a;
+        const float nx = __fmaf_rn(z, M[2], __fmaf_rn(y, M[1], __fmul_rn(x, M[0])));
+        const float ny = __fmaf_rn(z, M[5], __fmaf_rn(y, M[4], __fmul_rn(x, M[3])));
+        const float nz = __fmaf_rn(z, M[8], __fmaf_rn(y, M[7], __fmul_rn(x, M[6])));
+        x = nx; y = ny; z = nz;
+    }
+}
+
+typedef unsigned long long vs_u64;
+#define VS_EMPTY64 0xffffffffffffffffull
+#define VS_REP_BITS 14                 // n <= VS_MAXN = 10240 < 2^14
+#define VS_CELL_MAX 65535              // 16 bits per axis: sqrt(target) * 2^round cells at most; 50 * 2^10 < 65536
+
 __global__ __launch_bounds__(VS_NT) void voxel_sample_kernel(const float* __restrict__ pts_all, int n, int target, float vox,
                                                              const float* __restrict__ rots_all, int nrot, unsigned seed0,
+                                                             const unsigned* __restrict__ prio_all,
                                                              int64_t* __restrict__ out_ids_all, int* __restrict__ out_rounds_all) {
     const float* __restrict__ pts = pts_all + (size_t)blockIdx.x * n * 3;
-    const float* __restrict__ rots = rots_all + (size_t)blockIdx.x * nrot * 9;
+    const float* __restrict__ rots = rots_all + (size_t)blockIdx.x * nrot * 27;
+    const unsigned* __restrict__ prio = prio_all ? prio_all + (size_t)blockIdx.x * n : nullptr;
     int64_t* __restrict__ out_ids = out_ids_all + (size_t)blockIdx.x * target;
     int* __restrict__ out_rounds = out_rounds_all ? out_rounds_all + blockIdx.x : nullptr;
     const unsigned seed = seed0 + blockIdx.x * 0x9e3779b9u;
-    __shared__ unsigned tkey[VS_TABLE];
-    __shared__ unsigned trep[VS_TABLE];
+    __shared__ vs_u64 tslot[VS_TABLE];           // (voxel key << 14) | representative: one 64-bit atomicMax keeps the LARGEST index
     __shared__ unsigned char state[VS_MAXN];     // bit0 alive, bit1 representative of this round, bit2 selected
     __shared__ int red_i[VS_NT / 64 + 1];
     __shared__ float red_f[VS_NT / 64 + 1];
@@ -62,53 +83,57 @@ __global__ __launch_bounds__(VS_NT) void voxel_sample_kernel(const float* __rest
     for (int i = tid; i < n; i += VS_NT) state[i] = 1;
     __syncthreads();
     if (!(vox > 0.f)) {
-        // default voxel edge: bounding-box diagonal / sqrt(target)   (poco_data_loader.py:85-88)
+        // default voxel edge: bounding-box diagonal / sqrt(target)   (poco_data_loader.py:85-88), float32, no contraction
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {INFINITY, INFINITY, INFINITY};      // hi holds the minimum of -x
         for (int i = tid; i < n; i += VS_NT)
             for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], pts[3 * i + c]); hi[c] = fminf(hi[c], -pts[3 * i + c]); }
-        float d2 = 0.f;
-        for (int c = 0; c < 3; ++c) {
-            const float e = -block_min_float(hi[c], red_f) - block_min_float(lo[c], red_f);
-            d2 += e * e;
-        }
-        vox = sqrtf(d2) / sqrtf((float)target);
+        float e[3];
+        for (int c = 0; c < 3; ++c) e[c] = __fsub_rn(-block_min_float(hi[c], red_f), block_min_float(lo[c], red_f));
+        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(e[0], e[0]), __fmul_rn(e[1], e[1])), __fmul_rn(e[2], e[2]));
+        vox = __fdiv_rn(__fsqrt_rn(d2), __fsqrt_rn((float)target));
     }
     int count = 0, rounds = 0;
     bool done = false;
     for (int r = 0; r < nrot && !done; ++r, ++rounds) {
-        const float* R = rots + r * 9;
+        const float* R = rots + r * 27;
         // bounding-box minimum of the rotated remaining points (voxel_grid anchors its grid there)
         float mx = INFINITY, my = INFINITY, mz = INFINITY;
         for (int i = tid; i < n; i += VS_NT)
             if (state[i] & 1) {
-                const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
-                mx = fminf(mx, R[0] * x + R[1] * y + R[2] * z);
-                my = fminf(my, R[3] * x + R[4] * y + R[5] * z);
-                mz = fminf(mz, R[6] * x + R[7] * y + R[8] * z);
+                float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+                vs_rotate3(R, x, y, z);
+                mx = fminf(mx, x); my = fminf(my, y); mz = fminf(mz, z);
             }
         mx = block_min_float(mx, red_f); my = block_min_float(my, red_f); mz = block_min_float(mz, red_f);
-        for (int s = tid; s < VS_TABLE; s += VS_NT) { tkey[s] = VS_EMPTY; trep[s] = VS_EMPTY; }
+        for (int s = tid; s < VS_TABLE; s += VS_NT) tslot[s] = VS_EMPTY64;
         __syncthreads();
-        // one representative (smallest index) per occupied voxel
+        // one representative per occupied voxel: the LARGEST point index, like consecutive_cluster's sequential scatter_ on
+        // the CPU (torch_geometric; oracle/driver_oracle.py consecutive_representatives)
         for (int i = tid; i < n; i += VS_NT)
             if (state[i] & 1) {
-                const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
-                const int cx = min(1023, (int)floorf((R[0] * x + R[1] * y + R[2] * z - mx) / vox));
-                const int cy = min(1023, (int)floorf((R[3] * x + R[4] * y + R[5] * z - my) / vox));
-                const int cz = min(1023, (int)floorf((R[6] * x + R[7] * y + R[8] * z - mz) / vox));
-                const unsigned key = (unsigned)cx | ((unsigned)cy << 10) | ((unsigned)cz << 20);
-                unsigned slot = vs_hash(key) & (VS_TABLE - 1);
+                float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+                vs_rotate3(R, x, y, z);
+                const int cx = min(VS_CELL_MAX, (int)__fdiv_rn(__fsub_rn(x, mx), vox));
+                const int cy = min(VS_CELL_MAX, (int)__fdiv_rn(__fsub_rn(y, my), vox));
+                const int cz = min(VS_CELL_MAX, (int)__fdiv_rn(__fsub_rn(z, mz), vox));
+                const vs_u64 key = (vs_u64)cx | ((vs_u64)cy << 16) | ((vs_u64)cz << 32);
+                const vs_u64 mine = (key << VS_REP_BITS) | (vs_u64)i;
+                unsigned slot = vs_hash((unsigned)key ^ vs_hash((unsigned)(key >> 24))) & (VS_TABLE - 1);
                 for (;;) {
-                    const unsigned old = atomicCAS(&tkey[slot], VS_EMPTY, key);
-                    if (old == VS_EMPTY || old == key) { atomicMin(&trep[slot], (unsigned)i); break; }
+                    vs_u64 old = *(volatile vs_u64*)&tslot[slot];
+                    if (old == VS_EMPTY64) {
+                        old = atomicCAS(&tslot[slot], VS_EMPTY64, mine);
+                        if (old == VS_EMPTY64) break;
+                    }
+                    if ((old >> VS_REP_BITS) == key) { atomicMax(&tslot[slot], mine); break; }
                     slot = (slot + 1) & (VS_TABLE - 1);
                 }
             }
         __syncthreads();
-        int mine = 0;
+        int mine_n = 0;
         for (int s = tid; s < VS_TABLE; s += VS_NT)
-            if (tkey[s] != VS_EMPTY) { state[trep[s]] |= 2; ++mine; }
-        const int nrep = block_sum_int(mine, red_i);
+            if (tslot[s] != VS_EMPTY64) { state[(unsigned)(tslot[s] & ((1u << VS_REP_BITS) - 1))] |= 2; ++mine_n; }
+        const int nrep = block_sum_int(mine_n, red_i);
         if (count + nrep < target) {
             // take every representative, drop it from the pool, halve the voxel
             for (int i = tid; i < n; i += VS_NT)
@@ -117,33 +142,42 @@ __global__ __launch_bounds__(VS_NT) void voxel_sample_kernel(const float* __rest
             vox *= 0.5f;
             __syncthreads();
         } else {
-            // last round: a uniformly random subset of the representatives (rank by a per-point hash, threshold by bisection)
+            // last round: a uniformly random subset of the representatives (rank by priority -- given, or a per-point hash --
+            // threshold by bisection)
             const int need = target - count;
+#define VS_PRIO(i) (prio ? prio[i] : vs_hash(seed ^ (unsigned)((i) * 2654435761u)))
             unsigned lo = 0u, hi = 0xffffffffu;           // smallest T with |{rep : h <= T}| >= need
             while (lo < hi) {
                 const unsigned mid = lo + ((hi - lo) >> 1);
                 int c = 0;
                 for (int i = tid; i < n; i += VS_NT)
-                    if ((state[i] & 2) && vs_hash(seed ^ (unsigned)(i * 2654435761u)) <= mid) ++c;
+                    if ((state[i] & 2) && VS_PRIO(i) <= mid) ++c;
                 c = block_sum_int(c, red_i);
                 if (c >= need) hi = mid; else lo = mid + 1;
             }
             int below = 0;
             for (int i = tid; i < n; i += VS_NT)
-                if ((state[i] & 2) && vs_hash(seed ^ (unsigned)(i * 2654435761u)) < lo) ++below;
+                if ((state[i] & 2) && VS_PRIO(i) < lo) ++below;
             below = block_sum_int(below, red_i);
-            // hash ties at the threshold (practically never more than one point): lowest indices first, serially
+            // priority ties at the threshold: lowest indices first.  Rank among the tied representatives by a serial scan of
+            // thread 0 (ties are practically absent with hashed / permuted priorities; correctness matters, speed does not)
             __shared__ int tie_left;
             if (tid == 0) tie_left = need - below;
             __syncthreads();
             for (int i = tid; i < n; i += VS_NT)
                 if (state[i] & 2) {
-                    const unsigned h = vs_hash(seed ^ (unsigned)(i * 2654435761u));
+                    const unsigned h = VS_PRIO(i);
                     if (h < lo) state[i] = 4;
-                    else if (h == lo) { if (atomicSub(&tie_left, 1) > 0) state[i] = 4; else state[i] &= 1; }
-                    else state[i] &= 1;
+                    else if (h > lo) state[i] &= 1;
                 }
             __syncthreads();
+            if (tid == 0)
+                for (int i = 0; i < n; ++i)
+                    if ((state[i] & 2) && !(state[i] & 4)) {          // tied at the threshold, ascending index
+                        if (tie_left > 0) { state[i] = 4; --tie_left; } else state[i] &= 1;
+                    }
+            __syncthreads();
+#undef VS_PRIO
             count = target;
             done = true;
         }
@@ -287,19 +321,19 @@ extern "C" {
 int pps_voxel_sample_max_points(void) { return VS_MAXN; }
 
 int pps_voxel_sample_f32(const float* pts, int64_t n, int64_t target, float vox, const float* rots, int nrot, uint32_t seed,
-                         int64_t* out_ids, int32_t* out_rounds, void* stream) {
+                         const uint32_t* priority, int64_t* out_ids, int32_t* out_rounds, void* stream) {
     if (!pts || !rots || !out_ids || n < 2 || n > VS_MAXN || target < 1 || target >= n || nrot < 1) return PPS_ERR_ARG;
     hipLaunchKernelGGL(voxel_sample_kernel, dim3(1), dim3(VS_NT), 0, (hipStream_t)stream, pts, (int)n, (int)target, vox, rots, nrot, seed,
-                       out_ids, out_rounds);
+                       priority, out_ids, out_rounds);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 
 int pps_voxel_sample_batch_f32(const float* pts, int64_t b, int64_t n, int64_t target, const float* rots, int nrot, uint32_t seed,
-                               int64_t* out_ids, int32_t* out_rounds, void* stream) {
+                               const uint32_t* priority, int64_t* out_ids, int32_t* out_rounds, void* stream) {
     if (b == 0) return PPS_OK;
     if (!pts || !rots || !out_ids || b < 0 || n < 2 || n > VS_MAXN || target < 1 || target >= n || nrot < 1) return PPS_ERR_ARG;
     hipLaunchKernelGGL(voxel_sample_kernel, dim3((unsigned)b), dim3(VS_NT), 0, (hipStream_t)stream, pts, (int)n, (int)target, -1.f, rots, nrot,
-                       seed, out_ids, out_rounds);
+                       seed, priority, out_ids, out_rounds);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 

@@ -102,7 +102,8 @@ class TestDataset(ReconstructionDataset):
             item['pts_ms'] = item['pts_ms'][sel]
             item['normals_ms'] = item['normals_ms'][sel]
         q = item['pts_query_ms'].to(self.device)
-        item['pts_local_ps'] = spatial.get_pts_local_ps(raw, q, self.num_pts_local)
+        if self.num_pts_local is not None:                      # PocoDataset has no patches (poco_data_loader.py:344-396)
+            item['pts_local_ps'] = spatial.get_pts_local_ps(raw, q, self.num_pts_local)
         item = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in item.items()}
         return spatial.get_data_poco(item)
 
@@ -229,7 +230,8 @@ class DeviceBatchLoader:
             else:
                 idx = list(range(n))
             total = -(-n // self.world_size) * self.world_size
-            idx += idx[:total - n]
+            if total > n:                                       # DistributedSampler: repeat the list as often as the padding needs
+                idx = (idx * -(-total // max(n, 1)))[:total]
             return idx[self.rank:total:self.world_size]
         return torch.randperm(n).tolist() if self.shuffle else list(range(n))
 

@@ -52,12 +52,18 @@ def autocast_context(precision, device_type='cuda'):
     raise ValueError('unsupported trainer.precision {!r}'.format(precision))
 
 
+LIGHTNING_CKPT_VERSION = '2.0.0'
+
+
 def save_checkpoint(path, model, optimizer, scheduler, epoch, global_step):
     os.makedirs(os.path.dirname(path), exist_ok=True)
     tmp = path + '.tmp'
+    # key layout of a Lightning 2 checkpoint (the reference pins pytorch-lightning>=2.0, requirements.txt:3): the version must be
+    # a valid PEP 440 string (Lightning's migrate_checkpoint parses it), 'loops' / 'callbacks' may be empty
     torch.save({'state_dict': model.state_dict(), 'epoch': epoch, 'global_step': global_step,
                 'optimizer_states': [optimizer.state_dict()], 'lr_schedulers': [scheduler.state_dict()] if scheduler is not None else [],
-                'pytorch-lightning_version': 'ppsurf_amd'}, tmp)
+                'pytorch-lightning_version': LIGHTNING_CKPT_VERSION, 'loops': {}, 'callbacks': {}, 'hyper_parameters': {},
+                'ppsurf_amd': True}, tmp)
     os.replace(tmp, path)
 
 
@@ -148,9 +154,7 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
             with torch.no_grad():
                 for bi, batch in enumerate(val_loader):
                     vals.append(float(model.validation_step(batch, bi)))
-            vloss = sum(vals) / max(len(vals), 1)
-            if world > 1:
-                vloss = sharding.mean_over_ranks(vloss, device)
+            vloss = sharding.weighted_mean_over_ranks(sum(vals), len(vals), device)      # ranks weigh in by their batch count
             msg += ', val loss {:.4f}'.format(vloss)
             if mfile is not None:
                 mfile.write(json.dumps({'epoch': epoch, 'loss/val/00_all': vloss, 'metrics/val/F1': metrics.read().get('metrics/val/F1')}) + '\n')

@@ -238,20 +238,56 @@ class PocoModel(_Base):
                   prog_bar=f1_in_prog_bar)
 
     # ---- reconstruction (poco_model.py:183-273) -----------------------------------------------------------------
+    @staticmethod
+    def _draw_subset(covered, current_value, m, gen=None):
+        """The ids of one encoder pass (poco_model.py:210-224), or None when every point has been covered `current_value + 1`
+        times.  All counts are >= current_value when round `current_value` runs, so the reference's loop condition
+        `counts.min() < current_value + 1` (:209) is the same as "valid_ids is not empty" -- the nonzero() below is the only host
+        synchronisation of a pass.  Random numbers as in the reference: the subset permutation comes from the CPU generator
+        (`torch.randperm(valid_ids.shape[0])`, :213), the top-up permutation from the generator of the cloud's device (:217-219);
+        `gen` (a seeded CPU generator shared by all ranks of a query-sharded run) replaces both."""
+        n, dev = covered.shape[0], covered.device
+        valid_ids = torch.nonzero(covered == current_value)[:, 0]
+        if valid_ids.shape[0] == 0:
+            return None
+        if n < m:
+            return torch.arange(n, device=dev)
+        ids = valid_ids[torch.randperm(valid_ids.shape[0], generator=gen)[:m].to(dev)]
+        if ids.shape[0] < m:
+            top = torch.randperm(n, device=dev) if gen is None else torch.randperm(n, generator=gen).to(dev)
+            ids = torch.cat([ids, top[:m - ids.shape[0]]], dim=0)
+        return ids
+
+    def _encode_subsets(self, pts_cf, subsets):
+        """Latents of several equally sized subsets of one cloud in batched HIP launches: [B, m, C] point-major."""
+        enc = self.network.encoder
+        assert not enc.training
+        if len(subsets) == 1:
+            data_partial = {'pts': pts_cf[:, subsets[0]].unsqueeze(0)}
+            data_partial.update(spatial.get_fkaconv_ids(data_partial))
+            return enc.forward_point_major(data_partial, 0).unsqueeze(0)
+        data_partial = {'pts': torch.stack([pts_cf[:, ids] for ids in subsets])}
+        data_partial.update(spatial.get_fkaconv_ids(data_partial))
+        return enc.forward_batch_point_major(data_partial)                     # folded BatchNorm, one launch sequence for all subsets
+
     @torch.no_grad()
-    def encode_latents(self, pts_cf: torch.Tensor, progress=None) -> torch.Tensor:
+    def encode_latents(self, pts_cf: torch.Tensor, progress=None, encode_subsets=None, trace=None) -> torch.Tensor:
         """Latent loop of poco_model.py:203-236 for one cloud.  pts_cf [3,N] on the device -> latents POINT-MAJOR [N,C]:
         coverage-balanced random subsets of gen_subsample_manifold points until every point has been encoded
-        gen_subsample_manifold_iter times; latents are averaged.
+        gen_subsample_manifold_iter times; latents are averaged.  Parity with the reference's loop (same torch seed -> same
+        subsets, counts and latents, for `latent_batch` 1 and 10): tests/test_driver_parity_cpu.py against
+        tests/golden/latent_loop.npz.
 
-        With torch.distributed initialised and `shard_queries` set, the encoder passes of each coverage round are dealt
-        round-robin to the ranks (the subset selection comes from a generator seeded identically on every rank) and the
-        partial sums / counts are all-reduced once per round.
+        Which points a pass covers depends only on the coverage COUNTS, never on latents, so up to `latent_batch` (default 10)
+        consecutive subsets are drawn exactly like the reference draws them one after the other and then encoded as ONE batch
+        (batched sampling / kNN tables / FKAConv geometry and aggregation kernels, MFMA GEMMs with the folded BatchNorm over the
+        rows of all subsets at once): a 10k-point pass alone cannot fill 256 CUs.
 
-        Single rank: which points a pass covers depends only on the coverage COUNTS, never on latents, so up to
-        `latent_batch` (default 10) consecutive subsets are drawn exactly like the reference draws them one after the other and
-        then encoded as ONE batch (batched sampling / kNN tables / FKAConv geometry and aggregation kernels, MFMA GEMMs with the
-        folded BatchNorm over the rows of all subsets at once): a 10k-point pass alone cannot fill 256 CUs."""
+        With torch.distributed initialised and `shard_queries` set, the subsets of a batch are dealt round-robin to the ranks
+        (the selection comes from a generator seeded identically on every rank) and the partial sums / counts are all-reduced
+        once per batch.
+
+        encode_subsets(pts_cf, [ids...]) -> [B,m,C] replaces the HIP encoder (tests); `trace` collects the ids of every pass."""
         n, dev = pts_cf.shape[1], pts_cf.device
         latent = torch.zeros((n, self.network_latent_size), dtype=torch.float32, device=dev)
         counts = torch.zeros((n,), dtype=torch.float32, device=dev)
@@ -261,66 +297,41 @@ class PocoModel(_Base):
         if world > 1:
             gen = torch.Generator(device='cpu')
             gen.manual_seed(int(n) * 1000003 + 12345)
-
-        def randperm(k):
-            return torch.randperm(k, device=dev) if gen is None else torch.randperm(k, generator=gen).to(dev)
-
+        encode = encode_subsets if encode_subsets is not None else self._encode_subsets
+        batch = max(1, int(getattr(self, 'latent_batch', 10)))
+        if world > 1:
+            batch = -(-batch // world) * world                               # whole waves: every rank encodes batch / world subsets
         iteration = 0
-        batch = int(getattr(self, 'latent_batch', 10))
-        if world == 1 and batch > 1 and n >= m:
-            enc = self.network.encoder
-            assert not enc.training
-            for current_value in range(self.gen_subsample_manifold_iter):
-                while float(counts.min()) < current_value + 1:
-                    covered, subsets = counts.clone(), []
-                    while len(subsets) < batch and (not subsets or float(covered.min()) < current_value + 1):
-                        valid_ids = torch.nonzero(covered == current_value)[:, 0]
-                        ids = valid_ids[randperm(valid_ids.shape[0])[:m]]
-                        if ids.shape[0] < m:
-                            ids = torch.cat([ids, randperm(n)[:m - ids.shape[0]]], dim=0)
-                        covered[ids] += 1
-                        subsets.append(ids)
-                    data_partial = {'pts': torch.stack([pts_cf[:, ids] for ids in subsets])}
-                    data_partial.update(spatial.get_fkaconv_ids(data_partial))
-                    lat_b = enc.forward_batch_point_major(data_partial)                 # [B, m, C]: batched HIP launches, folded BatchNorm
-                    for i, ids in enumerate(subsets):
-                        latent[ids] += lat_b[i].float()                                # duplicates: last write wins, like the reference
-                        counts[ids] += 1
-                    iteration += len(subsets)
-                    if progress is not None:
-                        progress('get_latent iter: {}'.format(iteration))
-            return latent / counts.unsqueeze(1)
         for current_value in range(self.gen_subsample_manifold_iter):
-            while float(counts.min()) < current_value + 1:
-                # one "wave" of passes: with one rank exactly the reference's loop body; with several ranks every rank draws
-                # the same `world` consecutive subsets of the still uncovered points and encodes the one it owns
-                part = torch.zeros_like(latent) if world > 1 else latent
-                cnt = torch.zeros_like(counts) if world > 1 else counts
-                covered = counts.clone()
-                for r in range(world):
-                    if n >= m:
-                        valid_ids = torch.nonzero(covered == current_value)[:, 0]
-                        if valid_ids.shape[0] == 0 and r > 0:
-                            break
-                        ids = valid_ids[randperm(valid_ids.shape[0])[:m]]
-                        if ids.shape[0] < m:
-                            ids = torch.cat([ids, randperm(n)[:m - ids.shape[0]]], dim=0)
-                        assert ids.shape[0] == m
-                    else:
-                        ids = torch.arange(n, device=dev)
-                    covered[ids] += 1
-                    if r == rank:
-                        data_partial = {'pts': pts_cf[:, ids].unsqueeze(0)}
-                        data_partial.update(spatial.get_fkaconv_ids(data_partial))
-                        part[ids] += self.network.encoder.forward_point_major(data_partial, 0)   # duplicates: last write wins, like the reference
-                        cnt[ids] += 1
-                    if n < m:
+            round_done = False
+            while not round_done:
+                covered, subsets = counts.clone() if batch > 1 else counts, []
+                while len(subsets) < batch:
+                    ids = self._draw_subset(covered, current_value, m, gen)
+                    if ids is None:
+                        round_done = True
                         break
+                    subsets.append(ids)
+                    if batch > 1:
+                        covered[ids] += 1                                    # what `counts[ids] += 1` will have done by the next draw
+                    else:
+                        break
+                if not subsets:
+                    break
+                mine = subsets[rank::world] if world > 1 else subsets
+                part, cnt = (torch.zeros_like(latent), torch.zeros_like(counts)) if world > 1 else (latent, counts)
+                if mine:
+                    lat_b = encode(pts_cf, mine)
+                    for i, ids in enumerate(mine):
+                        part[ids] += lat_b[i].float()                        # duplicate ids (top-up): one write wins, counted once, like the reference
+                        cnt[ids] += 1
                 if world > 1:
                     sharding.allreduce_latents(part, cnt)
                     latent += part
                     counts += cnt
-                iteration += 1
+                if trace is not None:
+                    trace.extend(subsets)
+                iteration += len(subsets)
                 if progress is not None:
                     progress('get_latent iter: {}'.format(iteration))
         return latent / counts.unsqueeze(1)

@@ -298,6 +298,21 @@ def _channel_first(t):
     return t if t.shape[1] == 3 else t.transpose(1, 2)
 
 
+def _cached_point_table(net, latents_b, plan):
+    """One-entry cache of the per-point table G of `latents_b`.  The entry KEEPS the latent tensor (and the plan): while it
+    is alive the allocator cannot hand its storage to the next shape's latents, so `same storage + same _version` really
+    means "same values" (a pointer-only key matched the recycled block of the previous, equally sized shape)."""
+    ent = net._table
+    if (ent is not None and ent[1] is plan and ent[0]._version == ent[2] and ent[0].data_ptr() == latents_b.data_ptr()
+            and ent[0].shape == latents_b.shape and ent[0].stride() == latents_b.stride()
+            and ent[0].untyped_storage().data_ptr() == latents_b.untyped_storage().data_ptr()):
+        return ent[3]
+    net._table = None                                                 # drop the old table before allocating the new one
+    table = plan.point_table(latents_b)
+    net._table = (latents_b, plan, latents_b._version, table)
+    return table
+
+
 class PPSurfNetwork(_Base):
     def __init__(self, in_channels, latent_size, out_channels, k, num_pts_local, pointnet_latent_size):
         super().__init__()
@@ -327,10 +342,7 @@ class PPSurfNetwork(_Base):
     def point_table(self, latents_b, plan):
         """Per-point table G = fc1_latent(latents)+b1 of one batch item, cached while the caller keeps passing the
         same latent tensor (the reference re-reads data['latents'] for every query chunk, poco_utils.py:220-223)."""
-        key = (latents_b.data_ptr(), latents_b._version, tuple(latents_b.shape), tuple(latents_b.stride()), id(plan))
-        if self._table is None or self._table[0] != key:
-            self._table = (key, plan.point_table(latents_b))
-        return self._table[1]
+        return _cached_point_table(self, latents_b, plan)
 
     # -- reference API -------------------------------------------------------------------------------------------
     def forward(self, data):
@@ -408,10 +420,7 @@ class PocoNetwork(_Base):
         return self._dec[1]
 
     def point_table(self, latents_b, plan):
-        key = (latents_b.data_ptr(), latents_b._version, tuple(latents_b.shape), tuple(latents_b.stride()), id(plan))
-        if self._table is None or self._table[0] != key:
-            self._table = (key, plan.point_table(latents_b))
-        return self._table[1]
+        return _cached_point_table(self, latents_b, plan)
 
     def get_latent(self, data):
         data['latents'] = self.encoder.forward(data, spectral_only=False)

@@ -108,6 +108,43 @@ def create_volume(field, pts_ids: torch.Tensor, resolution: int, step: float, bm
     return volume
 
 
+def refine_vertices(eval_occ, verts: torch.Tensor, volume: torch.Tensor, step, bmin_pad, refine_iter: int, progress=None) -> torch.Tensor:
+    """Bisection of the Marching-Cubes edge vertices (poco_utils.py:111-168) on the device of `verts`.
+    verts [V,3] float64 in GRID coordinates; volume float64 with NaN = unseen; eval_occ(points float32 [q,3]) -> occ [q];
+    step / bmin_pad: numpy float32 scalars of the grid geometry.  Returns the vertices in model space, float64 [V,3].
+    Same arithmetic as the reference (float32 corner coordinates and queries, float64 volume values and vertex array; the
+    vertices are written back once at the end instead of after every round): tests/test_driver_parity_cpu.py compares it with
+    the reference's own output (tests/golden/refine.npz)."""
+    step32, bmin32 = np.float32(step), np.float32(bmin_pad)
+    if refine_iter <= 0 or verts.shape[0] == 0:
+        return verts * step32 + bmin32
+    frac = (verts - torch.floor(verts)) > 0
+    nfrac = frac.sum(dim=1)
+    sel = torch.nonzero((nfrac > 0) & (nfrac < 2))[:, 0]               # vertices on a grid edge (:115-117)
+    v = verts[sel]
+    v1i = torch.floor(v).to(torch.int64)
+    v2i = v1i + frac[sel].to(torch.int64)
+    p1 = volume[v1i[:, 0], v1i[:, 1], v1i[:, 2]]
+    p2 = volume[v2i[:, 0], v2i[:, 1], v2i[:, 2]]
+    ok = ~torch.isnan(p1) & ~torch.isnan(p2)                           # :131-137
+    sel, v, v1i, v2i, p1, p2 = sel[ok], v[ok], v1i[ok], v2i[ok], p1[ok].clone(), p2[ok].clone()
+    v1 = v1i.to(torch.float32) * step32 + bmin32
+    v2 = v2i.to(torch.float32) * step32 + bmin32
+    verts = verts * step32 + bmin32
+    vq = (v * step32 + bmin32).to(torch.float32)
+    for it in range(refine_iter):                                       # :146-165
+        pr = eval_occ(vq).to(torch.float64)
+        m1 = (pr * p1) > 0
+        v1[m1] = vq[m1]; p1[m1] = pr[m1]
+        m2 = (pr * p2) > 0
+        v2[m2] = vq[m2]; p2[m2] = pr[m2]
+        vq = (v2 + v1) / 2
+        if progress is not None:
+            progress('refine iter {}'.format(it))
+    verts[sel] = vq.to(verts.dtype)
+    return verts
+
+
 def export_mesh_and_refine_vertices_region_growing_v3(network, latent: dict, pts_raw_ms, resolution: int, padding=0, mc_value=0,
                                                       num_pts=50000, num_pts_local=None, refine_iter=10, input_points=None,
                                                       out_value=np.nan, dilation_size=2, prog_bar=None, pc_file_in: str = 'unknown'):
@@ -132,33 +169,8 @@ def export_mesh_and_refine_vertices_region_growing_v3(network, latent: dict, pts
         return None
     # Marching Cubes, clean-up and the bisection refinement stay on the device (poco_utils.py:96-168)
     verts, faces = mcubes.marching_cubes_torch(volume, mc_value)
+    verts = verts.to(torch.float32).to(torch.float64)            # skimage returns float32 vertices, trimesh stores them as float64
     verts, faces = mcubes.clean_mesh_torch(verts, faces, min_component_faces=6)
-    if refine_iter > 0 and verts.shape[0] > 0:
-        frac = (verts - torch.floor(verts)) > 0
-        nfrac = frac.sum(dim=1)
-        sel = torch.nonzero((nfrac > 0) & (nfrac < 2))[:, 0]               # vertices on a grid edge
-        v = verts[sel]
-        v1i = torch.floor(v).to(torch.int64)
-        v2i = v1i + frac[sel].to(torch.int64)
-        p1 = volume[v1i[:, 0], v1i[:, 1], v1i[:, 2]]
-        p2 = volume[v2i[:, 0], v2i[:, 1], v2i[:, 2]]
-        ok = ~torch.isnan(p1) & ~torch.isnan(p2)
-        sel, v, v1i, v2i, p1, p2 = sel[ok], v[ok], v1i[ok], v2i[ok], p1[ok], p2[ok]
-        v1 = v1i.to(torch.float32) * np.float32(step) + np.float32(bmin_pad)
-        v2 = v2i.to(torch.float32) * np.float32(step) + np.float32(bmin_pad)
-        verts = verts * step + bmin_pad
-        vq = (v * step + bmin_pad).to(torch.float32)
-        for it in range(refine_iter):                                       # bisection (poco_utils.py:146-165)
-            pr = sharding.sharded_map(field, vq).to(torch.float64)
-            m1 = (pr * p1) > 0
-            v1[m1] = vq[m1]; p1[m1] = pr[m1]
-            m2 = (pr * p2) > 0
-            v2[m2] = vq[m2]; p2[m2] = pr[m2]
-            vq = (v2 + v1) / 2
-            if progress is not None:
-                progress('refine iter {}'.format(it))
-        verts[sel] = vq.to(verts.dtype)
-    else:
-        verts = verts * step + bmin_pad
+    verts = refine_vertices(lambda q: sharding.sharded_map(field, q), verts, volume, step, bmin_pad, refine_iter, progress)
     verts, faces = mcubes.clean_mesh_torch(verts, faces, min_component_faces=6)
     return verts.to(torch.float32).cpu().numpy(), faces.cpu().numpy()

@@ -69,6 +69,17 @@ def mean_over_ranks(value: float, device) -> float:
     return float(t.item()) / ws
 
 
+def weighted_mean_over_ranks(total: float, count: int, device) -> float:
+    """sum(total over ranks) / sum(count over ranks): a rank without batches contributes nothing instead of a zero."""
+    import torch.distributed as dist
+    _, ws = world()
+    if ws > 1:
+        t = torch.tensor([total, float(count)], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total, count = float(t[0]), float(t[1])
+    return total / count if count > 0 else float('nan')
+
+
 def allreduce_latents(latent_sum: torch.Tensor, counts: torch.Tensor):
     """Sum the per-rank partial latent sums / counts of a latent loop whose encoder passes were dealt round-robin."""
     import torch.distributed as dist

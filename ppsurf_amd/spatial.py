@@ -40,55 +40,56 @@ def knn(points: torch.Tensor, support_points: torch.Tensor, k: int, workers: int
     return torch.stack(out, dim=0)
 
 
-def _rotation(axis: int) -> torch.Tensor:
-    """Random rotation about one axis by U(-180, 180) degrees (torch_geometric RandomRotate semantics, python `random`)."""
-    a = math.pi * random.uniform(-180.0, 180.0) / 180.0
-    s, c = math.sin(a), math.cos(a)
+def _axis_rotation(axis: int, angle: float):
+    """torch_geometric RandomRotate matrix about one axis (applied as pos @ m.t())."""
+    s, c = math.sin(angle), math.cos(angle)
     if axis == 0:
-        m = [[1, 0, 0], [0, c, s], [0, -s, c]]
-    elif axis == 1:
-        m = [[c, 0, -s], [0, 1, 0], [s, 0, c]]
-    else:
-        m = [[c, s, 0], [-s, c, 0], [0, 0, 1]]
-    return torch.tensor(m, dtype=torch.float32)
-
-
-def _one_per_voxel(pos: torch.Tensor, size: float) -> torch.Tensor:
-    """Index of one representative point per occupied voxel of edge `size` (grid anchored at the bbox minimum)."""
-    start = pos.min(dim=0)[0]
-    cell = torch.floor((pos - start) / size).to(torch.int64)
-    dims = cell.max(dim=0)[0] + 1
-    key = (cell[:, 2] * dims[1] + cell[:, 1]) * dims[0] + cell[:, 0]
-    skey, order = torch.sort(key, stable=True)
-    first = torch.ones_like(skey, dtype=torch.bool)
-    first[1:] = skey[1:] != skey[:-1]
-    return order[first]
+        return [[1, 0, 0], [0, c, s], [0, -s, c]]
+    if axis == 1:
+        return [[c, 0, -s], [0, 1, 0], [s, 0, c]]
+    return [[c, s, 0], [-s, c, 0], [0, 0, 1]]
 
 
 def draw_rotations(n: int = N_ROT, batch: int = None) -> torch.Tensor:
-    """n composed random rotations Rz Ry Rx (angles from python `random`, U(-180,180) degrees per axis like torch_geometric's
-    RandomRotate; drawn in the order x, y, z per rotation) -> float32 [n,3,3] ([batch,n,3,3]) on the CPU.  Vectorised."""
-    import numpy as np
+    """The axis rotations of n sampling rounds: per round three matrices in the order the reference draws and applies them
+    (x, y, z; angles U(-180,180) degrees from Python's `random` like torch_geometric's RandomRotate, poco_data_loader.py:90-103)
+    -> float32 [n,3,3,3] ([batch,n,3,3,3]) on the CPU.  The reference draws one triple per round it actually runs; drawing N_ROT
+    of them up front lets all rounds run in one launch (the extra draws only advance Python's random stream)."""
     total = n * (batch or 1)
-    ang = np.array([[random.uniform(-180.0, 180.0) for _ in range(3)] for _ in range(total)]) * (math.pi / 180.0)
-    s, c = np.sin(ang), np.cos(ang)
-    rx, ry, rz = (np.zeros((total, 3, 3)) for _ in range(3))
-    rx[:, 0, 0] = 1; rx[:, 1, 1] = c[:, 0]; rx[:, 1, 2] = s[:, 0]; rx[:, 2, 1] = -s[:, 0]; rx[:, 2, 2] = c[:, 0]
-    ry[:, 1, 1] = 1; ry[:, 0, 0] = c[:, 1]; ry[:, 0, 2] = -s[:, 1]; ry[:, 2, 0] = s[:, 1]; ry[:, 2, 2] = c[:, 1]
-    rz[:, 2, 2] = 1; rz[:, 0, 0] = c[:, 2]; rz[:, 0, 1] = s[:, 2]; rz[:, 1, 0] = -s[:, 2]; rz[:, 1, 1] = c[:, 2]
-    r = torch.from_numpy((rz @ ry @ rx).astype(np.float32))
-    return r.view(batch, n, 3, 3) if batch else r
+    r = torch.tensor([[_axis_rotation(a, math.pi * random.uniform(-180.0, 180.0) / 180.0) for a in (0, 1, 2)] for _ in range(total)],
+                     dtype=torch.float32)
+    return r.view(batch, n, 3, 3, 3) if batch else r
 
 
-def voxel_sample_point_major(pts_pm: torch.Tensor, target: int, rotations: torch.Tensor = None, seed: int = None) -> torch.Tensor:
-    """One cloud [n,3] on the GPU -> int64 [target] ascending, through pps_voxel_sample_f32 (all rounds in one launch)."""
+def _representatives(pos: torch.Tensor, size) -> torch.Tensor:
+    """One representative per occupied voxel of edge `size`: torch_geometric's voxel_grid (grid anchored at the minimum, cell =
+    trunc((pos - start) / size), id = cx + cy*nx + cz*nx*ny) followed by consecutive_cluster's `perm` -- voxels in ascending
+    id order, the LARGEST point index of each voxel (what the sequential CPU scatter_ leaves; oracle/driver_oracle.py)."""
+    start, end = pos.min(dim=0)[0], pos.max(dim=0)[0]
+    nvox = ((end - start) / size).to(torch.long) + 1
+    cell = ((pos - start) / size).to(torch.long)
+    key = cell[:, 0] + cell[:, 1] * nvox[0] + cell[:, 2] * nvox[0] * nvox[1]
+    skey, order = torch.sort(key, stable=True)
+    last = torch.ones_like(skey, dtype=torch.bool)
+    last[:-1] = skey[1:] != skey[:-1]
+    return order[last]
+
+
+def _prio(priority, device):
+    return None if priority is None else priority.to(device=device, dtype=torch.int64).to(torch.int32).contiguous()   # uint32 bit pattern
+
+
+def voxel_sample_point_major(pts_pm: torch.Tensor, target: int, rotations: torch.Tensor = None, seed: int = None, priority=None) -> torch.Tensor:
+    """One cloud [n,3] on the GPU -> int64 [target] ascending, through pps_voxel_sample_f32 (all rounds in one launch).
+    rotations: float32 [R,3,3,3] (draw_rotations); priority: optional integer tensor [n] with values < 2^32."""
     n = pts_pm.shape[0]
-    rot = (draw_rotations() if rotations is None else rotations).to(torch.float32).reshape(-1, 9).contiguous().to(pts_pm.device, non_blocking=True)
+    rot = (draw_rotations() if rotations is None else rotations).to(torch.float32).reshape(-1, 27).contiguous().to(pts_pm.device, non_blocking=True)
     if seed is None:
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    pr = _prio(priority, pts_pm.device)
     out = torch.empty((target,), dtype=torch.int64, device=pts_pm.device)
     _lib.check(_lib.lib().pps_voxel_sample_f32(pts_pm.data_ptr(), n, int(target), ctypes.c_float(-1.0), rot.data_ptr(), rot.shape[0],
-                                               ctypes.c_uint32(seed & 0xffffffff), out.data_ptr(), None,
+                                               ctypes.c_uint32(seed & 0xffffffff), pr.data_ptr() if pr is not None else None, out.data_ptr(), None,
                                                torch.cuda.current_stream(pts_pm.device).cuda_stream), 'pps_voxel_sample_f32')
     return out
 
@@ -96,21 +97,24 @@ def voxel_sample_point_major(pts_pm: torch.Tensor, target: int, rotations: torch
 def voxel_sample_batch_point_major(pts_bpm: torch.Tensor, target: int) -> torch.Tensor:
     """A batch of equally sized clouds [b,n,3] on the GPU -> int64 [b,target], one launch (one workgroup per cloud)."""
     b, n = pts_bpm.shape[0], pts_bpm.shape[1]
-    rot = draw_rotations(batch=b).reshape(b, -1, 9).contiguous().to(pts_bpm.device, non_blocking=True)
+    rot = draw_rotations(batch=b).reshape(b, -1, 27).contiguous().to(pts_bpm.device, non_blocking=True)
     seed = random.getrandbits(31)
     out = torch.empty((b, target), dtype=torch.int64, device=pts_bpm.device)
     _lib.check(_lib.lib().pps_voxel_sample_batch_f32(pts_bpm.data_ptr(), b, n, int(target), rot.data_ptr(), rot.shape[1],
-                                                     ctypes.c_uint32(seed & 0xffffffff), out.data_ptr(), None,
+                                                     ctypes.c_uint32(seed & 0xffffffff), None, out.data_ptr(), None,
                                                      torch.cuda.current_stream(pts_bpm.device).cuda_stream), 'pps_voxel_sample_batch_f32')
     return out
 
 
-def sampling_quantized(pts_batch, ratio=None, n_support=None, support_points=None, support_points_ids=None, _rotations=None):
+def sampling_quantized(pts_batch, ratio=None, n_support=None, support_points=None, support_points_ids=None, _rotations=None, _priority=None):
     """Voxel-stratified random sub-sampling to exactly max(1, int(N*ratio)) points (poco_data_loader.py:59-134):
-    voxel edge = bbox diagonal / sqrt(n), random 3-axis rotation, one point per occupied voxel, remove, halve, repeat;
+    voxel edge = bbox diagonal / sqrt(n), three random axis rotations, one point per occupied voxel, remove, halve, repeat;
     the last round is truncated at random.  Stochastic (python `random`, torch RNG) like the reference.
-    GPU clouds of up to pps_voxel_sample_max_points() points go through the HIP kernel; anything else through the
-    equivalent torch-op loop below (`_rotations`: test hook, one [R,3,3] tensor of rotations shared by both paths)."""
+    GPU clouds of up to pps_voxel_sample_max_points() points go through the HIP kernel (ids ascending); anything else through
+    the torch-op loop below, which on CPU tensors consumes `random` / the torch generator exactly like the reference and
+    returns its ids in its order (tests/test_driver_parity_cpu.py against tests/golden/sampling.npz).
+    Test hooks shared by both paths: `_rotations` [R,3,3,3]; `_priority` integer [N] (< 2^32): the last round keeps the
+    representatives with the smallest priority instead of drawing a permutation."""
     if support_points is not None:
         return support_points, support_points_ids
     assert (ratio is None) != (n_support is None)
@@ -122,20 +126,23 @@ def sampling_quantized(pts_batch, ratio=None, n_support=None, support_points=Non
     if not 0 < target < n:
         raise ValueError('Search Quantized - ratio value error {} should be in ]0,1]'.format(ratio))
     if pts_batch.is_cuda and 2 <= n <= _lib.lib().pps_voxel_sample_max_points():
-        ids = torch.stack([voxel_sample_point_major(_point_major(pts_batch[i]), target, _rotations) for i in range(b)], dim=0)
+        ids = torch.stack([voxel_sample_point_major(_point_major(pts_batch[i]), target, _rotations, priority=_priority) for i in range(b)], dim=0)
         return torch.gather(pts_batch, 2, ids.unsqueeze(1).expand(b, 3, target)), ids
     extent = pts_batch.max(dim=2)[0] - pts_batch.min(dim=2)[0]
-    vox0 = (extent.norm(2, dim=1) / math.sqrt(target)).tolist()
+    vox0 = extent.norm(2, dim=1) / math.sqrt(target)
     all_ids = []
     for i in range(b):
-        pts = pts_batch[i].transpose(0, 1)
+        pts = pts_batch[i].clone().transpose(0, 1)
         ids = torch.arange(pts.shape[0], device=pts.device)
         vox, count, picked = vox0[i], 0, []
         rnd = 0
         while True:
-            rot = ((_rotation(2) @ _rotation(1) @ _rotation(0)) if _rotations is None else _rotations[rnd]).to(pts.device)
+            mats = draw_rotations(1)[0] if _rotations is None else _rotations[rnd]
             rnd += 1
-            perm = _one_per_voxel(pts @ rot.t(), vox)
+            rot = pts
+            for a in range(3):
+                rot = rot @ mats[a].t().to(pts.device, pts.dtype)
+            perm = _representatives(rot, vox)
             if count + perm.shape[0] < target:
                 picked.append(ids[perm])
                 count += perm.shape[0]
@@ -144,8 +151,14 @@ def sampling_quantized(pts_batch, ratio=None, n_support=None, support_points=Non
                 pts, ids = pts[keep], ids[keep]
                 vox = vox / 2
             else:
-                sel = torch.randperm(perm.shape[0], device=pts.device)[:target - count]
-                picked.append(ids[perm[sel]])
+                need = target - count
+                if _priority is None:
+                    sel = perm[torch.randperm(perm.shape[0])[:need].to(perm.device)]
+                else:
+                    cand = ids[perm]
+                    pr = _priority.to(cand.device)[cand].to(torch.int64)
+                    sel = perm[torch.argsort(pr * (n + 1) + cand)[:need]]
+                picked.append(ids[sel])
                 break
         all_ids.append(torch.cat(picked))
     ids = torch.stack(all_ids, dim=0)

@@ -62,6 +62,20 @@ def fill_state_dict(manifest, salt: int = 0) -> dict:
     return {name: fill_param(name, shape, salt) for name, shape in manifest}
 
 
+def network_state_dict(kind: str = 'ppsurf', salt: int = 0, num_pts_local: int = 50, as_torch: bool = True, quiet: bool = True) -> dict:
+    """Formula-filled state dict of a whole network ('ppsurf': PPSurfNetwork(3,256,2,64,P,256), ppsurf_model.py:21-24 with
+    configs/ppsurf.yaml; 'poco': PocoNetwork(3,32,2,64)).  Names and shapes come from this package's own parameter holders
+    (identical to the reference's 455 / 363 entries, tests/test_host_api_cpu.py), so bench.py and smoke() need no fixture file."""
+    import contextlib
+    import io
+    import torch
+    from . import modules
+    with contextlib.redirect_stdout(io.StringIO()) if quiet else contextlib.nullcontext():
+        net = (modules.PPSurfNetwork(3, 256, 2, 64, num_pts_local, 256) if kind == 'ppsurf' else modules.PocoNetwork(3, 32, 2, 64))
+    sd = fill_state_dict([(k, tuple(v.shape)) for k, v in net.state_dict().items()], salt)
+    return {k: torch.from_numpy(v) for k, v in sd.items()} if as_torch else sd
+
+
 def state_dict_digest(sd: dict) -> str:
     """Order-independent digest of a {name: array} dict (names, shapes, bytes)."""
     import hashlib

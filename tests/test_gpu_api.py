@@ -72,8 +72,46 @@ def test_forward_with_precomputed_ids_vs_oracle():
     ref = O.ppsurf_from_latent(sd, dict(data, latents=ref_lat), k=64)
     gdata = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in data.items()}
     out = net.forward(gdata)
-    np.testing.assert_allclose(gdata['latents'].cpu().numpy(), ref_lat.numpy(), rtol=1e-3, atol=2e-4)
-    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-4)
+    np.testing.assert_allclose(gdata['latents'].cpu().numpy(), ref_lat.numpy(), rtol=0, atol=1e-4)     # latents are O(20)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-4)
+
+
+def test_full_size_forward_matches_reference_fixture():
+    """PPSurfNetwork.forward at full size -- FKAConvNetwork(hidden=64) on a 10000-point cloud, 64-NN interpolation, 50-NN
+    patches -- against the REFERENCE's own output (tests/golden/ppsurf_forward.npz): logits within 1e-4 absolute, the
+    north_star's tolerance, end to end through encoder and decoder."""
+    from golden.cases_r2 import forward_case
+    g = load_golden('ppsurf_forward')
+    net = network()
+    data = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in forward_case(g).items()}
+    out = net.forward(data)
+    assert tuple(out.shape) == (1, 2, 256)
+    lat = data['latents'][0, :, ::25].cpu().numpy()
+    err_lat, err = np.abs(lat - g['latents_sub']).max(), np.abs(out.cpu().numpy() - g['logits']).max()
+    print('full-size forward: latents |max| {:.1f} err {:.2e}; logits err {:.2e}'.format(float(g['latents_absmax']), err_lat, err))
+    assert err_lat < 1e-4 and err < 1e-4
+
+
+def test_equal_sized_shapes_do_not_share_the_point_table():
+    """consecutive shapes with the same N get their latents at the same address once the previous tensor
+    is freed; the per-shape table cache must not hand shape i the table of shape i-1."""
+    net = network()
+    g = load_golden('ppsurf_from_latent')
+    base = {'pts': torch.from_numpy(g['cloud'].T.copy()).unsqueeze(0).to(DEV), 'pts_query': torch.from_numpy(g['query']).unsqueeze(0).to(DEV),
+            'pts_local_ps': torch.from_numpy(g['patches']).unsqueeze(0).to(DEV)}
+    outs, ptrs = [], []
+    for seed in (77, 78, 79):
+        lat = torch.from_numpy(make_latents(256, g['cloud'].shape[0], seed)).to(DEV)      # freshly allocated per shape, _version 0
+        ptrs.append(lat.data_ptr())
+        outs.append(net.from_latent(dict(base, latents=lat)).cpu().numpy())
+        del lat
+    np.testing.assert_allclose(outs[0], g['logits'], rtol=0, atol=1e-4)
+    sd = filled_sd('', key='ppsurf')
+    for seed, out in zip((78, 79), outs[1:]):
+        ref = O.ppsurf_from_latent(sd, {'latents': torch.from_numpy(make_latents(256, g['cloud'].shape[0], seed)), 'pts': base['pts'].cpu(),
+                                        'pts_query': base['pts_query'].cpu(), 'pts_local_ps': base['pts_local_ps'].cpu()}, k=64)
+        np.testing.assert_allclose(out, ref.numpy(), rtol=0, atol=1e-4)
+    assert np.abs(outs[1] - outs[0]).max() > 1e-2
 
 
 def test_get_latent_builds_neighbourhoods_on_device():

@@ -26,36 +26,56 @@ def test_sampling_contract_every_level(n):
     assert torch.equal(sup[0], pts[0][:, ids[0]])
 
 
-def test_full_rounds_match_the_torch_reference_of_the_contract():
-    """With the SAME rotations, every point taken in a full round (one representative = smallest index per occupied voxel,
-    grid anchored at the rotated bbox minimum, voxel halved each round) is identical between the HIP kernel and the
-    torch-op loop; only the random truncation of the last round may differ."""
-    random.seed(5)
+def _cases():
+    from golden.cases_r2 import SAMPLING_CASES
+    return [(c[0], c[1]) for c in SAMPLING_CASES]
+
+
+@pytest.mark.parametrize('tag,gen', _cases(), ids=[c[0] for c in _cases()])
+def test_kernel_equals_pinned_oracle_given_rotations_and_priority(tag, gen):
+    """pps_voxel_sample_f32 against the oracle restatement of sampling_quantized (oracle/driver_oracle.py, pinned to the
+    reference's own function by tests/golden/sampling.npz): with the SAME per-round axis rotations and the SAME truncation
+    priorities the selected SET is identical -- every full round (sequential fp32 rotations, voxel grid anchored at the rotated
+    minimum, largest index per voxel, halving) and the truncated last round."""
+    from oracle import driver_oracle as D
+    cloud = gen()
+    n, target = cloud.shape[0], max(1, int(cloud.shape[0] * 0.25))
+    random.seed(n + 3)
     rots = spatial.draw_rotations()
-    rng = np.random.default_rng(3)                       # clustered cloud: the first voxel sizes hold many points per voxel
-    cloud = (rng.uniform(-0.5, 0.5, (200, 1, 3)) + rng.normal(0, 0.004, (200, 50, 3))).reshape(-1, 3).astype(np.float32)
+    prio = torch.from_numpy(np.random.default_rng(n).permutation(n).astype(np.int64))
     pts = torch.from_numpy(cloud.T.copy()).unsqueeze(0)
-    _, ids_k = spatial.sampling_quantized(pts.to(DEV), 0.25, _rotations=rots)
-    # torch-op loop on the CPU (n is small enough for the kernel, so force the fallback by running it on CPU tensors)
-    torch.manual_seed(0)
-    _, ids_t = spatial.sampling_quantized(pts, 0.25, _rotations=rots)
-    a, b = set(ids_k[0].cpu().tolist()), set(ids_t[0].tolist())
-    # replay the full rounds to know which ids are not subject to the random truncation
-    p = torch.from_numpy(cloud)
-    alive = torch.arange(10000)
-    ext = (p.max(0)[0] - p.min(0)[0]).norm(2).item()
-    vox, full, cnt, r = ext / np.sqrt(2500), [], 0, 0
-    while True:
-        perm = spatial._one_per_voxel(p[alive] @ rots[r].t(), vox)
-        if cnt + perm.shape[0] < 2500:
-            full += alive[perm].tolist(); cnt += perm.shape[0]
-            keep = torch.ones(alive.shape[0], dtype=torch.bool); keep[perm] = False
-            alive = alive[keep]; vox /= 2; r += 1
-        else:
-            last = set(alive[perm].tolist())
-            break
-    assert r >= 2 and len(full) > 500 and set(full) <= a and set(full) <= b      # several full rounds happened
-    assert (a - set(full)) <= last and (b - set(full)) <= last and len(a) == len(b) == 2500
+    _, ids_k = spatial.sampling_quantized(pts.to(DEV), 0.25, _rotations=rots, _priority=prio)
+    ref, rounds = D.sampling_quantized_ids(cloud, target, rotations=[list(r.numpy()) for r in rots], priority=prio.numpy().astype(np.uint32),
+                                           return_rounds=True)
+    got = ids_k[0].cpu().numpy()
+    assert np.array_equal(got, np.sort(ref)), '{}: {} rounds, {} ids differ'.format(tag, len(rounds), len(set(got) ^ set(ref)))
+    # the product's torch-op path (used for clouds beyond the kernel's size limit) gives the same set, in the reference's order
+    _, ids_t = spatial.sampling_quantized(pts, 0.25, _rotations=rots, _priority=prio)
+    assert np.array_equal(ids_t[0].numpy(), ref)
+
+
+def test_kernel_hash_truncation_is_uniform():
+    """Without priorities the last round is ranked by a hash of (seed, index): over many seeds every representative of the
+    last round is kept about equally often (the reference draws torch.randperm there, poco_data_loader.py:123)."""
+    from oracle import driver_oracle as D
+    cloud = make_cloud(2500, seed=22)
+    random.seed(9)
+    rots = spatial.draw_rotations()
+    _, rounds = D.sampling_quantized_ids(cloud, 625, rotations=[list(r.numpy()) for r in rots], priority=np.zeros(2500, np.uint32),
+                                         return_rounds=True)
+    full = set(np.concatenate(rounds[:-1]).tolist()) if len(rounds) > 1 else set()
+    last = np.array(sorted(rounds[-1].tolist()))
+    need = 625 - len(full)
+    pm = torch.from_numpy(cloud).to(DEV)
+    hits = np.zeros(2500)
+    trials = 400
+    for s in range(trials):
+        ids = spatial.voxel_sample_point_major(pm, 625, rots, seed=1000 + 7919 * s).cpu().numpy()
+        assert full <= set(ids.tolist()) and set(ids.tolist()) - full <= set(last.tolist())
+        hits[ids] += 1
+    p = need / last.shape[0]
+    freq = hits[last] / trials
+    assert abs(freq.mean() - p) < 1e-9 and freq.std() < 2.0 * np.sqrt(p * (1 - p) / trials)
 
 
 def test_stratification_is_better_than_random():
