@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), 'libppsurf_amd.so does not export ' + name
     assert declared == set(_lib.SIGNATURES.keys())
-    assert lib.pps_abi_version() == 1
+    assert lib.pps_abi_version() == 2
 
 
 def test_pack_roundtrip_and_padding():
