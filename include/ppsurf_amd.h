@@ -154,6 +154,12 @@ int pps_decode_tail_f32(const float* pooled, const float* xbar, int64_t q, const
 size_t pps_decode_ws_bytes(int64_t q);
 int pps_decode_fwd_f32(const float* table, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
                        const float* patches, int p, const float* const* weights, float* logits, float* occ, void* ws, void* stream);
+/* The same call with measurement marks: events is a [host] array of 6 hipEvent_t (entries may be NULL) recorded on `stream`
+ * before the first launch and after each of the five kernels (interp_pool, stn_rows, stn_fc, feat_rows, tail), so that the
+ * per-kernel durations of the PRODUCT call can be read with hipEventElapsedTime (bench.py's roofline leg). */
+int pps_decode_fwd_events_f32(const float* table, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
+                              const float* patches, int p, const float* const* weights, float* logits, float* occ, void* ws,
+                              void* const* events, void* stream);
 
 /* ---- FKAConv encoder (eval mode), point-major activations, one batch item per call ----------------- */
 

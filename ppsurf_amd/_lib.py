@@ -35,6 +35,7 @@ SIGNATURES = {
     'pps_decode_tail_f32': (_I, [_P, _P, _I64, _P, _P, _P, _P, _P]),
     'pps_decode_ws_bytes': (_SZ, [_I64]),
     'pps_decode_fwd_f32': (_I, [_P, _P, _P, _P, _I64, _I, _P, _I, _P, _P, _P, _P, _P]),
+    'pps_decode_fwd_events_f32': (_I, [_P, _P, _P, _P, _I64, _I, _P, _I, _P, _P, _P, _P, _P, _P]),
     'pps_fkaconv_geo_floats': (_SZ, []),
     'pps_fkaconv_ws_bytes': (_SZ, [_I64, _I]),
     'pps_fkaconv_fwd_f32': (_I, [_P, _P, _P, _P, _I64, _I64, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),

@@ -978,8 +978,9 @@ int pps_decode_tail_f32(const float* pooled, const float* xbar, int64_t q, const
 /* The whole decoder of one query chunk in one call: the five launches above on `stream`, intermediates in caller scratch. */
 size_t pps_decode_ws_bytes(int64_t q) { return q < 0 ? 0 : (size_t)q * (256 + 256 + 4096 + 256) * sizeof(float); }
 
-int pps_decode_fwd_f32(const float* table, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
-                       const float* patches, int p, const float* const* weights, float* logits, float* occ, void* ws, void* stream) {
+static int decode_fwd(const float* table, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
+                      const float* patches, int p, const float* const* weights, float* logits, float* occ, void* ws, void* const* events,
+                      void* stream) {
     if (q < 0) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
     if (!weights || !ws || !logits) return PPS_ERR_ARG;
@@ -989,12 +990,32 @@ int pps_decode_fwd_f32(const float* table, const float* pts, const float* query,
     float* g = pooled + q * 256;
     float* trans2 = g + q * 256;
     float* xbar = trans2 + q * 4096;
+    hipStream_t st = (hipStream_t)stream;
+#define PPS_MARK(i) do { if (events && events[i] && hipEventRecord((hipEvent_t)events[i], st) != hipSuccess) return PPS_ERR_LAUNCH; } while (0)
+    PPS_MARK(0);
     int rc = pps_interp_pool_f32(table, pts, query, idx, q, k, weights[0], weights[1], pooled, stream);
+    PPS_MARK(1);
     if (rc == PPS_OK) rc = pps_pointnet_stn_rows_f32(patches, q, p, weights[2], weights[3], g, stream);
+    PPS_MARK(2);
     if (rc == PPS_OK) rc = pps_pointnet_stn_fc_f32(g, q, weights[4], weights[5], trans2, stream);
+    PPS_MARK(3);
     if (rc == PPS_OK) rc = pps_pointnet_feat_rows_f32(patches, trans2, q, p, weights[6], weights[7], xbar, stream);
+    PPS_MARK(4);
     if (rc == PPS_OK) rc = pps_decode_tail_f32(pooled, xbar, q, weights[8], weights[9], logits, occ, stream);
+    PPS_MARK(5);
+#undef PPS_MARK
     return rc;
+}
+
+int pps_decode_fwd_f32(const float* table, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
+                       const float* patches, int p, const float* const* weights, float* logits, float* occ, void* ws, void* stream) {
+    return decode_fwd(table, pts, query, idx, q, k, patches, p, weights, logits, occ, ws, nullptr, stream);
+}
+
+int pps_decode_fwd_events_f32(const float* table, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
+                              const float* patches, int p, const float* const* weights, float* logits, float* occ, void* ws,
+                              void* const* events, void* stream) {
+    return decode_fwd(table, pts, query, idx, q, k, patches, p, weights, logits, occ, ws, events, stream);
 }
 
 }  // extern "C"

@@ -163,47 +163,27 @@ class DecoderPlan:
                                                     self.w['g_b'].data_ptr(), out.data_ptr(), st), 'pps_rows_dense256_f32')
         return out
 
-    def decode(self, table, pts, query, idx, patches, want_occ=True, interp_events=None):
-        """table G [N,256]; pts [N,3]; query [Q,3]; idx int64 [Q,k]; patches [Q,P,3] -> (logits [Q,2], occ [Q] | None).
-        interp_events: optional (start, end) torch.cuda.Event pair recorded around the dominant kernel (bench.py)."""
+    def decode(self, table, pts, query, idx, patches, want_occ=True, stage_events=None):
+        """table G [N,256]; pts [N,3]; query [Q,3]; idx int64 [Q,k]; patches [Q,P,3] -> (logits [Q,2], occ [Q] | None): the whole
+        chunk in one C call (pps_decode_fwd_f32).  stage_events: optional ctypes array of 6 hipEvent_t handles recorded around
+        the five kernels of that same call (pps_decode_fwd_events_f32; bench.py)."""
         L = _lib.lib()
         q, k, p = query.shape[0], idx.shape[1], patches.shape[1]
         for t in (table, pts, query, idx, patches):
             assert t.is_contiguous() and t.device == self.device
         st = torch.cuda.current_stream(self.device).cuda_stream
-        if interp_events is None:                                   # product path: the whole chunk in one C call
-            import ctypes
-            logits = torch.empty((q, 2), dtype=torch.float32, device=self.device)
-            occ = torch.empty((q,), dtype=torch.float32, device=self.device) if want_occ else None
-            ws = self.scratch('decode_ws', (L.pps_decode_ws_bytes(q) // 4,))
-            if getattr(self, '_wptrs', None) is None:
-                self._wptrs = (ctypes.c_void_p * 10)(*[self.w[n].data_ptr() for n in ('ip_w', 'ip_b', 'pa_w', 'pa_b', 'pb_w', 'pb_b', 'pc_w',
-                                                                                      'pc_b', 'tl_w', 'tl_b')])
-            _lib.check(L.pps_decode_fwd_f32(table.data_ptr(), pts.data_ptr(), query.data_ptr(), idx.data_ptr(), q, k, patches.data_ptr(), p,
-                                            self._wptrs, logits.data_ptr(), occ.data_ptr() if want_occ else None, ws.data_ptr(), st),
-                       'pps_decode_fwd_f32')
-            return logits, occ
-        pooled = self.scratch('pooled', (q, C))
-        g = self.scratch('g', (q, C))
-        trans2 = self.scratch('trans2', (q, 4096))
-        xbar = self.scratch('xbar', (q, C))
         logits = torch.empty((q, 2), dtype=torch.float32, device=self.device)
         occ = torch.empty((q,), dtype=torch.float32, device=self.device) if want_occ else None
-        w = self.w
-        if interp_events is not None:
-            interp_events[0].record()
-        _lib.check(L.pps_interp_pool_f32(table.data_ptr(), pts.data_ptr(), query.data_ptr(), idx.data_ptr(), q, k,
-                                         w['ip_w'].data_ptr(), w['ip_b'].data_ptr(), pooled.data_ptr(), st), 'pps_interp_pool_f32')
-        if interp_events is not None:
-            interp_events[1].record()
-        _lib.check(L.pps_pointnet_stn_rows_f32(patches.data_ptr(), q, p, w['pa_w'].data_ptr(), w['pa_b'].data_ptr(),
-                                               g.data_ptr(), st), 'pps_pointnet_stn_rows_f32')
-        _lib.check(L.pps_pointnet_stn_fc_f32(g.data_ptr(), q, w['pb_w'].data_ptr(), w['pb_b'].data_ptr(), trans2.data_ptr(), st),
-                   'pps_pointnet_stn_fc_f32')
-        _lib.check(L.pps_pointnet_feat_rows_f32(patches.data_ptr(), trans2.data_ptr(), q, p, w['pc_w'].data_ptr(),
-                                                w['pc_b'].data_ptr(), xbar.data_ptr(), st), 'pps_pointnet_feat_rows_f32')
-        _lib.check(L.pps_decode_tail_f32(pooled.data_ptr(), xbar.data_ptr(), q, w['tl_w'].data_ptr(), w['tl_b'].data_ptr(),
-                                         logits.data_ptr(), occ.data_ptr() if want_occ else None, st), 'pps_decode_tail_f32')
+        ws = self.scratch('decode_ws', (L.pps_decode_ws_bytes(q) // 4,))
+        if getattr(self, '_wptrs', None) is None:
+            self._wptrs = (ctypes.c_void_p * 10)(*[self.w[n].data_ptr() for n in ('ip_w', 'ip_b', 'pa_w', 'pa_b', 'pb_w', 'pb_b', 'pc_w',
+                                                                                  'pc_b', 'tl_w', 'tl_b')])
+        args = (table.data_ptr(), pts.data_ptr(), query.data_ptr(), idx.data_ptr(), q, k, patches.data_ptr(), p, self._wptrs,
+                logits.data_ptr(), occ.data_ptr() if want_occ else None, ws.data_ptr())
+        if stage_events is None:
+            _lib.check(L.pps_decode_fwd_f32(*args, st), 'pps_decode_fwd_f32')
+        else:
+            _lib.check(L.pps_decode_fwd_events_f32(*args, stage_events, st), 'pps_decode_fwd_events_f32')
         return logits, occ
 
 
@@ -238,7 +218,7 @@ class ChunkPipeline:
             self.raw_blocks.query(q, self.p, out=src)
         self.ops.patch_normalize(self.raw, q, src, self.p, out=self.patches[b][:m])
 
-    def run(self, chunks, want_occ=True, interp_events=None):
+    def run(self, chunks, want_occ=True, stage_events=None):
         """chunks: list of contiguous float32 [q_i,3] device tensors -> list of (logits, occ)."""
         main = torch.cuda.current_stream(self.plan.device)
         out = []
@@ -254,8 +234,8 @@ class ChunkPipeline:
             else:
                 self._spatial(q, b)
             m = q.shape[0]
-            ev = interp_events[i] if interp_events is not None else None
-            out.append(self.plan.decode(self.table, self.pts, q, self.idx[b][:m], self.patches[b][:m], want_occ=want_occ, interp_events=ev))
+            ev = stage_events[i] if stage_events is not None else None
+            out.append(self.plan.decode(self.table, self.pts, q, self.idx[b][:m], self.patches[b][:m], want_occ=want_occ, stage_events=ev))
             self.free[b].record(main)
         self.n += len(chunks)
         return out

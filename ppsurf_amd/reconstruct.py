@@ -70,6 +70,9 @@ class OccupancyField:
         return torch.cat(out)
 
 
+FIELD_CLASS = OccupancyField          # measurement workloads substitute a subclass (ppsurf_amd/workloads.py)
+
+
 def create_volume(field, pts_ids: torch.Tensor, resolution: int, step: float, bmin_pad: float, padding=1, dilation_size=2,
                   out_value=1.0, progress=None):
     """Region growing (poco_utils.py:178-254).  pts_ids int64 [n,3] voxel ids of the input points (device).
@@ -155,7 +158,7 @@ def export_mesh_and_refine_vertices_region_growing_v3(network, latent: dict, pts
     progress = None
     if prog_bar is not None and getattr(prog_bar, 'predict_progress_bar', None) is not None:
         progress = lambda s: prog_bar.predict_progress_bar.set_postfix_str('{}, {}'.format(pc_file_in[-24:], s), refresh=True)
-    field = OccupancyField(network, latent, pts_raw_ms, num_pts, num_pts_local)
+    field = FIELD_CLASS(network, latent, pts_raw_ms, num_pts, num_pts_local)
     dev = field.dev
     input_points = np.asarray(input_points)
     bmin, bmax = input_points.min(), input_points.max()

@@ -3,6 +3,8 @@ xGMI on the GPU box, 'gloo' in the CPU tests).
 
 Queries are independent given the replicated per-shape state (cloud + per-point table, ~104 MB), so the data path needs a
 single exchange per growth round: a variable-length all-gather of 4 bytes per query."""
+import contextlib
+
 import torch
 
 
@@ -30,23 +32,66 @@ def shard_range(n: int, rank: int, world_size: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def sharded_map(fn, items: torch.Tensor) -> torch.Tensor:
+MIN_SHARD = 8192        # a rank never gets fewer queries than this: the persistent decoder kernels need ~8k queries to fill 256 CUs
+STATS = {'collective_events': None, 'calls': 0, 'items': 0}
+
+
+def profile_collectives(on: bool):
+    """Record a (start, end) CUDA event pair around every data-path collective (read with collective_seconds())."""
+    STATS['collective_events'] = [] if on else None
+    STATS['calls'], STATS['items'] = 0, 0
+
+
+def collective_seconds() -> float:
+    ev = STATS['collective_events'] or []
+    if ev:
+        torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in ev) * 1e-3
+
+
+@contextlib.contextmanager
+def _timed_collective(device):
+    ev = STATS['collective_events']
+    if ev is None or torch.device(device).type != 'cuda':
+        yield
+        return
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    yield
+    b.record()
+    ev.append((a, b))
+
+
+def shard_ranges(n: int, world_size: int, min_shard: int = None):
+    """[lo, hi) of every rank: the first `active` ranks share the n items evenly, where `active` is the largest rank count that
+    keeps every share >= min_shard (at least one rank); the others get empty ranges."""
+    min_shard = MIN_SHARD if min_shard is None else min_shard
+    active = max(1, min(world_size, n // max(1, min_shard)))
+    out = [shard_range(n, r, active) if r < active else (n, n) for r in range(world_size)]
+    return out
+
+
+def sharded_map(fn, items: torch.Tensor, min_shard: int = None) -> torch.Tensor:
     """Every rank evaluates fn on its contiguous slice of `items` [n, ...] (fn returns one float32 per item) and all
-    ranks receive the concatenated result [n] in the original order."""
+    ranks receive the concatenated result [n] in the original order: one all-gather of 4 bytes per item.
+    Small lists are not split below MIN_SHARD items per rank (ranks without a share only take part in the collective)."""
     import torch.distributed as dist
     rank, ws = world()
     n = items.shape[0]
     if ws == 1 or not _QUERY_SHARDING:
         return fn(items)
-    lo, hi = shard_range(n, rank, ws)
-    local = fn(items[lo:hi]).to(torch.float32).contiguous()
-    width = -(-n // ws)
-    pad = torch.zeros((width,), dtype=torch.float32, device=local.device)
-    pad[:hi - lo] = local
+    ranges = shard_ranges(n, ws, min_shard)
+    lo, hi = ranges[rank]
+    width = max(h - l for l, h in ranges)
+    pad = torch.zeros((max(width, 1),), dtype=torch.float32, device=items.device)
+    if hi > lo:
+        pad[:hi - lo] = fn(items[lo:hi]).to(torch.float32)
     parts = [torch.empty_like(pad) for _ in range(ws)]
-    dist.all_gather(parts, pad)
-    out = [parts[r][:shard_range(n, r, ws)[1] - shard_range(n, r, ws)[0]] for r in range(ws)]
-    return torch.cat(out)
+    with _timed_collective(items.device):
+        dist.all_gather(parts, pad)
+    STATS['calls'] += 1
+    STATS['items'] += n
+    return torch.cat([parts[r][:h - l] for r, (l, h) in enumerate(ranges)])
 
 
 def max_over_ranks(seconds: float, device) -> float:
@@ -85,8 +130,9 @@ def allreduce_latents(latent_sum: torch.Tensor, counts: torch.Tensor):
     import torch.distributed as dist
     _, ws = world()
     if ws > 1:
-        dist.all_reduce(latent_sum, op=dist.ReduceOp.SUM)
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        with _timed_collective(latent_sum.device):
+            dist.all_reduce(latent_sum, op=dist.ReduceOp.SUM)
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     return latent_sum, counts
 
 

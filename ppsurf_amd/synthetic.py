@@ -98,15 +98,39 @@ def normalize_cloud(pts: np.ndarray, padding_factor: float = 0.05) -> np.ndarray
     return ((pts - centre) / scale).astype(np.float32)
 
 
-def make_cloud(n: int, seed: int = 42, noise: float = 0.005) -> np.ndarray:
-    """Bumpy sphere, float32 [n,3] inside the unit box."""
+def _bumpy_radius(d):
+    """Radius of the synthetic shape along unit directions d [..,3] (numpy array or torch tensor)."""
+    if isinstance(d, np.ndarray):
+        sin, cos = np.sin, np.cos
+    else:
+        import torch
+        sin, cos = torch.sin, torch.cos
+    return 0.45 * (1.0 + 0.08 * sin(3.0 * d[..., 0]) * cos(2.0 * d[..., 1]) + 0.05 * sin(5.0 * d[..., 2]) + 0.04 * cos(4.0 * d[..., 0] + 1.0))
+
+
+def make_cloud(n: int, seed: int = 42, noise: float = 0.005, return_norm: bool = False):
+    """Bumpy sphere, float32 [n,3] inside the unit box.  return_norm: also (centre [3], scale) of the
+    normalisation, for `bumpy_occupancy`."""
     rng = np.random.default_rng(seed)
     d = rng.standard_normal((n, 3))
     d /= np.linalg.norm(d, axis=1, keepdims=True)
-    r = 0.45 * (1.0 + 0.08 * np.sin(3.0 * d[:, 0]) * np.cos(2.0 * d[:, 1]) + 0.05 * np.sin(5.0 * d[:, 2])
-                + 0.04 * np.cos(4.0 * d[:, 0] + 1.0))
-    pts = d * r[:, None] + noise * rng.standard_normal((n, 3))
-    return normalize_cloud(pts)
+    pts = d * _bumpy_radius(d)[:, None] + noise * rng.standard_normal((n, 3))
+    out = normalize_cloud(pts)
+    if return_norm:
+        bb_min, bb_max = pts.min(axis=0), pts.max(axis=0)
+        return out, ((bb_min + bb_max) * 0.5, float((bb_max - bb_min).max()) * 1.05)
+    return out
+
+
+def bumpy_occupancy(q, norm):
+    """Analytic stand-in occupancy of the make_cloud shape at normalised query points q [m,3] (torch tensor): > 0 inside,
+    magnitude ~ distance to the surface along the ray from the centre.  Used to STEER region growing / refinement in timing
+    workloads (formula-filled weights describe no surface); never a network output."""
+    import torch
+    centre, scale = norm
+    p = q.double() * scale + torch.as_tensor(centre, dtype=torch.float64, device=q.device)
+    r = torch.linalg.norm(p, dim=1).clamp_min(1e-12)
+    return ((_bumpy_radius(p / r[:, None]) - r) / scale).to(torch.float32)
 
 
 def make_band_queries(pts: np.ndarray, m: int, resolution: int = 257, seed: int = 1, spread: int = 2) -> np.ndarray:

@@ -1,0 +1,171 @@
+"""Synthetic MEASUREMENT workloads on top of the product path (bench.py, tools/): nothing here is used by predict / fit.
+
+  band_chunks            the query list of the FIRST region-growing round of a cloud (every voxel within +-2 of a voxel that holds
+                         an input point, poco_utils.py:181-213), cut into rec_batch_size chunks
+  SteeredField           OccupancyField whose RESULT is replaced by the analytic occupancy of the synthetic shape after the real
+                         kernels have decoded the chunk: formula-filled weights describe no surface, so region growing would stop
+                         after one round; with the steering the query counts are those of a real shape of that geometry
+  reconstruct_steered    one whole reconstruction (latent loop, region growing, Marching Cubes, clean-up, 10 refinement rounds)
+  FitStep                one optimisation step at BASELINE config 3 (B shapes x 10k points, 2000 queries, P = 50)
+  HipEvents              hipEvent_t handles for timing kernels INSIDE a C-ABI call (pps_decode_fwd_events_f32)
+"""
+import contextlib
+import ctypes
+import io
+import time
+
+import numpy as np
+import torch
+
+from . import reconstruct, spatial, synthetic
+
+
+class HipEvents:
+    """n hipEvent_t created through the HIP runtime (the library torch has already loaded)."""
+    _hip = None
+
+    def __init__(self, n):
+        if HipEvents._hip is None:
+            HipEvents._hip = ctypes.CDLL('libamdhip64.so')
+        self.n = n
+        self.arr = (ctypes.c_void_p * n)()
+        for i in range(n):
+            ev = ctypes.c_void_p()
+            if HipEvents._hip.hipEventCreate(ctypes.byref(ev)) != 0:
+                raise RuntimeError('hipEventCreate failed')
+            self.arr[i] = ev
+
+    def elapsed_ms(self, i, j):
+        ms = ctypes.c_float()
+        rc = HipEvents._hip.hipEventElapsedTime(ctypes.byref(ms), ctypes.c_void_p(self.arr[i]), ctypes.c_void_p(self.arr[j]))
+        if rc != 0:
+            raise RuntimeError('hipEventElapsedTime failed ({})'.format(rc))
+        return ms.value
+
+    def __del__(self):
+        try:
+            for i in range(self.n):
+                HipEvents._hip.hipEventDestroy(ctypes.c_void_p(self.arr[i]))
+        except Exception:
+            pass
+
+
+def grid_geometry(cloud: np.ndarray, resolution: int, padding: int = 1):
+    """poco_utils.py:52-61: scalar bounds, step, padded origin, voxel ids of the input points."""
+    bmin, bmax = cloud.min(), cloud.max()
+    step = (bmax - bmin) / (resolution - 1)
+    bmin_pad = bmin - padding * step
+    pts_ids = ((cloud - bmin) / step + padding).astype(np.int32).astype(np.int64)
+    return step, bmin_pad, pts_ids
+
+
+def band_chunks(cloud: np.ndarray, resolution: int, chunk: int, device, full_only: bool = True):
+    """The first growth round of create_volume for `cloud`: all voxels of the (R+2)^3 grid within +-2 of an occupied voxel, in
+    index order, as float32 coordinates, cut into chunks of `chunk` queries (only full chunks when full_only)."""
+    step, bmin_pad, pts_ids = grid_geometry(cloud, resolution)
+    n = resolution + 2
+    ids = torch.from_numpy(pts_ids).to(device)
+    seeds = torch.zeros((n, n, n), dtype=torch.bool, device=device)
+    seeds[ids[:, 0], ids[:, 1], ids[:, 2]] = True
+    coords = torch.nonzero(reconstruct._dilate(seeds, 2))
+    q = coords.to(torch.float32) * np.float32(step) + np.float32(bmin_pad)
+    chunks = [q[s:s + chunk].contiguous() for s in range(0, q.shape[0], chunk)]
+    if full_only and chunks and chunks[-1].shape[0] < chunk:
+        chunks.pop()
+    return chunks, int(q.shape[0])
+
+
+class SteeredField(reconstruct.OccupancyField):
+    norm = None                                     # (centre, scale) of the synthetic cloud, set by the caller
+
+    def __call__(self, q):
+        super().__call__(q)                         # the real kNN + patches + decoder; result discarded
+        return synthetic.bumpy_occupancy(q, self.norm)
+
+
+def make_model(resolution=257, p=50, chunk=50000, device='cuda:0'):
+    from .lightning_api import PPSurfModel
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = PPSurfModel(pointnet_latent_size=256, output_names=['imp_surf_sign'], in_channels=3, out_channels=2, k=64, lambda_l1=0.0,
+                            debug=False, in_file='x.npy', results_dir='/tmp/res', padding_factor=0.05, name='bench', network_latent_size=256,
+                            gen_subsample_manifold_iter=10, gen_subsample_manifold=10000, gen_resolution_global=resolution, num_pts_local=p,
+                            rec_batch_size=chunk, gen_refine_iter=10, workers=1)
+    model.network.load_state_dict(synthetic.network_state_dict('ppsurf', num_pts_local=p))
+    return model.to(device).eval()
+
+
+def reconstruct_steered(model, n_points=100_000, seed=42, device='cuda:0'):
+    """One reconstruction with the product's own driver (encode_latents + export_mesh_and_refine_vertices_region_growing_v3),
+    every query decoded by the real kernels, growth steered by the analytic shape.  Returns a dict of seconds / counts."""
+    cloud, norm = synthetic.make_cloud(n_points, seed=seed, noise=0.0, return_norm=True)
+    cloud_t = torch.from_numpy(cloud).to(device)
+    pts_cf = cloud_t.t().contiguous()
+    SteeredField.norm = norm
+    fields = []
+
+    class _Field(SteeredField):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            fields.append(self)
+
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    lat = model.encode_latents(pts_cf)
+    torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    shape = {'pts': pts_cf.unsqueeze(0), 'latents': lat.t().unsqueeze(0)}
+    old = reconstruct.FIELD_CLASS
+    reconstruct.FIELD_CLASS = _Field
+    try:
+        mesh = reconstruct.export_mesh_and_refine_vertices_region_growing_v3(
+            network=model.network, latent=shape, pts_raw_ms=cloud_t.unsqueeze(0), resolution=model.gen_resolution_global, padding=1,
+            mc_value=0, num_pts=model.rec_batch_size, num_pts_local=model.num_pts_local, input_points=cloud,
+            refine_iter=model.gen_refine_iter, out_value=1)
+    finally:
+        reconstruct.FIELD_CLASS = old
+    torch.cuda.synchronize(device)
+    t2 = time.perf_counter()
+    verts, faces = mesh if mesh is not None else (np.zeros((0, 3)), np.zeros((0, 3)))
+    return {'latent_s': t1 - t0, 'surface_s': t2 - t1, 'total_s': t2 - t0, 'decoder_queries': fields[0].n_queries if fields else 0,
+            'vertices': int(verts.shape[0]), 'faces': int(faces.shape[0])}
+
+
+class FitStep:
+    """BASELINE config 3 on one GPU: B shapes x 10 000 points, 2000 queries per shape, P = 50; id tables and patches are built
+    on the device inside the step (what the reference's dataset workers do on the CPU), then forward, loss, backward, AdamW."""
+
+    def __init__(self, batch=10, n=10000, q=2000, p=50, precision='bf16-mixed', device='cuda:0', n_batches=2):
+        from . import modules
+        self.p, self.dev = p, torch.device(device)
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = modules.PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=p, pointnet_latent_size=256)
+        net.load_state_dict(synthetic.network_state_dict('ppsurf', num_pts_local=p))
+        self.net = net.to(self.dev).train()
+        self.opt = torch.optim.AdamW(self.net.parameters(), lr=1e-3, eps=1e-5, weight_decay=1e-2)       # configs/poco.yaml:60-69
+        self.autocast = {'bf16-mixed': torch.bfloat16, '16-mixed': torch.float16}.get(precision)
+        self.batches = [self._raw_batch(batch, n, q, s) for s in range(n_batches)]
+        self.i = 0
+
+    def _raw_batch(self, b, n, q, seed):
+        rng = np.random.default_rng(seed)
+        pts, qry, dist = [], [], []
+        for i in range(b):
+            c = synthetic.make_cloud(n, seed=seed * 100 + i)
+            qq = (c[rng.choice(n, q)] + rng.normal(0, 0.02, (q, 3))).astype(np.float32)
+            pts.append(c); qry.append(qq); dist.append((0.4 - np.linalg.norm(qq, axis=1)).astype(np.float32))
+        return {'pts_ms': torch.from_numpy(np.stack(pts)).to(self.dev), 'pts_query_ms': torch.from_numpy(np.stack(qry)).to(self.dev),
+                'imp_surf_dist_ms': torch.from_numpy(np.stack(dist)).to(self.dev)}
+
+    def __call__(self):
+        batch = dict(self.batches[self.i % len(self.batches)])
+        self.i += 1
+        b = batch['pts_ms'].shape[0]
+        batch['pts_local_ps'] = spatial.get_pts_local_ps_batch([batch['pts_ms'][i] for i in range(b)], batch['pts_query_ms'], self.p)
+        batch = spatial.get_data_poco(batch)
+        self.opt.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=self.autocast or torch.bfloat16, enabled=self.autocast is not None):
+            logits = self.net.forward(batch)
+            loss = torch.nn.functional.cross_entropy(logits.float(), batch['occ'], reduction='none').mean()
+        loss.backward()
+        self.opt.step()
+        return loss

@@ -21,6 +21,7 @@ def _worker(rank, world, port, out_dir):
     from ppsurf_amd import sharding
     from ppsurf_amd.reconstruct import create_volume
     sharding.set_query_sharding(True)
+    sharding.MIN_SHARD = 1                                   # tiny lists here: let every rank take its share
     g = load_golden('create_volume')
     seen = []
 
@@ -109,3 +110,50 @@ def test_two_rank_gradient_buckets_equal_full_batch_gradients(tmp_path):
     assert np.array_equal(r0['g0'], r1['g0']) and np.array_equal(r0['g1'], r1['g1']) and np.array_equal(r0['w'], r1['w'])
     assert r0['unused_none0'].all() and r0['unused_none1'].all()
     assert np.array_equal(r0['w'][-w_unused0.size:], w_unused0)              # untouched by AdamW's weight decay
+
+
+def _four_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ppsurf_amd import sharding
+    sharding.set_query_sharding(True)
+    out = {}
+    for tag, n, floor in (('uneven', 1003, 1), ('floor', 1003, 400), ('one', 50, 400), ('empty', 0, 1)):
+        seen = []
+
+        def fn(x):
+            seen.append(x.shape[0])
+            return x[:, 0] * 3 + rank * 0              # value independent of the rank that computed it
+        items = torch.arange(n, dtype=torch.float32).view(n, 1)
+        res = sharding.sharded_map(fn, items, min_shard=floor) if n else sharding.sharded_map(fn, items.view(0, 1), min_shard=floor)
+        out[tag] = res.numpy()
+        out[tag + '_seen'] = np.array(sum(seen))
+    lat = torch.full((7, 2), float(rank)); cnt = torch.full((7,), 1.0)
+    sharding.allreduce_latents(lat, cnt)
+    out['lat'], out['cnt'] = lat.numpy(), cnt.numpy()
+    out['wm'] = np.array(sharding.weighted_mean_over_ranks(float(rank + 1) * (rank % 2), rank % 2, 'cpu'))      # ranks 0, 2 have no batches
+    np.savez(os.path.join(out_dir, 'f{}.npz'.format(rank)), **out)
+    dist.destroy_process_group()
+
+
+def test_four_ranks_uneven_ranges_and_chunk_floor(tmp_path):
+    """world_size 4 over gloo: contiguous ranges that differ by one item, the per-rank floor (a rank never decodes fewer than
+    MIN_SHARD queries; the others only join the collective), empty lists, and the weighted validation mean."""
+    from ppsurf_amd.sharding import shard_ranges
+    assert shard_ranges(1003, 4, 1) == [(0, 251), (251, 502), (502, 753), (753, 1003)]
+    assert shard_ranges(1003, 4, 400) == [(0, 502), (502, 1003), (1003, 1003), (1003, 1003)]
+    assert shard_ranges(50, 4, 400) == [(0, 50), (50, 50), (50, 50), (50, 50)]
+    assert shard_ranges(100_000, 8) [3] == (37500, 50000) and shard_ranges(20_000, 8)[2] == (20000, 20000)
+    port = 33000 + os.getpid() % 2000
+    mp.spawn(_four_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    r = [np.load(tmp_path / 'f{}.npz'.format(i)) for i in range(4)]
+    for i in range(4):
+        assert np.array_equal(r[i]['uneven'], np.arange(1003) * 3.0) and np.array_equal(r[i]['floor'], np.arange(1003) * 3.0)
+        assert np.array_equal(r[i]['one'], np.arange(50) * 3.0) and r[i]['empty'].shape == (0,)
+        assert (r[i]['lat'] == 6.0).all() and (r[i]['cnt'] == 4.0).all()
+        assert float(r[i]['wm']) == (2.0 + 4.0) / 2
+    assert [int(r[i]['uneven_seen']) for i in range(4)] == [251, 251, 251, 250]
+    assert [int(r[i]['floor_seen']) for i in range(4)] == [502, 501, 0, 0]
+    assert [int(r[i]['one_seen']) for i in range(4)] == [50, 0, 0, 0]
