@@ -239,20 +239,25 @@ class PocoModel(_Base):
 
     # ---- reconstruction (poco_model.py:183-273) -----------------------------------------------------------------
     @staticmethod
-    def _draw_subset(covered, current_value, m, gen=None):
+    def _draw_subset(covered, current_value, m, gen=None, device_rng=False):
         """The ids of one encoder pass (poco_model.py:210-224), or None when every point has been covered `current_value + 1`
         times.  All counts are >= current_value when round `current_value` runs, so the reference's loop condition
         `counts.min() < current_value + 1` (:209) is the same as "valid_ids is not empty" -- the nonzero() below is the only host
         synchronisation of a pass.  Random numbers as in the reference: the subset permutation comes from the CPU generator
         (`torch.randperm(valid_ids.shape[0])`, :213), the top-up permutation from the generator of the cloud's device (:217-219);
-        `gen` (a seeded CPU generator shared by all ranks of a query-sharded run) replaces both."""
+        `gen` (a seeded CPU generator shared by all ranks of a query-sharded run) replaces both.  device_rng: draw the subset
+        permutation on the device as well -- same distribution, no host permutation of up to N elements + copy per pass; the
+        subsets then no longer follow the reference's CPU random stream (PocoModel.latent_rng)."""
         n, dev = covered.shape[0], covered.device
         valid_ids = torch.nonzero(covered == current_value)[:, 0]
         if valid_ids.shape[0] == 0:
             return None
         if n < m:
             return torch.arange(n, device=dev)
-        ids = valid_ids[torch.randperm(valid_ids.shape[0], generator=gen)[:m].to(dev)]
+        if device_rng and gen is None:
+            ids = valid_ids[torch.randperm(valid_ids.shape[0], device=dev)[:m]]
+        else:
+            ids = valid_ids[torch.randperm(valid_ids.shape[0], generator=gen)[:m].to(dev)]
         if ids.shape[0] < m:
             top = torch.randperm(n, device=dev) if gen is None else torch.randperm(n, generator=gen).to(dev)
             ids = torch.cat([ids, top[:m - ids.shape[0]]], dim=0)
@@ -299,6 +304,9 @@ class PocoModel(_Base):
             gen.manual_seed(int(n) * 1000003 + 12345)
         encode = encode_subsets if encode_subsets is not None else self._encode_subsets
         batch = max(1, int(getattr(self, 'latent_batch', 10)))
+        # 'reference': subsets follow torch's CPU generator like the reference (same seed -> same subsets; the parity tests);
+        # 'device' (default on a GPU): the permutation is drawn where the counts live
+        device_rng = getattr(self, 'latent_rng', 'device') == 'device' and dev.type == 'cuda'
         if world > 1:
             batch = -(-batch // world) * world                               # whole waves: every rank encodes batch / world subsets
         iteration = 0
@@ -307,7 +315,7 @@ class PocoModel(_Base):
             while not round_done:
                 covered, subsets = counts.clone() if batch > 1 else counts, []
                 while len(subsets) < batch:
-                    ids = self._draw_subset(covered, current_value, m, gen)
+                    ids = self._draw_subset(covered, current_value, m, gen, device_rng)
                     if ids is None:
                         round_done = True
                         break
