@@ -48,11 +48,12 @@ def load_shape_data_pc(in_file, padding_factor, shape_name, normalize=False):
         normals = nrm / np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-20)
         pts = pts[:, :3]
     else:
-        normals = np.zeros_like(pts)
+        normals = np.zeros(pts.shape, dtype=np.float64)            # the reference's zeros_like of trimesh's float64 vertices
     if normalize:
         bb_min, bb_max = pts.min(axis=0), pts.max(axis=0)
         pts = (pts - (bb_min + bb_max) * 0.5) / (np.max(bb_max - bb_min) * (1.0 + padding_factor))
-    return {'pts_ms': pts.astype(np.float32), 'normals_ms': normals.astype(np.float32), 'pc_file_in': pts_file}
+    # pts are cast to float32 after normalisation, normals stay float64 (occupancy_data_module.py:236-241; tests/golden/batch_manifest.json)
+    return {'pts_ms': pts.astype(np.float32), 'normals_ms': normals.astype(np.float64), 'pc_file_in': pts_file}
 
 
 class ReconstructionDataset(torch.utils.data.Dataset):
@@ -155,7 +156,7 @@ class TrainDataset(ReconstructionDataset):
         if self.do_data_augmentation:
             rot = random_rotation_matrix(self.rng.rand(3))
             pts = (pts @ rot.T).astype(np.float32)
-            normals = (normals @ rot.T).astype(np.float32)
+            normals = (normals @ rot.T).astype(np.float32)           # trafo.transform_points(...).astype(np.float32), poco_data_loader.py:322-323
             q = (q @ rot.T).astype(np.float32)
         return {'pts_ms': pts, 'normals_ms': normals, 'pts_query_ms': q, 'imp_surf_dist_ms': dist_, 'pts_raw_ms': raw,
                 'pc_file_in': data['pc_file_in'], 'shape_id': i}
@@ -168,7 +169,8 @@ class TrainDataset(ReconstructionDataset):
         batch['pc_file_in'] = [it['pc_file_in'] for it in items]
         if self.num_pts_local is not None:
             raws = [torch.from_numpy(it['pts_raw_ms']).to(device, non_blocking=True) for it in items]
-            batch['pts_local_ps'] = spatial.get_pts_local_ps_batch(raws, batch['pts_query_ms'], self.num_pts_local)
+            batch['pts_local_ps'], batch['pts_local_ms'] = spatial.get_pts_local_ps_batch(raws, batch['pts_query_ms'], self.num_pts_local,
+                                                                                          return_ms=True)
         return spatial.get_data_poco(batch)
 
 

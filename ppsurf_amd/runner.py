@@ -19,6 +19,21 @@ import torch
 import yaml
 
 
+class _Loader(yaml.SafeLoader):
+    """YAML 1.2 floats: PyYAML (YAML 1.1) reads `eps: 1e-5` / `weight_decay: 1e-2` (configs/poco.yaml:66-67) as STRINGS; jsonargparse,
+    which the reference's LightningCLI uses, coerces them to the annotated float type.  Resolve them as floats here."""
+
+
+_Loader.add_implicit_resolver(
+    'tag:yaml.org,2002:float',
+    __import__('re').compile(r'^[-+]?(?:[0-9][0-9_]*)(?:[eE][-+]?[0-9]+)$|^[-+]?(?:[0-9][0-9_]*)?\.[0-9_]+(?:[eE][-+]?[0-9]+)?$'),
+    list('-+0123456789.'))
+
+
+def _yaml_load(text):
+    return yaml.load(text, Loader=_Loader)
+
+
 def _merge(dst, src):
     for k, v in src.items():
         if isinstance(v, dict) and isinstance(dst.get(k), dict):
@@ -33,7 +48,7 @@ def _set_dotted(cfg, dotted, value):
     cur = cfg
     for k in keys[:-1]:
         cur = cur.setdefault(k, {})
-    cur[keys[-1]] = yaml.safe_load(value)
+    cur[keys[-1]] = _yaml_load(value)
 
 
 def handle_rec_subcommand(args):
@@ -61,7 +76,7 @@ def parse(argv):
         a = argv[i]
         if a in ('-c', '--config'):
             with open(argv[i + 1]) as f:
-                _merge(cfg, yaml.safe_load(f) or {})
+                _merge(cfg, _yaml_load(f) or {})
             i += 2
         elif a == '--ckpt_path':
             ckpt = argv[i + 1]

@@ -305,9 +305,10 @@ def get_pts_local_ps(pts_raw_ms, pts_query, num_pts_local, idx=None):
     return ops.patch_normalize(pts_raw_ms, pts_query, idx, num_pts_local)
 
 
-def get_pts_local_ps_batch(raws, queries, num_pts_local):
+def get_pts_local_ps_batch(raws, queries, num_pts_local, return_ms=False):
     """Patches of a fit batch: raws = list of B raw clouds [n_b,3] (sizes may differ), queries [B,Q,3] -> [B,Q,P,3].
-    The B patch searches are one launch (pps_knn_multi_f32) when P <= 64."""
+    The B patch searches are one launch (pps_knn_multi_f32) when P <= 64.  return_ms: also the un-normalised neighbour
+    coordinates `pts_local_ms` [B,Q,P,3] that the reference's dataset leaves in the batch (ppsurf_data_loader.py:83-89)."""
     b = len(raws)
     raws = [r.contiguous().float() for r in raws]
     qs = [queries[i].contiguous().float() for i in range(b)]
@@ -315,4 +316,7 @@ def get_pts_local_ps_batch(raws, queries, num_pts_local):
         ids = ops.knn_batch_point_major(raws, qs, [min(num_pts_local, r.shape[0]) for r in raws])
     else:
         ids = [ops.KnnBlocks(r).query(q, num_pts_local) for r, q in zip(raws, qs)]
-    return torch.stack([ops.patch_normalize(raws[i], qs[i], ids[i], num_pts_local) for i in range(b)])
+    ps = torch.stack([ops.patch_normalize(raws[i], qs[i], ids[i], num_pts_local) for i in range(b)])
+    if return_ms:
+        return ps, torch.stack([raws[i][ids[i]] for i in range(b)])
+    return ps

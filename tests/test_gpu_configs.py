@@ -1,0 +1,244 @@
+"""BASELINE.json configurations at their own sizes and with the reference's REAL configuration files
+(tests/golden/configs/*.yaml, copied byte for byte from the reference by tests/golden/make_golden_r2.py) on the real-data
+fixture tests/golden/abc_mini4 (four shapes of the reference's datasets/abc_minimal).
+
+  config 1  ppsurf_mini predict, gen_resolution_global=33 (its GPU form: trainer.accelerator stays `gpu`; there is no CPU path)
+  config 2  ppsurf_50nn predict, one ABC shape, R=129
+  config 3  ppsurf_50nn fit step at B=10 x 10000 points x 2000 queries, fp32 and bf16-mixed
+  config 5  ppsurf_200nn chunk: N=250000, P=200, rec_batch_size 25000
+"""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import GOLDEN
+from oracle import ppsurf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+CFG = os.path.join(GOLDEN, 'configs')
+
+
+def _stack(*names):
+    out = []
+    for n in names:
+        out += ['-c', os.path.join(CFG, n + '.yaml')]
+    return out
+
+
+@pytest.fixture(scope='module')
+def trained(tmp_path_factory):
+    """A short fit with the reference's real YAML stack (poco + ppsurf + ppsurf_mini: AdamW / MultiStepLR / 16-mixed / callbacks /
+    TensorBoardLogger keys included) on the three training shapes of abc_mini4 -> last.ckpt with learned weights."""
+    from ppsurf_amd import runner
+    root = tmp_path_factory.mktemp('cfg')
+    shutil.copytree(os.path.join(GOLDEN, 'abc_mini4'), root / 'abc')
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        runner.main(['pps.py', 'fit'] + _stack('poco', 'ppsurf', 'ppsurf_mini') + [
+            '--data.init_args.in_file', str(root / 'abc' / 'testset.txt'), '--data.init_args.batch_size', '3',
+            '--data.init_args.manifold_points', '5000', '--trainer.max_epochs', '30', '--trainer.check_val_every_n_epoch', '15',
+            '--trainer.precision', 'bf16-mixed', '--lr_scheduler.init_args.milestones', '[22, 27]'])
+    finally:
+        os.chdir(cwd)
+    ckpt = root / 'models' / 'ppsurf_mini' / 'version_0' / 'checkpoints' / 'last.ckpt'
+    assert ckpt.is_file()
+    return root, str(ckpt)
+
+
+def test_config1_ppsurf_mini_predict_real_yaml_stack(trained, capsys):
+    """`pps.py predict -c configs/poco.yaml -c configs/ppsurf.yaml -c configs/ppsurf_mini.yaml
+    --model.init_args.gen_resolution_global 33` (BASELINE config 1, README 'minimal' flow) with the reference's files unchanged."""
+    from ppsurf_amd import runner, meshio
+    root, ckpt = trained
+    state = torch.load(ckpt, map_location='cpu')
+    assert state['pytorch-lightning_version'] == '2.0.0' and len(state['state_dict']) == 455
+    model = runner.main(['pps.py', 'predict'] + _stack('poco', 'ppsurf', 'ppsurf_mini') + [
+        '--ckpt_path', ckpt, '--data.init_args.in_file', str(root / 'abc' / 'testset.txt'), '--model.init_args.gen_resolution_global', '33',
+        '--trainer.logger', 'False', '--trainer.devices', '1', '--model.init_args.results_dir', str(root / 'res1')])
+    assert type(model).__name__ == 'PPSurfModel' and model.name == 'ppsurf_mini' and model.rec_batch_size == 25000 and model.k == 64
+    assert model.gen_subsample_manifold == 10000 and model.gen_refine_iter == 10 and model.num_pts_local == 50
+    names = [l.strip() for l in open(root / 'abc' / 'testset.txt') if l.strip()]
+    out = capsys.readouterr().out
+    mesh_dir = root / 'res1' / 'ppsurf_mini' / 'abc' / 'meshes'
+    done = [n for n in names if (mesh_dir / (n + '.xyz.ply')).is_file()]
+    assert len(done) + out.count('No reconstruction for') == len(names) and len(done) >= 1
+    for n in done:
+        v = meshio.read_ply_vertices(str(mesh_dir / (n + '.xyz.ply')))[:, :3]
+        assert v.shape[0] > 100 and np.isfinite(v).all() and np.abs(v).max() < 0.75
+
+
+def test_consecutive_shapes_of_equal_size_are_decoded_with_their_own_latents(trained):
+    """three of the four abc_mini4 clouds have the same N.  Reconstructing [A, B] in one process must give
+    the same mesh for B as reconstructing B alone (the per-shape table cache may not survive the shape it was built for)."""
+    from ppsurf_amd import runner
+    root, ckpt = trained
+    names = [l.strip() for l in open(root / 'abc' / 'trainset.txt') if l.strip()]
+    from ppsurf_amd import meshio
+    sizes = {n: meshio.load_pts(str(root / 'abc' / '04_pts_vis' / (n + '.xyz.ply'))).shape[0] for n in names}
+    pair = [n for n in names if list(sizes.values()).count(sizes[n]) >= 2][:2]
+    assert len(pair) == 2, sizes
+
+    def run(shapes, tag):
+        lst = root / 'abc' / ('pair_{}.txt'.format(tag))
+        lst.write_text('\n'.join(shapes) + '\n')
+        torch.manual_seed(7)
+        import random
+        random.seed(7)
+        model = runner.main(['pps.py', 'predict'] + _stack('poco', 'ppsurf', 'ppsurf_mini') + [
+            '--ckpt_path', ckpt, '--data.init_args.in_file', str(lst), '--model.init_args.gen_resolution_global', '25', '--seed_everything', 'null',
+            '--model.init_args.gen_subsample_manifold_iter', '1', '--trainer.logger', 'False', '--model.init_args.results_dir', str(root / ('res_' + tag))])
+        return model.last_prediction
+
+    both = run(pair, 'ab')
+    alone = run(pair[1:], 'b')
+    assert (both is None) == (alone is None)
+    if both is not None:
+        # the latent loop and the support sampling are stochastic, so the two runs differ in the last digits of the latents;
+        # a table of the WRONG shape would move the surface by whole voxels
+        va, vb = both[0], alone[0]
+        assert abs(va.shape[0] - vb.shape[0]) < 0.1 * vb.shape[0]
+        d = np.sqrt(((va[::7, None, :] - vb[None, ::3, :]) ** 2).sum(-1)).min(axis=1)
+        assert np.median(d) < 0.5 / 24, np.median(d)
+
+
+def test_config2_ppsurf_50nn_predict_one_abc_shape_r129(trained):
+    """BASELINE config 2: poco + ppsurf + ppsurf_50nn YAMLs, one ABC shape, gen_resolution_global=129, rec_batch_size 50000."""
+    from ppsurf_amd import runner, meshio
+    root, ckpt = trained
+    names = [l.strip() for l in open(root / 'abc' / 'trainset.txt') if l.strip()]
+    one = root / 'abc' / 'one.txt'
+    one.write_text(names[0] + '\n')
+    model = runner.main(['pps.py', 'predict'] + _stack('poco', 'ppsurf', 'ppsurf_50nn') + [
+        '--ckpt_path', ckpt, '--data.init_args.in_file', str(one), '--model.init_args.gen_resolution_global', '129',
+        '--trainer.logger', 'False', '--trainer.devices', '1', '--model.init_args.results_dir', str(root / 'res2')])
+    assert model.name == 'ppsurf_50nn' and model.rec_batch_size == 50000 and model.gen_resolution_global == 129
+    f = root / 'res2' / 'ppsurf_50nn' / 'abc' / 'meshes' / (names[0] + '.xyz.ply')
+    assert f.is_file()
+    v = meshio.read_ply_vertices(str(f))[:, :3]
+    cloud = meshio.read_ply_vertices(str(root / 'abc' / '04_pts_vis' / (names[0] + '.xyz.ply')))[:, :3]
+    d = np.sqrt(((cloud[::10, None, :] - v[None, ::2, :]) ** 2).sum(-1)).min(axis=1)
+    # a surface at R=129 (voxel 1/128 of the bounding cube) that follows the input cloud of the over-fitted shape
+    assert v.shape[0] > 10000 and np.median(d) < 4.0 / 128, (v.shape, np.median(d))
+
+
+def test_poco_test_subcommand_real_yaml(trained, capsys):
+    """`test` with the POCO configuration (no patches: PocoDataset) must not ask for pts_local_ps."""
+    from ppsurf_amd import runner
+    root, _ = trained
+    runner.main(['pps.py', 'test'] + _stack('poco', 'poco_mini') + ['--data.init_args.in_file', str(root / 'abc' / 'testset.txt'),
+                                                                    '--trainer.logger', 'False', '--model.init_args.results_dir', str(root / 'res_poco')])
+    out = capsys.readouterr().out
+    assert out.count('loss ') == 2 and 'Test results (mean): Loss=' in out
+    assert (root / 'res_poco' / 'poco_mini' / 'abc' / 'metrics_poco_mini.csv').is_file()
+
+
+def test_batch_dictionaries_match_the_reference_manifest(trained):
+    """Keys / dtypes / shapes of the predict and fit batch dictionaries against the manifest recorded from the reference's own
+    datasets (PPSurfReconstructionDataset / PPSurfDataset + default_collate on datasets/abc_minimal, batch_manifest.json)."""
+    from ppsurf_amd.data import PPSurfDataModule
+    root, _ = trained
+    man = json.load(open(os.path.join(GOLDEN, 'batch_manifest.json')))
+    dm = PPSurfDataModule(num_pts_local=50, in_file=str(root / 'abc' / 'testset.txt'), workers=0, use_ddp=False, padding_factor=0.05, seed=42,
+                          manifold_points=10000, patches_per_shape=2000, do_data_augmentation=False, batch_size=2)
+    dm.device = torch.device(DEV)
+    pred = next(iter(dm.predict_dataloader()))
+    ref = man['predict_batch1']
+    assert set(pred.keys()) == set(ref.keys()), set(pred.keys()) ^ set(ref.keys())
+    for k, (dt, shape) in ref.items():
+        if torch.is_tensor(pred[k]):
+            assert str(pred[k].dtype).replace('torch.', '') == dt and pred[k].dim() == len(shape), (k, pred[k].dtype, pred[k].shape, dt, shape)
+            assert pred[k].shape[0] == 1 and tuple(pred[k].shape[2:]) == tuple(shape[2:])
+        else:
+            assert type(pred[k]).__name__ == dt
+    dm.trainset = str(root / 'abc' / 'trainset.txt')
+    fit = next(iter(dm.train_dataloader()))
+    ref = man['fit_batch2']
+    missing = set(ref.keys()) - set(k for k in fit.keys() if not k.startswith('_'))
+    assert not missing, missing
+    for k, (dt, shape) in ref.items():
+        if torch.is_tensor(fit[k]):
+            assert str(fit[k].dtype).replace('torch.', '') == dt, (k, fit[k].dtype, dt)
+            assert tuple(fit[k].shape) == tuple(shape), (k, tuple(fit[k].shape), shape)      # B=2, 10000-point sub-samples, 2000 queries, P=50
+        else:
+            assert type(fit[k]).__name__ == dt and len(fit[k]) == shape
+
+
+@pytest.mark.parametrize('precision', ['32', 'bf16-mixed'])
+def test_config3_fit_step_at_full_batch_size(precision):
+    """BASELINE config 3 on one GPU: B = 10 shapes x 10000 points, 2000 queries per shape, P = 50.  The HIP training step against
+    the same graph on plain-torch twins of the HIP ops (tests/train_ref_ops.py), like for like: loss within 2e-4 (fp32) / the
+    bf16 noise floor, gradients finite everywhere, no parameter without gradient besides the reference's own set."""
+    import train_ref_ops as ref
+    from ppsurf_amd import workloads
+    from ppsurf_amd import spatial
+    step = workloads.FitStep(batch=10, precision=precision, device=DEV, n_batches=1)
+    for m in step.net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    import random
+    random.seed(3); torch.manual_seed(3)
+    batch = dict(step.batches[0])
+    batch['pts_local_ps'] = spatial.get_pts_local_ps_batch([batch['pts_ms'][i] for i in range(10)], batch['pts_query_ms'], 50)
+    batch = spatial.get_data_poco(batch)
+    assert tuple(batch['pts'].shape) == (10, 3, 10000) and tuple(batch['pts_local_ps'].shape) == (10, 2000, 50, 3) and tuple(batch['ids00'].shape) == (10, 10000, 16)
+    sd0 = {k: v.clone() for k, v in step.net.state_dict().items()}
+    losses = []
+    for twins in (False, True):
+        step.net.load_state_dict(sd0)
+        step.net.zero_grad(set_to_none=True)
+        ctx = ref.patched() if twins else __import__('contextlib').nullcontext()
+        with ctx, torch.autocast('cuda', dtype=torch.bfloat16, enabled=precision != '32'):
+            logits = step.net.forward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
+            loss = torch.nn.functional.cross_entropy(logits.float(), batch['occ'], reduction='none').mean()
+        loss.backward()
+        grads = {k: p.grad for k, p in step.net.named_parameters()}
+        assert torch.isfinite(loss) and tuple(logits.shape) == (10, 2, 2000)
+        assert all(torch.isfinite(g).all() for g in grads.values() if g is not None)
+        losses.append((float(loss), sorted(k for k, g in grads.items() if g is None)))
+    assert losses[0][1] == losses[1][1] == []
+    assert abs(losses[0][0] - losses[1][0]) < (2e-4 if precision == '32' else 2e-2), losses
+
+
+def test_config5_ppsurf_200nn_chunk_at_size():
+    """BASELINE config 5 chunk: N = 250 000 points, P = 200, rec_batch_size = 25 000, k = 64 (configs/ppsurf_200nn.yaml) through the
+    product's chunk loop: exact 64-NN and 200-NN tables, finite outputs, permutation equivariance, 64 sampled queries vs the oracle."""
+    from ppsurf_amd.decoder import DecoderPlan, ChunkPipeline
+    from ppsurf_amd.synthetic import make_cloud, make_latents, network_state_dict
+    from ppsurf_amd import workloads
+    n, p, qn = 250_000, 200, 25_000
+    sd = network_state_dict('ppsurf', num_pts_local=p)
+    plan = DecoderPlan(sd, DEV)
+    cloud = make_cloud(n, seed=5)
+    lat = make_latents(256, n, seed=6)
+    pts = torch.from_numpy(cloud).to(DEV)
+    table = plan.point_table(torch.from_numpy(lat[0]).to(DEV))
+    chunks, n_band = workloads.band_chunks(cloud, 513, qn, DEV)
+    assert n_band > 5_000_000 and len(chunks) > 200                         # the R=513 band of this cloud
+    q = chunks[len(chunks) // 2]
+    pipe = ChunkPipeline(plan, table, pts, pts, 64, p, same_cloud=True, max_chunk=qn)
+    (logits, occ), = pipe.run([q])
+    lg = logits.cpu().numpy()
+    assert lg.shape == (qn, 2) and np.isfinite(lg).all() and (np.abs(occ.cpu().numpy()) <= 1).all()
+    perm = torch.randperm(qn, device=DEV)
+    (lg2, _), = pipe.run([q[perm].contiguous()])
+    assert float((lg2 - logits[perm]).abs().max()) < 2e-5
+    sel = np.random.default_rng(2).choice(qn, 64, replace=False)
+    qs = q[torch.from_numpy(sel).to(DEV)].cpu().numpy()
+    ids200 = O.knn_point_major(cloud, qs, 200)
+    b = (pipe.n - 1) & 1
+    # the tables of the LAST run belong to the permuted chunk: compare through the permutation
+    inv = torch.empty_like(perm); inv[perm] = torch.arange(qn, device=DEV)
+    rows = inv[torch.from_numpy(sel).to(DEV)]
+    assert np.array_equal(pipe.pidx[b][rows].cpu().numpy(), ids200)                          # 200-NN patch table: bit-exact
+    assert np.array_equal(pipe.idx[b][rows].cpu().numpy(), ids200[:, :64])                  # 64-NN = its prefix
+    patches = O.normalize_patches(cloud[ids200], qs).astype(np.float32)
+    data = {'latents': torch.from_numpy(lat), 'pts': torch.from_numpy(cloud.T.copy()).unsqueeze(0), 'pts_query': torch.from_numpy(qs).unsqueeze(0),
+            'pts_local_ps': torch.from_numpy(patches).unsqueeze(0)}
+    ref = O.ppsurf_from_latent(sd, data, k=64)[0].T.numpy()
+    np.testing.assert_allclose(lg[sel], ref, rtol=0, atol=1e-4)
