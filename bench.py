@@ -196,6 +196,33 @@ def main():
         }
     extra = world == 1 and not args.quick
     if extra:
+        # ---- opt-in split-precision decoder (dtype "f16x3": fc2 / fc3 / fc_query of the interpolation branch as 3 f16 MFMA products
+        # per fp32 product; logits within ~1e-5 of the fp32 path, tests/test_gpu_decoder.py).  NOT the headline value. ----------
+        plan16 = DecoderPlan(sd, dev, dtype='f16x3')
+        n16 = min(args.steps, 100)
+        w16 = [(ChunkPipeline(plan16, pipe.table, pipe.pts, pipe.pts, K_PROJ, P_LOCAL, same_cloud=True, max_chunk=Q_CHUNK), c)
+               for pipe, c in work[args.warmup:args.warmup + 1]]
+        pipes16 = {}
+        ev16 = [workloads.HipEvents(6) for _ in range(n16)]
+        seq = work[args.warmup:args.warmup + n16]
+        for pipe, c in seq:
+            if id(pipe) not in pipes16:
+                pipes16[id(pipe)] = ChunkPipeline(plan16, pipe.table, pipe.pts, pipe.pts, K_PROJ, P_LOCAL, same_cloud=True, max_chunk=Q_CHUNK)
+        for pipe, c in seq[:5]:
+            pipes16[id(pipe)].run([c])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i, (pipe, c) in enumerate(seq):
+            r16 = pipes16[id(pipe)].run([c], want_occ=True, stage_events=[ev16[i].arr])
+        torch.cuda.synchronize()
+        dt16 = time.perf_counter() - t0
+        ref_occ = pipe.run([c], want_occ=True)[0][1]
+        out['f16x3'] = {'value': Q_CHUNK * len(seq) / dt16, 'unit': 'queries/s', 'ms_per_step': dt16 / len(seq) * 1e3, 'steps': len(seq),
+                        'stage_ms': {name: float(np.mean([e.elapsed_ms(j, j + 1) for e in ev16])) for j, name in enumerate(STAGES)},
+                        'max_abs_occ_diff_vs_f32_last_chunk': float((r16[0][1] - ref_occ).abs().max()),
+                        'note': 'opt-in decoder dtype (DecoderPlan(dtype="f16x3") / PPS_DECODER_DTYPE): interpolation branch on the f16 matrix '
+                                'pipe in split precision, PointNet branch and tail in fp32; same chunks as the fp32 run'}
+        del plan16, pipes16, w16, ev16
         del work, ev
         torch.cuda.empty_cache()
         model = workloads.make_model(RES, P_LOCAL, Q_CHUNK, dev)

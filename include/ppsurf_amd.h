@@ -86,6 +86,10 @@ size_t pps_packed_dense_floats(int out, int in);
 /* packed[ob][kb][lane][s] = W[16*ob + (lane&15)][16*kb + 4*(lane>>4) + s]  (zero padded) */
 int pps_pack_dense_f32(const float* W, int out, int in, float* packed /* [host] */);
 /* xyz layer [out,3]: packed[ob][lane] = W[16*ob + (lane&15)][lane>>4] (0 for lane>>4 == 3) */
+/* Split-precision ("f16x3") A operands for v_mfma_f32_16x16x32_f16: hi = f16(W), lo = f16(W - hi), 2 x 64 x 8 halfs per
+ * (16-output block, 32-input block), channel map documented in csrc/pps_common.h.  out padded to 32, in padded to 32. */
+size_t pps_packed_dense_f16x3_halfs(int out, int in);
+int pps_pack_dense_f16x3(const float* W /* [host] [out,in] */, int out, int in, uint16_t* packed /* [host] */);
 size_t pps_packed_xyz_floats(int out);
 int pps_pack_xyz_f32(const float* W, int out, float* packed /* [host] */);
 
@@ -160,6 +164,17 @@ int pps_decode_fwd_f32(const float* table, const float* pts, const float* query,
 int pps_decode_fwd_events_f32(const float* table, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
                               const float* patches, int p, const float* const* weights, float* logits, float* occ, void* ws,
                               void* const* events, void* stream);
+
+/* Opt-in split-precision interpolation branch (decoder dtype "f16x3"): same contract as pps_interp_pool_f32 with fc2 / fc3 / fc_query
+ * evaluated as three f16 MFMA products per fp32 product (error ~1e-5 on logits of magnitude 30, tests/test_gpu_decoder.py).
+ * wxyz: the 1024 packed floats of fc1's xyz part (front of the fp32 image); w16: pps_pack_dense_f16x3 images of fc2, fc3, fc_query
+ * back to back (147456 halfs x 2); bias [256 | 256 | 64] floats. */
+int pps_interp_pool_f16x3(const float* G, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
+                          const float* wxyz, const void* w16, const float* bias, float* pooled, void* stream);
+/* pps_decode_fwd_events_f32 with the interpolation branch in split precision (interp_w16 as above; events may be NULL). */
+int pps_decode_fwd_mixed_f32(const float* table, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
+                             const float* patches, int p, const float* const* weights, const void* interp_w16, float* logits, float* occ,
+                             void* ws, void* const* events, void* stream);
 
 /* ---- FKAConv encoder (eval mode), point-major activations, one batch item per call ----------------- */
 

@@ -24,6 +24,8 @@ SIGNATURES = {
     'pps_patch_normalize_f32': (_I, [_P, _P, _P, _I64, _I64, _I, _P, _P]),
     'pps_packed_dense_floats': (_SZ, [_I, _I]),
     'pps_pack_dense_f32': (_I, [_P, _I, _I, _P]),
+    'pps_packed_dense_f16x3_halfs': (_SZ, [_I, _I]),
+    'pps_pack_dense_f16x3': (_I, [_P, _I, _I, _P]),
     'pps_packed_xyz_floats': (_SZ, [_I]),
     'pps_pack_xyz_f32': (_I, [_P, _I, _P]),
     'pps_rows_dense256_f32': (_I, [_P, _I64, _I64, _I64, _P, _P, _P, _P]),
@@ -36,6 +38,8 @@ SIGNATURES = {
     'pps_decode_ws_bytes': (_SZ, [_I64]),
     'pps_decode_fwd_f32': (_I, [_P, _P, _P, _P, _I64, _I, _P, _I, _P, _P, _P, _P, _P]),
     'pps_decode_fwd_events_f32': (_I, [_P, _P, _P, _P, _I64, _I, _P, _I, _P, _P, _P, _P, _P, _P]),
+    'pps_decode_fwd_mixed_f32': (_I, [_P, _P, _P, _P, _I64, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    'pps_interp_pool_f16x3': (_I, [_P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P]),
     'pps_fkaconv_geo_floats': (_SZ, []),
     'pps_fkaconv_ws_bytes': (_SZ, [_I64, _I]),
     'pps_fkaconv_fwd_f32': (_I, [_P, _P, _P, _P, _I64, _I64, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),

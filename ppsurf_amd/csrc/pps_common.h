@@ -127,6 +127,85 @@ __device__ __forceinline__ void dense_blocks(const f32x4 (&in)[KB], f32x4* out, 
     }
 }
 
+// ---- split-precision dense layer: fp32-grade products on the f16 matrix pipe (opt-in decoder dtype "f16x3") ----------
+// x = hi + lo with hi = f16(x) (round toward zero, v_cvt_pkrtz_f16_f32) and lo = f16(x - hi) (the subtraction is exact), so
+// hi + lo carries ~21 significant bits; W = Whi + Wlo likewise (round to nearest, packed on the host).  One product needs three
+// MFMAs, Whi.hi + Whi.lo + Wlo.hi (the lo.lo term is below 2^-21), each v_mfma_f32_16x16x32_f16 doing 8x the work of
+// v_mfma_f32_16x16x4_f32 in half its issue time: 16/3 of the fp32 matrix rate.  Measured error of the whole decoder on the
+// reference's golden logits: 1e-6 at logit scale 1, 1.2e-5 at scale 28 (tools/split_precision_study.py) -- the level of the fp32
+// path's own rounding noise.
+// Layout: the C/D tile of the 16x16 MFMA is the same as for the f32 instruction (lane (n,g), register r <-> row n, channel
+// 16 ob + 4 g + r), so two finished output blocks (2 kb, 2 kb + 1) ARE the B operand of k-block kb of the next layer once
+// split: element j of lane (n,g) is channel 32 kb + 16 (j >> 2) + 4 g + (j & 3).  The packed weights use the same map:
+//     packed[ob][kb][part][lane][j] = f16 part (0: hi, 1: lo) of W[16 ob + (l & 15)][32 kb + 16 (j >> 2) + 4 (l >> 4) + (j & 3)].
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct HiLo { half8 hi, lo; };
+
+__device__ __forceinline__ HiLo split_f16(const f32x4& x0, const f32x4& x1) {
+    u32x4 hp, lp;
+    const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const auto h = __builtin_amdgcn_cvt_pkrtz(v[2 * p], v[2 * p + 1]);
+        const auto l = __builtin_amdgcn_cvt_pkrtz(v[2 * p] - (float)h[0], v[2 * p + 1] - (float)h[1]);
+        hp[p] = __builtin_bit_cast(unsigned, h);
+        lp[p] = __builtin_bit_cast(unsigned, l);
+    }
+    return HiLo{__builtin_bit_cast(half8, hp), __builtin_bit_cast(half8, lp)};
+}
+// back to fp32 (hi + lo), blocks 2 kb and 2 kb + 1
+__device__ __forceinline__ void join_f16(const HiLo& x, f32x4& y0, f32x4& y1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        y0[r] = (float)x.hi[r] + (float)x.lo[r];
+        y1[r] = (float)x.hi[4 + r] + (float)x.lo[4 + r];
+    }
+}
+
+// out blocks OB0 .. OB0+NOB-1 (NOB even) of act(bias + W in): in[kb] = split activations of k-block kb (KB blocks of 32 channels),
+// w -> packed half8 fragments of (ob = OB0, kb = 0) for this wave: [ob][kb][hi|lo][64 lanes].  The result of each output-block
+// PAIR is handed to `sink(pair_index, f32x4 block_even, f32x4 block_odd)`.
+// Main products (hi.hi) and corrections (hi.lo + lo.hi) accumulate separately: dependent MFMAs are 4 issues apart, and the small
+// terms are summed among themselves before they meet the large ones.
+template <int KB, int NOB, int ACT, class Sink>
+__device__ __forceinline__ void dense_blocks_f16x3(const HiLo (&in)[KB], const half8* __restrict__ w, const f32x4* __restrict__ bias, int lane,
+                                                   Sink&& sink) {
+    static_assert(NOB % 2 == 0, "output blocks are processed in pairs");
+    const int g = lane >> 4;
+#pragma unroll
+    for (int ob = 0; ob < NOB; ob += 2) {
+        f32x4 m0 = bias[(ob) * 4 + g], m1 = bias[(ob + 1) * 4 + g];
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+        const half8* w0 = w + ((ob) * KB) * 128 + lane;
+        const half8* w1 = w + ((ob + 1) * KB) * 128 + lane;
+        half8 ph0 = w0[0], pl0 = w0[64], ph1 = w1[0], pl1 = w1[64];          // fragments of step kb are requested during step kb-1
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const half8 ah0 = ph0, al0 = pl0, ah1 = ph1, al1 = pl1;
+            if (kb + 1 < KB) {
+                ph0 = w0[(kb + 1) * 128]; pl0 = w0[(kb + 1) * 128 + 64];
+                ph1 = w1[(kb + 1) * 128]; pl1 = w1[(kb + 1) * 128 + 64];
+            }
+            m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, in[kb].hi, m0, 0, 0, 0);
+            m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, in[kb].hi, m1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, in[kb].lo, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, in[kb].lo, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, in[kb].hi, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, in[kb].hi, c1, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(PPS_SG_DSREAD, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(PPS_SG_MFMA, 6, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 o0 = m0 + c0, o1 = m1 + c1;
+        if (ACT == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { o0[r] = fmaxf(o0[r], 0.f); o1[r] = fmaxf(o1[r], 0.f); }
+        }
+        sink(ob >> 1, o0, o1);
+    }
+}
+
 // first layer for xyz inputs (K = 3 padded to 4): B operand of lane (n,g) is coordinate g of row n (0 for g = 3).
 // wxyz packed [ob][lane]:  W[16*ob + (l & 15)][l >> 4]  (0 for l >> 4 == 3).
 template <int NOB>

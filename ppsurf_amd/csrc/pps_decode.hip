@@ -268,6 +268,149 @@ __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restr
 }
 
 // =====================================================================================================
+// interp_pool_f16x3: the same branch with the three big layers (fc2, fc3, fc_query) on the f16 matrix pipe in split precision
+// (pps_common.h, dense_blocks_f16x3) -- opt-in decoder dtype "f16x3"; gather, the xyz part of fc1, softmax and pooling stay fp32.
+// One workgroup = 8 waves = 2 queries per weight pass (the 576 KB weight stream, not the matrix pipe, bounds this kernel:
+// twice the rows per pass halve it).
+// weights: wxyz (floats) [xyz 1024]; w16 (half8 fragments) [fc2 16 ob x 8 kb][fc3 16 x 8][fcq 4 x 8], 2 KiB per (ob, kb);
+// bias (floats): [256][256][64]
+// =====================================================================================================
+#define IH_NT 512
+#define IH_NW (IH_NT / 64)
+#define IH_LDS_BYTES (2 * CH4 * 16 + (IP_W_XYZ + IP_NBIAS + IH_NW * 64 * 3 + IH_NW * 256) * 4)
+
+__global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float* __restrict__ G, const float* __restrict__ pts,
+                                                                     const float* __restrict__ query, const int64_t* __restrict__ idx,
+                                                                     int64_t Q, int k, const float* __restrict__ wxyz,
+                                                                     const f32x4* __restrict__ w16, const float* __restrict__ bias,
+                                                                     float* __restrict__ pooled) {
+    f32x4* buf0 = (f32x4*)pps_smem;
+    f32x4* buf1 = buf0 + CH4;
+    float* xyz_l = (float*)(buf1 + CH4);
+    float* bias_l = xyz_l + IP_W_XYZ;
+    float* msm = bias_l + IP_NBIAS;
+    float* mss = msm + IH_NW * 64;
+    float* f_l = mss + IH_NW * 64;
+    float* part = f_l + IH_NW * 64;
+    const f32x4* bias4 = (const f32x4*)bias_l;
+    const f32x4* wg = w16;
+    const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+
+    lds_fill(xyz_l, wxyz, IP_W_XYZ);
+    lds_fill(bias_l, bias, IP_NBIAS);
+    stream_prologue<CH4, IH_NT>(wg, buf0);
+    __syncthreads();
+    f32x4 *cur = buf0, *nxt = buf1;
+
+    const int ntiles = (int)((Q + IH_NW / 4 - 1) / (IH_NW / 4));
+    int first, count, stride;
+    xcd_tile_range(ntiles, first, count, stride);
+    const int wq = wave & 3, wbase = wave & ~3;
+    for (int it = 0; it < count; ++it) {
+        const int64_t qi = (int64_t)(first + it * stride) * (IH_NW / 4) + (wave >> 2);
+        const bool qv = qi < Q;
+        const int64_t qc = qv ? qi : Q - 1;
+        const int row = wq * 16 + n;
+        const bool valid = row < k;
+        const int64_t i = idx[qc * k + (valid ? row : 0)];
+
+        HiLo x[8], y[8];
+        {
+            f32x4 a[16];
+            const f32x4* grow = (const f32x4*)(G + i * 256) + g;
+#pragma unroll
+            for (int bb = 0; bb < 16; ++bb) a[bb] = grow[4 * bb];
+            const float coord = (g < 3) ? (query[qc * 3 + g] - pts[i * 3 + g]) : 0.f;   // query minus neighbour (poco_model.py:402)
+            xyz_blocks<16>(coord, a, xyz_l, lane);
+            relu_blocks<16>(a);
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) x[kb] = split_f16(a[2 * kb], a[2 * kb + 1]);
+        }
+        __builtin_amdgcn_s_setprio(PPS_PRIO);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)                                    // fc2: chunk c holds output blocks 2c, 2c+1 = k-block c of fc3
+            stream_step<CH4, IH_NT>(wg + (c + 1) * CH4, cur, nxt, [&](const f32x4* w) {
+                dense_blocks_f16x3<8, 2, 1>(x, (const half8*)w, bias4 + 8 * c, lane,
+                                            [&](int, const f32x4& o0, const f32x4& o1) { y[c] = split_f16(o0, o1); });
+            });
+#pragma unroll
+        for (int c = 0; c < 8; ++c)                                    // fc3
+            stream_step<CH4, IH_NT>(wg + (c + 9) * CH4, cur, nxt, [&](const f32x4* w) {
+                dense_blocks_f16x3<8, 2, 1>(y, (const half8*)w, bias4 + 64 + 8 * c, lane,
+                                            [&](int, const f32x4& o0, const f32x4& o1) { x[c] = split_f16(o0, o1); });
+            });
+        f32x4 b[4];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)                                    // fc_query: 64 heads
+            stream_step<CH4, IH_NT>(wg + ((c + 17) % 18) * CH4, cur, nxt, [&](const f32x4* w) {
+                dense_blocks_f16x3<8, 2, 0>(x, (const half8*)w, bias4 + 128 + 8 * c, lane,
+                                            [&](int, const f32x4& o0, const f32x4& o1) { b[2 * c] = o0; b[2 * c + 1] = o1; });
+            });
+        __builtin_amdgcn_s_setprio(0);
+        // ---- softmax over the 64 neighbours (4 waves x 16 rows) for each of the 64 heads: as in interp_pool_kernel -------------
+        float e[16];
+        {
+            f32x4 m4[4], s4[4];
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = valid ? b[bb][r] : -INFINITY;
+                    const float mx = row16_max(v);
+                    const float ev = valid ? __expf(v - mx) : 0.f;
+                    e[bb * 4 + r] = ev;
+                    m4[bb][r] = mx;
+                    s4[bb][r] = row16_sum(ev);
+                }
+            if (n < 4) {
+                const f32x4 mm = (n == 0) ? m4[0] : (n == 1) ? m4[1] : (n == 2) ? m4[2] : m4[3];
+                const f32x4 ss = (n == 0) ? s4[0] : (n == 1) ? s4[1] : (n == 2) ? s4[2] : s4[3];
+                ((f32x4*)(msm + wave * 64))[4 * n + g] = mm;
+                ((f32x4*)(mss + wave * 64))[4 * n + g] = ss;
+            }
+        }
+        __syncthreads();
+        {
+            float mw[4], sw[4];
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) { mw[w2] = msm[(wbase + w2) * 64 + lane]; sw[w2] = mss[(wbase + w2) * 64 + lane]; }
+            const float M = fmaxf(fmaxf(mw[0], mw[1]), fmaxf(mw[2], mw[3]));
+            float S = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) S += sw[w2] * __expf(mw[w2] - M);
+            f_l[wave * 64 + lane] = __expf(mw[wq] - M) / (64.f * S);
+        }
+        __syncthreads();
+        float an = 0.f;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const f32x4 f4 = ((const f32x4*)(f_l + wave * 64))[4 * bb + g];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) an += e[bb * 4 + r] * f4[r];
+        }
+        an += __shfl_xor(an, 16);
+        an += __shfl_xor(an, 32);           // attention weight of row n (mean over the 64 heads)
+        f32x4 a[16];
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) {                               // h3 back to fp32 (hi + lo) in the standard block layout
+            join_f16(x[kb], a[2 * kb], a[2 * kb + 1]);
+            a[2 * kb] *= an;
+            a[2 * kb + 1] *= an;
+        }
+        rows16_sum_transposed(a, lane);
+        ((f32x4*)(part + wave * 256))[4 * n + g] = a[0];
+        __syncthreads();
+        if (wq == 0 && qv) {
+            f32x4 s = ((const f32x4*)(part + (wbase + 0) * 256))[lane];
+            s += ((const f32x4*)(part + (wbase + 1) * 256))[lane];
+            s += ((const f32x4*)(part + (wbase + 2) * 256))[lane];
+            s += ((const f32x4*)(part + (wbase + 3) * 256))[lane];
+            ((f32x4*)(pooled + qi * 256))[lane] = s;
+        }
+    }
+}
+
+// =====================================================================================================
 // interp_small: the POCO projection head (source/poco_model.py:362-419 with latent_size C = 16*CB <= 64 and a handful of
 // output channels, configs/poco.yaml:47-48: C = 32, out = 2).  Same register-tile chain as interp_pool; all weights
 // (a few KiB) stay resident in LDS, and fc8 . fc_value (composed on the host) is applied to the pooled feature in place.
@@ -903,6 +1046,22 @@ int pps_interp_pool_f32(const float* G, const float* pts, const float* query, co
     return PPS_LAUNCH_CHECK();
 }
 
+int pps_interp_pool_f16x3(const float* G, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
+                          const float* wxyz, const void* w16, const float* bias, float* pooled, void* stream) {
+    if (q < 0 || k < 1 || k > 64) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    if (!G || !pts || !query || !idx || !wxyz || !w16 || !bias || !pooled) return PPS_ERR_ARG;
+    static int once = set_lds(interp_pool_f16x3_kernel, IH_LDS_BYTES);
+    (void)once;
+    int cus = cu_count();
+    if (cus <= 0) cus = 256;
+    const int64_t ntiles = (q + IH_NW / 4 - 1) / (IH_NW / 4);
+    const int grid = (int)(ntiles < cus ? ntiles : cus);               // one 8-wave workgroup per CU
+    hipLaunchKernelGGL(interp_pool_f16x3_kernel, dim3(grid), dim3(IH_NT), IH_LDS_BYTES, (hipStream_t)stream,
+                       G, pts, query, idx, q, k, wxyz, (const f32x4*)w16, bias, pooled);
+    return PPS_LAUNCH_CHECK();
+}
+
 int pps_interp_small_f32(const float* G, const float* pts, const float* query, const int64_t* idx, int64_t q, int k, int c,
                          const float* wpack, const float* bias, const float* wtail, int nout, float* out, void* stream) {
     if (q < 0 || k < 1 || k > 64 || (c != 32 && c != 64) || nout < 1 || nout > IS_MAX_OUT) return PPS_ERR_ARG;
@@ -980,7 +1139,7 @@ size_t pps_decode_ws_bytes(int64_t q) { return q < 0 ? 0 : (size_t)q * (256 + 25
 
 static int decode_fwd(const float* table, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
                       const float* patches, int p, const float* const* weights, float* logits, float* occ, void* ws, void* const* events,
-                      void* stream) {
+                      void* stream, const void* interp_w16 = nullptr) {
     if (q < 0) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
     if (!weights || !ws || !logits) return PPS_ERR_ARG;
@@ -993,7 +1152,8 @@ static int decode_fwd(const float* table, const float* pts, const float* query, 
     hipStream_t st = (hipStream_t)stream;
 #define PPS_MARK(i) do { if (events && events[i] && hipEventRecord((hipEvent_t)events[i], st) != hipSuccess) return PPS_ERR_LAUNCH; } while (0)
     PPS_MARK(0);
-    int rc = pps_interp_pool_f32(table, pts, query, idx, q, k, weights[0], weights[1], pooled, stream);
+    int rc = interp_w16 ? pps_interp_pool_f16x3(table, pts, query, idx, q, k, weights[0], interp_w16, weights[1], pooled, stream)
+                        : pps_interp_pool_f32(table, pts, query, idx, q, k, weights[0], weights[1], pooled, stream);
     PPS_MARK(1);
     if (rc == PPS_OK) rc = pps_pointnet_stn_rows_f32(patches, q, p, weights[2], weights[3], g, stream);
     PPS_MARK(2);
@@ -1016,6 +1176,13 @@ int pps_decode_fwd_events_f32(const float* table, const float* pts, const float*
                               const float* patches, int p, const float* const* weights, float* logits, float* occ, void* ws,
                               void* const* events, void* stream) {
     return decode_fwd(table, pts, query, idx, q, k, patches, p, weights, logits, occ, ws, events, stream);
+}
+
+int pps_decode_fwd_mixed_f32(const float* table, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
+                             const float* patches, int p, const float* const* weights, const void* interp_w16, float* logits, float* occ,
+                             void* ws, void* const* events, void* stream) {
+    if (!interp_w16) return PPS_ERR_ARG;
+    return decode_fwd(table, pts, query, idx, q, k, patches, p, weights, logits, occ, ws, events, stream, interp_w16);
 }
 
 }  // extern "C"

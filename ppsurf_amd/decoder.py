@@ -49,6 +49,14 @@ def pack_dense(w):
     return out
 
 
+def pack_dense_f16x3(w):
+    """[out,in] float -> uint16 image of the split-precision A operands (hi | lo f16 fragments, pps_pack_dense_f16x3)."""
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    out = np.empty(_lib.lib().pps_packed_dense_f16x3_halfs(w.shape[0], w.shape[1]), dtype=np.uint16)
+    _lib.check(_lib.lib().pps_pack_dense_f16x3(w.ctypes.data, w.shape[0], w.shape[1], out.ctypes.data), 'pps_pack_dense_f16x3')
+    return out
+
+
 def pack_xyz(w):
     w = np.ascontiguousarray(w, dtype=np.float32)
     out = np.empty(_lib.lib().pps_packed_xyz_floats(w.shape[0]), dtype=np.float32)
@@ -65,8 +73,17 @@ def _pad(v, n):
 class DecoderPlan:
     """Packed, device-resident weights of the eval-mode PPSurf decoder."""
 
-    def __init__(self, sd, device, prefix=''):
+    DTYPES = ('f32', 'f16x3')
+
+    def __init__(self, sd, device, prefix='', dtype=None):
+        """dtype 'f32' (default; exact fp32 MFMA everywhere -- the parity path) or 'f16x3' (opt-in, also through the environment
+        variable PPS_DECODER_DTYPE): the interpolation branch's fc2 / fc3 / fc_query run on the f16 matrix pipe in split precision
+        (three f16 products per fp32 product, fp32 accumulation; csrc/pps_common.h) -- logits agree with the fp32 path to ~1e-5."""
+        import os
         p = prefix
+        self.dtype = dtype or os.environ.get('PPS_DECODER_DTYPE', 'f32')
+        if self.dtype not in self.DTYPES:
+            raise ValueError('decoder dtype must be one of {} (got {!r})'.format(self.DTYPES, self.dtype))
         f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
         # ---- interpolation branch (poco_model.py:364-419) ------------------------------------------------
         w1, b1 = _wb(sd, p + 'projection.fc1')
@@ -126,6 +143,11 @@ class DecoderPlan:
             assert host[k].shape == (n,), (k, host[k].shape, n)
         self.device = torch.device(device)
         self.w = {k: torch.from_numpy(v).to(self.device) for k, v in host.items()}
+        self.ip_w16 = None
+        if self.dtype == 'f16x3':
+            img = np.concatenate([pack_dense_f16x3(w2), pack_dense_f16x3(w3), pack_dense_f16x3(wq)])
+            assert img.shape == (2 * (65536 * 2 + 16384),)
+            self.ip_w16 = torch.from_numpy(img.view(np.int16)).to(self.device)
         self._scratch = {}
 
     # ---- scratch management: caller-owned buffers, reused across chunks -------------------------------------
@@ -180,7 +202,9 @@ class DecoderPlan:
                                                                                   'pc_b', 'tl_w', 'tl_b')])
         args = (table.data_ptr(), pts.data_ptr(), query.data_ptr(), idx.data_ptr(), q, k, patches.data_ptr(), p, self._wptrs,
                 logits.data_ptr(), occ.data_ptr() if want_occ else None, ws.data_ptr())
-        if stage_events is None:
+        if self.ip_w16 is not None:
+            _lib.check(L.pps_decode_fwd_mixed_f32(*args[:9], self.ip_w16.data_ptr(), *args[9:], stage_events, st), 'pps_decode_fwd_mixed_f32')
+        elif stage_events is None:
             _lib.check(L.pps_decode_fwd_f32(*args, st), 'pps_decode_fwd_f32')
         else:
             _lib.check(L.pps_decode_fwd_events_f32(*args, stage_events, st), 'pps_decode_fwd_events_f32')

@@ -166,3 +166,79 @@ def test_pointnet_branch_matches_reference_module_fixture(name, p):
     wv = pn[pre + 'att.fc_value.weight'].reshape(256, 256).double()
     got = inter['xbar'].double().cpu() @ wv.t() + pn[pre + 'att.fc_value.bias'].double()
     np.testing.assert_allclose(got.numpy(), feat, rtol=0, atol=5e-5)
+
+
+# ---- opt-in split-precision decoder dtype ("f16x3"): same 1e-4 bar as the fp32 path -----------------------------------------
+_plan16 = None
+
+
+def plan16():
+    global _plan16
+    if _plan16 is None:
+        _plan16 = DecoderPlan(filled_sd('', key='ppsurf'), DEV, dtype='f16x3')
+    return _plan16
+
+
+def test_f16x3_pack_layout_roundtrip():
+    """hi + lo of the packed split-precision image reproduce the weights to 2^-21 and follow the documented channel map."""
+    from ppsurf_amd.decoder import pack_dense_f16x3
+    rng = np.random.default_rng(0)
+    w = (rng.standard_normal((64, 256)) * 0.1).astype(np.float32)
+    img = pack_dense_f16x3(w).view(np.float16).reshape(4, 8, 2, 64, 8).astype(np.float64)
+    rec = np.zeros((64, 256))
+    for l in range(64):
+        for j in range(8):
+            rec[(l & 15)::16, (16 * (j >> 2) + 4 * (l >> 4) + (j & 3))::32] = img[:, :, 0, l, j] + img[:, :, 1, l, j]
+    assert np.abs(rec - w).max() <= np.abs(w).max() * 2.0 ** -21
+    assert np.array_equal(img[:, :, 0, :, :].astype(np.float16), img[:, :, 0, :, :])          # parts are f16 values
+
+
+def test_f16x3_reference_golden_logits():
+    g = load_golden('ppsurf_from_latent')
+    pl = plan16()
+    cloud = g['cloud']
+    lat = make_latents(256, cloud.shape[0], 77)[0]
+    logits, occ = pl.decode(pl.point_table(dev(lat)), dev(cloud), dev(g['query']), dev(g['proj_ids'][0]), dev(g['patches']))
+    err = np.abs(logits.cpu().numpy() - g['logits'][0].T).max()
+    print('f16x3 vs reference golden: max |dlogit| = {:.2e}'.format(err))
+    assert err < 1e-4
+    np.testing.assert_allclose(occ.cpu().numpy(), g['occ'], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize('scale', [1.0, 25.0])
+@pytest.mark.parametrize('p,q,k', [(50, 203, 64), (50, 1, 64), (10, 77, 64), (200, 21, 64), (50, 64, 20), (50, 130, 5)])
+def test_f16x3_matches_oracle(p, q, k, scale):
+    """Split precision against the oracle for ragged query counts, small k (rows beyond k masked), P = 10 / 50 / 200, and latents
+    at the magnitude the real encoder produces (|latent| ~ 25 -> logits ~ 30: the absolute 1e-4 bar is hardest there)."""
+    sd = filled_sd('', key='ppsurf')
+    if p != 50:
+        from ppsurf_amd.synthetic import network_state_dict
+        sd = network_state_dict('ppsurf', num_pts_local=p)
+    pl = DecoderPlan(sd, DEV, dtype='f16x3') if p != 50 else plan16()
+    cloud = make_cloud(1500, seed=p + q)
+    qry = make_band_queries(cloud, q, resolution=33, seed=q)
+    kk = min(k, 64)
+    ids = O.knn_point_major(cloud, qry, kk)
+    patches = O.normalize_patches(cloud[O.knn_point_major(cloud, qry, p)], qry).astype(np.float32)
+    lat = make_latents(256, cloud.shape[0], seed=q) * np.float32(scale)
+    data = {'latents': torch.from_numpy(lat), 'pts': torch.from_numpy(cloud.T.copy()).unsqueeze(0),
+            'pts_query': torch.from_numpy(qry).unsqueeze(0), 'pts_local_ps': torch.from_numpy(patches).unsqueeze(0)}
+    ref = O.ppsurf_from_latent(sd, data, k=kk)[0].T.numpy()
+    logits, _ = pl.decode(pl.point_table(dev(lat[0])), dev(cloud), dev(qry), dev(ids), dev(patches))
+    np.testing.assert_allclose(logits.cpu().numpy(), ref, rtol=0, atol=1e-4)
+
+
+def test_f16x3_full_chunk_against_fp32_path():
+    """BASELINE chunk (N=100k, Q=50k): the split-precision branch against the fp32 kernels on every query."""
+    pl, pl16 = plan(), plan16()
+    cloud = make_cloud(100_000, seed=42)
+    qry = make_band_queries(cloud, 50_000, resolution=257, seed=1)
+    pts, qd = dev(cloud), dev(qry)
+    lat = make_latents(256, cloud.shape[0], seed=77) * np.float32(20.0)
+    idx = ops.knn_point_major(pts, qd, 64)
+    patches = ops.patch_normalize(pts, qd, idx, 50)
+    a, _ = pl.decode(pl.point_table(dev(lat[0])), pts, qd, idx, patches)
+    b, _ = pl16.decode(pl16.point_table(dev(lat[0])), pts, qd, idx, patches)
+    err = float((a - b).abs().max())
+    print('f16x3 vs fp32, 50000 queries, logits |max| {:.1f}: max diff {:.2e}'.format(float(a.abs().max()), err))
+    assert torch.isfinite(b).all() and err < 5e-5
