@@ -171,9 +171,15 @@ int pps_decode_fwd_events_f32(const float* table, const float* pts, const float*
  * back to back (147456 halfs x 2); bias [256 | 256 | 64] floats. */
 int pps_interp_pool_f16x3(const float* G, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
                           const float* wxyz, const void* w16, const float* bias, float* pooled, void* stream);
-/* pps_decode_fwd_events_f32 with the interpolation branch in split precision (interp_w16 as above; events may be NULL). */
+/* The PointNet branch in split precision: weights = the six fp32 images (stn_rows, stn_fc, feat_rows: wpack, bias each -- xyz layers and
+ * biases are read from them), w16 [host] array of 3 pps_pack_dense_f16x3 image sets: (c0b, s1, s2, s3), (fc1, fc2, fc3), (c0b, c1, c2, c3);
+ * g [q,256], trans2 (q x 16 KiB: pre-split fragments of the per-query feature transform), xbar [q,256]; events: 3 hipEvent_t or NULL. */
+int pps_pointnet_f16x3(const float* patches, int64_t q, int p, const float* const* weights, const void* const* w16, float* g, float* trans2,
+                       float* xbar, void* const* events, void* stream);
+/* pps_decode_fwd_events_f32 with branches in split precision: w16 [host] array of 4 image sets (interp, stn_rows, stn_fc, feat_rows);
+ * w16[0] NULL keeps the fp32 interpolation branch, any of w16[1..3] NULL keeps the fp32 PointNet branch.  events may be NULL. */
 int pps_decode_fwd_mixed_f32(const float* table, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
-                             const float* patches, int p, const float* const* weights, const void* interp_w16, float* logits, float* occ,
+                             const float* patches, int p, const float* const* weights, const void* const* w16, float* logits, float* occ,
                              void* ws, void* const* events, void* stream);
 
 /* ---- FKAConv encoder (eval mode), point-major activations, one batch item per call ----------------- */

@@ -586,16 +586,54 @@ __device__ __forceinline__ void stn_chain(float coord, f32x4 (&z)[16], const flo
     __builtin_amdgcn_s_setprio(0);
 }
 
+// the same chain in split precision (decoder dtype "f16x3"): conv0a stays an fp32 MFMA (K = 3), the four dense layers run as
+// three f16 products each; `wg` -> pps_pack_dense_f16x3 images of c0b, s1, s2, s3 (same byte sizes and chunk boundaries as fp32)
+__device__ __forceinline__ void stn_chain_h(float coord, f32x4 (&z)[16], const float* xyz_l, const f32x4* bias4, const f32x4* wg,
+                                            f32x4*& cur, f32x4*& nxt, int lane) {
+    const int g = lane >> 4;
+    HiLo a[2], b[2], y[4];
+    {
+        f32x4 x0[4];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) x0[bb] = bias4[4 * bb + g];
+        xyz_blocks<4>(coord, x0, xyz_l, lane);
+        relu_blocks<4>(x0);
+        a[0] = split_f16(x0[0], x0[1]);
+        a[1] = split_f16(x0[2], x0[3]);
+    }
+    __builtin_amdgcn_s_setprio(PPS_PRIO_PN);
+    stream_step<1024, PNT>(wg + 1024, cur, nxt, [&](const f32x4* w) {
+        dense_blocks_f16x3<2, 4, 1>(a, (const half8*)w, bias4 + 16, lane, [&](int i, const f32x4& o0, const f32x4& o1) { b[i] = split_f16(o0, o1); }); });
+    stream_step<PCH4, PNT>(wg + 2048, cur, nxt, [&](const f32x4* w) {
+        dense_blocks_f16x3<2, 4, 1>(b, (const half8*)w, bias4 + 32, lane, [&](int i, const f32x4& o0, const f32x4& o1) { a[i] = split_f16(o0, o1); }); });
+#pragma unroll
+    for (int h = 0; h < PN_C2N; ++h)
+        stream_step<PCH4, PNT>(wg + 2048 + (h + 1) * PCH4, cur, nxt, [&](const f32x4* w) {
+            dense_blocks_f16x3<2, PN_C2OB, 1>(a, (const half8*)w, bias4 + 48 + 4 * PN_C2OB * h, lane,
+                                              [&](int i, const f32x4& o0, const f32x4& o1) { y[PN_C2OB / 2 * h + i] = split_f16(o0, o1); }); });
+#pragma unroll
+    for (int c = 0; c < PN_C3N - 1; ++c)
+        stream_step<PCH4, PNT>(wg + 4096 + (c + 1) * PCH4, cur, nxt, [&](const f32x4* w) {
+            dense_blocks_f16x3<4, PN_C3OB, 1>(y, (const half8*)w, bias4 + 80 + 4 * PN_C3OB * c, lane,
+                                              [&](int i, const f32x4& o0, const f32x4& o1) { z[PN_C3OB * c + 2 * i] = o0; z[PN_C3OB * c + 2 * i + 1] = o1; }); });
+    stream_step<1024, PNT>(wg, cur, nxt, [&](const f32x4* w) {
+        dense_blocks_f16x3<4, PN_C3OB, 1>(y, (const half8*)w, bias4 + 80 + 4 * PN_C3OB * (PN_C3N - 1), lane,
+                                          [&](int i, const f32x4& o0, const f32x4& o1) { z[PN_C3OB * (PN_C3N - 1) + 2 * i] = o0; z[PN_C3OB * (PN_C3N - 1) + 2 * i + 1] = o1; }); });
+    __builtin_amdgcn_s_setprio(0);
+}
+
+// H = false: fp32 (wdense = wpack + 256 floats of the same image); H = true: split precision (wdense = the f16x3 image)
+template <bool H>
 __global__ __launch_bounds__(PNT, 2) void pointnet_stn_rows_kernel(const float* __restrict__ patches, int64_t Q, int P, int pack,
-                                                                   const float* __restrict__ wpack, const float* __restrict__ bias,
-                                                                   float* __restrict__ gout) {
+                                                                   const float* __restrict__ wpack, const f32x4* __restrict__ wdense,
+                                                                   const float* __restrict__ bias, float* __restrict__ gout) {
     f32x4* buf0 = (f32x4*)pps_smem;
     f32x4* buf1 = buf0 + PCH4;
     float* xyz_l = (float*)(buf1 + PCH4);
     float* bias_l = xyz_l + PA_W_XYZ;
     float* park = bias_l + PA_NBIAS;                       // [PNW][PN_PARK_ROWS][PN_ROWF] per-query left-over maxima
     const f32x4* bias4 = (const f32x4*)bias_l;
-    const f32x4* wg = (const f32x4*)(wpack + PA_W_XYZ);
+    const f32x4* wg = wdense;
     const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
     float* mypark = park + wave * PN_PARK_ROWS * PN_ROWF;
 
@@ -618,7 +656,7 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_stn_rows_kernel(const float* 
             const int ql = n / pk.lo;
             const int64_t qq = (q0 + ql < Q) ? q0 + ql : Q - 1;
             const float coord = (g < 3) ? patches[(qq * P + pk.fb * 16 + (n % pk.lo)) * 3 + g] : 0.f;
-            stn_chain(coord, z, xyz_l, bias4, wg, cur, nxt, lane);
+            if (H) stn_chain_h(coord, z, xyz_l, bias4, wg, cur, nxt, lane); else stn_chain(coord, z, xyz_l, bias4, wg, cur, nxt, lane);
 #pragma unroll
             for (int bb = 0; bb < 16; ++bb) {
                 f32x4 m;
@@ -639,7 +677,7 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_stn_rows_kernel(const float* 
                 const int row = rb * 16 + n;
                 const int rowc = row < P ? row : P - 1;       // padded rows repeat a valid point: max unaffected
                 const float coord = (g < 3) ? patches[(qc * P + rowc) * 3 + g] : 0.f;
-                stn_chain(coord, z, xyz_l, bias4, wg, cur, nxt, lane);
+                if (H) stn_chain_h(coord, z, xyz_l, bias4, wg, cur, nxt, lane); else stn_chain(coord, z, xyz_l, bias4, wg, cur, nxt, lane);
 #pragma unroll
                 for (int bb = 0; bb < 16; ++bb)
 #pragma unroll
@@ -733,6 +771,64 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_kernel(const float* __r
     }
 }
 
+// Split-precision variant ("f16x3"): the three layers as f16 hi/lo products, and trans2 is written ALREADY SPLIT in the A-operand
+// fragment order of pointnet_feat_rows_kernel<true>:  trans2h[q][ob 4][kb 2][part 2][lane (m + 16 g)][8 halfs]  with
+// element j of lane (m, g) = trans2[q][16 ob + m][32 kb + 16 (j >> 2) + 4 g + (j & 3)]  (16 KiB per query, like the fp32 matrix):
+// the pair of output blocks (4a + 2kb, 4a + 2kb + 1) of fc3 held by lane (query n, g) IS that fragment for row a = 16 ob + m.
+__global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_h_kernel(const float* __restrict__ gin, int64_t Q, const f32x4* __restrict__ w16,
+                                                                  const float* __restrict__ bias, half8* __restrict__ trans2h) {
+    f32x4* buf0 = (f32x4*)pps_smem;
+    f32x4* buf1 = buf0 + CH4;
+    float* bias_l = (float*)(buf1 + CH4);
+    const f32x4* bias4 = (const f32x4*)bias_l;
+    const f32x4* wg = w16;
+    const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+
+    lds_fill(bias_l, bias, PB_NBIAS);
+    stream_prologue<CH4>(wg, buf0);
+    __syncthreads();
+    f32x4 *cur = buf0, *nxt = buf1;
+    const int ntiles = (int)((Q + NW * 16 - 1) / (NW * 16));
+    int first, count, stride;
+    xcd_tile_range(ntiles, first, count, stride);
+    for (int it = 0; it < count; ++it) {
+        const int64_t qi = (int64_t)(first + it * stride) * (NW * 16) + wave * 16 + n;
+        const bool qv = qi < Q;
+        const int64_t qc = qv ? qi : Q - 1;
+        HiLo ah[8], h[4], u[2];
+        {
+            f32x4 a[16];
+            const f32x4* src = (const f32x4*)(gin + qc * 256) + g;
+#pragma unroll
+            for (int bb = 0; bb < 16; ++bb) a[bb] = src[4 * bb];
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) ah[kb] = split_f16(a[2 * kb], a[2 * kb + 1]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            stream_step<CH4>(wg + (c + 1) * CH4, cur, nxt, [&](const f32x4* w) {
+                dense_blocks_f16x3<8, 2, 1>(ah, (const half8*)w, bias4 + 8 * c, lane, [&](int, const f32x4& o0, const f32x4& o1) { h[c] = split_f16(o0, o1); }); });
+        stream_step<CH4>(wg + 5 * CH4, cur, nxt, [&](const f32x4* w) {
+            dense_blocks_f16x3<4, 4, 1>(h, (const half8*)w, bias4 + 32, lane, [&](int i, const f32x4& o0, const f32x4& o1) { u[i] = split_f16(o0, o1); }); });
+        half8* dst = trans2h + qc * 1024 + (n * 0) + 16 * g;          // + ((ob*2 + kb)*2 + part)*64 + m
+#pragma unroll 1
+        for (int c = 0; c < 32; ++c) {
+            const f32x4* gn = (c + 1 < 32) ? wg + (6 + c) * CH4 : wg;
+            stream_step<CH4>(gn, cur, nxt, [&](const f32x4* w) {
+                dense_blocks_f16x3<2, 8, 0>(u, (const half8*)w, bias4 + 48 + 32 * c, lane, [&](int i, const f32x4& o0, const f32x4& o1) {
+                    // blocks 8c + 2i, 8c + 2i + 1: row a = 2c + (i >> 1), k-block kb = i & 1
+                    const int a = 2 * c + (i >> 1), kb = i & 1;
+                    const HiLo v = split_f16(o0, o1);
+                    if (qv) {
+                        half8* d = dst + (((a >> 4) * 2 + kb) * 2) * 64 + (a & 15);
+                        d[0] = v.hi;
+                        d[64] = v.lo;
+                    }
+                }); });
+        }
+    }
+}
+
 // =====================================================================================================
 // PointNet phase C: conv0a, conv0b, x <- trans2 x, conv1, conv2 (+ReLU), conv3 (no ReLU), attention pooling
 // weights (floats): [xyz 256][c0b 4096][c1 4096][c2 8192][c3 32768]   bias [64][64][64][128][256][wq 256][bq 4]
@@ -808,9 +904,88 @@ __device__ __forceinline__ float feat_chain(float coord, const float* __restrict
     return s + bq;
 }
 
+// split precision: `trans2` is the pre-split fragment image written by pointnet_stn_fc_h_kernel (A operands straight from global,
+// no conversion work here); wg -> f16x3 images of c0b, c1, c2, c3
+__device__ __forceinline__ float feat_chain_h(float coord, const float* __restrict__ trans2, int64_t q0, int64_t Q, int nq, int rows_per_query,
+                                              f32x4 (&z)[16], const float* xyz_l, const f32x4* bias4, const f32x4* wq4, float bq,
+                                              const f32x4* wg, f32x4*& cur, f32x4*& nxt, int lane) {
+    const int n = lane & 15, g = lane >> 4;
+    HiLo a[2], b[2], y[4];
+    {
+        f32x4 x0[4];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) x0[bb] = bias4[4 * bb + g];
+        xyz_blocks<4>(coord, x0, xyz_l, lane);
+        relu_blocks<4>(x0);
+        a[0] = split_f16(x0[0], x0[1]);
+        a[1] = split_f16(x0[2], x0[3]);
+    }
+    __builtin_amdgcn_s_setprio(PPS_PRIO_PN);
+    stream_step<1024, PNT>(wg + 1024, cur, nxt, [&](const f32x4* w) {
+        dense_blocks_f16x3<2, 4, 1>(a, (const half8*)w, bias4 + 16, lane, [&](int i, const f32x4& o0, const f32x4& o1) { b[i] = split_f16(o0, o1); }); });
+    // feature transform with the per-query 64 x 64 matrix: three f16 products per (output block, k-block)
+    f32x4 t0[4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) t0[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+    for (int qi = 0; qi < nq; ++qi) {
+        const int64_t qq = (q0 + qi < Q) ? q0 + qi : Q - 1;
+        const half8* tq = (const half8*)trans2 + qq * 1024 + lane;
+        const bool mine = (n / rows_per_query) == qi;
+        HiLo xm[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) { xm[kb].hi = mine ? b[kb].hi : zero8; xm[kb].lo = mine ? b[kb].lo : zero8; }
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            half8 th[2], tl[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) { th[kb] = tq[((ob * 2 + kb) * 2) * 64]; tl[kb] = tq[((ob * 2 + kb) * 2 + 1) * 64]; }
+            f32x4 o = t0[ob], c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(th[kb], xm[kb].hi, o, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(th[kb], xm[kb].lo, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl[kb], xm[kb].hi, c, 0, 0, 0);
+            }
+            t0[ob] = o + c;
+        }
+    }
+    a[0] = split_f16(t0[0], t0[1]);
+    a[1] = split_f16(t0[2], t0[3]);
+    stream_step<PCH4, PNT>(wg + 2048, cur, nxt, [&](const f32x4* w) {
+        dense_blocks_f16x3<2, 4, 1>(a, (const half8*)w, bias4 + 32, lane, [&](int i, const f32x4& o0, const f32x4& o1) { b[i] = split_f16(o0, o1); }); });
+#pragma unroll
+    for (int h = 0; h < PN_C2N; ++h)
+        stream_step<PCH4, PNT>(wg + 2048 + (h + 1) * PCH4, cur, nxt, [&](const f32x4* w) {
+            dense_blocks_f16x3<2, PN_C2OB, 1>(b, (const half8*)w, bias4 + 48 + 4 * PN_C2OB * h, lane,
+                                              [&](int i, const f32x4& o0, const f32x4& o1) { y[PN_C2OB / 2 * h + i] = split_f16(o0, o1); }); });
+#pragma unroll
+    for (int c = 0; c < PN_C3N - 1; ++c)
+        stream_step<PCH4, PNT>(wg + 4096 + (c + 1) * PCH4, cur, nxt, [&](const f32x4* w) {
+            dense_blocks_f16x3<4, PN_C3OB, 0>(y, (const half8*)w, bias4 + 80 + 4 * PN_C3OB * c, lane,
+                                              [&](int i, const f32x4& o0, const f32x4& o1) { z[PN_C3OB * c + 2 * i] = o0; z[PN_C3OB * c + 2 * i + 1] = o1; }); });
+    stream_step<1024, PNT>(wg, cur, nxt, [&](const f32x4* w) {
+        dense_blocks_f16x3<4, PN_C3OB, 0>(y, (const half8*)w, bias4 + 80 + 4 * PN_C3OB * (PN_C3N - 1), lane,
+                                          [&](int i, const f32x4& o0, const f32x4& o1) { z[PN_C3OB * (PN_C3N - 1) + 2 * i] = o0; z[PN_C3OB * (PN_C3N - 1) + 2 * i + 1] = o1; }); });
+    __builtin_amdgcn_s_setprio(0);
+    float s = 0.f;
+#pragma unroll
+    for (int bb = 0; bb < 16; ++bb) {
+        const f32x4 w4 = wq4[4 * bb + g];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += w4[r] * z[bb][r];
+    }
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    return s + bq;
+}
+
+template <bool H>
 __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float* __restrict__ patches, const float* __restrict__ trans2,
                                                                     int64_t Q, int P, int pack, const float* __restrict__ wpack,
-                                                                    const float* __restrict__ bias, float* __restrict__ xbar) {
+                                                                    const f32x4* __restrict__ wdense, const float* __restrict__ bias,
+                                                                    float* __restrict__ xbar) {
     f32x4* buf0 = (f32x4*)pps_smem;
     f32x4* buf1 = buf0 + PCH4;
     float* xyz_l = (float*)(buf1 + PCH4);
@@ -818,7 +993,7 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float*
     float* park = bias_l + PC_NBIAS;                   // [PNW][PN_PARK_ROWS][PN_ROWF]: A[256], m, S of the left-over rows
     const f32x4* bias4 = (const f32x4*)bias_l;
     const f32x4* wq4 = bias4 + 144;
-    const f32x4* wg = (const f32x4*)(wpack + PC_W_XYZ);
+    const f32x4* wg = wdense;
     const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
     float* mypark = park + wave * PN_PARK_ROWS * PN_ROWF;
 
@@ -841,7 +1016,8 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float*
             const int ql = n / pk.lo;
             const int64_t qq = (q0 + ql < Q) ? q0 + ql : Q - 1;
             const float coord = (g < 3) ? patches[(qq * P + pk.fb * 16 + (n % pk.lo)) * 3 + g] : 0.f;
-            const float s = feat_chain(coord, trans2, q0, Q, pk.qg, pk.lo, z, xyz_l, bias4, wq4, bq, wg, cur, nxt, lane);
+            const float s = H ? feat_chain_h(coord, trans2, q0, Q, pk.qg, pk.lo, z, xyz_l, bias4, wq4, bq, wg, cur, nxt, lane)
+                              : feat_chain(coord, trans2, q0, Q, pk.qg, pk.lo, z, xyz_l, bias4, wq4, bq, wg, cur, nxt, lane);
             const float m = group_max(s, pk.lo);
             const float e = __expf(s - m);
             const float S = group_sum(e, pk.lo);
@@ -877,7 +1053,8 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float*
                 const bool valid = rowi < P;
                 const int rowc = valid ? rowi : P - 1;
                 const float coord = (g < 3) ? patches[(qc * P + rowc) * 3 + g] : 0.f;
-                const float s = feat_chain(coord, trans2, qc, Q, 1, 16, z, xyz_l, bias4, wq4, bq, wg, cur, nxt, lane);
+                const float s = H ? feat_chain_h(coord, trans2, qc, Q, 1, 16, z, xyz_l, bias4, wq4, bq, wg, cur, nxt, lane)
+                                  : feat_chain(coord, trans2, qc, Q, 1, 16, z, xyz_l, bias4, wq4, bq, wg, cur, nxt, lane);
                 // online softmax over the patch points (nn.py:91-93)
                 const float mblk = row16_max(valid ? s : -INFINITY);
                 const float mnew = fmaxf(mrun, mblk);
@@ -1007,6 +1184,38 @@ static PnSplit pn_split(int64_t q, int p) {
 
 #define PPS_LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH)
 
+template <bool H>
+static int launch_stn_rows(const float* patches, int64_t q, int p, const float* wpack, const void* wdense, const float* bias, float* g,
+                           void* stream) {
+    static int once = set_lds(pointnet_stn_rows_kernel<H>, PA_LDS_BYTES);
+    (void)once;
+    const PnSplit sp = pn_split(q, p);
+    if (sp.q_packed > 0)
+        hipLaunchKernelGGL(pointnet_stn_rows_kernel<H>, dim3(sp.grid_packed), dim3(PNT), PA_LDS_BYTES, (hipStream_t)stream, patches,
+                           sp.q_packed, p, 1, wpack, (const f32x4*)wdense, bias, g);
+    if (q > sp.q_packed)
+        hipLaunchKernelGGL(pointnet_stn_rows_kernel<H>, dim3(sp.grid_rest), dim3(PNT), PA_LDS_BYTES, (hipStream_t)stream,
+                           patches + sp.q_packed * p * 3, q - sp.q_packed, p, 0, wpack, (const f32x4*)wdense, bias, g + sp.q_packed * 256);
+    return PPS_LAUNCH_CHECK();
+}
+
+template <bool H>
+static int launch_feat_rows(const float* patches, const float* trans2, int64_t q, int p, const float* wpack, const void* wdense,
+                            const float* bias, float* xbar, void* stream) {
+    static int once = set_lds(pointnet_feat_rows_kernel<H>, PC_LDS_BYTES);
+    (void)once;
+    const PnSplit sp = pn_split(q, p);
+    if (sp.q_packed > 0)
+        hipLaunchKernelGGL(pointnet_feat_rows_kernel<H>, dim3(sp.grid_packed), dim3(PNT), PC_LDS_BYTES, (hipStream_t)stream, patches,
+                           trans2, sp.q_packed, p, 1, wpack, (const f32x4*)wdense, bias, xbar);
+    if (q > sp.q_packed)
+        hipLaunchKernelGGL(pointnet_feat_rows_kernel<H>, dim3(sp.grid_rest), dim3(PNT), PC_LDS_BYTES, (hipStream_t)stream,
+                           patches + sp.q_packed * p * 3, trans2 + sp.q_packed * 4096, q - sp.q_packed, p, 0, wpack, (const f32x4*)wdense, bias,
+                           xbar + sp.q_packed * 256);
+    return PPS_LAUNCH_CHECK();
+}
+
+
 extern "C" {
 
 int pps_abi_version(void) { return 2; }
@@ -1015,8 +1224,8 @@ int pps_abi_version(void) { return 2; }
 int pps_debug_occupancy(int which) {
     int n = -1;
     if (which == 0) { set_lds(interp_pool_kernel, IP_LDS_BYTES); hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, interp_pool_kernel, NT, IP_LDS_BYTES); }
-    if (which == 1) { set_lds(pointnet_stn_rows_kernel, PA_LDS_BYTES); hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pointnet_stn_rows_kernel, PNT, PA_LDS_BYTES); }
-    if (which == 2) { set_lds(pointnet_feat_rows_kernel, PC_LDS_BYTES); hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pointnet_feat_rows_kernel, PNT, PC_LDS_BYTES); }
+    if (which == 1) { set_lds(pointnet_stn_rows_kernel<false>, PA_LDS_BYTES); hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pointnet_stn_rows_kernel<false>, PNT, PA_LDS_BYTES); }
+    if (which == 2) { set_lds(pointnet_feat_rows_kernel<false>, PC_LDS_BYTES); hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pointnet_feat_rows_kernel<false>, PNT, PC_LDS_BYTES); }
     return n;
 }
 int pps_device_cu_count(void) { return cu_count(); }
@@ -1081,16 +1290,7 @@ int pps_pointnet_stn_rows_f32(const float* patches, int64_t q, int p, const floa
     if (q < 0 || p < 1) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
     if (!patches || !wpack || !bias || !g) return PPS_ERR_ARG;
-    static int once = set_lds(pointnet_stn_rows_kernel, PA_LDS_BYTES);
-    (void)once;
-    const PnSplit sp = pn_split(q, p);
-    if (sp.q_packed > 0)
-        hipLaunchKernelGGL(pointnet_stn_rows_kernel, dim3(sp.grid_packed), dim3(PNT), PA_LDS_BYTES, (hipStream_t)stream, patches,
-                           sp.q_packed, p, 1, wpack, bias, g);
-    if (q > sp.q_packed)
-        hipLaunchKernelGGL(pointnet_stn_rows_kernel, dim3(sp.grid_rest), dim3(PNT), PA_LDS_BYTES, (hipStream_t)stream,
-                           patches + sp.q_packed * p * 3, q - sp.q_packed, p, 0, wpack, bias, g + sp.q_packed * 256);
-    return PPS_LAUNCH_CHECK();
+    return launch_stn_rows<false>(patches, q, p, wpack, wpack + PA_W_XYZ, bias, g, stream);
 }
 
 int pps_pointnet_stn_fc_f32(const float* g, int64_t q, const float* wpack, const float* bias, float* trans2, void* stream) {
@@ -1109,17 +1309,29 @@ int pps_pointnet_feat_rows_f32(const float* patches, const float* trans2, int64_
     if (q < 0 || p < 1) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
     if (!patches || !trans2 || !wpack || !bias || !xbar) return PPS_ERR_ARG;
-    static int once = set_lds(pointnet_feat_rows_kernel, PC_LDS_BYTES);
+    return launch_feat_rows<false>(patches, trans2, q, p, wpack, wpack + PC_W_XYZ, bias, xbar, stream);
+}
+
+/* Split-precision PointNet branch ("f16x3"): w16[0..2] = f16x3 images of (c0b, s1, s2, s3), (fc1, fc2, fc3), (c0b, c1, c2, c3); the fp32
+ * images supply the xyz layers and the biases.  trans2 (q x 16 KiB of scratch) holds the pre-split fragments between the kernels. */
+int pps_pointnet_f16x3(const float* patches, int64_t q, int p, const float* const* weights /* [2..7] of the decode array */,
+                       const void* const* w16, float* g, float* trans2, float* xbar, void* const* events, void* stream) {
+    if (q < 0 || p < 1) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    if (!patches || !weights || !w16 || !w16[0] || !w16[1] || !w16[2] || !g || !trans2 || !xbar) return PPS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_stn_rows<true>(patches, q, p, weights[0], w16[0], weights[1], g, stream);
+    if (events && events[0]) hipEventRecord((hipEvent_t)events[0], st);
+    if (rc != PPS_OK) return rc;
+    static int once = set_lds(pointnet_stn_fc_h_kernel, PB_LDS_BYTES);
     (void)once;
-    const PnSplit sp = pn_split(q, p);
-    if (sp.q_packed > 0)
-        hipLaunchKernelGGL(pointnet_feat_rows_kernel, dim3(sp.grid_packed), dim3(PNT), PC_LDS_BYTES, (hipStream_t)stream, patches,
-                           trans2, sp.q_packed, p, 1, wpack, bias, xbar);
-    if (q > sp.q_packed)
-        hipLaunchKernelGGL(pointnet_feat_rows_kernel, dim3(sp.grid_rest), dim3(PNT), PC_LDS_BYTES, (hipStream_t)stream,
-                           patches + sp.q_packed * p * 3, trans2 + sp.q_packed * 4096, q - sp.q_packed, p, 0, wpack, bias,
-                           xbar + sp.q_packed * 256);
-    return PPS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pointnet_stn_fc_h_kernel, dim3(grid_for((q + NW * 16 - 1) / (NW * 16))), dim3(NT), PB_LDS_BYTES, st, g, q,
+                       (const f32x4*)w16[1], weights[3], (half8*)trans2);
+    if (events && events[1]) hipEventRecord((hipEvent_t)events[1], st);
+    if (hipGetLastError() != hipSuccess) return PPS_ERR_LAUNCH;
+    rc = launch_feat_rows<true>(patches, trans2, q, p, weights[4], w16[2], weights[5], xbar, stream);
+    if (events && events[2]) hipEventRecord((hipEvent_t)events[2], st);
+    return rc;
 }
 
 int pps_decode_tail_f32(const float* pooled, const float* xbar, int64_t q, const float* wpack, const float* bias,
@@ -1139,7 +1351,9 @@ size_t pps_decode_ws_bytes(int64_t q) { return q < 0 ? 0 : (size_t)q * (256 + 25
 
 static int decode_fwd(const float* table, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
                       const float* patches, int p, const float* const* weights, float* logits, float* occ, void* ws, void* const* events,
-                      void* stream, const void* interp_w16 = nullptr) {
+                      void* stream, const void* const* w16 = nullptr) {
+    const void* interp_w16 = w16 ? w16[0] : nullptr;
+    const bool pn16 = w16 && w16[1] && w16[2] && w16[3];
     if (q < 0) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
     if (!weights || !ws || !logits) return PPS_ERR_ARG;
@@ -1155,12 +1369,16 @@ static int decode_fwd(const float* table, const float* pts, const float* query, 
     int rc = interp_w16 ? pps_interp_pool_f16x3(table, pts, query, idx, q, k, weights[0], interp_w16, weights[1], pooled, stream)
                         : pps_interp_pool_f32(table, pts, query, idx, q, k, weights[0], weights[1], pooled, stream);
     PPS_MARK(1);
-    if (rc == PPS_OK) rc = pps_pointnet_stn_rows_f32(patches, q, p, weights[2], weights[3], g, stream);
-    PPS_MARK(2);
-    if (rc == PPS_OK) rc = pps_pointnet_stn_fc_f32(g, q, weights[4], weights[5], trans2, stream);
-    PPS_MARK(3);
-    if (rc == PPS_OK) rc = pps_pointnet_feat_rows_f32(patches, trans2, q, p, weights[6], weights[7], xbar, stream);
-    PPS_MARK(4);
+    if (pn16) {
+        if (rc == PPS_OK) rc = pps_pointnet_f16x3(patches, q, p, weights + 2, w16 + 1, g, trans2, xbar, events ? events + 2 : nullptr, stream);
+    } else {
+        if (rc == PPS_OK) rc = pps_pointnet_stn_rows_f32(patches, q, p, weights[2], weights[3], g, stream);
+        PPS_MARK(2);
+        if (rc == PPS_OK) rc = pps_pointnet_stn_fc_f32(g, q, weights[4], weights[5], trans2, stream);
+        PPS_MARK(3);
+        if (rc == PPS_OK) rc = pps_pointnet_feat_rows_f32(patches, trans2, q, p, weights[6], weights[7], xbar, stream);
+        PPS_MARK(4);
+    }
     if (rc == PPS_OK) rc = pps_decode_tail_f32(pooled, xbar, q, weights[8], weights[9], logits, occ, stream);
     PPS_MARK(5);
 #undef PPS_MARK
@@ -1179,10 +1397,10 @@ int pps_decode_fwd_events_f32(const float* table, const float* pts, const float*
 }
 
 int pps_decode_fwd_mixed_f32(const float* table, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
-                             const float* patches, int p, const float* const* weights, const void* interp_w16, float* logits, float* occ,
+                             const float* patches, int p, const float* const* weights, const void* const* w16, float* logits, float* occ,
                              void* ws, void* const* events, void* stream) {
-    if (!interp_w16) return PPS_ERR_ARG;
-    return decode_fwd(table, pts, query, idx, q, k, patches, p, weights, logits, occ, ws, events, stream, interp_w16);
+    if (!w16) return PPS_ERR_ARG;
+    return decode_fwd(table, pts, query, idx, q, k, patches, p, weights, logits, occ, ws, events, stream, w16);
 }
 
 }  // extern "C"

