@@ -217,11 +217,13 @@ def main():
         torch.cuda.synchronize()
         dt16 = time.perf_counter() - t0
         ref_occ = pipe.run([c], want_occ=True)[0][1]
-        out['f16x3'] = {'value': Q_CHUNK * len(seq) / dt16, 'unit': 'queries/s', 'ms_per_step': dt16 / len(seq) * 1e3, 'steps': len(seq),
+        f16_stats = {'value': Q_CHUNK * len(seq) / dt16, 'unit': 'queries/s', 'ms_per_step': dt16 / len(seq) * 1e3, 'steps': len(seq),
                         'stage_ms': {name: float(np.mean([e.elapsed_ms(j, j + 1) for e in ev16])) for j, name in enumerate(STAGES)},
                         'max_abs_occ_diff_vs_f32_last_chunk': float((r16[0][1] - ref_occ).abs().max()),
-                        'note': 'opt-in decoder dtype (DecoderPlan(dtype="f16x3") / PPS_DECODER_DTYPE): interpolation branch on the f16 matrix '
-                                'pipe in split precision, PointNet branch and tail in fp32; same chunks as the fp32 run'}
+                        'note': 'opt-in decoder dtype (DecoderPlan(dtype="f16x3") / network.decoder_dtype / PPS_DECODER_DTYPE): the dense layers of '
+                                'the interpolation and PointNet branches on the f16 matrix pipe in split precision (3 f16 products per fp32 product, '
+                                'fp32 accumulation); per-point table, xyz layers, softmax / pooling and tail fp32; same chunks as the fp32 run'}
+        out['f16x3'] = f16_stats
         del plan16, pipes16, w16, ev16
         del work, ev
         torch.cuda.empty_cache()
@@ -235,6 +237,10 @@ def main():
                                  'note': 'whole R=257 reconstruction of a 100k-point cloud by the product driver: latent loop (100 encoder '
                                          'passes), region growing, Marching Cubes + clean-up, 10 refinement rounds; every query decoded by the real '
                                          'kernels, growth steered by the analytic shape (formula-filled weights describe no surface)'}
+        model.network.decoder_dtype = 'f16x3'
+        runs16 = [workloads.reconstruct_steered(model, N_POINTS, seed=42 + i, device=dev) for i in range(2)]
+        out['f16x3']['shapes_per_hour'] = 3600.0 / runs16[-1]['total_s']
+        out['f16x3']['reconstruction_steady_s'] = runs16[-1]['total_s']
         del model
         torch.cuda.empty_cache()
         fit = workloads.FitStep(batch=10, precision='bf16-mixed', device=dev)

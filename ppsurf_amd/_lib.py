@@ -7,6 +7,8 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libppsurf_amd.so')
+if os.environ.get('PPS_LIB_VARIANT'):          # development aid: an ablation / tuning build made by `python -m ppsurf_amd.build --variant NAME`
+    LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), 'libppsurf_amd_{}.so'.format(os.environ['PPS_LIB_VARIANT']))
 
 _c = ctypes
 _P, _I64, _I, _SZ = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_size_t

@@ -168,7 +168,9 @@ __device__ __forceinline__ void join_f16(const HiLo& x, f32x4& y0, f32x4& y1) {
 // PAIR is handed to `sink(pair_index, f32x4 block_even, f32x4 block_odd)`.
 // Main products (hi.hi) and corrections (hi.lo + lo.hi) accumulate separately: dependent MFMAs are 4 issues apart, and the small
 // terms are summed among themselves before they meet the large ones.
-template <int KB, int NOB, int ACT, class Sink>
+// FENCE = false drops the scheduling fence after each k-step: for short contractions (KB = 2) the epilogue of one pair (split +
+// stores) then overlaps the MFMAs of the next pair instead of running alone.
+template <int KB, int NOB, int ACT, bool FENCE = true, class Sink>
 __device__ __forceinline__ void dense_blocks_f16x3(const HiLo (&in)[KB], const half8* __restrict__ w, const f32x4* __restrict__ bias, int lane,
                                                    Sink&& sink) {
     static_assert(NOB % 2 == 0, "output blocks are processed in pairs");
@@ -193,9 +195,11 @@ __device__ __forceinline__ void dense_blocks_f16x3(const HiLo (&in)[KB], const h
             c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, in[kb].lo, c1, 0, 0, 0);
             c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, in[kb].hi, c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, in[kb].hi, c1, 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(PPS_SG_DSREAD, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(PPS_SG_MFMA, 6, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            if (FENCE) {
+                __builtin_amdgcn_sched_group_barrier(PPS_SG_DSREAD, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(PPS_SG_MFMA, 6, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         f32x4 o0 = m0 + c0, o1 = m1 + c1;
         if (ACT == 1) {

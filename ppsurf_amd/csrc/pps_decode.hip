@@ -772,7 +772,8 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_kernel(const float* __r
 }
 
 // Split-precision variant ("f16x3"): the three layers as f16 hi/lo products, and trans2 is written ALREADY SPLIT in the A-operand
-// fragment order of pointnet_feat_rows_kernel<true>:  trans2h[q][ob 4][kb 2][part 2][lane (m + 16 g)][8 halfs]  with
+// fragment order of pointnet_feat_rows_kernel<true>:  trans2h[q][ob 4][kb 2][part 2][slot 4 m + g][8 halfs]  (the four k-groups of a row
+// are adjacent, so the four lanes (query n, g = 0..3) of the writer store 64 contiguous bytes, like the fp32 kernel does)  with
 // element j of lane (m, g) = trans2[q][16 ob + m][32 kb + 16 (j >> 2) + 4 g + (j & 3)]  (16 KiB per query, like the fp32 matrix):
 // the pair of output blocks (4a + 2kb, 4a + 2kb + 1) of fc3 held by lane (query n, g) IS that fragment for row a = 16 ob + m.
 __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_h_kernel(const float* __restrict__ gin, int64_t Q, const f32x4* __restrict__ w16,
@@ -810,17 +811,21 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_h_kernel(const float* _
                 dense_blocks_f16x3<8, 2, 1>(ah, (const half8*)w, bias4 + 8 * c, lane, [&](int, const f32x4& o0, const f32x4& o1) { h[c] = split_f16(o0, o1); }); });
         stream_step<CH4>(wg + 5 * CH4, cur, nxt, [&](const f32x4* w) {
             dense_blocks_f16x3<4, 4, 1>(h, (const half8*)w, bias4 + 32, lane, [&](int i, const f32x4& o0, const f32x4& o1) { u[i] = split_f16(o0, o1); }); });
-        half8* dst = trans2h + qc * 1024 + (n * 0) + 16 * g;          // + ((ob*2 + kb)*2 + part)*64 + m
+        half8* dst = trans2h + qc * 1024 + g;                         // + ((ob*2 + kb)*2 + part)*64 + 4*m
 #pragma unroll 1
         for (int c = 0; c < 32; ++c) {
             const f32x4* gn = (c + 1 < 32) ? wg + (6 + c) * CH4 : wg;
             stream_step<CH4>(gn, cur, nxt, [&](const f32x4* w) {
-                dense_blocks_f16x3<2, 8, 0>(u, (const half8*)w, bias4 + 48 + 32 * c, lane, [&](int i, const f32x4& o0, const f32x4& o1) {
+                dense_blocks_f16x3<2, 8, 0, false>(u, (const half8*)w, bias4 + 48 + 32 * c, lane, [&](int i, const f32x4& o0, const f32x4& o1) {
                     // blocks 8c + 2i, 8c + 2i + 1: row a = 2c + (i >> 1), k-block kb = i & 1
                     const int a = 2 * c + (i >> 1), kb = i & 1;
                     const HiLo v = split_f16(o0, o1);
+#ifdef PPS_ABL_NOSTORE
+                    if (qv && o0.x == 123.456f) {
+#else
                     if (qv) {
-                        half8* d = dst + (((a >> 4) * 2 + kb) * 2) * 64 + (a & 15);
+#endif
+                        half8* d = dst + (((a >> 4) * 2 + kb) * 2) * 64 + 4 * (a & 15);
                         d[0] = v.hi;
                         d[64] = v.lo;
                     }
@@ -931,7 +936,7 @@ __device__ __forceinline__ float feat_chain_h(float coord, const float* __restri
 #pragma unroll 1
     for (int qi = 0; qi < nq; ++qi) {
         const int64_t qq = (q0 + qi < Q) ? q0 + qi : Q - 1;
-        const half8* tq = (const half8*)trans2 + qq * 1024 + lane;
+        const half8* tq = (const half8*)trans2 + qq * 1024 + 4 * n + g;       // slot 4 m + g of each 1 KiB fragment block
         const bool mine = (n / rows_per_query) == qi;
         HiLo xm[2];
 #pragma unroll

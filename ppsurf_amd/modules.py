@@ -332,10 +332,12 @@ class PPSurfNetwork(_Base):
     # -- plans / caches ------------------------------------------------------------------------------------------
     def decoder_plan(self, device) -> DecoderPlan:
         mods = nn.ModuleList([self.projection, self.point_net, self.mlp])
-        ver = _params_version(mods) + (self.training,)
+        # decoder_dtype: None / 'f32' = exact fp32 MFMA (the parity path), 'f16x3' = opt-in split precision (decoder.DecoderPlan);
+        # unset, the environment variable PPS_DECODER_DTYPE decides
+        ver = _params_version(mods) + (self.training, getattr(self, 'decoder_dtype', None))
         if self._dec is None or self._dec[0] != ver or self._dec[1].device != torch.device(device):
             sd = {k: v for k, v in _sd(self).items() if not k.startswith('encoder.')}
-            self._dec = (ver, DecoderPlan(sd, device))
+            self._dec = (ver, DecoderPlan(sd, device, dtype=getattr(self, 'decoder_dtype', None)))
             self._table = None
         return self._dec[1]
 
