@@ -92,6 +92,8 @@ def main():
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
     ap.add_argument('--quick', action='store_true', help='query throughput only: no shapes/hour, fit step or CPU baseline legs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dtype', choices=['f32', 'f16x3'], default='f32', help="decoder dtype of the timed loop; 'f16x3' (opt-in split precision) is for profiling "
+                    'runs -- the headline value is the f32 run')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1 ('nccl' = RCCL; 'gloo' only for single-GPU rehearsals)")
     ap.add_argument('--same-gpu', action='store_true', help='rehearsal: every rank uses cuda:0 (needs --backend gloo)')
     args = ap.parse_args()
@@ -127,7 +129,7 @@ def main():
         return strong(args, rank, world, dev, dist, red_dev)
 
     sd = network_state_dict('ppsurf')
-    plan = DecoderPlan(sd, dev)
+    plan = DecoderPlan(sd, dev, dtype=args.dtype)
     # ---- resident inputs: as many shapes as it takes to give every step its own chunk of a real first-round band ----------
     total_chunks = args.warmup + args.steps
     shapes, work = [], []                                        # work: (pipeline, chunk) per step
@@ -177,7 +179,7 @@ def main():
         out = {
             'metric': 'occupancy query-points/sec @ res=257, 50NN', 'value': value, 'unit': 'queries/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'ppsurf_50nn predict, R=257: {} distinct first-growth-round band chunks of {} queries '
                                    '(rec_batch_size) over {} synthetic 100k-point clouds per GPU, k=64, P=50'.format(args.steps, Q_CHUNK, len(shapes)),
                        'parallelism': 'query-block sharding x{}'.format(world), 'weights': 'formula-filled (no checkpoint offline)',
@@ -194,7 +196,7 @@ def main():
             'whole_path_algorithmic_tflops': ALG_MFLOP_PER_QUERY * 1e6 * value / world / 1e12,
             'whole_path_executed_mfma_frac': sum(STAGE_EXEC_MFMA_PER_QUERY.values()) * 2048.0 * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS,
         }
-    extra = world == 1 and not args.quick
+    extra = world == 1 and not args.quick and args.dtype == 'f32'
     if extra:
         # ---- opt-in split-precision decoder (dtype "f16x3": fc2 / fc3 / fc_query of the interpolation branch as 3 f16 MFMA products
         # per fp32 product; logits within ~1e-5 of the fp32 path, tests/test_gpu_decoder.py).  NOT the headline value. ----------

@@ -2,15 +2,19 @@
 import json
 import sys
 
-ORDER = ['interp_pool_kernel', 'pointnet_feat_rows_kernel', 'pointnet_stn_rows_kernel', 'pointnet_stn_fc_kernel', 'knn_blocked_kernel<1>',
-         'decode_tail_kernel', 'patch_normalize_kernel', 'rows_dense256_kernel']
+ORDER = ['interp_pool_kernel', 'interp_pool_f16x3_kernel', 'pointnet_feat_rows_kernel<false>', 'pointnet_feat_rows_kernel<true>',
+         'pointnet_stn_rows_kernel<false>', 'pointnet_stn_rows_kernel<true>', 'pointnet_stn_fc_kernel', 'pointnet_stn_fc_h_kernel',
+         'pointnet_feat_rows_kernel', 'pointnet_stn_rows_kernel', 'knn_blocked_kernel<1>', 'decode_tail_kernel', 'patch_normalize_kernel',
+         'rows_dense256_kernel']
 
 
 def main(prefix):
     k = json.load(open(prefix + '_pmc.json'))['kernels']
-    lines = ['# Per-kernel HBM traffic and MFMA utilisation (round 1, one MI355X)', '',
-             'Source: `round1_rocprof_summary.txt` / `round1_pmc.json` (`tools/profile_round.sh`: `rocprofv3 --kernel-trace --stats` and separate',
-             '`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--pmc SQ_*/GRBM_GUI_ACTIVE` passes of `python bench.py --steps 10 --warmup 2`).',
+    import os
+    tag = os.path.basename(prefix)
+    lines = ['# Per-kernel HBM traffic and MFMA utilisation ({}, one MI355X)'.format(tag), '',
+             'Source: `{0}_rocprof_summary.txt` / `{0}_pmc.json` (`tools/profile_round.sh`: `rocprofv3 --kernel-trace --stats` and separate'.format(tag),
+             '`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, `--pmc SQ_*/GRBM_GUI_ACTIVE` passes of `python bench.py --steps 20 --warmup 3 --quick`).',
              'FETCH_SIZE is doubled (gfx950 reports half of a wide coalesced read stream, MI355X_MICROARCH.md §HBM); KiB -> MB.',
              'MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs x 1024 SIMDs).  The PointNet row kernels are launched twice per',
              'step (packed full rounds + per-query remainder); their rows are the average over both launches.', '',
@@ -25,8 +29,8 @@ def main(prefix):
         util = v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (cyc * 1024.0)
         lines.append('| `{}` | {:.1f} | {:.1f} | {:.1f} | {:.3f} | {:.1f} % | {:.2f} |'.format(name, us, rd, wr, (rd + wr) / us, 100 * util,
                                                                                            cyc / (us * 1e3)))
-    lines += ['', 'All decoder kernels are MFMA-bound (HBM < 1.5 TB/s of ~6.3 achievable); `knn_blocked_kernel` is VALU/selection-bound with its',
-              '1.2 MB cloud in L2 (15 MB fetched per launch for 5·10⁹ candidate pairs before culling).']
+    lines += ['', 'MFMA utilisation counts BUSY cycles of the matrix pipe whatever the operand type (fp32 MFMA in the f32 run, f16 MFMA in the',
+              'f16x3 run).  `knn_blocked_kernel` is VALU/selection-bound with its 1.2 MB cloud in L2.']
     open(prefix + '_kernel_table.md', 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines[9:20]))
 
