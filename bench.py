@@ -171,10 +171,10 @@ def main():
         k_ms = stage_ms['interp_pool']
         executed = INTERP_EXEC_FLOP_PER_QUERY * Q_CHUNK / (k_ms * 1e-3) / 1e12
         traffic, traffic_src = None, None
-        pmc = os.path.join(REPO, 'profiles', 'round1_pmc.json')
+        pmc = os.path.join(REPO, 'profiles', 'round2_f32_pmc.json')
         if os.path.isfile(pmc):
             traffic = json.load(open(pmc)).get('interp_pool_hbm_bytes_per_launch')
-            traffic_src = 'profiles/round1_pmc.json (rocprofv3 --pmc passes of a previous run, NOT measured in this run)'
+            traffic_src = 'profiles/round2_f32_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes of this bench (a previous run, NOT measured in this run)'
         stage_frac = {n: STAGE_EXEC_MFMA_PER_QUERY[n] * 2048.0 * Q_CHUNK / (stage_ms[n] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS for n in STAGES}
         out = {
             'metric': 'occupancy query-points/sec @ res=257, 50NN', 'value': value, 'unit': 'queries/s',
