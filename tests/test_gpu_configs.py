@@ -242,3 +242,43 @@ def test_config5_ppsurf_200nn_chunk_at_size():
             'pts_local_ps': torch.from_numpy(patches).unsqueeze(0)}
     ref = O.ppsurf_from_latent(sd, data, k=64)[0].T.numpy()
     np.testing.assert_allclose(lg[sel], ref, rtol=0, atol=1e-4)
+
+
+def test_f16x3_reconstruction_equals_fp32_reconstruction(trained):
+    """The opt-in split-precision decoder end to end: same latents, same driver -> the occupancy of every band voxel agrees with the
+    fp32 decoder within 1e-4 and the two meshes coincide (learned weights of the abc_mini4 fit, R = 65)."""
+    from ppsurf_amd import reconstruct, meshio
+    from ppsurf_amd.lightning_api import PPSurfModel
+    import contextlib, io
+    root, ckpt = trained
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = PPSurfModel(pointnet_latent_size=256, output_names=['imp_surf_sign'], in_channels=3, out_channels=2, k=64, lambda_l1=0.0, debug=False,
+                            in_file='x.npy', results_dir=str(root / 'r16'), padding_factor=0.05, name='t', network_latent_size=256,
+                            gen_subsample_manifold_iter=3, gen_subsample_manifold=10000, gen_resolution_global=65, num_pts_local=50,
+                            rec_batch_size=50000, gen_refine_iter=10, workers=1)
+    model.load_state_dict(torch.load(ckpt, map_location='cpu')['state_dict'])
+    model = model.to(DEV).eval()
+    names = [l.strip() for l in open(root / 'abc' / 'trainset.txt') if l.strip()]
+    cloud = meshio.load_pts(str(root / 'abc' / '04_pts_vis' / (names[0] + '.xyz.ply')))[:, :3].astype(np.float32)
+    pts_cf = torch.from_numpy(cloud).to(DEV).t().contiguous()
+    lat = model.encode_latents(pts_cf)
+    shape = {'pts': pts_cf.unsqueeze(0), 'latents': lat.t().unsqueeze(0)}
+    out = {}
+    for dt in ('f32', 'f16x3'):
+        model.network.decoder_dtype = dt
+        field = reconstruct.OccupancyField(model.network, shape, pts_cf.t().unsqueeze(0), 50000, 50)
+        assert field.plan.dtype == dt
+        step, bmin_pad, pts_ids = __import__('ppsurf_amd.workloads', fromlist=['x']).grid_geometry(cloud, 65)
+        vol = reconstruct.create_volume(field, torch.from_numpy(pts_ids).to(DEV), 65, step, bmin_pad)
+        mesh = reconstruct.export_mesh_and_refine_vertices_region_growing_v3(
+            network=model.network, latent=shape, pts_raw_ms=pts_cf.t().unsqueeze(0), resolution=65, padding=1, mc_value=0, num_pts=50000,
+            num_pts_local=50, input_points=cloud, refine_iter=10, out_value=1)
+        out[dt] = (vol.cpu().numpy(), mesh)
+    va, vb = out['f32'][0], out['f16x3'][0]
+    both = ~np.isnan(va) & ~np.isnan(vb)
+    assert (np.isnan(va) != np.isnan(vb)).mean() < 1e-3                      # the same band (a sign flip needs |occ| < 1e-4)
+    assert np.abs(va[both] - vb[both]).max() < 1e-4
+    ma, mb = out['f32'][1], out['f16x3'][1]
+    assert ma is not None and mb is not None and abs(ma[0].shape[0] - mb[0].shape[0]) <= 0.002 * ma[0].shape[0] + 2
+    d = np.sqrt(((ma[0][::9, None, :] - mb[0][None, :, :]) ** 2).sum(-1)).min(axis=1)
+    assert np.median(d) < 1e-4 and np.percentile(d, 99) < 0.05 / 64
