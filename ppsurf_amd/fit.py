@@ -7,6 +7,10 @@
     all-reduce over RCCL overlapped with the backward pass (sharding.GradBuckets) -> optimizer step;
   * BatchNorm / norm_radius buffers follow DDP semantics (`broadcast_buffers=True`): rank 0's values are broadcast, coalesced
     into one message, at the start of every step; between two steps they are rank-local;
+  * single GPU: after three eager steps the WHOLE optimisation step (forward, loss, backward, gradient-buffer handling, fused AdamW,
+    loss scaling) is captured into one HIP graph per batch signature and replayed (`GraphedStep`; ~1500 launches per step, many of
+    them on 39 .. 625-point encoder levels, are launch-bound otherwise); the batch is copied into static buffers, the id tables stay
+    outside the graph.  `PPS_FIT_GRAPH=0` disables it; multi-GPU runs stay eager (the bucketed all-reduce is driven by autograd hooks);
   * validation every `check_val_every_n_epoch` epochs in eval() mode -- that is the fused HIP inference path;
   * ModelCheckpoint(save_last) -> models/<name>/version_0/checkpoints/last.ckpt with Lightning's key layout
     ({'state_dict': {'network.<...>': tensor}, 'epoch', 'global_step', 'optimizer_states', 'lr_schedulers'}), so checkpoints
@@ -41,6 +45,59 @@ class _MetricLog:
         return {k: (float(v) if torch.is_tensor(v) else v) for k, v in self.values.items()}
 
 
+class GraphedStep:
+    """One optimisation step as a replayable HIP graph (torch.cuda.CUDAGraph = hipGraph on ROCm), one graph per batch signature
+    (keys, shapes, dtypes).  `eager(batch, bi)` is the step body; it must be free of host synchronisation and data-dependent shapes
+    (it is: metrics are device tensors, id tables are inputs, the optimizer is fused + capturable)."""
+    WARMUP = 3
+
+    def __init__(self, eager, metrics, enabled=True, max_graphs=2):
+        self.eager, self.metrics, self.enabled, self.max_graphs = eager, metrics, enabled, max_graphs
+        self.seen, self.graphs, self.failed = {}, {}, False
+
+    @staticmethod
+    def signature(batch):
+        return tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in batch.items() if torch.is_tensor(v)))
+
+    def run(self, batch, bi):
+        """Executes the step (eagerly, or by replaying the captured graph) and leaves the logged values in self.metrics.values."""
+        if self.enabled and not self.failed:
+            sig = self.signature(batch)
+            entry = self.graphs.get(sig)
+            if entry is None:
+                n = self.seen.get(sig, 0)
+                self.seen[sig] = n + 1
+                if n >= self.WARMUP and len(self.graphs) < self.max_graphs:
+                    entry = self._capture(batch, bi)           # records only; the replay below executes this batch
+                    if entry is not None:
+                        self.graphs[sig] = entry
+            if entry is not None:
+                static, graph, logged = entry
+                for k, v in static.items():
+                    v.copy_(batch[k], non_blocking=True)
+                graph.replay()
+                # the logged tensors are outputs of the graph and are overwritten by the next replay: hand out copies
+                self.metrics.values = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in logged.items()}
+                return
+        self.eager(batch, bi)
+
+    def _capture(self, batch, bi):
+        static = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
+        rest = {k: v for k, v in batch.items() if not torch.is_tensor(v) and not k.startswith('_')}      # '_...' entries are caches of device tensors
+        graph = torch.cuda.CUDAGraph()
+        try:
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                self.eager(dict(static, **rest), bi)
+            logged = dict(self.metrics.values)
+        except Exception as exc:                               # anything that cannot be captured: stay eager for the rest of the run
+            self.failed = True
+            print('fit: HIP-graph capture of the step failed ({}: {}); continuing eagerly'.format(type(exc).__name__, str(exc).split('\n')[0]))
+            torch.cuda.synchronize()
+            return None
+        return static, graph, logged
+
+
 def autocast_context(precision, device_type='cuda'):
     precision = str(precision)
     if precision in ('16-mixed', '16'):
@@ -60,8 +117,10 @@ def save_checkpoint(path, model, optimizer, scheduler, epoch, global_step):
     tmp = path + '.tmp'
     # key layout of a Lightning 2 checkpoint (the reference pins pytorch-lightning>=2.0, requirements.txt:3): the version must be
     # a valid PEP 440 string (Lightning's migrate_checkpoint parses it), 'loops' / 'callbacks' may be empty
+    osd = optimizer.state_dict()
+    osd['param_groups'] = [dict(g, lr=float(g['lr'])) for g in osd['param_groups']]          # plain floats, whatever the run kept on the device
     torch.save({'state_dict': model.state_dict(), 'epoch': epoch, 'global_step': global_step,
-                'optimizer_states': [optimizer.state_dict()], 'lr_schedulers': [scheduler.state_dict()] if scheduler is not None else [],
+                'optimizer_states': [osd], 'lr_schedulers': [scheduler.state_dict()] if scheduler is not None else [],
                 'pytorch-lightning_version': LIGHTNING_CKPT_VERSION, 'loops': {}, 'callbacks': {}, 'hyper_parameters': {},
                 'ppsurf_amd': True}, tmp)
     os.replace(tmp, path)
@@ -77,7 +136,14 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
     params = [p for p in model.parameters() if p.requires_grad]
     if not cfg.get('optimizer'):
         raise ValueError('fit needs an `optimizer:` section (class_path / init_args), as in configs/poco.yaml:60-69')
-    optimizer = _instantiate(cfg['optimizer'], params)
+    use_graph = world == 1 and torch.device(device).type == 'cuda' and os.environ.get('PPS_FIT_GRAPH', '1') != '0'
+    ospec = cfg['optimizer']
+    if use_graph and ospec.get('class_path', '').rsplit('.', 1)[-1] in ('AdamW', 'Adam'):
+        # the fused implementation takes the loss scale / found-inf tensors on the device (no host sync in GradScaler.step) and,
+        # with capturable=True, keeps its step counter on the device: the same update rule, recordable into a graph
+        ospec = dict(ospec, init_args=dict(ospec.get('init_args', {}), fused=True, capturable=True))
+    optimizer = _instantiate(ospec, params)
+
     scheduler = _instantiate(cfg['lr_scheduler'], optimizer) if cfg.get('lr_scheduler') else None
     scaler = torch.amp.GradScaler(torch.device(device).type, enabled=use_scaler)
     start_epoch, global_step = 0, 0
@@ -89,6 +155,9 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
         if scheduler is not None and state.get('lr_schedulers'):
             scheduler.load_state_dict(state['lr_schedulers'][0])
         start_epoch, global_step = int(state.get('epoch', -1)) + 1, int(state.get('global_step', 0))
+    if use_graph:
+        for group in optimizer.param_groups:                   # a device-side learning rate: the scheduler's changes reach the replayed graph
+            group['lr'] = torch.tensor(float(group['lr']), dtype=torch.float32, device=device)
     if world > 1:
         import torch.distributed as dist
         for t in list(model.parameters()) + list(model.buffers()):
@@ -116,27 +185,32 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
         if mfile is not None:
             mfile.write(json.dumps(rec) + '\n')
 
+    def eager_step(batch, bi):
+        buckets.zero()
+        metrics.values = {}
+        sharding.broadcast_buffers(model)
+        with ctx:
+            loss = model.training_step(batch, bi)
+        scaler.scale(loss).backward()
+        model.on_after_backward()
+        buckets.finish()
+        scaler.step(optimizer)
+        scaler.update()
+        train_graph.release_step_caches()
+
+    stepper = GraphedStep(eager_step, metrics, enabled=use_graph)
     for epoch in range(start_epoch, max_epochs):
+        host_lr = float(optimizer.param_groups[0]['lr'])        # once per epoch (the scheduler steps per epoch): no per-step read of a device value
         model.train()
         train_loader.set_epoch(epoch)
         t0 = time.time()
         for bi, batch in enumerate(train_loader):
-            buckets.zero()
-            metrics.values = {}
-            sharding.broadcast_buffers(model)
-            with ctx:
-                loss = model.training_step(batch, bi)
-            scaler.scale(loss).backward()
-            model.on_after_backward()
-            buckets.finish()
-            scaler.step(optimizer)
-            scaler.update()
-            train_graph.release_step_caches()
+            stepper.run(batch, bi)
             global_step += 1
             # the step's logged values are still device tensors: they are read one step LATER (when they are long finished), so
             # the host never waits for the GPU inside the loop and keeps queueing the next step's launches
             flush(pending)
-            pending = (metrics.values, dict(epoch=epoch, step=global_step, lr=optimizer.param_groups[0]['lr']))
+            pending = (metrics.values, dict(epoch=epoch, step=global_step, lr=host_lr))
             if 0 < max_steps <= global_step:
                 done = True
                 break

@@ -132,19 +132,26 @@ def reconstruct_steered(model, n_points=100_000, seed=42, device='cuda:0'):
 
 class FitStep:
     """BASELINE config 3 on one GPU: B shapes x 10 000 points, 2000 queries per shape, P = 50; id tables and patches are built
-    on the device inside the step (what the reference's dataset workers do on the CPU), then forward, loss, backward, AdamW."""
+    on the device inside the step (what the reference's dataset workers do on the CPU), then forward, loss, backward, AdamW --
+    the step body of ppsurf_amd.fit, replayed as a HIP graph after three eager steps like `pps.py fit` does on one GPU."""
 
-    def __init__(self, batch=10, n=10000, q=2000, p=50, precision='bf16-mixed', device='cuda:0', n_batches=2):
-        from . import modules
+    def __init__(self, batch=10, n=10000, q=2000, p=50, precision='bf16-mixed', device='cuda:0', n_batches=2, graph=True):
+        from . import modules, fit
         self.p, self.dev = p, torch.device(device)
         with contextlib.redirect_stdout(io.StringIO()):
             net = modules.PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=p, pointnet_latent_size=256)
         net.load_state_dict(synthetic.network_state_dict('ppsurf', num_pts_local=p))
         self.net = net.to(self.dev).train()
-        self.opt = torch.optim.AdamW(self.net.parameters(), lr=1e-3, eps=1e-5, weight_decay=1e-2)       # configs/poco.yaml:60-69
+        self.opt = torch.optim.AdamW(self.net.parameters(), lr=1e-3, eps=1e-5, weight_decay=1e-2, fused=graph, capturable=graph)   # configs/poco.yaml:60-69
         self.autocast = {'bf16-mixed': torch.bfloat16, '16-mixed': torch.float16}.get(precision)
         self.batches = [self._raw_batch(batch, n, q, s) for s in range(n_batches)]
         self.i = 0
+        self.loss = None
+
+        class _Log:
+            values = {}
+
+        self.stepper = fit.GraphedStep(self._body, _Log(), enabled=graph)
 
     def _raw_batch(self, b, n, q, seed):
         rng = np.random.default_rng(seed)
@@ -156,16 +163,22 @@ class FitStep:
         return {'pts_ms': torch.from_numpy(np.stack(pts)).to(self.dev), 'pts_query_ms': torch.from_numpy(np.stack(qry)).to(self.dev),
                 'imp_surf_dist_ms': torch.from_numpy(np.stack(dist)).to(self.dev)}
 
-    def __call__(self):
-        batch = dict(self.batches[self.i % len(self.batches)])
-        self.i += 1
-        b = batch['pts_ms'].shape[0]
-        batch['pts_local_ps'] = spatial.get_pts_local_ps_batch([batch['pts_ms'][i] for i in range(b)], batch['pts_query_ms'], self.p)
-        batch = spatial.get_data_poco(batch)
-        self.opt.zero_grad(set_to_none=True)
+    def _body(self, batch, bi):
+        from . import train_graph
+        self.opt.zero_grad(set_to_none=False)
         with torch.autocast('cuda', dtype=self.autocast or torch.bfloat16, enabled=self.autocast is not None):
             logits = self.net.forward(batch)
             loss = torch.nn.functional.cross_entropy(logits.float(), batch['occ'], reduction='none').mean()
         loss.backward()
         self.opt.step()
-        return loss
+        train_graph.release_step_caches()
+        self.stepper.metrics.values = {'loss': loss.detach()}
+
+    def __call__(self):
+        batch = dict(self.batches[self.i % len(self.batches)])
+        self.i += 1
+        b = batch['pts_ms'].shape[0]
+        batch['pts_local_ps'] = spatial.get_pts_local_ps_batch([batch['pts_ms'][i] for i in range(b)], batch['pts_query_ms'], self.p)
+        batch = {k: v for k, v in spatial.get_data_poco(batch).items() if not k.startswith('_')}
+        self.stepper.run(batch, self.i)
+        return self.stepper.metrics.values['loss']
