@@ -92,6 +92,9 @@ class GraphedStep:
             logged = dict(self.metrics.values)
         except Exception as exc:                               # anything that cannot be captured: stay eager for the rest of the run
             self.failed = True
+            if os.environ.get('PPS_FIT_GRAPH_DEBUG'):
+                import traceback
+                traceback.print_exc()
             print('fit: HIP-graph capture of the step failed ({}: {}); continuing eagerly'.format(type(exc).__name__, str(exc).split('\n')[0]))
             torch.cuda.synchronize()
             return None

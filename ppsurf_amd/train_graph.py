@@ -134,7 +134,7 @@ def pack_geo(layer):
     """The layer's small parameters as ONE differentiable vector in the layout of the HIP kernels (pps_fka_common.h):
     [norm_radius, alpha, beta, activation (1 relu / 2 silu), fc1 [16,3], fc2 [16,32], fc3 [16,32], bn1 w, bn1 b, bn2 w, bn2 b]."""
     act = 2.0 if isinstance(layer.activation, torch.nn.SiLU) else 1.0
-    head = torch.tensor([act], dtype=layer.alpha.dtype, device=layer.alpha.device)
+    head = torch.full((1,), act, dtype=layer.alpha.dtype, device=layer.alpha.device)        # a fill kernel, not a host-to-device copy: recordable into a HIP graph
     parts = [layer.norm_radius.detach().reshape(1), layer.alpha.reshape(1), layer.beta.reshape(1), head, layer.fc1.weight.reshape(-1),
              layer.fc2.weight.reshape(-1), layer.fc3.weight.reshape(-1), layer.bn1.weight, layer.bn1.bias, layer.bn2.weight, layer.bn2.bias]
     return torch.cat([p.to(layer.alpha.dtype) for p in parts])
