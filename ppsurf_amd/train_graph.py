@@ -150,7 +150,8 @@ def fkaconv_layer(layer, x, pts, sup, ids):
     momentum = layer.norm_radius_momentum if layer.training else 0.0
     g, radius = train_ops.fka_geometry(pack_geo(layer), pts.reshape(b * n, 3), sup.reshape(b * m, 3), flat, b, m, momentum)
     if layer.training:
-        layer.norm_radius.data = radius.reshape(layer.norm_radius.shape).to(layer.norm_radius.dtype)
+        with torch.no_grad():                               # IN PLACE: a replayed HIP graph reads and writes the buffer's own storage
+            layer.norm_radius.copy_(radius.detach().reshape(layer.norm_radius.shape))
     feat = train_ops.neighbour_contract(x.reshape(b * n, cin), flat, g)                  # [B*M, Cin*16]
     return rows_linear(feat, _w2d(layer.cv)).view(b, m, -1)                              # Conv2d (1,16): (c,t) -> c*16+t
 

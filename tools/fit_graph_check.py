@@ -1,0 +1,21 @@
+import sys, torch
+sys.path.insert(0, '.')
+from ppsurf_amd import workloads
+import random
+res = {}
+for graph in (False, True):
+    random.seed(0); torch.manual_seed(0)
+    fit = workloads.FitStep(batch=4, n=2000, q=300, precision='32', graph=True, n_batches=2)
+    fit.stepper.enabled = graph                            # same fused / capturable AdamW in both runs
+    for m in fit.net.modules():
+        if isinstance(m, torch.nn.Dropout): m.p = 0.0
+    losses = []
+    for i in range(8):
+        random.seed(100 + i); torch.manual_seed(100 + i)          # the support sampling draws from both
+        losses.append(float(fit()))
+    res[graph] = (losses, {k: v.clone() for k, v in fit.net.state_dict().items()})
+    print('graph' if graph else 'eager', ['%.6f' % l for l in losses], len(fit.stepper.graphs))
+a, b = res[False], res[True]
+print('max loss diff', max(abs(x - y) for x, y in zip(a[0], b[0])))
+d = sorted(((float((a[1][k].float() - b[1][k].float()).abs().max()), k) for k in a[1]), reverse=True)
+print('largest state-dict differences', d[:5])
