@@ -36,7 +36,9 @@ def _w2d(layer):
 
 
 SPLITK_MIN_ROWS = 32768
-SPLITK_SLABS = 128           # row slabs of the split-K weight gradient (64 / 128 / 256 measured within 3 % of each other)
+SPLITK_SLABS = 64            # row slabs of the split-K weight gradient (64 / 128 / 256 measured within 3 % of each other).  NOT more than 64: with 128
+                             # or 256 batches the library's strided-batched bf16 GEMM faults when the step is replayed as a HIP graph (memory
+                             # aperture violation on replay, tools/fit_graph_matrix.py; 32 and 64 replay correctly)
 
 
 class _RowsLinear(torch.autograd.Function):

@@ -1,18 +1,31 @@
-"""Debug aid: which batch geometries survive capture + replay of the fit step (each in its own process)."""
+"""Debug aid: which variants of the fit step survive capture + replay at full size, bf16-mixed (each in its own process)."""
 import subprocess, sys, os
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = '''
-import sys, torch
+import sys, torch, os
 sys.path.insert(0, %r)
-from ppsurf_amd import workloads
-b, n, q, prec = %d, %d, %d, %r
-fit = workloads.FitStep(batch=b, n=n, q=q, precision=prec, graph=True)
+from ppsurf_amd import workloads, train_graph, train_ops
+knob = %r
+if "nosplitk" in knob: train_graph.SPLITK_MIN_ROWS = 10**12
+if "s64" in knob: train_graph.SPLITK_SLABS = 10**9
+if "s256" in knob: train_graph.SPLITK_SLABS = 256
+if "s32" in knob: train_graph.SPLITK_SLABS = 32
+if "nobn" in knob: train_ops.bn_supported = lambda r, c: False
+if "nocache" in knob:
+    _ac = torch.autocast
+    class AC(_ac):
+        def __init__(self, *a, **k):
+            k["cache_enabled"] = False
+            super().__init__(*a, **k)
+    torch.autocast = AC
+fit = workloads.FitStep(batch=10, n=10000, q=2000, precision="bf16-mixed", graph=True)
+if "noenc" in knob:
+    fit.net.encoder.requires_grad_(False)
 for i in range(8):
     l = fit(); torch.cuda.synchronize()
 print("OK", float(l), len(fit.stepper.graphs), fit.stepper.failed)
 '''
-for cfg in [(4, 2000, 300, '32'), (10, 2000, 300, 'bf16-mixed'), (4, 10000, 300, 'bf16-mixed'), (4, 2000, 2000, 'bf16-mixed'), (10, 10000, 2000, '32'),
-            (10, 10000, 2000, 'bf16-mixed')]:
-    r = subprocess.run([sys.executable, '-c', code % ((REPO,) + cfg)], capture_output=True, text=True)
-    tail = [l for l in (r.stdout + r.stderr).split('\n') if l.strip() and 'amdgpu' not in l][-2:]
-    print(cfg, 'rc', r.returncode, tail, flush=True)
+for knob in sys.argv[1:] or ['s64', 's256', 's32']:
+    r = subprocess.run([sys.executable, '-c', code % (REPO, knob)], capture_output=True, text=True)
+    tail = [l for l in (r.stdout + r.stderr).split('\n') if l.strip() and 'amdgpu' not in l and 'coredump' not in l and 'core dump' not in l][-1:]
+    print(knob, 'rc', r.returncode, tail, flush=True)
