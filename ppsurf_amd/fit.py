@@ -53,7 +53,7 @@ class GraphedStep:
 
     def __init__(self, eager, metrics, enabled=True, max_graphs=2):
         self.eager, self.metrics, self.enabled, self.max_graphs = eager, metrics, enabled, max_graphs
-        self.seen, self.graphs, self.failed = {}, {}, False
+        self.seen, self.graphs, self.failed, self._done = {}, {}, False, None
 
     @staticmethod
     def signature(batch):
@@ -73,9 +73,19 @@ class GraphedStep:
                         self.graphs[sig] = entry
             if entry is not None:
                 static, graph, logged = entry
+                # The static inputs may only be overwritten once the previous replay has finished READING them.  Stream order should
+                # guarantee that, but with the host several steps ahead the copies were observed to race the tail of the previous
+                # replay (id tables changing under the CSR sort -> out-of-bounds scatter inside rocprim's onesweep kernel,
+                # tools/fit_graph_matrix2.py); waiting on an event recorded behind the replay costs nothing -- the id-table kernels
+                # of this step are already queued behind the previous replay when the host gets here.
+                if self._done is not None:
+                    self._done.synchronize()
                 for k, v in static.items():
                     v.copy_(batch[k], non_blocking=True)
                 graph.replay()
+                if self._done is None:
+                    self._done = torch.cuda.Event()
+                self._done.record()
                 # the logged tensors are outputs of the graph and are overwritten by the next replay: hand out copies
                 self.metrics.values = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in logged.items()}
                 return

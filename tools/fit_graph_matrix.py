@@ -21,11 +21,13 @@ if "nocache" in knob:
 fit = workloads.FitStep(batch=10, n=10000, q=2000, precision="bf16-mixed", graph=True)
 if "noenc" in knob:
     fit.net.encoder.requires_grad_(False)
-for i in range(8):
-    l = fit(); torch.cuda.synchronize()
+for i in range(int(os.environ.get('NSTEPS', 8))):
+    l = fit()
+    if 'sync' in knob: torch.cuda.synchronize()
+torch.cuda.synchronize()
 print("OK", float(l), len(fit.stepper.graphs), fit.stepper.failed)
 '''
-for knob in sys.argv[1:] or ['s64', 's256', 's32']:
+for knob in sys.argv[1:] or ['sync', 'nosync']:
     r = subprocess.run([sys.executable, '-c', code % (REPO, knob)], capture_output=True, text=True)
     tail = [l for l in (r.stdout + r.stderr).split('\n') if l.strip() and 'amdgpu' not in l and 'coredump' not in l and 'core dump' not in l][-1:]
     print(knob, 'rc', r.returncode, tail, flush=True)
