@@ -7,10 +7,13 @@
     all-reduce over RCCL overlapped with the backward pass (sharding.GradBuckets) -> optimizer step;
   * BatchNorm / norm_radius buffers follow DDP semantics (`broadcast_buffers=True`): rank 0's values are broadcast, coalesced
     into one message, at the start of every step; between two steps they are rank-local;
-  * single GPU: after three eager steps the WHOLE optimisation step (forward, loss, backward, gradient-buffer handling, fused AdamW,
-    loss scaling) is captured into one HIP graph per batch signature and replayed (`GraphedStep`; ~1500 launches per step, many of
-    them on 39 .. 625-point encoder levels, are launch-bound otherwise); the batch is copied into static buffers, the id tables stay
-    outside the graph.  `PPS_FIT_GRAPH=0` disables it; multi-GPU runs stay eager (the bucketed all-reduce is driven by autograd hooks);
+  * Adam / AdamW run fused (one launch per dtype group; same update rule);
+  * opt-in, single GPU (`PPS_FIT_GRAPH=1`): after three eager steps the WHOLE optimisation step (forward, loss, backward,
+    gradient-buffer handling, fused capturable AdamW, loss scaling) is captured into one HIP graph per batch signature and replayed
+    (`GraphedStep`); the batch is copied into static buffers, the id tables stay outside the graph.  Replay is bit-identical to the
+    eager step (tools/fit_graph_check.py), but at the full config-3 batch size replays fault intermittently inside rocprim's onesweep
+    radix sort (the CSR sort of the id tables; memory aperture violation, timing dependent, tools/fit_graph_matrix2.py) -- hence
+    off by default until the sort is moved out of the graph;
   * validation every `check_val_every_n_epoch` epochs in eval() mode -- that is the fused HIP inference path;
   * ModelCheckpoint(save_last) -> models/<name>/version_0/checkpoints/last.ckpt with Lightning's key layout
     ({'state_dict': {'network.<...>': tensor}, 'epoch', 'global_step', 'optimizer_states', 'lr_schedulers'}), so checkpoints
@@ -149,12 +152,14 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
     params = [p for p in model.parameters() if p.requires_grad]
     if not cfg.get('optimizer'):
         raise ValueError('fit needs an `optimizer:` section (class_path / init_args), as in configs/poco.yaml:60-69')
-    use_graph = world == 1 and torch.device(device).type == 'cuda' and os.environ.get('PPS_FIT_GRAPH', '1') != '0'
+    on_gpu = torch.device(device).type == 'cuda'
+    use_graph = world == 1 and on_gpu and os.environ.get('PPS_FIT_GRAPH', '0') == '1'
     ospec = cfg['optimizer']
-    if use_graph and ospec.get('class_path', '').rsplit('.', 1)[-1] in ('AdamW', 'Adam'):
-        # the fused implementation takes the loss scale / found-inf tensors on the device (no host sync in GradScaler.step) and,
-        # with capturable=True, keeps its step counter on the device: the same update rule, recordable into a graph
-        ospec = dict(ospec, init_args=dict(ospec.get('init_args', {}), fused=True, capturable=True))
+    if on_gpu and ospec.get('class_path', '').rsplit('.', 1)[-1] in ('AdamW', 'Adam') and 'fused' not in ospec.get('init_args', {}):
+        # the fused implementation (one launch per dtype group instead of ~10 small foreach launches over 298 parameter tensors: 57.6 ->
+        # 46.6 ms per step) applies the same update rule, takes the loss scale / found-inf tensors on the device (no host sync in
+        # GradScaler.step) and, with capturable=True, keeps its step counter on the device so that the step can be recorded into a graph
+        ospec = dict(ospec, init_args=dict(ospec.get('init_args', {}), fused=True, capturable=use_graph))
     optimizer = _instantiate(ospec, params)
 
     scheduler = _instantiate(cfg['lr_scheduler'], optimizer) if cfg.get('lr_scheduler') else None

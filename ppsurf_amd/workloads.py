@@ -133,16 +133,16 @@ def reconstruct_steered(model, n_points=100_000, seed=42, device='cuda:0'):
 class FitStep:
     """BASELINE config 3 on one GPU: B shapes x 10 000 points, 2000 queries per shape, P = 50; id tables and patches are built
     on the device inside the step (what the reference's dataset workers do on the CPU), then forward, loss, backward, AdamW --
-    the step body of ppsurf_amd.fit, replayed as a HIP graph after three eager steps like `pps.py fit` does on one GPU."""
+    the step body of ppsurf_amd.fit (fused AdamW; graph=True additionally replays it as a HIP graph like PPS_FIT_GRAPH=1)."""
 
-    def __init__(self, batch=10, n=10000, q=2000, p=50, precision='bf16-mixed', device='cuda:0', n_batches=2, graph=True):
+    def __init__(self, batch=10, n=10000, q=2000, p=50, precision='bf16-mixed', device='cuda:0', n_batches=2, graph=False):
         from . import modules, fit
         self.p, self.dev = p, torch.device(device)
         with contextlib.redirect_stdout(io.StringIO()):
             net = modules.PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=p, pointnet_latent_size=256)
         net.load_state_dict(synthetic.network_state_dict('ppsurf', num_pts_local=p))
         self.net = net.to(self.dev).train()
-        self.opt = torch.optim.AdamW(self.net.parameters(), lr=1e-3, eps=1e-5, weight_decay=1e-2, fused=graph, capturable=graph)   # configs/poco.yaml:60-69
+        self.opt = torch.optim.AdamW(self.net.parameters(), lr=1e-3, eps=1e-5, weight_decay=1e-2, fused=True, capturable=graph)   # configs/poco.yaml:60-69, fused like ppsurf_amd.fit
         self.autocast = {'bf16-mixed': torch.bfloat16, '16-mixed': torch.float16}.get(precision)
         self.batches = [self._raw_batch(batch, n, q, s) for s in range(n_batches)]
         self.i = 0
