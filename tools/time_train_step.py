@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
 from ppsurf_amd import modules, spatial, synthetic  # noqa: E402
-from golden_util import filled_sd  # noqa: E402
+from ppsurf_amd.synthetic import network_state_dict  # noqa: E402
 
 
 def make_batch(b, n, q, p, dev, seed=0):
@@ -45,13 +45,14 @@ def main():
     dev = torch.device('cuda')
     if a.poco:
         net = modules.PocoNetwork(in_channels=3, latent_size=32, out_channels=2, k=64)
+        from golden_util import filled_sd
         sd = filled_sd('POCO.', 'poco')
         net.load_state_dict({k[5:]: v for k, v in sd.items()})
     else:
         net = modules.PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=50, pointnet_latent_size=256)
-        net.load_state_dict(filled_sd('', 'ppsurf'))
+        net.load_state_dict(network_state_dict('ppsurf'))
     net = net.to(dev).train()
-    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, eps=1e-5, weight_decay=1e-2)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, eps=1e-5, weight_decay=1e-2, fused=True)       # like ppsurf_amd.fit
 
     def step(i, times=None):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
