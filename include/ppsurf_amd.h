@@ -52,6 +52,18 @@ int pps_knn_blocked_f32(const float* pts_blocked, const int32_t* orig_idx, const
 int pps_knn_multi_f32(int ntasks, const float* const* pts, const int64_t* n, const float* const* query, const int64_t* m,
                       const int* k, int64_t* const* out_idx, void* stream);
 
+/* The large neighbourhood tables (k <= 64) of a BATCH of equally sized clouds in one launch of the block-culling search: kind t is one
+ * table for all `nclouds` clouds -- points of a level arranged per cloud like for pps_knn_blocked_f32 (pts_blocked[t] [nclouds, nb*64, 3],
+ * orig_idx[t] [nclouds, nb*64] (-1 = padding), bbox[t] [nclouds, nb, 6], win_bbox[t] [nclouds, n_win, 6] = boxes of the full blocks),
+ * queries query[t] with query_stride[t] floats between clouds (m[t] queries each); q_orig[t] (int32 [nclouds, query_stride/3] or NULL) maps
+ * the query position to its output row (queries given in Morton order: q_orig = that level's orig_idx).  out_idx[t] int64 [nclouds, m, k]
+ * holds per-cloud ORIGINAL point indices, bit-identical to pps_knn_f32.  Arrays of the argument list are [host] arrays of length nkinds <= 8.
+ * replaces: the kd-tree builds + queries of source/poco_data_loader.py:155-168 for the tables over the two finest levels. */
+int pps_knn_blocked_batch_f32(int nkinds, int64_t nclouds, const float* const* pts_blocked, const int32_t* const* orig_idx,
+                              const float* const* bbox, const int64_t* nb, const float* const* win_bbox, const int64_t* n_win,
+                              const float* const* query, const int32_t* const* q_orig, const int64_t* query_stride, const int64_t* m,
+                              const int* k, int64_t* const* out_idx, void* stream);
+
 /* Voxel-stratified sub-sampling of one cloud to exactly `target` unique points, all rounds in one workgroup.
  * replaces: source/poco_data_loader.py:59-134 `sampling_quantized` (per batch item) with the semantics of its CPU execution
  * (restated and pinned in oracle/driver_oracle.py): per round the three axis rotations rots[r][0..2] (row-major 3x3 each, x

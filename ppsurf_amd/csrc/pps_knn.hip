@@ -262,6 +262,122 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_blocked_kernel(const float
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Batched blocked search (k <= 64): the large neighbourhood tables of a whole batch of clouds in ONE launch.  A "kind" is one table
+// of the encoder (e.g. ids01: points of level 0, queries of level 1) for all B clouds of the batch; every cloud's level has been
+// arranged by the caller like for knn_blocked_kernel (Morton order, blocks of 64, boxes), all clouds of a kind with the same sizes and
+// a constant stride between them.  Queries may be given in Morton order too (q_orig maps the position to the output row): the 8
+// queries of a wave are then neighbours in space and share the blocks they have to visit.
+// replaces: the 13 kd-tree builds + queries per cloud of source/poco_data_loader.py:155-168 for the tables whose point set is large.
+// ---------------------------------------------------------------------------------------------------------------
+#define KBB_MAX 8
+struct KbbKind {
+    const float* pts; const int* orig; const float* bbox; const float* win; const float* query; const int* q_orig; int64_t* out;
+    int64_t pts_stride, orig_stride, bbox_stride, win_stride, query_stride, qorig_stride, out_stride;      // elements between clouds
+    int nb, n_win, m, k, groups, group_end;
+};
+struct KbbArgs { KbbKind kind[KBB_MAX]; int nkinds, nclouds; };
+
+__global__ __launch_bounds__(KNN_WAVES * 64) void knn_blocked_batch_kernel(const KbbArgs a) {
+    __shared__ u64 cand_all[KNN_WAVES][KNN_QW][KNN_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int total = a.kind[a.nkinds - 1].group_end;
+    for (int grp = blockIdx.x * KNN_WAVES + wave; grp < total; grp += gridDim.x * KNN_WAVES) {
+        int t = 0;
+        while (grp >= a.kind[t].group_end) ++t;
+        const KbbKind& kd = a.kind[t];
+        const int local = grp - (t == 0 ? 0 : a.kind[t - 1].group_end);
+        const int cloud = local / kd.groups, q0 = (local % kd.groups) * KNN_QW;
+        const float* __restrict__ pts = kd.pts + cloud * kd.pts_stride;
+        const int* __restrict__ orig = kd.orig + cloud * kd.orig_stride;
+        const float* __restrict__ bbox = kd.bbox + cloud * kd.bbox_stride;
+        const float* __restrict__ win_bbox = kd.win + cloud * kd.win_stride;
+        const float* __restrict__ query = kd.query + cloud * kd.query_stride;
+        const int nb = kd.nb, n_win = kd.n_win, m = kd.m, k = kd.k;
+        float qx[KNN_QW], qy[KNN_QW], qz[KNN_QW], tau[KNN_QW];
+        u64 list[KNN_QW];
+        int cnt[KNN_QW];
+#pragma unroll
+        for (int j = 0; j < KNN_QW; ++j) {
+            const int qq = (q0 + j < m) ? q0 + j : m - 1;
+            qx[j] = __shfl(query[qq * 3], 0); qy[j] = __shfl(query[qq * 3 + 1], 0); qz[j] = __shfl(query[qq * 3 + 2], 0);
+            tau[j] = INFINITY;
+            list[j] = ~0ull;
+            cnt[j] = 0;
+        }
+        for (int b0 = 0; b0 < n_win; b0 += 64) {                  // initial tau: farthest corner of any FULL block (>= k points inside)
+            const int b = b0 + lane;
+            const bool bv = b < n_win;
+            const float* bb = win_bbox + (int64_t)(bv ? b : 0) * 6;
+            const float lx = bb[0], ly = bb[1], lz = bb[2], hx = bb[3], hy = bb[4], hz = bb[5];
+#pragma unroll
+            for (int j = 0; j < KNN_QW; ++j) {
+                const float fx = fmaxf(fabsf(__fsub_rn(qx[j], lx)), fabsf(__fsub_rn(qx[j], hx)));
+                const float fy = fmaxf(fabsf(__fsub_rn(qy[j], ly)), fabsf(__fsub_rn(qy[j], hy)));
+                const float fz = fmaxf(fabsf(__fsub_rn(qz[j], lz)), fabsf(__fsub_rn(qz[j], hz)));
+                float far2 = bv ? __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz)) : INFINITY;
+#pragma unroll
+                for (int s = 32; s > 0; s >>= 1) far2 = fminf(far2, __shfl_xor(far2, s));
+                tau[j] = fminf(tau[j], far2);
+            }
+        }
+        for (int b0 = 0; b0 < nb; b0 += 64) {
+            const int b = b0 + lane;
+            const bool bv = b < nb;
+            const float* bb = bbox + (int64_t)(bv ? b : 0) * 6;
+            const float lx = bb[0], ly = bb[1], lz = bb[2], hx = bb[3], hy = bb[4], hz = bb[5];
+            u64 need[KNN_QW];
+            u64 any = 0ull;
+#pragma unroll
+            for (int j = 0; j < KNN_QW; ++j) {
+                const float gx = fmaxf(fmaxf(__fsub_rn(lx, qx[j]), __fsub_rn(qx[j], hx)), 0.f);
+                const float gy = fmaxf(fmaxf(__fsub_rn(ly, qy[j]), __fsub_rn(qy[j], hy)), 0.f);
+                const float gz = fmaxf(fmaxf(__fsub_rn(lz, qz[j]), __fsub_rn(qz[j], hz)), 0.f);
+                const float near2 = __fadd_rn(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)), __fmul_rn(gz, gz));
+                need[j] = __ballot(bv && near2 <= tau[j]);
+                any |= need[j];
+            }
+            while (any != 0ull) {
+                const int bit = __builtin_ctzll(any);
+                any &= any - 1ull;
+                const int p = (b0 + bit) * 64 + lane;
+                const float px = pts[3 * p], py = pts[3 * p + 1], pz = pts[3 * p + 2];
+                const int oi = orig[p];
+                const bool pv = oi >= 0;
+#pragma unroll
+                for (int j = 0; j < KNN_QW; ++j) {
+                    if (((need[j] >> bit) & 1ull) == 0ull) continue;
+                    const float dx = __fsub_rn(qx[j], px), dy = __fsub_rn(qy[j], py), dz = __fsub_rn(qz[j], pz);
+                    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                    const bool pass = pv && (d2 <= tau[j]);
+                    const u64 mask = __ballot(pass);
+                    if (mask != 0ull) {
+                        u64* cand = cand_all[wave][j];
+                        const int pos = cnt[j] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                        if (pass) cand[pos] = ((u64)__float_as_uint(d2) << 32) | (unsigned)oi;
+                        cnt[j] += __popcll(mask);
+                        if (cnt[j] > KNN_CAP - 64) {
+                            list[j] = knn_flush(list[j], cand, cnt[j], lane);
+                            cnt[j] = 0;
+                            tau[j] = fminf(tau[j], __uint_as_float((unsigned)(shfl_u64(list[j], k - 1) >> 32)));
+                        }
+                    }
+                }
+            }
+        }
+        const int* __restrict__ q_orig = kd.q_orig ? kd.q_orig + cloud * kd.qorig_stride : nullptr;
+        int64_t* __restrict__ out = kd.out + cloud * kd.out_stride;
+#pragma unroll
+        for (int j = 0; j < KNN_QW; ++j) {
+            list[j] = knn_flush(list[j], cand_all[wave][j], cnt[j], lane);
+            if (q0 + j < m && lane < k) {
+                const int row = q_orig ? q_orig[q0 + j] : q0 + j;
+                out[(int64_t)row * k + lane] = (int64_t)(unsigned)(list[j] & 0xffffffffull);
+            }
+        }
+    }
+}
+
 // one wave per query: lane j < P handles neighbour j
 __global__ __launch_bounds__(256) void patch_normalize_kernel(const float* __restrict__ raw, const float* __restrict__ query,
                                                               const int64_t* __restrict__ idx, int64_t idx_stride, int64_t Q, int P,
@@ -327,6 +443,41 @@ int pps_knn_blocked_f32(const float* pts_blocked, const int32_t* orig_idx, const
     else if (r == 3) PPS_KNN_LAUNCH(3);
     else PPS_KNN_LAUNCH(4);
 #undef PPS_KNN_LAUNCH
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+int pps_knn_blocked_batch_f32(int nkinds, int64_t nclouds, const float* const* pts_blocked, const int32_t* const* orig_idx,
+                              const float* const* bbox, const int64_t* nb, const float* const* win_bbox, const int64_t* n_win,
+                              const float* const* query, const int32_t* const* q_orig, const int64_t* query_stride, const int64_t* m,
+                              const int* k, int64_t* const* out_idx, void* stream) {
+    if (nkinds < 1 || nkinds > KBB_MAX || nclouds < 1 || !pts_blocked || !orig_idx || !bbox || !nb || !win_bbox || !n_win || !query || !q_orig ||
+        !query_stride || !m || !k || !out_idx)
+        return PPS_ERR_ARG;
+    KbbArgs a;
+    int64_t total = 0;
+    for (int t = 0; t < nkinds; ++t) {
+        if (!pts_blocked[t] || !orig_idx[t] || !bbox[t] || !query[t] || !out_idx[t] || nb[t] < 1 || nb[t] > 0x1ffffff || m[t] < 1 || k[t] < 1 ||
+            k[t] > 64 || n_win[t] < 0 || (n_win[t] > 0 && !win_bbox[t]) || query_stride[t] < m[t] * 3)
+            return PPS_ERR_ARG;
+        KbbKind& kd = a.kind[t];
+        kd.pts = pts_blocked[t]; kd.orig = orig_idx[t]; kd.bbox = bbox[t]; kd.win = win_bbox[t] ? win_bbox[t] : bbox[t];
+        kd.query = query[t]; kd.q_orig = q_orig[t]; kd.out = out_idx[t];
+        kd.pts_stride = nb[t] * 64 * 3; kd.orig_stride = nb[t] * 64; kd.bbox_stride = nb[t] * 6; kd.win_stride = n_win[t] * 6;
+        kd.query_stride = query_stride[t]; kd.qorig_stride = query_stride[t] / 3; kd.out_stride = m[t] * k[t];
+        kd.nb = (int)nb[t]; kd.n_win = (int)n_win[t]; kd.m = (int)m[t]; kd.k = k[t];
+        kd.groups = (int)((m[t] + KNN_QW - 1) / KNN_QW);
+        total += nclouds * kd.groups;
+        if (total > 0x7fffffff) return PPS_ERR_ARG;
+        kd.group_end = (int)total;
+    }
+    for (int t = nkinds; t < KBB_MAX; ++t) { a.kind[t] = a.kind[nkinds - 1]; a.kind[t].group_end = (int)total; }
+    a.nkinds = nkinds;
+    a.nclouds = (int)nclouds;
+    int64_t blocks = (total + KNN_WAVES - 1) / KNN_WAVES;
+    int cus = pps_device_cu_count();
+    if (cus <= 0) cus = 256;
+    if (blocks > (int64_t)cus * 8) blocks = (int64_t)cus * 8;
+    hipLaunchKernelGGL(knn_blocked_batch_kernel, dim3((unsigned)blocks), dim3(KNN_WAVES * 64), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 

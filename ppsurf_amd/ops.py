@@ -44,6 +44,65 @@ def knn_batch_point_major(pts_list, query_list, k_list):
     return outs
 
 
+def _morton_spread(v):                                   # 10 bits -> every third bit
+    v = (v | (v << 16)) & 0x030000FF
+    v = (v | (v << 8)) & 0x0300F00F
+    v = (v | (v << 4)) & 0x030C30C3
+    return (v | (v << 2)) & 0x09249249
+
+
+class BlockedLevel:
+    """One level of a BATCH of equally sized clouds [B,n,3] arranged for pps_knn_blocked_batch_f32 with batched torch ops (one sort for
+    all clouds): per cloud Morton order, blocks of 64 points (the tail repeats the last point, orig = -1), boxes, boxes of the full blocks."""
+
+    def __init__(self, pts_b: torch.Tensor):
+        b, n = pts_b.shape[0], pts_b.shape[1]
+        lo = pts_b.amin(dim=1, keepdim=True)
+        span = (pts_b.amax(dim=1, keepdim=True) - lo).amax(dim=2, keepdim=True).clamp_min(1e-20)
+        cell = ((pts_b - lo) / span * 1023.0).to(torch.int64).clamp_(0, 1023)
+        code = _morton_spread(cell[..., 0]) | (_morton_spread(cell[..., 1]) << 1) | (_morton_spread(cell[..., 2]) << 2)
+        order = torch.sort(code, dim=1, stable=True)[1]
+        self.b, self.n, self.nb = b, n, (n + 63) // 64
+        pad = self.nb * 64 - n
+        sp = torch.gather(pts_b, 1, order.unsqueeze(-1).expand(b, n, 3))
+        self.pts = torch.cat([sp, sp[:, -1:].expand(b, pad, 3)], dim=1).contiguous()
+        self.orig = torch.cat([order.to(torch.int32), torch.full((b, pad), -1, dtype=torch.int32, device=pts_b.device)], dim=1).contiguous()
+        blk = self.pts.view(b, self.nb, 64, 3)
+        self.bbox = torch.cat([blk.amin(dim=2), blk.amax(dim=2)], dim=2).contiguous()
+        self.n_win = n // 64
+        self.win = self.bbox[:, :self.n_win].contiguous() if self.n_win > 0 else None
+
+
+def knn_blocked_batch(kinds):
+    """kinds: list of (points BlockedLevel, queries BlockedLevel | tensor [B,m,3], k) -> list of int64 [B,m,k] (per-cloud original indices),
+    one launch of pps_knn_blocked_batch_f32 per 8 kinds."""
+    import ctypes
+    outs = []
+    for s in range(0, len(kinds), 8):
+        part = kinds[s:s + 8]
+        nt = len(part)
+        P, I64, I = ctypes.c_void_p * nt, ctypes.c_int64 * nt, ctypes.c_int * nt
+        pts, orig, bbox, win, qry, qorig, out = P(), P(), P(), P(), P(), P(), P()
+        nb, nwin, qstride, ms, ks = I64(), I64(), I64(), I64(), I()
+        keep = []
+        for t, (pl, ql, k) in enumerate(part):
+            if isinstance(ql, BlockedLevel):
+                q_t, qo_t, m, stride = ql.pts, ql.orig, ql.n, ql.nb * 64 * 3
+            else:
+                q_t = ql.contiguous().float()
+                qo_t, m, stride = None, q_t.shape[1], q_t.shape[1] * 3
+            k = min(int(k), pl.n)
+            o = torch.empty((pl.b, m, k), dtype=torch.int64, device=pl.pts.device)
+            keep.append(q_t)
+            outs.append(o)
+            pts[t], orig[t], bbox[t], win[t] = pl.pts.data_ptr(), pl.orig.data_ptr(), pl.bbox.data_ptr(), pl.win.data_ptr() if pl.win is not None else None
+            qry[t], qorig[t], out[t] = q_t.data_ptr(), qo_t.data_ptr() if qo_t is not None else None, o.data_ptr()
+            nb[t], nwin[t], qstride[t], ms[t], ks[t] = pl.nb, pl.n_win, stride, m, k
+        _lib.check(_lib.lib().pps_knn_blocked_batch_f32(nt, part[0][0].b, pts, orig, bbox, nb, win, nwin, qry, qorig, qstride, ms, ks, out,
+                                                        _stream(part[0][0].pts)), 'pps_knn_blocked_batch_f32')
+    return outs
+
+
 def patch_normalize(raw: torch.Tensor, query: torch.Tensor, idx: torch.Tensor, p: int, out: torch.Tensor = None) -> torch.Tensor:
     """raw [n,3], query [q,3], idx int64 [q,>=p] -> patches [q,p,3] in patch space (ppsurf_data_loader.py:91-123)."""
     raw = raw.contiguous().float()

@@ -166,43 +166,39 @@ def sampling_quantized(pts_batch, ratio=None, n_support=None, support_points=Non
     return support, ids
 
 
-def _tables_point_major(levels_pm, segmentation=True):
-    """The 9 (+4) kNN tables of one cloud from its 5 point-major levels in ONE launch (pps_knn_multi_f32)."""
-    tasks = []
+BLOCKED_MIN_POINTS = 1024        # levels with at least this many points per cloud are searched with block culling
+
+
+def _tables_batch(levels, segmentation=True):
+    """The 9 (+4) kNN tables of a batch of equally sized clouds from its 5 levels ([B,n_a,3] each) -> {name: int64 [B,m,k]}.
+    Tables over the large levels (>= BLOCKED_MIN_POINTS points: levels 0 and 1 of a 10k-point pass) go through the block-culling
+    search in ONE launch (pps_knn_blocked_batch_f32; their query sets are visited in Morton order), the small ones through the
+    exhaustive pps_knn_multi_f32.  Same results either way (bit-identical indices, tests/test_gpu_sampling.py)."""
+    nb = levels[0].shape[0]
+    todo = []
     for a in range(5):
-        tasks.append(('ids{}{}'.format(a, a), levels_pm[a], levels_pm[a], 16))
+        todo.append(('ids{}{}'.format(a, a), a, a, 16))
         if a < 4:
-            tasks.append(('ids{}{}'.format(a, a + 1), levels_pm[a], levels_pm[a + 1], 16))
+            todo.append(('ids{}{}'.format(a, a + 1), a, a + 1, 16))
             if segmentation:
-                tasks.append(('ids{}{}'.format(a + 1, a), levels_pm[a + 1], levels_pm[a], 1))
-    dev = levels_pm[0].device
-    outs, nt = {}, len(tasks)
-    P, I64, I = ctypes.c_void_p * nt, ctypes.c_int64 * nt, ctypes.c_int * nt
-    pts, qry, out, ns, ms, ks = P(), P(), P(), I64(), I64(), I()
-    for t, (name, p, q, k) in enumerate(tasks):
-        k = min(k, p.shape[0])
-        o = torch.empty((q.shape[0], k), dtype=torch.int64, device=dev)
-        outs[name] = o
-        pts[t], qry[t], out[t], ns[t], ms[t], ks[t] = p.data_ptr(), q.data_ptr(), o.data_ptr(), p.shape[0], q.shape[0], k
-    _lib.check(_lib.lib().pps_knn_multi_f32(nt, pts, ns, qry, ms, ks, out, torch.cuda.current_stream(dev).cuda_stream), 'pps_knn_multi_f32')
-    return outs
-
-
-def _tables_point_major_batch(per_lv, segmentation=True):
-    """_tables_point_major for several clouds: their searches share launches (up to 64 per pps_knn_multi_f32 call)."""
-    names, ps, qs, ks = [], [], [], []
-    for lv in per_lv:
-        for a in range(5):
-            todo = [('ids{}{}'.format(a, a), lv[a], lv[a], 16)]
-            if a < 4:
-                todo.append(('ids{}{}'.format(a, a + 1), lv[a], lv[a + 1], 16))
-                if segmentation:
-                    todo.append(('ids{}{}'.format(a + 1, a), lv[a + 1], lv[a], 1))
-            for name, p, q, k in todo:
-                names.append(name); ps.append(p); qs.append(q); ks.append(min(k, p.shape[0]))
-    outs = ops.knn_batch_point_major(ps, qs, ks)
-    per = len(names) // len(per_lv)
-    return [dict(zip(names[i * per:(i + 1) * per], outs[i * per:(i + 1) * per])) for i in range(len(per_lv))]
+                todo.append(('ids{}{}'.format(a + 1, a), a + 1, a, 1))
+    blocked = {a: ops.BlockedLevel(levels[a]) for a in range(5) if levels[a].shape[1] >= BLOCKED_MIN_POINTS}
+    big = [(name, pa, qa, k) for name, pa, qa, k in todo if pa in blocked]
+    small = [(name, pa, qa, k) for name, pa, qa, k in todo if pa not in blocked]
+    ret = {}
+    if big:
+        outs = ops.knn_blocked_batch([(blocked[pa], blocked.get(qa, levels[qa]), k) for _, pa, qa, k in big])
+        for (name, _, _, _), o in zip(big, outs):
+            ret[name] = o
+    if small:
+        ps, qs, ks = [], [], []
+        for _, pa, qa, k in small:
+            for b in range(nb):
+                ps.append(levels[pa][b]); qs.append(levels[qa][b]); ks.append(min(k, levels[pa].shape[1]))
+        outs = ops.knn_batch_point_major(ps, qs, ks)
+        for i, (name, _, _, _) in enumerate(small):
+            ret[name] = torch.stack(outs[i * nb:(i + 1) * nb], dim=0)
+    return ret
 
 
 def get_fkaconv_ids(data, segmentation: bool = True):
@@ -225,17 +221,13 @@ def get_fkaconv_ids(data, segmentation: bool = True):
             else:
                 ids = voxel_sample_batch_point_major(cur, target)
                 levels.append(torch.gather(cur, 1, ids.unsqueeze(-1).expand(nb, target, 3)).contiguous())
-        per_lv = [[levels[a][b] for a in range(5)] for b in range(nb)]
-        tables = _tables_point_major_batch(per_lv, segmentation)
-        per_item = list(zip(per_lv, tables))
         ret = {}
-        for name in per_item[0][1]:
-            t = torch.stack([it[1][name] for it in per_item], dim=0)
+        for name, t in _tables_batch(levels, segmentation).items():
             ret[name] = t.squeeze(0) if unbatched else t
         for a in range(1, 5):
-            t = torch.stack([it[0][a].t() for it in per_item], dim=0)
+            t = levels[a].transpose(1, 2).contiguous()
             ret['support{}'.format(a)] = t.squeeze(0) if unbatched else t
-        ret['_levels_point_major'] = [it[0] for it in per_item]      # reused by FKAConvNetwork.forward_point_major
+        ret['_levels_point_major'] = [[levels[a][b] for a in range(5)] for b in range(nb)]      # reused by FKAConvNetwork.forward_point_major
         return ret
     levels = [pts]
     for _ in range(4):

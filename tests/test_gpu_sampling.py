@@ -107,3 +107,40 @@ def test_get_fkaconv_ids_tables_are_exact_knn_of_the_levels():
     d2 = spatial.get_fkaconv_ids({'pts': pts[0, :, :300]})
     assert tuple(d2['support1'].shape) == (3, 75) and tuple(d2['ids00'].shape) == (300, 16) and tuple(d2['ids44'].shape) == (1, 1)
     assert tuple(d2['ids34'].shape) == (1, 4) and tuple(d2['ids10'].shape) == (300, 1)
+
+
+@pytest.mark.parametrize('n,b', [(10000, 3), (4100, 2), (1500, 2), (1023, 1), (130, 2)])
+def test_batched_block_culling_tables_equal_exhaustive_search(n, b):
+    """spatial._tables_batch (block-culling search for the levels with >= 1024 points, queries in Morton order, exhaustive search for
+    the small levels) against the oracle's exact kNN of the same levels: bit-identical indices for every table of every cloud,
+    including level sizes that are no multiple of 64 and levels just above / below the switch-over."""
+    rng = np.random.default_rng(n)
+    levels = [torch.from_numpy(np.stack([make_cloud(n, seed=100 * n + i) for i in range(b)])).to(DEV)]
+    for _ in range(4):
+        cur = levels[-1]
+        m = max(1, int(cur.shape[1] * 0.25))
+        sel = torch.from_numpy(np.stack([np.sort(rng.choice(cur.shape[1], m, replace=False)) for _ in range(b)])).to(DEV)
+        levels.append(torch.gather(cur, 1, sel.unsqueeze(-1).expand(b, m, 3)).contiguous())
+    tables = spatial._tables_batch(levels)
+    assert len(tables) == 13
+    for name, t in tables.items():
+        pa, qa = int(name[3]), int(name[4])
+        k = min(1 if pa == qa + 1 else 16, levels[pa].shape[1])
+        assert tuple(t.shape) == (b, levels[qa].shape[1], k), name
+        for i in range(b):
+            ref = O.knn_point_major(levels[pa][i].cpu().numpy(), levels[qa][i].cpu().numpy(), k)
+            assert np.array_equal(t[i].cpu().numpy(), ref), (name, i)
+
+
+def test_batched_block_culling_handles_ties_and_duplicates():
+    """Lattice points (many equal distances) and duplicated points: the (d2, index) order of the exhaustive search is kept."""
+    g = np.stack(np.meshgrid(*[np.arange(11)] * 3, indexing='ij'), -1).reshape(-1, 3).astype(np.float32) / 10 - 0.5       # 1331 lattice points
+    cloud = np.concatenate([g, g[:200]])                                                                                  # + duplicates
+    lv0 = torch.from_numpy(np.stack([cloud, cloud[::-1].copy()])).to(DEV)
+    levels = [lv0] + [lv0[:, :m].contiguous() for m in (380, 95, 23, 5)]
+    tables = spatial._tables_batch(levels)
+    for name in ('ids00', 'ids01', 'ids10'):
+        pa, qa = int(name[3]), int(name[4])
+        for i in range(2):
+            k = tables[name].shape[2]
+            assert np.array_equal(tables[name][i].cpu().numpy(), O.knn_point_major(levels[pa][i].cpu().numpy(), levels[qa][i].cpu().numpy(), k)), name
