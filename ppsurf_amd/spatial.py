@@ -166,12 +166,16 @@ def sampling_quantized(pts_batch, ratio=None, n_support=None, support_points=Non
     return support, ids
 
 
-BLOCKED_MIN_POINTS = 1024        # levels with at least this many points per cloud are searched with block culling
+# Levels with at least this many points per cloud are searched with block culling.  Measured on 10 x 10 000-point clouds
+# (tools/time_id_tables.py): arranging levels 0 and 1 costs 0.81 ms of small torch launches and the culling search of their five tables
+# 1.00 ms against 1.36 ms for the exhaustive search -- with k = 16 the per-query merge networks, not the distance tests, bound both
+# kernels, so culling only pays for larger clouds.  A 10k-point encoder pass therefore stays on the exhaustive kernel.
+BLOCKED_MIN_POINTS = 16384
 
 
 def _tables_batch(levels, segmentation=True):
     """The 9 (+4) kNN tables of a batch of equally sized clouds from its 5 levels ([B,n_a,3] each) -> {name: int64 [B,m,k]}.
-    Tables over the large levels (>= BLOCKED_MIN_POINTS points: levels 0 and 1 of a 10k-point pass) go through the block-culling
+    Tables over large levels (>= BLOCKED_MIN_POINTS points per cloud) go through the block-culling
     search in ONE launch (pps_knn_blocked_batch_f32; their query sets are visited in Morton order), the small ones through the
     exhaustive pps_knn_multi_f32.  Same results either way (bit-identical indices, tests/test_gpu_sampling.py)."""
     nb = levels[0].shape[0]

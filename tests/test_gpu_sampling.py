@@ -110,7 +110,7 @@ def test_get_fkaconv_ids_tables_are_exact_knn_of_the_levels():
 
 
 @pytest.mark.parametrize('n,b', [(10000, 3), (4100, 2), (1500, 2), (1023, 1), (130, 2)])
-def test_batched_block_culling_tables_equal_exhaustive_search(n, b):
+def test_batched_block_culling_tables_equal_exhaustive_search(n, b, monkeypatch):
     """spatial._tables_batch (block-culling search for the levels with >= 1024 points, queries in Morton order, exhaustive search for
     the small levels) against the oracle's exact kNN of the same levels: bit-identical indices for every table of every cloud,
     including level sizes that are no multiple of 64 and levels just above / below the switch-over."""
@@ -121,6 +121,7 @@ def test_batched_block_culling_tables_equal_exhaustive_search(n, b):
         m = max(1, int(cur.shape[1] * 0.25))
         sel = torch.from_numpy(np.stack([np.sort(rng.choice(cur.shape[1], m, replace=False)) for _ in range(b)])).to(DEV)
         levels.append(torch.gather(cur, 1, sel.unsqueeze(-1).expand(b, m, 3)).contiguous())
+    monkeypatch.setattr(spatial, 'BLOCKED_MIN_POINTS', 1024)
     tables = spatial._tables_batch(levels)
     assert len(tables) == 13
     for name, t in tables.items():
@@ -132,7 +133,8 @@ def test_batched_block_culling_tables_equal_exhaustive_search(n, b):
             assert np.array_equal(t[i].cpu().numpy(), ref), (name, i)
 
 
-def test_batched_block_culling_handles_ties_and_duplicates():
+def test_batched_block_culling_handles_ties_and_duplicates(monkeypatch):
+    monkeypatch.setattr(spatial, 'BLOCKED_MIN_POINTS', 1024)
     """Lattice points (many equal distances) and duplicated points: the (d2, index) order of the exhaustive search is kept."""
     g = np.stack(np.meshgrid(*[np.arange(11)] * 3, indexing='ij'), -1).reshape(-1, 3).astype(np.float32) / 10 - 0.5       # 1331 lattice points
     cloud = np.concatenate([g, g[:200]])                                                                                  # + duplicates
