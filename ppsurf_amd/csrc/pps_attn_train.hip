@@ -1,0 +1,174 @@
+// Attention pooling of the interpolation head in the TRAINING step, forward and backward (gfx950).
+//
+// replaces (reference, under autograd): source/poco_model.py:412-414
+//     attention_weights = softmax(query, dim = neighbours).mean(dim = heads);   x = matmul(attention_weights, value)
+// in the pooled form of DESIGN.md section 2 (identity 2: fc_value runs after the pooling): per query q with k <= 64 neighbours,
+// H = 64 heads and C <= 256 channels
+//     a[j] = 1/H * sum_h softmax_j(qy[q, j, h]),     pooled[q, c] = sum_j a[j] * h[q, j, c].
+// torch runs this as softmax (fwd + bwd), mean, cast, two batched GEMMs and their transposes over [Q*k, H] and [Q*k, C] tensors
+// (~3 ms per step at Q*k = 1.28 M); here it is ONE streaming kernel each way: a workgroup per query keeps the 64 x 64 logits in LDS,
+// reads the neighbour rows once, and writes only the pooled row (forward) or the two gradients (backward; the softmax is recomputed
+// from the logits, nothing but the inputs is saved).  HBM-bound: 40 KB (fwd) / 80 KB (bwd) per query in bf16.
+// Storage type T: float or bf16 (as uint16), arithmetic fp32.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ppsurf_amd.h"
+
+#define PPS_OK 0
+#define PPS_ERR_ARG 1
+#define PPS_ERR_LAUNCH 2
+
+namespace {
+
+constexpr int AT_NT = 256;      // threads per workgroup = 4 waves; wave w owns neighbours [16w, 16w+16), lane = head
+constexpr int AT_H = 64;
+constexpr int AT_KMAX = 64;
+
+__device__ __forceinline__ float ld(const float* p, int64_t i) { return p[i]; }
+__device__ __forceinline__ float ld(const uint16_t* p, int64_t i) { return __uint_as_float((unsigned)p[i] << 16); }
+__device__ __forceinline__ void st(float* p, int64_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void st(uint16_t* p, int64_t i, float v) {            // round to nearest even, like torch's float -> bfloat16
+    unsigned u = __float_as_uint(v);
+    if ((u & 0x7f800000u) == 0x7f800000u && (u & 0x007fffffu)) { p[i] = (uint16_t)((u >> 16) | 0x40); return; }
+    u += 0x7fffu + ((u >> 16) & 1u);
+    p[i] = (uint16_t)(u >> 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+    return v;
+}
+
+// logits of query q -> LDS e[j][h] = exp(qy - max_j), inv_s[h] = 1 / sum_j e; returns nothing, all threads sync'ed on exit
+template <typename T>
+__device__ __forceinline__ void softmax_to_lds(const T* __restrict__ qy, int64_t q, int k, float (*e)[AT_H + 1], float* red, float* inv_s) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const T* src = qy + q * (int64_t)k * AT_H;
+    for (int i = threadIdx.x; i < k * AT_H; i += AT_NT) e[i >> 6][i & 63] = ld(src, i);
+    __syncthreads();
+    float m = -INFINITY;
+    for (int j = wave * 16; j < wave * 16 + 16 && j < k; ++j) m = fmaxf(m, e[j][lane]);
+    red[wave * 64 + lane] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[lane], red[64 + lane]), fmaxf(red[128 + lane], red[192 + lane]));
+    __syncthreads();
+    float s = 0.f;
+    for (int j = wave * 16; j < wave * 16 + 16 && j < k; ++j) {
+        const float v = __expf(e[j][lane] - m);
+        e[j][lane] = v;
+        s += v;
+    }
+    red[wave * 64 + lane] = s;
+    __syncthreads();
+    if (threadIdx.x < 64) inv_s[lane] = 1.f / (red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane]);
+    __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(AT_NT) void attn_pool_fwd_kernel(const T* __restrict__ qy, const T* __restrict__ h, int64_t Q, int k, int C,
+                                                              T* __restrict__ pooled) {
+    __shared__ float e[AT_KMAX][AT_H + 1];
+    __shared__ float red[4 * 64], inv_s[64], a[AT_KMAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t q = blockIdx.x; q < Q; q += gridDim.x) {
+        softmax_to_lds(qy, q, k, e, red, inv_s);
+        for (int j = wave * 16; j < wave * 16 + 16 && j < k; ++j) {                  // a[j] = mean over the heads
+            const float v = wave_sum(e[j][lane] * inv_s[lane]);
+            if (lane == 0) a[j] = v * (1.f / AT_H);
+        }
+        __syncthreads();
+        const T* hq = h + q * (int64_t)k * C;
+        for (int c = threadIdx.x; c < C; c += AT_NT) {
+            float acc = 0.f;
+            for (int j = 0; j < k; ++j) acc += a[j] * ld(hq, (int64_t)j * C + c);
+            st(pooled, q * (int64_t)C + c, acc);
+        }
+        __syncthreads();
+    }
+}
+
+// d_h[q,j,c] = a[j] dP[c];   da[j] = sum_c dP[c] h[q,j,c];   d_qy[q,j,h] = s[j,h]/H * (da[j] - sum_j' s[j',h] da[j'])
+template <typename T>
+__global__ __launch_bounds__(AT_NT) void attn_pool_bwd_kernel(const T* __restrict__ qy, const T* __restrict__ h, const T* __restrict__ dpooled,
+                                                              int64_t Q, int k, int C, T* __restrict__ dqy, T* __restrict__ dh) {
+    __shared__ float e[AT_KMAX][AT_H + 1];
+    __shared__ float red[4 * 64], inv_s[64], a[AT_KMAX], da[AT_KMAX], dp[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t q = blockIdx.x; q < Q; q += gridDim.x) {
+        softmax_to_lds(qy, q, k, e, red, inv_s);
+        for (int c = threadIdx.x; c < C; c += AT_NT) dp[c] = ld(dpooled, q * (int64_t)C + c);
+        for (int j = wave * 16; j < wave * 16 + 16 && j < k; ++j) {
+            const float s = e[j][lane] * inv_s[lane];
+            e[j][lane] = s;                                                          // e now holds the softmax probabilities s[j][h]
+            const float v = wave_sum(s);
+            if (lane == 0) a[j] = v * (1.f / AT_H);
+        }
+        __syncthreads();
+        const T* hq = h + q * (int64_t)k * C;
+        T* dhq = dh + q * (int64_t)k * C;
+        for (int j = wave * 16; j < wave * 16 + 16 && j < k; ++j) {                  // one neighbour row per wave pass
+            float part = 0.f;
+            const float aj = a[j];
+            for (int c = lane; c < C; c += 64) {
+                part += dp[c] * ld(hq, (int64_t)j * C + c);
+                st(dhq, (int64_t)j * C + c, aj * dp[c]);
+            }
+            part = wave_sum(part);
+            if (lane == 0) da[j] = part;
+        }
+        __syncthreads();
+        float d = 0.f;                                                                // D[h] = sum_j s[j][h] da[j]
+        for (int j = wave * 16; j < wave * 16 + 16 && j < k; ++j) d += e[j][lane] * da[j];
+        red[wave * 64 + lane] = d;
+        __syncthreads();
+        d = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane];
+        T* dq = dqy + q * (int64_t)k * AT_H;
+        for (int i = threadIdx.x; i < k * AT_H; i += AT_NT) {
+            const int j = i >> 6, hh = i & 63;
+            st(dq, i, e[j][hh] * (1.f / AT_H) * (da[j] - d));                          // hh == lane (AT_NT is a multiple of 64): d is D[hh]
+        }
+        __syncthreads();
+    }
+}
+
+int grid_for(int64_t q) {
+    const int64_t cap = 256 * 16;
+    return (int)(q < cap ? q : cap);
+}
+
+}  // namespace
+
+extern "C" {
+
+int pps_attn_pool_fwd(const void* qy, const void* h, int64_t q, int k, int heads, int c, int bf16, void* pooled, void* stream) {
+    if (q < 0 || k < 1 || k > AT_KMAX || heads != AT_H || c < 1 || c > 256) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    if (!qy || !h || !pooled) return PPS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (bf16)
+        hipLaunchKernelGGL(attn_pool_fwd_kernel<uint16_t>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const uint16_t*)qy, (const uint16_t*)h, q, k, c,
+                           (uint16_t*)pooled);
+    else
+        hipLaunchKernelGGL(attn_pool_fwd_kernel<float>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const float*)qy, (const float*)h, q, k, c,
+                           (float*)pooled);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+int pps_attn_pool_bwd(const void* qy, const void* h, const void* dpooled, int64_t q, int k, int heads, int c, int bf16, void* dqy, void* dh,
+                      void* stream) {
+    if (q < 0 || k < 1 || k > AT_KMAX || heads != AT_H || c < 1 || c > 256) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    if (!qy || !h || !dpooled || !dqy || !dh) return PPS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (bf16)
+        hipLaunchKernelGGL(attn_pool_bwd_kernel<uint16_t>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const uint16_t*)qy, (const uint16_t*)h,
+                           (const uint16_t*)dpooled, q, k, c, (uint16_t*)dqy, (uint16_t*)dh);
+    else
+        hipLaunchKernelGGL(attn_pool_bwd_kernel<float>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const float*)qy, (const float*)h,
+                           (const float*)dpooled, q, k, c, (float*)dqy, (float*)dh);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+}  // extern "C"

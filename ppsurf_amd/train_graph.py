@@ -237,10 +237,14 @@ def interp_attention(proj, latents, pts, query, ids, last_layer=True):
     h = F.relu(train_ops.gather_rows(table, flat) + rows_linear(rel, w1[:, c:]).to(table.dtype))
     h = F.relu(dense(proj.fc2, h))
     h = F.relu(dense(proj.fc3, h))
-    att = torch.softmax(dense(proj.fc_query, h).view(b * q, k, -1), dim=1).mean(dim=2)  # softmax over neighbours, mean of heads
     # sum_j a_j (W_v h_j + b_v) = W_v (sum_j a_j h_j) + b_v because the weights of a query sum to 1 (:412-414): fc_value runs on
     # Q rows instead of Q*k (same identity as the inference kernel); autograd differentiates the pooled form
-    pooled = torch.bmm(att.unsqueeze(1).to(h.dtype), h.view(b * q, k, -1)).squeeze(1)
+    qy = dense(proj.fc_query, h).view(b * q, k, -1)
+    if h.is_cuda and train_ops.attn_pool_supported(k, qy.shape[2], h.shape[1]):
+        pooled = train_ops.attn_pool(qy, h.view(b * q, k, -1))          # softmax over neighbours, mean of heads, pooling: one HIP op
+    else:
+        att = torch.softmax(qy, dim=1).mean(dim=2)
+        pooled = torch.bmm(att.unsqueeze(1).to(h.dtype), h.view(b * q, k, -1)).squeeze(1)
     out = dense(proj.fc_value, pooled)
     if last_layer:
         out = dense(proj.fc8, out)

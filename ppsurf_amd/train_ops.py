@@ -242,6 +242,44 @@ class _BnAct(torch.autograd.Function):
         return dx, dgamma.to(ctx.dtypes[0]), dbeta.to(ctx.dtypes[1]), None, None, None, None, None
 
 
+class _AttnPool(torch.autograd.Function):
+    """pooled[q] = sum_j mean_h softmax_j(qy[q,j,h]) * h[q,j]  (poco_model.py:412-414 in the pooled form): one HIP kernel forward, one
+    backward; fp32 or bf16 storage, fp32 arithmetic; the softmax is recomputed in backward, only the two inputs are saved."""
+
+    @staticmethod
+    def forward(ctx, qy, h):
+        _need_cuda(qy, h)
+        dt = h.dtype if h.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        qy, h = qy.to(dt).contiguous(), h.to(dt).contiguous()
+        q, k, heads = qy.shape
+        c = h.shape[2]
+        pooled = torch.empty((q, c), device=h.device, dtype=dt)
+        _lib.check(_lib.lib().pps_attn_pool_fwd(qy.data_ptr(), h.data_ptr(), q, k, heads, c, int(dt == torch.bfloat16), pooled.data_ptr(), _stream()),
+                   'pps_attn_pool_fwd')
+        ctx.save_for_backward(qy, h)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        qy, h = ctx.saved_tensors
+        q, k, heads = qy.shape
+        c = h.shape[2]
+        dpooled = dpooled.to(h.dtype).contiguous()
+        dqy, dh = torch.empty_like(qy), torch.empty_like(h)
+        _lib.check(_lib.lib().pps_attn_pool_bwd(qy.data_ptr(), h.data_ptr(), dpooled.data_ptr(), q, k, heads, c, int(h.dtype == torch.bfloat16),
+                                                dqy.data_ptr(), dh.data_ptr(), _stream()), 'pps_attn_pool_bwd')
+        return dqy, dh
+
+
+def attn_pool_supported(k, heads, c):
+    return k <= 64 and heads == 64 and c <= 256
+
+
+def attn_pool(qy, h):
+    """qy [Q,k,64] attention logits, h [Q,k,C] -> pooled [Q,C] (dtype of h)."""
+    return _AttnPool.apply(qy, h)
+
+
 def bn_supported(rows, c):
     return c % 4 == 0 and c <= 1024 and 256 % (c // 4) == 0
 

@@ -146,6 +146,30 @@ def test_bn_act_fwd_bwd(rows, c, relu, dt):
         assert float((a - b_).abs().max()) <= rel * scale, '{}: err {:.3e} of {:.3e}'.format(name, float((a - b_).abs().max()), scale)
 
 
+@pytest.mark.parametrize('q,k,c,dt', [(37, 64, 256, torch.float32), (20, 64, 256, torch.bfloat16), (9, 20, 256, torch.float32), (5, 5, 64, torch.float32),
+                                      (3, 1, 32, torch.float32)])
+def test_attn_pool_fwd_bwd(q, k, c, dt):
+    """Fused attention pooling (softmax over neighbours per head, mean over the 64 heads, weighted sum of the neighbour rows;
+    poco_model.py:412-414) against the torch composition in float64: output and both gradients, full and short neighbour lists."""
+    from ppsurf_amd import train_ops
+    rng = np.random.default_rng(q * 100 + k)
+    qy0 = torch.from_numpy((3.0 * rng.standard_normal((q, k, 64))).astype(np.float32)).to(DEV)
+    h0 = torch.from_numpy(rng.standard_normal((q, k, c)).astype(np.float32)).to(DEV)
+    w = torch.from_numpy(rng.standard_normal((q, c)).astype(np.float32)).to(DEV)
+    qy, h = qy0.to(dt).requires_grad_(True), h0.to(dt).requires_grad_(True)
+    out = train_ops.attn_pool(qy, h)
+    assert out.dtype == dt and tuple(out.shape) == (q, c)
+    (out.float() * w).sum().backward()
+    qr, hr = qy.detach().double().requires_grad_(True), h.detach().double().requires_grad_(True)          # the same (rounded) inputs
+    want = torch.bmm(torch.softmax(qr, dim=1).mean(dim=2).unsqueeze(1), hr).squeeze(1)
+    (want * w.double()).sum().backward()
+    tol = dict(rtol=1e-5, atol=1e-5) if dt == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(out.double(), want, **tol)
+    torch.testing.assert_close(h.grad.double(), hr.grad, **tol)
+    tolq = dict(rtol=1e-4, atol=1e-6) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-3)
+    torch.testing.assert_close(qy.grad.double(), qr.grad, **tolq)
+
+
 def test_gather_rows_bf16_keeps_the_dtype():
     from ppsurf_amd import train_ops
     rng = np.random.default_rng(0)

@@ -66,7 +66,16 @@ def bn_supported(rows, c):
     return True
 
 
-_NAMES = ('gather_rows', 'neighbour_max', 'neighbour_contract', 'fka_geometry', 'bn_act', 'bn_supported')
+def attn_pool(qy, h):
+    att = torch.softmax(qy.float(), dim=1).mean(dim=2)
+    return torch.bmm(att.unsqueeze(1).to(h.dtype), h).squeeze(1)
+
+
+def attn_pool_supported(k, heads, c):
+    return True
+
+
+_NAMES = ('gather_rows', 'neighbour_max', 'neighbour_contract', 'fka_geometry', 'bn_act', 'bn_supported', 'attn_pool', 'attn_pool_supported')
 
 
 @contextlib.contextmanager
