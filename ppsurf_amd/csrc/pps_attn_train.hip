@@ -3,7 +3,7 @@
 // replaces (reference, under autograd): source/poco_model.py:412-414
 //     attention_weights = softmax(query, dim = neighbours).mean(dim = heads);   x = matmul(attention_weights, value)
 // in the pooled form of DESIGN.md section 2 (identity 2: fc_value runs after the pooling): per query q with k <= 64 neighbours,
-// H = 64 heads and C <= 256 channels
+// H <= 64 heads (64 in the interpolation head; 1 in PointNet's attention pooling, source/base/nn.py:84-96) and C <= 256 channels
 //     a[j] = 1/H * sum_h softmax_j(qy[q, j, h]),     pooled[q, c] = sum_j a[j] * h[q, j, c].
 // torch runs this as softmax (fwd + bwd), mean, cast, two batched GEMMs and their transposes over [Q*k, H] and [Q*k, C] tensors
 // (~3 ms per step at Q*k = 1.28 M); here it is ONE streaming kernel each way: a workgroup per query keeps the 64 x 64 logits in LDS,
@@ -43,10 +43,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // logits of query q -> LDS e[j][h] = exp(qy - max_j), inv_s[h] = 1 / sum_j e; returns nothing, all threads sync'ed on exit
 template <typename T>
-__device__ __forceinline__ void softmax_to_lds(const T* __restrict__ qy, int64_t q, int k, float (*e)[AT_H + 1], float* red, float* inv_s) {
+__device__ __forceinline__ void softmax_to_lds(const T* __restrict__ qy, int64_t q, int k, int H, float (*e)[AT_H + 1], float* red, float* inv_s) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const T* src = qy + q * (int64_t)k * AT_H;
-    for (int i = threadIdx.x; i < k * AT_H; i += AT_NT) e[i >> 6][i & 63] = ld(src, i);
+    const T* src = qy + q * (int64_t)k * H;
+    for (int i = threadIdx.x; i < k * AT_H; i += AT_NT) {                            // heads beyond H: logit 0 (their columns are never used)
+        const int j = i >> 6, hh = i & 63;
+        e[j][hh] = hh < H ? ld(src, (int64_t)j * H + hh) : 0.f;
+    }
     __syncthreads();
     float m = -INFINITY;
     for (int j = wave * 16; j < wave * 16 + 16 && j < k; ++j) m = fmaxf(m, e[j][lane]);
@@ -67,16 +70,17 @@ __device__ __forceinline__ void softmax_to_lds(const T* __restrict__ qy, int64_t
 }
 
 template <typename T>
-__global__ __launch_bounds__(AT_NT) void attn_pool_fwd_kernel(const T* __restrict__ qy, const T* __restrict__ h, int64_t Q, int k, int C,
+__global__ __launch_bounds__(AT_NT) void attn_pool_fwd_kernel(const T* __restrict__ qy, const T* __restrict__ h, int64_t Q, int k, int H, int C,
                                                               T* __restrict__ pooled) {
     __shared__ float e[AT_KMAX][AT_H + 1];
     __shared__ float red[4 * 64], inv_s[64], a[AT_KMAX];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int64_t q = blockIdx.x; q < Q; q += gridDim.x) {
-        softmax_to_lds(qy, q, k, e, red, inv_s);
+        softmax_to_lds(qy, q, k, H, e, red, inv_s);
+        const float inv_h = 1.f / (float)H;
         for (int j = wave * 16; j < wave * 16 + 16 && j < k; ++j) {                  // a[j] = mean over the heads
-            const float v = wave_sum(e[j][lane] * inv_s[lane]);
-            if (lane == 0) a[j] = v * (1.f / AT_H);
+            const float v = wave_sum(lane < H ? e[j][lane] * inv_s[lane] : 0.f);
+            if (lane == 0) a[j] = v * inv_h;
         }
         __syncthreads();
         const T* hq = h + q * (int64_t)k * C;
@@ -92,18 +96,19 @@ __global__ __launch_bounds__(AT_NT) void attn_pool_fwd_kernel(const T* __restric
 // d_h[q,j,c] = a[j] dP[c];   da[j] = sum_c dP[c] h[q,j,c];   d_qy[q,j,h] = s[j,h]/H * (da[j] - sum_j' s[j',h] da[j'])
 template <typename T>
 __global__ __launch_bounds__(AT_NT) void attn_pool_bwd_kernel(const T* __restrict__ qy, const T* __restrict__ h, const T* __restrict__ dpooled,
-                                                              int64_t Q, int k, int C, T* __restrict__ dqy, T* __restrict__ dh) {
+                                                              int64_t Q, int k, int H, int C, T* __restrict__ dqy, T* __restrict__ dh) {
     __shared__ float e[AT_KMAX][AT_H + 1];
-    __shared__ float red[4 * 64], inv_s[64], a[AT_KMAX], da[AT_KMAX], dp[256];
+    __shared__ float red[4 * 64], inv_s[64], a[AT_KMAX], da[AT_KMAX], dp[256], dsum[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int64_t q = blockIdx.x; q < Q; q += gridDim.x) {
-        softmax_to_lds(qy, q, k, e, red, inv_s);
+        softmax_to_lds(qy, q, k, H, e, red, inv_s);
+        const float inv_h = 1.f / (float)H;
         for (int c = threadIdx.x; c < C; c += AT_NT) dp[c] = ld(dpooled, q * (int64_t)C + c);
         for (int j = wave * 16; j < wave * 16 + 16 && j < k; ++j) {
-            const float s = e[j][lane] * inv_s[lane];
+            const float s = lane < H ? e[j][lane] * inv_s[lane] : 0.f;
             e[j][lane] = s;                                                          // e now holds the softmax probabilities s[j][h]
             const float v = wave_sum(s);
-            if (lane == 0) a[j] = v * (1.f / AT_H);
+            if (lane == 0) a[j] = v * inv_h;
         }
         __syncthreads();
         const T* hq = h + q * (int64_t)k * C;
@@ -123,11 +128,12 @@ __global__ __launch_bounds__(AT_NT) void attn_pool_bwd_kernel(const T* __restric
         for (int j = wave * 16; j < wave * 16 + 16 && j < k; ++j) d += e[j][lane] * da[j];
         red[wave * 64 + lane] = d;
         __syncthreads();
-        d = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane];
-        T* dq = dqy + q * (int64_t)k * AT_H;
-        for (int i = threadIdx.x; i < k * AT_H; i += AT_NT) {
-            const int j = i >> 6, hh = i & 63;
-            st(dq, i, e[j][hh] * (1.f / AT_H) * (da[j] - d));                          // hh == lane (AT_NT is a multiple of 64): d is D[hh]
+        if (threadIdx.x < 64) dsum[lane] = red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane];
+        __syncthreads();
+        T* dq = dqy + q * (int64_t)k * H;
+        for (int i = threadIdx.x; i < k * H; i += AT_NT) {
+            const int j = i / H, hh = i - j * H;
+            st(dq, i, e[j][hh] * inv_h * (da[j] - dsum[hh]));
         }
         __syncthreads();
     }
@@ -143,31 +149,31 @@ int grid_for(int64_t q) {
 extern "C" {
 
 int pps_attn_pool_fwd(const void* qy, const void* h, int64_t q, int k, int heads, int c, int bf16, void* pooled, void* stream) {
-    if (q < 0 || k < 1 || k > AT_KMAX || heads != AT_H || c < 1 || c > 256) return PPS_ERR_ARG;
+    if (q < 0 || k < 1 || k > AT_KMAX || heads < 1 || heads > AT_H || c < 1 || c > 256) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
     if (!qy || !h || !pooled) return PPS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (bf16)
-        hipLaunchKernelGGL(attn_pool_fwd_kernel<uint16_t>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const uint16_t*)qy, (const uint16_t*)h, q, k, c,
+        hipLaunchKernelGGL(attn_pool_fwd_kernel<uint16_t>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const uint16_t*)qy, (const uint16_t*)h, q, k, heads, c,
                            (uint16_t*)pooled);
     else
-        hipLaunchKernelGGL(attn_pool_fwd_kernel<float>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const float*)qy, (const float*)h, q, k, c,
+        hipLaunchKernelGGL(attn_pool_fwd_kernel<float>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const float*)qy, (const float*)h, q, k, heads, c,
                            (float*)pooled);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 
 int pps_attn_pool_bwd(const void* qy, const void* h, const void* dpooled, int64_t q, int k, int heads, int c, int bf16, void* dqy, void* dh,
                       void* stream) {
-    if (q < 0 || k < 1 || k > AT_KMAX || heads != AT_H || c < 1 || c > 256) return PPS_ERR_ARG;
+    if (q < 0 || k < 1 || k > AT_KMAX || heads < 1 || heads > AT_H || c < 1 || c > 256) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
     if (!qy || !h || !dpooled || !dqy || !dh) return PPS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (bf16)
         hipLaunchKernelGGL(attn_pool_bwd_kernel<uint16_t>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const uint16_t*)qy, (const uint16_t*)h,
-                           (const uint16_t*)dpooled, q, k, c, (uint16_t*)dqy, (uint16_t*)dh);
+                           (const uint16_t*)dpooled, q, k, heads, c, (uint16_t*)dqy, (uint16_t*)dh);
     else
         hipLaunchKernelGGL(attn_pool_bwd_kernel<float>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const float*)qy, (const float*)h,
-                           (const float*)dpooled, q, k, c, (float*)dqy, (float*)dh);
+                           (const float*)dpooled, q, k, heads, c, (float*)dqy, (float*)dh);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 

@@ -274,8 +274,12 @@ def pointnet(pn, patches):
     h = batch_norm(pn.bn1, dense(pn.conv1, h), relu=True)
     h = batch_norm(pn.bn2, dense(pn.conv2, h), relu=True)
     h = batch_norm(pn.bn3, dense(pn.conv3, h))
-    w = torch.softmax(dense(pn.att.fc_query, h).view(nq, p), dim=1)
-    pooled = torch.bmm(w.unsqueeze(1).to(h.dtype), h.view(nq, p, -1)).squeeze(1)          # pool first: the weights sum to 1
+    logit = dense(pn.att.fc_query, h).view(nq, p, 1)
+    if h.is_cuda and train_ops.attn_pool_supported(p, 1, h.shape[1]):
+        pooled = train_ops.attn_pool(logit, h.view(nq, p, -1))                           # softmax over the patch + pooling: one HIP op (P <= 64)
+    else:
+        w = torch.softmax(logit.view(nq, p), dim=1)
+        pooled = torch.bmm(w.unsqueeze(1).to(h.dtype), h.view(nq, p, -1)).squeeze(1)      # pool first: the weights sum to 1
     return dense(pn.att.fc_value, pooled), trans2
 
 

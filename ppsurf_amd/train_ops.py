@@ -272,7 +272,7 @@ class _AttnPool(torch.autograd.Function):
 
 
 def attn_pool_supported(k, heads, c):
-    return k <= 64 and heads == 64 and c <= 256
+    return 1 <= k <= 64 and 1 <= heads <= 64 and c <= 256
 
 
 def attn_pool(qy, h):

@@ -146,14 +146,16 @@ def test_bn_act_fwd_bwd(rows, c, relu, dt):
         assert float((a - b_).abs().max()) <= rel * scale, '{}: err {:.3e} of {:.3e}'.format(name, float((a - b_).abs().max()), scale)
 
 
-@pytest.mark.parametrize('q,k,c,dt', [(37, 64, 256, torch.float32), (20, 64, 256, torch.bfloat16), (9, 20, 256, torch.float32), (5, 5, 64, torch.float32),
-                                      (3, 1, 32, torch.float32)])
-def test_attn_pool_fwd_bwd(q, k, c, dt):
-    """Fused attention pooling (softmax over neighbours per head, mean over the 64 heads, weighted sum of the neighbour rows;
-    poco_model.py:412-414) against the torch composition in float64: output and both gradients, full and short neighbour lists."""
+@pytest.mark.parametrize('q,k,c,dt,heads', [(37, 64, 256, torch.float32, 64), (20, 64, 256, torch.bfloat16, 64), (9, 20, 256, torch.float32, 64),
+                                            (5, 5, 64, torch.float32, 64), (3, 1, 32, torch.float32, 64), (33, 50, 256, torch.float32, 1),
+                                            (12, 50, 256, torch.bfloat16, 1), (7, 10, 256, torch.float32, 1), (6, 40, 128, torch.float32, 7)])
+def test_attn_pool_fwd_bwd(q, k, c, dt, heads):
+    """Fused attention pooling (softmax over neighbours per head, mean over the heads, weighted sum of the neighbour rows;
+    poco_model.py:412-414 with 64 heads, PointNet's AttentionPoco nn.py:84-96 with 1 head over the patch) against the torch composition in
+    float64: output and both gradients, full and short neighbour lists."""
     from ppsurf_amd import train_ops
     rng = np.random.default_rng(q * 100 + k)
-    qy0 = torch.from_numpy((3.0 * rng.standard_normal((q, k, 64))).astype(np.float32)).to(DEV)
+    qy0 = torch.from_numpy((3.0 * rng.standard_normal((q, k, heads))).astype(np.float32)).to(DEV)
     h0 = torch.from_numpy(rng.standard_normal((q, k, c)).astype(np.float32)).to(DEV)
     w = torch.from_numpy(rng.standard_normal((q, c)).astype(np.float32)).to(DEV)
     qy, h = qy0.to(dt).requires_grad_(True), h0.to(dt).requires_grad_(True)
