@@ -35,6 +35,19 @@ __device__ __forceinline__ void st(uint16_t* p, int64_t i, float v) {           
     p[i] = (uint16_t)(u >> 16);
 }
 
+// four consecutive channels of one row per lane (8 bytes in bf16, 16 in fp32): a wave covers a 256-channel row with ONE load
+__device__ __forceinline__ float4 ld4(const float* p, int64_t i) { return *(const float4*)(p + i); }
+__device__ __forceinline__ float4 ld4(const uint16_t* p, int64_t i) {
+    const uint2 u = *(const uint2*)(p + i);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(float* p, int64_t i, float4 v) { *(float4*)(p + i) = v; }
+__device__ __forceinline__ void st4(uint16_t* p, int64_t i, float4 v) {
+    uint16_t t[4];
+    st(t, 0, v.x); st(t, 1, v.y); st(t, 2, v.z); st(t, 3, v.w);
+    *(uint2*)(p + i) = make_uint2((unsigned)t[0] | ((unsigned)t[1] << 16), (unsigned)t[2] | ((unsigned)t[3] << 16));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
@@ -84,10 +97,28 @@ __global__ __launch_bounds__(AT_NT) void attn_pool_fwd_kernel(const T* __restric
         }
         __syncthreads();
         const T* hq = h + q * (int64_t)k * C;
-        for (int c = threadIdx.x; c < C; c += AT_NT) {
-            float acc = 0.f;
-            for (int j = 0; j < k; ++j) acc += a[j] * ld(hq, (int64_t)j * C + c);
-            st(pooled, q * (int64_t)C + c, acc);
+        if (C == 256) {                                                              // wave w sums its 16 rows, lane = 4 channels
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = wave * 16; j < wave * 16 + 16 && j < k; ++j) {
+                const float4 v = ld4(hq, (int64_t)j * 256 + 4 * lane);
+                const float aj = a[j];
+                acc.x += aj * v.x; acc.y += aj * v.y; acc.z += aj * v.z; acc.w += aj * v.w;
+            }
+            float4* part = (float4*)&e[0][0];                                        // the logits are no longer needed: 4 x 64 float4
+            __syncthreads();
+            part[wave * 64 + lane] = acc;
+            __syncthreads();
+            if (wave == 0) {
+                const float4 p0 = part[lane], p1 = part[64 + lane], p2 = part[128 + lane], p3 = part[192 + lane];
+                st4(pooled, q * 256 + 4 * lane, make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y),
+                                                            (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w)));
+            }
+        } else {
+            for (int c = threadIdx.x; c < C; c += AT_NT) {
+                float acc = 0.f;
+                for (int j = 0; j < k; ++j) acc += a[j] * ld(hq, (int64_t)j * C + c);
+                st(pooled, q * (int64_t)C + c, acc);
+            }
         }
         __syncthreads();
     }
@@ -113,15 +144,26 @@ __global__ __launch_bounds__(AT_NT) void attn_pool_bwd_kernel(const T* __restric
         __syncthreads();
         const T* hq = h + q * (int64_t)k * C;
         T* dhq = dh + q * (int64_t)k * C;
-        for (int j = wave * 16; j < wave * 16 + 16 && j < k; ++j) {                  // one neighbour row per wave pass
-            float part = 0.f;
-            const float aj = a[j];
-            for (int c = lane; c < C; c += 64) {
-                part += dp[c] * ld(hq, (int64_t)j * C + c);
-                st(dhq, (int64_t)j * C + c, aj * dp[c]);
+        if (C == 256) {
+            const float4 d4 = make_float4(dp[4 * lane], dp[4 * lane + 1], dp[4 * lane + 2], dp[4 * lane + 3]);
+            for (int j = wave * 16; j < wave * 16 + 16 && j < k; ++j) {              // one neighbour row per wave pass, 4 channels per lane
+                const float4 v = ld4(hq, (int64_t)j * 256 + 4 * lane);
+                const float aj = a[j];
+                st4(dhq, (int64_t)j * 256 + 4 * lane, make_float4(aj * d4.x, aj * d4.y, aj * d4.z, aj * d4.w));
+                const float part = wave_sum((d4.x * v.x + d4.y * v.y) + (d4.z * v.z + d4.w * v.w));
+                if (lane == 0) da[j] = part;
             }
-            part = wave_sum(part);
-            if (lane == 0) da[j] = part;
+        } else {
+            for (int j = wave * 16; j < wave * 16 + 16 && j < k; ++j) {
+                float part = 0.f;
+                const float aj = a[j];
+                for (int c = lane; c < C; c += 64) {
+                    part += dp[c] * ld(hq, (int64_t)j * C + c);
+                    st(dhq, (int64_t)j * C + c, aj * dp[c]);
+                }
+                part = wave_sum(part);
+                if (lane == 0) da[j] = part;
+            }
         }
         __syncthreads();
         float d = 0.f;                                                                // D[h] = sum_j s[j][h] da[j]
