@@ -134,8 +134,8 @@ def test_batched_block_culling_tables_equal_exhaustive_search(n, b, monkeypatch)
 
 
 def test_batched_block_culling_handles_ties_and_duplicates(monkeypatch):
-    monkeypatch.setattr(spatial, 'BLOCKED_MIN_POINTS', 1024)
     """Lattice points (many equal distances) and duplicated points: the (d2, index) order of the exhaustive search is kept."""
+    monkeypatch.setattr(spatial, 'BLOCKED_MIN_POINTS', 1024)
     g = np.stack(np.meshgrid(*[np.arange(11)] * 3, indexing='ij'), -1).reshape(-1, 3).astype(np.float32) / 10 - 0.5       # 1331 lattice points
     cloud = np.concatenate([g, g[:200]])                                                                                  # + duplicates
     lv0 = torch.from_numpy(np.stack([cloud, cloud[::-1].copy()])).to(DEV)
