@@ -836,7 +836,7 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_h_kernel(const float* _
 
 // =====================================================================================================
 // PointNet phase C: conv0a, conv0b, x <- trans2 x, conv1, conv2 (+ReLU), conv3 (no ReLU), attention pooling
-// weights (floats): [xyz 256][c0b 4096][c1 4096][c2 8192][c3 32768]   bias [64][64][64][128][256][wq 256][bq 4]
+// weights (floats): [xyz 256][c0b 4096][c1 4096][c2 8192][c3 32768]   bias [64][64][64][128][256][u = W3^T wq 128 | pad 128][wq.b3 + bq, 0, 0, 0]
 // Row packing as in phase A; the left-over tile parks, per query, the softmax partials (max m, sum S, weighted sum A[256]).
 // =====================================================================================================
 #define PC_W_XYZ 256
@@ -845,9 +845,14 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_h_kernel(const float* _
 
 // conv0a .. conv3 on one 16-row tile of query `tq` (per-row feature transform), then the attention logit of each row
 // rows_per_query = 16 and nq = 1 for a tile of one query; a left-over tile holds nq queries x rows_per_query rows
-__device__ __forceinline__ float feat_chain(float coord, const float* __restrict__ trans2, int64_t q0, int64_t Q, int nq, int rows_per_query,
-                                            f32x4 (&z)[16], const float* xyz_l, const f32x4* bias4, const f32x4* wq4, float bq,
-                                            const f32x4* wg, f32x4*& cur, f32x4*& nxt, int lane) {
+// The attention logit of a row (nn.py:88) is linear in conv3's INPUT: s = wq.(W3 y + b3) + bq = (W3^T wq).y + (wq.b3 + bq); the host
+// packs u = W3^T wq (128 values) and the constant, so s is known BEFORE conv3 runs: `on_logit(s)` updates the softmax state and the 16
+// output blocks of conv3 are handed to `on_block(first_block, z0, z1)` as they leave the matrix pipe -- the tile's 256 channels are
+// never held at once (64 VGPRs less than computing s from the finished tile).
+template <class OnLogit, class OnBlock>
+__device__ __forceinline__ void feat_chain(float coord, const float* __restrict__ trans2, int64_t q0, int64_t Q, int nq, int rows_per_query,
+                                           const float* xyz_l, const f32x4* bias4, const f32x4* u4, float s0,
+                                           const f32x4* wg, f32x4*& cur, f32x4*& nxt, int lane, OnLogit&& on_logit, OnBlock&& on_block) {
     const int n = lane & 15, g = lane >> 4;
     f32x4 x0[4], x1[4], y[8];
 #pragma unroll
@@ -890,30 +895,40 @@ __device__ __forceinline__ float feat_chain(float coord, const float* __restrict
     for (int h = 0; h < PN_C2N; ++h)
         stream_step<PCH4, PNT>(wg + 2048 + (h + 1) * PCH4, cur, nxt,
                                [&](const f32x4* w) { dense_blocks<4, PN_C2OB, 1>(x1, &y[PN_C2OB * h], w, bias4 + 48 + 4 * PN_C2OB * h, lane); });
+    {
+        float s = 0.f;                               // attention logit of row n from conv3's input
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+            const f32x4 w4 = u4[4 * bb + g];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += w4[r] * y[bb][r];
+        }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        on_logit(s + s0);
+    }
+    static_assert(PN_C3OB == 2, "conv3 is streamed two output blocks per chunk");
 #pragma unroll
     for (int c = 0; c < PN_C3N - 1; ++c)
-        stream_step<PCH4, PNT>(wg + 4096 + (c + 1) * PCH4, cur, nxt,
-                               [&](const f32x4* w) { dense_blocks<8, PN_C3OB, 0>(y, &z[PN_C3OB * c], w, bias4 + 80 + 4 * PN_C3OB * c, lane); });
+        stream_step<PCH4, PNT>(wg + 4096 + (c + 1) * PCH4, cur, nxt, [&](const f32x4* w) {
+            f32x4 zz[2];
+            dense_blocks<8, 2, 0>(y, zz, w, bias4 + 80 + 8 * c, lane);
+            on_block(2 * c, zz[0], zz[1]);
+        });
     stream_step<1024, PNT>(wg, cur, nxt, [&](const f32x4* w) {
-        dense_blocks<8, PN_C3OB, 0>(y, &z[PN_C3OB * (PN_C3N - 1)], w, bias4 + 80 + 4 * PN_C3OB * (PN_C3N - 1), lane); });
+        f32x4 zz[2];
+        dense_blocks<8, 2, 0>(y, zz, w, bias4 + 80 + 8 * (PN_C3N - 1), lane);
+        on_block(2 * (PN_C3N - 1), zz[0], zz[1]);
+    });
     __builtin_amdgcn_s_setprio(0);
-    float s = 0.f;                                   // attention logit of row n (nn.py:88)
-#pragma unroll
-    for (int bb = 0; bb < 16; ++bb) {
-        const f32x4 w4 = wq4[4 * bb + g];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s += w4[r] * z[bb][r];
-    }
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    return s + bq;
 }
 
 // split precision: `trans2` is the pre-split fragment image written by pointnet_stn_fc_h_kernel (A operands straight from global,
 // no conversion work here); wg -> f16x3 images of c0b, c1, c2, c3
-__device__ __forceinline__ float feat_chain_h(float coord, const float* __restrict__ trans2, int64_t q0, int64_t Q, int nq, int rows_per_query,
-                                              f32x4 (&z)[16], const float* xyz_l, const f32x4* bias4, const f32x4* wq4, float bq,
-                                              const f32x4* wg, f32x4*& cur, f32x4*& nxt, int lane) {
+template <class OnLogit, class OnBlock>
+__device__ __forceinline__ void feat_chain_h(float coord, const float* __restrict__ trans2, int64_t q0, int64_t Q, int nq, int rows_per_query,
+                                             const float* xyz_l, const f32x4* bias4, const f32x4* u4, float s0,
+                                             const f32x4* wg, f32x4*& cur, f32x4*& nxt, int lane, OnLogit&& on_logit, OnBlock&& on_block) {
     const int n = lane & 15, g = lane >> 4;
     HiLo a[2], b[2], y[4];
     {
@@ -960,30 +975,29 @@ __device__ __forceinline__ float feat_chain_h(float coord, const float* __restri
     a[1] = split_f16(t0[2], t0[3]);
     stream_step<PCH4, PNT>(wg + 2048, cur, nxt, [&](const f32x4* w) {
         dense_blocks_f16x3<2, 4, 1>(a, (const half8*)w, bias4 + 32, lane, [&](int i, const f32x4& o0, const f32x4& o1) { b[i] = split_f16(o0, o1); }); });
+    float s = 0.f;                                   // attention logit, accumulated while conv2's output blocks are still fp32
 #pragma unroll
     for (int h = 0; h < PN_C2N; ++h)
         stream_step<PCH4, PNT>(wg + 2048 + (h + 1) * PCH4, cur, nxt, [&](const f32x4* w) {
-            dense_blocks_f16x3<2, PN_C2OB, 1>(b, (const half8*)w, bias4 + 48 + 4 * PN_C2OB * h, lane,
-                                              [&](int i, const f32x4& o0, const f32x4& o1) { y[PN_C2OB / 2 * h + i] = split_f16(o0, o1); }); });
+            dense_blocks_f16x3<2, PN_C2OB, 1>(b, (const half8*)w, bias4 + 48 + 4 * PN_C2OB * h, lane, [&](int i, const f32x4& o0, const f32x4& o1) {
+                const int bb = PN_C2OB * h + 2 * i;
+                const f32x4 w0 = u4[4 * bb + g], w1 = u4[4 * (bb + 1) + g];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s += w0[r] * o0[r] + w1[r] * o1[r];
+                y[PN_C2OB / 2 * h + i] = split_f16(o0, o1);
+            }); });
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    on_logit(s + s0);
 #pragma unroll
     for (int c = 0; c < PN_C3N - 1; ++c)
         stream_step<PCH4, PNT>(wg + 4096 + (c + 1) * PCH4, cur, nxt, [&](const f32x4* w) {
-            dense_blocks_f16x3<4, PN_C3OB, 0>(y, (const half8*)w, bias4 + 80 + 4 * PN_C3OB * c, lane,
-                                              [&](int i, const f32x4& o0, const f32x4& o1) { z[PN_C3OB * c + 2 * i] = o0; z[PN_C3OB * c + 2 * i + 1] = o1; }); });
+            dense_blocks_f16x3<4, 2, 0>(y, (const half8*)w, bias4 + 80 + 8 * c, lane,
+                                        [&](int, const f32x4& o0, const f32x4& o1) { on_block(2 * c, o0, o1); }); });
     stream_step<1024, PNT>(wg, cur, nxt, [&](const f32x4* w) {
-        dense_blocks_f16x3<4, PN_C3OB, 0>(y, (const half8*)w, bias4 + 80 + 4 * PN_C3OB * (PN_C3N - 1), lane,
-                                          [&](int i, const f32x4& o0, const f32x4& o1) { z[PN_C3OB * (PN_C3N - 1) + 2 * i] = o0; z[PN_C3OB * (PN_C3N - 1) + 2 * i + 1] = o1; }); });
+        dense_blocks_f16x3<4, 2, 0>(y, (const half8*)w, bias4 + 80 + 8 * (PN_C3N - 1), lane,
+                                    [&](int, const f32x4& o0, const f32x4& o1) { on_block(2 * (PN_C3N - 1), o0, o1); }); });
     __builtin_amdgcn_s_setprio(0);
-    float s = 0.f;
-#pragma unroll
-    for (int bb = 0; bb < 16; ++bb) {
-        const f32x4 w4 = wq4[4 * bb + g];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s += w4[r] * z[bb][r];
-    }
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    return s + bq;
 }
 
 template <bool H>
@@ -997,7 +1011,7 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float*
     float* bias_l = xyz_l + PC_W_XYZ;
     float* park = bias_l + PC_NBIAS;                   // [PNW][PN_PARK_ROWS][PN_ROWF]: A[256], m, S of the left-over rows
     const f32x4* bias4 = (const f32x4*)bias_l;
-    const f32x4* wq4 = bias4 + 144;
+    const f32x4* u4 = bias4 + 144;                       // W3^T wq: 128 values in the block layout of conv3's input
     const f32x4* wg = wdense;
     const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
     float* mypark = park + wave * PN_PARK_ROWS * PN_ROWF;
@@ -1007,7 +1021,7 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float*
     stream_prologue<1024, PNT>(wg, buf0);
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
-    const float bq = bias_l[576 + 256];
+    const float s0 = bias_l[576 + 256];                   // wq . b3 + bq
 
     const PatchPacking pk = patch_packing(P, pack != 0);
     const int64_t ngroups = (Q + pk.qg - 1) / pk.qg;
@@ -1016,25 +1030,26 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float*
     xcd_tile_range(ntiles, first, count, stride);
     for (int it = 0; it < count; ++it) {
         const int64_t q0 = ((int64_t)(first + it * stride) * PNW + wave) * pk.qg;
-        f32x4 z[16];
         if (pk.packed) {
             const int ql = n / pk.lo;
             const int64_t qq = (q0 + ql < Q) ? q0 + ql : Q - 1;
             const float coord = (g < 3) ? patches[(qq * P + pk.fb * 16 + (n % pk.lo)) * 3 + g] : 0.f;
-            const float s = H ? feat_chain_h(coord, trans2, q0, Q, pk.qg, pk.lo, z, xyz_l, bias4, wq4, bq, wg, cur, nxt, lane)
-                              : feat_chain(coord, trans2, q0, Q, pk.qg, pk.lo, z, xyz_l, bias4, wq4, bq, wg, cur, nxt, lane);
-            const float m = group_max(s, pk.lo);
-            const float e = __expf(s - m);
-            const float S = group_sum(e, pk.lo);
             float* row = mypark + ql * PN_ROWF;
+            float e = 0.f;
+            auto on_logit = [&](float s) {
+                const float m = group_max(s, pk.lo);
+                e = __expf(s - m);
+                const float S = group_sum(e, pk.lo);
+                if ((n % pk.lo) == 0 && g == 0) { row[256] = m; row[257] = S; }
+            };
+            auto on_block = [&](int bb, const f32x4& z0, const f32x4& z1) {
+                f32x4 a0, a1;
 #pragma unroll
-            for (int bb = 0; bb < 16; ++bb) {
-                f32x4 a4;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) a4[r] = group_sum(e * z[bb][r], pk.lo);
-                if ((n % pk.lo) == 0) ((f32x4*)row)[4 * bb + g] = a4;
-            }
-            if ((n % pk.lo) == 0 && g == 0) { row[256] = m; row[257] = S; }
+                for (int r = 0; r < 4; ++r) { a0[r] = group_sum(e * z0[r], pk.lo); a1[r] = group_sum(e * z1[r], pk.lo); }
+                if ((n % pk.lo) == 0) { ((f32x4*)row)[4 * bb + g] = a0; ((f32x4*)row)[4 * (bb + 1) + g] = a1; }
+            };
+            if (H) feat_chain_h(coord, trans2, q0, Q, pk.qg, pk.lo, xyz_l, bias4, u4, s0, wg, cur, nxt, lane, on_logit, on_block);
+            else feat_chain(coord, trans2, q0, Q, pk.qg, pk.lo, xyz_l, bias4, u4, s0, wg, cur, nxt, lane, on_logit, on_block);
         }
         for (int qi = 0; qi < pk.qg; ++qi) {
             const int64_t q = q0 + qi;
@@ -1058,19 +1073,27 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float*
                 const bool valid = rowi < P;
                 const int rowc = valid ? rowi : P - 1;
                 const float coord = (g < 3) ? patches[(qc * P + rowc) * 3 + g] : 0.f;
-                const float s = H ? feat_chain_h(coord, trans2, qc, Q, 1, 16, z, xyz_l, bias4, wq4, bq, wg, cur, nxt, lane)
-                                  : feat_chain(coord, trans2, qc, Q, 1, 16, z, xyz_l, bias4, wq4, bq, wg, cur, nxt, lane);
-                // online softmax over the patch points (nn.py:91-93)
-                const float mblk = row16_max(valid ? s : -INFINITY);
-                const float mnew = fmaxf(mrun, mblk);
-                const float scale = __expf(mrun - mnew);
-                const float en = valid ? __expf(s - mnew) : 0.f;
-                mrun = mnew;
-                ssum = ssum * scale + en;
+                float en = 0.f;
+                // online softmax over the patch points (nn.py:91-93): the state is advanced as soon as the tile's logits are known,
+                // the accumulators take conv3's output blocks as they are produced
+                auto on_logit = [&](float s) {
+                    const float mblk = row16_max(valid ? s : -INFINITY);
+                    const float mnew = fmaxf(mrun, mblk);
+                    const float scale = __expf(mrun - mnew);
+                    en = valid ? __expf(s - mnew) : 0.f;
+                    mrun = mnew;
+                    ssum = ssum * scale + en;
 #pragma unroll
-                for (int bb = 0; bb < 16; ++bb)
+                    for (int bb = 0; bb < 16; ++bb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[bb][r] = acc[bb][r] * scale + en * z[bb][r];
+                        for (int r = 0; r < 4; ++r) acc[bb][r] *= scale;
+                };
+                auto on_block = [&](int bb, const f32x4& z0, const f32x4& z1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { acc[bb][r] += en * z0[r]; acc[bb + 1][r] += en * z1[r]; }
+                };
+                if (H) feat_chain_h(coord, trans2, qc, Q, 1, 16, xyz_l, bias4, u4, s0, wg, cur, nxt, lane, on_logit, on_block);
+                else feat_chain(coord, trans2, qc, Q, 1, 16, xyz_l, bias4, u4, s0, wg, cur, nxt, lane, on_logit, on_block);
             }
             const float inv = 1.f / row16_sum(ssum);
             rows16_sum_transposed(acc, lane);             // lane (n,g): acc[0] = sum over the 16 lanes of block n

@@ -125,7 +125,11 @@ class DecoderPlan:
         host['pb_w'] = np.concatenate([pack_dense(f1[0]), pack_dense(f2[0]), pack_dense(f3w)])
         host['pb_b'] = f32(np.concatenate([f1[1], f2[1], f3b + np.eye(64).reshape(-1)]))        # + identity (nn.py:187-188)
         host['pc_w'] = np.concatenate([pack_xyz(c0a[0]), pack_dense(c0b[0]), pack_dense(c1[0]), pack_dense(c2[0]), pack_dense(c3[0])])
-        host['pc_b'] = f32(np.concatenate([c0a[1], c0b[1], c1[1], c2[1], c3[1], aq_w.reshape(-1), _pad(aq_b, 4)]))
+        # the attention logit of a patch point is linear in conv3's input: wq.(W3 y + b3) + bq = (W3^T wq).y + (wq.b3 + bq) (nn.py:88,336);
+        # the kernels take u = W3^T wq and the constant, so the logit is known before conv3 runs (pps_decode.hip, feat_chain)
+        u_att = c3[0].T @ aq_w.reshape(-1)
+        s0_att = float(aq_w.reshape(-1) @ c3[1] + aq_b.reshape(-1)[0])
+        host['pc_b'] = f32(np.concatenate([c0a[1], c0b[1], c1[1], c2[1], c3[1], u_att, np.zeros(128), [s0_att, 0.0, 0.0, 0.0]]))
         # ---- tail: fc_value . fc8 | att.fc_value, branch sum (ppsurf_model.py:100), MLP (nn.py:376-417) --
         m = p + 'mlp.layers.'
         l1 = _fold_bn(*_wb(sd, m + '0.0'), sd, m + '0.1')

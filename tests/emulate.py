@@ -80,8 +80,8 @@ def decode(w, latents_cn, pts, query, idx, patches):
     y = np.einsum('qab,qpb->qpa', trans2, y1)
     y = relu(y @ unpack_dense(c1, 64, 64).T + bc[2])
     y = relu(y @ unpack_dense(c2, 128, 64).T + bc[3])
+    wgt = softmax(y @ bc[5][:128] + bc[6][0], axis=1)          # attention logit from conv3's INPUT: u = W3^T wq, constant wq.b3 + bq
     y = y @ unpack_dense(c3, 256, 128).T + bc[4]
-    wgt = softmax(y @ bc[5] + bc[6][0], axis=1)
     xbar = (wgt[:, :, None] * y).sum(axis=1)
     wa, wb, l2w, l3w = _split(w['tl_w'], [65536, 65536, 65536, 8192])
     bt = _split(w['tl_b'].astype(np.float64), [256, 256, 32])

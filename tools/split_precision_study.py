@@ -81,8 +81,8 @@ def decode(w, latents_cn, pts, query, idx, patches):
         y = np.stack([mm(y1[q], trans2[q].T) for q in range(y1.shape[0])])
     y = E.relu(mm(y, E.unpack_dense(c1, 64, 64).T) + bc[2])
     y = E.relu(mm(y, E.unpack_dense(c2, 128, 64).T) + bc[3])
+    wgt = E.softmax(y @ bc[5][:128] + bc[6][0], axis=1)        # logit from conv3's input (u = W3^T wq), as the kernels compute it
     y = mm(y, E.unpack_dense(c3, 256, 128).T) + bc[4]
-    wgt = E.softmax(y @ bc[5] + bc[6][0], axis=1)
     xbar = (wgt[:, :, None] * y).sum(axis=1)
     wa, wb, l2w, l3w = E._split(w['tl_w'], [65536, 65536, 65536, 8192])
     bt = E._split(w['tl_b'].astype(np.float64), [256, 256, 32])
