@@ -300,6 +300,26 @@ int pps_attn_pool_fwd(const void* qy, const void* h, int64_t q, int k, int heads
 int pps_attn_pool_bwd(const void* qy, const void* h, const void* dpooled, int64_t q, int k, int heads, int c, int bf16, void* dqy, void* dh,
                       void* stream);
 
+/* Dense layer of the training step over point-major rows with the previous layer's BatchNorm + ReLU applied on load and this layer's
+ * batch statistics taken on store (replaces the conv -> bn -> relu -> conv chains of source/base/nn.py:162-190, 323-336, 376-417 and the
+ * fc -> relu -> fc chain of source/poco_model.py:400-410 under autograd and bf16 autocast; pps_rows_train.hip).
+ *   x [rows, cin], y [rows, cout] bfloat16 RAW layer outputs; cin, cout in {64, 128, 256} (pps_rows_layer_supported)
+ *   act(x) = relu?(x * in_scale + in_shift)   (in_scale / in_shift [cin], both NULL = identity; in_relu needs them)
+ *   fwd:  y = act(x) w^T + bias  (w [cout, cin] fp32, rounded to bf16 for the product; bias NULL = none).  With gamma != NULL the batch
+ *         statistics of y give out_affine [2][cout] = (gamma rstd, beta - mean gamma rstd), save [2][cout] = (mean, rstd) and the
+ *         running statistics are updated like torch.nn.BatchNorm1d (both NULL = not tracked).
+ *   bwd:  from gy [rows, cout] bf16 and d_affine [2][cout] (loss gradient wrt out_affine; with gamma): dx [rows, cin] bf16 (NULL = skip),
+ *         d_in_affine [2][cin] (NULL = skip), dw [cout, cin], dbias [cout] (NULL = skip), dgamma, dbeta [cout].
+ * ws: pps_rows_layer_ws_bytes(cin, cout) bytes of device scratch.  Deterministic. */
+int pps_rows_layer_supported(int cin, int cout);
+size_t pps_rows_layer_ws_bytes(int cin, int cout);
+int pps_rows_layer_fwd(const void* x, int64_t rows, int cin, const float* in_scale, const float* in_shift, int in_relu, const float* w,
+                       const float* bias, int cout, void* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                       float momentum, float eps, float* out_affine, float* save, void* ws, void* stream);
+int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t rows, int cin, int cout, const float* in_scale,
+                       const float* in_shift, int in_relu, const float* w, const float* gamma, const float* save, const float* d_affine,
+                       void* dx, float* d_in_affine, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

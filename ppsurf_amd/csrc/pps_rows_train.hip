@@ -1,0 +1,728 @@
+// Dense layers of the TRAINING step over point-major rows, with the BatchNorm + ReLU of the PREVIOUS layer applied while the input is
+// loaded and the batch statistics of THIS layer's output taken while it is stored (gfx950, bf16 storage, fp32 accumulation).
+//
+// replaces (reference, under autograd and bf16 autocast): every  conv -> bn -> relu -> conv  chain over rows of
+// source/base/nn.py (STN :162-190, PointNetfeat :323-336, MLP :376-417) and the fc -> relu -> fc chain of the interpolation head
+// (source/poco_model.py:400-410).  As separate ops one such layer is 5 streaming passes forward (GEMM out, statistics in, normalise
+// in + out, next GEMM in) and ~10 backward over tensors of up to 1.28 M x 256 elements; the layers are bandwidth-bound
+// (32-128 flop/byte), so the passes ARE the cost.  Here the normalised activation is never written:
+//
+//   forward    y[rows, cout] = act(x) W^T + b,   act(x) = relu?(x * scale_in + shift_in)        x, y bf16 RAW layer outputs
+//              statistics of the (rounded) y per channel -> scale_out = gamma * rstd, shift_out = beta - mean * scale_out, the
+//              running statistics updated like torch.nn.BatchNorm1d (momentum, unbiased variance)
+//   backward   G = gy + gS + 2 y gQ   (gS, gQ: what the loss gradient wrt scale_out / shift_out means for every row of y)
+//              dx = (G W) * [act mask] * scale_in,   d scale_in = sum_rows (G W) * mask * x,   d shift_in = sum_rows (G W) * mask
+//              dW = G^T act(x),  db = sum_rows G,    dgamma, dbeta
+//   = 2 passes forward (x in, y out) and 2 x (gy, y, x in) + dx out backward.
+//
+// Kernels (8 waves per workgroup, persistent over row tiles):
+//   rows_fwd_kernel   transposed product  D[cout][row] = W[cout][k] act(x)[row][k]  on v_mfma_f32_16x16x32_bf16: the B operand (8 input
+//                     channels of a row per lane) is loaded straight from global memory in fragment order, the whole W sits in LDS as
+//                     A fragments; a lane ends up with 16 CONSECUTIVE output channels of one row (the assignment of output channels to
+//                     MFMA rows is free, so it is chosen for 32-byte stores); per-lane statistics in registers, reduced in a fixed order
+//   rows_dx_kernel    same shape with the roles of the channel axes swapped, W^T fragments in LDS
+//   rows_dw_kernel    contraction over the ROWS: tiles of 32 rows of G and act(x) are written row-major into LDS and read back as MFMA
+//                     operands with ds_read_b64_tr_b16 (the LDS transpose read of gfx950, tools/ubench/tr_probe.hip); a workgroup keeps
+//                     the whole [cout, cin] product in registers over its slab of rows; slab partials are summed in a fixed order
+// Everything is deterministic (no floating-point atomics).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ppsurf_amd.h"
+
+#define PPS_OK 0
+#define PPS_ERR_ARG 1
+#define PPS_ERR_LAUNCH 2
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int NT = 512;                 // 8 waves
+constexpr int NWAVE = NT / 64;
+constexpr int MAXP = 256;               // most workgroups (= slab partials) of a launch
+
+__device__ __forceinline__ float lo16(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float hi16(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack2(float a, float b) {                     // round to nearest even: v_cvt_pk_bf16_f32
+    const f32x2 v = {a, b};
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    return *(const unsigned*)&h;
+}
+__device__ __forceinline__ bf16x8 as_frag(const u32x4& u) { return *(const bf16x8*)&u; }
+
+// output channel of MFMA row m = 4 g + r of 16-row block ob: lane (row n, g) then holds, over the 4 blocks of a group and r = 0..3,
+// the 16 consecutive channels 64 (ob >> 2) + 16 g + [4 (ob & 3) + r]
+__device__ __forceinline__ void block_row_of(int c, int& ob, int& m) {
+    const int rem = c & 63;
+    ob = 4 * (c >> 6) + ((rem >> 2) & 3);
+    m = 4 * (rem >> 4) + (rem & 3);
+}
+
+__device__ __forceinline__ float row16_sum(float v) {                            // over the 16 lanes that share lane >> 4
+#pragma unroll
+    for (int s = 1; s < 16; s <<= 1) v += __shfl_xor(v, s);
+    return v;
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward / input gradient: one kernel body.
+//   CK   channels contracted (fwd: cin, dx: cout)       CO  channels produced (fwd: cout, dx: cin)
+//   DX   false: forward -- B operand = act(x), epilogue = + bias, store y, statistics of y
+//        true : dx      -- B operand = G = gy + gS + gQ2 * y, epilogue = mask, * scale_in, store dx, sums for d scale_in / d shift_in
+// ---------------------------------------------------------------------------------------------------------------------
+struct LayerArgs {
+    const uint16_t* src;          // fwd: x [rows, CK]            dx: gy [rows, CK]
+    const uint16_t* src2;         // fwd: -                       dx: y [rows, CK] or NULL (no statistics on the output)
+    const float* pre_a;           // fwd: scale_in [CK] or NULL   dx: gS [CK] or NULL
+    const float* pre_b;           // fwd: shift_in [CK] or NULL   dx: 2 gQ [CK] or NULL
+    int pre_relu;                 // fwd: relu on the input
+    const float* w;               // [cout, cin] fp32 master weights
+    const float* bias;            // fwd: [CO] or NULL
+    const uint16_t* xin;          // dx: x [rows, CO] (mask, d scale_in) or NULL (identity input)
+    const float* in_scale;        // dx: [CO] or NULL
+    const float* in_shift;        // dx: [CO] or NULL
+    int in_relu;
+    uint16_t* dst;                // fwd: y [rows, CO]            dx: dx [rows, CO]
+    float* partials;              // [gridDim.x][2][CO] or NULL: fwd (sum y, sum y^2); dx (sum d * x, sum d)
+    int64_t rows;
+};
+
+// R = 16-row tiles a wave carries through the weights together: 2, except 1 in the input-gradient kernel with 128 channels per wave,
+// whose epilogue (x, scale, shift, two sums per channel) would not fit the registers next to two tiles of accumulators
+template <int CO, bool DX>
+constexpr int tiles_of() { return (DX && CO >= 128) ? 1 : 2; }
+
+template <int CK, int CO, bool DX>
+__global__ __launch_bounds__(NT, 1) void rows_layer_kernel(const LayerArgs a) {
+    constexpr int R = tiles_of<CO, DX>();
+    constexpr int KS = CK / 32;                     // k-steps of 32 channels
+    constexpr int KC = KS < 4 ? KS : 4;             // k-steps whose B fragments are in flight together
+    constexpr int NOB = CO / 16;                    // 16-channel output blocks
+    constexpr int HALVES = CO > 128 ? 2 : 1;        // a wave carries at most 128 output channels (registers)
+    constexpr int CW = CO / HALVES;
+    constexpr int NB = CW / 16;
+    constexpr int NG = NB / 4;                      // groups of 4 blocks = 64 channels = 16 per lane
+    constexpr int SLOTS = NWAVE / HALVES;           // row-tile groups in flight per workgroup
+
+    bf16x8* wimg = (bf16x8*)smem;                                   // [KS][NOB][64] A fragments
+    float* pa = (float*)(wimg + KS * NOB * 64);                     // [CK]
+    float* pb = pa + CK;                                            // [CK]
+    float* ea = pb + CK;                                            // [CO] fwd: bias        dx: scale_in
+    float* eb = ea + CO;                                            // [CO]                  dx: shift_in
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    const int half = wave % HALVES, slot = wave / HALVES;
+
+    // ---- weights -> A fragments.  fwd: A[m <-> cout][k <-> cin] = W[cout][cin];  dx: A[m <-> cin][k <-> cout] = W[cout][cin]
+    for (int i = threadIdx.x; i < CO * (CK / 8); i += NT) {
+        int co, kc;
+        if (!DX) { co = i / (CK / 8); kc = i % (CK / 8); } else { kc = i / CO; co = i % CO; }      // consecutive threads: consecutive fp32 words of W
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = DX ? a.w[(int64_t)(8 * kc + j) * CO + co] : a.w[(int64_t)co * CK + 8 * kc + j];
+        int ob, m;
+        block_row_of(co, ob, m);
+        u32x4 p = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        wimg[((kc >> 2) * NOB + ob) * 64 + (kc & 3) * 16 + m] = as_frag(p);
+    }
+    const bool has_pre = a.pre_a != nullptr;
+    for (int i = threadIdx.x; i < CK; i += NT) {
+        pa[i] = has_pre ? a.pre_a[i] : (DX ? 0.f : 1.f);
+        pb[i] = has_pre ? a.pre_b[i] : 0.f;
+    }
+    for (int i = threadIdx.x; i < CO; i += NT) {
+        if (!DX) { ea[i] = a.bias ? a.bias[i] : 0.f; eb[i] = 0.f; }
+        else { ea[i] = a.in_scale ? a.in_scale[i] : 1.f; eb[i] = a.in_shift ? a.in_shift[i] : 0.f; }
+    }
+    __syncthreads();
+
+    const float relu_floor = a.pre_relu ? 0.f : -INFINITY;
+    const bool dx_y = DX && a.src2 != nullptr;
+    const bool dx_x = DX && a.xin != nullptr;
+    const float in_floor = a.in_relu ? 0.f : -INFINITY;
+
+    float st0[NB][4], st1[NB][4];                    // per-lane partial sums (fwd: y, y^2;  dx: d * x, d)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st0[b][r] = 0.f; st1[b][r] = 0.f; }
+
+    const int64_t nunits = (a.rows + 16 * R - 1) / (16 * R);
+    for (int64_t u = (int64_t)blockIdx.x * SLOTS + slot; u < nunits; u += (int64_t)gridDim.x * SLOTS) {
+        const int64_t r0 = u * (16 * R);
+        if (KS * NB > 8) asm volatile("" ::: "memory");      // keeps the A fragments in LDS: hoisted out of this loop they would take KS * NB * 4 registers
+        f32x4 acc[R][NB];
+#pragma unroll
+        for (int t = 0; t < R; ++t)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int64_t rowc[R];
+        bool valid[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const int64_t row = r0 + 16 * t + n;
+            valid[t] = row < a.rows;
+            rowc[t] = valid[t] ? row : a.rows - 1;
+        }
+        // the B fragments of KC k-steps are requested together, then consumed; the other wave of the SIMD computes meanwhile
+#pragma unroll 1
+        for (int s0 = 0; s0 < KS; s0 += KC) {
+            u32x4 raw[KC][R], raw2[KC][R];
+#pragma unroll
+            for (int sc = 0; sc < KC; ++sc)
+#pragma unroll
+                for (int t = 0; t < R; ++t) {
+                    raw[sc][t] = *(const u32x4*)(a.src + rowc[t] * CK + 32 * (s0 + sc) + 8 * g);
+                    if (dx_y) raw2[sc][t] = *(const u32x4*)(a.src2 + rowc[t] * CK + 32 * (s0 + sc) + 8 * g);
+                }
+#pragma unroll
+            for (int sc = 0; sc < KC; ++sc) {
+                const int s = s0 + sc;
+                bf16x8 bfr[R];
+                if ((!DX && has_pre) || dx_y) {
+                    const f32x4 a0 = *(const f32x4*)(pa + 32 * s + 8 * g), a1 = *(const f32x4*)(pa + 32 * s + 8 * g + 4);
+                    const f32x4 b0 = *(const f32x4*)(pb + 32 * s + 8 * g), b1 = *(const f32x4*)(pb + 32 * s + 8 * g + 4);
+#pragma unroll
+                    for (int t = 0; t < R; ++t) {
+                        const u32x4 q = raw[sc][t];
+                        float e[8] = {lo16(q.x), hi16(q.x), lo16(q.y), hi16(q.y), lo16(q.z), hi16(q.z), lo16(q.w), hi16(q.w)};
+                        if (!DX) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                e[j] = fmaxf(__builtin_fmaf(e[j], a0[j], b0[j]), relu_floor);
+                                e[4 + j] = fmaxf(__builtin_fmaf(e[4 + j], a1[j], b1[j]), relu_floor);
+                            }
+                        } else {
+                            const u32x4 q2 = raw2[sc][t];
+                            const float y[8] = {lo16(q2.x), hi16(q2.x), lo16(q2.y), hi16(q2.y), lo16(q2.z), hi16(q2.z), lo16(q2.w), hi16(q2.w)};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                e[j] = __builtin_fmaf(y[j], b0[j], e[j] + a0[j]);
+                                e[4 + j] = __builtin_fmaf(y[4 + j], b1[j], e[4 + j] + a1[j]);
+                            }
+                        }
+                        const u32x4 p = {pack2(e[0], e[1]), pack2(e[2], e[3]), pack2(e[4], e[5]), pack2(e[6], e[7])};
+                        bfr[t] = as_frag(p);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < R; ++t) bfr[t] = as_frag(raw[sc][t]);
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const bf16x8 af = wimg[(s * NOB + half * NB + b) * 64 + lane];
+#pragma unroll
+                    for (int t = 0; t < R; ++t) acc[t][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[t], acc[t][b], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue: lane (row n, g) holds channels half*CW + 64 grp + 16 g + [0, 16)
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const int64_t row = rowc[t];
+            const float live = valid[t] ? 1.f : 0.f;
+#pragma unroll
+            for (int grp = 0; grp < NG; ++grp) {
+                const int c0 = half * CW + 64 * grp + 16 * g;
+                unsigned out[8];
+                if (!DX) {
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        const f32x4 bi = *(const f32x4*)(ea + c0 + 4 * o);
+                        const f32x4 v = acc[t][4 * grp + o] + bi;
+                        out[2 * o] = pack2(v[0], v[1]);
+                        out[2 * o + 1] = pack2(v[2], v[3]);
+                        if (a.partials) {
+                            const float y4[4] = {lo16(out[2 * o]), hi16(out[2 * o]), lo16(out[2 * o + 1]), hi16(out[2 * o + 1])};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                st0[4 * grp + o][r] += live * y4[r];
+                                st1[4 * grp + o][r] += live * y4[r] * y4[r];
+                            }
+                        }
+                    }
+                } else {
+                    u32x4 x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0};
+                    if (dx_x) {
+                        x0 = *(const u32x4*)(a.xin + row * CO + c0);
+                        x1 = *(const u32x4*)(a.xin + row * CO + c0 + 8);
+                    }
+                    const unsigned xw[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        const f32x4 sc = *(const f32x4*)(ea + c0 + 4 * o), sh = *(const f32x4*)(eb + c0 + 4 * o);
+                        const float x4[4] = {lo16(xw[2 * o]), hi16(xw[2 * o]), lo16(xw[2 * o + 1]), hi16(xw[2 * o + 1])};
+                        float d[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pre = __builtin_fmaf(x4[r], sc[r], sh[r]);
+                            d[r] = (!dx_x || pre > in_floor) ? acc[t][4 * grp + o][r] : 0.f;          // ReLU mask of the layer's input
+                            st0[4 * grp + o][r] += live * d[r] * x4[r];
+                            st1[4 * grp + o][r] += live * d[r];
+                            d[r] *= sc[r];
+                        }
+                        out[2 * o] = pack2(d[0], d[1]);
+                        out[2 * o + 1] = pack2(d[2], d[3]);
+                    }
+                }
+                if (valid[t]) {
+                    uint16_t* dstp = a.dst + row * CO + c0;
+                    *(u32x4*)dstp = u32x4{out[0], out[1], out[2], out[3]};
+                    *(u32x4*)(dstp + 8) = u32x4{out[4], out[5], out[6], out[7]};
+                }
+            }
+        }
+    }
+
+    // ---- per-channel sums of the workgroup, in a fixed order: lanes of a row group (shuffles), then the SLOTS waves of a half (LDS)
+    if (a.partials) {
+        __syncthreads();                              // the weight image is no longer needed: reuse it
+        float* red = (float*)smem;                    // [SLOTS][2][CO]
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s0 = row16_sum(st0[b][r]), s1 = row16_sum(st1[b][r]);
+                if (n == 0) {
+                    const int c = half * CW + 64 * (b >> 2) + 16 * g + 4 * (b & 3) + r;
+                    red[(slot * 2 + 0) * CO + c] = s0;
+                    red[(slot * 2 + 1) * CO + c] = s1;
+                }
+            }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * CO; i += NT) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q) s += red[q * 2 * CO + i];
+            a.partials[(int64_t)blockIdx.x * 2 * CO + i] = s;
+        }
+    }
+}
+
+template <int CK, int CO>
+constexpr size_t layer_lds() {
+    return (size_t)CK * CO * 2 + (size_t)(2 * CK + 2 * CO) * 4;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weight gradient: dW[cout][cin] = sum_rows G[row][cout] * act(x)[row][cin],  db[cout] = sum_rows G[row][cout]
+// ---------------------------------------------------------------------------------------------------------------------
+struct DwArgs {
+    const uint16_t* gy;           // [rows, CO]
+    const uint16_t* y;            // [rows, CO] or NULL
+    const float* gs;              // [CO] or NULL
+    const float* gq2;             // [CO] or NULL
+    const uint16_t* x;            // [rows, CI]
+    const float* in_scale;        // [CI] or NULL
+    const float* in_shift;
+    int in_relu;
+    float* dw_part;               // [gridDim.x][CO][CI]
+    float* db_part;               // [gridDim.x][CO]
+    int64_t rows;
+};
+
+__device__ __forceinline__ u32x2 lds_tr_read(const uint16_t* p) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((unsigned)(uintptr_t)p) : "memory");
+    return v;
+}
+// the compiler does not count the reads above: every fragment passes through a wait before its first use (the first one waits, the rest are free)
+__device__ __forceinline__ void lds_tr_wait(u32x2& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) : : "memory"); }
+
+template <int CI, int CO>
+__global__ __launch_bounds__(NT, 1) void rows_dw_kernel(const DwArgs a) {
+    constexpr int KR = 32;                          // rows per step = the contraction length of one MFMA
+    constexpr int PG = CO + 16, PA = CI + 16;       // LDS row pitch in elements: + 32 bytes keeps the transpose reads of a half-wave on 64 banks
+    constexpr int WM = 4, WN = 2;                   // waves along cout / cin
+    constexpr int MB = CO / 16 / WM, NBK = CI / 16 / WN;
+    constexpr int GCH = KR * CO / 8, ACH = KR * CI / 8;                     // 16-byte chunks of a tile
+    constexpr int GIT = (GCH + NT - 1) / NT, AIT = (ACH + NT - 1) / NT;
+
+    uint16_t* gimg = (uint16_t*)smem;                                       // [2][KR][PG]
+    uint16_t* aimg = gimg + 2 * KR * PG;                                    // [2][KR][PA]
+    float* prm = (float*)(aimg + 2 * KR * PA);                              // gs[CO], gq2[CO], scale[CI], shift[CI]
+    float* gs = prm, *gq2 = prm + CO, *isc = prm + 2 * CO, *ish = prm + 2 * CO + CI;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, kg = lane >> 4;
+    const int wm = wave % WM, wn = wave / WM;
+    const bool has_y = a.y != nullptr, has_aff = a.in_scale != nullptr;
+    for (int i = threadIdx.x; i < CO; i += NT) { gs[i] = has_y ? a.gs[i] : 0.f; gq2[i] = has_y ? a.gq2[i] : 0.f; }
+    for (int i = threadIdx.x; i < CI; i += NT) { isc[i] = has_aff ? a.in_scale[i] : 1.f; ish[i] = has_aff ? a.in_shift[i] : 0.f; }
+    __syncthreads();
+    const float in_floor = a.in_relu ? 0.f : -INFINITY;
+    const bool transform_x = has_aff || a.in_relu;
+
+    // slab of rows of this workgroup: whole steps of KR rows
+    const int64_t nsteps = (a.rows + KR - 1) / KR;
+    const int64_t per = (nsteps + gridDim.x - 1) / gridDim.x;
+    const int64_t s_begin = (int64_t)blockIdx.x * per, s_end = (s_begin + per < nsteps) ? s_begin + per : nsteps;
+
+    f32x4 acc[MB][NBK];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int k = 0; k < NBK; ++k) acc[m][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float db[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) db[j] = 0.f;
+
+    u32x4 rg[GIT], ry[GIT], rx[AIT];
+    auto fetch = [&](int64_t step) {
+        const int64_t r0 = step * KR;
+#pragma unroll
+        for (int it = 0; it < GIT; ++it) {
+            const int id = threadIdx.x + NT * it;
+            const int row = id / (CO / 8), ch = id % (CO / 8);
+            const int64_t rr = r0 + row;
+            const bool ok = id < GCH && rr < a.rows;
+            rg[it] = ok ? *(const u32x4*)(a.gy + rr * CO + 8 * ch) : u32x4{0, 0, 0, 0};
+            if (has_y) ry[it] = ok ? *(const u32x4*)(a.y + rr * CO + 8 * ch) : u32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int it = 0; it < AIT; ++it) {
+            const int id = threadIdx.x + NT * it;
+            const int row = id / (CI / 8), ch = id % (CI / 8);
+            const int64_t rr = r0 + row;
+            const bool ok = id < ACH && rr < a.rows;
+            rx[it] = ok ? *(const u32x4*)(a.x + rr * CI + 8 * ch) : u32x4{0, 0, 0, 0};
+        }
+    };
+    auto stage = [&](int buf, int64_t step) {
+        const int64_t r0 = step * KR;
+        uint16_t* gdst = gimg + buf * KR * PG;
+        uint16_t* adst = aimg + buf * KR * PA;
+#pragma unroll
+        for (int it = 0; it < GIT; ++it) {
+            const int id = threadIdx.x + NT * it;
+            if (id >= GCH) break;
+            const int row = id / (CO / 8), ch = id % (CO / 8);
+            const bool live = r0 + row < a.rows;
+            const u32x4 q = rg[it];
+            float e[8] = {lo16(q.x), hi16(q.x), lo16(q.y), hi16(q.y), lo16(q.z), hi16(q.z), lo16(q.w), hi16(q.w)};
+            u32x4 p = q;
+            if (has_y) {
+                const u32x4 q2 = ry[it];
+                const float yv[8] = {lo16(q2.x), hi16(q2.x), lo16(q2.y), hi16(q2.y), lo16(q2.z), hi16(q2.z), lo16(q2.w), hi16(q2.w)};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = live ? __builtin_fmaf(yv[j], gq2[8 * ch + j], e[j] + gs[8 * ch + j]) : 0.f;
+                p = u32x4{pack2(e[0], e[1]), pack2(e[2], e[3]), pack2(e[4], e[5]), pack2(e[6], e[7])};
+                e[0] = lo16(p.x); e[1] = hi16(p.x); e[2] = lo16(p.y); e[3] = hi16(p.y); e[4] = lo16(p.z); e[5] = hi16(p.z); e[6] = lo16(p.w); e[7] = hi16(p.w);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) db[j] += e[j];
+            *(u32x4*)(gdst + row * PG + 8 * ch) = p;
+        }
+#pragma unroll
+        for (int it = 0; it < AIT; ++it) {
+            const int id = threadIdx.x + NT * it;
+            if (id >= ACH) break;
+            const int row = id / (CI / 8), ch = id % (CI / 8);
+            const bool live = r0 + row < a.rows;
+            u32x4 p = rx[it];
+            if (transform_x) {
+                float e[8] = {lo16(p.x), hi16(p.x), lo16(p.y), hi16(p.y), lo16(p.z), hi16(p.z), lo16(p.w), hi16(p.w)};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = live ? fmaxf(__builtin_fmaf(e[j], isc[8 * ch + j], ish[8 * ch + j]), in_floor) : 0.f;
+                p = u32x4{pack2(e[0], e[1]), pack2(e[2], e[3]), pack2(e[4], e[5]), pack2(e[6], e[7])};
+            }
+            *(u32x4*)(adst + row * PA + 8 * ch) = p;
+        }
+    };
+
+    if (s_begin < s_end) fetch(s_begin);
+    for (int64_t step = s_begin; step < s_end; ++step) {
+        const int buf = (int)((step - s_begin) & 1);
+        stage(buf, step);
+        if (step + 1 < s_end) fetch(step + 1);                      // in flight during the products below
+        __syncthreads();                                            // also orders: the products of step - 1 (other buffer) precede the stage of step + 1
+        const uint16_t* gsrc = gimg + buf * KR * PG;
+        const uint16_t* asrc = aimg + buf * KR * PA;
+        // operand element j of lane (column i16, kg) = tile row (j < 4 ? 4 kg + j : 16 + 4 kg + j - 4): two transpose reads; lane i16 supplies
+        // the 8-byte piece (row 4 kg + (i16 >> 2), columns 4 (i16 & 3) ..) of the 16-column block and receives column i16
+        const int prow = 4 * kg + (i16 >> 2), pcol = 4 * (i16 & 3);
+        u32x2 af[MB][2], bf[NBK][2];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const uint16_t* p = gsrc + prow * PG + 16 * (wm * MB + m) + pcol;
+            af[m][0] = lds_tr_read(p);
+            af[m][1] = lds_tr_read(p + 16 * PG);
+        }
+#pragma unroll
+        for (int k = 0; k < NBK; ++k) {
+            const uint16_t* p = asrc + prow * PA + 16 * (wn * NBK + k) + pcol;
+            bf[k][0] = lds_tr_read(p);
+            bf[k][1] = lds_tr_read(p + 16 * PA);
+        }
+#pragma unroll
+        for (int m = 0; m < MB; ++m) { lds_tr_wait(af[m][0]); lds_tr_wait(af[m][1]); }
+#pragma unroll
+        for (int k = 0; k < NBK; ++k) { lds_tr_wait(bf[k][0]); lds_tr_wait(bf[k][1]); }
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const u32x4 am = {af[m][0].x, af[m][0].y, af[m][1].x, af[m][1].y};
+#pragma unroll
+            for (int k = 0; k < NBK; ++k) {
+                const u32x4 bk = {bf[k][0].x, bf[k][0].y, bf[k][1].x, bf[k][1].y};
+                acc[m][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(am), as_frag(bk), acc[m][k], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- slab partials: D row 4 g + r <-> cout, column i16 <-> cin
+    float* dwp = a.dw_part + (int64_t)blockIdx.x * CO * CI;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int k = 0; k < NBK; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dwp[(int64_t)(16 * (wm * MB + m) + 4 * kg + r) * CI + 16 * (wn * NBK + k) + i16] = acc[m][k][r];
+    if (a.db_part) {
+        // a thread always stages the same 8 channels (NT is a multiple of CO / 8): threads with equal chunk are summed in thread order
+        __syncthreads();
+        float* red = (float*)smem;                                   // [NT][8]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = db[j];
+        __syncthreads();
+        for (int c = threadIdx.x; c < CO; c += NT) {
+            const int ch = c >> 3, j = c & 7;
+            float s = 0.f;
+            for (int t = ch; t < NT && t < GCH; t += CO / 8) s += red[t * 8 + j];
+            a.db_part[(int64_t)blockIdx.x * CO + c] = s;
+        }
+    }
+}
+
+template <int CI, int CO>
+constexpr size_t dw_lds() {
+    return (size_t)2 * 32 * (CO + 16 + CI + 16) * 2 + (size_t)(2 * CO + 2 * CI) * 4;
+}
+
+// out[i] = sum_p part[p][i] in double, p ascending
+__global__ void sum_partials_kernel(const float* __restrict__ part, int np, int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int p = 0; p < np; ++p) s += (double)part[(int64_t)p * n + i];
+    out[i] = (float)s;
+}
+
+// BatchNorm parameters of the output from the slab partials (sum y, sum y^2): scale = gamma rstd, shift = beta - mean scale;
+// save = (mean, rstd); running statistics like torch.nn.BatchNorm1d (biased variance for the batch, unbiased for the running value)
+__global__ void bn_affine_kernel(const float* __restrict__ part, int np, int c, double rows, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                                 float eps, float* __restrict__ affine, float* __restrict__ save) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    double s = 0.0, q = 0.0;
+    for (int p = 0; p < np; ++p) {
+        s += (double)part[(int64_t)p * 2 * c + i];
+        q += (double)part[(int64_t)p * 2 * c + c + i];
+    }
+    const double mean = s / rows;
+    double var = q / rows - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double sc = (double)gamma[i] * rstd;
+    affine[i] = (float)sc;
+    affine[c + i] = (float)((double)beta[i] - mean * sc);
+    save[i] = (float)mean;
+    save[c + i] = (float)rstd;
+    if (running_mean && running_var) {
+        const double unbiased = rows > 1.0 ? var * rows / (rows - 1.0) : var;
+        running_mean[i] = (float)((1.0 - momentum) * (double)running_mean[i] + momentum * mean);
+        running_var[i] = (float)((1.0 - momentum) * (double)running_var[i] + momentum * unbiased);
+    }
+}
+
+// gradients wrt (scale, shift) of the output -> what every row of y receives (gS, 2 gQ) + dgamma, dbeta
+__global__ void bn_affine_bwd_kernel(const float* __restrict__ d_affine, const float* __restrict__ save, const float* __restrict__ gamma, int c,
+                                     double rows, float* __restrict__ gstat, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    const double ds = d_affine[i], dt = d_affine[c + i], mean = save[i], rstd = save[c + i], gm = gamma[i];
+    const double dsc = ds - mean * dt;                       // total gradient of scale = gamma * rstd (shift = beta - mean * scale)
+    dgamma[i] = (float)(rstd * dsc);
+    dbeta[i] = (float)dt;
+    const double drstd = gm * dsc;
+    const double dvar = -0.5 * rstd * rstd * rstd * drstd;
+    const double dmean = -dt * gm * rstd - 2.0 * mean * dvar;  // var = Q / rows - mean^2
+    gstat[i] = (float)(dmean / rows);
+    gstat[c + i] = (float)(2.0 * dvar / rows);
+}
+
+int g_cus = 0;
+int cu_count() {
+    if (g_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return g_cus;
+}
+int grid_for(int64_t units) {
+    int g = cu_count();
+    if (g > MAXP) g = MAXP;
+    return (int)(units < g ? (units > 0 ? units : 1) : g);
+}
+
+template <typename K>
+bool allow_lds(K kernel, size_t bytes) { return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess; }
+
+template <int CK, int CO, bool DX>
+int launch_layer(const LayerArgs& a, int grid, hipStream_t st) {
+    static bool ok = allow_lds(rows_layer_kernel<CK, CO, DX>, layer_lds<CK, CO>());
+    if (!ok) return PPS_ERR_LAUNCH;
+    constexpr size_t lds = layer_lds<CK, CO>();
+    hipLaunchKernelGGL((rows_layer_kernel<CK, CO, DX>), dim3(grid), dim3(NT), lds, st, a);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+template <int CI, int CO>
+int launch_dw(const DwArgs& a, int grid, hipStream_t st) {
+    static bool ok = allow_lds(rows_dw_kernel<CI, CO>, dw_lds<CI, CO>());
+    if (!ok) return PPS_ERR_LAUNCH;
+    constexpr size_t lds = dw_lds<CI, CO>();
+    hipLaunchKernelGGL((rows_dw_kernel<CI, CO>), dim3(grid), dim3(NT), lds, st, a);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+bool dim_ok(int c) { return c == 64 || c == 128 || c == 256; }
+
+#define PPS_DISPATCH(CI, CO, CALL)                                            \
+    do {                                                                      \
+        const int key_ = (CI) * 1000 + (CO);                                  \
+        switch (key_) {                                                       \
+            case 64064: { constexpr int I = 64, O = 64; CALL; } break;        \
+            case 64128: { constexpr int I = 64, O = 128; CALL; } break;       \
+            case 64256: { constexpr int I = 64, O = 256; CALL; } break;       \
+            case 128064: { constexpr int I = 128, O = 64; CALL; } break;      \
+            case 128128: { constexpr int I = 128, O = 128; CALL; } break;     \
+            case 128256: { constexpr int I = 128, O = 256; CALL; } break;     \
+            case 256064: { constexpr int I = 256, O = 64; CALL; } break;      \
+            case 256128: { constexpr int I = 256, O = 128; CALL; } break;     \
+            case 256256: { constexpr int I = 256, O = 256; CALL; } break;     \
+            default: return PPS_ERR_ARG;                                      \
+        }                                                                     \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int pps_rows_layer_supported(int cin, int cout) { return dim_ok(cin) && dim_ok(cout) ? 1 : 0; }
+
+/* scratch of one call: slab partials of the statistics / input-affine sums, of dW and of db */
+size_t pps_rows_layer_ws_bytes(int cin, int cout) {
+    if (!dim_ok(cin) || !dim_ok(cout)) return 0;
+    const size_t big = (size_t)(cin > cout ? cin : cout);
+    return (size_t)MAXP * (2 * big + (size_t)cin * cout + cout) * sizeof(float) + (size_t)2 * cout * sizeof(float);
+}
+
+int pps_rows_layer_fwd(const void* x, int64_t rows, int cin, const float* in_scale, const float* in_shift, int in_relu, const float* w,
+                       const float* bias, int cout, void* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                       float momentum, float eps, float* out_affine, float* save, void* ws, void* stream) {
+    if (rows < 1 || !dim_ok(cin) || !dim_ok(cout)) return PPS_ERR_ARG;
+    if (!x || !w || !y || !ws || ((in_scale == nullptr) != (in_shift == nullptr))) return PPS_ERR_ARG;
+    const bool bn = gamma != nullptr;
+    if (bn && (!beta || !out_affine || !save)) return PPS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid_for((rows + 31) / 32);
+    LayerArgs a{};
+    a.src = (const uint16_t*)x;
+    a.pre_a = in_scale;
+    a.pre_b = in_shift;
+    a.pre_relu = in_relu;
+    if (!in_scale && in_relu) return PPS_ERR_ARG;               // a bare ReLU is passed as scale 1, shift 0
+    a.w = w;
+    a.bias = bias;
+    a.dst = (uint16_t*)y;
+    a.partials = bn ? (float*)ws : nullptr;
+    a.rows = rows;
+    int rc = PPS_OK;
+    PPS_DISPATCH(cin, cout, rc = (launch_layer<I, O, false>(a, grid, st)));
+    if (rc != PPS_OK) return rc;
+    if (bn) {
+        hipLaunchKernelGGL(bn_affine_kernel, dim3((cout + 63) / 64), dim3(64), 0, st, (const float*)ws, grid, cout, (double)rows, gamma, beta,
+                           running_mean, running_var, momentum, eps, out_affine, save);
+        if (hipGetLastError() != hipSuccess) return PPS_ERR_LAUNCH;
+    }
+    return PPS_OK;
+}
+
+int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t rows, int cin, int cout, const float* in_scale,
+                       const float* in_shift, int in_relu, const float* w, const float* gamma, const float* save, const float* d_affine,
+                       void* dx, float* d_in_affine, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws, void* stream) {
+    if (rows < 1 || !dim_ok(cin) || !dim_ok(cout)) return PPS_ERR_ARG;
+    if (!x || !gy || !w || !ws || ((in_scale == nullptr) != (in_shift == nullptr))) return PPS_ERR_ARG;
+    if (!in_scale && in_relu) return PPS_ERR_ARG;
+    const bool bn = gamma != nullptr;
+    if (bn && (!y || !save || !d_affine || !dgamma || !dbeta)) return PPS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t big = (size_t)(cin > cout ? cin : cout);
+    float* part_aff = (float*)ws;                                       // [MAXP][2][big]
+    float* part_dw = part_aff + (size_t)MAXP * 2 * big;                 // [MAXP][cout][cin]
+    float* part_db = part_dw + (size_t)MAXP * cin * cout;               // [MAXP][cout]
+    float* gstat = part_db + (size_t)MAXP * cout;                       // [2][cout]
+    if (bn) {
+        hipLaunchKernelGGL(bn_affine_bwd_kernel, dim3((cout + 63) / 64), dim3(64), 0, st, d_affine, save, gamma, cout, (double)rows, gstat, dgamma,
+                           dbeta);
+        if (hipGetLastError() != hipSuccess) return PPS_ERR_LAUNCH;
+    }
+    int rc = PPS_OK;
+    if (dx) {
+        const int grid = grid_for((rows + 31) / 32);
+        LayerArgs a{};
+        a.src = (const uint16_t*)gy;
+        a.src2 = bn ? (const uint16_t*)y : nullptr;
+        a.pre_a = bn ? gstat : nullptr;
+        a.pre_b = bn ? gstat + cout : nullptr;
+        a.w = w;
+        a.xin = (in_scale || in_relu) ? (const uint16_t*)x : nullptr;
+        a.in_scale = in_scale;
+        a.in_shift = in_shift;
+        a.in_relu = in_relu;
+        a.dst = (uint16_t*)dx;
+        a.partials = d_in_affine ? part_aff : nullptr;
+        a.rows = rows;
+        PPS_DISPATCH(cin, cout, rc = (launch_layer<O, I, true>(a, grid, st)));
+        if (rc != PPS_OK) return rc;
+        if (d_in_affine) {
+            hipLaunchKernelGGL(sum_partials_kernel, dim3((2 * cin + 255) / 256), dim3(256), 0, st, (const float*)part_aff, grid, (int64_t)2 * cin,
+                               d_in_affine);
+            if (hipGetLastError() != hipSuccess) return PPS_ERR_LAUNCH;
+        }
+    }
+    if (dw) {
+        const int64_t nsteps = (rows + 31) / 32;
+        int grid = grid_for(nsteps);
+        const int64_t per = (nsteps + grid - 1) / grid;
+        grid = (int)((nsteps + per - 1) / per);                          // no empty slabs
+        DwArgs a{};
+        a.gy = (const uint16_t*)gy;
+        a.y = bn ? (const uint16_t*)y : nullptr;
+        a.gs = bn ? gstat : nullptr;
+        a.gq2 = bn ? gstat + cout : nullptr;
+        a.x = (const uint16_t*)x;
+        a.in_scale = in_scale;
+        a.in_shift = in_shift;
+        a.in_relu = in_relu;
+        a.dw_part = part_dw;
+        a.db_part = dbias ? part_db : nullptr;
+        a.rows = rows;
+        PPS_DISPATCH(cin, cout, rc = (launch_dw<I, O>(a, grid, st)));
+        if (rc != PPS_OK) return rc;
+        const int64_t nw = (int64_t)cin * cout;
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, (const float*)part_dw, grid, nw, dw);
+        if (dbias) hipLaunchKernelGGL(sum_partials_kernel, dim3((cout + 255) / 256), dim3(256), 0, st, (const float*)part_db, grid, (int64_t)cout, dbias);
+        if (hipGetLastError() != hipSuccess) return PPS_ERR_LAUNCH;
+    }
+    return PPS_OK;
+}
+
+}  // extern "C"

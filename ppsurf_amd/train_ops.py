@@ -271,6 +271,97 @@ class _AttnPool(torch.autograd.Function):
         return dqy, dh
 
 
+class Act:
+    """A layer output that is NOT stored in its activated form: `raw` [rows, C] bf16 plus the per-channel `affine` [2, C] (scale, shift;
+    None = identity) and `relu` that the consumer applies while loading -- act = relu?(raw * scale + shift)."""
+    __slots__ = ('raw', 'affine', 'relu')
+
+    def __init__(self, raw, affine=None, relu=False):
+        self.raw, self.affine, self.relu = raw, affine, relu
+
+    def materialize(self):
+        if self.affine is None:
+            return torch.relu(self.raw) if self.relu else self.raw
+        z = self.raw.float() * self.affine[0] + self.affine[1]
+        return (torch.relu(z) if self.relu else z).to(self.raw.dtype)
+
+
+class _RowsLayer(torch.autograd.Function):
+    """y = act(x) W^T + b over rows with the input's BatchNorm + ReLU applied on load and the output's batch statistics taken on store
+    (pps_rows_train.hip).  Returns (y bf16, out_affine [2, cout] or None)."""
+
+    @staticmethod
+    def forward(ctx, x, in_affine, in_relu, w, b, gamma, beta, running_mean, running_var, momentum, eps):
+        _need_cuda(x, w)
+        L = _lib.lib()
+        x = x.to(torch.bfloat16).contiguous()
+        rows, cin = x.shape
+        cout = w.shape[0]
+        w32 = w.detach().float().contiguous()
+        b32 = None if b is None else b.detach().float().contiguous()
+        aff = None if in_affine is None else in_affine.detach().float().contiguous()
+        bn = gamma is not None
+        g32 = gamma.detach().float().contiguous() if bn else None
+        be32 = beta.detach().float().contiguous() if bn else None
+        y = torch.empty((rows, cout), device=x.device, dtype=torch.bfloat16)
+        out_affine = torch.empty((2, cout), device=x.device, dtype=torch.float32) if bn else None
+        save = torch.empty((2, cout), device=x.device, dtype=torch.float32) if bn else None
+        ws = torch.empty((L.pps_rows_layer_ws_bytes(cin, cout),), device=x.device, dtype=torch.uint8)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        _lib.check(L.pps_rows_layer_fwd(x.data_ptr(), rows, cin, ptr(aff), None if aff is None else aff.data_ptr() + 4 * cin, int(bool(in_relu)),
+                                        w32.data_ptr(), ptr(b32), cout, y.data_ptr(), ptr(g32), ptr(be32), ptr(running_mean), ptr(running_var),
+                                        float(momentum or 0.0), float(eps or 0.0), ptr(out_affine), ptr(save), ws.data_ptr(), _stream()),
+                   'pps_rows_layer_fwd')
+        ctx.save_for_backward(x, aff, w32, g32, save, y)
+        ctx.meta = (bool(in_relu), b is not None, bn, w.dtype, None if b is None else b.dtype)
+        return y, out_affine
+
+    @staticmethod
+    def backward(ctx, gy, g_affine):
+        x, aff, w32, g32, save, y = ctx.saved_tensors
+        in_relu, has_b, bn, wdt, bdt = ctx.meta
+        L = _lib.lib()
+        rows, cin = x.shape
+        cout = w32.shape[0]
+        dev = x.device
+        gy = gy.to(torch.bfloat16).contiguous()
+        if bn:
+            g_affine = torch.zeros((2, cout), device=dev, dtype=torch.float32) if g_affine is None else g_affine.float().contiguous()
+        need_dx, need_daff = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and aff is not None
+        dx = torch.empty_like(x) if (need_dx or need_daff) else None
+        d_in = torch.empty((2, cin), device=dev, dtype=torch.float32) if need_daff else None
+        dw = torch.empty((cout, cin), device=dev, dtype=torch.float32)
+        db = torch.empty((cout,), device=dev, dtype=torch.float32) if has_b else None
+        dgamma = torch.empty((cout,), device=dev, dtype=torch.float32) if bn else None
+        dbeta = torch.empty((cout,), device=dev, dtype=torch.float32) if bn else None
+        ws = torch.empty((L.pps_rows_layer_ws_bytes(cin, cout),), device=dev, dtype=torch.uint8)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        _lib.check(L.pps_rows_layer_bwd(x.data_ptr(), y.data_ptr(), gy.data_ptr(), rows, cin, cout, ptr(aff),
+                                        None if aff is None else aff.data_ptr() + 4 * cin, int(in_relu), w32.data_ptr(), ptr(g32), ptr(save),
+                                        ptr(g_affine) if bn else None, ptr(dx), ptr(d_in), dw.data_ptr(), ptr(db), ptr(dgamma), ptr(dbeta),
+                                        ws.data_ptr(), _stream()), 'pps_rows_layer_bwd')
+        return (dx if need_dx else None, d_in, None, dw.to(wdt), None if db is None else db.to(bdt), dgamma, dbeta, None, None, None, None)
+
+
+def rows_layer_supported(rows, cin, cout):
+    return rows >= 1 and bool(_lib.lib().pps_rows_layer_supported(int(cin), int(cout)))
+
+
+def rows_layer(act, w, b, bn=None, relu=False):
+    """act: Act (input in its stored form); w [cout, cin], b [cout] or None; bn: BatchNorm1d holder whose batch statistics are taken on the
+    output (train mode), or None.  -> Act(raw output, affine of bn or None, relu)."""
+    in_aff = act.affine
+    if in_aff is None and act.relu:                      # a bare ReLU on the input: scale 1, shift 0
+        c = act.raw.shape[1]
+        in_aff = torch.cat([torch.ones((1, c), device=act.raw.device), torch.zeros((1, c), device=act.raw.device)])
+    act = Act(act.raw, in_aff, act.relu)
+    if bn is not None:
+        y, aff = _RowsLayer.apply(act.raw, act.affine, act.relu, w, b, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+    else:
+        y, aff = _RowsLayer.apply(act.raw, act.affine, act.relu, w, b, None, None, None, None, None, None)
+    return Act(y, aff, relu)
+
+
 def attn_pool_supported(k, heads, c):
     return 1 <= k <= 64 and 1 <= heads <= 64 and c <= 256
 
