@@ -311,6 +311,17 @@ int pps_attn_pool_bwd(const void* qy, const void* h, const void* dpooled, int64_
  *   bwd:  from gy [rows, cout] bf16 and d_affine [2][cout] (loss gradient wrt out_affine; with gamma): dx [rows, cin] bf16 (NULL = skip),
  *         d_in_affine [2][cin] (NULL = skip), dw [cout, cin], dbias [cout] (NULL = skip), dgamma, dbeta [cout].
  * ws: pps_rows_layer_ws_bytes(cin, cout) bytes of device scratch.  Deterministic. */
+/* Single-head attention pooling over the rows of a group with the logit computed inside (PointNet's AttentionPoco, source/base/nn.py:84-96, applied to
+ * the raw conv3 output: the logit is linear in it and softmax ignores the constant): a = softmax_j(h[q,j,:] . v), pooled[q,:] = sum_j a_j h[q,j,:].
+ * h [q, k, 256] bfloat16, k <= 64, v [256] fp32, pooled [q, 256] fp32.  Backward: dh [q, k, 256] bfloat16; dv_part [pps_patch_attn_partials(q)][256],
+ * to be summed over its first axis. */
+int pps_patch_attn_partials(int64_t q);
+int pps_patch_attn_fwd(const void* h, const float* v, int64_t q, int k, int c, float* pooled, void* stream);
+int pps_patch_attn_bwd(const void* h, const float* v, const float* dpooled, int64_t q, int k, int c, void* dh, float* dv_part, void* stream);
+
+/* Extrema over the p rows of every group of x [groups, p, c] (bfloat16, c % 4 == 0): mx, mn [groups, c] fp32 and the row of each
+ * (first occurrence).  The max-pool over the patch points (source/base/nn.py:181) of relu(bn(x)) follows from them without the activated tensor. */
+int pps_rows_extrema_bf16(const void* x, int64_t groups, int p, int c, float* mx, float* mn, int* amx, int* amn, void* stream);
 int pps_rows_layer_supported(int cin, int cout);
 size_t pps_rows_layer_ws_bytes(int cin, int cout);
 int pps_rows_layer_fwd(const void* x, int64_t rows, int cin, const float* in_scale, const float* in_shift, int in_relu, const float* w,

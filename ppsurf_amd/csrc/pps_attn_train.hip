@@ -181,6 +181,120 @@ __global__ __launch_bounds__(AT_NT) void attn_pool_bwd_kernel(const T* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Single-head attention pooling over the k <= 64 rows of a group with the LOGIT computed inside (PointNet's AttentionPoco,
+// source/base/nn.py:84-96, on the raw output of conv3: the logit fc_query(bn3(y)) = y . (w_q * scale) + const and softmax ignores the constant):
+//     a = softmax_j(h_j . v),   pooled = sum_j a_j h_j            h [Q, k, 256] bf16, v [256] fp32, pooled [Q, 256] fp32
+// One wave per group, 4 channels per lane; the per-row dot products of a group are turned into one value per lane by recursive halving.
+// Backward: dh_j = a_j dP + dl_j v,  dl_j = a_j (dP . h_j - sum_i a_i dP . h_i),  dv = sum_{q,j} dl_j h_j  (per-wave partials, summed by the caller)
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PA_K = 64;
+constexpr int PA_WAVES = 4;
+constexpr int PA_MAXBLK = 512;
+
+__device__ __forceinline__ float4 unpack4(const uint2 u) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
+    return v;
+}
+
+// 64 per-lane partial sums (one per row) -> lane l holds the total of row l: recursive halving, 63 shuffles instead of 64 x 6
+__device__ __forceinline__ float rows_to_lanes(float (&p)[PA_K], int lane) {
+#pragma unroll
+    for (int half = 32; half >= 1; half >>= 1) {
+        const bool up = (lane & half) != 0;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+            const float send = up ? p[i] : p[i + half];
+            const float keep = up ? p[i + half] : p[i];
+            p[i] = keep + __shfl_xor(send, half);
+        }
+    }
+    return p[0];
+}
+
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+__device__ __forceinline__ float4 row4(const uint16_t* __restrict__ src, int j, int lane) { return unpack4(*(const uint2*)(src + (int64_t)j * 256 + 4 * lane)); }
+
+// lane j: softmax weight of row j (0 beyond k).  The rows are read here for the logits and AGAIN by the caller for the pooling (the
+// 25 KB of a group come from L2 the second time): keeping them in registers costs more in occupancy than the second read.
+__device__ __forceinline__ float patch_softmax(const uint16_t* __restrict__ src, int k, const float4 v4, int lane) {
+    float p[PA_K];
+#pragma unroll
+    for (int j = 0; j < PA_K; ++j) {                               // no branch around the loads: rows beyond k re-read the last row and are zeroed
+        const float d = dot4(row4(src, j < k ? j : k - 1, lane), v4);
+        p[j] = j < k ? d : 0.f;
+    }
+    const float d = rows_to_lanes(p, lane);
+    const float logit = lane < k ? d : -INFINITY;
+    const float m = wave_max(logit);
+    const float e = lane < k ? __expf(logit - m) : 0.f;
+    return e / wave_sum(e);
+}
+
+__global__ __launch_bounds__(PA_WAVES * 64, 2) void patch_attn_fwd_kernel(const uint16_t* __restrict__ h, const float* __restrict__ v, int64_t Q, int k,
+                                                                         float* __restrict__ pooled) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float4 v4 = *(const float4*)(v + 4 * lane);
+    for (int64_t q = (int64_t)blockIdx.x * PA_WAVES + wave; q < Q; q += (int64_t)gridDim.x * PA_WAVES) {
+        const uint16_t* src = h + q * (int64_t)k * 256;
+        const float a = patch_softmax(src, k, v4, lane);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int j = 0; j < k; ++j) {
+            const float aj = __shfl(a, j);
+            const float4 x = row4(src, j, lane);
+            acc.x += aj * x.x; acc.y += aj * x.y; acc.z += aj * x.z; acc.w += aj * x.w;
+        }
+        *(float4*)(pooled + q * 256 + 4 * lane) = acc;
+    }
+}
+
+__global__ __launch_bounds__(PA_WAVES * 64, 2) void patch_attn_bwd_kernel(const uint16_t* __restrict__ h, const float* __restrict__ v,
+                                                                         const float* __restrict__ dpooled, int64_t Q, int k, uint16_t* __restrict__ dh,
+                                                                         float* __restrict__ dv_part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float4 v4 = *(const float4*)(v + 4 * lane);
+    float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t q = (int64_t)blockIdx.x * PA_WAVES + wave; q < Q; q += (int64_t)gridDim.x * PA_WAVES) {
+        const uint16_t* src = h + q * (int64_t)k * 256;
+        const float4 dp = *(const float4*)(dpooled + q * 256 + 4 * lane);
+        float p[PA_K], pt[PA_K];
+#pragma unroll
+        for (int j = 0; j < PA_K; ++j) {
+            const float4 x = row4(src, j < k ? j : k - 1, lane);      // no branch around the loads
+            p[j] = j < k ? dot4(x, v4) : 0.f;
+            pt[j] = j < k ? dot4(x, dp) : 0.f;
+        }
+        const float d = rows_to_lanes(p, lane);
+        const float t = rows_to_lanes(pt, lane);                 // lane j: dP . h_j
+        const float logit = lane < k ? d : -INFINITY;
+        const float m = wave_max(logit);
+        const float e = lane < k ? __expf(logit - m) : 0.f;
+        const float a = e / wave_sum(e);
+        const float tbar = wave_sum(a * t);
+        const float dl = a * (t - tbar);
+        uint16_t* dst = dh + q * (int64_t)k * 256 + 4 * lane;
+#pragma unroll 8
+        for (int j = 0; j < k; ++j) {
+            const float aj = __shfl(a, j), dj = __shfl(dl, j);
+            const float4 x = row4(src, j, lane);
+            st4(dst, (int64_t)j * 256, make_float4(aj * dp.x + dj * v4.x, aj * dp.y + dj * v4.y, aj * dp.z + dj * v4.z, aj * dp.w + dj * v4.w));
+            dv.x += dj * x.x; dv.y += dj * x.y; dv.z += dj * x.z; dv.w += dj * x.w;
+        }
+    }
+    *(float4*)(dv_part + ((int64_t)blockIdx.x * PA_WAVES + wave) * 256 + 4 * lane) = dv;
+}
+
+int patch_grid(int64_t q) {
+    const int64_t blocks = (q + PA_WAVES - 1) / PA_WAVES;
+    return (int)(blocks < PA_MAXBLK ? blocks : PA_MAXBLK);
+}
+
 int grid_for(int64_t q) {
     const int64_t cap = 256 * 16;
     return (int)(q < cap ? q : cap);
@@ -216,6 +330,28 @@ int pps_attn_pool_bwd(const void* qy, const void* h, const void* dpooled, int64_
     else
         hipLaunchKernelGGL(attn_pool_bwd_kernel<float>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const float*)qy, (const float*)h,
                            (const float*)dpooled, q, k, heads, c, (float*)dqy, (float*)dh);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+/* Single-head attention pooling with the logit computed inside: a = softmax_j(h[q,j,:] . v), pooled[q,:] = sum_j a_j h[q,j,:]
+ * (h [q, k, 256] bfloat16, k <= 64, v [256], pooled [q, 256] fp32).  Backward: dh [q, k, 256] bfloat16 and dv_part
+ * [pps_patch_attn_partials(q)][256] whose sum over the first axis is dv. */
+int pps_patch_attn_partials(int64_t q) { return q > 0 ? patch_grid(q) * PA_WAVES : 0; }
+
+int pps_patch_attn_fwd(const void* h, const float* v, int64_t q, int k, int c, float* pooled, void* stream) {
+    if (q < 0 || k < 1 || k > PA_K || c != 256) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    if (!h || !v || !pooled) return PPS_ERR_ARG;
+    hipLaunchKernelGGL(patch_attn_fwd_kernel, dim3(patch_grid(q)), dim3(PA_WAVES * 64), 0, (hipStream_t)stream, (const uint16_t*)h, v, q, k, pooled);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+int pps_patch_attn_bwd(const void* h, const float* v, const float* dpooled, int64_t q, int k, int c, void* dh, float* dv_part, void* stream) {
+    if (q < 0 || k < 1 || k > PA_K || c != 256) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    if (!h || !v || !dpooled || !dh || !dv_part) return PPS_ERR_ARG;
+    hipLaunchKernelGGL(patch_attn_bwd_kernel, dim3(patch_grid(q)), dim3(PA_WAVES * 64), 0, (hipStream_t)stream, (const uint16_t*)h, v, dpooled, q, k,
+                       (uint16_t*)dh, dv_part);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 

@@ -503,27 +503,58 @@ constexpr size_t dw_lds() {
     return (size_t)2 * 32 * (CO + 16 + CI + 16) * 2 + (size_t)(2 * CO + 2 * CI) * 4;
 }
 
-// out[i] = sum_p part[p][i] in double, p ascending
-__global__ void sum_partials_kernel(const float* __restrict__ part, int np, int64_t n, float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// out[i] = sum_p part[p][i]: SL threads share an element (p = slice, slice + SL, ... in double), their sums are added in slice order
+template <int SL>
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int np, int64_t n, float* __restrict__ out) {
+    constexpr int E = 256 / SL;
+    __shared__ double red[SL][E];
+    const int e = threadIdx.x % E, sl = threadIdx.x / E;
+    const int64_t i = (int64_t)blockIdx.x * E + e;
     double s = 0.0;
-    for (int p = 0; p < np; ++p) s += (double)part[(int64_t)p * n + i];
-    out[i] = (float)s;
+    if (i < n) {
+#pragma unroll 8
+        for (int p = sl; p < np; p += SL) s += (double)part[(int64_t)p * n + i];
+    }
+    red[sl][e] = s;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < SL; ++q) t += red[q][e];
+        out[i] = (float)t;
+    }
+}
+
+void launch_sum_partials(const float* part, int np, int64_t n, float* out, hipStream_t st) {
+    if (n <= 4096) hipLaunchKernelGGL(sum_partials_kernel<16>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, np, n, out);
+    else hipLaunchKernelGGL(sum_partials_kernel<4>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, part, np, n, out);
 }
 
 // BatchNorm parameters of the output from the slab partials (sum y, sum y^2): scale = gamma rstd, shift = beta - mean scale;
-// save = (mean, rstd); running statistics like torch.nn.BatchNorm1d (biased variance for the batch, unbiased for the running value)
-__global__ void bn_affine_kernel(const float* __restrict__ part, int np, int c, double rows, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
-                                 float eps, float* __restrict__ affine, float* __restrict__ save) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c) return;
+// save = (mean, rstd); running statistics like torch.nn.BatchNorm1d (biased variance for the batch, unbiased for the running value).
+// 16 channels per workgroup, 16 threads per channel over the partials.
+__global__ __launch_bounds__(256) void bn_affine_kernel(const float* __restrict__ part, int np, int c, double rows, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                       float* __restrict__ running_var, float momentum, float eps, float* __restrict__ affine,
+                                                       float* __restrict__ save) {
+    __shared__ double red[2][16][16];
+    const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + e;
     double s = 0.0, q = 0.0;
-    for (int p = 0; p < np; ++p) {
-        s += (double)part[(int64_t)p * 2 * c + i];
-        q += (double)part[(int64_t)p * 2 * c + c + i];
+    if (i < c) {
+#pragma unroll 4
+        for (int p = sl; p < np; p += 16) {
+            s += (double)part[(int64_t)p * 2 * c + i];
+            q += (double)part[(int64_t)p * 2 * c + c + i];
+        }
     }
+    red[0][sl][e] = s;
+    red[1][sl][e] = q;
+    __syncthreads();
+    if (sl != 0 || i >= c) return;
+    s = 0.0; q = 0.0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { s += red[0][t][e]; q += red[1][t][e]; }
     const double mean = s / rows;
     double var = q / rows - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -554,6 +585,34 @@ __global__ void bn_affine_bwd_kernel(const float* __restrict__ d_affine, const f
     const double dmean = -dt * gm * rstd - 2.0 * mean * dvar;  // var = Q / rows - mean^2
     gstat[i] = (float)(dmean / rows);
     gstat[c + i] = (float)(2.0 * dvar / rows);
+}
+
+// per (group, channel) extrema of raw rows: x [groups, p, c] bf16 -> mx, mn [groups, c] fp32 and the row (0..p-1) of each (first occurrence).
+// A monotone per-channel activation commutes with the extremum: max_p relu(x s + t) = relu(s * (s >= 0 ? max_p x : min_p x) + t), so the
+// max-pool over the patch (source/base/nn.py:181) needs only these, not the activated tensor.  One wave per group, 4 channels per lane.
+__global__ __launch_bounds__(256) void rows_extrema_kernel(const uint16_t* __restrict__ x, int64_t groups, int p, int c, float* __restrict__ mx,
+                                                          float* __restrict__ mn, int* __restrict__ amx, int* __restrict__ amn) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < groups; q += (int64_t)gridDim.x * 4) {
+        for (int c0 = 4 * lane; c0 < c; c0 += 256) {
+            float hi[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, lo[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+            int ihi[4] = {0, 0, 0, 0}, ilo[4] = {0, 0, 0, 0};
+            const uint16_t* src = x + q * (int64_t)p * c + c0;
+            for (int j = 0; j < p; ++j) {
+                const u32x2 u = *(const u32x2*)(src + (int64_t)j * c);
+                const float v[4] = {lo16(u.x), hi16(u.x), lo16(u.y), hi16(u.y)};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (v[r] > hi[r]) { hi[r] = v[r]; ihi[r] = j; }
+                    if (v[r] < lo[r]) { lo[r] = v[r]; ilo[r] = j; }
+                }
+            }
+            *(f32x4*)(mx + q * c + c0) = f32x4{hi[0], hi[1], hi[2], hi[3]};
+            *(f32x4*)(mn + q * c + c0) = f32x4{lo[0], lo[1], lo[2], lo[3]};
+            *(int4*)(amx + q * c + c0) = make_int4(ihi[0], ihi[1], ihi[2], ihi[3]);
+            *(int4*)(amn + q * c + c0) = make_int4(ilo[0], ilo[1], ilo[2], ilo[3]);
+        }
+    }
 }
 
 int g_cus = 0;
@@ -624,6 +683,16 @@ size_t pps_rows_layer_ws_bytes(int cin, int cout) {
     return (size_t)MAXP * (2 * big + (size_t)cin * cout + cout) * sizeof(float) + (size_t)2 * cout * sizeof(float);
 }
 
+int pps_rows_extrema_bf16(const void* x, int64_t groups, int p, int c, float* mx, float* mn, int* amx, int* amn, void* stream) {
+    if (groups < 0 || p < 1 || c < 4 || (c & 3)) return PPS_ERR_ARG;
+    if (groups == 0) return PPS_OK;
+    if (!x || !mx || !mn || !amx || !amn) return PPS_ERR_ARG;
+    const int64_t blocks = (groups + 3) / 4;
+    const int grid = (int)(blocks < 8 * (int64_t)cu_count() ? blocks : 8 * (int64_t)cu_count());
+    hipLaunchKernelGGL(rows_extrema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, groups, p, c, mx, mn, amx, amn);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
 int pps_rows_layer_fwd(const void* x, int64_t rows, int cin, const float* in_scale, const float* in_shift, int in_relu, const float* w,
                        const float* bias, int cout, void* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
                        float momentum, float eps, float* out_affine, float* save, void* ws, void* stream) {
@@ -648,7 +717,7 @@ int pps_rows_layer_fwd(const void* x, int64_t rows, int cin, const float* in_sca
     PPS_DISPATCH(cin, cout, rc = (launch_layer<I, O, false>(a, grid, st)));
     if (rc != PPS_OK) return rc;
     if (bn) {
-        hipLaunchKernelGGL(bn_affine_kernel, dim3((cout + 63) / 64), dim3(64), 0, st, (const float*)ws, grid, cout, (double)rows, gamma, beta,
+        hipLaunchKernelGGL(bn_affine_kernel, dim3((cout + 15) / 16), dim3(256), 0, st, (const float*)ws, grid, cout, (double)rows, gamma, beta,
                            running_mean, running_var, momentum, eps, out_affine, save);
         if (hipGetLastError() != hipSuccess) return PPS_ERR_LAUNCH;
     }
@@ -693,8 +762,7 @@ int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t row
         PPS_DISPATCH(cin, cout, rc = (launch_layer<O, I, true>(a, grid, st)));
         if (rc != PPS_OK) return rc;
         if (d_in_affine) {
-            hipLaunchKernelGGL(sum_partials_kernel, dim3((2 * cin + 255) / 256), dim3(256), 0, st, (const float*)part_aff, grid, (int64_t)2 * cin,
-                               d_in_affine);
+            launch_sum_partials(part_aff, grid, (int64_t)2 * cin, d_in_affine, st);
             if (hipGetLastError() != hipSuccess) return PPS_ERR_LAUNCH;
         }
     }
@@ -718,8 +786,8 @@ int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t row
         PPS_DISPATCH(cin, cout, rc = (launch_dw<I, O>(a, grid, st)));
         if (rc != PPS_OK) return rc;
         const int64_t nw = (int64_t)cin * cout;
-        hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, (const float*)part_dw, grid, nw, dw);
-        if (dbias) hipLaunchKernelGGL(sum_partials_kernel, dim3((cout + 255) / 256), dim3(256), 0, st, (const float*)part_db, grid, (int64_t)cout, dbias);
+        launch_sum_partials(part_dw, grid, nw, dw, st);
+        if (dbias) launch_sum_partials(part_db, grid, (int64_t)cout, dbias, st);
         if (hipGetLastError() != hipSuccess) return PPS_ERR_LAUNCH;
     }
     return PPS_OK;

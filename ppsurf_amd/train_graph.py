@@ -264,9 +264,65 @@ def stn(t, h, nq, p):
     return z.view(nq, d, d)
 
 
+def fused_rows_ok(x, *bns):
+    """The fused row layers (train_ops.rows_layer: bf16 storage, BatchNorm statistics of train()) apply: device tensor, bf16 autocast, every
+    BatchNorm in train() with a momentum."""
+    return (x.is_cuda and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+            and all(b.training and b.track_running_stats and b.momentum is not None for b in bns))
+
+
+def _layer(act, conv, bn, relu):
+    """conv (1x1 / Linear holder) -> bn (train() statistics) on a stored activation, as ONE op: train_ops.Act in, Act out."""
+    if bn is not None and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return train_ops.rows_layer(act, _w2d(conv), conv.bias, bn, relu)
+
+
+def _stn_fused(t, act, nq, p):
+    """stn() on a stored activation: the three row layers and the max over the patch never write an activated [nq*p, C] tensor."""
+    d = t.dim
+    z = _layer(act, t.conv1, t.bn1, True)
+    z = _layer(z, t.conv2, t.bn2, True)
+    z = _layer(z, t.conv3, t.bn3, True)
+    z = train_ops.act_max(z, nq, p)
+    z = batch_norm(t.bn4, dense(t.fc1, z), relu=True)
+    z = batch_norm(t.bn5, dense(t.fc2, z), relu=True)
+    z = dense(t.fc3, z) + torch.eye(d, dtype=z.dtype, device=z.device).reshape(1, d * d)
+    return z.view(nq, d, d)
+
+
+def _pointnet_fused(pn, patches):
+    """pointnet() with the 64..256-channel row layers as fused ops (pps_rows_train.hip): per layer the raw output is written once and read
+    by its consumers, which apply BatchNorm + ReLU on load."""
+    nq, p, _ = patches.shape
+    h = batch_norm(pn.bn0a, dense(pn.conv0a, patches.reshape(nq * p, 3)), relu=True)            # 3 input channels: not an MFMA shape
+    l0b = _layer(train_ops.Act(h), pn.conv0b, pn.bn0b, True)
+    trans2 = _stn_fused(pn.stn2, l0b, nq, p)
+    h = torch.bmm(l0b.materialize().view(nq, p, -1), trans2.transpose(1, 2).to(torch.bfloat16)).reshape(nq * p, -1)
+    z = _layer(train_ops.Act(h), pn.conv1, pn.bn1, True)
+    z = _layer(z, pn.conv2, pn.bn2, True)
+    z = _layer(z, pn.conv3, pn.bn3, False)
+    # AttentionPoco (nn.py:84-96) on h = raw * scale + shift (no ReLU after bn3): the logit is linear in raw, and the pooled row of h is the
+    # affine image of the pooled raw row because the weights of a patch sum to 1
+    scale, shift = z.affine[0], z.affine[1]
+    wq = _w2d(pn.att.fc_query).float()
+    # (softmax ignores the constant w_q . shift + b_q; it stays in the graph with weight 0 so that fc_query.bias gets its zero gradient, not None)
+    const = (wq * shift).sum() + pn.att.fc_query.bias.float().sum()
+    pooled = train_ops.patch_attn(z.raw.view(nq, p, -1), (wq * scale).reshape(-1))
+    pooled = (pooled * scale + shift + 0.0 * const).to(torch.bfloat16)
+    return dense(pn.att.fc_value, pooled), trans2
+
+
+FUSED_ROWS = True            # False: every row layer through the separate ops (library GEMM + fused BatchNorm op), e.g. to compare
+
+
 def pointnet(pn, patches):
     """patches [Q', P, 3] -> (feat [Q', C], trans2 [Q', 64, 64])."""
     nq, p, _ = patches.shape
+    t = pn.stn2
+    if (FUSED_ROWS and fused_rows_ok(patches, pn.bn0a, pn.bn0b, pn.bn1, pn.bn2, pn.bn3, t.bn1, t.bn2, t.bn3)
+            and train_ops.patch_attn_supported(p, _w2d(pn.conv3).shape[0])):
+        return _pointnet_fused(pn, patches)
     h = batch_norm(pn.bn0a, dense(pn.conv0a, patches.reshape(nq * p, 3)), relu=True)
     h = batch_norm(pn.bn0b, dense(pn.conv0b, h), relu=True)
     trans2 = stn(pn.stn2, h, nq, p)

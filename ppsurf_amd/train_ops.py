@@ -343,6 +343,92 @@ class _RowsLayer(torch.autograd.Function):
         return (dx if need_dx else None, d_in, None, dw.to(wdt), None if db is None else db.to(bdt), dgamma, dbeta, None, None, None, None)
 
 
+class _PatchAttn(torch.autograd.Function):
+    """pooled[q] = sum_j softmax_j(h[q,j] . v) h[q,j] over the k <= 64 rows of every group, h [Q, k, 256] bf16 -> [Q, 256] fp32: logits, softmax
+    and pooling in one kernel each way, h read once (pps_attn_train.hip)."""
+
+    @staticmethod
+    def forward(ctx, h, v):
+        _need_cuda(h, v)
+        h = h.to(torch.bfloat16).contiguous()
+        v32 = v.detach().float().contiguous()
+        q, k, c = h.shape
+        pooled = torch.empty((q, c), device=h.device, dtype=torch.float32)
+        _lib.check(_lib.lib().pps_patch_attn_fwd(h.data_ptr(), v32.data_ptr(), q, k, c, pooled.data_ptr(), _stream()), 'pps_patch_attn_fwd')
+        ctx.save_for_backward(h, v32)
+        ctx.vdtype = v.dtype
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        h, v32 = ctx.saved_tensors
+        q, k, c = h.shape
+        L = _lib.lib()
+        dpooled = dpooled.float().contiguous()
+        dh = torch.empty_like(h)
+        part = torch.empty((L.pps_patch_attn_partials(q), c), device=h.device, dtype=torch.float32)
+        _lib.check(L.pps_patch_attn_bwd(h.data_ptr(), v32.data_ptr(), dpooled.data_ptr(), q, k, c, dh.data_ptr(), part.data_ptr(), _stream()),
+                   'pps_patch_attn_bwd')
+        return dh, part.sum(0).to(ctx.vdtype)
+
+
+def patch_attn_supported(k, c):
+    return 1 <= k <= 64 and c == 256
+
+
+def patch_attn(h, v):
+    return _PatchAttn.apply(h, v)
+
+
+class _ActMax(torch.autograd.Function):
+    """max over the p rows of every group of act(raw) = relu?(raw * scale + shift) WITHOUT the activated tensor: the activation is monotone
+    per channel, so the extremum of the raw rows (max where scale >= 0, min otherwise) is activated instead (pps_rows_extrema_bf16)."""
+
+    @staticmethod
+    def forward(ctx, raw, affine, relu, groups, p):
+        _need_cuda(raw)
+        raw = raw.to(torch.bfloat16).contiguous()
+        c = raw.shape[1]
+        dev = raw.device
+        mx, mn = torch.empty((groups, c), device=dev), torch.empty((groups, c), device=dev)
+        amx, amn = torch.empty((groups, c), device=dev, dtype=torch.int32), torch.empty((groups, c), device=dev, dtype=torch.int32)
+        _lib.check(_lib.lib().pps_rows_extrema_bf16(raw.data_ptr(), groups, p, c, mx.data_ptr(), mn.data_ptr(), amx.data_ptr(), amn.data_ptr(),
+                                                    _stream()), 'pps_rows_extrema_bf16')
+        if affine is None:
+            ext, arg, out = mx, amx, mx
+            scale = None
+        else:
+            scale, shift = affine[0].float(), affine[1].float()
+            up = scale >= 0
+            ext, arg = torch.where(up, mx, mn), torch.where(up, amx, amn)
+            out = ext * scale + shift
+        live = None
+        if relu:
+            live = out > 0
+            out = torch.relu(out)
+        ctx.save_for_backward(ext, arg, scale, live)
+        ctx.meta = (groups, p, c, affine is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ext, arg, scale, live = ctx.saved_tensors
+        groups, p, c, has_aff = ctx.meta
+        d = dout.float()
+        if live is not None:
+            d = d * live
+        daff = torch.stack([(d * ext).sum(0), d.sum(0)]) if has_aff and ctx.needs_input_grad[1] else None
+        dval = d * scale if has_aff else d
+        draw = torch.zeros((groups, p, c), device=dout.device, dtype=torch.bfloat16)
+        draw.scatter_(1, arg.long().unsqueeze(1), dval.to(torch.bfloat16).unsqueeze(1))
+        return draw.view(groups * p, c), daff, None, None, None
+
+
+def act_max(act, groups, p):
+    """[groups * p, C] stored activation -> [groups, C] fp32: max over the p rows of every group of the ACTIVATED values."""
+    return _ActMax.apply(act.raw, act.affine, act.relu, groups, p)
+
+
 def rows_layer_supported(rows, cin, cout):
     return rows >= 1 and bool(_lib.lib().pps_rows_layer_supported(int(cin), int(cout)))
 

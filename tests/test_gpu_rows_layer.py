@@ -149,3 +149,91 @@ def test_rows_layer_is_deterministic():
         outs.append((out.raw.detach().clone(), out.affine.detach().clone(), xo.grad.clone(), wo.grad.clone(), H.weight.grad.clone()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_pointnet_with_fused_row_layers_is_as_close_to_fp32_as_the_separate_ops():
+    """train_graph.pointnet under bf16 autocast, fused row layers vs the separate ops (library GEMMs + fused BatchNorm op), both measured
+    against the fp32 run of the same graph: the max-pool of the STN makes bf16 gradients differ by whole arg-max switches, so the two
+    bf16 paths are not compared with each other but by their distance to fp32."""
+    import contextlib
+    import io
+    from ppsurf_amd import modules, synthetic, train_graph
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = modules.PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=50, pointnet_latent_size=256)
+    net.load_state_dict(synthetic.network_state_dict('ppsurf', num_pts_local=50))
+    pn = net.point_net.to(DEV).train()
+    state = {k: v.clone() for k, v in pn.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    patches = (torch.randn(2000, 50, 3, generator=g) * 0.4).to(DEV)
+    gout = torch.randn(2000, 256, generator=g).to(DEV)
+    res = {}
+    for mode in ('fp32', 'separate', 'fused'):
+        pn.load_state_dict(state)
+        pn.zero_grad(set_to_none=True)
+        train_graph.FUSED_ROWS = mode == 'fused'
+        try:
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=mode != 'fp32'):
+                feat, trans2 = train_graph.pointnet(pn, patches)
+            (feat.float() * gout).sum().backward()
+        finally:
+            train_graph.FUSED_ROWS = True
+        res[mode] = (feat.detach().float(), trans2.detach().float(), {k: p.grad.detach().clone() for k, p in pn.named_parameters() if p.grad is not None},
+                     {k: v.clone() for k, v in pn.state_dict().items() if 'running' in k})
+
+    def dist(a, b):
+        return float((a - b).abs().max())
+
+    ref = res['fp32']
+    for i, name in ((0, 'features'), (1, 'trans2')):
+        scale = float(ref[i].abs().max())
+        assert dist(res['fused'][i], ref[i]) <= 2.5 * dist(res['separate'][i], ref[i]) + 1e-2 * scale, name
+    assert set(res['fused'][2]) == set(ref[2]) == set(res['separate'][2])
+    gmax = max(float(v.abs().max()) for v in ref[2].values())
+    worse = []
+    for k, g32 in ref[2].items():
+        scale = float(g32.abs().max())
+        if scale < 1e-6 * gmax:
+            continue                                                    # biases in front of a BatchNorm: the gradient is rounding noise everywhere
+        ef, es = dist(res['fused'][2][k], g32), dist(res['separate'][2][k], g32)
+        if ef > 2.5 * es + 2e-2 * scale:
+            worse.append((k, ef, es, scale))
+    assert not worse, worse
+    for k, v32 in ref[3].items():
+        assert dist(res['fused'][3][k], v32) <= 2.5 * dist(res['separate'][3][k], v32) + 2e-3 * float(v32.abs().max()) + 1e-5, k
+
+
+@pytest.mark.parametrize('q,k', [(37, 50), (5, 64), (300, 1), (2049, 20)])
+def test_patch_attention_pooling_matches_torch(q, k):
+    from ppsurf_amd import train_ops
+    g = torch.Generator().manual_seed(q * 100 + k)
+    h = (torch.randn(q, k, 256, generator=g)).to(DEV).to(torch.bfloat16)
+    v = (torch.randn(256, generator=g) * 0.2).to(DEV)
+    gp = torch.randn(q, 256, generator=g).to(DEV)
+    ho, vo = h.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    out = train_ops.patch_attn(ho, vo)
+    (out * gp).sum().backward()
+    ht, vt = h.double().requires_grad_(True), v.double().requires_grad_(True)
+    a = torch.softmax(ht @ vt, dim=1)
+    ref = (a.unsqueeze(-1) * ht).sum(1)
+    (ref * gp.double()).sum().backward()
+    assert torch.allclose(out.double(), ref, rtol=1e-4, atol=1e-5)
+    assert float((ho.grad.double() - ht.grad).abs().max()) <= 6e-3 * float(ht.grad.abs().max())          # dh is stored in bf16
+    assert torch.allclose(vo.grad.double(), vt.grad, rtol=2e-4, atol=2e-4 * float(vt.grad.abs().max()))
+
+
+def test_act_max_matches_the_materialised_maximum():
+    from ppsurf_amd import train_ops
+    g = torch.Generator().manual_seed(11)
+    raw = torch.randn(90 * 50, 256, generator=g).to(DEV).to(torch.bfloat16)
+    aff = torch.stack([torch.randn(256, generator=g), torch.randn(256, generator=g)]).to(DEV)      # negative scales included
+    go = torch.randn(90, 256, generator=g).to(DEV)
+    ro, ao = raw.clone().requires_grad_(True), aff.clone().requires_grad_(True)
+    out = train_ops.act_max(train_ops.Act(ro, ao, True), 90, 50)
+    (out * go).sum().backward()
+    rt, at = raw.float().requires_grad_(True), aff.clone().requires_grad_(True)
+    ref = torch.relu(rt * at[0] + at[1]).view(90, 50, 256).max(dim=1)[0]
+    (ref * go).sum().backward()
+    assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(ao.grad, at.grad, rtol=1e-4, atol=1e-4)
+    # ties between equal bf16 values may pick another row: compare the gradient summed over the patch
+    assert torch.allclose(ro.grad.float().view(90, 50, 256).sum(1), rt.grad.view(90, 50, 256).sum(1), rtol=1e-2, atol=1e-2)
