@@ -295,10 +295,11 @@ int pps_bn_train_bwd(const void* x, const void* dy, int64_t rows, int c, int dty
 /* Attention pooling of the interpolation head in train(): a[j] = mean_h softmax_j(qy[q,j,h]), pooled[q,c] = sum_j a[j] h[q,j,c]
  * (replaces source/poco_model.py:412-414 under autograd, in the pooled form where fc_value follows the pooling).  qy [q,k,heads], h [q,k,c],
  * pooled [q,c]; heads <= 64 (64: interpolation head; 1: PointNet's AttentionPoco, source/base/nn.py:84-96 with k = patch points), k <= 64, c <= 256; storage float (bf16 = 0) or bfloat16 (bf16 = 1), arithmetic fp32.
- * Backward: dqy [q,k,heads], dh [q,k,c] from dpooled [q,c]; the softmax is recomputed from qy. */
-int pps_attn_pool_fwd(const void* qy, const void* h, int64_t q, int k, int heads, int c, int bf16, void* pooled, void* stream);
-int pps_attn_pool_bwd(const void* qy, const void* h, const void* dpooled, int64_t q, int k, int heads, int c, int bf16, void* dqy, void* dh,
-                      void* stream);
+ * Backward: dqy [q,k,heads], dh [q,k,c] from dpooled [q,c]; the softmax is recomputed from qy.
+ * relu_h != 0: h is stored BEFORE its ReLU (the raw output of fc3): the ReLU is applied on load and dh is the gradient wrt the stored values. */
+int pps_attn_pool_fwd(const void* qy, const void* h, int64_t q, int k, int heads, int c, int bf16, int relu_h, void* pooled, void* stream);
+int pps_attn_pool_bwd(const void* qy, const void* h, const void* dpooled, int64_t q, int k, int heads, int c, int bf16, int relu_h, void* dqy,
+                      void* dh, void* stream);
 
 /* Dense layer of the training step over point-major rows with the previous layer's BatchNorm + ReLU applied on load and this layer's
  * batch statistics taken on store (replaces the conv -> bn -> relu -> conv chains of source/base/nn.py:162-190, 323-336, 376-417 and the

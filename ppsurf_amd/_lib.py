@@ -60,8 +60,8 @@ SIGNATURES = {
     'pps_fka_train_ws_bytes': (_SZ, [_I64, _I64, _I]),
     'pps_fka_geometry_fwd_f32': (_I, [_P, _P, _P, _I64, _I64, _I, _P, _c.c_float, _P, _P, _P, _P]),
     'pps_fka_geometry_bwd_f32': (_I, [_P, _P, _P, _I64, _I64, _I, _P, _P, _P, _P, _P, _P]),
-    'pps_attn_pool_fwd': (_I, [_P, _P, _I64, _I, _I, _I, _I, _P, _P]),
-    'pps_attn_pool_bwd': (_I, [_P, _P, _P, _I64, _I, _I, _I, _I, _P, _P, _P]),
+    'pps_attn_pool_fwd': (_I, [_P, _P, _I64, _I, _I, _I, _I, _I, _P, _P]),
+    'pps_attn_pool_bwd': (_I, [_P, _P, _P, _I64, _I, _I, _I, _I, _I, _P, _P, _P]),
     'pps_patch_attn_partials': (_I, [_I64]),
     'pps_patch_attn_fwd': (_I, [_P, _P, _I64, _I, _I, _P, _P]),
     'pps_patch_attn_bwd': (_I, [_P, _P, _P, _I64, _I, _I, _P, _P, _P]),

@@ -84,7 +84,8 @@ __device__ __forceinline__ void softmax_to_lds(const T* __restrict__ qy, int64_t
 
 template <typename T>
 __global__ __launch_bounds__(AT_NT) void attn_pool_fwd_kernel(const T* __restrict__ qy, const T* __restrict__ h, int64_t Q, int k, int H, int C,
-                                                              T* __restrict__ pooled) {
+                                                              int relu_h, T* __restrict__ pooled) {
+    const float hfloor = relu_h ? 0.f : -INFINITY;                                  // relu_h: h is stored BEFORE its ReLU (train_ops.Act)
     __shared__ float e[AT_KMAX][AT_H + 1];
     __shared__ float red[4 * 64], inv_s[64], a[AT_KMAX];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -100,7 +101,8 @@ __global__ __launch_bounds__(AT_NT) void attn_pool_fwd_kernel(const T* __restric
         if (C == 256) {                                                              // wave w sums its 16 rows, lane = 4 channels
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int j = wave * 16; j < wave * 16 + 16 && j < k; ++j) {
-                const float4 v = ld4(hq, (int64_t)j * 256 + 4 * lane);
+                float4 v = ld4(hq, (int64_t)j * 256 + 4 * lane);
+                v = make_float4(fmaxf(v.x, hfloor), fmaxf(v.y, hfloor), fmaxf(v.z, hfloor), fmaxf(v.w, hfloor));
                 const float aj = a[j];
                 acc.x += aj * v.x; acc.y += aj * v.y; acc.z += aj * v.z; acc.w += aj * v.w;
             }
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(AT_NT) void attn_pool_fwd_kernel(const T* __restric
         } else {
             for (int c = threadIdx.x; c < C; c += AT_NT) {
                 float acc = 0.f;
-                for (int j = 0; j < k; ++j) acc += a[j] * ld(hq, (int64_t)j * C + c);
+                for (int j = 0; j < k; ++j) acc += a[j] * fmaxf(ld(hq, (int64_t)j * C + c), hfloor);
                 st(pooled, q * (int64_t)C + c, acc);
             }
         }
@@ -127,7 +129,8 @@ __global__ __launch_bounds__(AT_NT) void attn_pool_fwd_kernel(const T* __restric
 // d_h[q,j,c] = a[j] dP[c];   da[j] = sum_c dP[c] h[q,j,c];   d_qy[q,j,h] = s[j,h]/H * (da[j] - sum_j' s[j',h] da[j'])
 template <typename T>
 __global__ __launch_bounds__(AT_NT) void attn_pool_bwd_kernel(const T* __restrict__ qy, const T* __restrict__ h, const T* __restrict__ dpooled,
-                                                              int64_t Q, int k, int H, int C, T* __restrict__ dqy, T* __restrict__ dh) {
+                                                              int64_t Q, int k, int H, int C, int relu_h, T* __restrict__ dqy, T* __restrict__ dh) {
+    const float hfloor = relu_h ? 0.f : -INFINITY;
     __shared__ float e[AT_KMAX][AT_H + 1];
     __shared__ float red[4 * 64], inv_s[64], a[AT_KMAX], da[AT_KMAX], dp[256], dsum[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -147,9 +150,12 @@ __global__ __launch_bounds__(AT_NT) void attn_pool_bwd_kernel(const T* __restric
         if (C == 256) {
             const float4 d4 = make_float4(dp[4 * lane], dp[4 * lane + 1], dp[4 * lane + 2], dp[4 * lane + 3]);
             for (int j = wave * 16; j < wave * 16 + 16 && j < k; ++j) {              // one neighbour row per wave pass, 4 channels per lane
-                const float4 v = ld4(hq, (int64_t)j * 256 + 4 * lane);
+                float4 v = ld4(hq, (int64_t)j * 256 + 4 * lane);
                 const float aj = a[j];
-                st4(dhq, (int64_t)j * 256 + 4 * lane, make_float4(aj * d4.x, aj * d4.y, aj * d4.z, aj * d4.w));
+                // with relu_h the gradient goes to the stored pre-activation: masked where it was clipped
+                st4(dhq, (int64_t)j * 256 + 4 * lane, make_float4(v.x > hfloor ? aj * d4.x : 0.f, v.y > hfloor ? aj * d4.y : 0.f,
+                                                                  v.z > hfloor ? aj * d4.z : 0.f, v.w > hfloor ? aj * d4.w : 0.f));
+                v = make_float4(fmaxf(v.x, hfloor), fmaxf(v.y, hfloor), fmaxf(v.z, hfloor), fmaxf(v.w, hfloor));
                 const float part = wave_sum((d4.x * v.x + d4.y * v.y) + (d4.z * v.z + d4.w * v.w));
                 if (lane == 0) da[j] = part;
             }
@@ -158,8 +164,9 @@ __global__ __launch_bounds__(AT_NT) void attn_pool_bwd_kernel(const T* __restric
                 float part = 0.f;
                 const float aj = a[j];
                 for (int c = lane; c < C; c += 64) {
-                    part += dp[c] * ld(hq, (int64_t)j * C + c);
-                    st(dhq, (int64_t)j * C + c, aj * dp[c]);
+                    const float hv = ld(hq, (int64_t)j * C + c);
+                    part += dp[c] * fmaxf(hv, hfloor);
+                    st(dhq, (int64_t)j * C + c, hv > hfloor ? aj * dp[c] : 0.f);
                 }
                 part = wave_sum(part);
                 if (lane == 0) da[j] = part;
@@ -304,32 +311,32 @@ int grid_for(int64_t q) {
 
 extern "C" {
 
-int pps_attn_pool_fwd(const void* qy, const void* h, int64_t q, int k, int heads, int c, int bf16, void* pooled, void* stream) {
+int pps_attn_pool_fwd(const void* qy, const void* h, int64_t q, int k, int heads, int c, int bf16, int relu_h, void* pooled, void* stream) {
     if (q < 0 || k < 1 || k > AT_KMAX || heads < 1 || heads > AT_H || c < 1 || c > 256) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
     if (!qy || !h || !pooled) return PPS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (bf16)
         hipLaunchKernelGGL(attn_pool_fwd_kernel<uint16_t>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const uint16_t*)qy, (const uint16_t*)h, q, k, heads, c,
-                           (uint16_t*)pooled);
+                           relu_h, (uint16_t*)pooled);
     else
         hipLaunchKernelGGL(attn_pool_fwd_kernel<float>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const float*)qy, (const float*)h, q, k, heads, c,
-                           (float*)pooled);
+                           relu_h, (float*)pooled);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 
-int pps_attn_pool_bwd(const void* qy, const void* h, const void* dpooled, int64_t q, int k, int heads, int c, int bf16, void* dqy, void* dh,
-                      void* stream) {
+int pps_attn_pool_bwd(const void* qy, const void* h, const void* dpooled, int64_t q, int k, int heads, int c, int bf16, int relu_h, void* dqy,
+                      void* dh, void* stream) {
     if (q < 0 || k < 1 || k > AT_KMAX || heads < 1 || heads > AT_H || c < 1 || c > 256) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
     if (!qy || !h || !dpooled || !dqy || !dh) return PPS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (bf16)
         hipLaunchKernelGGL(attn_pool_bwd_kernel<uint16_t>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const uint16_t*)qy, (const uint16_t*)h,
-                           (const uint16_t*)dpooled, q, k, heads, c, (uint16_t*)dqy, (uint16_t*)dh);
+                           (const uint16_t*)dpooled, q, k, heads, c, relu_h, (uint16_t*)dqy, (uint16_t*)dh);
     else
         hipLaunchKernelGGL(attn_pool_bwd_kernel<float>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const float*)qy, (const float*)h,
-                           (const float*)dpooled, q, k, heads, c, (float*)dqy, (float*)dh);
+                           (const float*)dpooled, q, k, heads, c, relu_h, (float*)dqy, (float*)dh);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 

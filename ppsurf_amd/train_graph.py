@@ -221,6 +221,16 @@ def encoder(enc, data):
     return dense(enc.fcout, xo.reshape(-1, xo.shape[-1])).view(b, pts.shape[1], -1)
 
 
+FUSED_ROWS = True            # False: every row layer through the separate ops (library GEMM + fused BatchNorm op), e.g. to compare
+
+
+def fused_rows_ok(x, *bns):
+    """The fused row layers (train_ops.rows_layer: bf16 storage, BatchNorm statistics of train()) apply: device tensor, bf16 autocast, every
+    BatchNorm in train() with a momentum."""
+    return (x.is_cuda and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+            and all(b.training and b.track_running_stats and b.momentum is not None for b in bns))
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # decoder
 # ---------------------------------------------------------------------------------------------------------------------
@@ -234,6 +244,19 @@ def interp_attention(proj, latents, pts, query, ids, last_layer=True):
     w1 = _w2d(proj.fc1)
     table = rows_linear(latents.reshape(b * n, c), w1[:, :c], proj.fc1.bias)             # [B*N, C]
     rel = (query.unsqueeze(2) - pts.reshape(b * n, 3)[flat].view(b, q, k, 3)).reshape(-1, 3)     # query minus neighbour
+    if (FUSED_ROWS and fused_rows_ok(latents) and train_ops.attn_pool_supported(k, _w2d(proj.fc_query).shape[0], 256)
+            and all(train_ops.rows_layer_supported(b * q * k, *reversed(_w2d(l).shape)) for l in (proj.fc2, proj.fc3, proj.fc_query))):
+        # fc2, fc3, fc_query as fused row layers (pps_rows_train.hip): each stores its RAW output once, the ReLU is applied by the consumer on
+        # load (and masks the gradient on the way back), so no activated [B*Q*k, 256] tensor is written or read
+        h1 = train_ops.gather_rows(table, flat) + rows_linear(rel, w1[:, c:]).to(table.dtype)
+        y2 = train_ops.rows_layer(train_ops.Act(h1, None, True), _w2d(proj.fc2), proj.fc2.bias, None, True)
+        y3 = train_ops.rows_layer(y2, _w2d(proj.fc3), proj.fc3.bias, None, True)
+        qy = train_ops.rows_layer(y3, _w2d(proj.fc_query), proj.fc_query.bias, None, False)
+        pooled = train_ops.attn_pool(qy.raw.view(b * q, k, -1), y3.raw.view(b * q, k, -1), relu_h=True)
+        out = dense(proj.fc_value, pooled)
+        if last_layer:
+            out = dense(proj.fc8, out)
+        return out.view(b, q, -1)
     h = F.relu(train_ops.gather_rows(table, flat) + rows_linear(rel, w1[:, c:]).to(table.dtype))
     h = F.relu(dense(proj.fc2, h))
     h = F.relu(dense(proj.fc3, h))
@@ -262,13 +285,6 @@ def stn(t, h, nq, p):
     z = batch_norm(t.bn5, dense(t.fc2, z), relu=True)
     z = dense(t.fc3, z) + torch.eye(d, dtype=z.dtype, device=z.device).reshape(1, d * d)
     return z.view(nq, d, d)
-
-
-def fused_rows_ok(x, *bns):
-    """The fused row layers (train_ops.rows_layer: bf16 storage, BatchNorm statistics of train()) apply: device tensor, bf16 autocast, every
-    BatchNorm in train() with a momentum."""
-    return (x.is_cuda and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
-            and all(b.training and b.track_running_stats and b.momentum is not None for b in bns))
 
 
 def _layer(act, conv, bn, relu):
@@ -311,9 +327,6 @@ def _pointnet_fused(pn, patches):
     pooled = train_ops.patch_attn(z.raw.view(nq, p, -1), (wq * scale).reshape(-1))
     pooled = (pooled * scale + shift + 0.0 * const).to(torch.bfloat16)
     return dense(pn.att.fc_value, pooled), trans2
-
-
-FUSED_ROWS = True            # False: every row layer through the separate ops (library GEMM + fused BatchNorm op), e.g. to compare
 
 
 def pointnet(pn, patches):

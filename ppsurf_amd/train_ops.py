@@ -247,14 +247,15 @@ class _AttnPool(torch.autograd.Function):
     backward; fp32 or bf16 storage, fp32 arithmetic; the softmax is recomputed in backward, only the two inputs are saved."""
 
     @staticmethod
-    def forward(ctx, qy, h):
+    def forward(ctx, qy, h, relu_h=False):
         _need_cuda(qy, h)
+        ctx.relu_h = int(bool(relu_h))
         dt = h.dtype if h.dtype in (torch.float32, torch.bfloat16) else torch.float32
         qy, h = qy.to(dt).contiguous(), h.to(dt).contiguous()
         q, k, heads = qy.shape
         c = h.shape[2]
         pooled = torch.empty((q, c), device=h.device, dtype=dt)
-        _lib.check(_lib.lib().pps_attn_pool_fwd(qy.data_ptr(), h.data_ptr(), q, k, heads, c, int(dt == torch.bfloat16), pooled.data_ptr(), _stream()),
+        _lib.check(_lib.lib().pps_attn_pool_fwd(qy.data_ptr(), h.data_ptr(), q, k, heads, c, int(dt == torch.bfloat16), ctx.relu_h, pooled.data_ptr(), _stream()),
                    'pps_attn_pool_fwd')
         ctx.save_for_backward(qy, h)
         return pooled
@@ -267,8 +268,8 @@ class _AttnPool(torch.autograd.Function):
         dpooled = dpooled.to(h.dtype).contiguous()
         dqy, dh = torch.empty_like(qy), torch.empty_like(h)
         _lib.check(_lib.lib().pps_attn_pool_bwd(qy.data_ptr(), h.data_ptr(), dpooled.data_ptr(), q, k, heads, c, int(h.dtype == torch.bfloat16),
-                                                dqy.data_ptr(), dh.data_ptr(), _stream()), 'pps_attn_pool_bwd')
-        return dqy, dh
+                                                ctx.relu_h, dqy.data_ptr(), dh.data_ptr(), _stream()), 'pps_attn_pool_bwd')
+        return dqy, dh, None
 
 
 class Act:
@@ -452,9 +453,9 @@ def attn_pool_supported(k, heads, c):
     return 1 <= k <= 64 and 1 <= heads <= 64 and c <= 256
 
 
-def attn_pool(qy, h):
-    """qy [Q,k,64] attention logits, h [Q,k,C] -> pooled [Q,C] (dtype of h)."""
-    return _AttnPool.apply(qy, h)
+def attn_pool(qy, h, relu_h=False):
+    """qy [Q,k,64] attention logits, h [Q,k,C] -> pooled [Q,C] (dtype of h).  relu_h: h is the stored PRE-activation, relu(h) is pooled."""
+    return _AttnPool.apply(qy, h, relu_h)
 
 
 def bn_supported(rows, c):

@@ -237,3 +237,46 @@ def test_act_max_matches_the_materialised_maximum():
     assert torch.allclose(ao.grad, at.grad, rtol=1e-4, atol=1e-4)
     # ties between equal bf16 values may pick another row: compare the gradient summed over the patch
     assert torch.allclose(ro.grad.float().view(90, 50, 256).sum(1), rt.grad.view(90, 50, 256).sum(1), rtol=1e-2, atol=1e-2)
+
+
+def test_interpolation_head_with_fused_row_layers_is_as_close_to_fp32_as_the_separate_ops():
+    import contextlib
+    import io
+    from ppsurf_amd import modules, synthetic, train_graph
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = modules.PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=50, pointnet_latent_size=256)
+    net.load_state_dict(synthetic.network_state_dict('ppsurf', num_pts_local=50))
+    proj = net.projection.to(DEV).train()
+    g = torch.Generator().manual_seed(8)
+    b, n, q, k = 2, 3000, 400, 64
+    lat0 = (torch.randn(b, n, 256, generator=g) * 0.5).to(DEV)
+    pts = torch.rand(b, n, 3, generator=g).to(DEV)
+    query = torch.rand(b, q, 3, generator=g).to(DEV)
+    ids = torch.randint(0, n, (b, q, k), generator=g).to(DEV)
+    gout = torch.randn(b, q, 256, generator=g).to(DEV)
+    res = {}
+    for mode in ('fp32', 'separate', 'fused'):
+        proj.zero_grad(set_to_none=True)
+        lat = lat0.clone().requires_grad_(True)
+        train_graph.FUSED_ROWS = mode == 'fused'
+        try:
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=mode != 'fp32'):
+                out = train_graph.interp_attention(proj, lat, pts, query, ids, last_layer=True)
+            (out.float() * gout).sum().backward()
+        finally:
+            train_graph.FUSED_ROWS = True
+            train_graph.release_step_caches()
+        grads = {k_: p.grad.detach().clone() for k_, p in proj.named_parameters() if p.grad is not None}
+        grads['latents'] = lat.grad.detach().clone()
+        res[mode] = (out.detach().float(), grads)
+    dist = lambda a, c: float((a - c).abs().max())
+    ref = res['fp32']
+    assert dist(res['fused'][0], ref[0]) <= 2.5 * dist(res['separate'][0], ref[0]) + 1e-2 * float(ref[0].abs().max())
+    assert set(res['fused'][1]) == set(ref[1])
+    worse = []
+    for name, g32 in ref[1].items():
+        scale = float(g32.abs().max())
+        ef, es = dist(res['fused'][1][name], g32), dist(res['separate'][1][name], g32)
+        if ef > 2.5 * es + 2e-2 * scale:
+            worse.append((name, ef, es, scale))
+    assert not worse, worse
