@@ -309,7 +309,8 @@ int pps_attn_pool_bwd(const void* qy, const void* h, const void* dpooled, int64_
  *   fwd:  y = act(x) w^T + bias  (w [cout, cin] fp32, rounded to bf16 for the product; bias NULL = none).  With gamma != NULL the batch
  *         statistics of y give out_affine [2][cout] = (gamma rstd, beta - mean gamma rstd), save [2][cout] = (mean, rstd) and the
  *         running statistics are updated like torch.nn.BatchNorm1d (both NULL = not tracked).
- *   bwd:  from gy [rows, cout] bf16 and d_affine [2][cout] (loss gradient wrt out_affine; with gamma): dx [rows, cin] bf16 (NULL = skip),
+ *   bwd:  from gy [rows, cout] bf16 and d_affine [2][cout] (loss gradient wrt out_affine; with gamma): dx [rows, cin] bf16 (NULL = skip;
+ *         dx_add [rows, cin] bf16, NULL or a gradient of x from another consumer that is added to the result -- may be dx itself),
  *         d_in_affine [2][cin] (NULL = skip), dw [cout, cin], dbias [cout] (NULL = skip), dgamma, dbeta [cout].
  * ws: pps_rows_layer_ws_bytes(cin, cout) bytes of device scratch.  Deterministic. */
 /* Single-head attention pooling over the rows of a group with the logit computed inside (PointNet's AttentionPoco, source/base/nn.py:84-96, applied to
@@ -330,7 +331,8 @@ int pps_rows_layer_fwd(const void* x, int64_t rows, int cin, const float* in_sca
                        float momentum, float eps, float* out_affine, float* save, void* ws, void* stream);
 int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t rows, int cin, int cout, const float* in_scale,
                        const float* in_shift, int in_relu, const float* w, const float* gamma, const float* save, const float* d_affine,
-                       void* dx, float* d_in_affine, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws, void* stream);
+                       void* dx, const void* dx_add, float* d_in_affine, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws,
+                       void* stream);
 
 #ifdef __cplusplus
 }

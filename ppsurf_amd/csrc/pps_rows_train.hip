@@ -90,6 +90,7 @@ struct LayerArgs {
     const float* in_scale;        // dx: [CO] or NULL
     const float* in_shift;        // dx: [CO] or NULL
     int in_relu;
+    const uint16_t* addend;       // dx: [rows, CO] added to the result (the other gradient of x; may be dst itself) or NULL
     uint16_t* dst;                // fwd: y [rows, CO]            dx: dx [rows, CO]
     float* partials;              // [gridDim.x][2][CO] or NULL: fwd (sum y, sum y^2); dx (sum d * x, sum d)
     int64_t rows;
@@ -255,6 +256,12 @@ __global__ __launch_bounds__(NT, 1) void rows_layer_kernel(const LayerArgs a) {
                         x1 = *(const u32x4*)(a.xin + row * CO + c0 + 8);
                     }
                     const unsigned xw[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                    u32x4 g0 = {0, 0, 0, 0}, g1 = {0, 0, 0, 0};
+                    if (a.addend) {
+                        g0 = *(const u32x4*)(a.addend + row * CO + c0);
+                        g1 = *(const u32x4*)(a.addend + row * CO + c0 + 8);
+                    }
+                    const unsigned gw[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
                     for (int o = 0; o < 4; ++o) {
                         const f32x4 sc = *(const f32x4*)(ea + c0 + 4 * o), sh = *(const f32x4*)(eb + c0 + 4 * o);
@@ -268,6 +275,7 @@ __global__ __launch_bounds__(NT, 1) void rows_layer_kernel(const LayerArgs a) {
                             st1[4 * grp + o][r] += live * d[r];
                             d[r] *= sc[r];
                         }
+                        d[0] += lo16(gw[2 * o]); d[1] += hi16(gw[2 * o]); d[2] += lo16(gw[2 * o + 1]); d[3] += hi16(gw[2 * o + 1]);
                         out[2 * o] = pack2(d[0], d[1]);
                         out[2 * o + 1] = pack2(d[2], d[3]);
                     }
@@ -726,7 +734,8 @@ int pps_rows_layer_fwd(const void* x, int64_t rows, int cin, const float* in_sca
 
 int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t rows, int cin, int cout, const float* in_scale,
                        const float* in_shift, int in_relu, const float* w, const float* gamma, const float* save, const float* d_affine,
-                       void* dx, float* d_in_affine, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws, void* stream) {
+                       void* dx, const void* dx_add, float* d_in_affine, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws,
+                       void* stream) {
     if (rows < 1 || !dim_ok(cin) || !dim_ok(cout)) return PPS_ERR_ARG;
     if (!x || !gy || !w || !ws || ((in_scale == nullptr) != (in_shift == nullptr))) return PPS_ERR_ARG;
     if (!in_scale && in_relu) return PPS_ERR_ARG;
@@ -757,6 +766,7 @@ int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t row
         a.in_shift = in_shift;
         a.in_relu = in_relu;
         a.dst = (uint16_t*)dx;
+        a.addend = (const uint16_t*)dx_add;
         a.partials = d_in_affine ? part_aff : nullptr;
         a.rows = rows;
         PPS_DISPATCH(cin, cout, rc = (launch_layer<O, I, true>(a, grid, st)));

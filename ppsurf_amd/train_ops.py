@@ -339,7 +339,7 @@ class _RowsLayer(torch.autograd.Function):
         ptr = lambda t: None if t is None else t.data_ptr()
         _lib.check(L.pps_rows_layer_bwd(x.data_ptr(), y.data_ptr(), gy.data_ptr(), rows, cin, cout, ptr(aff),
                                         None if aff is None else aff.data_ptr() + 4 * cin, int(in_relu), w32.data_ptr(), ptr(g32), ptr(save),
-                                        ptr(g_affine) if bn else None, ptr(dx), ptr(d_in), dw.data_ptr(), ptr(db), ptr(dgamma), ptr(dbeta),
+                                        ptr(g_affine) if bn else None, ptr(dx), None, ptr(d_in), dw.data_ptr(), ptr(db), ptr(dgamma), ptr(dbeta),
                                         ws.data_ptr(), _stream()), 'pps_rows_layer_bwd')
         return (dx if need_dx else None, d_in, None, dw.to(wdt), None if db is None else db.to(bdt), dgamma, dbeta, None, None, None, None)
 
@@ -447,6 +447,58 @@ def rows_layer(act, w, b, bn=None, relu=False):
     else:
         y, aff = _RowsLayer.apply(act.raw, act.affine, act.relu, w, b, None, None, None, None, None, None)
     return Act(y, aff, relu)
+
+
+class _QueryAttnPool(torch.autograd.Function):
+    """The end of the interpolation head on the stored (pre-ReLU) output y3 of fc3 [Q*k, 256]:  qy = fc_query(relu(y3)),  pooled[q] = sum_j mean_h
+    softmax_j(qy) relu(y3)[q, j]  as ONE autograd node: y3 has two consumers, and their two gradients are summed inside the input-gradient
+    kernel of fc_query (dx_add) instead of by a separate pass over [Q*k, 256]."""
+
+    @staticmethod
+    def forward(ctx, y3, wq, bq, k):
+        _need_cuda(y3, wq)
+        L = _lib.lib()
+        y3 = y3.to(torch.bfloat16).contiguous()
+        rows, c = y3.shape
+        heads = wq.shape[0]
+        w32 = wq.detach().float().contiguous()
+        b32 = None if bq is None else bq.detach().float().contiguous()
+        aff = torch.cat([torch.ones((1, c), device=y3.device), torch.zeros((1, c), device=y3.device)])
+        qy = torch.empty((rows, heads), device=y3.device, dtype=torch.bfloat16)
+        ws = torch.empty((L.pps_rows_layer_ws_bytes(c, heads),), device=y3.device, dtype=torch.uint8)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        _lib.check(L.pps_rows_layer_fwd(y3.data_ptr(), rows, c, aff.data_ptr(), aff.data_ptr() + 4 * c, 1, w32.data_ptr(), ptr(b32), heads, qy.data_ptr(),
+                                        None, None, None, None, 0.0, 0.0, None, None, ws.data_ptr(), _stream()), 'pps_rows_layer_fwd')
+        pooled = torch.empty((rows // k, c), device=y3.device, dtype=torch.bfloat16)
+        _lib.check(L.pps_attn_pool_fwd(qy.data_ptr(), y3.data_ptr(), rows // k, k, heads, c, 1, 1, pooled.data_ptr(), _stream()), 'pps_attn_pool_fwd')
+        ctx.save_for_backward(y3, w32, qy, aff)
+        ctx.meta = (k, bq is not None, wq.dtype, None if bq is None else bq.dtype)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        y3, w32, qy, aff = ctx.saved_tensors
+        k, has_b, wdt, bdt = ctx.meta
+        L = _lib.lib()
+        rows, c = y3.shape
+        heads = w32.shape[0]
+        dev = y3.device
+        dpooled = dpooled.to(torch.bfloat16).contiguous()
+        dqy, dy3 = torch.empty_like(qy), torch.empty_like(y3)
+        _lib.check(L.pps_attn_pool_bwd(qy.data_ptr(), y3.data_ptr(), dpooled.data_ptr(), rows // k, k, heads, c, 1, 1, dqy.data_ptr(), dy3.data_ptr(),
+                                       _stream()), 'pps_attn_pool_bwd')
+        dw = torch.empty((heads, c), device=dev, dtype=torch.float32)
+        db = torch.empty((heads,), device=dev, dtype=torch.float32) if has_b else None
+        ws = torch.empty((L.pps_rows_layer_ws_bytes(c, heads),), device=dev, dtype=torch.uint8)
+        _lib.check(L.pps_rows_layer_bwd(y3.data_ptr(), qy.data_ptr(), dqy.data_ptr(), rows, c, heads, aff.data_ptr(), aff.data_ptr() + 4 * c, 1,
+                                        w32.data_ptr(), None, None, None, dy3.data_ptr(), dy3.data_ptr(), None, dw.data_ptr(),
+                                        None if db is None else db.data_ptr(), None, None, ws.data_ptr(), _stream()), 'pps_rows_layer_bwd')
+        return dy3, dw.to(wdt), None if db is None else db.to(bdt), None
+
+
+def query_attn_pool(y3, wq, bq, k):
+    """y3 [Q*k, 256] stored BEFORE its ReLU, fc_query weights [heads, 256] -> pooled [Q, 256] bf16."""
+    return _QueryAttnPool.apply(y3, wq, bq, k)
 
 
 def attn_pool_supported(k, heads, c):

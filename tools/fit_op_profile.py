@@ -15,8 +15,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--rows', type=int, default=45)
+    ap.add_argument('--encoder-only', action='store_true', help='PointNet and interpolation head replaced by zeros (tools/fit_module_breakdown.py): encoder + MLP + data preparation + AdamW')
+    ap.add_argument('--kernels', action='store_true', help='list device kernels instead of framework ops')
     a = ap.parse_args()
     step = workloads.FitStep()
+    if a.encoder_only:
+        from ppsurf_amd import train_graph
+        train_graph.pointnet = lambda pn, patches: (torch.zeros((patches.shape[0], 256), device=patches.device), None)
+        train_graph.interp_attention = lambda proj, latents, pts, query, ids, last_layer=True: (latents.sum() * 0).expand(query.shape[0], query.shape[1], 256)
     for _ in range(3):
         step()
     torch.cuda.synchronize()
@@ -25,13 +31,13 @@ def main():
         for _ in range(a.steps):
             step()
         torch.cuda.synchronize()
-    ka = prof.key_averages(group_by_input_shape=True)
+    ka = prof.key_averages(group_by_input_shape=not a.kernels)
     rows = []
     for e in ka:
         t = getattr(e, 'self_device_time_total', None)
         if t is None:
             t = e.self_cuda_time_total
-        if t > 0:
+        if t > 0 and (not a.kernels or e.device_type.name != 'CPU'):
             rows.append((t / a.steps / 1000.0, e.count / a.steps, e.key, str(e.input_shapes)[:90]))
     rows.sort(reverse=True)
     print('total device ms/step {:.2f}'.format(sum(r[0] for r in rows)))
