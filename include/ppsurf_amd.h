@@ -321,6 +321,25 @@ int pps_patch_attn_partials(int64_t q);
 int pps_patch_attn_fwd(const void* h, const float* v, int64_t q, int k, int c, float* pooled, void* stream);
 int pps_patch_attn_bwd(const void* h, const float* v, const float* dpooled, int64_t q, int k, int c, void* dh, float* dv_part, void* stream);
 
+/* conv0a of PointNet in train() (3 coordinates -> 64 channels, source/base/nn.py:323): y [rows, 64] bf16 = x [rows, 3] w^T + bias with the batch
+ * statistics of y -> out_affine / save / running statistics as in pps_rows_layer_fwd; backward: dw [64, 3], dbias [64] (NULL = skip), dgamma,
+ * dbeta (x gets no gradient: it is the input patch).  ws: pps_rows3_ws_bytes() bytes. */
+size_t pps_rows3_ws_bytes(void);
+int pps_rows3_fwd(const float* x, int64_t rows, const float* w, const float* bias, void* y, const float* gamma, const float* beta,
+                  float* running_mean, float* running_var, float momentum, float eps, float* out_affine, float* save, void* ws, void* stream);
+int pps_rows3_bwd(const float* x, const void* y, const void* gy, int64_t rows, const float* gamma, const float* save, const float* d_affine,
+                  float* dw, float* dbias, float* dgamma, float* dbeta, void* ws, void* stream);
+
+/* Feature transform of PointNet in train() (source/base/nn.py:330-331, torch.bmm(trans2, x)): out[q,i,:] = act(x)[q,i,:] T[q]^T per group q of
+ * p <= 64 rows.  x [q*p, 64] bf16 stored activation, act = relu?(x * in_scale + in_shift) (NULL = identity), T [q, 64, 64] bf16 (+ I if
+ * add_identity), out [q*p, 64] bf16.  Backward from g = d out: dx [q*p, 64] bf16, dt [q, 64, 64] bf16, d_in_affine [2][64] (NULL = skip).
+ * ws: pps_patch_transform_ws_bytes() bytes. */
+size_t pps_patch_transform_ws_bytes(void);
+int pps_patch_transform_fwd(const void* x, const float* in_scale, const float* in_shift, int in_relu, const void* t, int add_identity, int64_t q,
+                            int p, void* out, void* stream);
+int pps_patch_transform_bwd(const void* x, const float* in_scale, const float* in_shift, int in_relu, const void* t, int add_identity, const void* g,
+                            int64_t q, int p, void* dx, void* dt, float* d_in_affine, void* ws, void* stream);
+
 /* Extrema over the p rows of every group of x [groups, p, c] (bfloat16, c % 4 == 0): mx, mn [groups, c] fp32 and the row of each
  * (first occurrence).  The max-pool over the patch points (source/base/nn.py:181) of relu(bn(x)) follows from them without the activated tensor. */
 int pps_rows_extrema_bf16(const void* x, int64_t groups, int p, int c, float* mx, float* mn, int* amx, int* amn, void* stream);

@@ -65,6 +65,12 @@ SIGNATURES = {
     'pps_patch_attn_partials': (_I, [_I64]),
     'pps_patch_attn_fwd': (_I, [_P, _P, _I64, _I, _I, _P, _P]),
     'pps_patch_attn_bwd': (_I, [_P, _P, _P, _I64, _I, _I, _P, _P, _P]),
+    'pps_rows3_ws_bytes': (_SZ, []),
+    'pps_rows3_fwd': (_I, [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _c.c_float, _P, _P, _P, _P]),
+    'pps_rows3_bwd': (_I, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'pps_patch_transform_ws_bytes': (_SZ, []),
+    'pps_patch_transform_fwd': (_I, [_P, _P, _P, _I, _P, _I, _I64, _I, _P, _P]),
+    'pps_patch_transform_bwd': (_I, [_P, _P, _P, _I, _P, _I, _P, _I64, _I, _P, _P, _P, _P, _P]),
     'pps_rows_extrema_bf16': (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P]),
     'pps_rows_layer_supported': (_I, [_I, _I]),
     'pps_rows_layer_ws_bytes': (_SZ, [_I, _I]),

@@ -623,6 +623,291 @@ __global__ __launch_bounds__(256) void rows_extrema_kernel(const uint16_t* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// First layer of PointNet: 3 coordinates -> 64 channels (conv0a, source/base/nn.py:323) -- not an MFMA shape.  A thread computes 8 channels
+// of a row (16-byte store), 8 threads a row; statistics / weight gradients per thread, reduced over the block in a fixed order.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int R3_ROWS = 32;            // rows per block iteration (256 threads / 8 channel chunks)
+
+__global__ __launch_bounds__(256) void rows3_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                       int64_t rows, uint16_t* __restrict__ y, float* __restrict__ partials) {
+    __shared__ float red[256][17];
+    const int ch = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    float wv[8][3], bv[8], s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        wv[j][0] = w[(8 * ch + j) * 3]; wv[j][1] = w[(8 * ch + j) * 3 + 1]; wv[j][2] = w[(8 * ch + j) * 3 + 2];
+        bv[j] = bias ? bias[8 * ch + j] : 0.f;
+        s0[j] = 0.f; s1[j] = 0.f;
+    }
+    for (int64_t row = (int64_t)blockIdx.x * R3_ROWS + rl; row < rows; row += (int64_t)gridDim.x * R3_ROWS) {
+        const float x0 = x[row * 3], x1 = x[row * 3 + 1], x2 = x[row * 3 + 2];
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = __builtin_fmaf(wv[j][2], x2, __builtin_fmaf(wv[j][1], x1, __builtin_fmaf(wv[j][0], x0, bv[j])));
+        const u32x4 p = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+        *(u32x4*)(y + row * 64 + 8 * ch) = p;
+        const float r[8] = {lo16(p.x), hi16(p.x), lo16(p.y), hi16(p.y), lo16(p.z), hi16(p.z), lo16(p.w), hi16(p.w)};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s0[j] += r[j]; s1[j] += r[j] * r[j]; }
+    }
+    if (!partials) return;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[threadIdx.x][j] = s0[j]; red[threadIdx.x][8 + j] = s1[j]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {                                      // (statistic, channel): threads of equal chunk in row-lane order
+        const int st = threadIdx.x >> 6, c = threadIdx.x & 63;
+        float t = 0.f;
+        for (int q = 0; q < R3_ROWS; ++q) t += red[q * 8 + (c >> 3)][8 * st + (c & 7)];
+        partials[(int64_t)blockIdx.x * 128 + st * 64 + c] = t;
+    }
+}
+
+// partial [block][256]: dW [64][3] then db [64]
+__global__ __launch_bounds__(256) void rows3_bwd_kernel(const float* __restrict__ x, const uint16_t* __restrict__ y, const uint16_t* __restrict__ gy,
+                                                       const float* __restrict__ gstat, int64_t rows, float* __restrict__ partials) {
+    __shared__ float red[256][33];
+    const int ch = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    float gs[8], gq[8], acc[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        gs[j] = gstat ? gstat[8 * ch + j] : 0.f;
+        gq[j] = gstat ? gstat[64 + 8 * ch + j] : 0.f;
+        acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.f;
+    }
+    for (int64_t row = (int64_t)blockIdx.x * R3_ROWS + rl; row < rows; row += (int64_t)gridDim.x * R3_ROWS) {
+        const float x0 = x[row * 3], x1 = x[row * 3 + 1], x2 = x[row * 3 + 2];
+        const u32x4 g4 = *(const u32x4*)(gy + row * 64 + 8 * ch);
+        float g[8] = {lo16(g4.x), hi16(g4.x), lo16(g4.y), hi16(g4.y), lo16(g4.z), hi16(g4.z), lo16(g4.w), hi16(g4.w)};
+        if (gstat) {
+            const u32x4 y4 = *(const u32x4*)(y + row * 64 + 8 * ch);
+            const float yv[8] = {lo16(y4.x), hi16(y4.x), lo16(y4.y), hi16(y4.y), lo16(y4.z), hi16(y4.z), lo16(y4.w), hi16(y4.w)};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = __builtin_fmaf(yv[j], gq[j], g[j] + gs[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc[j][0] += g[j] * x0; acc[j][1] += g[j] * x1; acc[j][2] += g[j] * x2; acc[j][3] += g[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[threadIdx.x][4 * j + k] = acc[j][k];
+    __syncthreads();
+    {
+        const int c = threadIdx.x >> 2, k = threadIdx.x & 3;       // 64 channels x (3 weights + bias)
+        float t = 0.f;
+        for (int q = 0; q < R3_ROWS; ++q) t += red[q * 8 + (c >> 3)][4 * (c & 7) + k];
+        float* out = partials + (int64_t)blockIdx.x * 256;
+        if (k < 3) out[c * 3 + k] = t; else out[192 + c] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Feature transform of PointNet (source/base/nn.py:330-331, torch.bmm(trans2, x)): per group q of p <= 64 rows
+//     out[q, i, :] = act(x)[q, i, :] T[q]^T,      x [Q*p, 64] bf16 stored activation, T [Q, 64, 64] bf16 (+ I), out [Q*p, 64] bf16
+// forward: a wave per group, T[q] and the rows straight from global memory as MFMA operands.
+// backward: a workgroup per group; T[q], act(x) and the output gradient G go row-major into LDS and the three products
+//     dA = G T (-> dx, d scale, d shift),    dT^T-free form  dT[j][k] = sum_i G[i][j] act(x)[i][k]
+// take their column operands with ds_read_b64_tr_b16.
+// ---------------------------------------------------------------------------------------------------------------------
+struct PtArgs {
+    const uint16_t* x;            // [Q*p, 64]
+    const float* scale;           // [64] or NULL
+    const float* shift;
+    int relu;
+    const uint16_t* t;            // [Q, 64, 64]
+    int add_identity;
+    int64_t nq;
+    int p;
+    uint16_t* out;                // fwd: [Q*p, 64]
+    const uint16_t* g;            // bwd: d out [Q*p, 64]
+    uint16_t* dx;                 // bwd: [Q*p, 64]
+    uint16_t* dt;                 // bwd: [Q, 64, 64]
+    float* partials;              // bwd: [gridDim.x][2][64] (d scale, d shift) or NULL
+};
+
+__device__ __forceinline__ u32x4 act8(const u32x4 q, const float* sc, const float* sh, float floor_) {
+    float e[8] = {lo16(q.x), hi16(q.x), lo16(q.y), hi16(q.y), lo16(q.z), hi16(q.z), lo16(q.w), hi16(q.w)};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = fmaxf(__builtin_fmaf(e[j], sc[j], sh[j]), floor_);
+    return u32x4{pack2(e[0], e[1]), pack2(e[2], e[3]), pack2(e[4], e[5]), pack2(e[6], e[7])};
+}
+
+// 8 consecutive elements of row j of T starting at column k0, + 1 on the diagonal
+__device__ __forceinline__ u32x4 t_chunk(const uint16_t* __restrict__ tq, int j, int k0, int add_identity) {
+    u32x4 v = *(const u32x4*)(tq + j * 64 + k0);
+    if (add_identity && j >= k0 && j < k0 + 8) {
+        unsigned* w = (unsigned*)&v;
+        const int e = j - k0;
+        const float f = (e & 1) ? hi16(w[e >> 1]) : lo16(w[e >> 1]);
+        const unsigned r = pack2(f + 1.f, 0.f) & 0xffffu;
+        w[e >> 1] = (e & 1) ? ((w[e >> 1] & 0xffffu) | (r << 16)) : ((w[e >> 1] & 0xffff0000u) | r);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256, 2) void patch_transform_fwd_kernel(const PtArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+    const bool has_act = a.scale != nullptr;
+    const float floor_ = a.relu ? 0.f : -INFINITY;
+    float sc[2][8], sh[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sc[s][j] = has_act ? a.scale[32 * s + 8 * g + j] : 1.f;
+            sh[s][j] = has_act ? a.shift[32 * s + 8 * g + j] : 0.f;
+        }
+    for (int64_t q = (int64_t)blockIdx.x * 4 + wave; q < a.nq; q += (int64_t)gridDim.x * 4) {
+        const uint16_t* tq = a.t + q * 4096;
+        const uint16_t* xq = a.x + q * (int64_t)a.p * 64;
+        bf16x8 af[2][4], bfr[2][4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob)                        // MFMA row m <-> output channel 16 (m >> 2) + 4 ob + (m & 3): 16 consecutive per lane in the result
+                af[s][ob] = as_frag(t_chunk(tq, 16 * (n >> 2) + 4 * ob + (n & 3), 32 * s + 8 * g, a.add_identity));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = 16 * t + n < a.p ? 16 * t + n : a.p - 1;
+                const u32x4 raw = *(const u32x4*)(xq + row * 64 + 32 * s + 8 * g);
+                bfr[s][t] = as_frag((has_act || a.relu) ? act8(raw, sc[s], sh[s], floor_) : raw);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) {
+                acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s][ob], bfr[s][t], acc[ob], 0, 0, 0);
+            }
+            if (16 * t + n < a.p) {
+                uint16_t* dst = a.out + (q * a.p + 16 * t + n) * 64 + 16 * g;
+                *(u32x4*)dst = u32x4{pack2(acc[0][0], acc[0][1]), pack2(acc[0][2], acc[0][3]), pack2(acc[1][0], acc[1][1]), pack2(acc[1][2], acc[1][3])};
+                *(u32x4*)(dst + 8) = u32x4{pack2(acc[2][0], acc[2][1]), pack2(acc[2][2], acc[2][3]), pack2(acc[3][0], acc[3][1]), pack2(acc[3][2], acc[3][3])};
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ u32x2 lds_tr_read(const uint16_t* p);
+__device__ __forceinline__ void lds_tr_wait(u32x2& v);
+
+constexpr int PT_PITCH = 80;            // LDS row pitch in elements (64 + 16)
+
+__global__ __launch_bounds__(256, 2) void patch_transform_bwd_kernel(const PtArgs a) {
+    __shared__ __attribute__((aligned(16))) uint16_t timg[64 * PT_PITCH], ximg[64 * PT_PITCH], gimg[64 * PT_PITCH];
+    __shared__ float scl[64], shl[64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, i16 = lane & 15, kg = lane >> 4;
+    const bool has_act = a.scale != nullptr;
+    const float floor_ = a.relu ? 0.f : -INFINITY;
+    if (threadIdx.x < 64) { scl[threadIdx.x] = has_act ? a.scale[threadIdx.x] : 1.f; shl[threadIdx.x] = has_act ? a.shift[threadIdx.x] : 0.f; }
+    __syncthreads();
+    float dsc[4] = {0.f, 0.f, 0.f, 0.f}, dsh[4] = {0.f, 0.f, 0.f, 0.f};       // channels 16 w + 4 kg + r
+    const f32x4 sc4 = *(const f32x4*)(scl + 16 * w + 4 * kg), sh4 = *(const f32x4*)(shl + 16 * w + 4 * kg);
+
+    for (int64_t q = blockIdx.x; q < a.nq; q += gridDim.x) {
+        const uint16_t* tq = a.t + q * 4096;
+        const uint16_t* xq = a.x + q * (int64_t)a.p * 64;
+        const uint16_t* gq = a.g + q * (int64_t)a.p * 64;
+        __syncthreads();                                          // the previous group's operands have been read
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int id = threadIdx.x + 256 * it, row = id >> 3, ch = id & 7;
+            *(u32x4*)(timg + row * PT_PITCH + 8 * ch) = t_chunk(tq, row, 8 * ch, a.add_identity);
+            u32x4 xv = {0, 0, 0, 0}, gv = {0, 0, 0, 0};
+            if (row < a.p) {
+                xv = *(const u32x4*)(xq + row * 64 + 8 * ch);
+                gv = *(const u32x4*)(gq + row * 64 + 8 * ch);
+                if (has_act || a.relu) xv = act8(xv, scl + 8 * ch, shl + 8 * ch, floor_);
+            }
+            *(u32x4*)(ximg + row * PT_PITCH + 8 * ch) = xv;       // rows beyond p: zeros in both operands
+            *(u32x4*)(gimg + row * PT_PITCH + 8 * ch) = gv;
+        }
+        __syncthreads();
+        const int prow = 4 * kg + (i16 >> 2), pcol = 4 * (i16 & 3);
+
+        // ---- dA[i][k] = sum_j G[i][j] T[j][k]:  D[m <-> k = 16 w + m][n <-> row i],  contraction over j in two steps of 32
+        f32x4 da[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) da[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x2 a0 = lds_tr_read(timg + (32 * s + prow) * PT_PITCH + 16 * w + pcol);
+            u32x2 a1 = lds_tr_read(timg + (32 * s + 16 + prow) * PT_PITCH + 16 * w + pcol);
+            lds_tr_wait(a0); lds_tr_wait(a1);
+            const u32x4 am = {a0.x, a0.y, a1.x, a1.y};            // element e < 4: j = 32 s + 4 kg + e;  e >= 4: j = 32 s + 16 + 4 kg + e - 4
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint16_t* gr = gimg + (16 * t + i16) * PT_PITCH + 32 * s + 4 * kg;
+                const u32x2 b0 = *(const u32x2*)gr, b1 = *(const u32x2*)(gr + 16);
+                const u32x4 bm = {b0.x, b0.y, b1.x, b1.y};
+                da[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(am), as_frag(bm), da[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = 16 * t + i16;
+            if (row < a.p) {
+                const int64_t off = (q * a.p + row) * 64 + 16 * w + 4 * kg;
+                const u32x2 xr = *(const u32x2*)(a.x + off);
+                const float x4[4] = {lo16(xr.x), hi16(xr.x), lo16(xr.y), hi16(xr.y)};
+                float d[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pre = __builtin_fmaf(x4[r], sc4[r], sh4[r]);
+                    d[r] = pre > floor_ ? da[t][r] : 0.f;
+                    dsc[r] += d[r] * x4[r];
+                    dsh[r] += d[r];
+                    d[r] *= sc4[r];
+                }
+                *(u32x2*)(a.dx + off) = u32x2{pack2(d[0], d[1]), pack2(d[2], d[3])};
+            }
+        }
+
+        // ---- dT[j][k] = sum_i G[i][j] act(x)[i][k]:  D[m <-> k = 16 (m >> 2) + 4 kb + (m & 3)][n <-> j = 16 w + n],  contraction over rows
+        f32x4 dtv[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) dtv[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x2 b0 = lds_tr_read(gimg + (32 * s + prow) * PT_PITCH + 16 * w + pcol);
+            u32x2 b1 = lds_tr_read(gimg + (32 * s + 16 + prow) * PT_PITCH + 16 * w + pcol);
+            u32x2 x0[4], x1[4];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {                      // the four 4-column pieces of the block sit 16 columns apart: lane m receives column 16 (m >> 2) + 4 kb + (m & 3)
+                x0[kb] = lds_tr_read(ximg + (32 * s + prow) * PT_PITCH + 16 * (i16 & 3) + 4 * kb);
+                x1[kb] = lds_tr_read(ximg + (32 * s + 16 + prow) * PT_PITCH + 16 * (i16 & 3) + 4 * kb);
+            }
+            lds_tr_wait(b0); lds_tr_wait(b1);
+            const u32x4 bm = {b0.x, b0.y, b1.x, b1.y};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                lds_tr_wait(x0[kb]); lds_tr_wait(x1[kb]);
+                const u32x4 am = {x0[kb].x, x0[kb].y, x1[kb].x, x1[kb].y};
+                dtv[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(am), as_frag(bm), dtv[kb], 0, 0, 0);
+            }
+        }
+        {
+            uint16_t* dst = a.dt + q * 4096 + (16 * w + i16) * 64 + 16 * kg;      // lane (j = 16 w + i16, kg): k = 16 kg + 4 kb + r
+            *(u32x4*)dst = u32x4{pack2(dtv[0][0], dtv[0][1]), pack2(dtv[0][2], dtv[0][3]), pack2(dtv[1][0], dtv[1][1]), pack2(dtv[1][2], dtv[1][3])};
+            *(u32x4*)(dst + 8) = u32x4{pack2(dtv[2][0], dtv[2][1]), pack2(dtv[2][2], dtv[2][3]), pack2(dtv[3][0], dtv[3][1]), pack2(dtv[3][2], dtv[3][3])};
+        }
+    }
+    if (a.partials) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float s0 = row16_sum(dsc[r]), s1 = row16_sum(dsh[r]);
+            if (i16 == 0) {
+                a.partials[(int64_t)blockIdx.x * 128 + 16 * w + 4 * kg + r] = s0;
+                a.partials[(int64_t)blockIdx.x * 128 + 64 + 16 * w + 4 * kg + r] = s1;
+            }
+        }
+    }
+}
+
 int g_cus = 0;
 int cu_count() {
     if (g_cus == 0) {
@@ -689,6 +974,81 @@ size_t pps_rows_layer_ws_bytes(int cin, int cout) {
     if (!dim_ok(cin) || !dim_ok(cout)) return 0;
     const size_t big = (size_t)(cin > cout ? cin : cout);
     return (size_t)MAXP * (2 * big + (size_t)cin * cout + cout) * sizeof(float) + (size_t)2 * cout * sizeof(float);
+}
+
+/* conv0a of PointNet in train(): y [rows, 64] bf16 = x [rows, 3] w^T + bias, batch statistics -> out_affine / save / running statistics as in
+ * pps_rows_layer_fwd; backward: dw [64, 3], dbias [64] (NULL = skip), dgamma, dbeta (x gets no gradient: it is the input patch).
+ * ws: pps_rows3_ws_bytes() bytes. */
+size_t pps_rows3_ws_bytes() { return (size_t)((MAXP * 4 + 1) * 256 + 128 + 256) * sizeof(float); }
+
+int pps_rows3_fwd(const float* x, int64_t rows, const float* w, const float* bias, void* y, const float* gamma, const float* beta,
+                  float* running_mean, float* running_var, float momentum, float eps, float* out_affine, float* save, void* ws, void* stream) {
+    if (rows < 1 || !x || !w || !y || !ws) return PPS_ERR_ARG;
+    const bool bn = gamma != nullptr;
+    if (bn && (!beta || !out_affine || !save)) return PPS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t blocks = (rows + R3_ROWS - 1) / R3_ROWS;
+    const int grid = (int)(blocks < 4 * MAXP ? blocks : 4 * MAXP);
+    hipLaunchKernelGGL(rows3_fwd_kernel, dim3(grid), dim3(256), 0, st, x, w, bias, rows, (uint16_t*)y, bn ? (float*)ws : nullptr);
+    if (bn)
+        hipLaunchKernelGGL(bn_affine_kernel, dim3(4), dim3(256), 0, st, (const float*)ws, grid, 64, (double)rows, gamma, beta, running_mean, running_var,
+                           momentum, eps, out_affine, save);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+int pps_rows3_bwd(const float* x, const void* y, const void* gy, int64_t rows, const float* gamma, const float* save, const float* d_affine,
+                  float* dw, float* dbias, float* dgamma, float* dbeta, void* ws, void* stream) {
+    if (rows < 1 || !x || !gy || !dw || !ws) return PPS_ERR_ARG;
+    const bool bn = gamma != nullptr;
+    if (bn && (!y || !save || !d_affine || !dgamma || !dbeta)) return PPS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)ws;
+    float* total = part + (size_t)MAXP * 4 * 256;                 // [256]: dW [64][3] then db [64]
+    float* gstat = total + 256;                                   // [2][64]
+    if (bn) hipLaunchKernelGGL(bn_affine_bwd_kernel, dim3(1), dim3(64), 0, st, d_affine, save, gamma, 64, (double)rows, gstat, dgamma, dbeta);
+    const int64_t blocks = (rows + R3_ROWS - 1) / R3_ROWS;
+    const int grid = (int)(blocks < 4 * MAXP ? blocks : 4 * MAXP);
+    hipLaunchKernelGGL(rows3_bwd_kernel, dim3(grid), dim3(256), 0, st, x, (const uint16_t*)y, (const uint16_t*)gy, bn ? gstat : nullptr, rows, part);
+    launch_sum_partials(part, grid, 256, total, st);
+    if (hipMemcpyAsync(dw, total, 192 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return PPS_ERR_LAUNCH;
+    if (dbias && hipMemcpyAsync(dbias, total + 192, 64 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return PPS_ERR_LAUNCH;
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+/* Feature transform of PointNet in train() (source/base/nn.py:330-331): out[q,i,:] = act(x)[q,i,:] T[q]^T per group q of p <= 64 rows.
+ * x [q*p, 64] bf16 stored activation with act = relu?(x * in_scale + in_shift) (NULL = identity), T [q, 64, 64] bf16 (+ I if add_identity),
+ * out [q*p, 64] bf16.  Backward from g = d out: dx [q*p, 64] bf16, dt [q, 64, 64] bf16, d_in_affine [2][64] (NULL = skip).
+ * ws: pps_patch_transform_ws_bytes() bytes. */
+size_t pps_patch_transform_ws_bytes() { return (size_t)4 * MAXP * 128 * sizeof(float); }
+
+int pps_patch_transform_fwd(const void* x, const float* in_scale, const float* in_shift, int in_relu, const void* t, int add_identity, int64_t q,
+                            int p, void* out, void* stream) {
+    if (q < 0 || p < 1 || p > 64 || ((in_scale == nullptr) != (in_shift == nullptr)) || (!in_scale && in_relu)) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    if (!x || !t || !out) return PPS_ERR_ARG;
+    PtArgs a{};
+    a.x = (const uint16_t*)x; a.scale = in_scale; a.shift = in_shift; a.relu = in_relu; a.t = (const uint16_t*)t; a.add_identity = add_identity;
+    a.nq = q; a.p = p; a.out = (uint16_t*)out;
+    const int64_t blocks = (q + 3) / 4;
+    const int grid = (int)(blocks < 8 * (int64_t)cu_count() ? blocks : 8 * (int64_t)cu_count());
+    hipLaunchKernelGGL(patch_transform_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+int pps_patch_transform_bwd(const void* x, const float* in_scale, const float* in_shift, int in_relu, const void* t, int add_identity, const void* g,
+                            int64_t q, int p, void* dx, void* dt, float* d_in_affine, void* ws, void* stream) {
+    if (q < 0 || p < 1 || p > 64 || ((in_scale == nullptr) != (in_shift == nullptr)) || (!in_scale && in_relu)) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    if (!x || !t || !g || !dx || !dt || !ws) return PPS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    PtArgs a{};
+    a.x = (const uint16_t*)x; a.scale = in_scale; a.shift = in_shift; a.relu = in_relu; a.t = (const uint16_t*)t; a.add_identity = add_identity;
+    a.nq = q; a.p = p; a.g = (const uint16_t*)g; a.dx = (uint16_t*)dx; a.dt = (uint16_t*)dt;
+    a.partials = d_in_affine ? (float*)ws : nullptr;
+    const int grid = (int)(q < 4 * (int64_t)MAXP ? q : 4 * (int64_t)MAXP);
+    hipLaunchKernelGGL(patch_transform_bwd_kernel, dim3(grid), dim3(256), 0, st, a);
+    if (d_in_affine) launch_sum_partials((const float*)ws, grid, 128, d_in_affine, st);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 
 int pps_rows_extrema_bf16(const void* x, int64_t groups, int p, int c, float* mx, float* mn, int* amx, int* amn, void* stream) {

@@ -341,18 +341,20 @@ def _stn_fused(t, act, nq, p):
     z = train_ops.act_max(z, nq, p)
     z = batch_norm(t.bn4, dense(t.fc1, z), relu=True)
     z = batch_norm(t.bn5, dense(t.fc2, z), relu=True)
-    z = dense(t.fc3, z) + torch.eye(d, dtype=z.dtype, device=z.device).reshape(1, d * d)
-    return z.view(nq, d, d)
+    return dense(t.fc3, z).view(nq, d, d)                  # WITHOUT the identity (:188): the feature transform adds it on load
 
 
-def _pointnet_fused(pn, patches):
+def _pointnet_fused(pn, patches, need_trans=True):
     """pointnet() with the 64..256-channel row layers as fused ops (pps_rows_train.hip): per layer the raw output is written once and read
     by its consumers, which apply BatchNorm + ReLU on load."""
     nq, p, _ = patches.shape
-    h = batch_norm(pn.bn0a, dense(pn.conv0a, patches.reshape(nq * p, 3)), relu=True)            # 3 input channels: not an MFMA shape
-    l0b = _layer(train_ops.Act(h), pn.conv0b, pn.bn0b, True)
-    trans2 = _stn_fused(pn.stn2, l0b, nq, p)
-    h = torch.bmm(l0b.materialize().view(nq, p, -1), trans2.transpose(1, 2).to(torch.bfloat16)).reshape(nq * p, -1)
+    _count_batch(pn.bn0a)
+    l0a = train_ops.rows3_layer(patches.reshape(nq * p, 3), _w2d(pn.conv0a), pn.conv0a.bias, pn.bn0a, True)   # 3 input channels: not an MFMA shape
+    l0b = _layer(l0a, pn.conv0b, pn.bn0b, True)
+    t_raw = _stn_fused(pn.stn2, l0b, nq, p)
+    h = train_ops.patch_transform(l0b, t_raw, p)                     # (t_raw + I) applied to every patch point: trans2 @ x (:330-331)
+    d = pn.stn2.dim
+    trans2 = t_raw.detach().float() + torch.eye(d, device=h.device).view(1, d, d) if need_trans else None
     z = _layer(train_ops.Act(h), pn.conv1, pn.bn1, True)
     z = _layer(z, pn.conv2, pn.bn2, True)
     z = _layer(z, pn.conv3, pn.bn3, False)
@@ -368,13 +370,14 @@ def _pointnet_fused(pn, patches):
 
 
 @_counted
-def pointnet(pn, patches):
-    """patches [Q', P, 3] -> (feat [Q', C], trans2 [Q', 64, 64])."""
+def pointnet(pn, patches, need_trans=True):
+    """patches [Q', P, 3] -> (feat [Q', C], trans2 [Q', 64, 64] or None if not need_trans)."""
     nq, p, _ = patches.shape
     t = pn.stn2
     if (FUSED_ROWS and fused_rows_ok(patches, pn.bn0a, pn.bn0b, pn.bn1, pn.bn2, pn.bn3, t.bn1, t.bn2, t.bn3)
-            and train_ops.patch_attn_supported(p, _w2d(pn.conv3).shape[0])):
-        return _pointnet_fused(pn, patches)
+            and train_ops.patch_attn_supported(p, _w2d(pn.conv3).shape[0]) and train_ops.patch_transform_supported(p, t.dim)
+            and tuple(_w2d(pn.conv0a).shape) == (64, 3)):
+        return _pointnet_fused(pn, patches, need_trans)
     h = batch_norm(pn.bn0a, dense(pn.conv0a, patches.reshape(nq * p, 3)), relu=True)
     h = batch_norm(pn.bn0b, dense(pn.conv0b, h), relu=True)
     trans2 = stn(pn.stn2, h, nq, p)
@@ -413,7 +416,7 @@ def ppsurf_from_latent(net, latents, data, proj_ids):
     b, q = query.shape[0], query.shape[1]
     feat_proj = interp_attention(net.projection, latents, pts, query, proj_ids)
     pl = data['pts_local_ps']
-    feat_pn, _ = pointnet(net.point_net, pl.reshape(b * q, pl.shape[2], 3))
+    feat_pn, _ = pointnet(net.point_net, pl.reshape(b * q, pl.shape[2], 3), need_trans=False)
     out = mlp(net.mlp, feat_proj.reshape(b * q, -1) + feat_pn)
     return out.view(b, q, -1).transpose(1, 2)
 

@@ -344,6 +344,99 @@ class _RowsLayer(torch.autograd.Function):
         return (dx if need_dx else None, d_in, None, dw.to(wdt), None if db is None else db.to(bdt), dgamma, dbeta, None, None, None, None)
 
 
+class _Rows3Layer(torch.autograd.Function):
+    """conv0a of PointNet in train(): x [rows, 3] fp32 -> (y [rows, 64] bf16, out_affine [2, 64] of the BatchNorm on y); x gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, momentum, eps):
+        _need_cuda(x, w)
+        L = _lib.lib()
+        x = x.detach().float().contiguous()
+        rows = x.shape[0]
+        w32 = w.detach().float().contiguous()
+        b32 = None if b is None else b.detach().float().contiguous()
+        g32, be32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        y = torch.empty((rows, 64), device=x.device, dtype=torch.bfloat16)
+        aff, save = torch.empty((2, 64), device=x.device), torch.empty((2, 64), device=x.device)
+        ws = torch.empty((L.pps_rows3_ws_bytes(),), device=x.device, dtype=torch.uint8)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        _lib.check(L.pps_rows3_fwd(x.data_ptr(), rows, w32.data_ptr(), ptr(b32), y.data_ptr(), g32.data_ptr(), be32.data_ptr(), ptr(running_mean),
+                                   ptr(running_var), float(momentum), float(eps), aff.data_ptr(), save.data_ptr(), ws.data_ptr(), _stream()), 'pps_rows3_fwd')
+        ctx.save_for_backward(x, y, g32, save)
+        ctx.meta = (b is not None, w.dtype, None if b is None else b.dtype)
+        return y, aff
+
+    @staticmethod
+    def backward(ctx, gy, g_aff):
+        x, y, g32, save = ctx.saved_tensors
+        has_b, wdt, bdt = ctx.meta
+        L = _lib.lib()
+        dev = x.device
+        gy = gy.to(torch.bfloat16).contiguous()
+        g_aff = torch.zeros((2, 64), device=dev) if g_aff is None else g_aff.float().contiguous()
+        dw = torch.empty((64, 3), device=dev)
+        db = torch.empty((64,), device=dev) if has_b else None
+        dgamma, dbeta = torch.empty((64,), device=dev), torch.empty((64,), device=dev)
+        ws = torch.empty((L.pps_rows3_ws_bytes(),), device=dev, dtype=torch.uint8)
+        _lib.check(L.pps_rows3_bwd(x.data_ptr(), y.data_ptr(), gy.data_ptr(), x.shape[0], g32.data_ptr(), save.data_ptr(), g_aff.data_ptr(), dw.data_ptr(),
+                                   None if db is None else db.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream()), 'pps_rows3_bwd')
+        return None, dw.to(wdt), None if db is None else db.to(bdt), dgamma, dbeta, None, None, None, None
+
+
+def rows3_layer(x, w, b, bn, relu=True):
+    """x [rows, 3] -> Act(raw [rows, 64] bf16, affine of bn (train() statistics), relu)."""
+    y, aff = _Rows3Layer.apply(x, w, b, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+    return Act(y, aff, relu)
+
+
+class _PatchTransform(torch.autograd.Function):
+    """out[q, i, :] = act(x)[q, i, :] (T[q] + I)^T for groups of p <= 64 rows (PointNet's feature transform, nn.py:330-331): x [Q*p, 64] stored
+    activation, t [Q, 64, 64] the RAW output of the STN's fc3 (the identity is added inside) -> [Q*p, 64] bf16."""
+
+    @staticmethod
+    def forward(ctx, x, affine, relu, t, p):
+        _need_cuda(x, t)
+        L = _lib.lib()
+        x = x.to(torch.bfloat16).contiguous()
+        t16 = t.to(torch.bfloat16).contiguous()
+        nq = t16.shape[0]
+        aff = None if affine is None else affine.detach().float().contiguous()
+        out = torch.empty_like(x)
+        _lib.check(L.pps_patch_transform_fwd(x.data_ptr(), None if aff is None else aff.data_ptr(), None if aff is None else aff.data_ptr() + 256,
+                                             int(bool(relu)), t16.data_ptr(), 1, nq, p, out.data_ptr(), _stream()), 'pps_patch_transform_fwd')
+        ctx.save_for_backward(x, aff, t16)
+        ctx.meta = (bool(relu), p, t.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, aff, t16 = ctx.saved_tensors
+        relu, p, tdt = ctx.meta
+        L = _lib.lib()
+        nq = t16.shape[0]
+        g = g.to(torch.bfloat16).contiguous()
+        dx, dt = torch.empty_like(x), torch.empty_like(t16)
+        need_daff = aff is not None and ctx.needs_input_grad[1]
+        daff = torch.empty((2, 64), device=x.device) if need_daff else None
+        ws = torch.empty((L.pps_patch_transform_ws_bytes(),), device=x.device, dtype=torch.uint8)
+        _lib.check(L.pps_patch_transform_bwd(x.data_ptr(), None if aff is None else aff.data_ptr(), None if aff is None else aff.data_ptr() + 256,
+                                             int(relu), t16.data_ptr(), 1, g.data_ptr(), nq, p, dx.data_ptr(), dt.data_ptr(),
+                                             None if daff is None else daff.data_ptr(), ws.data_ptr(), _stream()), 'pps_patch_transform_bwd')
+        return dx, daff, None, dt.to(tdt), None
+
+
+def patch_transform_supported(p, c):
+    return 1 <= p <= 64 and c == 64
+
+
+def patch_transform(act, t_raw, p):
+    """act: Act with 64 channels; t_raw [Q, 64, 64] (fc3 output, identity not yet added) -> [Q*p, 64] bf16."""
+    aff = act.affine
+    if aff is None and act.relu:
+        aff = torch.cat([torch.ones((1, 64), device=act.raw.device), torch.zeros((1, 64), device=act.raw.device)])
+    return _PatchTransform.apply(act.raw, aff, act.relu, t_raw, p)
+
+
 class _PatchAttn(torch.autograd.Function):
     """pooled[q] = sum_j softmax_j(h[q,j] . v) h[q,j] over the k <= 64 rows of every group, h [Q, k, 256] bf16 -> [Q, 256] fp32: logits, softmax
     and pooling in one kernel each way, h read once (pps_attn_train.hip)."""

@@ -280,3 +280,63 @@ def test_interpolation_head_with_fused_row_layers_is_as_close_to_fp32_as_the_sep
         if ef > 2.5 * es + 2e-2 * scale:
             worse.append((name, ef, es, scale))
     assert not worse, worse
+
+
+def test_rows3_layer_matches_torch():
+    from ppsurf_amd import train_ops
+    g = torch.Generator().manual_seed(21)
+    rows = 7013
+    x = (torch.randn(rows, 3, generator=g) * 0.5).to(DEV)
+    w, b = (torch.randn(64, 3, generator=g)).to(DEV), (torch.randn(64, generator=g) * 0.1).to(DEV)
+    gy = _bf(torch.randn(rows, 64, generator=g)).to(DEV)
+    ga = (torch.randn(2, 64, generator=g) * 30).to(DEV)
+
+    class H:
+        weight, bias = (torch.rand(64, generator=g) + 0.5).to(DEV).requires_grad_(True), torch.randn(64, generator=g).to(DEV).requires_grad_(True)
+        running_mean, running_var, momentum, eps = torch.zeros(64, device=DEV), torch.ones(64, device=DEV), 0.1, 1e-5
+    wo, bo = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    out = train_ops.rows3_layer(x, wo, bo, H, True)
+    ((out.raw.float() * gy).sum() + (out.affine * ga).sum()).backward()
+    wt, bt = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    gt, bet = H.weight.detach().double().requires_grad_(True), H.bias.detach().double().requires_grad_(True)
+    y = x.double() @ wt.t() + bt
+    yr = y + (y.float().to(torch.bfloat16).double() - y).detach()
+    mean = yr.mean(0)
+    var = (yr * yr).mean(0) - mean * mean
+    sc = gt / torch.sqrt(var + 1e-5)
+    aff = torch.stack([sc, bet - mean * sc])
+    ((y * gy.double()).sum() + (aff * ga.double()).sum()).backward()
+    rel = lambda a, c: float((a.detach().double() - c.detach()).abs().max()) / (float(c.detach().abs().max()) + 1e-12)
+    assert rel(out.raw.float(), y.detach()) <= 6e-3
+    assert rel(out.affine, aff.detach()) <= 2e-4
+    assert rel(wo.grad, wt.grad) <= 2e-3 and rel(bo.grad, bt.grad) <= 2e-3
+    assert rel(H.weight.grad, gt.grad) <= 2e-3 and rel(H.bias.grad, bet.grad) <= 2e-3
+    assert rel(H.running_mean, 0.1 * mean.detach()) <= 2e-4
+
+
+@pytest.mark.parametrize('nq,p,affine', [(37, 50, True), (5, 64, False), (130, 17, True)])
+def test_patch_transform_matches_torch(nq, p, affine):
+    from ppsurf_amd import train_ops
+    g = torch.Generator().manual_seed(nq + p)
+    x = _bf(torch.randn(nq * p, 64, generator=g)).to(DEV)
+    t = _bf(torch.randn(nq, 64, 64, generator=g) * 0.3).to(DEV)
+    aff = torch.stack([torch.randn(64, generator=g) * 0.3 + 1, torch.randn(64, generator=g) * 0.3]).to(DEV) if affine else None
+    go = _bf(torch.randn(nq * p, 64, generator=g)).to(DEV)
+    xo, to_ = x.to(torch.bfloat16).requires_grad_(True), t.to(torch.bfloat16).requires_grad_(True)
+    ao = aff.clone().requires_grad_(True) if affine else None
+    out = train_ops.patch_transform(train_ops.Act(xo, ao, affine), to_, p)
+    (out.float() * go).sum().backward()
+    xt, tt = x.double().requires_grad_(True), t.double().requires_grad_(True)
+    at = aff.double().requires_grad_(True) if affine else None
+    a = torch.relu(xt * at[0] + at[1]) if affine else xt
+    a = a + (a.float().to(torch.bfloat16).double() - a).detach()                         # the operand is bf16
+    tm = tt + torch.eye(64, device=DEV, dtype=torch.float64)
+    tm = tm + (tm.float().to(torch.bfloat16).double() - tm).detach()
+    ref = torch.bmm(a.view(nq, p, 64), tm.transpose(1, 2)).reshape(nq * p, 64)
+    (ref * go.double()).sum().backward()
+    rel = lambda u, v: float((u.detach().double() - v.detach()).abs().max()) / (float(v.detach().abs().max()) + 1e-12)
+    assert rel(out.float(), ref.detach()) <= 6e-3
+    assert rel(xo.grad.float(), xt.grad) <= 8e-3
+    assert rel(to_.grad.float(), tt.grad) <= 8e-3
+    if affine:
+        assert rel(ao.grad, at.grad) <= 2e-3

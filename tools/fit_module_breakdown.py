@@ -31,7 +31,7 @@ def main():
     full = timed(step, a.steps)
     real_pn, real_ia = train_graph.pointnet, train_graph.interp_attention
 
-    def no_pn(pn, patches):
+    def no_pn(pn, patches, need_trans=True):
         return torch.zeros((patches.shape[0], 256), device=patches.device, dtype=torch.float32), None
 
     def no_ia(proj, latents, pts, query, ids, last_layer=True):

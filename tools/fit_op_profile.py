@@ -21,7 +21,7 @@ def main():
     step = workloads.FitStep()
     if a.encoder_only:
         from ppsurf_amd import train_graph
-        train_graph.pointnet = lambda pn, patches: (torch.zeros((patches.shape[0], 256), device=patches.device), None)
+        train_graph.pointnet = lambda pn, patches, need_trans=True: (torch.zeros((patches.shape[0], 256), device=patches.device), None)
         train_graph.interp_attention = lambda proj, latents, pts, query, ids, last_layer=True: (latents.sum() * 0).expand(query.shape[0], query.shape[1], 256)
     for _ in range(3):
         step()
