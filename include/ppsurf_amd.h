@@ -305,7 +305,7 @@ int pps_attn_pool_bwd(const void* qy, const void* h, const void* dpooled, int64_
  * batch statistics taken on store (replaces the conv -> bn -> relu -> conv chains of source/base/nn.py:162-190, 323-336, 376-417 and the
  * fc -> relu -> fc chain of source/poco_model.py:400-410 under autograd and bf16 autocast; pps_rows_train.hip).
  *   x [rows, cin], y [rows, cout] bfloat16 RAW layer outputs; cin, cout in {64, 128, 256} (pps_rows_layer_supported)
- *   act(x) = relu?(x * in_scale + in_shift)   (in_scale / in_shift [cin], both NULL = identity; in_relu needs them)
+ *   act(x) = relu?(x * in_scale + in_shift)   (in_scale / in_shift [cin], both NULL = no affine part: identity, or a bare ReLU with in_relu)
  *   fwd:  y = act(x) w^T + bias  (w [cout, cin] fp32, rounded to bf16 for the product; bias NULL = none).  With gamma != NULL the batch
  *         statistics of y give out_affine [2][cout] = (gamma rstd, beta - mean gamma rstd), save [2][cout] = (mean, rstd) and the
  *         running statistics are updated like torch.nn.BatchNorm1d (both NULL = not tracked).

@@ -208,18 +208,21 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// 64 per-lane partial sums (one per row) -> lane l holds the total of row l: recursive halving, 63 shuffles instead of 64 x 6
-__device__ __forceinline__ float rows_to_lanes(float (&p)[PA_K], int lane) {
+// 64 per-lane partial sums (one per row) -> lane l holds the total of row l: recursive halving, 63 shuffles instead of 64 x 6.
+// (template recursion: every array index is a compile-time constant, the array stays in registers)
+template <int HALF>
+__device__ __forceinline__ void halve_rows(float (&p)[PA_K], int lane) {
+    const bool up = (lane & HALF) != 0;
 #pragma unroll
-    for (int half = 32; half >= 1; half >>= 1) {
-        const bool up = (lane & half) != 0;
-#pragma unroll
-        for (int i = 0; i < half; ++i) {
-            const float send = up ? p[i] : p[i + half];
-            const float keep = up ? p[i + half] : p[i];
-            p[i] = keep + __shfl_xor(send, half);
-        }
+    for (int i = 0; i < HALF; ++i) {
+        const float send = up ? p[i] : p[i + HALF];
+        const float keep = up ? p[i + HALF] : p[i];
+        p[i] = keep + __shfl_xor(send, HALF);
     }
+    if constexpr (HALF > 1) halve_rows<HALF / 2>(p, lane);
+}
+__device__ __forceinline__ float rows_to_lanes(float (&p)[PA_K], int lane) {
+    halve_rows<32>(p, lane);
     return p[0];
 }
 

@@ -56,6 +56,14 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {                   
 }
 __device__ __forceinline__ bf16x8 as_frag(const u32x4& u) { return *(const bf16x8*)&u; }
 
+// ReLU of 8 packed bf16: negative values (sign bit set) are negative as int16 too: v_pk_max_i16 with 0
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned relu_bf16x2(unsigned u) {
+    const s16x2 v = __builtin_elementwise_max(*(const s16x2*)&u, s16x2{0, 0});
+    return *(const unsigned*)&v;
+}
+__device__ __forceinline__ u32x4 relu_bf16x8(const u32x4& q) { return u32x4{relu_bf16x2(q.x), relu_bf16x2(q.y), relu_bf16x2(q.z), relu_bf16x2(q.w)}; }
+
 // output channel of MFMA row m = 4 g + r of 16-row block ob: lane (row n, g) then holds, over the 4 blocks of a group and r = 0..3,
 // the 16 consecutive channels 64 (ob >> 2) + 16 g + [4 (ob & 3) + r]
 __device__ __forceinline__ void block_row_of(int c, int& ob, int& m) {
@@ -145,6 +153,7 @@ __global__ __launch_bounds__(NT, 1) void rows_layer_kernel(const LayerArgs a) {
     __syncthreads();
 
     const float relu_floor = a.pre_relu ? 0.f : -INFINITY;
+    const bool bare_relu = !DX && !has_pre && a.pre_relu;        // ReLU without an affine part: integer max on the packed pairs
     const bool dx_y = DX && a.src2 != nullptr;
     const bool dx_x = DX && a.xin != nullptr;
     const float in_floor = a.in_relu ? 0.f : -INFINITY;
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(NT, 1) void rows_layer_kernel(const LayerArgs a) {
                     }
                 } else {
 #pragma unroll
-                    for (int t = 0; t < R; ++t) bfr[t] = as_frag(raw[sc][t]);
+                    for (int t = 0; t < R; ++t) bfr[t] = as_frag(bare_relu ? relu_bf16x8(raw[sc][t]) : raw[sc][t]);
                 }
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
@@ -345,8 +354,12 @@ __device__ __forceinline__ u32x2 lds_tr_read(const uint16_t* p) {
 __device__ __forceinline__ void lds_tr_wait(u32x2& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) : : "memory"); }
 
 template <int CI, int CO>
+constexpr int dw_ksteps() { return CI + CO <= 128 ? 4 : (CI + CO <= 384 ? 2 : 1); }
+
+template <int CI, int CO, bool HAS_Y>
 __global__ __launch_bounds__(NT, 1) void rows_dw_kernel(const DwArgs a) {
-    constexpr int KR = 32;                          // rows per step = the contraction length of one MFMA
+    constexpr int KRS = dw_ksteps<CI, CO>();        // MFMA contraction steps (32 rows each) per staged tile: narrow layers stage more rows per barrier
+    constexpr int KR = 32 * KRS;                    // rows per step
     constexpr int PG = CO + 16, PA = CI + 16;       // LDS row pitch in elements: + 32 bytes keeps the transpose reads of a half-wave on 64 banks
     constexpr int WM = 4, WN = 2;                   // waves along cout / cin
     constexpr int MB = CO / 16 / WM, NBK = CI / 16 / WN;
@@ -359,12 +372,23 @@ __global__ __launch_bounds__(NT, 1) void rows_dw_kernel(const DwArgs a) {
     float* gs = prm, *gq2 = prm + CO, *isc = prm + 2 * CO, *ish = prm + 2 * CO + CI;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, kg = lane >> 4;
     const int wm = wave % WM, wn = wave / WM;
-    const bool has_y = a.y != nullptr, has_aff = a.in_scale != nullptr;
-    for (int i = threadIdx.x; i < CO; i += NT) { gs[i] = has_y ? a.gs[i] : 0.f; gq2[i] = has_y ? a.gq2[i] : 0.f; }
-    for (int i = threadIdx.x; i < CI; i += NT) { isc[i] = has_aff ? a.in_scale[i] : 1.f; ish[i] = has_aff ? a.in_shift[i] : 0.f; }
+    constexpr bool has_y = HAS_Y;                                           // a.y != NULL: the statistics of y carry gradient (a BatchNorm follows)
+    const bool has_aff = a.in_scale != nullptr;
+    // per-channel parameters, stored [j][chunk] (channel 8 chunk + j): the threads of a wave hold consecutive chunks, so reading element j of
+    // every chunk is conflict-free (channel-major storage is an 8-way bank conflict per read -- it doubled the kernel's time)
+    for (int i = threadIdx.x; i < CO; i += NT) {
+        const int t = (i & 7) * (CO / 8) + (i >> 3);
+        gs[t] = has_y ? a.gs[i] : 0.f;
+        gq2[t] = has_y ? a.gq2[i] : 0.f;
+    }
+    for (int i = threadIdx.x; i < CI; i += NT) {
+        const int t = (i & 7) * (CI / 8) + (i >> 3);
+        isc[t] = has_aff ? a.in_scale[i] : 1.f;
+        ish[t] = has_aff ? a.in_shift[i] : 0.f;
+    }
     __syncthreads();
     const float in_floor = a.in_relu ? 0.f : -INFINITY;
-    const bool transform_x = has_aff || a.in_relu;
+    const bool relu_only = !has_aff && a.in_relu;                 // a bare ReLU on the input: integer max on the packed bf16 pairs
 
     // slab of rows of this workgroup: whole steps of KR rows
     const int64_t nsteps = (a.rows + KR - 1) / KR;
@@ -380,28 +404,30 @@ __global__ __launch_bounds__(NT, 1) void rows_dw_kernel(const DwArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) db[j] = 0.f;
 
-    u32x4 rg[GIT], ry[GIT], rx[AIT];
-    auto fetch = [&](int64_t step) {
+    struct Regs { u32x4 g[GIT], y[HAS_Y ? GIT : 1], x[AIT]; };
+    auto fetch = [&](Regs& rr_, int64_t step) {
+        u32x4 (&rg)[GIT] = rr_.g; u32x4 (&ry)[HAS_Y ? GIT : 1] = rr_.y; u32x4 (&rx)[AIT] = rr_.x;
         const int64_t r0 = step * KR;
 #pragma unroll
         for (int it = 0; it < GIT; ++it) {
             const int id = threadIdx.x + NT * it;
             const int row = id / (CO / 8), ch = id % (CO / 8);
-            const int64_t rr = r0 + row;
-            const bool ok = id < GCH && rr < a.rows;
-            rg[it] = ok ? *(const u32x4*)(a.gy + rr * CO + 8 * ch) : u32x4{0, 0, 0, 0};
-            if (has_y) ry[it] = ok ? *(const u32x4*)(a.y + rr * CO + 8 * ch) : u32x4{0, 0, 0, 0};
+            const int64_t rr = r0 + row < a.rows ? r0 + row : a.rows - 1;     // rows past the end re-read the last row (zeroed when staged): no
+            if (id < GCH) {                                                  // lane-dependent branch around the loads, they all issue back to back
+                rg[it] = *(const u32x4*)(a.gy + rr * CO + 8 * ch);
+                if constexpr (HAS_Y) ry[it] = *(const u32x4*)(a.y + rr * CO + 8 * ch);
+            }
         }
 #pragma unroll
         for (int it = 0; it < AIT; ++it) {
             const int id = threadIdx.x + NT * it;
             const int row = id / (CI / 8), ch = id % (CI / 8);
-            const int64_t rr = r0 + row;
-            const bool ok = id < ACH && rr < a.rows;
-            rx[it] = ok ? *(const u32x4*)(a.x + rr * CI + 8 * ch) : u32x4{0, 0, 0, 0};
+            const int64_t rr = r0 + row < a.rows ? r0 + row : a.rows - 1;
+            if (id < ACH) rx[it] = *(const u32x4*)(a.x + rr * CI + 8 * ch);
         }
     };
-    auto stage = [&](int buf, int64_t step) {
+    auto stage = [&](const Regs& rr_, int buf, int64_t step) {
+        const u32x4 (&rg)[GIT] = rr_.g; const u32x4 (&ry)[HAS_Y ? GIT : 1] = rr_.y; const u32x4 (&rx)[AIT] = rr_.x;
         const int64_t r0 = step * KR;
         uint16_t* gdst = gimg + buf * KR * PG;
         uint16_t* adst = aimg + buf * KR * PA;
@@ -411,14 +437,18 @@ __global__ __launch_bounds__(NT, 1) void rows_dw_kernel(const DwArgs a) {
             if (id >= GCH) break;
             const int row = id / (CO / 8), ch = id % (CO / 8);
             const bool live = r0 + row < a.rows;
-            const u32x4 q = rg[it];
+            const u32x4 q = live ? rg[it] : u32x4{0, 0, 0, 0};
             float e[8] = {lo16(q.x), hi16(q.x), lo16(q.y), hi16(q.y), lo16(q.z), hi16(q.z), lo16(q.w), hi16(q.w)};
             u32x4 p = q;
-            if (has_y) {
+#ifdef PPS_ABL_DW_NOMATH
+            if constexpr (false) {
+#else
+            if constexpr (HAS_Y) {
+#endif
                 const u32x4 q2 = ry[it];
                 const float yv[8] = {lo16(q2.x), hi16(q2.x), lo16(q2.y), hi16(q2.y), lo16(q2.z), hi16(q2.z), lo16(q2.w), hi16(q2.w)};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) e[j] = live ? __builtin_fmaf(yv[j], gq2[8 * ch + j], e[j] + gs[8 * ch + j]) : 0.f;
+                for (int j = 0; j < 8; ++j) e[j] = live ? __builtin_fmaf(yv[j], gq2[j * (CO / 8) + ch], e[j] + gs[j * (CO / 8) + ch]) : 0.f;
                 p = u32x4{pack2(e[0], e[1]), pack2(e[2], e[3]), pack2(e[4], e[5]), pack2(e[6], e[7])};
                 e[0] = lo16(p.x); e[1] = hi16(p.x); e[2] = lo16(p.y); e[3] = hi16(p.y); e[4] = lo16(p.z); e[5] = hi16(p.z); e[6] = lo16(p.w); e[7] = hi16(p.w);
             }
@@ -432,29 +462,34 @@ __global__ __launch_bounds__(NT, 1) void rows_dw_kernel(const DwArgs a) {
             if (id >= ACH) break;
             const int row = id / (CI / 8), ch = id % (CI / 8);
             const bool live = r0 + row < a.rows;
-            u32x4 p = rx[it];
-            if (transform_x) {
+            u32x4 p = live ? rx[it] : u32x4{0, 0, 0, 0};
+            if (relu_only) p = relu_bf16x8(p);
+#ifdef PPS_ABL_DW_NOMATH
+            if (false) {
+#else
+            if (has_aff) {
+#endif
                 float e[8] = {lo16(p.x), hi16(p.x), lo16(p.y), hi16(p.y), lo16(p.z), hi16(p.z), lo16(p.w), hi16(p.w)};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) e[j] = live ? fmaxf(__builtin_fmaf(e[j], isc[8 * ch + j], ish[8 * ch + j]), in_floor) : 0.f;
+                for (int j = 0; j < 8; ++j) e[j] = live ? fmaxf(__builtin_fmaf(e[j], isc[j * (CI / 8) + ch], ish[j * (CI / 8) + ch]), in_floor) : 0.f;
                 p = u32x4{pack2(e[0], e[1]), pack2(e[2], e[3]), pack2(e[4], e[5]), pack2(e[6], e[7])};
             }
             *(u32x4*)(adst + row * PA + 8 * ch) = p;
         }
     };
 
-    if (s_begin < s_end) fetch(s_begin);
-    for (int64_t step = s_begin; step < s_end; ++step) {
-        const int buf = (int)((step - s_begin) & 1);
-        stage(buf, step);
-        if (step + 1 < s_end) fetch(step + 1);                      // in flight during the products below
-        __syncthreads();                                            // also orders: the products of step - 1 (other buffer) precede the stage of step + 1
-        const uint16_t* gsrc = gimg + buf * KR * PG;
-        const uint16_t* asrc = aimg + buf * KR * PA;
+    auto products = [&](int buf) {
+        const uint16_t* gbase = gimg + buf * KR * PG;
+        const uint16_t* abase = aimg + buf * KR * PA;
         // operand element j of lane (column i16, kg) = tile row (j < 4 ? 4 kg + j : 16 + 4 kg + j - 4): two transpose reads; lane i16 supplies
         // the 8-byte piece (row 4 kg + (i16 >> 2), columns 4 (i16 & 3) ..) of the 16-column block and receives column i16
         const int prow = 4 * kg + (i16 >> 2), pcol = 4 * (i16 & 3);
-        u32x2 af[MB][2], bf[NBK][2];
+        constexpr int KH = NBK > 4 ? 4 : NBK;                       // B fragments are read 4 at a time (registers)
+#pragma unroll
+        for (int ks = 0; ks < KRS; ++ks) {
+        const uint16_t* gsrc = gbase + 32 * ks * PG;
+        const uint16_t* asrc = abase + 32 * ks * PA;
+        u32x2 af[MB][2];
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
             const uint16_t* p = gsrc + prow * PG + 16 * (wm * MB + m) + pcol;
@@ -462,23 +497,50 @@ __global__ __launch_bounds__(NT, 1) void rows_dw_kernel(const DwArgs a) {
             af[m][1] = lds_tr_read(p + 16 * PG);
         }
 #pragma unroll
-        for (int k = 0; k < NBK; ++k) {
-            const uint16_t* p = asrc + prow * PA + 16 * (wn * NBK + k) + pcol;
-            bf[k][0] = lds_tr_read(p);
-            bf[k][1] = lds_tr_read(p + 16 * PA);
-        }
+        for (int k0 = 0; k0 < NBK; k0 += KH) {
+            u32x2 bf[KH][2];
 #pragma unroll
-        for (int m = 0; m < MB; ++m) { lds_tr_wait(af[m][0]); lds_tr_wait(af[m][1]); }
-#pragma unroll
-        for (int k = 0; k < NBK; ++k) { lds_tr_wait(bf[k][0]); lds_tr_wait(bf[k][1]); }
-#pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const u32x4 am = {af[m][0].x, af[m][0].y, af[m][1].x, af[m][1].y};
-#pragma unroll
-            for (int k = 0; k < NBK; ++k) {
-                const u32x4 bk = {bf[k][0].x, bf[k][0].y, bf[k][1].x, bf[k][1].y};
-                acc[m][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(am), as_frag(bk), acc[m][k], 0, 0, 0);
+            for (int k = 0; k < KH; ++k) {
+                const uint16_t* p = asrc + prow * PA + 16 * (wn * NBK + k0 + k) + pcol;
+                bf[k][0] = lds_tr_read(p);
+                bf[k][1] = lds_tr_read(p + 16 * PA);
             }
+            if (k0 == 0) {
+#pragma unroll
+                for (int m = 0; m < MB; ++m) { lds_tr_wait(af[m][0]); lds_tr_wait(af[m][1]); }
+            }
+#pragma unroll
+            for (int k = 0; k < KH; ++k) { lds_tr_wait(bf[k][0]); lds_tr_wait(bf[k][1]); }
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                const u32x4 am = {af[m][0].x, af[m][0].y, af[m][1].x, af[m][1].y};
+#pragma unroll
+                for (int k = 0; k < KH; ++k) {
+                    const u32x4 bk = {bf[k][0].x, bf[k][0].y, bf[k][1].x, bf[k][1].y};
+                    acc[m][k0 + k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag(am), as_frag(bk), acc[m][k0 + k], 0, 0, 0);
+                }
+            }
+        }
+        }
+    };
+    // tiles are fetched TWO steps ahead (two register sets): one 32-row tile in flight per workgroup leaves the memory pipe idle most of the time
+    Regs ra, rb;
+    if (s_begin < s_end) fetch(ra, s_begin);
+    if (s_begin + 1 < s_end) fetch(rb, s_begin + 1);
+    for (int64_t step = s_begin; step < s_end; step += 2) {
+        stage(ra, 0, step);
+        if (step + 2 < s_end) fetch(ra, step + 2);
+        __syncthreads();                                            // also orders: the products of the previous step (other buffer) precede the next stage into it
+#ifndef PPS_ABL_DW_NOPROD
+        products(0);
+#endif
+        if (step + 1 < s_end) {
+            stage(rb, 1, step + 1);
+            if (step + 3 < s_end) fetch(rb, step + 3);
+            __syncthreads();
+#ifndef PPS_ABL_DW_NOPROD
+            products(1);
+#endif
         }
     }
 
@@ -508,7 +570,7 @@ __global__ __launch_bounds__(NT, 1) void rows_dw_kernel(const DwArgs a) {
 
 template <int CI, int CO>
 constexpr size_t dw_lds() {
-    return (size_t)2 * 32 * (CO + 16 + CI + 16) * 2 + (size_t)(2 * CO + 2 * CI) * 4;
+    return (size_t)2 * 32 * dw_ksteps<CI, CO>() * (CO + 16 + CI + 16) * 2 + (size_t)(2 * CO + 2 * CI) * 4;
 }
 
 // out[i] = sum_p part[p][i]: SL threads share an element (p = slice, slice + SL, ... in double), their sums are added in slice order
@@ -935,13 +997,17 @@ int launch_layer(const LayerArgs& a, int grid, hipStream_t st) {
     hipLaunchKernelGGL((rows_layer_kernel<CK, CO, DX>), dim3(grid), dim3(NT), lds, st, a);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
-template <int CI, int CO>
-int launch_dw(const DwArgs& a, int grid, hipStream_t st) {
-    static bool ok = allow_lds(rows_dw_kernel<CI, CO>, dw_lds<CI, CO>());
+template <int CI, int CO, bool HAS_Y>
+int launch_dw_y(const DwArgs& a, int grid, hipStream_t st) {
+    static bool ok = allow_lds(rows_dw_kernel<CI, CO, HAS_Y>, dw_lds<CI, CO>());
     if (!ok) return PPS_ERR_LAUNCH;
     constexpr size_t lds = dw_lds<CI, CO>();
-    hipLaunchKernelGGL((rows_dw_kernel<CI, CO>), dim3(grid), dim3(NT), lds, st, a);
+    hipLaunchKernelGGL((rows_dw_kernel<CI, CO, HAS_Y>), dim3(grid), dim3(NT), lds, st, a);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+template <int CI, int CO>
+int launch_dw(const DwArgs& a, int grid, hipStream_t st) {
+    return a.y ? launch_dw_y<CI, CO, true>(a, grid, st) : launch_dw_y<CI, CO, false>(a, grid, st);
 }
 
 bool dim_ok(int c) { return c == 64 || c == 128 || c == 256; }
@@ -1075,7 +1141,6 @@ int pps_rows_layer_fwd(const void* x, int64_t rows, int cin, const float* in_sca
     a.pre_a = in_scale;
     a.pre_b = in_shift;
     a.pre_relu = in_relu;
-    if (!in_scale && in_relu) return PPS_ERR_ARG;               // a bare ReLU is passed as scale 1, shift 0
     a.w = w;
     a.bias = bias;
     a.dst = (uint16_t*)y;
@@ -1098,7 +1163,6 @@ int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t row
                        void* stream) {
     if (rows < 1 || !dim_ok(cin) || !dim_ok(cout)) return PPS_ERR_ARG;
     if (!x || !gy || !w || !ws || ((in_scale == nullptr) != (in_shift == nullptr))) return PPS_ERR_ARG;
-    if (!in_scale && in_relu) return PPS_ERR_ARG;
     const bool bn = gamma != nullptr;
     if (bn && (!y || !save || !d_affine || !dgamma || !dbeta)) return PPS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -1137,7 +1201,9 @@ int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t row
         }
     }
     if (dw) {
-        const int64_t nsteps = (rows + 31) / 32;
+        int kr = 32;
+        PPS_DISPATCH(cin, cout, kr = 32 * (dw_ksteps<I, O>()));
+        const int64_t nsteps = (rows + kr - 1) / kr;
         int grid = grid_for(nsteps);
         const int64_t per = (nsteps + grid - 1) / grid;
         grid = (int)((nsteps + per - 1) / per);                          // no empty slabs

@@ -530,11 +530,6 @@ def rows_layer_supported(rows, cin, cout):
 def rows_layer(act, w, b, bn=None, relu=False):
     """act: Act (input in its stored form); w [cout, cin], b [cout] or None; bn: BatchNorm1d holder whose batch statistics are taken on the
     output (train mode), or None.  -> Act(raw output, affine of bn or None, relu)."""
-    in_aff = act.affine
-    if in_aff is None and act.relu:                      # a bare ReLU on the input: scale 1, shift 0
-        c = act.raw.shape[1]
-        in_aff = torch.cat([torch.ones((1, c), device=act.raw.device), torch.zeros((1, c), device=act.raw.device)])
-    act = Act(act.raw, in_aff, act.relu)
     if bn is not None:
         y, aff = _RowsLayer.apply(act.raw, act.affine, act.relu, w, b, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
     else:
@@ -556,21 +551,20 @@ class _QueryAttnPool(torch.autograd.Function):
         heads = wq.shape[0]
         w32 = wq.detach().float().contiguous()
         b32 = None if bq is None else bq.detach().float().contiguous()
-        aff = torch.cat([torch.ones((1, c), device=y3.device), torch.zeros((1, c), device=y3.device)])
         qy = torch.empty((rows, heads), device=y3.device, dtype=torch.bfloat16)
         ws = torch.empty((L.pps_rows_layer_ws_bytes(c, heads),), device=y3.device, dtype=torch.uint8)
         ptr = lambda t: None if t is None else t.data_ptr()
-        _lib.check(L.pps_rows_layer_fwd(y3.data_ptr(), rows, c, aff.data_ptr(), aff.data_ptr() + 4 * c, 1, w32.data_ptr(), ptr(b32), heads, qy.data_ptr(),
+        _lib.check(L.pps_rows_layer_fwd(y3.data_ptr(), rows, c, None, None, 1, w32.data_ptr(), ptr(b32), heads, qy.data_ptr(),
                                         None, None, None, None, 0.0, 0.0, None, None, ws.data_ptr(), _stream()), 'pps_rows_layer_fwd')
         pooled = torch.empty((rows // k, c), device=y3.device, dtype=torch.bfloat16)
         _lib.check(L.pps_attn_pool_fwd(qy.data_ptr(), y3.data_ptr(), rows // k, k, heads, c, 1, 1, pooled.data_ptr(), _stream()), 'pps_attn_pool_fwd')
-        ctx.save_for_backward(y3, w32, qy, aff)
+        ctx.save_for_backward(y3, w32, qy)
         ctx.meta = (k, bq is not None, wq.dtype, None if bq is None else bq.dtype)
         return pooled
 
     @staticmethod
     def backward(ctx, dpooled):
-        y3, w32, qy, aff = ctx.saved_tensors
+        y3, w32, qy = ctx.saved_tensors
         k, has_b, wdt, bdt = ctx.meta
         L = _lib.lib()
         rows, c = y3.shape
@@ -583,7 +577,7 @@ class _QueryAttnPool(torch.autograd.Function):
         dw = torch.empty((heads, c), device=dev, dtype=torch.float32)
         db = torch.empty((heads,), device=dev, dtype=torch.float32) if has_b else None
         ws = torch.empty((L.pps_rows_layer_ws_bytes(c, heads),), device=dev, dtype=torch.uint8)
-        _lib.check(L.pps_rows_layer_bwd(y3.data_ptr(), qy.data_ptr(), dqy.data_ptr(), rows, c, heads, aff.data_ptr(), aff.data_ptr() + 4 * c, 1,
+        _lib.check(L.pps_rows_layer_bwd(y3.data_ptr(), qy.data_ptr(), dqy.data_ptr(), rows, c, heads, None, None, 1,
                                         w32.data_ptr(), None, None, None, dy3.data_ptr(), dy3.data_ptr(), None, dw.data_ptr(),
                                         None if db is None else db.data_ptr(), None, None, ws.data_ptr(), _stream()), 'pps_rows_layer_bwd')
         return dy3, dw.to(wdt), None if db is None else db.to(bdt), None
