@@ -5,8 +5,13 @@
 // i.e. everything of FKAConvLayer.forward that produces the [M, K, 16] kernel-weighting matrix `g`; ~60 ATen launches
 // forward and ~150 backward per layer on [B, M, K, 16] tensors (12 ms per 10 x 10k-point layer) become 4 + 3 launches.
 //
-// Mapping as in the inference kernels: 16 lanes (one DPP row) hold the K <= 16 neighbours of one support point, each lane
-// its neighbour's 16 channels in registers; the per-layer parameters (1140 floats, `geo`) are read with scalar loads.
+// Mapping: a WAVE works on one support point at a time.  Lane (j, q) = (lane & 15, lane >> 4) holds, for neighbour j of the point, the four
+// channels 4 q .. 4 q + 3 of every 16-channel activation -- which is both the C/D layout of v_mfma_f32_16x16x4_f32 for the matrix
+// [channel][neighbour] and, with the contraction index ordered (step s, group q) <-> channel 4 q + s, its B operand layout.  So the two
+// 32 -> 16 layers (and their transposes in the backward pass) are chains of fp32 MFMAs whose A operands, the layer's weights, sit in 8
+// registers per lane each; pooling over the neighbours is a DPP row reduction of 4 values per lane.  (An earlier version kept a whole
+// 16-channel row per lane and multiplied on the VALU: the 1140 parameters do not fit the SGPR file, the compiler parked them in VGPR lanes
+// and the backward passes executed 4.6 v_readlane per FMA.)  fp32 MFMA is an exact fmaf chain, the arithmetic is unchanged.
 // Nothing but `g` is stored by the forward pass: the backward pass RECOMPUTES the branch in each of its three passes (the
 // two InstanceNorms are reductions over all (point, neighbour) pairs of a shape, so their backward needs the sums
 // sum(dy), sum(dy * xhat) of a whole shape before the gradient can go further up):
@@ -23,7 +28,7 @@
 #include "../../include/ppsurf_amd.h"
 
 #define FT_NT 256
-#define FT_TM 16
+#define FT_TM 4                          // support points per workgroup iteration: one per wave
 #define FT_GMAX_CAP 512                  // upper bound of blocks per shape (grid = G x B), each loops over its tiles
 
 namespace {
@@ -36,66 +41,12 @@ __device__ __forceinline__ float act_grad(float y, int act) {
     return y > 0.f ? 1.f : 0.f;
 }
 
-__device__ __forceinline__ float in_apply(float z, const float* st, int t, const float* geo, int wofs, int bofs, int K) {
-    return K > 1 ? (z - st[2 * t]) * st[2 * t + 1] * geo[wofs + t] + geo[bofs + t] : z;
-}
-
-// [a ; max_j(a * dw)] for the 16 channels of this lane
-__device__ __forceinline__ void pool16(const float (&a)[16], const Geo& g, float (&p)[16]) {
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const float v = row16_max(g.valid ? a[t] * g.dw : -INFINITY);
-        p[t] = v == -INFINITY ? 0.f : v;               // rows past the end of the shape: keep everything finite (0 * inf = NaN)
-    }
-}
-
-// o[c] = sum_t w[t][c] * d[t]   (transposed 16x32 product)
-__device__ __forceinline__ void fc32_t(const float (&d)[16], const float* w, float (&o)[32]) {
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-        float s = 0.f;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) s += w[t * 32 + c] * d[t];
-        o[c] = s;
-    }
-}
-
 // first lane of the DPP row (lowest neighbour index) for which `hit` holds
 __device__ __forceinline__ bool first_in_row(bool hit) {
     const unsigned long long bal = __ballot(hit);
     const int lane = threadIdx.x & 63;
     const unsigned row = (unsigned)(bal >> (lane & 48)) & 0xffffu;
     return hit && ((row & ((1u << (lane & 15)) - 1u)) == 0u);
-}
-
-// per-wave LDS staging area for the outer-product accumulation
-struct Stage {
-    float d[64][17];
-    float i[64][33];
-};
-
-// acc[h][r] += sum over the wave's 64 lanes of dz[t] * in[c],  t = 4*(lane>>4)+r,  c = (lane&15) + 16*h   (NI = 32 or 3 inputs)
-template <int NI>
-__device__ __forceinline__ void outer_acc(const float (&dz)[16], const float* in, Stage* sg, f32x4 (&acc)[2]) {
-    const int lane = threadIdx.x & 63;
-    Stage& s = sg[threadIdx.x >> 6];
-    __syncthreads();                                  // previous tile's fragment reads are done
-#pragma unroll
-    for (int t = 0; t < 16; ++t) s.d[lane][t] = dz[t];
-#pragma unroll
-    for (int c = 0; c < NI; ++c) s.i[lane][c] = in[c];
-    __syncthreads();
-    const int n = lane & 15, k = lane >> 4;
-#pragma unroll
-    for (int kb = 0; kb < 16; ++kb) {
-        const float a = s.d[4 * kb + k][n];
-        if (NI == 32) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, s.i[4 * kb + k][n], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, s.i[4 * kb + k][16 + n], acc[1], 0, 0, 0);
-        } else {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, n < NI ? s.i[4 * kb + k][n] : 0.f, acc[0], 0, 0, 0);
-        }
-    }
 }
 
 // sum the 4 waves' accumulators and write the block partial: out[t * ld + c]
@@ -112,21 +63,6 @@ __device__ __forceinline__ void outer_store(const f32x4 (&acc)[2], float* red /*
         const int t = e >> 5, c = e & 31;
         if (c < NI) out[t * NI + c] = red[e] + red[512 + e] + red[1024 + e] + red[1536 + e];
     }
-}
-
-// block sums of 32 per-lane float accumulators (in double) -> part[32]
-__device__ __forceinline__ void block_sum32(const float (&s1)[16], const float (&s2)[16], double* __restrict__ part, double* red /* LDS [4][32] */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        double a = (double)s1[t], b = (double)s2[t];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-        if (lane == 0) { red[wave * 32 + 2 * t] = a; red[wave * 32 + 2 * t + 1] = b; }
-    }
-    __syncthreads();
-    if (threadIdx.x < 32) part[threadIdx.x] = red[threadIdx.x] + red[32 + threadIdx.x] + red[64 + threadIdx.x] + red[96 + threadIdx.x];
 }
 
 __device__ __forceinline__ double block_sum1(float v, double* red /* LDS [4] */) {
@@ -148,7 +84,7 @@ struct Tile {
 __device__ __forceinline__ Tile tile_of(int tile, int64_t M) {
     Tile t;
     const int64_t b = blockIdx.y;
-    t.mg = b * M + (int64_t)tile * FT_TM + (threadIdx.x >> 4);
+    t.mg = b * M + (int64_t)tile * 16 + (threadIdx.x >> 4);        // 16 points per workgroup iteration, one DPP row each (fka_radius_kernel)
     t.lim = (b + 1) * M;
     t.j = threadIdx.x & 15;
     return t;
@@ -160,7 +96,7 @@ __device__ __forceinline__ Tile tile_of(int tile, int64_t M) {
 __global__ __launch_bounds__(FT_NT) void fka_radius_kernel(const float* __restrict__ pts, const float* __restrict__ sup,
                                                            const int64_t* __restrict__ idx, int64_t M, int K, double* __restrict__ part) {
     __shared__ double red[4];
-    const int ntiles = (int)((M + FT_TM - 1) / FT_TM);
+    const int ntiles = (int)((M + 15) / 16);
     float acc = 0.f;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const Tile t = tile_of(tile, M);
@@ -186,6 +122,137 @@ __global__ __launch_bounds__(64) void fka_fin_radius_kernel(const double* __rest
     }
 }
 
+// ---- one support point per wave -----------------------------------------------------------------------------------------
+
+struct Pt {
+    float dw;        // normalised distance weight of neighbour j (nn.py:619-624)
+    float pn[3];     // neighbour offset / norm_radius (nn.py:601,616)
+    float d, u, ssum;
+    bool valid;
+    int64_t e;       // entry number mg * K + j (valid lanes)
+};
+
+__device__ __forceinline__ Pt point_geometry(const float* __restrict__ pts, const float* __restrict__ sup, const int64_t* __restrict__ idx,
+                                             int64_t mg, int64_t lim, int j, int K, float radius, float alpha, float beta) {
+    Pt r;
+    r.valid = (mg < lim) && (j < K);
+    r.e = mg * K + j;
+    r.d = 0.f;
+    r.pn[0] = r.pn[1] = r.pn[2] = 0.f;
+    if (r.valid) {
+        const int64_t i = idx[r.e];
+        const float px = pts[i * 3] - sup[mg * 3], py = pts[i * 3 + 1] - sup[mg * 3 + 1], pz = pts[i * 3 + 2] - sup[mg * 3 + 2];
+        r.d = sqrtf(px * px + py * py + pz * pz);
+        r.pn[0] = px / radius; r.pn[1] = py / radius; r.pn[2] = pz / radius;
+    }
+    r.u = r.valid ? 1.f / (1.f + __expf(-(-alpha * r.d + beta))) : 0.f;
+    float sm = row16_sum(r.u);
+    sm = sm + (sm == 0.f ? 1.f : 0.f) + 1e-6f;
+    r.ssum = sm;
+    r.dw = r.u / sm * (float)K;
+    return r;
+}
+
+// the layer's parameters as this lane needs them (lane (j, q): channels t = 4 q + r; as MFMA row m = lane & 15)
+struct LaneParams {
+    float w1[4][3];              // fc1 rows of the lane's channels
+    float in1w[4], in1b[4], in2w[4], in2b[4];
+    float w2a[8], w3a[8];        // A operands of fc2 / fc3: W[m][in], in = (s < 4 ? 4 q + s : 16 + 4 q + s - 4) for contraction step s
+    float w2t[2][4], w3t[2][4];  // A operands of the transposed products: W[4 q + s][16 mb + m]
+    float radius, alpha, beta;
+    int act;
+};
+
+template <bool BWD>
+__device__ __forceinline__ LaneParams load_params(const float* __restrict__ geo) {
+    LaneParams P;
+    const int lane = threadIdx.x & 63, m = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = 4 * q + r;
+        P.w1[r][0] = geo[GEO_FC1 + t * 3]; P.w1[r][1] = geo[GEO_FC1 + t * 3 + 1]; P.w1[r][2] = geo[GEO_FC1 + t * 3 + 2];
+        P.in1w[r] = geo[GEO_IN1W + t]; P.in1b[r] = geo[GEO_IN1B + t]; P.in2w[r] = geo[GEO_IN2W + t]; P.in2b[r] = geo[GEO_IN2B + t];
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) {
+        const int in = s2 < 4 ? 4 * q + s2 : 16 + 4 * q + (s2 - 4);
+        P.w2a[s2] = geo[GEO_FC2 + m * 32 + in];
+        P.w3a[s2] = geo[GEO_FC3 + m * 32 + in];
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            P.w2t[mb][s2] = BWD ? geo[GEO_FC2 + (4 * q + s2) * 32 + 16 * mb + m] : 0.f;
+            P.w3t[mb][s2] = BWD ? geo[GEO_FC3 + (4 * q + s2) * 32 + 16 * mb + m] : 0.f;
+        }
+    P.radius = geo[GEO_RADIUS]; P.alpha = geo[GEO_ALPHA]; P.beta = geo[GEO_BETA];
+    P.act = (int)geo[GEO_ACT];
+    return P;
+}
+
+__device__ __forceinline__ f32x4 fc1_lane(const LaneParams& P, const Pt& g) {
+    f32x4 z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z[r] = P.w1[r][0] * g.pn[0] + P.w1[r][1] * g.pn[1] + P.w1[r][2] * g.pn[2];
+    return z;
+}
+
+// z[cout][j] = sum_in W[cout][in] * [a ; p][in][j]: 8 MFMAs, the activations are B operands as they are
+__device__ __forceinline__ f32x4 fc32_mfma(const float (&wa)[8], const f32x4& a, const f32x4& p) {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) z = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s2], a[s2], z, 0, 0, 0);
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) z = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[4 + s2], p[s2], z, 0, 0, 0);
+    return z;
+}
+
+// din[in][j] = sum_cout W[cout][in] * dz[cout][j] for the block mb of 16 inputs
+__device__ __forceinline__ f32x4 fc32_t_mfma(const float (&wt)[4], const f32x4& dz) {
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) o = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[s2], dz[s2], o, 0, 0, 0);
+    return o;
+}
+
+__device__ __forceinline__ f32x4 in_act(const f32x4& z, const float* st /* [16][2] mean, rstd of the shape */, const float (&w)[4], const float (&b)[4], int q,
+                                       int K, int act, f32x4& y) {
+    f32x4 a;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int t = 4 * q + r;
+        y[r] = K > 1 ? (z[r] - st[2 * t]) * st[2 * t + 1] * w[r] + b[r] : z[r];
+        a[r] = act_fn(y[r], act);
+    }
+    return a;
+}
+
+__device__ __forceinline__ f32x4 pool4(const f32x4& a, const Pt& g) {
+    f32x4 p;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float v = row16_max(g.valid ? a[r] * g.dw : -INFINITY);
+        p[r] = v == -INFINITY ? 0.f : v;               // points past the end of the shape: keep everything finite
+    }
+    return p;
+}
+
+// block sums of the 2 x 4 per-lane accumulators (channels 4 q + r) in double -> part[32] = (s1[t], s2[t]) interleaved per channel t
+__device__ __forceinline__ void block_sum_lane4(const float (&s1)[4], const float (&s2)[4], double* __restrict__ part, double* red /* LDS [4][32] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double a = (double)s1[r], b = (double)s2[r];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        if ((lane & 15) == 0) { red[wave * 32 + 2 * (4 * q + r)] = a; red[wave * 32 + 2 * (4 * q + r) + 1] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) part[threadIdx.x] = red[threadIdx.x] + red[32 + threadIdx.x] + red[64 + threadIdx.x] + red[96 + threadIdx.x];
+}
+
 // PHASE 1: statistics of fc1 output; PHASE 2: statistics of fc2 output; PHASE 3: g = act(fc3) * dw -> out
 template <int PHASE>
 __global__ __launch_bounds__(FT_NT) void fka_fwd_kernel(const float* __restrict__ pts, const float* __restrict__ sup,
@@ -195,50 +262,36 @@ __global__ __launch_bounds__(FT_NT) void fka_fwd_kernel(const float* __restrict_
     __shared__ double red[128];
     const float* st1 = stat1 + blockIdx.y * 32;
     const float* st2 = stat2 + blockIdx.y * 32;
-    const int act = (int)geo_g[GEO_ACT];
+    const LaneParams P = load_params<false>(geo_g);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
     const int ntiles = (int)((M + FT_TM - 1) / FT_TM);
-    float s1[16], s2[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) s1[t] = s2[t] = 0.f;
+    const int64_t lim = ((int64_t)blockIdx.y + 1) * M;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        // the 1140 parameters do not fit the SGPR file; the compiler hoists their scalar loads out of the tile loop and parks them
-        // in VGPR lanes (v_readlane per use).  Forcing a reload per tile instead was measured 1.9x SLOWER (exposed s_load latency
-        // at 2 waves/SIMD), and a copy in LDS 2x slower (the ds_reads get hoisted too: 256 VGPRs + 1.5 KB/lane of scratch), so the
-        // hoisting is left alone.
-        const float* geo = geo_g;
-        const Tile tl = tile_of(tile, M);
-        const Geo g = geometry(pts, sup, idx, tl.mg, tl.lim, tl.j, K, geo);
-        float v[16];
-        fc1_raw(g, geo, v);
+        const int64_t mg = (int64_t)blockIdx.y * M + (int64_t)tile * FT_TM + wave;
+        const Pt g = point_geometry(pts, sup, idx, mg, lim, j, K, P.radius, P.alpha, P.beta);
+        f32x4 v = fc1_lane(P, g);
         if (PHASE >= 2) {
-            float p[16], o[16];
-#pragma unroll
-            for (int t = 0; t < 16; ++t) v[t] = act_fn(in_apply(v[t], st1, t, geo, GEO_IN1W, GEO_IN1B, K), act);
-            pool16(v, g, p);
-            fc32(v, p, geo + GEO_FC2, o);
+            f32x4 y;
+            const f32x4 a1 = in_act(v, st1, P.in1w, P.in1b, q, K, P.act, y);
+            const f32x4 p1 = pool4(a1, g);
+            v = fc32_mfma(P.w2a, a1, p1);
             if (PHASE == 3) {
-#pragma unroll
-                for (int t = 0; t < 16; ++t) o[t] = act_fn(in_apply(o[t], st2, t, geo, GEO_IN2W, GEO_IN2B, K), act);
-                pool16(o, g, p);
-                fc32(o, p, geo + GEO_FC3, v);
-                if (g.valid) {
-                    f32x4* dst = (f32x4*)(gout + (tl.mg * K + tl.j) * 16);
-#pragma unroll
-                    for (int t4 = 0; t4 < 4; ++t4)
-                        dst[t4] = f32x4{act_fn(v[4 * t4], act) * g.dw, act_fn(v[4 * t4 + 1], act) * g.dw, act_fn(v[4 * t4 + 2], act) * g.dw,
-                                        act_fn(v[4 * t4 + 3], act) * g.dw};
-                }
+                const f32x4 a2 = in_act(v, st2, P.in2w, P.in2b, q, K, P.act, y);
+                const f32x4 p2 = pool4(a2, g);
+                const f32x4 z3 = fc32_mfma(P.w3a, a2, p2);
+                if (g.valid)
+                    *(f32x4*)(gout + g.e * 16 + 4 * q) = f32x4{act_fn(z3[0], P.act) * g.dw, act_fn(z3[1], P.act) * g.dw, act_fn(z3[2], P.act) * g.dw,
+                                                              act_fn(z3[3], P.act) * g.dw};
                 continue;
             }
-#pragma unroll
-            for (int t = 0; t < 16; ++t) v[t] = o[t];
         }
         if (g.valid) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) { s1[t] += v[t]; s2[t] += v[t] * v[t]; }
+            for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
         }
     }
-    if (PHASE < 3) block_sum32(s1, s2, part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 32, red);
+    if (PHASE < 3) block_sum_lane4(s1, s2, part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 32, red);
 }
 
 // part [B][G][32] (sum, sum of squares | sum dy, sum dy*xhat interleaved per channel) -> out [B][32]
@@ -271,6 +324,53 @@ __global__ __launch_bounds__(256) void fka_fin_stat_kernel(const double* __restr
 
 // ---- backward --------------------------------------------------------------------------------------------------------
 
+// per-wave staging area for the weight-gradient outer products: the matrices [channel][neighbour] the lanes hold in C/D layout are
+// needed with the NEIGHBOUR as contraction index, i.e. transposed
+struct Stage {
+    float d[16][17];     // dz[cout][j]
+    float i[32][17];     // in[k][j]
+};
+
+// acc[h][.] += sum_j dz[cout][j] * in[16 h + n][j]   (D rows = couts, columns = inputs;  NI = 32: both halves, NI = 3: pn, h = 0 only)
+template <int NI>
+__device__ __forceinline__ void outer_acc(const f32x4& dz, const f32x4& in_a, const f32x4& in_p, Stage& sg, f32x4 (&acc)[2]) {
+    const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sg.d[4 * q + r][j] = dz[r];
+        sg.i[4 * q + r][j] = in_a[r];                    // NI = 3: rows 0..2 = pn (the caller passes it in the q = 0 lanes), the rest 0
+        if (NI == 32) sg.i[16 + 4 * q + r][j] = in_p[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {                     // contraction step: neighbours 4 s + q;  lane & 15 = cout (A) / input (B)
+        const float a = sg.d[j][4 * s2 + q];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sg.i[j][4 * s2 + q], acc[0], 0, 0, 0);
+        if (NI == 32) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sg.i[16 + j][4 * s2 + q], acc[1], 0, 0, 0);
+    }
+}
+
+// sum over the four channel quarters of a per-neighbour value (lanes j, j + 16, j + 32, j + 48)
+__device__ __forceinline__ float quarters_sum(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// gradient of [a ; max_j(a * dw)] wrt a and dw: din_a + (this neighbour holds the maximum ? sum_j din_p * dw : 0)   (nn.py:631-633)
+__device__ __forceinline__ f32x4 pool_grad(const f32x4& din_a, const f32x4& din_p, const f32x4& a, const f32x4& p, const Pt& g, float& ddw) {
+    f32x4 da;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float dp = row16_sum(din_p[r]);
+        const bool first = first_in_row(g.valid && a[r] * g.dw == p[r]);
+        da[r] = din_a[r] + (first ? dp * g.dw : 0.f);
+        ddw += first ? dp * a[r] : 0.f;
+    }
+    return da;
+}
+
 template <int PASS>
 __global__ __launch_bounds__(FT_NT) void fka_bwd_kernel(const float* __restrict__ pts, const float* __restrict__ sup,
                                                         const int64_t* __restrict__ idx, int64_t M, int K, const float* __restrict__ geo_g,
@@ -284,145 +384,102 @@ __global__ __launch_bounds__(FT_NT) void fka_bwd_kernel(const float* __restrict_
     const float* st1 = stat1 + blockIdx.y * 32;
     const float* st2 = stat2 + blockIdx.y * 32;
     const float* gm = gmean ? gmean + blockIdx.y * 32 : nullptr;
-    const int act = (int)geo_g[GEO_ACT];
+    const LaneParams P = load_params<true>(geo_g);
+    const int act = P.act;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+    Stage& sg = stage[wave];
     const int ntiles = (int)((M + FT_TM - 1) / FT_TM);
+    const int64_t lim = ((int64_t)blockIdx.y + 1) * M;
     const int64_t blk = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
-    float s1[16], s2[16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) s1[t] = s2[t] = 0.f;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     float dalpha = 0.f, dbeta = 0.f;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const float* geo = geo_g;                                   // see fka_fwd_kernel
-        const Tile tl = tile_of(tile, M);
-        const Geo g = geometry(pts, sup, idx, tl.mg, tl.lim, tl.j, K, geo);
-        const int64_t e = tl.mg * K + tl.j;                         // entry number (valid lanes only)
-        float z1[16];
-        fc1_raw(g, geo, z1);
+        const int64_t mg = (int64_t)blockIdx.y * M + (int64_t)tile * FT_TM + wave;
+        const Pt g = point_geometry(pts, sup, idx, mg, lim, j, K, P.radius, P.alpha, P.beta);
+        const f32x4 z1 = fc1_lane(P, g);
 
         if (PASS == 3) {
-            float dz1[16];
-            if (g.valid) {
-                const f32x4* src = (const f32x4*)(dyb + e * 16);
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) { const f32x4 v = src[t4]; dz1[4 * t4] = v.x; dz1[4 * t4 + 1] = v.y; dz1[4 * t4 + 2] = v.z; dz1[4 * t4 + 3] = v.w; }
-            } else {
-#pragma unroll
-                for (int t = 0; t < 16; ++t) dz1[t] = 0.f;
-            }
+            f32x4 dz1 = g.valid ? *(const f32x4*)(dyb + g.e * 16 + 4 * q) : zero4;
             if (K > 1) {
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const float xh = (z1[t] - st1[2 * t]) * st1[2 * t + 1];
-                    dz1[t] = g.valid ? geo[GEO_IN1W + t] * st1[2 * t + 1] * (dz1[t] - gm[2 * t] - xh * gm[2 * t + 1]) : 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    const int t = 4 * q + r;
+                    const float xh = (z1[r] - st1[2 * t]) * st1[2 * t + 1];
+                    dz1[r] = g.valid ? P.in1w[r] * st1[2 * t + 1] * (dz1[r] - gm[2 * t] - xh * gm[2 * t + 1]) : 0.f;
                 }
             }
-            outer_acc<3>(dz1, g.pn, stage, acc);
-            // distance weights: dw_j = K u_j / s, u = sigmoid(-alpha d + beta)   (nn.py:619-624)
-            float d = 0.f;
-            if (g.valid) {
-                const int64_t i = idx[e];
-                const float px = pts[i * 3] - sup[tl.mg * 3], py = pts[i * 3 + 1] - sup[tl.mg * 3 + 1], pz = pts[i * 3 + 2] - sup[tl.mg * 3 + 2];
-                d = sqrtf(px * px + py * py + pz * pz);
-            }
-            const float u = g.valid ? 1.f / (1.f + __expf(-(-geo[GEO_ALPHA] * d + geo[GEO_BETA]))) : 0.f;
-            float ssum = row16_sum(u);
-            ssum = ssum + (ssum == 0.f ? 1.f : 0.f) + 1e-6f;
-            const float ddw = g.valid ? ddwb[e] : 0.f;
+            const f32x4 pn4 = q == 0 ? f32x4{g.pn[0], g.pn[1], g.pn[2], 0.f} : zero4;      // input rows 0..2 of the staging area
+            outer_acc<3>(dz1, pn4, zero4, sg, acc);
+            // distance weights: dw_j = K u_j / s, u = sigmoid(-alpha d + beta)   (nn.py:619-624); the four quarters hold the same values
+            const float ddw = g.valid ? ddwb[g.e] : 0.f;
             const float tot = row16_sum(ddw * g.dw);
-            const float du = ((float)K * ddw - tot) / ssum;
-            const float da = du * u * (1.f - u);
-            if (g.valid) { dalpha += -d * da; dbeta += da; }
+            const float du = ((float)K * ddw - tot) / g.ssum;
+            const float da = du * g.u * (1.f - g.u);
+            if (g.valid && q == 0) { dalpha += -g.d * da; dbeta += da; }
             continue;
         }
 
         // PASS 1 and 2 share the first stage of the recomputation
-        float a1[16], p1[16], y1[16];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) { y1[t] = in_apply(z1[t], st1, t, geo, GEO_IN1W, GEO_IN1B, K); a1[t] = act_fn(y1[t], act); }
-        pool16(a1, g, p1);
-        float z2[16];
-        fc32(a1, p1, geo + GEO_FC2, z2);
+        f32x4 y1;
+        const f32x4 a1 = in_act(z1, st1, P.in1w, P.in1b, q, K, act, y1);
+        const f32x4 p1 = pool4(a1, g);
+        const f32x4 z2 = fc32_mfma(P.w2a, a1, p1);
 
         if (PASS == 1) {
-            float a2[16], p2[16], y2[16], z3[16];
+            f32x4 y2;
+            const f32x4 a2 = in_act(z2, st2, P.in2w, P.in2b, q, K, act, y2);
+            const f32x4 p2 = pool4(a2, g);
+            const f32x4 z3 = fc32_mfma(P.w3a, a2, p2);
+            f32x4 dz3 = g.valid ? *(const f32x4*)(dg + g.e * 16 + 4 * q) : zero4;
+            float ddw = 0.f;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) { y2[t] = in_apply(z2[t], st2, t, geo, GEO_IN2W, GEO_IN2B, K); a2[t] = act_fn(y2[t], act); }
-            pool16(a2, g, p2);
-            fc32(a2, p2, geo + GEO_FC3, z3);
-            float dz3[16], ddw = 0.f;
-            if (g.valid) {
-                const f32x4* src = (const f32x4*)(dg + e * 16);
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) { const f32x4 v = src[t4]; dz3[4 * t4] = v.x; dz3[4 * t4 + 1] = v.y; dz3[4 * t4 + 2] = v.z; dz3[4 * t4 + 3] = v.w; }
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    ddw += dz3[t] * act_fn(z3[t], act);
-                    dz3[t] = dz3[t] * g.dw * act_grad(z3[t], act);
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < 16; ++t) dz3[t] = 0.f;
+            for (int r = 0; r < 4; ++r) {
+                ddw += dz3[r] * act_fn(z3[r], act);
+                dz3[r] = g.valid ? dz3[r] * g.dw * act_grad(z3[r], act) : 0.f;
             }
-            float in3[32], din[32];
+            outer_acc<32>(dz3, a2, p2, sg, acc);
+            const f32x4 din_a = fc32_t_mfma(P.w3t[0], dz3), din_p = fc32_t_mfma(P.w3t[1], dz3);
+            const f32x4 da = pool_grad(din_a, din_p, a2, p2, g, ddw);
+            f32x4 dy2;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) { in3[t] = a2[t]; in3[16 + t] = p2[t]; }
-            outer_acc<32>(dz3, in3, stage, acc);
-            fc32_t(dz3, geo + GEO_FC3, din);
-            float dy2[16];
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const float dp = row16_sum(din[16 + t]);
-                const bool first = first_in_row(g.valid && a2[t] * g.dw == p2[t]);
-                const float da = din[t] + (first ? dp * g.dw : 0.f);
-                ddw += first ? dp * a2[t] : 0.f;
-                dy2[t] = g.valid ? da * act_grad(y2[t], act) : 0.f;
-                if (K > 1 && g.valid) { s1[t] += dy2[t]; s2[t] += dy2[t] * (z2[t] - st2[2 * t]) * st2[2 * t + 1]; }
+            for (int r = 0; r < 4; ++r) {
+                const int t = 4 * q + r;
+                dy2[r] = g.valid ? da[r] * act_grad(y2[r], act) : 0.f;
+                if (K > 1 && g.valid) { s1[r] += dy2[r]; s2[r] += dy2[r] * (z2[r] - st2[2 * t]) * st2[2 * t + 1]; }
             }
+            ddw = quarters_sum(ddw);
             if (g.valid) {
-                f32x4* dst = (f32x4*)(dyb + e * 16);
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) dst[t4] = f32x4{dy2[4 * t4], dy2[4 * t4 + 1], dy2[4 * t4 + 2], dy2[4 * t4 + 3]};
-                ddwb[e] = ddw;
+                *(f32x4*)(dyb + g.e * 16 + 4 * q) = dy2;
+                if (q == 0) ddwb[g.e] = ddw;
             }
         } else {                                                     // PASS 2
-            float dz2[16];
-            if (g.valid) {
-                const f32x4* src = (const f32x4*)(dyb + e * 16);
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) { const f32x4 v = src[t4]; dz2[4 * t4] = v.x; dz2[4 * t4 + 1] = v.y; dz2[4 * t4 + 2] = v.z; dz2[4 * t4 + 3] = v.w; }
-            } else {
-#pragma unroll
-                for (int t = 0; t < 16; ++t) dz2[t] = 0.f;
-            }
+            f32x4 dz2 = g.valid ? *(const f32x4*)(dyb + g.e * 16 + 4 * q) : zero4;
             if (K > 1) {
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const float xh = (z2[t] - st2[2 * t]) * st2[2 * t + 1];
-                    dz2[t] = g.valid ? geo[GEO_IN2W + t] * st2[2 * t + 1] * (dz2[t] - gm[2 * t] - xh * gm[2 * t + 1]) : 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    const int t = 4 * q + r;
+                    const float xh = (z2[r] - st2[2 * t]) * st2[2 * t + 1];
+                    dz2[r] = g.valid ? P.in2w[r] * st2[2 * t + 1] * (dz2[r] - gm[2 * t] - xh * gm[2 * t + 1]) : 0.f;
                 }
             }
-            float in2[32], din[32];
+            outer_acc<32>(dz2, a1, p1, sg, acc);
+            const f32x4 din_a = fc32_t_mfma(P.w2t[0], dz2), din_p = fc32_t_mfma(P.w2t[1], dz2);
+            float ddw = 0.f;
+            const f32x4 da = pool_grad(din_a, din_p, a1, p1, g, ddw);
+            f32x4 dy1;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) { in2[t] = a1[t]; in2[16 + t] = p1[t]; }
-            outer_acc<32>(dz2, in2, stage, acc);
-            fc32_t(dz2, geo + GEO_FC2, din);
-            float dy1[16], ddw = 0.f;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const float dp = row16_sum(din[16 + t]);
-                const bool first = first_in_row(g.valid && a1[t] * g.dw == p1[t]);
-                const float da = din[t] + (first ? dp * g.dw : 0.f);
-                ddw += first ? dp * a1[t] : 0.f;
-                dy1[t] = g.valid ? da * act_grad(y1[t], act) : 0.f;
-                if (K > 1 && g.valid) { s1[t] += dy1[t]; s2[t] += dy1[t] * (z1[t] - st1[2 * t]) * st1[2 * t + 1]; }
+            for (int r = 0; r < 4; ++r) {
+                const int t = 4 * q + r;
+                dy1[r] = g.valid ? da[r] * act_grad(y1[r], act) : 0.f;
+                if (K > 1 && g.valid) { s1[r] += dy1[r]; s2[r] += dy1[r] * (z1[r] - st1[2 * t]) * st1[2 * t + 1]; }
             }
+            ddw = quarters_sum(ddw);
             if (g.valid) {
-                f32x4* dst = (f32x4*)(dyb + e * 16);
-#pragma unroll
-                for (int t4 = 0; t4 < 4; ++t4) dst[t4] = f32x4{dy1[4 * t4], dy1[4 * t4 + 1], dy1[4 * t4 + 2], dy1[4 * t4 + 3]};
-                ddwb[e] += ddw;
+                *(f32x4*)(dyb + g.e * 16 + 4 * q) = dy1;
+                if (q == 0) ddwb[g.e] += ddw;
             }
         }
     }
@@ -433,7 +490,7 @@ __global__ __launch_bounds__(FT_NT) void fka_bwd_kernel(const float* __restrict_
         if (threadIdx.x == 0) { part_ab[blk * 2] = a; part_ab[blk * 2 + 1] = b; }
     } else {
         outer_store<32>(acc, redw, part_w + blk * 512);
-        block_sum32(s1, s2, part_s + blk * 32, red);
+        block_sum_lane4(s1, s2, part_s + blk * 32, red);
     }
 }
 
