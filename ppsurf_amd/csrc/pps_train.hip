@@ -139,6 +139,80 @@ __global__ void __launch_bounds__(TB) contract_bwd_g_kernel(const float* __restr
     dg[t] = s;
 }
 
+// ---- the same three products on the matrix pipe (c a multiple of 16): per support point they are 16 x c x 16 matrix products, and the
+// operands can be loaded straight from global memory in v_mfma_f32_16x16x4_f32 fragment order (the contraction index may be permuted
+// freely, so a lane takes FOUR consecutive values with one 16-byte load and feeds them to four MFMA steps).  One wave per point.
+// fp32 MFMA is an exact fmaf chain: same arithmetic as the thread-per-output kernels above, which remain for c = 3 (the first layer).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int CW = 4;           // waves (= support points) per workgroup iteration
+
+// out[m, c*16 + t] = sum_j x[idx[m,j], c] g[m,j,t]:   D[c'][t] over 16-channel blocks, contraction over the neighbours j = 4 s + q
+__global__ void __launch_bounds__(CW * 64) contract_fwd_mfma_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
+                                                                    const float* __restrict__ g, int64_t m, int k, int c, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
+    for (int64_t row = (int64_t)blockIdx.x * CW + wave; row < m; row += (int64_t)gridDim.x * CW) {
+        float gb[4];
+        int64_t xr[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int j = 4 * s + q;
+            gb[s] = j < k ? g[(row * k + j) * KT + n] : 0.f;                     // B[j][t = n]
+            xr[s] = j < k ? idx[row * k + j] * c : -1;
+        }
+        for (int cb = 0; cb < c; cb += 16) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float a = xr[s] >= 0 ? x[xr[s] + cb + n] : 0.f;            // A[c' = n][j]
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gb[s], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(row * c + cb + 4 * q + r) * KT + n] = acc[r];      // D row 4 q + r = channel, column n = t
+        }
+    }
+}
+
+// dg[m,j,t] = sum_c dout[m, c*16+t] x[idx[m,j], c]:   D[j][t], contraction over the channels c = 16 cb + 4 q + s
+__global__ void __launch_bounds__(CW * 64) contract_bwd_g_mfma_kernel(const float* __restrict__ dout, const float* __restrict__ x,
+                                                                      const int64_t* __restrict__ idx, int64_t m, int k, int c,
+                                                                      float* __restrict__ dg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
+    for (int64_t row = (int64_t)blockIdx.x * CW + wave; row < m; row += (int64_t)gridDim.x * CW) {
+        const int64_t xr = n < k ? idx[row * k + n] * c : -1;                    // A row j = n
+        const float* dr = dout + row * c * KT + n;                               // B column t = n
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int cb = 0; cb < c; cb += 16) {
+            const f32x4 a4 = xr >= 0 ? *(const f32x4*)(x + xr + cb + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s], dr[(cb + 4 * q + s) * KT], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * q + r < k) dg[(row * k + 4 * q + r) * KT + n] = acc[r];
+    }
+}
+
+// dxg[m,j,c] = sum_t dout[m, c*16+t] g[m,j,t]:   D[c'][j], contraction over t = 4 q + s
+__global__ void __launch_bounds__(CW * 64) contract_bwd_x_mfma_kernel(const float* __restrict__ dout, const float* __restrict__ g, int64_t m, int k,
+                                                                      int c, float* __restrict__ dxg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
+    for (int64_t row = (int64_t)blockIdx.x * CW + wave; row < m; row += (int64_t)gridDim.x * CW) {
+        const f32x4 b4 = n < k ? *(const f32x4*)(g + (row * k + n) * KT + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};      // B[t][j = n]
+        for (int cb = 0; cb < c; cb += 16) {
+            const f32x4 a4 = *(const f32x4*)(dout + (row * c + cb + n) * KT + 4 * q);                               // A[c' = n][t]
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s], b4[s], acc, 0, 0, 0);
+            if (n < k) *(f32x4*)(dxg + (row * k + n) * c + cb + 4 * q) = acc;    // D rows 4 q + r = channels cb + 4 q + r, column n = j
+        }
+    }
+}
+
+inline unsigned point_blocks(int64_t m) {
+    const int64_t b = (m + CW - 1) / CW;
+    return (unsigned)(b < 8192 ? b : 8192);
+}
+
 // out[m,c] = max_j x[idx[m,j], c], arg[m,c] = first j attaining it
 __global__ void __launch_bounds__(TB) gather_max_arg_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
                                                             int64_t m, int k, int c, float* __restrict__ out,
@@ -215,7 +289,8 @@ int pps_neighbour_contract_fwd_f32(const float* x, const int64_t* idx, const flo
     if (m < 0 || k < 1 || c < 1) return 1;
     if (m == 0) return 0;
     if (!x || !idx || !g || !out) return 1;
-    contract_fwd_kernel<<<blocks_for(m * c), TB, 0, (hipStream_t)stream>>>(x, idx, g, m, k, c, out);
+    if ((c & 15) == 0 && k <= 16) contract_fwd_mfma_kernel<<<point_blocks(m), CW * 64, 0, (hipStream_t)stream>>>(x, idx, g, m, k, c, out);
+    else contract_fwd_kernel<<<blocks_for(m * c), TB, 0, (hipStream_t)stream>>>(x, idx, g, m, k, c, out);
     return launch_status();
 }
 
@@ -224,8 +299,15 @@ int pps_neighbour_contract_bwd_f32(const float* x, const int64_t* idx, const flo
     if (m < 0 || k < 1 || c < 1) return 1;
     if (m == 0) return 0;
     if (!x || !idx || !g || !dout || (!dxg && !dg)) return 1;
-    if (dxg) contract_bwd_x_kernel<<<blocks_for(m * c), TB, 0, (hipStream_t)stream>>>(dout, g, m, k, c, dxg);
-    if (dg) contract_bwd_g_kernel<<<blocks_for(m * k * KT), TB, 0, (hipStream_t)stream>>>(dout, x, idx, m, k, c, dg);
+    const bool mfma = (c & 15) == 0 && k <= 16;
+    if (dxg) {
+        if (mfma) contract_bwd_x_mfma_kernel<<<point_blocks(m), CW * 64, 0, (hipStream_t)stream>>>(dout, g, m, k, c, dxg);
+        else contract_bwd_x_kernel<<<blocks_for(m * c), TB, 0, (hipStream_t)stream>>>(dout, g, m, k, c, dxg);
+    }
+    if (dg) {
+        if (mfma) contract_bwd_g_mfma_kernel<<<point_blocks(m), CW * 64, 0, (hipStream_t)stream>>>(dout, x, idx, m, k, c, dg);
+        else contract_bwd_g_kernel<<<blocks_for(m * k * KT), TB, 0, (hipStream_t)stream>>>(dout, x, idx, m, k, c, dg);
+    }
     return launch_status();
 }
 
