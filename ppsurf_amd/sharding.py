@@ -156,12 +156,15 @@ def broadcast_buffers(module, src: int = 0):
 class GradBuckets:
     """Data-parallel gradient averaging for fit (one process per GPU, shapes sharded over the ranks).
 
-    All gradients live in a few large flat fp32 buffers (`p.grad` are views), filled in the order the backward pass produces
-    them (decoder first, encoder last).  When the last gradient of a bucket has been accumulated its all-reduce is issued
-    asynchronously, so the collective of the decoder bucket overlaps the encoder's backward; `finish()` launches whatever is
-    left (buckets holding parameters that got no gradient this step -- they contribute zeros, identically on every rank),
-    waits, and divides by the world size.  Few, large messages: a ring all-reduce over xGMI is per-link bound
-    (~153 GB/s), so 55 MB of fp32 gradients cost ~1 ms as 3 buckets and far more as 455 per-tensor collectives."""
+    All gradients end up in a few large flat fp32 buffers, in the order the backward pass produces them (decoder first, encoder
+    last).  Autograd hands every parameter its own gradient tensor (`p.grad` is None when backward starts, so nothing is added
+    to anything: accumulating into 298 pre-existing views cost 298 four-microsecond `add_` launches per step); when the last
+    gradient of a bucket has arrived, ONE multi-tensor copy moves the bucket's gradients into its flat buffer, `p.grad` is
+    re-pointed at the views and the bucket's all-reduce is issued asynchronously, so the collective of the decoder bucket
+    overlaps the encoder's backward; `finish()` launches whatever is left (buckets holding parameters that got no gradient
+    this step -- they contribute zeros, identically on every rank), waits, and divides by the world size.  Few, large
+    messages: a ring all-reduce over xGMI is per-link bound (~153 GB/s), so 55 MB of fp32 gradients cost ~1 ms as 3 buckets
+    and far more as 455 per-tensor collectives."""
 
     def __init__(self, params, n_buckets=3):
         import torch.distributed as dist
@@ -178,15 +181,17 @@ class GradBuckets:
                 cur, size = [], 0
         if cur:
             self.buckets.append(cur)
-        self.flat, self.pending, self.handles, self.launched = [], [], [], []
+        self.flat, self.views, self.pending, self.handles, self.launched = [], [], [], [], []
         for bi, bucket in enumerate(self.buckets):
             flat = torch.zeros(sum(p.numel() for p in bucket), dtype=torch.float32, device=bucket[0].device)
-            off = 0
+            off, views = 0, []
             for p in bucket:
-                p.grad = flat[off:off + p.numel()].view_as(p)
+                views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
+                p.grad = None
                 p.register_post_accumulate_grad_hook(self._hook(bi))
             self.flat.append(flat)
+            self.views.append(views)
         self._reset()
 
     def _reset(self):
@@ -206,18 +211,20 @@ class GradBuckets:
     def _launch(self, bi):
         _, ws = world()
         self.launched[bi] = True
+        pairs = [(v, p) for v, p in zip(self.views[bi], self.buckets[bi]) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        if pairs:
+            torch._foreach_copy_([v for v, _ in pairs], [p.grad for _, p in pairs])
+            for v, p in pairs:
+                p.grad = v
         if ws > 1:
             self.handles.append(self.dist.all_reduce(self.flat[bi], op=self.dist.ReduceOp.SUM, async_op=True))
 
     def zero(self):
-        """Replaces optimizer.zero_grad(): the views must stay attached to the flat buffers."""
+        """Replaces optimizer.zero_grad(): flat buffers cleared (slots of parameters without a gradient stay zero), every p.grad None."""
         for flat, bucket in zip(self.flat, self.buckets):
             flat.zero_()
-            off = 0
             for p in bucket:
-                if p.grad is None or p.grad.data_ptr() != flat.data_ptr() + 4 * off:
-                    p.grad = flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
+                p.grad = None
         self._reset()
 
     def finish(self):

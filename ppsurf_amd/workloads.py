@@ -136,13 +136,14 @@ class FitStep:
     the step body of ppsurf_amd.fit (fused AdamW; graph=True additionally replays it as a HIP graph like PPS_FIT_GRAPH=1)."""
 
     def __init__(self, batch=10, n=10000, q=2000, p=50, precision='bf16-mixed', device='cuda:0', n_batches=2, graph=False):
-        from . import modules, fit
+        from . import modules, fit, sharding
         self.p, self.dev = p, torch.device(device)
         with contextlib.redirect_stdout(io.StringIO()):
             net = modules.PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=p, pointnet_latent_size=256)
         net.load_state_dict(synthetic.network_state_dict('ppsurf', num_pts_local=p))
         self.net = net.to(self.dev).train()
         self.opt = torch.optim.AdamW(self.net.parameters(), lr=1e-3, eps=1e-5, weight_decay=1e-2, fused=True, capturable=graph)   # configs/poco.yaml:60-69, fused like ppsurf_amd.fit
+        self.buckets = sharding.GradBuckets([q for q in self.net.parameters() if q.requires_grad])      # as ppsurf_amd.fit (one rank: no collective)
         self.autocast = {'bf16-mixed': torch.bfloat16, '16-mixed': torch.float16}.get(precision)
         self.batches = [self._raw_batch(batch, n, q, s) for s in range(n_batches)]
         self.i = 0
@@ -165,11 +166,12 @@ class FitStep:
 
     def _body(self, batch, bi):
         from . import train_graph
-        self.opt.zero_grad(set_to_none=False)
+        self.buckets.zero()
         with torch.autocast('cuda', dtype=self.autocast or torch.bfloat16, enabled=self.autocast is not None):
             logits = self.net.forward(batch)
             loss = torch.nn.functional.cross_entropy(logits.float(), batch['occ'], reduction='none').mean()
         loss.backward()
+        self.buckets.finish()
         self.opt.step()
         train_graph.release_step_caches()
         self.stepper.metrics.values = {'loss': loss.detach()}
