@@ -41,6 +41,44 @@ SPLITK_SLABS = 64            # row slabs of the split-K weight gradient (64 / 12
                              # aperture violation on replay, tools/fit_graph_matrix.py; 32 and 64 replay correctly)
 
 
+# bf16 images of the fp32 master parameters, refreshed once per forward pass by ONE multi-tensor copy (prepare_shadows): the library GEMMs
+# of the encoder otherwise cast every weight and bias with a launch of its own (~140 four-microsecond kernels per step)
+_shadow = {}                 # id(parameter) -> bf16 tensor of the same shape (persistent storage)
+_shadow_live = [False]
+
+
+def prepare_shadows(module):
+    """Call at the start of a bf16-autocast forward pass in train(): parameters -> persistent bf16 images."""
+    params = [p for p in module.parameters() if p.is_cuda and p.dtype == torch.float32]
+    if not params:
+        return
+    with torch.no_grad():
+        for p in params:
+            t = _shadow.get(id(p))
+            if t is None or t.shape != p.shape or t.device != p.device:
+                _shadow[id(p)] = torch.empty_like(p, dtype=torch.bfloat16)
+        torch._foreach_copy_([_shadow[id(p)] for p in params], params)
+    _shadow_live[0] = True
+
+
+def _bf16_of(param):
+    """The bf16 image of a parameter if prepare_shadows() ran for this step, else None."""
+    return _shadow.get(id(param)) if _shadow_live[0] and param is not None else None
+
+
+_mm_fp32_out = [True]
+
+
+def _mm_f32(a, b):
+    """a @ b for bf16 operands with an fp32 result written by the GEMM itself (no separate cast of the weight gradient)."""
+    if _mm_fp32_out[0] and a.is_cuda and a.dtype == torch.bfloat16:
+        try:
+            return torch.mm(a, b, out_dtype=torch.float32)
+        except (TypeError, RuntimeError, NotImplementedError):
+            _mm_fp32_out[0] = False
+    return (a @ b).float()
+
+
 class _RowsLinear(torch.autograd.Function):
     """y = x W^T + b for a tall-skinny x [rows, K] (rows = all points / patch points / neighbours of the batch, K <= 512).
 
@@ -50,12 +88,14 @@ class _RowsLinear(torch.autograd.Function):
     accumulation and the partials are summed in fp32 (0.33 ms; 0.06 ms instead of 1.3 ms for the 64-channel PointNet layers)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, wc=None, bc=None):
         dev = x.device.type
         dt = torch.get_autocast_dtype(dev) if torch.is_autocast_enabled(dev) else x.dtype
-        xc, wc = x.to(dt), w.to(dt)
+        xc = x.to(dt)
+        wc = wc if (wc is not None and wc.dtype == dt) else w.to(dt)            # wc / bc: bf16 images of the step (prepare_shadows)
+        bc = None if b is None else (bc if (bc is not None and bc.dtype == dt) else b.to(dt))
         with torch.autocast(dev, enabled=False):
-            y = F.linear(xc, wc, None if b is None else b.to(dt))
+            y = F.linear(xc, wc, bc)
         ctx.save_for_backward(xc, wc)
         ctx.meta = (x.dtype, w.dtype, None if b is None else b.dtype)
         return y
@@ -71,27 +111,31 @@ class _RowsLinear(torch.autograd.Function):
             dx = (g @ wc).to(xdt)
         if ctx.needs_input_grad[1]:
             rows = g.shape[0]
-            s = SPLITK_SLABS if rows >= SPLITK_SLABS * 1024 else 64
-            rs = rows // s
-            main = rs * s
-            dw = torch.bmm(g[:main].view(s, rs, -1).transpose(1, 2), xc[:main].view(s, rs, -1)).sum(0, dtype=acc)
-            if main < rows:
-                dw = dw + (g[main:].t() @ xc[main:]).to(acc)
+            if rows < SPLITK_MIN_ROWS:
+                dw = _mm_f32(g.t(), xc) if acc == torch.float32 else g.t() @ xc
+            else:
+                s = SPLITK_SLABS if rows >= SPLITK_SLABS * 1024 else 64
+                rs = rows // s
+                main = rs * s
+                dw = torch.bmm(g[:main].view(s, rs, -1).transpose(1, 2), xc[:main].view(s, rs, -1)).sum(0, dtype=acc)
+                if main < rows:
+                    dw = dw + (g[main:].t() @ xc[main:]).to(acc)
             dw = dw.to(wdt)
         if bdt is not None and ctx.needs_input_grad[2]:
             db = g.sum(0, dtype=acc).to(bdt)
-        return dx, dw, db
+        return dx, dw, db, None, None
 
 
-def rows_linear(x, w, b=None):
-    if x.shape[0] >= SPLITK_MIN_ROWS and x.dim() == 2:
-        return _RowsLinear.apply(x, w, b)
+def rows_linear(x, w, b=None, wc=None, bc=None):
+    if x.dim() == 2 and (x.shape[0] >= SPLITK_MIN_ROWS or wc is not None):
+        return _RowsLinear.apply(x, w, b, wc, bc)
     return F.linear(x, w, b)
 
 
 def dense(layer, x):
     """1x1 Conv1d / Conv2d / Linear holder applied to rows."""
-    return rows_linear(x, _w2d(layer), layer.bias)
+    wc = _bf16_of(layer.weight)
+    return rows_linear(x, _w2d(layer), layer.bias, None if wc is None else wc.reshape(wc.shape[0], -1), _bf16_of(layer.bias))
 
 
 _counters = []
@@ -162,6 +206,7 @@ def release_step_caches():
     """Drop the id-table caches (call once per optimisation step, after backward)."""
     _flat_cache.clear()
     train_ops.clear_cache()
+    _shadow_live[0] = False
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -190,7 +235,8 @@ def fkaconv_layer(layer, x, pts, sup, ids):
         with torch.no_grad():                               # IN PLACE: a replayed HIP graph reads and writes the buffer's own storage
             layer.norm_radius.copy_(radius.detach().reshape(layer.norm_radius.shape))
     feat = train_ops.neighbour_contract(x.reshape(b * n, cin), flat, g)                  # [B*M, Cin*16]
-    return rows_linear(feat, _w2d(layer.cv)).view(b, m, -1)                              # Conv2d (1,16): (c,t) -> c*16+t
+    wc = _bf16_of(layer.cv.weight)
+    return rows_linear(feat, _w2d(layer.cv), None, None if wc is None else wc.reshape(wc.shape[0], -1)).view(b, m, -1)   # Conv2d (1,16): (c,t) -> c*16+t
 
 
 @_counted
@@ -280,7 +326,10 @@ def interp_attention(proj, latents, pts, query, ids, last_layer=True):
     # fc1 is linear in [latent ; q - p]: its latent part is evaluated once per POINT (B*N rows instead of B*Q*k) and gathered --
     # the per-point table G of the inference kernels (identity 1); autograd differentiates this form
     w1 = _w2d(proj.fc1)
-    table = rows_linear(latents.reshape(b * n, c), w1[:, :c], proj.fc1.bias)             # [B*N, C]
+    w1c = _bf16_of(proj.fc1.weight)
+    w1c = None if w1c is None else w1c.reshape(w1c.shape[0], -1)
+    table = rows_linear(latents.reshape(b * n, c), w1[:, :c], proj.fc1.bias, None if w1c is None else w1c[:, :c].contiguous(),
+                        _bf16_of(proj.fc1.bias))                                         # [B*N, C]
     rel = (query.unsqueeze(2) - pts.reshape(b * n, 3)[flat].view(b, q, k, 3)).reshape(-1, 3)     # query minus neighbour
     if (FUSED_ROWS and fused_rows_ok(latents) and train_ops.attn_pool_supported(k, _w2d(proj.fc_query).shape[0], 256)
             and all(train_ops.rows_layer_supported(b * q * k, *reversed(_w2d(l).shape)) for l in (proj.fc2, proj.fc3, proj.fc_query))):
@@ -421,13 +470,20 @@ def ppsurf_from_latent(net, latents, data, proj_ids):
     return out.view(b, q, -1).transpose(1, 2)
 
 
+def _prepare(net, x):
+    if x.is_cuda and net.training and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16:
+        prepare_shadows(net)
+
+
 @_counted
 def ppsurf_forward(net, data, proj_ids):
+    _prepare(net, data['pts'])
     return ppsurf_from_latent(net, encoder(net.encoder, data), data, proj_ids)
 
 
 @_counted
 def poco_forward(net, data, proj_ids):
+    _prepare(net, data['pts'])
     pts = _point_major(data['pts']).contiguous()
     query = _point_major(data['pts_query']).contiguous()
     return interp_attention(net.projection, encoder(net.encoder, data), pts, query, proj_ids).transpose(1, 2)
