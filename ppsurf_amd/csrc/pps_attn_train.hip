@@ -197,7 +197,7 @@ __global__ __launch_bounds__(AT_NT) void attn_pool_bwd_kernel(const T* __restric
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int PA_K = 64;
 constexpr int PA_WAVES = 4;
-constexpr int PA_MAXBLK = 512;
+constexpr int PA_MAXBLK = 2048;      // 8 workgroups per CU: the kernels alternate load and compute phases per group, more resident waves hide the loads
 
 __device__ __forceinline__ float4 unpack4(const uint2 u) {
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
