@@ -321,6 +321,16 @@ int pps_patch_attn_partials(int64_t q);
 int pps_patch_attn_fwd(const void* h, const float* v, int64_t q, int k, int c, float* pooled, void* stream);
 int pps_patch_attn_bwd(const void* h, const float* v, const float* dpooled, int64_t q, int k, int c, void* dh, float* dv_part, void* stream);
 
+/* Input of the interpolation head in train() (source/poco_model.py:400-404 with fc1 split into its latent and its offset part):
+ * h1[(q,j),:] = table[ids[q,j],:] + wx (query[q] - pts[ids[q,j]]).  table [n, c] bf16, ids [q*k] (rows of table and pts), pts [n, 3] and
+ * query [q, 3] fp32, wx [c, 3] fp32, h1 [q*k, c] bf16; c a multiple of 8 with (c / 8) dividing 256.  pps_head_input_dwx: d wx [c, 3] from
+ * dh1 [q*k, c] bf16 (d table is the segmented sum of dh1, pps_segment_sum_rows_bf16).  ws: pps_head_input_ws_bytes(c) bytes. */
+size_t pps_head_input_ws_bytes(int c);
+int pps_head_input_fwd(const void* table, const int64_t* ids, const float* pts, const float* query, int64_t q, int k, int c, const float* wx, void* h1,
+                       void* stream);
+int pps_head_input_dwx(const void* dh1, const int64_t* ids, const float* pts, const float* query, int64_t q, int k, int c, float* dwx, void* ws,
+                       void* stream);
+
 /* conv0a of PointNet in train() (3 coordinates -> 64 channels, source/base/nn.py:323): y [rows, 64] bf16 = x [rows, 3] w^T + bias with the batch
  * statistics of y -> out_affine / save / running statistics as in pps_rows_layer_fwd; backward: dw [64, 3], dbias [64] (NULL = skip), dgamma,
  * dbeta (x gets no gradient: it is the input patch).  ws: pps_rows3_ws_bytes() bytes. */

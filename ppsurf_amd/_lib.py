@@ -65,6 +65,9 @@ SIGNATURES = {
     'pps_patch_attn_partials': (_I, [_I64]),
     'pps_patch_attn_fwd': (_I, [_P, _P, _I64, _I, _I, _P, _P]),
     'pps_patch_attn_bwd': (_I, [_P, _P, _P, _I64, _I, _I, _P, _P, _P]),
+    'pps_head_input_ws_bytes': (_SZ, [_I]),
+    'pps_head_input_fwd': (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _P, _P]),
+    'pps_head_input_dwx': (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _P, _P]),
     'pps_rows3_ws_bytes': (_SZ, []),
     'pps_rows3_fwd': (_I, [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _c.c_float, _P, _P, _P, _P]),
     'pps_rows3_bwd': (_I, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -970,6 +970,60 @@ __global__ __launch_bounds__(256, 2) void patch_transform_bwd_kernel(const PtArg
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Input of the interpolation head (source/poco_model.py:400-404 with fc1 split into its latent and its offset part):
+//     h1[(q, j), :] = table[ids[q, j], :] + Wx (query[q] - pts[ids[q, j]])          table [N, C] bf16, h1 [Q*k, C] bf16, Wx [C, 3]
+// one 16-byte chunk (8 channels) per thread, written once (gather, offset, 3 -> C layer and the sum were four passes over [Q*k, C]).
+// Backward: d table through the segmented sum of the gather (pps_segment_sum_rows_bf16), d Wx[c][d] = sum_rows dh1[row][c] * rel[row][d] here.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_input_fwd_kernel(const uint16_t* __restrict__ table, const int64_t* __restrict__ ids,
+                                                            const float* __restrict__ pts, const float* __restrict__ query, int64_t rows, int k, int c,
+                                                            const float* __restrict__ wx, uint16_t* __restrict__ h1) {
+    const int cpr = c >> 3;                                   // chunks per row
+    const int ch = threadIdx.x % cpr, rl = threadIdx.x / cpr, rpb = 256 / cpr;
+    float w[8][3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { w[j][0] = wx[(8 * ch + j) * 3]; w[j][1] = wx[(8 * ch + j) * 3 + 1]; w[j][2] = wx[(8 * ch + j) * 3 + 2]; }
+    for (int64_t row = (int64_t)blockIdx.x * rpb + rl; row < rows; row += (int64_t)gridDim.x * rpb) {
+        const int64_t n = ids[row], q = row / k;
+        const float r0 = query[q * 3] - pts[n * 3], r1 = query[q * 3 + 1] - pts[n * 3 + 1], r2 = query[q * 3 + 2] - pts[n * 3 + 2];
+        const u32x4 t = *(const u32x4*)(table + n * c + 8 * ch);
+        float e[8] = {lo16(t.x), hi16(t.x), lo16(t.y), hi16(t.y), lo16(t.z), hi16(t.z), lo16(t.w), hi16(t.w)};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] += w[j][0] * r0 + w[j][1] * r1 + w[j][2] * r2;
+        *(u32x4*)(h1 + row * c + 8 * ch) = u32x4{pack2(e[0], e[1]), pack2(e[2], e[3]), pack2(e[4], e[5]), pack2(e[6], e[7])};
+    }
+}
+
+// partial [block][c * 3]: d Wx
+__global__ __launch_bounds__(256) void head_input_dwx_kernel(const uint16_t* __restrict__ dh1, const int64_t* __restrict__ ids,
+                                                            const float* __restrict__ pts, const float* __restrict__ query, int64_t rows, int k, int c,
+                                                            float* __restrict__ partials) {
+    __shared__ float red[256][25];
+    const int cpr = c >> 3;
+    const int ch = threadIdx.x % cpr, rl = threadIdx.x / cpr, rpb = 256 / cpr;
+    float acc[8][3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j][0] = acc[j][1] = acc[j][2] = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * rpb + rl; row < rows; row += (int64_t)gridDim.x * rpb) {
+        const int64_t n = ids[row], q = row / k;
+        const float r0 = query[q * 3] - pts[n * 3], r1 = query[q * 3 + 1] - pts[n * 3 + 1], r2 = query[q * 3 + 2] - pts[n * 3 + 2];
+        const u32x4 t = *(const u32x4*)(dh1 + row * c + 8 * ch);
+        const float g[8] = {lo16(t.x), hi16(t.x), lo16(t.y), hi16(t.y), lo16(t.z), hi16(t.z), lo16(t.w), hi16(t.w)};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { acc[j][0] += g[j] * r0; acc[j][1] += g[j] * r1; acc[j][2] += g[j] * r2; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[threadIdx.x][3 * j] = acc[j][0]; red[threadIdx.x][3 * j + 1] = acc[j][1]; red[threadIdx.x][3 * j + 2] = acc[j][2]; }
+    __syncthreads();
+    for (int o = threadIdx.x; o < c * 3; o += 256) {             // output (channel, d): the threads of that channel's chunk in row-lane order
+        const int cc = o / 3, d = o - 3 * cc;
+        float t = 0.f;
+        for (int r = 0; r < rpb; ++r) t += red[r * cpr + (cc >> 3)][3 * (cc & 7) + d];
+        partials[(int64_t)blockIdx.x * c * 3 + o] = t;
+    }
+}
+
 int g_cus = 0;
 int cu_count() {
     if (g_cus == 0) {
@@ -1114,6 +1168,35 @@ int pps_patch_transform_bwd(const void* x, const float* in_scale, const float* i
     const int grid = (int)(q < 4 * (int64_t)MAXP ? q : 4 * (int64_t)MAXP);
     hipLaunchKernelGGL(patch_transform_bwd_kernel, dim3(grid), dim3(256), 0, st, a);
     if (d_in_affine) launch_sum_partials((const float*)ws, grid, 128, d_in_affine, st);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+/* Input of the interpolation head in train(): h1[(q,j),:] = table[ids[q,j],:] + wx (query[q] - pts[ids[q,j]]) (source/poco_model.py:400-404 with
+ * fc1 split into latent and offset part).  table [n, c] bf16, ids [q*k] rows of table / pts, pts [n, 3], query [q, 3] fp32, wx [c, 3] fp32,
+ * h1 [q*k, c] bf16; c a multiple of 8 dividing 2048.  dwx: d wx [c, 3] from dh1 [q*k, c] bf16; ws: pps_head_input_ws_bytes(c) bytes. */
+size_t pps_head_input_ws_bytes(int c) { return c > 0 ? (size_t)4 * MAXP * c * 3 * sizeof(float) : 0; }
+
+int pps_head_input_fwd(const void* table, const int64_t* ids, const float* pts, const float* query, int64_t q, int k, int c, const float* wx, void* h1,
+                       void* stream) {
+    if (q < 0 || k < 1 || c < 8 || (c & 7) || 256 % (c >> 3)) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    if (!table || !ids || !pts || !query || !wx || !h1) return PPS_ERR_ARG;
+    const int64_t rows = q * k, blocks = (rows + 256 / (c >> 3) - 1) / (256 / (c >> 3));
+    const int grid = (int)(blocks < 16 * (int64_t)cu_count() ? blocks : 16 * (int64_t)cu_count());
+    hipLaunchKernelGGL(head_input_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)table, ids, pts, query, rows, k, c, wx,
+                       (uint16_t*)h1);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+int pps_head_input_dwx(const void* dh1, const int64_t* ids, const float* pts, const float* query, int64_t q, int k, int c, float* dwx, void* ws,
+                       void* stream) {
+    if (q < 1 || k < 1 || c < 8 || (c & 7) || 256 % (c >> 3)) return PPS_ERR_ARG;
+    if (!dh1 || !ids || !pts || !query || !dwx || !ws) return PPS_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t rows = q * k, blocks = (rows + 256 / (c >> 3) - 1) / (256 / (c >> 3));
+    const int grid = (int)(blocks < 4 * (int64_t)MAXP ? blocks : 4 * (int64_t)MAXP);
+    hipLaunchKernelGGL(head_input_dwx_kernel, dim3(grid), dim3(256), 0, st, (const uint16_t*)dh1, ids, pts, query, rows, k, c, (float*)ws);
+    launch_sum_partials((const float*)ws, grid, (int64_t)c * 3, dwx, st);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 

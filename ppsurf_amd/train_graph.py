@@ -330,12 +330,12 @@ def interp_attention(proj, latents, pts, query, ids, last_layer=True):
     w1c = None if w1c is None else w1c.reshape(w1c.shape[0], -1)
     table = rows_linear(latents.reshape(b * n, c), w1[:, :c], proj.fc1.bias, None if w1c is None else w1c[:, :c].contiguous(),
                         _bf16_of(proj.fc1.bias))                                         # [B*N, C]
-    rel = (query.unsqueeze(2) - pts.reshape(b * n, 3)[flat].view(b, q, k, 3)).reshape(-1, 3)     # query minus neighbour
     if (FUSED_ROWS and fused_rows_ok(latents) and train_ops.attn_pool_supported(k, _w2d(proj.fc_query).shape[0], 256)
-            and all(train_ops.rows_layer_supported(b * q * k, *reversed(_w2d(l).shape)) for l in (proj.fc2, proj.fc3, proj.fc_query))):
+            and all(train_ops.rows_layer_supported(b * q * k, *reversed(_w2d(l).shape)) for l in (proj.fc2, proj.fc3, proj.fc_query))
+            and train_ops.head_input_supported(w1.shape[0])):
         # fc2, fc3, fc_query as fused row layers (pps_rows_train.hip): each stores its RAW output once, the ReLU is applied by the consumer on
         # load (and masks the gradient on the way back), so no activated [B*Q*k, 256] tensor is written or read
-        h1 = train_ops.gather_rows(table, flat) + rows_linear(rel, w1[:, c:]).to(table.dtype)
+        h1 = train_ops.head_input(table, flat, pts.reshape(b * n, 3), query.reshape(b * q, 3), k, w1[:, c:])
         y2 = train_ops.rows_layer(train_ops.Act(h1, None, True), _w2d(proj.fc2), proj.fc2.bias, None, True)
         y3 = train_ops.rows_layer(y2, _w2d(proj.fc3), proj.fc3.bias, None, True)
         pooled = train_ops.query_attn_pool(y3.raw, _w2d(proj.fc_query), proj.fc_query.bias, k)      # fc_query + attention pooling: one node
@@ -343,6 +343,7 @@ def interp_attention(proj, latents, pts, query, ids, last_layer=True):
         if last_layer:
             out = dense(proj.fc8, out)
         return out.view(b, q, -1)
+    rel = (query.unsqueeze(2) - pts.reshape(b * n, 3)[flat].view(b, q, k, 3)).reshape(-1, 3)     # query minus neighbour
     h = F.relu(train_ops.gather_rows(table, flat) + rows_linear(rel, w1[:, c:]).to(table.dtype))
     h = F.relu(dense(proj.fc2, h))
     h = F.relu(dense(proj.fc3, h))

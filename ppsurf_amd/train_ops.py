@@ -88,6 +88,57 @@ class _GatherRows(torch.autograd.Function):
         return dx.to(ctx.dtype), None
 
 
+class _HeadInput(torch.autograd.Function):
+    """h1[(q,j)] = table[ids[q,j]] + wx (query[q] - pts[ids[q,j]]): gather, neighbour offset, 3 -> C layer and sum of the interpolation head's
+    first layer in one pass (pps_head_input_fwd); backward: d table by the segmented sum of the gather, d wx by pps_head_input_dwx."""
+
+    @staticmethod
+    def forward(ctx, table, ids, pts, query, k, wx):
+        _need_cuda(table, ids, pts, query, wx)
+        L = _lib.lib()
+        table = table.to(torch.bfloat16).contiguous()
+        ids = ids.contiguous()
+        pts32, q32 = pts.detach().float().contiguous(), query.detach().float().contiguous()
+        wx32 = wx.detach().float().contiguous()
+        nq, c = q32.shape[0], table.shape[1]
+        h1 = torch.empty((nq * k, c), device=table.device, dtype=torch.bfloat16)
+        _lib.check(L.pps_head_input_fwd(table.data_ptr(), ids.data_ptr(), pts32.data_ptr(), q32.data_ptr(), nq, k, c, wx32.data_ptr(), h1.data_ptr(),
+                                        _stream()), 'pps_head_input_fwd')
+        ctx.save_for_backward(ids, pts32, q32)
+        ctx.meta = (table.shape[0], k, c, wx.dtype, wx.shape)
+        return h1
+
+    @staticmethod
+    def backward(ctx, dh1):
+        ids, pts32, q32 = ctx.saved_tensors
+        n, k, c, wdt, wshape = ctx.meta
+        L = _lib.lib()
+        dh1 = dh1.to(torch.bfloat16).contiguous()
+        dtable = dwx = None
+        if ctx.needs_input_grad[0]:
+            order, offsets = csr(ids, n)
+            dt32 = torch.empty((n, c), device=dh1.device, dtype=torch.float32)
+            _lib.check(L.pps_segment_sum_rows_bf16(dh1.data_ptr(), order.data_ptr(), offsets.data_ptr(), n, c, dt32.data_ptr(), _stream()),
+                       'pps_segment_sum_rows_bf16')
+            dtable = dt32.to(torch.bfloat16)
+        if ctx.needs_input_grad[5]:
+            dwx = torch.empty((c, 3), device=dh1.device, dtype=torch.float32)
+            ws = torch.empty((L.pps_head_input_ws_bytes(c),), device=dh1.device, dtype=torch.uint8)
+            _lib.check(L.pps_head_input_dwx(dh1.data_ptr(), ids.data_ptr(), pts32.data_ptr(), q32.data_ptr(), q32.shape[0], k, c, dwx.data_ptr(),
+                                            ws.data_ptr(), _stream()), 'pps_head_input_dwx')
+            dwx = dwx.reshape(wshape).to(wdt)
+        return dtable, None, None, None, None, dwx
+
+
+def head_input_supported(c):
+    return c % 8 == 0 and 256 % (c // 8) == 0
+
+
+def head_input(table, ids, pts, query, k, wx):
+    """table [N, C] (bf16), ids [Q*k] rows of table / pts, pts [N, 3], query [Q, 3], wx [C, 3] -> h1 [Q*k, C] bf16 (before its ReLU)."""
+    return _HeadInput.apply(table, ids, pts, query, k, wx)
+
+
 class _NeighbourMax(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
