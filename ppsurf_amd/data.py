@@ -210,6 +210,48 @@ class PPSurfDataset(TrainDataset):
         return PPSurfDataset.model_space_to_patch_space(pts_local_ms, pts_query_ms, radius)
 
 
+def _record_stream(obj, stream):
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream)
+
+
+class DevicePrefetch:
+    """Builds the device side of the NEXT batch (patch search, support sampling, the 13 + 1 id tables: ~4 ms of kernels of which the sampling
+    runs on 10 workgroups) on a second HIP stream while the optimisation step of the current batch runs on the main stream -- what the
+    reference's DataLoader worker processes do on the CPU.  `take(make_current, make_next)` returns the current batch (built now if nothing was
+    prefetched) and starts the next one.  The tensors are allocated on the side stream: before they are handed to the consumer the main
+    stream waits for the side stream's event and every tensor is recorded on the main stream (caching-allocator rule for cross-stream use)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.side = torch.cuda.Stream(self.device)
+        self.pending = None                      # (batch, event)
+
+    def _launch(self, make):
+        main = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(main)              # inputs produced on the main stream (uploaded clouds) are complete
+        with torch.cuda.stream(self.side):
+            batch = make()
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        return batch, ev
+
+    def take(self, make_current, make_next):
+        main = torch.cuda.current_stream(self.device)
+        batch, ev = self.pending if self.pending is not None else self._launch(make_current)
+        main.wait_event(ev)
+        _record_stream(batch, main)
+        self.pending = self._launch(make_next) if make_next is not None else None
+        return batch
+
+
 class DeviceBatchLoader:
     """DataLoader stand-in for fit / validation: shuffling like torch's RandomSampler (non-DDP) or DistributedSampler
     (seed 0 + epoch, padded to a multiple of the world size, rank-strided; occupancy_data_module.py:108-137), batches built by
@@ -248,12 +290,29 @@ class DeviceBatchLoader:
         idx = self._indices()
         starts = list(range(0, len(idx), self.batch_size))
         load = lambda s: [self.dataset[i] for i in idx[s:s + self.batch_size]]
+        import os
+        dev = torch.device(self.device)
+        prefetch = DevicePrefetch(dev) if (dev.type == 'cuda' and os.environ.get('PPS_PREP_STREAM', '1') != '0') else None
         with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:
             nxt = pool.submit(load, starts[0]) if starts else None
+            if prefetch is None:
+                for k, s in enumerate(starts):
+                    items = nxt.result()
+                    nxt = pool.submit(load, starts[k + 1]) if k + 1 < len(starts) else None
+                    yield self.dataset.collate_on_device(items, self.device)
+                return
+            # the device side of batch k + 1 (patches, support levels, id tables) is issued on a second stream before batch k is handed out
+            items = nxt.result() if starts else None
             for k, s in enumerate(starts):
-                items = nxt.result()
                 nxt = pool.submit(load, starts[k + 1]) if k + 1 < len(starts) else None
-                yield self.dataset.collate_on_device(items, self.device)
+                cur_items, fut = items, nxt
+
+                def make_next(fut=fut):
+                    return self.dataset.collate_on_device(fut.result(), self.device)
+
+                batch = prefetch.take(lambda: self.dataset.collate_on_device(cur_items, self.device), make_next if fut is not None else None)
+                items = fut.result() if fut is not None else None
+                yield batch
 
 
 def _collate1(item):

@@ -135,7 +135,7 @@ class FitStep:
     on the device inside the step (what the reference's dataset workers do on the CPU), then forward, loss, backward, AdamW --
     the step body of ppsurf_amd.fit (fused AdamW; graph=True additionally replays it as a HIP graph like PPS_FIT_GRAPH=1)."""
 
-    def __init__(self, batch=10, n=10000, q=2000, p=50, precision='bf16-mixed', device='cuda:0', n_batches=2, graph=False):
+    def __init__(self, batch=10, n=10000, q=2000, p=50, precision='bf16-mixed', device='cuda:0', n_batches=2, graph=False, overlap_prep=True):
         from . import modules, fit, sharding
         self.p, self.dev = p, torch.device(device)
         with contextlib.redirect_stdout(io.StringIO()):
@@ -153,6 +153,8 @@ class FitStep:
             values = {}
 
         self.stepper = fit.GraphedStep(self._body, _Log(), enabled=graph)
+        from . import data
+        self.prefetch = data.DevicePrefetch(self.dev) if (overlap_prep and not graph) else None
 
     def _raw_batch(self, b, n, q, seed):
         rng = np.random.default_rng(seed)
@@ -176,11 +178,18 @@ class FitStep:
         train_graph.release_step_caches()
         self.stepper.metrics.values = {'loss': loss.detach()}
 
-    def __call__(self):
-        batch = dict(self.batches[self.i % len(self.batches)])
-        self.i += 1
+    def _prepare(self, i):
+        """Patches, support levels and id tables of batch i on the device (what data.TrainDataset.collate_on_device does)."""
+        batch = dict(self.batches[i % len(self.batches)])
         b = batch['pts_ms'].shape[0]
-        batch['pts_local_ps'] = spatial.get_pts_local_ps_batch([batch['pts_ms'][i] for i in range(b)], batch['pts_query_ms'], self.p)
-        batch = {k: v for k, v in spatial.get_data_poco(batch).items() if not k.startswith('_')}
+        batch['pts_local_ps'] = spatial.get_pts_local_ps_batch([batch['pts_ms'][j] for j in range(b)], batch['pts_query_ms'], self.p)
+        return {k: v for k, v in spatial.get_data_poco(batch).items() if not k.startswith('_')}
+
+    def __call__(self):
+        if self.prefetch is None:
+            batch = self._prepare(self.i)
+        else:
+            batch = self.prefetch.take(lambda: self._prepare(self.i), lambda: self._prepare(self.i + 1))
+        self.i += 1
         self.stepper.run(batch, self.i)
         return self.stepper.metrics.values['loss']
