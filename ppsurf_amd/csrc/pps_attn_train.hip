@@ -100,11 +100,16 @@ __global__ __launch_bounds__(AT_NT) void attn_pool_fwd_kernel(const T* __restric
         const T* hq = h + q * (int64_t)k * C;
         if (C == 256) {                                                              // wave w sums its 16 rows, lane = 4 channels
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int j = wave * 16; j < wave * 16 + 16 && j < k; ++j) {
-                float4 v = ld4(hq, (int64_t)j * 256 + 4 * lane);
-                v = make_float4(fmaxf(v.x, hfloor), fmaxf(v.y, hfloor), fmaxf(v.z, hfloor), fmaxf(v.w, hfloor));
-                const float aj = a[j];
-                acc.x += aj * v.x; acc.y += aj * v.y; acc.z += aj * v.z; acc.w += aj * v.w;
+            for (int j0 = wave * 16; j0 < wave * 16 + 16 && j0 < k; j0 += 4) {       // four rows in flight per wave
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = ld4(hq, (int64_t)(j0 + u < k ? j0 + u : k - 1) * 256 + 4 * lane);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float aj = j0 + u < k ? a[j0 + u] : 0.f;
+                    acc.x += aj * fmaxf(v[u].x, hfloor); acc.y += aj * fmaxf(v[u].y, hfloor);
+                    acc.z += aj * fmaxf(v[u].z, hfloor); acc.w += aj * fmaxf(v[u].w, hfloor);
+                }
             }
             float4* part = (float4*)&e[0][0];                                        // the logits are no longer needed: 4 x 64 float4
             __syncthreads();
@@ -149,15 +154,25 @@ __global__ __launch_bounds__(AT_NT) void attn_pool_bwd_kernel(const T* __restric
         T* dhq = dh + q * (int64_t)k * C;
         if (C == 256) {
             const float4 d4 = make_float4(dp[4 * lane], dp[4 * lane + 1], dp[4 * lane + 2], dp[4 * lane + 3]);
-            for (int j = wave * 16; j < wave * 16 + 16 && j < k; ++j) {              // one neighbour row per wave pass, 4 channels per lane
-                float4 v = ld4(hq, (int64_t)j * 256 + 4 * lane);
-                const float aj = a[j];
-                // with relu_h the gradient goes to the stored pre-activation: masked where it was clipped
-                st4(dhq, (int64_t)j * 256 + 4 * lane, make_float4(v.x > hfloor ? aj * d4.x : 0.f, v.y > hfloor ? aj * d4.y : 0.f,
-                                                                  v.z > hfloor ? aj * d4.z : 0.f, v.w > hfloor ? aj * d4.w : 0.f));
-                v = make_float4(fmaxf(v.x, hfloor), fmaxf(v.y, hfloor), fmaxf(v.z, hfloor), fmaxf(v.w, hfloor));
-                const float part = wave_sum((d4.x * v.x + d4.y * v.y) + (d4.z * v.z + d4.w * v.w));
-                if (lane == 0) da[j] = part;
+            // one neighbour row per wave pass, 4 channels per lane; the wave's 16 rows are requested four at a time (a row per iteration left
+            // the loads of a row waiting behind the shuffles of the previous one)
+            for (int j0 = wave * 16; j0 < wave * 16 + 16 && j0 < k; j0 += 4) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = ld4(hq, (int64_t)(j0 + u < k ? j0 + u : k - 1) * 256 + 4 * lane);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u;
+                    if (j < k) {
+                        const float aj = a[j];
+                        // with relu_h the gradient goes to the stored pre-activation: masked where it was clipped
+                        st4(dhq, (int64_t)j * 256 + 4 * lane, make_float4(v[u].x > hfloor ? aj * d4.x : 0.f, v[u].y > hfloor ? aj * d4.y : 0.f,
+                                                                          v[u].z > hfloor ? aj * d4.z : 0.f, v[u].w > hfloor ? aj * d4.w : 0.f));
+                        const float4 w = make_float4(fmaxf(v[u].x, hfloor), fmaxf(v[u].y, hfloor), fmaxf(v[u].z, hfloor), fmaxf(v[u].w, hfloor));
+                        const float part = wave_sum((d4.x * w.x + d4.y * w.y) + (d4.z * w.z + d4.w * w.w));
+                        if (lane == 0) da[j] = part;
+                    }
+                }
             }
         } else {
             for (int j = wave * 16; j < wave * 16 + 16 && j < k; ++j) {
