@@ -171,7 +171,11 @@ class TrainDataset(ReconstructionDataset):
             raws = [torch.from_numpy(it['pts_raw_ms']).to(device, non_blocking=True) for it in items]
             batch['pts_local_ps'], batch['pts_local_ms'] = spatial.get_pts_local_ps_batch(raws, batch['pts_query_ms'], self.num_pts_local,
                                                                                           return_ms=True)
-        return spatial.get_data_poco(batch)
+        batch = spatial.get_data_poco(batch)
+        from . import train_graph
+        with torch.no_grad():
+            batch.update(train_graph.table_extras(batch))       # flat ids + CSR of the id tables: built with the batch, not inside backward
+        return batch
 
 
 class PocoDataset(TrainDataset):
@@ -301,17 +305,17 @@ class DeviceBatchLoader:
                     nxt = pool.submit(load, starts[k + 1]) if k + 1 < len(starts) else None
                     yield self.dataset.collate_on_device(items, self.device)
                 return
-            # the device side of batch k + 1 (patches, support levels, id tables) is issued on a second stream before batch k is handed out
-            items = nxt.result() if starts else None
+            # the device side of batch k + 1 (patches, support levels, id tables) is issued on a second stream before batch k is handed out; its
+            # host items were requested one iteration earlier (the thread is two batches ahead), so nothing waits for a file here
+            futs = {0: nxt}
+            if len(starts) > 1:
+                futs[1] = pool.submit(load, starts[1])
             for k, s in enumerate(starts):
-                nxt = pool.submit(load, starts[k + 1]) if k + 1 < len(starts) else None
-                cur_items, fut = items, nxt
-
-                def make_next(fut=fut):
-                    return self.dataset.collate_on_device(fut.result(), self.device)
-
-                batch = prefetch.take(lambda: self.dataset.collate_on_device(cur_items, self.device), make_next if fut is not None else None)
-                items = fut.result() if fut is not None else None
+                if k + 2 < len(starts):
+                    futs[k + 2] = pool.submit(load, starts[k + 2])
+                cur, nxt_f = futs.pop(k), futs.get(k + 1)
+                batch = prefetch.take(lambda: self.dataset.collate_on_device(cur.result(), self.device),
+                                      (lambda f=nxt_f: self.dataset.collate_on_device(f.result(), self.device)) if nxt_f is not None else None)
                 yield batch
 
 

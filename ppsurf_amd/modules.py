@@ -349,7 +349,7 @@ class PPSurfNetwork(_Base):
     # -- reference API -------------------------------------------------------------------------------------------
     def forward(self, data):
         if self.training:
-            train_graph._prepare(self, data['pts'])             # bf16 images of all parameters for this step (one multi-tensor copy)
+            train_graph._prepare(self, data)             # bf16 images of all parameters for this step (one multi-tensor copy)
         data['latents'] = self.encoder.forward(data, spectral_only=True)
         return self.from_latent(data)
 
@@ -434,7 +434,7 @@ class PocoNetwork(_Base):
     def forward(self, data):
         """poco_model.py:345-349: encoder with the precomputed tables, projection with the PRECOMPUTED proj_ids."""
         if self.training:
-            train_graph._prepare(self, data['pts'])             # bf16 images of all parameters for this step (one multi-tensor copy)
+            train_graph._prepare(self, data)             # bf16 images of all parameters for this step (one multi-tensor copy)
         data['latents'] = self.encoder.forward(data, spectral_only=True)
         return self._project(data, has_proj_ids=True)
 

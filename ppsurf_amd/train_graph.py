@@ -187,19 +187,64 @@ def batch_norm(bn, x, relu=False):
 _flat_cache = {}
 
 
-def _flat_ids(ids, n):
+def _flat_ids(ids, n, up=False):
     """[B, M, K] ids into a batch item -> flat row numbers into [B*n, C].  Memoised per table (a table serves several
-    layers, and the CSR used by the backward kernels is cached on the flat tensor)."""
-    key = (ids.data_ptr(), ids._version, tuple(ids.shape), n)
+    layers, and the CSR used by the backward kernels is cached on the flat tensor).  up: nearest up-sampling table, -1 -> row 0."""
+    key = (ids.data_ptr(), ids._version, tuple(ids.shape), n, up)
     hit = _flat_cache.get(key)
     if hit is not None:
         return hit[1]
     b = ids.shape[0]
+    if up:
+        ids = torch.where(ids > -1, ids, torch.zeros_like(ids))
     flat = (ids + torch.arange(b, device=ids.device).view(b, 1, 1) * n).reshape(-1)
     if len(_flat_cache) > 64:
         _flat_cache.clear()
     _flat_cache[key] = (ids, flat)
     return flat
+
+
+UP_TABLES = ('ids43', 'ids32', 'ids21', 'ids10')          # nearest up-sampling tables (coarse level -> fine level, K = 1, -1 = none)
+
+
+def table_extras(data):
+    """Flat row numbers and CSR (entries sorted by target row) of every id table of a fit batch, as extra batch entries
+    `tables_flat_<name>`, `tables_order_<name>`, `tables_offsets_<name>`: built with the batch -- on the loader's side stream -- instead of
+    inside the backward pass (14 radix sorts per step), and ordinary input tensors of the step, so that a HIP-graph replay of the step
+    contains no sort."""
+    pts = data['pts']
+    b = pts.shape[0]
+    sizes = [pts.shape[2]] + [data['support{}'.format(a)].shape[2] for a in range(1, 5)]
+    out = {}
+    for name, ids in list(data.items()):
+        if name == 'proj_ids':
+            src = 0
+        elif len(name) == 5 and name.startswith('ids') and name[3:].isdigit():
+            src = int(name[3])
+        else:
+            continue
+        if not torch.is_tensor(ids) or ids.dim() != 3:
+            continue
+        n = sizes[src]
+        t = torch.where(ids > -1, ids, torch.zeros_like(ids)) if name in UP_TABLES else ids
+        flat = (t + torch.arange(b, device=ids.device).view(b, 1, 1) * n).reshape(-1)
+        order, offsets = train_ops.csr_build(flat, b * n)
+        out['tables_flat_' + name], out['tables_order_' + name], out['tables_offsets_' + name] = flat, order, offsets
+    return out
+
+
+def register_tables(data):
+    """Make the tables of table_extras() known to _flat_ids / train_ops.csr for this step (host-side dictionary entries only)."""
+    for key, flat in data.items():
+        if not key.startswith('tables_flat_'):
+            continue
+        name = key[len('tables_flat_'):]
+        ids = data[name]
+        order, offsets = data['tables_order_' + name], data['tables_offsets_' + name]
+        rows = offsets.numel() - 1
+        n = rows // ids.shape[0]
+        _flat_cache[(ids.data_ptr(), ids._version, tuple(ids.shape), n, name in UP_TABLES)] = (ids, flat)
+        train_ops.csr_register(flat, rows, order, offsets)
 
 
 def release_step_caches():
@@ -259,8 +304,7 @@ def residual_block(blk, x, pts, sup, ids):
 def _upsample(x, ids_up, n_coarse):
     """nearest-neighbour interpolation (nn.py:684-697 with K == 1): x [B,Nc,C], ids_up [B,Nf,1] -> [B,Nf,C]."""
     b, nf = ids_up.shape[0], ids_up.shape[1]
-    ids_up = torch.where(ids_up > -1, ids_up, torch.zeros_like(ids_up))
-    return train_ops.gather_rows(x.reshape(b * n_coarse, -1), _flat_ids(ids_up, n_coarse)).view(b, nf, -1)
+    return train_ops.gather_rows(x.reshape(b * n_coarse, -1), _flat_ids(ids_up, n_coarse, up=True)).view(b, nf, -1)
 
 
 @_counted
@@ -471,20 +515,23 @@ def ppsurf_from_latent(net, latents, data, proj_ids):
     return out.view(b, q, -1).transpose(1, 2)
 
 
-def _prepare(net, x):
-    if x.is_cuda and net.training and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16:
-        prepare_shadows(net)
+def _prepare(net, data):
+    x = data['pts']
+    if x.is_cuda and net.training:
+        register_tables(data)
+        if torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16:
+            prepare_shadows(net)
 
 
 @_counted
 def ppsurf_forward(net, data, proj_ids):
-    _prepare(net, data['pts'])
+    _prepare(net, data)
     return ppsurf_from_latent(net, encoder(net.encoder, data), data, proj_ids)
 
 
 @_counted
 def poco_forward(net, data, proj_ids):
-    _prepare(net, data['pts'])
+    _prepare(net, data)
     pts = _point_major(data['pts']).contiguous()
     query = _point_major(data['pts_query']).contiguous()
     return interp_attention(net.projection, encoder(net.encoder, data), pts, query, proj_ids).transpose(1, 2)

@@ -35,6 +35,20 @@ def csr(idx_flat: torch.Tensor, n: int):
     hit = _csr_cache.get(key)                       # the cached entry keeps the table alive, so the address cannot be reused
     if hit is not None:
         return hit[1], hit[2]
+    order, offsets = csr_build(idx_flat, n)
+    if len(_csr_cache) > 64:
+        _csr_cache.clear()
+    _csr_cache[key] = (idx_flat, order, offsets)
+    return order, offsets
+
+
+def csr_register(idx_flat, n, order, offsets):
+    """Enter a CSR built elsewhere (with the batch, train_graph.table_extras) so that the backward pass finds it."""
+    _csr_cache[(idx_flat.data_ptr(), idx_flat._version, idx_flat.numel(), n)] = (idx_flat, order, offsets)
+
+
+def csr_build(idx_flat: torch.Tensor, n: int):
+    """(order, offsets) of a flat id table, not cached."""
     # 32-bit keys: the radix sort makes half the passes of the 64-bit one (row numbers fit easily)
     small = n < 2 ** 31 - 1
     keys, order = torch.sort(idx_flat.to(torch.int32) if small else idx_flat, stable=True)
@@ -42,9 +56,6 @@ def csr(idx_flat: torch.Tensor, n: int):
     # first entry of every target row by binary search in the sorted keys (torch.bincount would synchronise with the host
     # in the middle of the backward pass)
     offsets = torch.searchsorted(keys, torch.arange(n + 1, dtype=keys.dtype, device=idx_flat.device))
-    if len(_csr_cache) > 64:
-        _csr_cache.clear()
-    _csr_cache[key] = (idx_flat, order, offsets)
     return order, offsets
 
 

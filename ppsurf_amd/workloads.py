@@ -183,7 +183,11 @@ class FitStep:
         batch = dict(self.batches[i % len(self.batches)])
         b = batch['pts_ms'].shape[0]
         batch['pts_local_ps'] = spatial.get_pts_local_ps_batch([batch['pts_ms'][j] for j in range(b)], batch['pts_query_ms'], self.p)
-        return {k: v for k, v in spatial.get_data_poco(batch).items() if not k.startswith('_')}
+        batch = {k: v for k, v in spatial.get_data_poco(batch).items() if not k.startswith('_')}
+        from . import train_graph
+        with torch.no_grad():
+            batch.update(train_graph.table_extras(batch))       # like data.TrainDataset.collate_on_device
+        return batch
 
     def __call__(self):
         if self.prefetch is None:
