@@ -259,4 +259,6 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
     if mfile is not None:
         mfile.close()
     model.__dict__.pop('_fit_log', None)
+    if use_graph and rank == 0:
+        print('fit: HIP-graph replay of the step: {} graph(s) captured{}'.format(len(stepper.graphs), ', capture FAILED (ran eagerly)' if stepper.failed else ''))
     return history
