@@ -238,9 +238,11 @@ class DevicePrefetch:
         self.side = torch.cuda.Stream(self.device)
         self.pending = None                      # (batch, event)
 
-    def _launch(self, make):
-        main = torch.cuda.current_stream(self.device)
-        self.side.wait_stream(main)              # inputs produced on the main stream (uploaded clouds) are complete
+    def launch(self, make, after_main=True):
+        """Runs make() on the side stream -> (batch, event).  May be called from a loader thread (the stream context is thread-local);
+        after_main: the side stream first waits for what the main stream has queued (inputs made there)."""
+        if after_main:
+            self.side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.side):
             batch = make()
             ev = torch.cuda.Event()
@@ -249,10 +251,17 @@ class DevicePrefetch:
 
     def take(self, make_current, make_next):
         main = torch.cuda.current_stream(self.device)
-        batch, ev = self.pending if self.pending is not None else self._launch(make_current)
+        batch, ev = self.pending if self.pending is not None else self.launch(make_current)
         main.wait_event(ev)
         _record_stream(batch, main)
-        self.pending = self._launch(make_next) if make_next is not None else None
+        self.pending = self.launch(make_next) if make_next is not None else None
+        return batch
+
+    def hand_over(self, batch, ev):
+        """A batch built by launch() in another thread becomes usable on the calling thread's current stream."""
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(ev)
+        _record_stream(batch, main)
         return batch
 
 
@@ -305,18 +314,17 @@ class DeviceBatchLoader:
                     nxt = pool.submit(load, starts[k + 1]) if k + 1 < len(starts) else None
                     yield self.dataset.collate_on_device(items, self.device)
                 return
-            # the device side of batch k + 1 (patches, support levels, id tables) is issued on a second stream before batch k is handed out; its
-            # host items were requested one iteration earlier (the thread is two batches ahead), so nothing waits for a file here
-            futs = {0: nxt}
-            if len(starts) > 1:
-                futs[1] = pool.submit(load, starts[1])
+            # the loader thread also issues the device side of its batch (patches, support levels, id tables, their CSR) -- on a second stream,
+            # so that it runs beside the optimisation step of the previous batch and its ~10 ms of host work are off the training thread.  The
+            # thread stays two batches ahead; uploads and searches depend on nothing the main stream produces (after_main=False).
+            nxt.cancel()
+            build = lambda s: prefetch.launch(lambda: self.dataset.collate_on_device(load(s), self.device), after_main=False)
+            futs = {k: pool.submit(build, starts[k]) for k in range(min(2, len(starts)))}
             for k, s in enumerate(starts):
+                batch, ev = futs.pop(k).result()
                 if k + 2 < len(starts):
-                    futs[k + 2] = pool.submit(load, starts[k + 2])
-                cur, nxt_f = futs.pop(k), futs.get(k + 1)
-                batch = prefetch.take(lambda: self.dataset.collate_on_device(cur.result(), self.device),
-                                      (lambda f=nxt_f: self.dataset.collate_on_device(f.result(), self.device)) if nxt_f is not None else None)
-                yield batch
+                    futs[k + 2] = pool.submit(build, starts[k + 2])
+                yield prefetch.hand_over(batch, ev)
 
 
 def _collate1(item):

@@ -8,12 +8,13 @@
   * BatchNorm / norm_radius buffers follow DDP semantics (`broadcast_buffers=True`): rank 0's values are broadcast, coalesced
     into one message, at the start of every step; between two steps they are rank-local;
   * Adam / AdamW run fused (one launch per dtype group; same update rule);
-  * opt-in, single GPU (`PPS_FIT_GRAPH=1`): after three eager steps the WHOLE optimisation step (forward, loss, backward,
+  * single GPU (`PPS_FIT_GRAPH=0` switches it off): after three eager steps the WHOLE optimisation step (forward, loss, backward,
     gradient-buffer handling, fused capturable AdamW, loss scaling) is captured into one HIP graph per batch signature and replayed
-    (`GraphedStep`); the batch is copied into static buffers, the id tables stay outside the graph.  Replay is bit-identical to the
-    eager step (tools/fit_graph_check.py), but at the full config-3 batch size replays fault intermittently inside rocprim's onesweep
-    radix sort (the CSR sort of the id tables; memory aperture violation, timing dependent, tools/fit_graph_matrix2.py) -- hence
-    off by default until the sort is moved out of the graph;
+    (`GraphedStep`); the batch is copied into static buffers; the id tables, their flat forms and CSRs are inputs built by the loader
+    (train_graph.table_extras), so the graph holds no sort (replays with the CSR radix sort inside faulted intermittently at the full
+    config-3 batch size).  Replay is bit-identical to the eager step (tools/fit_graph_check.py) and ran 1500 consecutive full-size steps
+    clean (tools/fit_graph_matrix2.py); the eager loop spends ~24 ms of Python per step on ~1400 launches and is host-bound (37-40 ms per
+    step), the replayed loop is GPU-bound (~30 ms);
   * validation every `check_val_every_n_epoch` epochs in eval() mode -- that is the fused HIP inference path;
   * ModelCheckpoint(save_last) -> models/<name>/version_0/checkpoints/last.ckpt with Lightning's key layout
     ({'state_dict': {'network.<...>': tensor}, 'epoch', 'global_step', 'optimizer_states', 'lr_schedulers'}), so checkpoints
@@ -57,6 +58,23 @@ class GraphedStep:
     def __init__(self, eager, metrics, enabled=True, max_graphs=2):
         self.eager, self.metrics, self.enabled, self.max_graphs = eager, metrics, enabled, max_graphs
         self.seen, self.graphs, self.failed, self._done = {}, {}, False, None
+        self.replayed = False
+
+    def touch(self, module):
+        """A replayed graph updates parameters and buffers in place WITHOUT the tensors' version counters moving (no op is dispatched), and
+        the inference plans of ppsurf_amd.modules are cached on those counters: before anything reads the module through eval()
+        (validation, predict after fit), bump them with an exact no-op."""
+        if not self.replayed:
+            return
+        self.replayed = False
+        with torch.no_grad():
+            ts = list(module.parameters()) + list(module.buffers())
+            fl = [t for t in ts if t.is_floating_point()]
+            it = [t for t in ts if not t.is_floating_point()]
+            if fl:
+                torch._foreach_mul_(fl, 1.0)
+            if it:
+                torch._foreach_add_(it, 0)
 
     @staticmethod
     def signature(batch):
@@ -86,6 +104,7 @@ class GraphedStep:
                 for k, v in static.items():
                     v.copy_(batch[k], non_blocking=True)
                 graph.replay()
+                self.replayed = True
                 if self._done is None:
                     self._done = torch.cuda.Event()
                 self._done.record()
@@ -134,7 +153,17 @@ def save_checkpoint(path, model, optimizer, scheduler, epoch, global_step):
     # key layout of a Lightning 2 checkpoint (the reference pins pytorch-lightning>=2.0, requirements.txt:3): the version must be
     # a valid PEP 440 string (Lightning's migrate_checkpoint parses it), 'loops' / 'callbacks' may be empty
     osd = optimizer.state_dict()
-    osd['param_groups'] = [dict(g, lr=float(g['lr'])) for g in osd['param_groups']]          # plain floats, whatever the run kept on the device
+    # plain floats, whatever the run kept on the device; with graph replay the learning rate lives in a float32 device tensor, so the exact
+    # double is taken from the scheduler's closed form where it has one (MultiStepLR: base_lr * gamma ** milestones passed)
+    lrs = [float(g['lr']) for g in osd['param_groups']]
+    if scheduler is not None and hasattr(scheduler, '_get_closed_form_lr'):
+        try:
+            closed = [float(v) for v in scheduler._get_closed_form_lr()]
+            if len(closed) == len(lrs) and all(abs(a - b) <= 1e-6 * abs(b) for a, b in zip(closed, lrs)):
+                lrs = closed
+        except Exception:
+            pass
+    osd['param_groups'] = [dict(g, lr=lr) for g, lr in zip(osd['param_groups'], lrs)]
     torch.save({'state_dict': model.state_dict(), 'epoch': epoch, 'global_step': global_step,
                 'optimizer_states': [osd], 'lr_schedulers': [scheduler.state_dict()] if scheduler is not None else [],
                 'pytorch-lightning_version': LIGHTNING_CKPT_VERSION, 'loops': {}, 'callbacks': {}, 'hyper_parameters': {},
@@ -153,7 +182,7 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
     if not cfg.get('optimizer'):
         raise ValueError('fit needs an `optimizer:` section (class_path / init_args), as in configs/poco.yaml:60-69')
     on_gpu = torch.device(device).type == 'cuda'
-    use_graph = world == 1 and on_gpu and os.environ.get('PPS_FIT_GRAPH', '0') == '1'
+    use_graph = world == 1 and on_gpu and os.environ.get('PPS_FIT_GRAPH', '1') != '0'
     ospec = cfg['optimizer']
     if on_gpu and ospec.get('class_path', '').rsplit('.', 1)[-1] in ('AdamW', 'Adam') and 'fused' not in ospec.get('init_args', {}):
         # the fused implementation (one launch per dtype group instead of ~10 small foreach launches over 298 parameter tensors: 57.6 ->
@@ -234,6 +263,7 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
                 break
         flush(pending)
         pending = None
+        stepper.touch(model)                                   # replays move no version counters: the eval() plans below are keyed on them
         if scheduler is not None:
             scheduler.step()
         last = history[-1] if history else {}

@@ -104,7 +104,9 @@ def test_consecutive_shapes_of_equal_size_are_decoded_with_their_own_latents(tra
         va, vb = both[0], alone[0]
         assert abs(va.shape[0] - vb.shape[0]) < 0.1 * vb.shape[0]
         d = np.sqrt(((va[::7, None, :] - vb[None, ::3, :]) ** 2).sum(-1)).min(axis=1)
-        assert np.median(d) < 0.5 / 24, np.median(d)
+        # (measured: 0.019 - 0.022 between two runs of the same shape = half a voxel of the R = 25 grid, depending on the dropout stream of the
+        # fit that made the checkpoint; a foreign table gives more than a voxel)
+        assert np.median(d) < 0.75 / 24, np.median(d)
 
 
 def test_config2_ppsurf_50nn_predict_one_abc_shape_r129(trained):
