@@ -349,3 +349,38 @@ def test_small_cloud_training_step_hip_ops_vs_torch_twins(n, q, p):
         # running statistics of the decoder heads sit behind the 1-point levels as well: same 8x rule as the gradients, or 3e-4 of the buffer's range
         # (measured on the N = 300 case: encoder.bn3d.running_mean 1.6e-4 vs 3.4e-5 of a range of 0.93; the geometry branch sums on fp32 MFMAs)
         assert mine <= max(8 * theirs, 1e-5 + 3e-4 * float(b3[k].abs().max())), '{}: {:.3e} (torch fp32 {:.3e})'.format(k, mine, theirs)
+
+
+def test_step_uses_the_tables_built_with_the_batch(monkeypatch):
+    """train_graph.table_extras builds flat ids + CSR of every id table with the batch; registered at the start of the forward pass, the
+    backward pass must not sort anything (that is what keeps radix sorts out of the replayed HIP graph) -- and the gradients must be the
+    ones of the step that builds its CSRs on the fly."""
+    from ppsurf_amd import workloads, train_ops, train_graph
+    torch.manual_seed(0)
+    step = workloads.FitStep(batch=2, n=1500, q=200, p=20, precision='32', overlap_prep=False)
+    for m in step.net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    batch = step._prepare(0)
+    assert sum(k.startswith('tables_order_') for k in batch) == 14
+    calls = []
+    real = train_ops.csr_build
+    monkeypatch.setattr(train_ops, 'csr_build', lambda idx, n: (calls.append(n), real(idx, n))[1])
+
+    state = {k: v.clone() for k, v in step.net.state_dict().items()}
+
+    def grads(b):
+        step.net.load_state_dict(state)                       # train() moves norm_radius and the running statistics
+        step.net.zero_grad(set_to_none=True)
+        logits = step.net.forward(dict(b))
+        torch.nn.functional.cross_entropy(logits.float(), b['occ']).backward()
+        train_graph.release_step_caches()
+        return {k: p.grad.clone() for k, p in step.net.named_parameters() if p.grad is not None}
+
+    with_tables = grads(batch)
+    assert calls == []
+    without = grads({k: v for k, v in batch.items() if not k.startswith('tables_')})
+    assert len(calls) >= 10
+    assert set(with_tables) == set(without)
+    for k in without:
+        assert torch.equal(with_tables[k], without[k]), k
