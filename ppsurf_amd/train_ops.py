@@ -5,6 +5,11 @@
     neighbour_contract(x [n,c], idx [m,k], g [m,k,16])-> [m, c*16]      (nn.py:598,647-649 FKAConv feature aggregation)
     fka_geometry(geo [1140], pts, sup, idx, b, m, momentum) -> (g [b*m,k,16], norm_radius')   (nn.py:601-643, pps_fka_train.hip)
     bn_act(x [rows,c], weight, bias, running_mean, running_var, momentum, eps, relu) -> [rows,c]   (train-mode BatchNorm1d + ReLU)
+    attn_pool(qy [Q,k,H], h [Q,k,C], relu_h) / query_attn_pool(y3, wq, bq, k)          (attention pooling of the interpolation head)
+  bf16 row layers on STORED activations (Act = raw tensor + per-channel (scale, shift) + relu flag, applied by the consumer on load;
+  pps_rows_train.hip):
+    rows_layer(act, w, b, bn, relu) -> Act        rows3_layer(x [rows,3], w, b, bn) -> Act        act_max(act, groups, p) -> [groups, C]
+    patch_transform(act, t_raw [Q,64,64], p)      patch_attn(h [Q,k,256], v [256])               head_input(table, ids, pts, query, k, wx)
 
 Device tensors only: there is no CPU implementation in the product (tests/train_ref_ops.py holds the torch twins the CPU
 suite patches in to check the surrounding graph).  Backward scatter-adds are atomics-free and bit-reproducible: the id table
