@@ -242,9 +242,8 @@ int pps_gather_rows_f32(const float* x, const int64_t* idx, int64_t r, int c, fl
 int pps_segment_sum_rows_f32(const float* vals, const int64_t* order, const int64_t* offsets, int64_t n, int c, float* out,
                              void* stream);
 
-/* the same with bf16 values (c % 4 == 0), fp32 accumulation and output */
-int pps_segment_sum_rows_bf16(const void* vals, const int64_t* order, const int64_t* offsets, int64_t n, int c, float* out,
-                              void* stream);
+/* the same with 16-bit values (dtype 1 bfloat16, 2 IEEE half; c % 4 == 0), fp32 accumulation and output */
+int pps_segment_sum_rows_16(const void* vals, const int64_t* order, const int64_t* offsets, int64_t n, int c, int dtype, float* out, void* stream);
 
 /* FKAConv feature aggregation, out[m, ch*16+t] = sum_j x[idx[m,j], ch] * g[m,j,t]  (x [n,c], idx int64 [m,k], g [m,k,16],
  * out [m, c*16] in the (channel, kernel-column) order of cv.weight[Cout, Cin, 1, 16]).
@@ -281,7 +280,7 @@ int pps_fka_geometry_bwd_f32(const float* pts, const float* sup, const int64_t* 
                              const float* stat, const float* dg, float* dgeo, void* ws, void* stream);
 
 /* BatchNorm1d in train() mode with the ReLU fused, on point-major activations x [rows, c] (c % 4 == 0, 256 % (c/4) == 0,
- * c <= 1024), storage dtype 0 = fp32, 1 = bf16 (x, y, dy, dx share it), fp32 arithmetic.
+ * c <= 1024), storage dtype 0 = fp32, 1 = bf16, 2 = IEEE half (x, y, dy, dx share it), fp32 arithmetic.
  * replaces: activation(bn(conv(x))) of source/base/nn.py:438-450,508-554,162-190,323-336,376-417 under autograd.
  * forward: batch statistics (biased variance) -> save [2][c] (mean, rstd); running_mean/var (NULL or both) updated in place with
  * `momentum` and the unbiased variance like torch.nn.BatchNorm1d; y = relu? max(0, .) : . of the normalised, affine output.
@@ -294,14 +293,17 @@ int pps_bn_train_bwd(const void* x, const void* dy, int64_t rows, int c, int dty
 
 /* Attention pooling of the interpolation head in train(): a[j] = mean_h softmax_j(qy[q,j,h]), pooled[q,c] = sum_j a[j] h[q,j,c]
  * (replaces source/poco_model.py:412-414 under autograd, in the pooled form where fc_value follows the pooling).  qy [q,k,heads], h [q,k,c],
- * pooled [q,c]; heads <= 64 (64: interpolation head; 1: PointNet's AttentionPoco, source/base/nn.py:84-96 with k = patch points), k <= 64, c <= 256; storage float (bf16 = 0) or bfloat16 (bf16 = 1), arithmetic fp32.
+ * pooled [q,c]; heads <= 64 (64: interpolation head; 1: PointNet's AttentionPoco, source/base/nn.py:84-96 with k = patch points), k <= 64, c <= 256; storage float (bf16 = 0), bfloat16 (bf16 = 1) or IEEE half (bf16 = 2), arithmetic fp32.
  * Backward: dqy [q,k,heads], dh [q,k,c] from dpooled [q,c]; the softmax is recomputed from qy.
  * relu_h != 0: h is stored BEFORE its ReLU (the raw output of fc3): the ReLU is applied on load and dh is the gradient wrt the stored values. */
 int pps_attn_pool_fwd(const void* qy, const void* h, int64_t q, int k, int heads, int c, int bf16, int relu_h, void* pooled, void* stream);
 int pps_attn_pool_bwd(const void* qy, const void* h, const void* dpooled, int64_t q, int k, int heads, int c, int bf16, int relu_h, void* dqy,
                       void* dh, void* stream);
 
-/* Dense layer of the training step over point-major rows with the previous layer's BatchNorm + ReLU applied on load and this layer's
+/* The 16-bit tensors of the training-step entries below are bfloat16 (dtype = 1, trainer.precision bf16-mixed) or IEEE half (dtype = 2,
+ * trainer.precision 16-mixed, the reference's default); "bf16" in the descriptions stands for either.
+ *
+ * Dense layer of the training step over point-major rows with the previous layer's BatchNorm + ReLU applied on load and this layer's
  * batch statistics taken on store (replaces the conv -> bn -> relu -> conv chains of source/base/nn.py:162-190, 323-336, 376-417 and the
  * fc -> relu -> fc chain of source/poco_model.py:400-410 under autograd and bf16 autocast; pps_rows_train.hip).
  *   x [rows, cin], y [rows, cout] bfloat16 RAW layer outputs; cin, cout in {64, 128, 256} (pps_rows_layer_supported)
@@ -318,26 +320,26 @@ int pps_attn_pool_bwd(const void* qy, const void* h, const void* dpooled, int64_
  * h [q, k, 256] bfloat16, k <= 64, v [256] fp32, pooled [q, 256] fp32.  Backward: dh [q, k, 256] bfloat16; dv_part [pps_patch_attn_partials(q)][256],
  * to be summed over its first axis. */
 int pps_patch_attn_partials(int64_t q);
-int pps_patch_attn_fwd(const void* h, const float* v, int64_t q, int k, int c, float* pooled, void* stream);
-int pps_patch_attn_bwd(const void* h, const float* v, const float* dpooled, int64_t q, int k, int c, void* dh, float* dv_part, void* stream);
+int pps_patch_attn_fwd(const void* h, const float* v, int64_t q, int k, int c, int dtype, float* pooled, void* stream);
+int pps_patch_attn_bwd(const void* h, const float* v, const float* dpooled, int64_t q, int k, int c, int dtype, void* dh, float* dv_part, void* stream);
 
 /* Input of the interpolation head in train() (source/poco_model.py:400-404 with fc1 split into its latent and its offset part):
  * h1[(q,j),:] = table[ids[q,j],:] + wx (query[q] - pts[ids[q,j]]).  table [n, c] bf16, ids [q*k] (rows of table and pts), pts [n, 3] and
  * query [q, 3] fp32, wx [c, 3] fp32, h1 [q*k, c] bf16; c a multiple of 8 with (c / 8) dividing 256.  pps_head_input_dwx: d wx [c, 3] from
- * dh1 [q*k, c] bf16 (d table is the segmented sum of dh1, pps_segment_sum_rows_bf16).  ws: pps_head_input_ws_bytes(c) bytes. */
+ * dh1 [q*k, c] bf16 (d table is the segmented sum of dh1, pps_segment_sum_rows_16).  ws: pps_head_input_ws_bytes(c) bytes. */
 size_t pps_head_input_ws_bytes(int c);
-int pps_head_input_fwd(const void* table, const int64_t* ids, const float* pts, const float* query, int64_t q, int k, int c, const float* wx, void* h1,
-                       void* stream);
-int pps_head_input_dwx(const void* dh1, const int64_t* ids, const float* pts, const float* query, int64_t q, int k, int c, float* dwx, void* ws,
+int pps_head_input_fwd(const void* table, const int64_t* ids, const float* pts, const float* query, int64_t q, int k, int c, int dtype, const float* wx,
+                       void* h1, void* stream);
+int pps_head_input_dwx(const void* dh1, const int64_t* ids, const float* pts, const float* query, int64_t q, int k, int c, int dtype, float* dwx, void* ws,
                        void* stream);
 
 /* conv0a of PointNet in train() (3 coordinates -> 64 channels, source/base/nn.py:323): y [rows, 64] bf16 = x [rows, 3] w^T + bias with the batch
  * statistics of y -> out_affine / save / running statistics as in pps_rows_layer_fwd; backward: dw [64, 3], dbias [64] (NULL = skip), dgamma,
  * dbeta (x gets no gradient: it is the input patch).  ws: pps_rows3_ws_bytes() bytes. */
 size_t pps_rows3_ws_bytes(void);
-int pps_rows3_fwd(const float* x, int64_t rows, const float* w, const float* bias, void* y, const float* gamma, const float* beta,
+int pps_rows3_fwd(const float* x, int64_t rows, const float* w, const float* bias, int dtype, void* y, const float* gamma, const float* beta,
                   float* running_mean, float* running_var, float momentum, float eps, float* out_affine, float* save, void* ws, void* stream);
-int pps_rows3_bwd(const float* x, const void* y, const void* gy, int64_t rows, const float* gamma, const float* save, const float* d_affine,
+int pps_rows3_bwd(const float* x, const void* y, const void* gy, int64_t rows, int dtype, const float* gamma, const float* save, const float* d_affine,
                   float* dw, float* dbias, float* dgamma, float* dbeta, void* ws, void* stream);
 
 /* Feature transform of PointNet in train() (source/base/nn.py:330-331, torch.bmm(trans2, x)): out[q,i,:] = act(x)[q,i,:] T[q]^T per group q of
@@ -346,19 +348,19 @@ int pps_rows3_bwd(const float* x, const void* y, const void* gy, int64_t rows, c
  * ws: pps_patch_transform_ws_bytes() bytes. */
 size_t pps_patch_transform_ws_bytes(void);
 int pps_patch_transform_fwd(const void* x, const float* in_scale, const float* in_shift, int in_relu, const void* t, int add_identity, int64_t q,
-                            int p, void* out, void* stream);
+                            int p, int dtype, void* out, void* stream);
 int pps_patch_transform_bwd(const void* x, const float* in_scale, const float* in_shift, int in_relu, const void* t, int add_identity, const void* g,
-                            int64_t q, int p, void* dx, void* dt, float* d_in_affine, void* ws, void* stream);
+                            int64_t q, int p, int dtype, void* dx, void* dt, float* d_in_affine, void* ws, void* stream);
 
 /* Extrema over the p rows of every group of x [groups, p, c] (bfloat16, c % 4 == 0): mx, mn [groups, c] fp32 and the row of each
  * (first occurrence).  The max-pool over the patch points (source/base/nn.py:181) of relu(bn(x)) follows from them without the activated tensor. */
-int pps_rows_extrema_bf16(const void* x, int64_t groups, int p, int c, float* mx, float* mn, int* amx, int* amn, void* stream);
+int pps_rows_extrema_16(const void* x, int64_t groups, int p, int c, int dtype, float* mx, float* mn, int* amx, int* amn, void* stream);
 int pps_rows_layer_supported(int cin, int cout);
 size_t pps_rows_layer_ws_bytes(int cin, int cout);
-int pps_rows_layer_fwd(const void* x, int64_t rows, int cin, const float* in_scale, const float* in_shift, int in_relu, const float* w,
+int pps_rows_layer_fwd(const void* x, int64_t rows, int cin, int dtype, const float* in_scale, const float* in_shift, int in_relu, const float* w,
                        const float* bias, int cout, void* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
                        float momentum, float eps, float* out_affine, float* save, void* ws, void* stream);
-int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t rows, int cin, int cout, const float* in_scale,
+int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t rows, int cin, int cout, int dtype, const float* in_scale,
                        const float* in_shift, int in_relu, const float* w, const float* gamma, const float* save, const float* d_affine,
                        void* dx, const void* dx_add, float* d_in_affine, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws,
                        void* stream);

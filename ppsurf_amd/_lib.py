@@ -52,7 +52,7 @@ SIGNATURES = {
     'pps_gather_max_f32': (_I, [_P, _P, _I64, _I, _I, _P, _P]),
     'pps_gather_rows_f32': (_I, [_P, _P, _I64, _I, _P, _P]),
     'pps_segment_sum_rows_f32': (_I, [_P, _P, _P, _I64, _I, _P, _P]),
-    'pps_segment_sum_rows_bf16': (_I, [_P, _P, _P, _I64, _I, _P, _P]),
+    'pps_segment_sum_rows_16': (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
     'pps_neighbour_contract_fwd_f32': (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
     'pps_neighbour_contract_bwd_f32': (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _P, _P]),
     'pps_gather_max_arg_f32': (_I, [_P, _P, _I64, _I, _I, _P, _P, _P]),
@@ -63,22 +63,22 @@ SIGNATURES = {
     'pps_attn_pool_fwd': (_I, [_P, _P, _I64, _I, _I, _I, _I, _I, _P, _P]),
     'pps_attn_pool_bwd': (_I, [_P, _P, _P, _I64, _I, _I, _I, _I, _I, _P, _P, _P]),
     'pps_patch_attn_partials': (_I, [_I64]),
-    'pps_patch_attn_fwd': (_I, [_P, _P, _I64, _I, _I, _P, _P]),
-    'pps_patch_attn_bwd': (_I, [_P, _P, _P, _I64, _I, _I, _P, _P, _P]),
+    'pps_patch_attn_fwd': (_I, [_P, _P, _I64, _I, _I, _I, _P, _P]),
+    'pps_patch_attn_bwd': (_I, [_P, _P, _P, _I64, _I, _I, _I, _P, _P, _P]),
     'pps_head_input_ws_bytes': (_SZ, [_I]),
-    'pps_head_input_fwd': (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _P, _P]),
-    'pps_head_input_dwx': (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _P, _P]),
+    'pps_head_input_fwd': (_I, [_P, _P, _P, _P, _I64, _I, _I, _I, _P, _P, _P]),
+    'pps_head_input_dwx': (_I, [_P, _P, _P, _P, _I64, _I, _I, _I, _P, _P, _P]),
     'pps_rows3_ws_bytes': (_SZ, []),
-    'pps_rows3_fwd': (_I, [_P, _I64, _P, _P, _P, _P, _P, _P, _P, _c.c_float, _c.c_float, _P, _P, _P, _P]),
-    'pps_rows3_bwd': (_I, [_P, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'pps_rows3_fwd': (_I, [_P, _I64, _P, _P, _I, _P, _P, _P, _P, _P, _c.c_float, _c.c_float, _P, _P, _P, _P]),
+    'pps_rows3_bwd': (_I, [_P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pps_patch_transform_ws_bytes': (_SZ, []),
-    'pps_patch_transform_fwd': (_I, [_P, _P, _P, _I, _P, _I, _I64, _I, _P, _P]),
-    'pps_patch_transform_bwd': (_I, [_P, _P, _P, _I, _P, _I, _P, _I64, _I, _P, _P, _P, _P, _P]),
-    'pps_rows_extrema_bf16': (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _P]),
+    'pps_patch_transform_fwd': (_I, [_P, _P, _P, _I, _P, _I, _I64, _I, _I, _P, _P]),
+    'pps_patch_transform_bwd': (_I, [_P, _P, _P, _I, _P, _I, _P, _I64, _I, _I, _P, _P, _P, _P, _P]),
+    'pps_rows_extrema_16': (_I, [_P, _I64, _I, _I, _I, _P, _P, _P, _P, _P]),
     'pps_rows_layer_supported': (_I, [_I, _I]),
     'pps_rows_layer_ws_bytes': (_SZ, [_I, _I]),
-    'pps_rows_layer_fwd': (_I, [_P, _I64, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _c.c_float, _c.c_float, _P, _P, _P, _P]),
-    'pps_rows_layer_bwd': (_I, [_P, _P, _P, _I64, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'pps_rows_layer_fwd': (_I, [_P, _I64, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _c.c_float, _c.c_float, _P, _P, _P, _P]),
+    'pps_rows_layer_bwd': (_I, [_P, _P, _P, _I64, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pps_bn_train_ws_bytes': (_SZ, [_I64, _I]),
     'pps_bn_train_fwd': (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _c.c_float, _c.c_float, _I, _P, _P, _P, _P]),
     'pps_bn_train_bwd': (_I, [_P, _P, _I64, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),

@@ -25,6 +25,10 @@ constexpr int AT_NT = 256;      // threads per workgroup = 4 waves; wave w owns 
 constexpr int AT_H = 64;
 constexpr int AT_KMAX = 64;
 
+typedef _Float16 half_t;                       // IEEE half storage (trainer.precision 16-mixed); uint16_t stands for bfloat16
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float ld(const half_t* p, int64_t i) { return (float)p[i]; }
+__device__ __forceinline__ void st(half_t* p, int64_t i, float v) { p[i] = (half_t)v; }
 __device__ __forceinline__ float ld(const float* p, int64_t i) { return p[i]; }
 __device__ __forceinline__ float ld(const uint16_t* p, int64_t i) { return __uint_as_float((unsigned)p[i] << 16); }
 __device__ __forceinline__ void st(float* p, int64_t i, float v) { p[i] = v; }
@@ -40,6 +44,15 @@ __device__ __forceinline__ float4 ld4(const float* p, int64_t i) { return *(cons
 __device__ __forceinline__ float4 ld4(const uint16_t* p, int64_t i) {
     const uint2 u = *(const uint2*)(p + i);
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ float4 ld4(const half_t* p, int64_t i) {
+    const uint2 u = *(const uint2*)(p + i);
+    const half2v a = *(const half2v*)&u.x, b = *(const half2v*)&u.y;
+    return make_float4((float)a[0], (float)a[1], (float)b[0], (float)b[1]);
+}
+__device__ __forceinline__ void st4(half_t* p, int64_t i, float4 v) {
+    const half2v a = {(half_t)v.x, (half_t)v.y}, b = {(half_t)v.z, (half_t)v.w};
+    *(uint2*)(p + i) = make_uint2(*(const unsigned*)&a, *(const unsigned*)&b);
 }
 __device__ __forceinline__ void st4(float* p, int64_t i, float4 v) { *(float4*)(p + i) = v; }
 __device__ __forceinline__ void st4(uint16_t* p, int64_t i, float4 v) {
@@ -243,11 +256,13 @@ __device__ __forceinline__ float rows_to_lanes(float (&p)[PA_K], int lane) {
 
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-__device__ __forceinline__ float4 row4(const uint16_t* __restrict__ src, int j, int lane) { return unpack4(*(const uint2*)(src + (int64_t)j * 256 + 4 * lane)); }
+template <typename T>
+__device__ __forceinline__ float4 row4(const T* __restrict__ src, int j, int lane) { return ld4(src, (int64_t)j * 256 + 4 * lane); }
 
 // lane j: softmax weight of row j (0 beyond k).  The rows are read here for the logits and AGAIN by the caller for the pooling (the
 // 25 KB of a group come from L2 the second time): keeping them in registers costs more in occupancy than the second read.
-__device__ __forceinline__ float patch_softmax(const uint16_t* __restrict__ src, int k, const float4 v4, int lane) {
+template <typename T>
+__device__ __forceinline__ float patch_softmax(const T* __restrict__ src, int k, const float4 v4, int lane) {
     float p[PA_K];
 #pragma unroll
     for (int j = 0; j < PA_K; ++j) {                               // no branch around the loads: rows beyond k re-read the last row and are zeroed
@@ -261,12 +276,13 @@ __device__ __forceinline__ float patch_softmax(const uint16_t* __restrict__ src,
     return e / wave_sum(e);
 }
 
-__global__ __launch_bounds__(PA_WAVES * 64, 2) void patch_attn_fwd_kernel(const uint16_t* __restrict__ h, const float* __restrict__ v, int64_t Q, int k,
+template <typename T>
+__global__ __launch_bounds__(PA_WAVES * 64, 2) void patch_attn_fwd_kernel(const T* __restrict__ h, const float* __restrict__ v, int64_t Q, int k,
                                                                          float* __restrict__ pooled) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4 v4 = *(const float4*)(v + 4 * lane);
     for (int64_t q = (int64_t)blockIdx.x * PA_WAVES + wave; q < Q; q += (int64_t)gridDim.x * PA_WAVES) {
-        const uint16_t* src = h + q * (int64_t)k * 256;
+        const T* src = h + q * (int64_t)k * 256;
         const float a = patch_softmax(src, k, v4, lane);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
@@ -279,14 +295,15 @@ __global__ __launch_bounds__(PA_WAVES * 64, 2) void patch_attn_fwd_kernel(const 
     }
 }
 
-__global__ __launch_bounds__(PA_WAVES * 64, 2) void patch_attn_bwd_kernel(const uint16_t* __restrict__ h, const float* __restrict__ v,
-                                                                         const float* __restrict__ dpooled, int64_t Q, int k, uint16_t* __restrict__ dh,
+template <typename T>
+__global__ __launch_bounds__(PA_WAVES * 64, 2) void patch_attn_bwd_kernel(const T* __restrict__ h, const float* __restrict__ v,
+                                                                         const float* __restrict__ dpooled, int64_t Q, int k, T* __restrict__ dh,
                                                                          float* __restrict__ dv_part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4 v4 = *(const float4*)(v + 4 * lane);
     float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t q = (int64_t)blockIdx.x * PA_WAVES + wave; q < Q; q += (int64_t)gridDim.x * PA_WAVES) {
-        const uint16_t* src = h + q * (int64_t)k * 256;
+        const T* src = h + q * (int64_t)k * 256;
         const float4 dp = *(const float4*)(dpooled + q * 256 + 4 * lane);
         float p[PA_K], pt[PA_K];
 #pragma unroll
@@ -303,7 +320,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, 2) void patch_attn_bwd_kernel(const 
         const float a = e / wave_sum(e);
         const float tbar = wave_sum(a * t);
         const float dl = a * (t - tbar);
-        uint16_t* dst = dh + q * (int64_t)k * 256 + 4 * lane;
+        T* dst = dh + q * (int64_t)k * 256 + 4 * lane;
 #pragma unroll 8
         for (int j = 0; j < k; ++j) {
             const float aj = __shfl(a, j), dj = __shfl(dl, j);
@@ -334,7 +351,10 @@ int pps_attn_pool_fwd(const void* qy, const void* h, int64_t q, int k, int heads
     if (q == 0) return PPS_OK;
     if (!qy || !h || !pooled) return PPS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (bf16)
+    if (bf16 == 2)
+        hipLaunchKernelGGL(attn_pool_fwd_kernel<half_t>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const half_t*)qy, (const half_t*)h, q, k, heads, c, relu_h,
+                           (half_t*)pooled);
+    else if (bf16)
         hipLaunchKernelGGL(attn_pool_fwd_kernel<uint16_t>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const uint16_t*)qy, (const uint16_t*)h, q, k, heads, c,
                            relu_h, (uint16_t*)pooled);
     else
@@ -349,7 +369,10 @@ int pps_attn_pool_bwd(const void* qy, const void* h, const void* dpooled, int64_
     if (q == 0) return PPS_OK;
     if (!qy || !h || !dpooled || !dqy || !dh) return PPS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (bf16)
+    if (bf16 == 2)
+        hipLaunchKernelGGL(attn_pool_bwd_kernel<half_t>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const half_t*)qy, (const half_t*)h, (const half_t*)dpooled, q,
+                           k, heads, c, relu_h, (half_t*)dqy, (half_t*)dh);
+    else if (bf16)
         hipLaunchKernelGGL(attn_pool_bwd_kernel<uint16_t>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const uint16_t*)qy, (const uint16_t*)h,
                            (const uint16_t*)dpooled, q, k, heads, c, relu_h, (uint16_t*)dqy, (uint16_t*)dh);
     else
@@ -363,20 +386,28 @@ int pps_attn_pool_bwd(const void* qy, const void* h, const void* dpooled, int64_
  * [pps_patch_attn_partials(q)][256] whose sum over the first axis is dv. */
 int pps_patch_attn_partials(int64_t q) { return q > 0 ? patch_grid(q) * PA_WAVES : 0; }
 
-int pps_patch_attn_fwd(const void* h, const float* v, int64_t q, int k, int c, float* pooled, void* stream) {
-    if (q < 0 || k < 1 || k > PA_K || c != 256) return PPS_ERR_ARG;
+int pps_patch_attn_fwd(const void* h, const float* v, int64_t q, int k, int c, int dtype, float* pooled, void* stream) {
+    if (q < 0 || k < 1 || k > PA_K || c != 256 || (dtype != 1 && dtype != 2)) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
     if (!h || !v || !pooled) return PPS_ERR_ARG;
-    hipLaunchKernelGGL(patch_attn_fwd_kernel, dim3(patch_grid(q)), dim3(PA_WAVES * 64), 0, (hipStream_t)stream, (const uint16_t*)h, v, q, k, pooled);
+    if (dtype == 2)
+        hipLaunchKernelGGL(patch_attn_fwd_kernel<half_t>, dim3(patch_grid(q)), dim3(PA_WAVES * 64), 0, (hipStream_t)stream, (const half_t*)h, v, q, k, pooled);
+    else
+        hipLaunchKernelGGL(patch_attn_fwd_kernel<uint16_t>, dim3(patch_grid(q)), dim3(PA_WAVES * 64), 0, (hipStream_t)stream, (const uint16_t*)h, v, q, k,
+                           pooled);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 
-int pps_patch_attn_bwd(const void* h, const float* v, const float* dpooled, int64_t q, int k, int c, void* dh, float* dv_part, void* stream) {
-    if (q < 0 || k < 1 || k > PA_K || c != 256) return PPS_ERR_ARG;
+int pps_patch_attn_bwd(const void* h, const float* v, const float* dpooled, int64_t q, int k, int c, int dtype, void* dh, float* dv_part, void* stream) {
+    if (q < 0 || k < 1 || k > PA_K || c != 256 || (dtype != 1 && dtype != 2)) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
     if (!h || !v || !dpooled || !dh || !dv_part) return PPS_ERR_ARG;
-    hipLaunchKernelGGL(patch_attn_bwd_kernel, dim3(patch_grid(q)), dim3(PA_WAVES * 64), 0, (hipStream_t)stream, (const uint16_t*)h, v, dpooled, q, k,
-                       (uint16_t*)dh, dv_part);
+    if (dtype == 2)
+        hipLaunchKernelGGL(patch_attn_bwd_kernel<half_t>, dim3(patch_grid(q)), dim3(PA_WAVES * 64), 0, (hipStream_t)stream, (const half_t*)h, v, dpooled, q, k,
+                           (half_t*)dh, dv_part);
+    else
+        hipLaunchKernelGGL(patch_attn_bwd_kernel<uint16_t>, dim3(patch_grid(q)), dim3(PA_WAVES * 64), 0, (hipStream_t)stream, (const uint16_t*)h, v, dpooled, q,
+                           k, (uint16_t*)dh, dv_part);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 

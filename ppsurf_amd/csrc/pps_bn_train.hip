@@ -6,7 +6,7 @@
 // elements; fused here into 2 + 2 (statistics, apply+act | mask+reduce, mask+elementwise), all pure streaming kernels:
 // 4 channels per thread (8/16-byte accesses), rows strided over the block, per-channel sums reduced in a fixed order
 // (per-thread fp32 partials shifted by a per-channel pivot, block partials and the final sums in double).
-// fp32 or bf16 storage (dtype 0 / 1), fp32 arithmetic.
+// fp32, bf16 or IEEE-half storage (dtype 0 / 1 / 2), fp32 arithmetic.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -28,6 +28,13 @@ template <> __device__ __forceinline__ F4 load4<uint16_t>(const uint16_t* p) {
     const uint2 t = *(const uint2*)p;
     return F4{{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)}};
 }
+typedef _Float16 half_t;
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+template <> __device__ __forceinline__ F4 load4<half_t>(const half_t* p) {
+    const uint2 t = *(const uint2*)p;
+    const half2v a = *(const half2v*)&t.x, b = *(const half2v*)&t.y;
+    return F4{{(float)a[0], (float)a[1], (float)b[0], (float)b[1]}};
+}
 __device__ __forceinline__ uint32_t bf16_rne(float f) {
     uint32_t u = __float_as_uint(f);
     u += 0x7fffu + ((u >> 16) & 1u);
@@ -35,6 +42,10 @@ __device__ __forceinline__ uint32_t bf16_rne(float f) {
 }
 template <typename T> __device__ __forceinline__ void store4(T* p, const F4& a);
 template <> __device__ __forceinline__ void store4<float>(float* p, const F4& a) { *(float4*)p = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]); }
+template <> __device__ __forceinline__ void store4<half_t>(half_t* p, const F4& a) {
+    const half2v x = {(half_t)a.v[0], (half_t)a.v[1]}, y = {(half_t)a.v[2], (half_t)a.v[3]};
+    *(uint2*)p = make_uint2(*(const unsigned*)&x, *(const unsigned*)&y);
+}
 template <> __device__ __forceinline__ void store4<uint16_t>(uint16_t* p, const F4& a) {
     *(uint2*)p = make_uint2(bf16_rne(a.v[0]) | (bf16_rne(a.v[1]) << 16), bf16_rne(a.v[2]) | (bf16_rne(a.v[3]) << 16));
 }
@@ -124,8 +135,7 @@ __global__ __launch_bounds__(BNT) void bn_finalize_kernel(const double* __restri
     if (lane != 0) return;
     const double n = (double)rows;
     if (MODE == 0) {
-        const uint16_t* xb = (const uint16_t*)x;
-        const double pivot = sizeof(T) == 4 ? (double)((const float*)x)[c] : (double)__uint_as_float((uint32_t)xb[c] << 16);
+        const double pivot = (double)load4<T>(x + (c & ~3)).v[c & 3];        // row 0 of the tensor, as in bn_reduce_kernel
         const double d = s1 / n;
         double var = s2 / n - d * d;
         if (var < 0.0) var = 0.0;
@@ -239,10 +249,12 @@ size_t pps_bn_train_ws_bytes(int64_t rows, int c) {
 int pps_bn_train_fwd(const void* x, int64_t rows, int c, int dtype, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, float momentum, float eps, int relu, void* y, float* save, void* ws, void* stream) {
     if (rows == 0) return 0;
-    if (!ok_shape(rows, c) || (dtype != 0 && dtype != 1) || !x || !gamma || !beta || !y || !save || !ws) return 1;
+    if (!ok_shape(rows, c) || (dtype < 0 || dtype > 2) || !x || !gamma || !beta || !y || !save || !ws) return 1;
     if ((running_mean == nullptr) != (running_var == nullptr)) return 1;
     if (dtype == 0)
         return fwd_t<float>((const float*)x, rows, c, gamma, beta, running_mean, running_var, momentum, eps, relu, (float*)y, save, ws, (hipStream_t)stream);
+    if (dtype == 2)
+        return fwd_t<half_t>((const half_t*)x, rows, c, gamma, beta, running_mean, running_var, momentum, eps, relu, (half_t*)y, save, ws, (hipStream_t)stream);
     return fwd_t<uint16_t>((const uint16_t*)x, rows, c, gamma, beta, running_mean, running_var, momentum, eps, relu, (uint16_t*)y, save, ws,
                            (hipStream_t)stream);
 }
@@ -250,9 +262,11 @@ int pps_bn_train_fwd(const void* x, int64_t rows, int c, int dtype, const float*
 int pps_bn_train_bwd(const void* x, const void* dy, int64_t rows, int c, int dtype, const float* gamma, const float* beta, const float* save,
                      int relu, void* dx, float* dgamma, float* dbeta, void* ws, void* stream) {
     if (rows == 0) return 0;
-    if (!ok_shape(rows, c) || (dtype != 0 && dtype != 1) || !x || !dy || !gamma || !beta || !save || !dx || !dgamma || !dbeta || !ws) return 1;
+    if (!ok_shape(rows, c) || (dtype < 0 || dtype > 2) || !x || !dy || !gamma || !beta || !save || !dx || !dgamma || !dbeta || !ws) return 1;
     if (dtype == 0)
         return bwd_t<float>((const float*)x, (const float*)dy, rows, c, gamma, beta, save, relu, (float*)dx, dgamma, dbeta, ws, (hipStream_t)stream);
+    if (dtype == 2)
+        return bwd_t<half_t>((const half_t*)x, (const half_t*)dy, rows, c, gamma, beta, save, relu, (half_t*)dx, dgamma, dbeta, ws, (hipStream_t)stream);
     return bwd_t<uint16_t>((const uint16_t*)x, (const uint16_t*)dy, rows, c, gamma, beta, save, relu, (uint16_t*)dx, dgamma, dbeta, ws,
                            (hipStream_t)stream);
 }

@@ -57,10 +57,12 @@ __global__ void __launch_bounds__(TB) segment_sum_rows_kernel(const V* __restric
     out[t] = acc;
 }
 
-// the same with bf16 values (4 channels = 8 bytes per thread), fp32 accumulation and output
-__global__ void __launch_bounds__(TB) segment_sum_rows_bf16_kernel(const uint2* __restrict__ vals, const int64_t* __restrict__ order,
-                                                                   const int64_t* __restrict__ offsets, int64_t n, int c4,
-                                                                   float4* __restrict__ out) {
+// the same with 16-bit values (bfloat16, or IEEE half with F16; 4 channels = 8 bytes per thread), fp32 accumulation and output
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+template <bool F16>
+__global__ void __launch_bounds__(TB) segment_sum_rows_16_kernel(const uint2* __restrict__ vals, const int64_t* __restrict__ order,
+                                                                 const int64_t* __restrict__ offsets, int64_t n, int c4,
+                                                                 float4* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (t >= n * c4) return;
     const int64_t row = t / c4;
@@ -69,8 +71,13 @@ __global__ void __launch_bounds__(TB) segment_sum_rows_bf16_kernel(const uint2* 
     const int64_t e1 = offsets[row + 1];
     for (int64_t e = offsets[row]; e < e1; ++e) {
         const uint2 v = vals[order[e] * c4 + col];
-        acc.x += __uint_as_float(v.x << 16); acc.y += __uint_as_float(v.x & 0xffff0000u);
-        acc.z += __uint_as_float(v.y << 16); acc.w += __uint_as_float(v.y & 0xffff0000u);
+        if (F16) {
+            const half2v a = *(const half2v*)&v.x, b = *(const half2v*)&v.y;
+            acc.x += (float)a[0]; acc.y += (float)a[1]; acc.z += (float)b[0]; acc.w += (float)b[1];
+        } else {
+            acc.x += __uint_as_float(v.x << 16); acc.y += __uint_as_float(v.x & 0xffff0000u);
+            acc.z += __uint_as_float(v.y << 16); acc.w += __uint_as_float(v.y & 0xffff0000u);
+        }
     }
     out[t] = acc;
 }
@@ -274,13 +281,14 @@ int pps_segment_sum_rows_f32(const float* vals, const int64_t* order, const int6
     return launch_status();
 }
 
-int pps_segment_sum_rows_bf16(const void* vals, const int64_t* order, const int64_t* offsets, int64_t n, int c, float* out,
-                              void* stream) {
-    if (n < 0 || c < 4 || (c & 3)) return 1;
+int pps_segment_sum_rows_16(const void* vals, const int64_t* order, const int64_t* offsets, int64_t n, int c, int dtype, float* out, void* stream) {
+    if (n < 0 || c < 4 || (c & 3) || (dtype != 1 && dtype != 2)) return 1;
     if (n == 0) return 0;
     if (!order || !offsets || !out) return 1;
-    segment_sum_rows_bf16_kernel<<<blocks_for(n * (c / 4)), TB, 0, (hipStream_t)stream>>>((const uint2*)vals, order, offsets, n, c / 4,
-                                                                                          (float4*)out);
+    if (dtype == 2)
+        segment_sum_rows_16_kernel<true><<<blocks_for(n * (c / 4)), TB, 0, (hipStream_t)stream>>>((const uint2*)vals, order, offsets, n, c / 4, (float4*)out);
+    else
+        segment_sum_rows_16_kernel<false><<<blocks_for(n * (c / 4)), TB, 0, (hipStream_t)stream>>>((const uint2*)vals, order, offsets, n, c / 4, (float4*)out);
     return launch_status();
 }
 

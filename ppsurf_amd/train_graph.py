@@ -47,16 +47,16 @@ _shadow = {}                 # id(parameter) -> bf16 tensor of the same shape (p
 _shadow_live = [False]
 
 
-def prepare_shadows(module):
-    """Call at the start of a bf16-autocast forward pass in train(): parameters -> persistent bf16 images."""
+def prepare_shadows(module, dtype=torch.bfloat16):
+    """Call at the start of an autocast forward pass in train(): parameters -> persistent images in the autocast type (bf16 / fp16)."""
     params = [p for p in module.parameters() if p.is_cuda and p.dtype == torch.float32]
     if not params:
         return
     with torch.no_grad():
         for p in params:
             t = _shadow.get(id(p))
-            if t is None or t.shape != p.shape or t.device != p.device:
-                _shadow[id(p)] = torch.empty_like(p, dtype=torch.bfloat16)
+            if t is None or t.shape != p.shape or t.device != p.device or t.dtype != dtype:
+                _shadow[id(p)] = torch.empty_like(p, dtype=dtype)
         torch._foreach_copy_([_shadow[id(p)] for p in params], params)
     _shadow_live[0] = True
 
@@ -71,7 +71,7 @@ _mm_fp32_out = [True]
 
 def _mm_f32(a, b):
     """a @ b for bf16 operands with an fp32 result written by the GEMM itself (no separate cast of the weight gradient)."""
-    if _mm_fp32_out[0] and a.is_cuda and a.dtype == torch.bfloat16:
+    if _mm_fp32_out[0] and a.is_cuda and a.dtype in train_ops.LOW:
         try:
             return torch.mm(a, b, out_dtype=torch.float32)
         except (TypeError, RuntimeError, NotImplementedError):
@@ -352,9 +352,9 @@ FUSED_ROWS = True            # False: every row layer through the separate ops (
 
 
 def fused_rows_ok(x, *bns):
-    """The fused row layers (train_ops.rows_layer: bf16 storage, BatchNorm statistics of train()) apply: device tensor, bf16 autocast, every
+    """The fused row layers (train_ops.rows_layer: 16-bit storage, BatchNorm statistics of train()) apply: device tensor, bf16 / fp16 autocast, every
     BatchNorm in train() with a momentum."""
-    return (x.is_cuda and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16
+    return (x.is_cuda and torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') in train_ops.LOW
             and all(b.training and b.track_running_stats and b.momentum is not None for b in bns))
 
 
@@ -459,7 +459,7 @@ def _pointnet_fused(pn, patches, need_trans=True):
     # (softmax ignores the constant w_q . shift + b_q; it stays in the graph with weight 0 so that fc_query.bias gets its zero gradient, not None)
     const = (wq * shift).sum() + pn.att.fc_query.bias.float().sum()
     pooled = train_ops.patch_attn(z.raw.view(nq, p, -1), (wq * scale).reshape(-1))
-    pooled = (pooled * scale + shift + 0.0 * const).to(torch.bfloat16)
+    pooled = (pooled * scale + shift + 0.0 * const).to(z.raw.dtype)
     return dense(pn.att.fc_value, pooled), trans2
 
 
@@ -519,8 +519,8 @@ def _prepare(net, data):
     x = data['pts']
     if x.is_cuda and net.training:
         register_tables(data)
-        if torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') == torch.bfloat16:
-            prepare_shadows(net)
+        if torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') in train_ops.LOW:
+            prepare_shadows(net, torch.get_autocast_dtype('cuda'))
 
 
 @_counted

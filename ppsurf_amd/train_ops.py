@@ -25,6 +25,24 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+LOW = (torch.bfloat16, torch.float16)          # 16-bit storage types of the fused training ops (trainer.precision bf16-mixed / 16-mixed)
+
+
+def _code(dt):
+    """dtype argument of the C entries: 1 bfloat16, 2 IEEE half."""
+    return 1 if dt == torch.bfloat16 else 2
+
+
+def _low(t, like=None):
+    """t in a 16-bit storage type: as it is if it has one, else the type of `like` / the autocast type / bfloat16."""
+    if t.dtype in LOW:
+        return t.contiguous()
+    if like is not None and like.dtype in LOW:
+        return t.to(like.dtype).contiguous()
+    dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else torch.bfloat16
+    return t.to(dt if dt in LOW else torch.bfloat16).contiguous()
+
+
 def _need_cuda(*tensors):
     for t in tensors:
         if not t.is_cuda:
@@ -75,7 +93,7 @@ class _GatherRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, idx):
         _need_cuda(x, idx)
-        if x.dtype not in (torch.float32, torch.bfloat16) or (x.dtype == torch.bfloat16 and x.shape[1] % 2):
+        if x.dtype not in (torch.float32,) + LOW or (x.dtype in LOW and x.shape[1] % 2):
             x = x.float()
         x = x.contiguous()
         idx = idx.contiguous()
@@ -96,9 +114,9 @@ class _GatherRows(torch.autograd.Function):
         order, offsets = csr(idx, ctx.n)
         dout = dout.contiguous()
         dx = torch.empty((ctx.n, dout.shape[1]), device=dout.device, dtype=torch.float32)
-        if dout.dtype == torch.bfloat16 and dout.shape[1] % 4 == 0:
-            _lib.check(_lib.lib().pps_segment_sum_rows_bf16(dout.data_ptr(), order.data_ptr(), offsets.data_ptr(), ctx.n, dout.shape[1],
-                                                            dx.data_ptr(), _stream()), 'pps_segment_sum_rows_bf16')
+        if dout.dtype in LOW and dout.shape[1] % 4 == 0:
+            _lib.check(_lib.lib().pps_segment_sum_rows_16(dout.data_ptr(), order.data_ptr(), offsets.data_ptr(), ctx.n, dout.shape[1],
+                                                          _code(dout.dtype), dx.data_ptr(), _stream()), 'pps_segment_sum_rows_16')
         else:
             dout = dout.float()
             _lib.check(_lib.lib().pps_segment_sum_rows_f32(dout.data_ptr(), order.data_ptr(), offsets.data_ptr(), ctx.n, dout.shape[1],
@@ -114,35 +132,35 @@ class _HeadInput(torch.autograd.Function):
     def forward(ctx, table, ids, pts, query, k, wx):
         _need_cuda(table, ids, pts, query, wx)
         L = _lib.lib()
-        table = table.to(torch.bfloat16).contiguous()
+        table = _low(table)
         ids = ids.contiguous()
         pts32, q32 = pts.detach().float().contiguous(), query.detach().float().contiguous()
         wx32 = wx.detach().float().contiguous()
         nq, c = q32.shape[0], table.shape[1]
-        h1 = torch.empty((nq * k, c), device=table.device, dtype=torch.bfloat16)
-        _lib.check(L.pps_head_input_fwd(table.data_ptr(), ids.data_ptr(), pts32.data_ptr(), q32.data_ptr(), nq, k, c, wx32.data_ptr(), h1.data_ptr(),
-                                        _stream()), 'pps_head_input_fwd')
+        h1 = torch.empty((nq * k, c), device=table.device, dtype=table.dtype)
+        _lib.check(L.pps_head_input_fwd(table.data_ptr(), ids.data_ptr(), pts32.data_ptr(), q32.data_ptr(), nq, k, c, _code(table.dtype), wx32.data_ptr(),
+                                        h1.data_ptr(), _stream()), 'pps_head_input_fwd')
         ctx.save_for_backward(ids, pts32, q32)
-        ctx.meta = (table.shape[0], k, c, wx.dtype, wx.shape)
+        ctx.meta = (table.shape[0], k, c, wx.dtype, wx.shape, table.dtype)
         return h1
 
     @staticmethod
     def backward(ctx, dh1):
         ids, pts32, q32 = ctx.saved_tensors
-        n, k, c, wdt, wshape = ctx.meta
+        n, k, c, wdt, wshape, dt = ctx.meta
         L = _lib.lib()
-        dh1 = dh1.to(torch.bfloat16).contiguous()
+        dh1 = dh1.to(dt).contiguous()
         dtable = dwx = None
         if ctx.needs_input_grad[0]:
             order, offsets = csr(ids, n)
             dt32 = torch.empty((n, c), device=dh1.device, dtype=torch.float32)
-            _lib.check(L.pps_segment_sum_rows_bf16(dh1.data_ptr(), order.data_ptr(), offsets.data_ptr(), n, c, dt32.data_ptr(), _stream()),
-                       'pps_segment_sum_rows_bf16')
-            dtable = dt32.to(torch.bfloat16)
+            _lib.check(L.pps_segment_sum_rows_16(dh1.data_ptr(), order.data_ptr(), offsets.data_ptr(), n, c, _code(dt), dt32.data_ptr(), _stream()),
+                       'pps_segment_sum_rows_16')
+            dtable = dt32.to(dt)
         if ctx.needs_input_grad[5]:
             dwx = torch.empty((c, 3), device=dh1.device, dtype=torch.float32)
             ws = torch.empty((L.pps_head_input_ws_bytes(c),), device=dh1.device, dtype=torch.uint8)
-            _lib.check(L.pps_head_input_dwx(dh1.data_ptr(), ids.data_ptr(), pts32.data_ptr(), q32.data_ptr(), q32.shape[0], k, c, dwx.data_ptr(),
+            _lib.check(L.pps_head_input_dwx(dh1.data_ptr(), ids.data_ptr(), pts32.data_ptr(), q32.data_ptr(), q32.shape[0], k, c, _code(dt), dwx.data_ptr(),
                                             ws.data_ptr(), _stream()), 'pps_head_input_dwx')
             dwx = dwx.reshape(wshape).to(wdt)
         return dtable, None, None, None, None, dwx
@@ -276,7 +294,7 @@ class _BnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu):
         _need_cuda(x, weight, bias)
-        if x.dtype not in (torch.float32, torch.bfloat16):
+        if x.dtype not in (torch.float32,) + LOW:
             x = x.float()
         x = x.contiguous()
         rows, c = x.shape
@@ -287,7 +305,7 @@ class _BnAct(torch.autograd.Function):
         if nbytes == 0 and rows > 0:
             raise ValueError('bn_act: unsupported shape [{}, {}]'.format(rows, c))
         ws = torch.empty((max(nbytes, 1),), device=x.device, dtype=torch.uint8)
-        _lib.check(_lib.lib().pps_bn_train_fwd(x.data_ptr(), rows, c, 1 if x.dtype == torch.bfloat16 else 0, w32.data_ptr(), b32.data_ptr(),
+        _lib.check(_lib.lib().pps_bn_train_fwd(x.data_ptr(), rows, c, _code(x.dtype) if x.dtype in LOW else 0, w32.data_ptr(), b32.data_ptr(),
                                                running_mean.data_ptr() if running_mean is not None else None,
                                                running_var.data_ptr() if running_var is not None else None, float(momentum), float(eps),
                                                int(bool(relu)), y.data_ptr(), save.data_ptr(), ws.data_ptr(), _stream()), 'pps_bn_train_fwd')
@@ -305,7 +323,7 @@ class _BnAct(torch.autograd.Function):
         dgamma = torch.empty((c,), device=x.device, dtype=torch.float32)
         dbeta = torch.empty((c,), device=x.device, dtype=torch.float32)
         ws = torch.empty((max(_lib.lib().pps_bn_train_ws_bytes(rows, c), 1),), device=x.device, dtype=torch.uint8)
-        _lib.check(_lib.lib().pps_bn_train_bwd(x.data_ptr(), dy.data_ptr(), rows, c, 1 if x.dtype == torch.bfloat16 else 0, w32.data_ptr(),
+        _lib.check(_lib.lib().pps_bn_train_bwd(x.data_ptr(), dy.data_ptr(), rows, c, _code(x.dtype) if x.dtype in LOW else 0, w32.data_ptr(),
                                                b32.data_ptr(), save.data_ptr(), int(ctx.relu), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                                ws.data_ptr(), _stream()), 'pps_bn_train_bwd')
         return dx, dgamma.to(ctx.dtypes[0]), dbeta.to(ctx.dtypes[1]), None, None, None, None, None
@@ -319,12 +337,12 @@ class _AttnPool(torch.autograd.Function):
     def forward(ctx, qy, h, relu_h=False):
         _need_cuda(qy, h)
         ctx.relu_h = int(bool(relu_h))
-        dt = h.dtype if h.dtype in (torch.float32, torch.bfloat16) else torch.float32
+        dt = h.dtype if h.dtype in (torch.float32,) + LOW else torch.float32
         qy, h = qy.to(dt).contiguous(), h.to(dt).contiguous()
         q, k, heads = qy.shape
         c = h.shape[2]
         pooled = torch.empty((q, c), device=h.device, dtype=dt)
-        _lib.check(_lib.lib().pps_attn_pool_fwd(qy.data_ptr(), h.data_ptr(), q, k, heads, c, int(dt == torch.bfloat16), ctx.relu_h, pooled.data_ptr(), _stream()),
+        _lib.check(_lib.lib().pps_attn_pool_fwd(qy.data_ptr(), h.data_ptr(), q, k, heads, c, _code(dt) if dt in LOW else 0, ctx.relu_h, pooled.data_ptr(), _stream()),
                    'pps_attn_pool_fwd')
         ctx.save_for_backward(qy, h)
         return pooled
@@ -336,7 +354,7 @@ class _AttnPool(torch.autograd.Function):
         c = h.shape[2]
         dpooled = dpooled.to(h.dtype).contiguous()
         dqy, dh = torch.empty_like(qy), torch.empty_like(h)
-        _lib.check(_lib.lib().pps_attn_pool_bwd(qy.data_ptr(), h.data_ptr(), dpooled.data_ptr(), q, k, heads, c, int(h.dtype == torch.bfloat16),
+        _lib.check(_lib.lib().pps_attn_pool_bwd(qy.data_ptr(), h.data_ptr(), dpooled.data_ptr(), q, k, heads, c, _code(h.dtype) if h.dtype in LOW else 0,
                                                 ctx.relu_h, dqy.data_ptr(), dh.data_ptr(), _stream()), 'pps_attn_pool_bwd')
         return dqy, dh, None
 
@@ -364,7 +382,7 @@ class _RowsLayer(torch.autograd.Function):
     def forward(ctx, x, in_affine, in_relu, w, b, gamma, beta, running_mean, running_var, momentum, eps):
         _need_cuda(x, w)
         L = _lib.lib()
-        x = x.to(torch.bfloat16).contiguous()
+        x = _low(x)
         rows, cin = x.shape
         cout = w.shape[0]
         w32 = w.detach().float().contiguous()
@@ -373,12 +391,12 @@ class _RowsLayer(torch.autograd.Function):
         bn = gamma is not None
         g32 = gamma.detach().float().contiguous() if bn else None
         be32 = beta.detach().float().contiguous() if bn else None
-        y = torch.empty((rows, cout), device=x.device, dtype=torch.bfloat16)
+        y = torch.empty((rows, cout), device=x.device, dtype=x.dtype)
         out_affine = torch.empty((2, cout), device=x.device, dtype=torch.float32) if bn else None
         save = torch.empty((2, cout), device=x.device, dtype=torch.float32) if bn else None
         ws = torch.empty((L.pps_rows_layer_ws_bytes(cin, cout),), device=x.device, dtype=torch.uint8)
         ptr = lambda t: None if t is None else t.data_ptr()
-        _lib.check(L.pps_rows_layer_fwd(x.data_ptr(), rows, cin, ptr(aff), None if aff is None else aff.data_ptr() + 4 * cin, int(bool(in_relu)),
+        _lib.check(L.pps_rows_layer_fwd(x.data_ptr(), rows, cin, _code(x.dtype), ptr(aff), None if aff is None else aff.data_ptr() + 4 * cin, int(bool(in_relu)),
                                         w32.data_ptr(), ptr(b32), cout, y.data_ptr(), ptr(g32), ptr(be32), ptr(running_mean), ptr(running_var),
                                         float(momentum or 0.0), float(eps or 0.0), ptr(out_affine), ptr(save), ws.data_ptr(), _stream()),
                    'pps_rows_layer_fwd')
@@ -394,7 +412,7 @@ class _RowsLayer(torch.autograd.Function):
         rows, cin = x.shape
         cout = w32.shape[0]
         dev = x.device
-        gy = gy.to(torch.bfloat16).contiguous()
+        gy = gy.to(x.dtype).contiguous()
         if bn:
             g_affine = torch.zeros((2, cout), device=dev, dtype=torch.float32) if g_affine is None else g_affine.float().contiguous()
         need_dx, need_daff = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and aff is not None
@@ -406,7 +424,7 @@ class _RowsLayer(torch.autograd.Function):
         dbeta = torch.empty((cout,), device=dev, dtype=torch.float32) if bn else None
         ws = torch.empty((L.pps_rows_layer_ws_bytes(cin, cout),), device=dev, dtype=torch.uint8)
         ptr = lambda t: None if t is None else t.data_ptr()
-        _lib.check(L.pps_rows_layer_bwd(x.data_ptr(), y.data_ptr(), gy.data_ptr(), rows, cin, cout, ptr(aff),
+        _lib.check(L.pps_rows_layer_bwd(x.data_ptr(), y.data_ptr(), gy.data_ptr(), rows, cin, cout, _code(x.dtype), ptr(aff),
                                         None if aff is None else aff.data_ptr() + 4 * cin, int(in_relu), w32.data_ptr(), ptr(g32), ptr(save),
                                         ptr(g_affine) if bn else None, ptr(dx), None, ptr(d_in), dw.data_ptr(), ptr(db), ptr(dgamma), ptr(dbeta),
                                         ws.data_ptr(), _stream()), 'pps_rows_layer_bwd')
@@ -425,11 +443,12 @@ class _Rows3Layer(torch.autograd.Function):
         w32 = w.detach().float().contiguous()
         b32 = None if b is None else b.detach().float().contiguous()
         g32, be32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
-        y = torch.empty((rows, 64), device=x.device, dtype=torch.bfloat16)
+        dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else torch.bfloat16
+        y = torch.empty((rows, 64), device=x.device, dtype=dt if dt in LOW else torch.bfloat16)
         aff, save = torch.empty((2, 64), device=x.device), torch.empty((2, 64), device=x.device)
         ws = torch.empty((L.pps_rows3_ws_bytes(),), device=x.device, dtype=torch.uint8)
         ptr = lambda t: None if t is None else t.data_ptr()
-        _lib.check(L.pps_rows3_fwd(x.data_ptr(), rows, w32.data_ptr(), ptr(b32), y.data_ptr(), g32.data_ptr(), be32.data_ptr(), ptr(running_mean),
+        _lib.check(L.pps_rows3_fwd(x.data_ptr(), rows, w32.data_ptr(), ptr(b32), _code(y.dtype), y.data_ptr(), g32.data_ptr(), be32.data_ptr(), ptr(running_mean),
                                    ptr(running_var), float(momentum), float(eps), aff.data_ptr(), save.data_ptr(), ws.data_ptr(), _stream()), 'pps_rows3_fwd')
         ctx.save_for_backward(x, y, g32, save)
         ctx.meta = (b is not None, w.dtype, None if b is None else b.dtype)
@@ -441,13 +460,13 @@ class _Rows3Layer(torch.autograd.Function):
         has_b, wdt, bdt = ctx.meta
         L = _lib.lib()
         dev = x.device
-        gy = gy.to(torch.bfloat16).contiguous()
+        gy = gy.to(y.dtype).contiguous()
         g_aff = torch.zeros((2, 64), device=dev) if g_aff is None else g_aff.float().contiguous()
         dw = torch.empty((64, 3), device=dev)
         db = torch.empty((64,), device=dev) if has_b else None
         dgamma, dbeta = torch.empty((64,), device=dev), torch.empty((64,), device=dev)
         ws = torch.empty((L.pps_rows3_ws_bytes(),), device=dev, dtype=torch.uint8)
-        _lib.check(L.pps_rows3_bwd(x.data_ptr(), y.data_ptr(), gy.data_ptr(), x.shape[0], g32.data_ptr(), save.data_ptr(), g_aff.data_ptr(), dw.data_ptr(),
+        _lib.check(L.pps_rows3_bwd(x.data_ptr(), y.data_ptr(), gy.data_ptr(), x.shape[0], _code(y.dtype), g32.data_ptr(), save.data_ptr(), g_aff.data_ptr(), dw.data_ptr(),
                                    None if db is None else db.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), _stream()), 'pps_rows3_bwd')
         return None, dw.to(wdt), None if db is None else db.to(bdt), dgamma, dbeta, None, None, None, None
 
@@ -466,13 +485,13 @@ class _PatchTransform(torch.autograd.Function):
     def forward(ctx, x, affine, relu, t, p):
         _need_cuda(x, t)
         L = _lib.lib()
-        x = x.to(torch.bfloat16).contiguous()
-        t16 = t.to(torch.bfloat16).contiguous()
+        x = _low(x)
+        t16 = t.to(x.dtype).contiguous()
         nq = t16.shape[0]
         aff = None if affine is None else affine.detach().float().contiguous()
         out = torch.empty_like(x)
         _lib.check(L.pps_patch_transform_fwd(x.data_ptr(), None if aff is None else aff.data_ptr(), None if aff is None else aff.data_ptr() + 256,
-                                             int(bool(relu)), t16.data_ptr(), 1, nq, p, out.data_ptr(), _stream()), 'pps_patch_transform_fwd')
+                                             int(bool(relu)), t16.data_ptr(), 1, nq, p, _code(x.dtype), out.data_ptr(), _stream()), 'pps_patch_transform_fwd')
         ctx.save_for_backward(x, aff, t16)
         ctx.meta = (bool(relu), p, t.dtype)
         return out
@@ -483,13 +502,13 @@ class _PatchTransform(torch.autograd.Function):
         relu, p, tdt = ctx.meta
         L = _lib.lib()
         nq = t16.shape[0]
-        g = g.to(torch.bfloat16).contiguous()
+        g = g.to(x.dtype).contiguous()
         dx, dt = torch.empty_like(x), torch.empty_like(t16)
         need_daff = aff is not None and ctx.needs_input_grad[1]
         daff = torch.empty((2, 64), device=x.device) if need_daff else None
         ws = torch.empty((L.pps_patch_transform_ws_bytes(),), device=x.device, dtype=torch.uint8)
         _lib.check(L.pps_patch_transform_bwd(x.data_ptr(), None if aff is None else aff.data_ptr(), None if aff is None else aff.data_ptr() + 256,
-                                             int(relu), t16.data_ptr(), 1, g.data_ptr(), nq, p, dx.data_ptr(), dt.data_ptr(),
+                                             int(relu), t16.data_ptr(), 1, g.data_ptr(), nq, p, _code(x.dtype), dx.data_ptr(), dt.data_ptr(),
                                              None if daff is None else daff.data_ptr(), ws.data_ptr(), _stream()), 'pps_patch_transform_bwd')
         return dx, daff, None, dt.to(tdt), None
 
@@ -513,11 +532,11 @@ class _PatchAttn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, v):
         _need_cuda(h, v)
-        h = h.to(torch.bfloat16).contiguous()
+        h = _low(h)
         v32 = v.detach().float().contiguous()
         q, k, c = h.shape
         pooled = torch.empty((q, c), device=h.device, dtype=torch.float32)
-        _lib.check(_lib.lib().pps_patch_attn_fwd(h.data_ptr(), v32.data_ptr(), q, k, c, pooled.data_ptr(), _stream()), 'pps_patch_attn_fwd')
+        _lib.check(_lib.lib().pps_patch_attn_fwd(h.data_ptr(), v32.data_ptr(), q, k, c, _code(h.dtype), pooled.data_ptr(), _stream()), 'pps_patch_attn_fwd')
         ctx.save_for_backward(h, v32)
         ctx.vdtype = v.dtype
         return pooled
@@ -530,7 +549,7 @@ class _PatchAttn(torch.autograd.Function):
         dpooled = dpooled.float().contiguous()
         dh = torch.empty_like(h)
         part = torch.empty((L.pps_patch_attn_partials(q), c), device=h.device, dtype=torch.float32)
-        _lib.check(L.pps_patch_attn_bwd(h.data_ptr(), v32.data_ptr(), dpooled.data_ptr(), q, k, c, dh.data_ptr(), part.data_ptr(), _stream()),
+        _lib.check(L.pps_patch_attn_bwd(h.data_ptr(), v32.data_ptr(), dpooled.data_ptr(), q, k, c, _code(h.dtype), dh.data_ptr(), part.data_ptr(), _stream()),
                    'pps_patch_attn_bwd')
         return dh, part.sum(0).to(ctx.vdtype)
 
@@ -550,13 +569,13 @@ class _ActMax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, raw, affine, relu, groups, p):
         _need_cuda(raw)
-        raw = raw.to(torch.bfloat16).contiguous()
+        raw = _low(raw)
         c = raw.shape[1]
         dev = raw.device
         mx, mn = torch.empty((groups, c), device=dev), torch.empty((groups, c), device=dev)
         amx, amn = torch.empty((groups, c), device=dev, dtype=torch.int32), torch.empty((groups, c), device=dev, dtype=torch.int32)
-        _lib.check(_lib.lib().pps_rows_extrema_bf16(raw.data_ptr(), groups, p, c, mx.data_ptr(), mn.data_ptr(), amx.data_ptr(), amn.data_ptr(),
-                                                    _stream()), 'pps_rows_extrema_bf16')
+        _lib.check(_lib.lib().pps_rows_extrema_16(raw.data_ptr(), groups, p, c, _code(raw.dtype), mx.data_ptr(), mn.data_ptr(), amx.data_ptr(), amn.data_ptr(),
+                                                  _stream()), 'pps_rows_extrema_16')
         if affine is None:
             ext, arg, out = mx, amx, mx
             scale = None
@@ -570,20 +589,20 @@ class _ActMax(torch.autograd.Function):
             live = out > 0
             out = torch.relu(out)
         ctx.save_for_backward(ext, arg, scale, live)
-        ctx.meta = (groups, p, c, affine is not None)
+        ctx.meta = (groups, p, c, affine is not None, raw.dtype)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         ext, arg, scale, live = ctx.saved_tensors
-        groups, p, c, has_aff = ctx.meta
+        groups, p, c, has_aff, rdt = ctx.meta
         d = dout.float()
         if live is not None:
             d = d * live
         daff = torch.stack([(d * ext).sum(0), d.sum(0)]) if has_aff and ctx.needs_input_grad[1] else None
         dval = d * scale if has_aff else d
-        draw = torch.zeros((groups, p, c), device=dout.device, dtype=torch.bfloat16)
-        draw.scatter_(1, arg.long().unsqueeze(1), dval.to(torch.bfloat16).unsqueeze(1))
+        draw = torch.zeros((groups, p, c), device=dout.device, dtype=rdt)
+        draw.scatter_(1, arg.long().unsqueeze(1), dval.to(rdt).unsqueeze(1))
         return draw.view(groups * p, c), daff, None, None, None
 
 
@@ -615,18 +634,18 @@ class _QueryAttnPool(torch.autograd.Function):
     def forward(ctx, y3, wq, bq, k):
         _need_cuda(y3, wq)
         L = _lib.lib()
-        y3 = y3.to(torch.bfloat16).contiguous()
+        y3 = _low(y3)
         rows, c = y3.shape
         heads = wq.shape[0]
         w32 = wq.detach().float().contiguous()
         b32 = None if bq is None else bq.detach().float().contiguous()
-        qy = torch.empty((rows, heads), device=y3.device, dtype=torch.bfloat16)
+        qy = torch.empty((rows, heads), device=y3.device, dtype=y3.dtype)
         ws = torch.empty((L.pps_rows_layer_ws_bytes(c, heads),), device=y3.device, dtype=torch.uint8)
         ptr = lambda t: None if t is None else t.data_ptr()
-        _lib.check(L.pps_rows_layer_fwd(y3.data_ptr(), rows, c, None, None, 1, w32.data_ptr(), ptr(b32), heads, qy.data_ptr(),
+        _lib.check(L.pps_rows_layer_fwd(y3.data_ptr(), rows, c, _code(y3.dtype), None, None, 1, w32.data_ptr(), ptr(b32), heads, qy.data_ptr(),
                                         None, None, None, None, 0.0, 0.0, None, None, ws.data_ptr(), _stream()), 'pps_rows_layer_fwd')
-        pooled = torch.empty((rows // k, c), device=y3.device, dtype=torch.bfloat16)
-        _lib.check(L.pps_attn_pool_fwd(qy.data_ptr(), y3.data_ptr(), rows // k, k, heads, c, 1, 1, pooled.data_ptr(), _stream()), 'pps_attn_pool_fwd')
+        pooled = torch.empty((rows // k, c), device=y3.device, dtype=y3.dtype)
+        _lib.check(L.pps_attn_pool_fwd(qy.data_ptr(), y3.data_ptr(), rows // k, k, heads, c, _code(y3.dtype), 1, pooled.data_ptr(), _stream()), 'pps_attn_pool_fwd')
         ctx.save_for_backward(y3, w32, qy)
         ctx.meta = (k, bq is not None, wq.dtype, None if bq is None else bq.dtype)
         return pooled
@@ -639,14 +658,14 @@ class _QueryAttnPool(torch.autograd.Function):
         rows, c = y3.shape
         heads = w32.shape[0]
         dev = y3.device
-        dpooled = dpooled.to(torch.bfloat16).contiguous()
+        dpooled = dpooled.to(y3.dtype).contiguous()
         dqy, dy3 = torch.empty_like(qy), torch.empty_like(y3)
-        _lib.check(L.pps_attn_pool_bwd(qy.data_ptr(), y3.data_ptr(), dpooled.data_ptr(), rows // k, k, heads, c, 1, 1, dqy.data_ptr(), dy3.data_ptr(),
+        _lib.check(L.pps_attn_pool_bwd(qy.data_ptr(), y3.data_ptr(), dpooled.data_ptr(), rows // k, k, heads, c, _code(y3.dtype), 1, dqy.data_ptr(), dy3.data_ptr(),
                                        _stream()), 'pps_attn_pool_bwd')
         dw = torch.empty((heads, c), device=dev, dtype=torch.float32)
         db = torch.empty((heads,), device=dev, dtype=torch.float32) if has_b else None
         ws = torch.empty((L.pps_rows_layer_ws_bytes(c, heads),), device=dev, dtype=torch.uint8)
-        _lib.check(L.pps_rows_layer_bwd(y3.data_ptr(), qy.data_ptr(), dqy.data_ptr(), rows, c, heads, None, None, 1,
+        _lib.check(L.pps_rows_layer_bwd(y3.data_ptr(), qy.data_ptr(), dqy.data_ptr(), rows, c, heads, _code(y3.dtype), None, None, 1,
                                         w32.data_ptr(), None, None, None, dy3.data_ptr(), dy3.data_ptr(), None, dw.data_ptr(),
                                         None if db is None else db.data_ptr(), None, None, ws.data_ptr(), _stream()), 'pps_rows_layer_bwd')
         return dy3, dw.to(wdt), None if db is None else db.to(bdt), None

@@ -10,8 +10,11 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def _bf(t):
-    return t.to(torch.bfloat16).float()
+DT16 = [torch.bfloat16, torch.float16]
+
+
+def _bf(t, dt=torch.bfloat16):
+    return t.to(dt).float()
 
 
 class _RoundGrad(torch.autograd.Function):
@@ -20,29 +23,30 @@ class _RoundGrad(torch.autograd.Function):
     bf16 values and rounding again is NOT unbiased within a binade, so an unrounded twin differs systematically in the sums over rows."""
 
     @staticmethod
-    def forward(ctx, t):
+    def forward(ctx, t, dt):
+        ctx.dt = dt
         return t.clone()
 
     @staticmethod
     def backward(ctx, g):
-        return g.float().to(torch.bfloat16).to(g.dtype)
+        return g.float().to(ctx.dt).to(g.dtype), None
 
 
-def _twin(x, aff, relu, w, b, gamma, beta, eps):
+def _twin(x, aff, relu, w, b, gamma, beta, eps, dt=torch.bfloat16):
     """float64 twin on the bf16-rounded operands.  Returns y (unrounded), out_affine or None."""
     a = x.double()
     if aff is not None:
         a = a * aff[0].double() + aff[1].double()
         if relu:
             a = torch.relu(a)
-    a = a.float().to(torch.bfloat16).double() if aff is not None else a        # the MFMA operand is bf16
-    y = a @ w.to(torch.bfloat16).double().t()
+    a = a.float().to(dt).double() if aff is not None else a                    # the MFMA operand is 16-bit
+    y = a @ w.to(dt).double().t()
     if b is not None:
         y = y + b.double()
-    y = _RoundGrad.apply(y)
+    y = _RoundGrad.apply(y, dt)
     if gamma is None:
         return y, None
-    yr = y.float().to(torch.bfloat16).double()                                # statistics are those of the stored y
+    yr = y.float().to(dt).double()                                            # statistics are those of the stored y
     yr = y + (yr - y).detach()
     m = yr.shape[0]
     mean = yr.sum(0) / m
@@ -56,18 +60,19 @@ CASES = [(5000, 64, 64, True, True, True), (3001, 64, 128, True, True, True), (4
          (40000, 128, 128, True, True, True), (33, 256, 128, True, True, True)]
 
 
+@pytest.mark.parametrize('dt', DT16)
 @pytest.mark.parametrize('rows,cin,cout,affine,bn,bias', CASES)
-def test_rows_layer_matches_the_torch_twin(rows, cin, cout, affine, bn, bias):
+def test_rows_layer_matches_the_torch_twin(rows, cin, cout, affine, bn, bias, dt):
     from ppsurf_amd import train_ops
     g = torch.Generator().manual_seed(rows + cin + cout)
     rnd = lambda *s: torch.randn(*s, generator=g)
-    x = _bf(rnd(rows, cin) * 1.5 + 0.3).to(DEV)
+    x = _bf(rnd(rows, cin) * 1.5 + 0.3, dt).to(DEV)
     w = (rnd(cout, cin) / cin ** 0.5).to(DEV)
     b = (rnd(cout) * 0.2).to(DEV) if bias else None
     aff = torch.stack([rnd(cin) * 0.3 + 1.0, rnd(cin) * 0.4]).to(DEV) if affine else None
     gamma = (rnd(cout) * 0.2 + 1.0).to(DEV) if bn else None
     beta = (rnd(cout) * 0.3).to(DEV) if bn else None
-    gy = _bf(rnd(rows, cout)).to(DEV)
+    gy = _bf(rnd(rows, cout), dt).to(DEV)
     ga = rnd(2, cout).to(DEV) * rows ** 0.5 if bn else None
     eps, mom = 1e-5, 0.1
 
@@ -81,7 +86,7 @@ def test_rows_layer_matches_the_torch_twin(rows, cin, cout, affine, bn, bias):
         hold.momentum, hold.eps = mom, eps
 
     # ---- ours
-    xo = x.to(torch.bfloat16).requires_grad_(True)
+    xo = x.to(dt).requires_grad_(True)
     wo = w.clone().requires_grad_(True)
     bo = b.clone().requires_grad_(True) if bias else None
     ao = aff.clone().requires_grad_(True) if affine else None
@@ -100,8 +105,8 @@ def test_rows_layer_matches_the_torch_twin(rows, cin, cout, affine, bn, bias):
     gt = gamma.clone().requires_grad_(True) if bn else None
     bet = beta.clone().requires_grad_(True) if bn else None
     # straight-through bf16 rounding of the weights (the twin differentiates wrt the fp32 master weights like the kernel does)
-    wq = wt + (wt.to(torch.bfloat16).float() - wt).detach()
-    y, oa = _twin(xt, at, affine, wq, bt, gt, bet, eps)
+    wq = wt + (wt.to(dt).float() - wt).detach()
+    y, oa = _twin(xt, at, affine, wq, bt, gt, bet, eps, dt)
     lt = (y * gy.double()).sum()
     if bn:
         lt = lt + (oa * ga.double()).sum()
@@ -116,7 +121,7 @@ def test_rows_layer_matches_the_torch_twin(rows, cin, cout, affine, bn, bias):
     close(out.raw, y.detach(), 6e-3, 'y')                               # bf16 storage of y: 2^-8
     if bn:
         close(out.affine, oa.detach(), 2e-4, 'out_affine')
-        yr = y.detach().float().to(torch.bfloat16).double()
+        yr = y.detach().float().to(dt).double()
         mean = yr.mean(0)
         var_unb = yr.var(0, unbiased=True)
         close(hold.running_mean, (mom * mean), 2e-4, 'running_mean')
@@ -151,7 +156,8 @@ def test_rows_layer_is_deterministic():
         assert torch.equal(a, b)
 
 
-def test_pointnet_with_fused_row_layers_is_as_close_to_fp32_as_the_separate_ops():
+@pytest.mark.parametrize('dt', DT16)
+def test_pointnet_with_fused_row_layers_is_as_close_to_fp32_as_the_separate_ops(dt):
     """train_graph.pointnet under bf16 autocast, fused row layers vs the separate ops (library GEMMs + fused BatchNorm op), both measured
     against the fp32 run of the same graph: the max-pool of the STN makes bf16 gradients differ by whole arg-max switches, so the two
     bf16 paths are not compared with each other but by their distance to fp32."""
@@ -160,7 +166,10 @@ def test_pointnet_with_fused_row_layers_is_as_close_to_fp32_as_the_separate_ops(
     from ppsurf_amd import modules, synthetic, train_graph
     with contextlib.redirect_stdout(io.StringIO()):
         net = modules.PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=50, pointnet_latent_size=256)
-    net.load_state_dict(synthetic.network_state_dict('ppsurf', num_pts_local=50))
+    if dt == torch.bfloat16:
+        net.load_state_dict(synthetic.network_state_dict('ppsurf', num_pts_local=50))
+    # (fp16: the constructor's default initialisation -- the formula-filled weights drive the raw conv outputs past 65504, the separate-op
+    # path then returns NaN and nothing can be compared)
     pn = net.point_net.to(DEV).train()
     state = {k: v.clone() for k, v in pn.state_dict().items()}
     g = torch.Generator().manual_seed(3)
@@ -172,7 +181,7 @@ def test_pointnet_with_fused_row_layers_is_as_close_to_fp32_as_the_separate_ops(
         pn.zero_grad(set_to_none=True)
         train_graph.FUSED_ROWS = mode == 'fused'
         try:
-            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=mode != 'fp32'):
+            with torch.autocast('cuda', dtype=dt, enabled=mode != 'fp32'):
                 feat, trans2 = train_graph.pointnet(pn, patches)
             (feat.float() * gout).sum().backward()
         finally:
@@ -202,11 +211,12 @@ def test_pointnet_with_fused_row_layers_is_as_close_to_fp32_as_the_separate_ops(
         assert dist(res['fused'][3][k], v32) <= 2.5 * dist(res['separate'][3][k], v32) + 2e-3 * float(v32.abs().max()) + 1e-5, k
 
 
+@pytest.mark.parametrize('dt', DT16)
 @pytest.mark.parametrize('q,k', [(37, 50), (5, 64), (300, 1), (2049, 20)])
-def test_patch_attention_pooling_matches_torch(q, k):
+def test_patch_attention_pooling_matches_torch(q, k, dt):
     from ppsurf_amd import train_ops
     g = torch.Generator().manual_seed(q * 100 + k)
-    h = (torch.randn(q, k, 256, generator=g)).to(DEV).to(torch.bfloat16)
+    h = (torch.randn(q, k, 256, generator=g)).to(DEV).to(dt)
     v = (torch.randn(256, generator=g) * 0.2).to(DEV)
     gp = torch.randn(q, 256, generator=g).to(DEV)
     ho, vo = h.clone().requires_grad_(True), v.clone().requires_grad_(True)
@@ -221,10 +231,11 @@ def test_patch_attention_pooling_matches_torch(q, k):
     assert torch.allclose(vo.grad.double(), vt.grad, rtol=2e-4, atol=2e-4 * float(vt.grad.abs().max()))
 
 
-def test_act_max_matches_the_materialised_maximum():
+@pytest.mark.parametrize('dt', DT16)
+def test_act_max_matches_the_materialised_maximum(dt):
     from ppsurf_amd import train_ops
     g = torch.Generator().manual_seed(11)
-    raw = torch.randn(90 * 50, 256, generator=g).to(DEV).to(torch.bfloat16)
+    raw = torch.randn(90 * 50, 256, generator=g).to(DEV).to(dt)
     aff = torch.stack([torch.randn(256, generator=g), torch.randn(256, generator=g)]).to(DEV)      # negative scales included
     go = torch.randn(90, 256, generator=g).to(DEV)
     ro, ao = raw.clone().requires_grad_(True), aff.clone().requires_grad_(True)
@@ -239,7 +250,8 @@ def test_act_max_matches_the_materialised_maximum():
     assert torch.allclose(ro.grad.float().view(90, 50, 256).sum(1), rt.grad.view(90, 50, 256).sum(1), rtol=1e-2, atol=1e-2)
 
 
-def test_interpolation_head_with_fused_row_layers_is_as_close_to_fp32_as_the_separate_ops():
+@pytest.mark.parametrize('dt', DT16)
+def test_interpolation_head_with_fused_row_layers_is_as_close_to_fp32_as_the_separate_ops(dt):
     import contextlib
     import io
     from ppsurf_amd import modules, synthetic, train_graph
@@ -260,7 +272,7 @@ def test_interpolation_head_with_fused_row_layers_is_as_close_to_fp32_as_the_sep
         lat = lat0.clone().requires_grad_(True)
         train_graph.FUSED_ROWS = mode == 'fused'
         try:
-            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=mode != 'fp32'):
+            with torch.autocast('cuda', dtype=dt, enabled=mode != 'fp32'):
                 out = train_graph.interp_attention(proj, lat, pts, query, ids, last_layer=True)
             (out.float() * gout).sum().backward()
         finally:
@@ -282,25 +294,28 @@ def test_interpolation_head_with_fused_row_layers_is_as_close_to_fp32_as_the_sep
     assert not worse, worse
 
 
-def test_rows3_layer_matches_torch():
+@pytest.mark.parametrize('dt', DT16)
+def test_rows3_layer_matches_torch(dt):
     from ppsurf_amd import train_ops
     g = torch.Generator().manual_seed(21)
     rows = 7013
     x = (torch.randn(rows, 3, generator=g) * 0.5).to(DEV)
     w, b = (torch.randn(64, 3, generator=g)).to(DEV), (torch.randn(64, generator=g) * 0.1).to(DEV)
-    gy = _bf(torch.randn(rows, 64, generator=g)).to(DEV)
+    gy = _bf(torch.randn(rows, 64, generator=g), dt).to(DEV)
     ga = (torch.randn(2, 64, generator=g) * 30).to(DEV)
 
     class H:
         weight, bias = (torch.rand(64, generator=g) + 0.5).to(DEV).requires_grad_(True), torch.randn(64, generator=g).to(DEV).requires_grad_(True)
         running_mean, running_var, momentum, eps = torch.zeros(64, device=DEV), torch.ones(64, device=DEV), 0.1, 1e-5
     wo, bo = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
-    out = train_ops.rows3_layer(x, wo, bo, H, True)
+    with torch.autocast('cuda', dtype=dt):
+        out = train_ops.rows3_layer(x, wo, bo, H, True)
+    assert out.raw.dtype == dt
     ((out.raw.float() * gy).sum() + (out.affine * ga).sum()).backward()
     wt, bt = w.double().requires_grad_(True), b.double().requires_grad_(True)
     gt, bet = H.weight.detach().double().requires_grad_(True), H.bias.detach().double().requires_grad_(True)
     y = x.double() @ wt.t() + bt
-    yr = y + (y.float().to(torch.bfloat16).double() - y).detach()
+    yr = y + (y.float().to(dt).double() - y).detach()
     mean = yr.mean(0)
     var = (yr * yr).mean(0) - mean * mean
     sc = gt / torch.sqrt(var + 1e-5)
@@ -314,24 +329,25 @@ def test_rows3_layer_matches_torch():
     assert rel(H.running_mean, 0.1 * mean.detach()) <= 2e-4
 
 
+@pytest.mark.parametrize('dt', DT16)
 @pytest.mark.parametrize('nq,p,affine', [(37, 50, True), (5, 64, False), (130, 17, True)])
-def test_patch_transform_matches_torch(nq, p, affine):
+def test_patch_transform_matches_torch(nq, p, affine, dt):
     from ppsurf_amd import train_ops
     g = torch.Generator().manual_seed(nq + p)
-    x = _bf(torch.randn(nq * p, 64, generator=g)).to(DEV)
-    t = _bf(torch.randn(nq, 64, 64, generator=g) * 0.3).to(DEV)
+    x = _bf(torch.randn(nq * p, 64, generator=g), dt).to(DEV)
+    t = _bf(torch.randn(nq, 64, 64, generator=g) * 0.3, dt).to(DEV)
     aff = torch.stack([torch.randn(64, generator=g) * 0.3 + 1, torch.randn(64, generator=g) * 0.3]).to(DEV) if affine else None
-    go = _bf(torch.randn(nq * p, 64, generator=g)).to(DEV)
-    xo, to_ = x.to(torch.bfloat16).requires_grad_(True), t.to(torch.bfloat16).requires_grad_(True)
+    go = _bf(torch.randn(nq * p, 64, generator=g), dt).to(DEV)
+    xo, to_ = x.to(dt).requires_grad_(True), t.to(dt).requires_grad_(True)
     ao = aff.clone().requires_grad_(True) if affine else None
     out = train_ops.patch_transform(train_ops.Act(xo, ao, affine), to_, p)
     (out.float() * go).sum().backward()
     xt, tt = x.double().requires_grad_(True), t.double().requires_grad_(True)
     at = aff.double().requires_grad_(True) if affine else None
     a = torch.relu(xt * at[0] + at[1]) if affine else xt
-    a = a + (a.float().to(torch.bfloat16).double() - a).detach()                         # the operand is bf16
+    a = a + (a.float().to(dt).double() - a).detach()                                     # the operand is 16-bit
     tm = tt + torch.eye(64, device=DEV, dtype=torch.float64)
-    tm = tm + (tm.float().to(torch.bfloat16).double() - tm).detach()
+    tm = tm + (tm.float().to(dt).double() - tm).detach()
     ref = torch.bmm(a.view(nq, p, 64), tm.transpose(1, 2)).reshape(nq * p, 64)
     (ref * go.double()).sum().backward()
     rel = lambda u, v: float((u.detach().double() - v.detach()).abs().max()) / (float(v.detach().abs().max()) + 1e-12)
