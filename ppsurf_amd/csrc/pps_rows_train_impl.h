@@ -953,7 +953,7 @@ __global__ __launch_bounds__(256, 2) void patch_transform_bwd_kernel(const PtArg
 // Input of the interpolation head (source/poco_model.py:400-404 with fc1 split into its latent and its offset part):
 //     h1[(q, j), :] = table[ids[q, j], :] + Wx (query[q] - pts[ids[q, j]])          table [N, C] bf16, h1 [Q*k, C] bf16, Wx [C, 3]
 // one 16-byte chunk (8 channels) per thread, written once (gather, offset, 3 -> C layer and the sum were four passes over [Q*k, C]).
-// Backward: d table through the segmented sum of the gather (pps_segment_sum_rows_bf16), d Wx[c][d] = sum_rows dh1[row][c] * rel[row][d] here.
+// Backward: d table through the segmented sum of the gather (pps_segment_sum_rows_16), d Wx[c][d] = sum_rows dh1[row][c] * rel[row][d] here.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void head_input_fwd_kernel(const uint16_t* __restrict__ table, const int64_t* __restrict__ ids,
                                                             const float* __restrict__ pts, const float* __restrict__ query, int64_t rows, int k, int c,
