@@ -8,7 +8,8 @@
   * BatchNorm / norm_radius buffers follow DDP semantics (`broadcast_buffers=True`): rank 0's values are broadcast, coalesced
     into one message, at the start of every step; between two steps they are rank-local;
   * Adam / AdamW run fused (one launch per dtype group; same update rule);
-  * single GPU (`PPS_FIT_GRAPH=0` switches it off): after three eager steps the WHOLE optimisation step (forward, loss, backward,
+  * (`PPS_FIT_GRAPH=0` switches it off; with several ranks only forward + backward are captured, the collectives and the optimizer run
+    eagerly behind the replay) after three eager steps the WHOLE optimisation step (forward, loss, backward,
     gradient-buffer handling, fused capturable AdamW, loss scaling) is captured into one HIP graph per batch signature and replayed
     (`GraphedStep`); the batch is copied into static buffers; the id tables, their flat forms and CSRs are inputs built by the loader
     (train_graph.table_extras), so the graph holds no sort (replays with the CSR radix sort inside faulted intermittently at the full
@@ -55,8 +56,9 @@ class GraphedStep:
     (it is: metrics are device tensors, id tables are inputs, the optimizer is fused + capturable)."""
     WARMUP = 3
 
-    def __init__(self, eager, metrics, enabled=True, max_graphs=2):
+    def __init__(self, eager, metrics, enabled=True, max_graphs=2, after_capture=None, after_replay=None):
         self.eager, self.metrics, self.enabled, self.max_graphs = eager, metrics, enabled, max_graphs
+        self.after_capture, self.after_replay = after_capture, after_replay      # host-side state a replay cannot reproduce (hooks that fired)
         self.seen, self.graphs, self.failed, self._done = {}, {}, False, None
         self.replayed = False
 
@@ -93,7 +95,7 @@ class GraphedStep:
                     if entry is not None:
                         self.graphs[sig] = entry
             if entry is not None:
-                static, graph, logged = entry
+                static, graph, logged, state = entry
                 # The static inputs may only be overwritten once the previous replay has finished READING them.  Stream order should
                 # guarantee that, but with the host several steps ahead the copies were observed to race the tail of the previous
                 # replay (id tables changing under the CSR sort -> out-of-bounds scatter inside rocprim's onesweep kernel,
@@ -110,6 +112,8 @@ class GraphedStep:
                 self._done.record()
                 # the logged tensors are outputs of the graph and are overwritten by the next replay: hand out copies
                 self.metrics.values = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in logged.items()}
+                if self.after_replay is not None:
+                    self.after_replay(state)
                 return
         self.eager(batch, bi)
 
@@ -130,7 +134,7 @@ class GraphedStep:
             print('fit: HIP-graph capture of the step failed ({}: {}); continuing eagerly'.format(type(exc).__name__, str(exc).split('\n')[0]))
             torch.cuda.synchronize()
             return None
-        return static, graph, logged
+        return static, graph, logged, (self.after_capture() if self.after_capture is not None else None)
 
 
 def autocast_context(precision, device_type='cuda'):
@@ -182,7 +186,9 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
     if not cfg.get('optimizer'):
         raise ValueError('fit needs an `optimizer:` section (class_path / init_args), as in configs/poco.yaml:60-69')
     on_gpu = torch.device(device).type == 'cuda'
-    use_graph = world == 1 and on_gpu and os.environ.get('PPS_FIT_GRAPH', '1') != '0'
+    graph_on = on_gpu and os.environ.get('PPS_FIT_GRAPH', '1') != '0'
+    use_graph = graph_on and world == 1                        # the whole step (optimizer included) as one graph
+    split_graph = graph_on and world > 1                       # forward + backward as a graph; collectives and optimizer eager behind it
     ospec = cfg['optimizer']
     if on_gpu and ospec.get('class_path', '').rsplit('.', 1)[-1] in ('AdamW', 'Adam') and 'fused' not in ospec.get('init_args', {}):
         # the fused implementation (one launch per dtype group instead of ~10 small foreach launches over 298 parameter tensors: 57.6 ->
@@ -209,7 +215,7 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
         import torch.distributed as dist
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src=0)
-    buckets = sharding.GradBuckets(params)
+    buckets = sharding.GradBuckets(params, defer=split_graph)
     out_dir = os.path.join('models', str(getattr(model, 'name', 'model')), 'version_0')
     ckpt_file = os.path.join(out_dir, 'checkpoints', 'last.ckpt')
     metrics = _MetricLog()
@@ -233,19 +239,43 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
             mfile.write(json.dumps(rec) + '\n')
 
     def eager_step(batch, bi):
+        sharding.broadcast_buffers(model)
+        compute_step(batch, bi)
+        apply_step()
+
+    def compute_step(batch, bi):                               # no collective, no optimizer: what the multi-rank run replays as a graph
         buckets.zero()
         metrics.values = {}
-        sharding.broadcast_buffers(model)
         with ctx:
             loss = model.training_step(batch, bi)
         scaler.scale(loss).backward()
         model.on_after_backward()
+
+    def apply_step():
         buckets.finish()
         scaler.step(optimizer)
         scaler.update()
         train_graph.release_step_caches()
 
-    stepper = GraphedStep(eager_step, metrics, enabled=use_graph)
+    if split_graph:
+        # several ranks: the gradient all-reduces (and the buffer broadcast) stay ordinary eager collectives AROUND a replayed forward +
+        # backward; they lose their overlap with the backward pass (~1 ms for 55 MB over xGMI) and the rank its ~25 ms of Python per step
+        core = GraphedStep(compute_step, metrics, enabled=True, after_capture=lambda: set(buckets.touched), after_replay=buckets.replayed)
+
+        class _Split:
+            graphs, failed = core.graphs, False
+
+            @staticmethod
+            def run(batch, bi):
+                sharding.broadcast_buffers(model)
+                core.run(batch, bi)
+                _Split.failed = core.failed
+                apply_step()
+
+            touch = staticmethod(core.touch)
+        stepper = _Split
+    else:
+        stepper = GraphedStep(eager_step, metrics, enabled=use_graph)
     for epoch in range(start_epoch, max_epochs):
         host_lr = float(optimizer.param_groups[0]['lr'])        # once per epoch (the scheduler steps per epoch): no per-step read of a device value
         model.train()
@@ -289,6 +319,6 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
     if mfile is not None:
         mfile.close()
     model.__dict__.pop('_fit_log', None)
-    if use_graph and rank == 0:
+    if (use_graph or split_graph) and rank == 0:
         print('fit: HIP-graph replay of the step: {} graph(s) captured{}'.format(len(stepper.graphs), ', capture FAILED (ran eagerly)' if stepper.failed else ''))
     return history

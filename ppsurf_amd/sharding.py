@@ -166,9 +166,10 @@ class GradBuckets:
     messages: a ring all-reduce over xGMI is per-link bound (~153 GB/s), so 55 MB of fp32 gradients cost ~1 ms as 3 buckets
     and far more as 455 per-tensor collectives."""
 
-    def __init__(self, params, n_buckets=3):
+    def __init__(self, params, n_buckets=3, defer=False):
         import torch.distributed as dist
         self.dist = dist
+        self.defer = bool(defer)                    # True: no collective inside backward (fit with the forward / backward replayed as a HIP graph)
         self.params = [p for p in params if p.requires_grad]
         rev = list(reversed(self.params))                                     # roughly the order of gradient production
         total = sum(p.numel() for p in rev)
@@ -216,8 +217,15 @@ class GradBuckets:
             torch._foreach_copy_([v for v, _ in pairs], [p.grad for _, p in pairs])
             for v, p in pairs:
                 p.grad = v
-        if ws > 1:
+        if ws > 1 and not self.defer:
             self.handles.append(self.dist.all_reduce(self.flat[bi], op=self.dist.ReduceOp.SUM, async_op=True))
+
+    def replayed(self, touched):
+        """The forward / backward of this step ran as a replayed HIP graph: none of the Python hooks fired.  `touched` = ids of the
+        parameters that received a gradient when the graph was captured (their p.grad already are the bucket views)."""
+        self.touched = set(touched)
+        self.launched = [True] * len(self.buckets)
+        self.handles = []
 
     def zero(self):
         """Replaces optimizer.zero_grad(): flat buffers cleared (slots of parameters without a gradient stay zero), every p.grad None."""
@@ -232,6 +240,8 @@ class GradBuckets:
         for bi in range(len(self.buckets)):
             if not self.launched[bi]:
                 self._launch(bi)
+        if ws > 1 and self.defer:                   # collectives kept out of a captured forward / backward: all buckets now
+            self.handles = [self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, async_op=True) for flat in self.flat]
         for h in self.handles:
             h.wait()
         if ws > 1:
