@@ -235,6 +235,8 @@ class DevicePrefetch:
 
     def __init__(self, device):
         self.device = torch.device(device)
+        if self.device.index is None:               # resolved HERE, on the constructing (training) thread: a loader thread starts on device 0
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.side = torch.cuda.Stream(self.device)
         self.pending = None                      # (batch, event)
 
@@ -243,7 +245,8 @@ class DevicePrefetch:
         after_main: the side stream first waits for what the main stream has queued (inputs made there)."""
         if after_main:
             self.side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(self.side):
+        # a new thread starts on device 0: the HIP launches of the C ABI go to the CURRENT device, so it is set for this scope (rank r > 0)
+        with torch.cuda.device(self.device), torch.cuda.stream(self.side):
             batch = make()
             ev = torch.cuda.Event()
             ev.record(self.side)
