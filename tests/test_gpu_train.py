@@ -386,3 +386,30 @@ def test_step_uses_the_tables_built_with_the_batch(monkeypatch):
     assert set(with_tables) == set(without)
     for k in without:
         assert torch.equal(with_tables[k], without[k]), k
+
+
+def test_device_prefetch_hands_over_finished_batches():
+    """data.DevicePrefetch: the next batch is built on a side stream (here: from a loader thread, like DeviceBatchLoader does) while the
+    consumer works on the main stream; what the consumer reads must be the finished tensors, batch after batch."""
+    import concurrent.futures
+    from ppsurf_amd import data
+    pf = data.DevicePrefetch(DEV)
+
+    def make(i):
+        a = torch.full((4096, 4096), float(i), device=DEV)
+        for _ in range(20):                                   # long enough to still be running when the consumer gets the handle
+            a = a @ torch.eye(4096, device=DEV)
+        return {'x': a, 'nested': [a[:1] + 1.0], 'name': 'b{}'.format(i)}
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:
+        futs = {0: pool.submit(lambda: pf.launch(lambda: make(0), after_main=False))}
+        seen = []
+        for i in range(6):
+            batch, ev = futs.pop(i).result()
+            if i + 1 < 6:
+                futs[i + 1] = pool.submit(lambda j=i + 1: pf.launch(lambda: make(j), after_main=False))
+            batch = pf.hand_over(batch, ev)
+            busy = torch.randn(2048, 2048, device=DEV) @ torch.randn(2048, 2048, device=DEV)      # consumer work on the main stream
+            seen.append((float(batch['x'].mean()), float(batch['nested'][0].mean()), batch['name']))
+            del batch, busy
+    assert seen == [(float(i), float(i) + 1.0, 'b{}'.format(i)) for i in range(6)]
