@@ -115,11 +115,11 @@ __global__ __launch_bounds__(FT_NT) void fka_radius_kernel(const float* __restri
 
 __global__ __launch_bounds__(64) void fka_fin_radius_kernel(const double* __restrict__ part, int n, double count, float momentum,
                                                             float* __restrict__ geo_w) {
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += part[i];
-        geo_w[GEO_RADIUS] = geo_w[GEO_RADIUS] * (1.f - momentum) + (float)(s / count) * momentum;
-    }
+    double s = 0.0;                                    // lanes stride over the block partials, fixed butterfly: deterministic
+    for (int i = threadIdx.x; i < n; i += 64) s += part[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) geo_w[GEO_RADIUS] = geo_w[GEO_RADIUS] * (1.f - momentum) + (float)(s / count) * momentum;
 }
 
 // ---- one support point per wave -----------------------------------------------------------------------------------------
