@@ -23,7 +23,7 @@ for rows, cin, cout, bn in [(1000000, 64, 64, True), (1000000, 128, 256, True), 
     st = torch.cuda.current_stream().cuda_stream
 
     def run():
-        rc = L.pps_rows_layer_bwd(x.data_ptr(), y.data_ptr(), gy.data_ptr(), rows, cin, cout, aff.data_ptr(), aff.data_ptr() + 4 * cin, 1, w.data_ptr(),
+        rc = L.pps_rows_layer_bwd(x.data_ptr(), y.data_ptr(), gy.data_ptr(), rows, cin, cout, 1, aff.data_ptr(), aff.data_ptr() + 4 * cin, 1, w.data_ptr(),
                                   gamma.data_ptr() if bn else None, save.data_ptr() if bn else None, daff.data_ptr() if bn else None, None, None, None,
                                   dw.data_ptr(), db.data_ptr(), dg.data_ptr() if bn else None, dbt.data_ptr() if bn else None, ws.data_ptr(), st)
         assert rc == 0
