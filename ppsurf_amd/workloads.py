@@ -132,8 +132,8 @@ def reconstruct_steered(model, n_points=100_000, seed=42, device='cuda:0'):
 
 class FitStep:
     """BASELINE config 3 on one GPU: B shapes x 10 000 points, 2000 queries per shape, P = 50; id tables and patches are built
-    on the device inside the step (what the reference's dataset workers do on the CPU), then forward, loss, backward, AdamW --
-    the step body of ppsurf_amd.fit (fused AdamW; graph=True additionally replays it as a HIP graph like PPS_FIT_GRAPH=1)."""
+    by a loader thread on a second stream (what the reference's dataset workers do on the CPU; overlap_prep=False: inline), then forward,
+    loss, backward, AdamW -- the step body of ppsurf_amd.fit (fused AdamW; graph=True replays it as a HIP graph like fit does by default)."""
 
     def __init__(self, batch=10, n=10000, q=2000, p=50, precision='bf16-mixed', device='cuda:0', n_batches=2, graph=False, overlap_prep=True):
         from . import modules, fit, sharding
@@ -154,7 +154,11 @@ class FitStep:
 
         self.stepper = fit.GraphedStep(self._body, _Log(), enabled=graph)
         from . import data
-        self.prefetch = data.DevicePrefetch(self.dev) if (overlap_prep and not graph) else None
+        self.prefetch = data.DevicePrefetch(self.dev) if overlap_prep else None
+        self.fut = None
+        if self.prefetch is not None:
+            import concurrent.futures
+            self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
 
     def _raw_batch(self, b, n, q, seed):
         rng = np.random.default_rng(seed)
@@ -189,11 +193,24 @@ class FitStep:
             batch.update(train_graph.table_extras(batch))       # like data.TrainDataset.collate_on_device
         return batch
 
+    def _build(self, i):
+        return self.prefetch.launch(lambda: self._prepare(i), after_main=False)
+
     def __call__(self):
         if self.prefetch is None:
             batch = self._prepare(self.i)
-        else:
-            batch = self.prefetch.take(lambda: self._prepare(self.i), lambda: self._prepare(self.i + 1))
+        else:                                         # like data.DeviceBatchLoader: a loader thread builds the next batch on the side stream
+            if self.fut is None:
+                self.fut = self.pool.submit(self._build, self.i)
+            batch, ev = self.fut.result()
+            self.fut = self.pool.submit(self._build, self.i + 1)
+            batch = self.prefetch.hand_over(batch, ev)
         self.i += 1
         self.stepper.run(batch, self.i)
         return self.stepper.metrics.values['loss']
+
+    def close(self):
+        if self.prefetch is not None:
+            if self.fut is not None:
+                self.fut.result()
+            self.pool.shutdown(wait=True)

@@ -27,7 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=10)
     a = ap.parse_args()
-    step = workloads.FitStep()
+    step = workloads.FitStep(overlap_prep=False)          # one thread, one stream: attributable timings
     full = timed(step, a.steps)
     real_pn, real_ia = train_graph.pointnet, train_graph.interp_attention
 

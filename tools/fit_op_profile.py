@@ -18,7 +18,7 @@ def main():
     ap.add_argument('--encoder-only', action='store_true', help='PointNet and interpolation head replaced by zeros (tools/fit_module_breakdown.py): encoder + MLP + data preparation + AdamW')
     ap.add_argument('--kernels', action='store_true', help='list device kernels instead of framework ops')
     a = ap.parse_args()
-    step = workloads.FitStep()
+    step = workloads.FitStep(overlap_prep=False)          # one thread, one stream: attributable timings
     if a.encoder_only:
         from ppsurf_amd import train_graph
         train_graph.pointnet = lambda pn, patches, need_trans=True: (torch.zeros((patches.shape[0], 256), device=patches.device), None)
