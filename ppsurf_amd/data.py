@@ -320,6 +320,20 @@ class DeviceBatchLoader:
             # the loader thread also issues the device side of its batch (patches, support levels, id tables, their CSR) -- on a second stream,
             # so that it runs beside the optimisation step of the previous batch and its ~10 ms of host work are off the training thread.  The
             # thread stays two batches ahead; uploads and searches depend on nothing the main stream produces (after_main=False).
+            if not getattr(self, 'thread_collate', True):
+                # eager step (PPS_FIT_GRAPH=0): the training thread needs the interpreter for its ~1400 launches per step, a second thread issuing
+                # the batch assembly starves it (36 instead of 27 ms per step) -- the assembly is then issued by the training thread itself,
+                # still on the side stream and one batch ahead; the loader thread only reads files
+                futs = {0: nxt}
+                if len(starts) > 1:
+                    futs[1] = pool.submit(load, starts[1])
+                for k, s in enumerate(starts):
+                    if k + 2 < len(starts):
+                        futs[k + 2] = pool.submit(load, starts[k + 2])
+                    cur, nxt_f = futs.pop(k), futs.get(k + 1)
+                    yield prefetch.take(lambda: self.dataset.collate_on_device(cur.result(), self.device),
+                                        (lambda f=nxt_f: self.dataset.collate_on_device(f.result(), self.device)) if nxt_f is not None else None)
+                return
             nxt.cancel()
             build = lambda s: prefetch.launch(lambda: self.dataset.collate_on_device(load(s), self.device), after_main=False)
             futs = {k: pool.submit(build, starts[k]) for k in range(min(2, len(starts)))}

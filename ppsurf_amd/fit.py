@@ -221,6 +221,7 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
     metrics = _MetricLog()
     model.__dict__['_fit_log'] = metrics
     train_loader, val_loader = data.train_dataloader(), data.val_dataloader()
+    train_loader.thread_collate = use_graph or split_graph      # see data.DeviceBatchLoader.__iter__
     mfile = None
     if rank == 0:
         os.makedirs(out_dir, exist_ok=True)
