@@ -243,11 +243,18 @@ class ChunkPipeline:
     def _spatial(self, q, b):
         m = q.shape[0]
         idx = self.idx[b][:m]
-        self.blocks.query(q, self.k, out=idx)
-        src = idx
-        if self.pidx is not None:
+        if self.pidx is not None and self.same_cloud and self.p > self.k:
+            # one search serves both tables: the neighbours come back in ascending (distance, index) order, so the k nearest are the first k
+            # columns of the P nearest (config 5: P = 200, k = 64; tests/test_gpu_knn.py checks the prefix property on tie-heavy clouds)
             src = self.pidx[b][:m]
             self.raw_blocks.query(q, self.p, out=src)
+            idx.copy_(src[:, :self.k])
+        else:
+            self.blocks.query(q, self.k, out=idx)
+            src = idx
+            if self.pidx is not None:
+                src = self.pidx[b][:m]
+                self.raw_blocks.query(q, self.p, out=src)
         self.ops.patch_normalize(self.raw, q, src, self.p, out=self.patches[b][:m])
 
     def run(self, chunks, want_occ=True, stage_events=None):

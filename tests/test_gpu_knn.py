@@ -137,6 +137,21 @@ def test_blocked_knn_large_k_vs_oracle(n, m, k):
     assert np.array_equal(d2.cpu().numpy(), ref_d2)
 
 
+def test_the_k_nearest_are_a_prefix_of_the_p_nearest_also_under_ties():
+    """decoder.ChunkPipeline makes ONE search with k = P when the patches (P = 100 / 200) and the projection table (k = 64) come from the
+    same cloud, and takes the first 64 columns: the (distance, index) order must make that the table of the separate k = 64 search."""
+    rng = np.random.default_rng(3)
+    lattice = (rng.integers(0, 7, (6000, 3)) / 8.0).astype(np.float32)      # many exact ties and duplicates
+    cloud = np.concatenate([make_cloud(20000, seed=5), lattice]).astype(np.float32)
+    qry = np.concatenate([make_band_queries(cloud[:20000], 1500, resolution=129, seed=2), lattice[:300]]).astype(np.float32)
+    blocks = ops.KnnBlocks(torch.from_numpy(cloud).to(DEV))
+    dq = torch.from_numpy(qry).to(DEV)
+    i64 = blocks.query(dq, 64)
+    for p in (100, 200):
+        assert torch.equal(blocks.query(dq, p)[:, :64], i64)
+    assert np.array_equal(i64.cpu().numpy(), O.knn_point_major(cloud, qry, 64))
+
+
 def test_knn_api_routes_large_k():
     from ppsurf_amd.spatial import knn
     pts = make_cloud(2000, seed=3)

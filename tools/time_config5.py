@@ -37,6 +37,14 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert bool(torch.isfinite(res[-1][1]).all())
+    from ppsurf_amd.workloads import HipEvents
+    evs = [HipEvents(6) for _ in range(a.steps)]
+    pipe.run([qd] * a.steps, want_occ=True, stage_events=[e.arr for e in evs])
+    torch.cuda.synchronize()
+    names = ['interp_pool', 'pointnet_stn_rows', 'pointnet_stn_fc', 'pointnet_feat_rows', 'decode_tail']
+    stage = [sum(e.elapsed_ms(i, i + 1) for e in evs) / a.steps for i in range(5)]
+    print('decoder stages (HIP events, ms): ' + ', '.join('{} {:.3f}'.format(n, t) for n, t in zip(names, stage)) +
+          ' | sum {:.2f} of {:.2f} ms/step (the rest: kNN + patches)'.format(sum(stage), dt / a.steps * 1e3))
     mflop = {50: 53.21, 200: 102.50}.get(a.p)
     print('P={} N={} Q={} R={}: {:.2f} ms/step, {:.3f} M queries/s{}'.format(
         a.p, a.n, a.q, a.res, dt / a.steps * 1e3, a.q * a.steps / dt / 1e6,
