@@ -44,6 +44,7 @@ INTERP_ALG_FLOP_PER_QUERY = 2.0 * (64 * 279_296 + 16_384)
 INTERP_EXEC_FLOP_PER_QUERY = 2320 * 4 * 2048.0
 STAGE_EXEC_MFMA_PER_QUERY = {'interp_pool': 9280, 'pointnet_stn_rows': 2413, 'pointnet_stn_fc': 296, 'pointnet_feat_rows': 2670, 'decode_tail': 200}
 PEAK_F32_MFMA_TFLOPS = 157.3                   # /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F16_MFMA_TFLOPS = 2500.0                  # dense f16 / bf16 matrix peak, same guide
 STAGES = ('interp_pool', 'pointnet_stn_rows', 'pointnet_stn_fc', 'pointnet_feat_rows', 'decode_tail')
 
 
@@ -175,7 +176,11 @@ def main():
         if os.path.isfile(pmc):
             traffic = json.load(open(pmc)).get('interp_pool_hbm_bytes_per_launch')
             traffic_src = 'profiles/round2_f32_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes of this bench (a previous run, NOT measured in this run)'
-        stage_frac = {n: STAGE_EXEC_MFMA_PER_QUERY[n] * 2048.0 * Q_CHUNK / (stage_ms[n] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS for n in STAGES}
+        # --dtype f16x3: the dense layers run as three f16 MFMA products per fp32 product -> executed flops x 3, priced against the dense f16 peak
+        f16 = args.dtype == 'f16x3'
+        peak, mult = (PEAK_F16_MFMA_TFLOPS, 3.0) if f16 else (PEAK_F32_MFMA_TFLOPS, 1.0)
+        executed *= mult
+        stage_frac = {n: mult * STAGE_EXEC_MFMA_PER_QUERY[n] * 2048.0 * Q_CHUNK / (stage_ms[n] * 1e-3) / 1e12 / peak for n in STAGES}
         out = {
             'metric': 'occupancy query-points/sec @ res=257, 50NN', 'value': value, 'unit': 'queries/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
@@ -184,17 +189,20 @@ def main():
                                    '(rec_batch_size) over {} synthetic 100k-point clouds per GPU, k=64, P=50'.format(args.steps, Q_CHUNK, len(shapes)),
                        'parallelism': 'query-block sharding x{}'.format(world), 'weights': 'formula-filled (no checkpoint offline)',
                        'entry': 'ChunkPipeline.run -> pps_knn_blocked_f32, pps_patch_normalize_f32, pps_decode_fwd_events_f32'},
-            'roofline': {'kernel': 'interp_pool_kernel (inside pps_decode_fwd_events_f32)', 'bound': 'mfma', 'achieved': executed,
-                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': executed / PEAK_F32_MFMA_TFLOPS,
+            'roofline': {'kernel': ('interp_pool_f16x3_kernel' if f16 else 'interp_pool_kernel') + ' (inside pps_decode_fwd_events_f32)', 'bound': 'mfma',
+                         'achieved': executed, 'peak': peak, 'unit': 'TFLOP/s', 'frac': executed / peak,
                          'traffic': traffic, 'traffic_source': traffic_src, 'avg_kernel_ms': k_ms,
                          'algorithmic_tflops': INTERP_ALG_FLOP_PER_QUERY * Q_CHUNK / (k_ms * 1e-3) / 1e12,
-                         'note': 'achieved / frac = MFMA flops the kernel EXECUTES (9280 v_mfma_f32_16x16x4_f32 per query x 2048) / its HIP-event '
-                                 'duration / the fp32 matrix peak; algorithmic_tflops prices the reference work it replaces (two exact identities '
-                                 'remove 47 % of it, DESIGN.md section 2) and is not a hardware fraction'},
+                         'note': ('achieved / frac = f16 MFMA flops the split-precision kernel executes (3 f16 products per fp32 product of the 9280 x 2048 '
+                                  'flop per query) / its HIP-event duration / the dense f16 matrix peak; the kernel is bound by its 576 KB weight stream '
+                                  'per pass (LDS-DMA), not by the f16 pipe (DESIGN.md section 4.1b)' if f16 else
+                                  'achieved / frac = MFMA flops the kernel EXECUTES (9280 v_mfma_f32_16x16x4_f32 per query x 2048) / its HIP-event '
+                                  'duration / the fp32 matrix peak; algorithmic_tflops prices the reference work it replaces (two exact identities '
+                                  'remove 47 % of it, DESIGN.md section 2) and is not a hardware fraction')},
             'stage_ms': stage_ms, 'stage_mfma_frac': stage_frac,
             'spatial_ms': ms_step - sum(stage_ms.values()),
             'whole_path_algorithmic_tflops': ALG_MFLOP_PER_QUERY * 1e6 * value / world / 1e12,
-            'whole_path_executed_mfma_frac': sum(STAGE_EXEC_MFMA_PER_QUERY.values()) * 2048.0 * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            'whole_path_executed_mfma_frac': mult * sum(STAGE_EXEC_MFMA_PER_QUERY.values()) * 2048.0 * value / world / 1e12 / peak,
         }
     extra = world == 1 and not args.quick and args.dtype == 'f32'
     if extra:
