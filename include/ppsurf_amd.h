@@ -291,6 +291,11 @@ int pps_bn_train_fwd(const void* x, int64_t rows, int c, int dtype, const float*
 int pps_bn_train_bwd(const void* x, const void* dy, int64_t rows, int c, int dtype, const float* gamma, const float* beta, const float* save,
                      int relu, void* dx, float* dgamma, float* dbeta, void* ws, void* stream);
 
+/* out[c] = sum over the rows of x [rows, c]: the bias gradient of a row layer (replaces the `grad_output.sum(0)` autograd runs for the bias of
+ * every Conv1d(…,1) / Linear of source/base/nn.py).  Shapes and dtype codes as pps_bn_train_*; ws: pps_bn_train_ws_bytes(rows, c) bytes.
+ * Deterministic (fixed-order fp32 per thread, double across threads and blocks). */
+int pps_col_sum(const void* x, int64_t rows, int c, int dtype, float* out, void* ws, void* stream);
+
 /* Attention pooling of the interpolation head in train(): a[j] = mean_h softmax_j(qy[q,j,h]), pooled[q,c] = sum_j a[j] h[q,j,c]
  * (replaces source/poco_model.py:412-414 under autograd, in the pooled form where fc_value follows the pooling).  qy [q,k,heads], h [q,k,c],
  * pooled [q,c]; heads <= 64 (64: interpolation head; 1: PointNet's AttentionPoco, source/base/nn.py:84-96 with k = patch points), k <= 64, c <= 256; storage float (bf16 = 0), bfloat16 (bf16 = 1) or IEEE half (bf16 = 2), arithmetic fp32.

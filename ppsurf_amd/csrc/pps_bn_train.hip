@@ -81,6 +81,11 @@ __global__ __launch_bounds__(BNT) void bn_reduce_kernel(const T* __restrict__ x,
             const F4 pv = load4<T>(x + 4 * m.cg);                       // pivot: row 0 of the tensor
 #pragma unroll
             for (int i = 0; i < 4; ++i) mu[i] = pv.v[i];
+            if (blockIdx.x == 0 && m.rl == 0) {
+                float* pivots = (float*)(part + (int64_t)gridDim.x * 2 * C);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pivots[4 * m.cg + i] = pv.v[i];
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -128,14 +133,25 @@ __global__ __launch_bounds__(BNT) void bn_finalize_kernel(const double* __restri
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int c = blockIdx.x * (BNT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
+    // operands of the tail requested before the partial sums are walked (three dependent memory latencies less at the end of a 5 us kernel)
+    float pivot_f = 0.f, rm0 = 0.f, rv0 = 0.f;
+    if (MODE == 0) {
+        pivot_f = ((const float*)(part + (int64_t)nblk * 2 * C))[c];          // written by block 0 of bn_reduce_kernel: reading row 0 of x here instead
+                                                                              // costs 4 us (a cold page of another allocation, measured)
+        if (running_mean) { rm0 = running_mean[c]; rv0 = running_var[c]; }
+    }
     double s1 = 0.0, s2 = 0.0;
-    for (int b = lane; b < nblk; b += 64) { s1 += part[((int64_t)b * C + c) * 2]; s2 += part[((int64_t)b * C + c) * 2 + 1]; }
+#pragma unroll 4
+    for (int b = lane; b < nblk; b += 64) {
+        const double2 v = *(const double2*)(part + ((int64_t)b * C + c) * 2);
+        s1 += v.x; s2 += v.y;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     if (lane != 0) return;
     const double n = (double)rows;
     if (MODE == 0) {
-        const double pivot = (double)load4<T>(x + (c & ~3)).v[c & 3];        // row 0 of the tensor, as in bn_reduce_kernel
+        const double pivot = (double)pivot_f;
         const double d = s1 / n;
         double var = s2 / n - d * d;
         if (var < 0.0) var = 0.0;
@@ -143,8 +159,8 @@ __global__ __launch_bounds__(BNT) void bn_finalize_kernel(const double* __restri
         out[c] = (float)mean;
         out[C + c] = (float)(1.0 / sqrt(var + (double)eps));
         if (running_mean) {
-            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * (rows > 1 ? var * n / (n - 1.0) : var));
+            running_mean[c] = (float)((1.0 - momentum) * rm0 + momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * rv0 + momentum * (rows > 1 ? var * n / (n - 1.0) : var));
         }
     } else {
         dbeta[c] = (float)s1;
@@ -203,6 +219,51 @@ inline int apply_blocks(int64_t rows, int C) {
     const int64_t nb = (rows + (int64_t)rpb * 4 - 1) / ((int64_t)rpb * 4);          // ~4 rows per thread
     return (int)(nb < 1 ? 1 : nb > 8192 ? 8192 : nb);
 }
+// column sums of a [rows, C] tensor (bias gradient of a row layer): per-block partials over a slab of rows, then one wave per channel
+template <typename T>
+__global__ __launch_bounds__(BNT) void col_sum_kernel(const T* __restrict__ x, int64_t rows, int C, double* __restrict__ part) {
+    extern __shared__ double red[];                 // [rpb][C]
+    const Map m = map_of(C);
+    const int64_t slab = (rows + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * slab, r1 = r0 + slab < rows ? r0 + slab : rows;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (m.rl < m.rpb) {
+        for (int64_t r = r0 + m.rl; r < r1; r += m.rpb) {
+            const F4 xv = load4<T>(x + r * C + 4 * m.cg);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[i] += xv.v[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[(int64_t)m.rl * C + 4 * m.cg + i] = (double)s[i];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < C; e += BNT) {
+        double t = 0.0;
+        for (int r = 0; r < m.rpb; ++r) t += red[(int64_t)r * C + e];
+        part[(int64_t)blockIdx.x * C + e] = t;
+    }
+}
+
+__global__ __launch_bounds__(BNT) void col_sum_finalize_kernel(const double* __restrict__ part, int nblk, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * (BNT / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double t = 0.0;
+#pragma unroll 4
+    for (int b = lane; b < nblk; b += 64) t += part[(int64_t)b * C + c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (lane == 0) out[c] = (float)t;
+}
+
+template <typename T>
+int col_sum_t(const T* x, int64_t rows, int c, float* out, void* ws, hipStream_t st, int nb) {
+    double* part = (double*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    const size_t lds = (size_t)(BNT / (c >> 2)) * c * sizeof(double);
+    hipLaunchKernelGGL((col_sum_kernel<T>), dim3(nb), dim3(BNT), lds, st, x, rows, c, part);
+    hipLaunchKernelGGL(col_sum_finalize_kernel, dim3((c + 3) / 4), dim3(BNT), 0, st, (const double*)part, nb, c, out);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 inline bool ok_shape(int64_t rows, int c) { return rows >= 1 && c >= 4 && c <= 1024 && (c & 3) == 0 && (BNT % (c >> 2)) == 0; }
 inline char* al(char* p) { return (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255); }
 
@@ -243,7 +304,16 @@ extern "C" {
 
 size_t pps_bn_train_ws_bytes(int64_t rows, int c) {
     if (!ok_shape(rows, c)) return 0;
-    return 1024 + (size_t)reduce_blocks(rows, c) * 2 * c * sizeof(double) + 2 * (size_t)c * sizeof(float);
+    return 1024 + (size_t)reduce_blocks(rows, c) * 2 * c * sizeof(double) + 4 * (size_t)c * sizeof(float);        // partials | pivots or gradient means
+}
+
+int pps_col_sum(const void* x, int64_t rows, int c, int dtype, float* out, void* ws, void* stream) {
+    if (!ok_shape(rows, c) || (dtype < 0 || dtype > 2) || !x || !out || !ws) return 1;
+    int nb = reduce_blocks(rows, c);
+    if (nb > 256) nb = 256;                              // one pass of <= 256 partial rows per channel in the second kernel
+    if (dtype == 0) return col_sum_t<float>((const float*)x, rows, c, out, ws, (hipStream_t)stream, nb);
+    if (dtype == 2) return col_sum_t<half_t>((const half_t*)x, rows, c, out, ws, (hipStream_t)stream, nb);
+    return col_sum_t<uint16_t>((const uint16_t*)x, rows, c, out, ws, (hipStream_t)stream, nb);
 }
 
 int pps_bn_train_fwd(const void* x, int64_t rows, int c, int dtype, const float* gamma, const float* beta, float* running_mean,

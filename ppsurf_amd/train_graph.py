@@ -39,12 +39,25 @@ SPLITK_MIN_ROWS = 32768
 SPLITK_SLABS = 64            # row slabs of the split-K weight gradient (64 / 128 / 256 measured within 3 % of each other).  NOT more than 64: with 128
                              # or 256 batches the library's strided-batched bf16 GEMM faults when the step is replayed as a HIP graph (memory
                              # aperture violation on replay, tools/fit_graph_matrix.py; 32 and 64 replay correctly)
+SPLITK_EXACT = (64, 32, 16, 8, 50, 40, 25, 20, 10, 5, 4)      # slab counts tried in this order: the first that divides the rows into slabs of
+SPLITK_SLAB_ROWS = 1000                                        # at least this many rows (no ragged tail -> no second GEMM + add for it)
+
+
+def splitk_slabs(rows):
+    """Slab count of the split-K weight gradient for `rows` rows, or 0 for one plain GEMM.  The encoder's levels (100 000 / 25 000 / 6 250 rows
+    per batch of 10) and the 20 000 query rows of the MLP run 3-6x faster split than as ONE library GEMM with a 256 x 256 (or smaller)
+    result, which occupies a handful of CUs (tools/time_dw_small.py: 25 000 x 128 -> 64: 96 us whole, 16 us as 8 slabs)."""
+    for s in SPLITK_EXACT:
+        if rows % s == 0 and rows // s >= SPLITK_SLAB_ROWS:
+            return s
+    return SPLITK_SLABS if rows >= SPLITK_MIN_ROWS else 0
 
 
 # bf16 images of the fp32 master parameters, refreshed once per forward pass by ONE multi-tensor copy (prepare_shadows): the library GEMMs
 # of the encoder otherwise cast every weight and bias with a launch of its own (~140 four-microsecond kernels per step)
 _shadow = {}                 # id(parameter) -> bf16 tensor of the same shape (persistent storage)
 _shadow_live = [False]
+_shadow_ver = {}             # id(parameter) -> parameter._version when its image was taken (an optimizer step in between makes the image stale)
 
 
 def prepare_shadows(module, dtype=torch.bfloat16):
@@ -58,12 +71,20 @@ def prepare_shadows(module, dtype=torch.bfloat16):
             if t is None or t.shape != p.shape or t.device != p.device or t.dtype != dtype:
                 _shadow[id(p)] = torch.empty_like(p, dtype=dtype)
         torch._foreach_copy_([_shadow[id(p)] for p in params], params)
+    for p in params:
+        _shadow_ver[id(p)] = p._version
     _shadow_live[0] = True
 
 
 def _bf16_of(param):
-    """The bf16 image of a parameter if prepare_shadows() ran for this step, else None."""
-    return _shadow.get(id(param)) if _shadow_live[0] and param is not None else None
+    """The 16-bit image of a parameter if prepare_shadows() took it during THIS forward pass in the autocast type in force, else None
+    (a flag left set by a pass that never reached release_step_caches(), or an image older than the parameter, must not be used)."""
+    if not _shadow_live[0] or param is None or not torch.is_autocast_enabled('cuda'):
+        return None
+    t = _shadow.get(id(param))
+    if t is None or t.dtype != torch.get_autocast_dtype('cuda') or _shadow_ver.get(id(param)) != param._version:
+        return None
+    return t
 
 
 _mm_fp32_out = [True]
@@ -111,10 +132,10 @@ class _RowsLinear(torch.autograd.Function):
             dx = (g @ wc).to(xdt)
         if ctx.needs_input_grad[1]:
             rows = g.shape[0]
-            if rows < SPLITK_MIN_ROWS:
+            s = splitk_slabs(rows) if xc.dtype in train_ops.LOW else (SPLITK_SLABS if rows >= SPLITK_MIN_ROWS else 0)
+            if s == 0:
                 dw = _mm_f32(g.t(), xc) if acc == torch.float32 else g.t() @ xc
             else:
-                s = SPLITK_SLABS if rows >= SPLITK_SLABS * 1024 else 64
                 rs = rows // s
                 main = rs * s
                 dw = torch.bmm(g[:main].view(s, rs, -1).transpose(1, 2), xc[:main].view(s, rs, -1)).sum(0, dtype=acc)
@@ -122,7 +143,8 @@ class _RowsLinear(torch.autograd.Function):
                     dw = dw + (g[main:].t() @ xc[main:]).to(acc)
             dw = dw.to(wdt)
         if bdt is not None and ctx.needs_input_grad[2]:
-            db = g.sum(0, dtype=acc).to(bdt)
+            db = train_ops.col_sum(g) if acc == torch.float32 else None
+            db = (g.sum(0, dtype=acc) if db is None else db).to(bdt)
         return dx, dw, db, None, None
 
 

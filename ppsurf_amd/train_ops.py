@@ -329,6 +329,22 @@ class _BnAct(torch.autograd.Function):
         return dx, dgamma.to(ctx.dtypes[0]), dbeta.to(ctx.dtypes[1]), None, None, None, None, None
 
 
+def col_sum(x):
+    """x [rows, c] -> fp32 [c] column sums (the bias gradient of a row layer) by the HIP reduction; None if the shape is not one it takes
+    (the caller then uses torch's sum).  No autograd: called from backward passes."""
+    if not x.is_cuda or x.dim() != 2 or x.dtype not in (torch.float32,) + LOW or not x.is_contiguous():
+        return None
+    rows, c = x.shape
+    nbytes = _lib.lib().pps_bn_train_ws_bytes(rows, c)
+    if nbytes == 0:
+        return None
+    out = torch.empty((c,), device=x.device, dtype=torch.float32)
+    ws = torch.empty((nbytes,), device=x.device, dtype=torch.uint8)
+    _lib.check(_lib.lib().pps_col_sum(x.data_ptr(), rows, c, _code(x.dtype) if x.dtype in LOW else 0, out.data_ptr(), ws.data_ptr(), _stream()),
+               'pps_col_sum')
+    return out
+
+
 class _AttnPool(torch.autograd.Function):
     """pooled[q] = sum_j mean_h softmax_j(qy[q,j,h]) * h[q,j]  (poco_model.py:412-414 in the pooled form): one HIP kernel forward, one
     backward; fp32 or bf16 storage, fp32 arithmetic; the softmax is recomputed in backward, only the two inputs are saved."""
@@ -700,8 +716,11 @@ def gather_rows(x, idx):
 
 
 def neighbour_max(x, idx):
-    return _NeighbourMax.apply(x, idx)
+    """A maximum of 16-bit values is one of them: the result goes back to the type it came in (the op computes in fp32), so that the residual
+    sum it feeds stays a same-type addition (a bf16 + fp32 addition runs ATen's slow mixed-type kernel and promotes everything downstream)."""
+    out = _NeighbourMax.apply(x.float(), idx)             # explicit: custom_fwd casts only inside an autocast region
+    return out.to(x.dtype) if x.dtype in LOW else out
 
 
 def neighbour_contract(x, idx, g):
-    return _NeighbourContract.apply(x, idx, g)
+    return _NeighbourContract.apply(x.float(), idx, g.float())

@@ -203,9 +203,11 @@ def test_pointnet_with_fused_row_layers_is_as_close_to_fp32_as_the_separate_ops(
         scale = float(g32.abs().max())
         if scale < 1e-6 * gmax:
             continue                                                    # biases in front of a BatchNorm: the gradient is rounding noise everywhere
-        ef, es = dist(res['fused'][2][k], g32), dist(res['separate'][2][k], g32)
-        if ef > 2.5 * es + 2e-2 * scale:
-            worse.append((k, ef, es, scale))
+        # in the root-mean-square sense: ONE arg-max switch of the STN's max-pool moves single entries of the early layers' gradients by 10 % of
+        # the largest entry in either 16-bit path (conv0a.weight in fp16: 971 fused, 319 separate of 6500), which says nothing about the path
+        ef, es = float((res['fused'][2][k] - g32).norm()), float((res['separate'][2][k] - g32).norm())
+        if ef > 2.5 * es + 2e-2 * float(g32.norm()):
+            worse.append((k, ef, es, float(g32.norm())))
     assert not worse, worse
     for k, v32 in ref[3].items():
         assert dist(res['fused'][3][k], v32) <= 2.5 * dist(res['separate'][3][k], v32) + 2e-3 * float(v32.abs().max()) + 1e-5, k

@@ -198,3 +198,12 @@ def test_ppsurf_training_step_dropout_same_generator():
     loss = nn.functional.cross_entropy(logits, occ, reduction='none').mean()
     _close(logits.detach(), g['logits_dropout'], 5e-5, 'logits')
     assert abs(float(loss.detach()) - float(g['loss_dropout'])) < 1e-5
+
+
+@pytest.mark.parametrize('rows,want', [(100000, 32), (25000, 8), (20000, 16), (6250, 5), (1000000, 64), (1280000, 64), (1560, 0), (40000, 32), (33000, 8),
+                                       (32771, 64), (999, 0)])
+def test_split_k_slab_choice(rows, want):
+    from ppsurf_amd import train_graph
+    s = train_graph.splitk_slabs(rows)
+    assert s == want
+    assert s == 0 or rows // s >= 500

@@ -1,24 +1,34 @@
-"""Fit step (BASELINE config 3, bf16-mixed) eager vs replayed HIP graph, each in its own process.   python tools/time_fit_graph.py"""
-import os, subprocess, sys
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-code = '''
-import sys, time, torch
-sys.path.insert(0, %r)
-from ppsurf_amd import workloads
-graph = %r
-fit = workloads.FitStep(batch=10, precision='bf16-mixed', graph=True)
-fit.stepper.enabled = graph
-for _ in range(6):
-    loss = fit()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-n = 20
-for _ in range(n):
-    loss = fit()
-torch.cuda.synchronize()
-print('graph' if graph else 'eager', '{:.2f} ms/step, loss {:.5f}, graphs captured: {}, failed: {}'.format(
-    (time.perf_counter() - t0) / n * 1e3, float(loss), len(fit.stepper.graphs), fit.stepper.failed))
-'''
-for graph in (False, True):
-    r = subprocess.run([sys.executable, '-c', code % (REPO, graph)], capture_output=True, text=True)
-    print('\n'.join(l for l in (r.stdout + r.stderr).split('\n') if l.strip() and 'amdgpu' not in l)[-400:], flush=True)
+"""The fit step exactly as bench.py's `fit_ms_per_step` leg runs it (workloads.FitStep(graph=True): replayed HIP graph, batch assembly on the
+loader thread / side stream), alone.  Usage: python tools/time_fit_graph.py [--steps 60] [--precision bf16-mixed|16-mixed] [--eager]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ppsurf_amd import workloads          # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--precision', default='bf16-mixed')
+    ap.add_argument('--eager', action='store_true')
+    a = ap.parse_args()
+    step = workloads.FitStep(batch=10, precision=a.precision, graph=not a.eager)
+    for _ in range(8):
+        step()
+    torch.cuda.synchronize()
+    for rep in range(3):
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        print('{} {}: {:.2f} ms/step  loss {:.4f}'.format(a.precision, 'eager' if a.eager else 'graph', (time.perf_counter() - t0) / a.steps * 1e3, float(loss)))
+    step.close()
+
+
+if __name__ == '__main__':
+    main()
