@@ -370,6 +370,17 @@ int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t row
                        void* dx, const void* dx_add, float* d_in_affine, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws,
                        void* stream);
 
+/* AdamW step over all parameter tensors of a group in one launch: replaces the optimizer step of the reference's trainer
+ * (configs/poco.yaml:60-69 torch.optim.AdamW; arithmetic of torch's fused implementation, amsgrad and maximize off).
+ * pieces: device array of n_pieces records of pps_adamw_piece_bytes() = 48 bytes {float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+ * const float* step, int32 n, int32 pad}, one workgroup per record (n <= 4096 elements of one tensor); steps: device array of the n_steps
+ * distinct `step` scalars (float, one per parameter tensor), each advanced by one before the update.  lr_dev (device float) overrides lr when
+ * not NULL.  grad_scale / found_inf (device floats, NULL = none) as torch.amp.GradScaler hands them to a fused optimizer: gradients are divided by
+ * *grad_scale (and written back), and nothing at all happens when *found_inf != 0. */
+int pps_adamw_piece_bytes(void);
+int pps_adamw_step(const void* pieces, int n_pieces, const void* steps, int n_steps, const float* lr_dev, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, const float* grad_scale, const float* found_inf, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,8 @@ SIGNATURES = {
     'pps_bn_train_fwd': (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _c.c_float, _c.c_float, _I, _P, _P, _P, _P]),
     'pps_bn_train_bwd': (_I, [_P, _P, _I64, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     'pps_col_sum': (_I, [_P, _I64, _I, _I, _P, _P, _P]),
+    'pps_adamw_piece_bytes': (_I, []),
+    'pps_adamw_step': (_I, [_P, _I, _P, _I, _P, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _P, _P, _P]),
 }
 
 _lib = None

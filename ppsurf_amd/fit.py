@@ -195,6 +195,10 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
         # 46.6 ms per step) applies the same update rule, takes the loss scale / found-inf tensors on the device (no host sync in
         # GradScaler.step) and, with capturable=True, keeps its step counter on the device so that the step can be recorded into a graph
         ospec = dict(ospec, init_args=dict(ospec.get('init_args', {}), fused=True, capturable=use_graph))
+        if ospec['class_path'] == 'torch.optim.AdamW':
+            # the same optimizer (state, checkpoints, GradScaler and graph-capture behaviour of the fused torch class it derives from) whose step is
+            # ONE launch over a table of 4096-element pieces instead of torch's 65 536-element slabs: 0.78 -> 0.15 ms per step (ppsurf_amd/optim.py)
+            ospec = dict(ospec, class_path='ppsurf_amd.optim.AdamW')
     optimizer = _instantiate(ospec, params)
 
     scheduler = _instantiate(cfg['lr_scheduler'], optimizer) if cfg.get('lr_scheduler') else None

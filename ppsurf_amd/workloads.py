@@ -142,7 +142,8 @@ class FitStep:
             net = modules.PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=p, pointnet_latent_size=256)
         net.load_state_dict(synthetic.network_state_dict('ppsurf', num_pts_local=p))
         self.net = net.to(self.dev).train()
-        self.opt = torch.optim.AdamW(self.net.parameters(), lr=1e-3, eps=1e-5, weight_decay=1e-2, fused=True, capturable=graph)   # configs/poco.yaml:60-69, fused like ppsurf_amd.fit
+        from . import optim
+        self.opt = optim.AdamW(self.net.parameters(), lr=1e-3, eps=1e-5, weight_decay=1e-2, capturable=graph)   # configs/poco.yaml:60-69, the class ppsurf_amd.fit puts in for torch.optim.AdamW
         self.buckets = sharding.GradBuckets([q for q in self.net.parameters() if q.requires_grad])      # as ppsurf_amd.fit (one rank: no collective)
         self.autocast = {'bf16-mixed': torch.bfloat16, '16-mixed': torch.float16}.get(precision)
         self.batches = [self._raw_batch(batch, n, q, s) for s in range(n_batches)]

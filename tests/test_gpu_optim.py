@@ -1,0 +1,166 @@
+"""ppsurf_amd.optim.AdamW (one HIP launch per step, pps_optim.hip) against torch.optim.AdamW(fused=True): parameters, state, GradScaler hand-over,
+HIP-graph capture and the checkpoint layout."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+SHAPES = [(1,), (5,), (4096,), (4097,), (64, 3), (256, 256), (100003,), (3, 7, 11)]
+KW = dict(lr=3e-3, betas=(0.9, 0.99), eps=1e-5, weight_decay=0.05)
+
+
+def _params(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(*s, generator=g).to(DEV).requires_grad_(True) for s in SHAPES]
+
+
+def _pair(**kw):
+    from ppsurf_amd import optim
+    a = _params()
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    return a, b, optim.AdamW(a, **dict(KW, **kw)), torch.optim.AdamW(b, fused=True, **dict(KW, **kw))
+
+
+def _set_grads(a, b, seed, skip=()):
+    g = torch.Generator().manual_seed(1000 + seed)
+    for i, (x, y) in enumerate(zip(a, b)):
+        if i in skip:
+            x.grad = y.grad = None
+            continue
+        gr = torch.randn(*x.shape, generator=g).to(DEV) * (1.0 + i)
+        x.grad, y.grad = gr.clone(), gr.clone()
+
+
+def _same(a, b, mine, ref, rtol=2e-6):
+    for x, y in zip(a, b):
+        torch.testing.assert_close(x, y, rtol=rtol, atol=1e-7)
+        if x in mine.state and len(mine.state[x]):
+            for k in ('exp_avg', 'exp_avg_sq'):
+                want = ref.state[y][k]
+                torch.testing.assert_close(mine.state[x][k], want, rtol=rtol, atol=1e-6 * float(want.abs().max()))      # an ulp of the LARGER operand of m + w (g - m)
+            assert float(mine.state[x]['step']) == float(ref.state[y]['step'])
+
+
+def test_steps_equal_torchs_fused_adamw_including_parameters_that_skip_steps():
+    a, b, mine, ref = _pair()
+    for step in range(7):
+        _set_grads(a, b, step, skip=(2, 5) if step in (1, 4) else ((0,) if step == 0 else ()))       # parameters without a gradient fall behind in `step`
+        mine.step()
+        ref.step()
+    assert mine.fast_steps == 7
+    _same(a, b, mine, ref)
+    assert float(mine.state[a[2]]['step']) == 5.0 and float(mine.state[a[0]]['step']) == 6.0 and float(mine.state[a[1]]['step']) == 7.0
+
+
+def test_grad_scale_and_found_inf_like_a_fused_optimizer_under_gradscaler():
+    a, b, mine, ref = _pair()
+    for step, (scale, inf) in enumerate([(1024.0, 0.0), (512.0, 1.0), (512.0, 0.0)]):
+        _set_grads(a, b, step)
+        for x, y in zip(a, b):
+            x.grad.mul_(scale)
+            y.grad.mul_(scale)
+        for opt in (mine, ref):
+            opt.grad_scale = torch.tensor(scale, device=DEV)
+            opt.found_inf = torch.tensor(inf, device=DEV)
+        before = [x.detach().clone() for x in a]
+        mine.step()
+        ref.step()
+        if inf:
+            assert all(torch.equal(x, w) for x, w in zip(a, before))                                  # the whole step is skipped
+    assert mine.fast_steps == 3 and float(mine.state[a[0]]['step']) == 2.0
+    _same(a, b, mine, ref, rtol=5e-6)
+    torch.testing.assert_close(a[3].grad, b[3].grad, rtol=1e-6, atol=0)                                # unscaled gradients are written back
+
+
+def test_real_gradscaler_drives_it_without_reading_anything_back():
+    from ppsurf_amd import optim
+    a = _params()
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    mine, ref = optim.AdamW(a, **KW), torch.optim.AdamW(b, fused=True, **KW)
+    sa, sb = torch.amp.GradScaler('cuda', init_scale=256.0), torch.amp.GradScaler('cuda', init_scale=256.0)
+    for step in range(3):
+        for params, opt, sc in ((a, mine, sa), (b, ref, sb)):
+            opt.zero_grad(set_to_none=True)
+            loss = sum(((p * (1.5 + i)) ** 2).sum() for i, p in enumerate(params)) * (float('inf') if step == 1 else 1.0)
+            sc.scale(loss).backward()
+            sc.step(opt)
+            sc.update()
+    assert mine.fast_steps == 3 and float(sa.get_scale()) == float(sb.get_scale()) == 128.0
+    _same(a, b, mine, ref, rtol=5e-6)
+
+
+def test_captured_into_a_hip_graph_with_a_device_learning_rate():
+    a, b, mine, ref = _pair(capturable=True)
+    for opt in (mine, ref):
+        for group in opt.param_groups:
+            group['lr'] = torch.tensor(float(group['lr']), device=DEV)
+    static = [torch.zeros_like(x) for x in a]
+    for x, s in zip(a, static):
+        x.grad = s
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        mine.step()                                                      # builds state and the pointer table outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    for y in b:
+        y.grad = torch.zeros_like(y)
+    ref.step()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        mine.step()
+    assert mine.fast_steps == 2                                          # recorded by the HIP path, not torch's fallback
+    for y in b:
+        y.grad = torch.zeros_like(y)
+    ref.step()                                                           # (a capture executes nothing: one replay below = this step)
+    graph.replay()
+    for step in range(3):
+        g = torch.Generator().manual_seed(step)
+        for s, y in zip(static, b):
+            gr = torch.randn(*s.shape, generator=g).to(DEV)
+            s.copy_(gr)
+            y.grad = gr.clone()
+        if step == 2:
+            for opt in (mine, ref):
+                opt.param_groups[0]['lr'].fill_(1e-4)                    # what a scheduler does between epochs
+        graph.replay()
+        ref.step()
+    torch.cuda.synchronize()
+    _same(a, b, mine, ref)
+    assert float(mine.state[a[0]]['step']) == 5.0                        # 1 eager + 4 replays
+
+
+def test_state_dict_is_torchs_and_moves_both_ways():
+    a, b, mine, ref = _pair()
+    for step in range(2):
+        _set_grads(a, b, step)
+        mine.step()
+        ref.step()
+    sd_mine, sd_ref = mine.state_dict(), ref.state_dict()
+    assert sd_mine['param_groups'][0].keys() == sd_ref['param_groups'][0].keys()
+    assert all(set(v) == {'step', 'exp_avg', 'exp_avg_sq'} for v in sd_mine['state'].values())
+    from ppsurf_amd import optim
+    a2 = [t.detach().clone().requires_grad_(True) for t in a]
+    b2 = [t.detach().clone().requires_grad_(True) for t in b]
+    mine2, ref2 = optim.AdamW(a2, **KW), torch.optim.AdamW(b2, fused=True, **KW)
+    mine2.load_state_dict(sd_ref)                                        # torch's checkpoint into the HIP optimizer
+    ref2.load_state_dict(sd_mine)                                        # and the other way round
+    for step in range(2, 4):
+        _set_grads(a2, b2, step)
+        mine2.step()
+        ref2.step()
+    assert mine2.fast_steps == 2
+    _same(a2, b2, mine2, ref2)
+
+
+def test_what_the_kernel_does_not_take_goes_through_torch():
+    from ppsurf_amd import optim
+    p = torch.randn(16, 8, device=DEV, dtype=torch.float64).requires_grad_(True)       # the kernel is fp32 only
+    q = p.detach().clone().requires_grad_(True)
+    mine, ref = optim.AdamW([p], **KW), torch.optim.AdamW([q], fused=True, **KW)
+    for step in range(2):
+        g = torch.randn(16, 8, device=DEV, dtype=torch.float64)
+        p.grad, q.grad = g.clone(), g.clone()
+        mine.step()
+        ref.step()
+    assert mine.fast_steps == 0
+    assert torch.equal(p, q)
