@@ -255,6 +255,14 @@ int pps_neighbour_contract_fwd_f32(const float* x, const int64_t* idx, const flo
 int pps_neighbour_contract_bwd_f32(const float* x, const int64_t* idx, const float* g, const float* dout, int64_t m, int k, int c,
                                    float* dxg, float* dg, void* stream);
 
+/* The same two with x, out and dout in the storage type of an autocast step (dtype 0 float = the _f32 entries, 1 bfloat16, 2 IEEE half; g, dxg, dg
+ * and the arithmetic stay fp32): no cast kernels around the op and half the traffic.  16-bit storage needs pps_neighbour_contract_16_supported(k, c)
+ * (c % 16 == 0, k <= 16: the matrix-pipe kernels). */
+int pps_neighbour_contract_16_supported(int k, int c);
+int pps_neighbour_contract_fwd(const void* x, const int64_t* idx, const float* g, int64_t m, int k, int c, int dtype, void* out, void* stream);
+int pps_neighbour_contract_bwd(const void* x, const int64_t* idx, const float* g, const void* dout, int64_t m, int k, int c, int dtype,
+                               float* dxg, float* dg, void* stream);
+
 /* Neighbourhood max-pool that also records the winning neighbour: out [m,c], arg int32 [m,c] (first j attaining the max).
  * replaces: source/base/nn.py:677-680 `max_pool` in training. */
 int pps_gather_max_arg_f32(const float* x, const int64_t* idx, int64_t m, int k, int c, float* out, int32_t* arg, void* stream);

@@ -55,6 +55,9 @@ SIGNATURES = {
     'pps_segment_sum_rows_16': (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
     'pps_neighbour_contract_fwd_f32': (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),
     'pps_neighbour_contract_bwd_f32': (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _P, _P]),
+    'pps_neighbour_contract_16_supported': (_I, [_I, _I]),
+    'pps_neighbour_contract_fwd': (_I, [_P, _P, _P, _I64, _I, _I, _I, _P, _P]),
+    'pps_neighbour_contract_bwd': (_I, [_P, _P, _P, _P, _I64, _I, _I, _I, _P, _P, _P]),
     'pps_gather_max_arg_f32': (_I, [_P, _P, _I64, _I, _I, _P, _P, _P]),
     'pps_gather_max_bwd_f32': (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _P]),
     'pps_fka_train_ws_bytes': (_SZ, [_I64, _I64, _I]),

@@ -153,9 +153,34 @@ __global__ void __launch_bounds__(TB) contract_bwd_g_kernel(const float* __restr
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int CW = 4;           // waves (= support points) per workgroup iteration
 
+// Storage of x, out and dout: float, bfloat16 (uint16_t) or IEEE half (_Float16) -- the 16-bit activations of an autocast step are read and
+// written as they are (no cast kernels around the op, half the traffic); the products and g / dg / dxg are fp32.
+typedef _Float16 half_c;
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const uint16_t* p) { return __uint_as_float((uint32_t)*p << 16); }
+__device__ __forceinline__ float ld1(const half_c* p) { return (float)*p; }
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 ld4(const uint16_t* p) {
+    const uint2 t = *(const uint2*)p;
+    return f32x4{__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u)};
+}
+__device__ __forceinline__ f32x4 ld4(const half_c* p) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const h4 t = *(const h4*)p;
+    return f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+}
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(uint16_t* p, float v) {
+    uint32_t u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);                     // round to nearest even (finite values)
+    *p = (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ void st1(half_c* p, float v) { *p = (half_c)v; }
+
 // out[m, c*16 + t] = sum_j x[idx[m,j], c] g[m,j,t]:   D[c'][t] over 16-channel blocks, contraction over the neighbours j = 4 s + q
-__global__ void __launch_bounds__(CW * 64) contract_fwd_mfma_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
-                                                                    const float* __restrict__ g, int64_t m, int k, int c, float* __restrict__ out) {
+template <typename T>
+__global__ void __launch_bounds__(CW * 64) contract_fwd_mfma_kernel(const T* __restrict__ x, const int64_t* __restrict__ idx,
+                                                                    const float* __restrict__ g, int64_t m, int k, int c, T* __restrict__ out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
     for (int64_t row = (int64_t)blockIdx.x * CW + wave; row < m; row += (int64_t)gridDim.x * CW) {
         float gb[4];
@@ -170,28 +195,29 @@ __global__ void __launch_bounds__(CW * 64) contract_fwd_mfma_kernel(const float*
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const float a = xr[s] >= 0 ? x[xr[s] + cb + n] : 0.f;            // A[c' = n][j]
+                const float a = xr[s] >= 0 ? ld1(x + xr[s] + cb + n) : 0.f;      // A[c' = n][j]
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, gb[s], acc, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[(row * c + cb + 4 * q + r) * KT + n] = acc[r];      // D row 4 q + r = channel, column n = t
+            for (int r = 0; r < 4; ++r) st1(out + (row * c + cb + 4 * q + r) * KT + n, acc[r]);      // D row 4 q + r = channel, column n = t
         }
     }
 }
 
 // dg[m,j,t] = sum_c dout[m, c*16+t] x[idx[m,j], c]:   D[j][t], contraction over the channels c = 16 cb + 4 q + s
-__global__ void __launch_bounds__(CW * 64) contract_bwd_g_mfma_kernel(const float* __restrict__ dout, const float* __restrict__ x,
+template <typename T>
+__global__ void __launch_bounds__(CW * 64) contract_bwd_g_mfma_kernel(const T* __restrict__ dout, const T* __restrict__ x,
                                                                       const int64_t* __restrict__ idx, int64_t m, int k, int c,
                                                                       float* __restrict__ dg) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
     for (int64_t row = (int64_t)blockIdx.x * CW + wave; row < m; row += (int64_t)gridDim.x * CW) {
         const int64_t xr = n < k ? idx[row * k + n] * c : -1;                    // A row j = n
-        const float* dr = dout + row * c * KT + n;                               // B column t = n
+        const T* dr = dout + row * c * KT + n;                                   // B column t = n
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int cb = 0; cb < c; cb += 16) {
-            const f32x4 a4 = xr >= 0 ? *(const f32x4*)(x + xr + cb + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 a4 = xr >= 0 ? ld4(x + xr + cb + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s], dr[(cb + 4 * q + s) * KT], acc, 0, 0, 0);
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s], ld1(dr + (cb + 4 * q + s) * KT), acc, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -200,13 +226,14 @@ __global__ void __launch_bounds__(CW * 64) contract_bwd_g_mfma_kernel(const floa
 }
 
 // dxg[m,j,c] = sum_t dout[m, c*16+t] g[m,j,t]:   D[c'][j], contraction over t = 4 q + s
-__global__ void __launch_bounds__(CW * 64) contract_bwd_x_mfma_kernel(const float* __restrict__ dout, const float* __restrict__ g, int64_t m, int k,
+template <typename T>
+__global__ void __launch_bounds__(CW * 64) contract_bwd_x_mfma_kernel(const T* __restrict__ dout, const float* __restrict__ g, int64_t m, int k,
                                                                       int c, float* __restrict__ dxg) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, q = lane >> 4;
     for (int64_t row = (int64_t)blockIdx.x * CW + wave; row < m; row += (int64_t)gridDim.x * CW) {
         const f32x4 b4 = n < k ? *(const f32x4*)(g + (row * k + n) * KT + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};      // B[t][j = n]
         for (int cb = 0; cb < c; cb += 16) {
-            const f32x4 a4 = *(const f32x4*)(dout + (row * c + cb + n) * KT + 4 * q);                               // A[c' = n][t]
+            const f32x4 a4 = ld4(dout + (row * c + cb + n) * KT + 4 * q);                                           // A[c' = n][t]
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s], b4[s], acc, 0, 0, 0);
@@ -219,6 +246,20 @@ inline unsigned point_blocks(int64_t m) {
     const int64_t b = (m + CW - 1) / CW;
     return (unsigned)(b < 8192 ? b : 8192);
 }
+
+template <typename T>
+int contract_fwd_t(const T* x, const int64_t* idx, const float* g, int64_t m, int k, int c, T* out, hipStream_t st) {
+    contract_fwd_mfma_kernel<T><<<point_blocks(m), CW * 64, 0, st>>>(x, idx, g, m, k, c, out);
+    return launch_status();
+}
+template <typename T>
+int contract_bwd_t(const T* x, const int64_t* idx, const float* g, const T* dout, int64_t m, int k, int c, float* dxg, float* dg,
+                          hipStream_t st) {
+    if (dxg) contract_bwd_x_mfma_kernel<T><<<point_blocks(m), CW * 64, 0, st>>>(dout, g, m, k, c, dxg);
+    if (dg) contract_bwd_g_mfma_kernel<T><<<point_blocks(m), CW * 64, 0, st>>>(dout, x, idx, m, k, c, dg);
+    return launch_status();
+}
+
 
 // out[m,c] = max_j x[idx[m,j], c], arg[m,c] = first j attaining it
 __global__ void __launch_bounds__(TB) gather_max_arg_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
@@ -297,7 +338,7 @@ int pps_neighbour_contract_fwd_f32(const float* x, const int64_t* idx, const flo
     if (m < 0 || k < 1 || c < 1) return 1;
     if (m == 0) return 0;
     if (!x || !idx || !g || !out) return 1;
-    if ((c & 15) == 0 && k <= 16) contract_fwd_mfma_kernel<<<point_blocks(m), CW * 64, 0, (hipStream_t)stream>>>(x, idx, g, m, k, c, out);
+    if ((c & 15) == 0 && k <= 16) contract_fwd_mfma_kernel<float><<<point_blocks(m), CW * 64, 0, (hipStream_t)stream>>>(x, idx, g, m, k, c, out);
     else contract_fwd_kernel<<<blocks_for(m * c), TB, 0, (hipStream_t)stream>>>(x, idx, g, m, k, c, out);
     return launch_status();
 }
@@ -309,14 +350,35 @@ int pps_neighbour_contract_bwd_f32(const float* x, const int64_t* idx, const flo
     if (!x || !idx || !g || !dout || (!dxg && !dg)) return 1;
     const bool mfma = (c & 15) == 0 && k <= 16;
     if (dxg) {
-        if (mfma) contract_bwd_x_mfma_kernel<<<point_blocks(m), CW * 64, 0, (hipStream_t)stream>>>(dout, g, m, k, c, dxg);
+        if (mfma) contract_bwd_x_mfma_kernel<float><<<point_blocks(m), CW * 64, 0, (hipStream_t)stream>>>(dout, g, m, k, c, dxg);
         else contract_bwd_x_kernel<<<blocks_for(m * c), TB, 0, (hipStream_t)stream>>>(dout, g, m, k, c, dxg);
     }
     if (dg) {
-        if (mfma) contract_bwd_g_mfma_kernel<<<point_blocks(m), CW * 64, 0, (hipStream_t)stream>>>(dout, x, idx, m, k, c, dg);
+        if (mfma) contract_bwd_g_mfma_kernel<float><<<point_blocks(m), CW * 64, 0, (hipStream_t)stream>>>(dout, x, idx, m, k, c, dg);
         else contract_bwd_g_kernel<<<blocks_for(m * k * KT), TB, 0, (hipStream_t)stream>>>(dout, x, idx, m, k, c, dg);
     }
     return launch_status();
+}
+
+int pps_neighbour_contract_16_supported(int k, int c) { return (c & 15) == 0 && k >= 1 && k <= 16; }
+
+int pps_neighbour_contract_fwd(const void* x, const int64_t* idx, const float* g, int64_t m, int k, int c, int dtype, void* out, void* stream) {
+    if (dtype == 0) return pps_neighbour_contract_fwd_f32((const float*)x, idx, g, m, k, c, (float*)out, stream);
+    if (m < 0 || (dtype != 1 && dtype != 2) || !pps_neighbour_contract_16_supported(k, c)) return 1;
+    if (m == 0) return 0;
+    if (!x || !idx || !g || !out) return 1;
+    if (dtype == 1) return contract_fwd_t<uint16_t>((const uint16_t*)x, idx, g, m, k, c, (uint16_t*)out, (hipStream_t)stream);
+    return contract_fwd_t<half_c>((const half_c*)x, idx, g, m, k, c, (half_c*)out, (hipStream_t)stream);
+}
+
+int pps_neighbour_contract_bwd(const void* x, const int64_t* idx, const float* g, const void* dout, int64_t m, int k, int c, int dtype,
+                               float* dxg, float* dg, void* stream) {
+    if (dtype == 0) return pps_neighbour_contract_bwd_f32((const float*)x, idx, g, (const float*)dout, m, k, c, dxg, dg, stream);
+    if (m < 0 || (dtype != 1 && dtype != 2) || !pps_neighbour_contract_16_supported(k, c)) return 1;
+    if (m == 0) return 0;
+    if (!x || !idx || !g || !dout || (!dxg && !dg)) return 1;
+    if (dtype == 1) return contract_bwd_t<uint16_t>((const uint16_t*)x, idx, g, (const uint16_t*)dout, m, k, c, dxg, dg, (hipStream_t)stream);
+    return contract_bwd_t<half_c>((const half_c*)x, idx, g, (const half_c*)dout, m, k, c, dxg, dg, (hipStream_t)stream);
 }
 
 int pps_gather_max_arg_f32(const float* x, const int64_t* idx, int64_t m, int k, int c, float* out, int32_t* arg, void* stream) {

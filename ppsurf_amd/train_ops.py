@@ -14,7 +14,8 @@
 Device tensors only: there is no CPU implementation in the product (tests/train_ref_ops.py holds the torch twins the CPU
 suite patches in to check the surrounding graph).  Backward scatter-adds are atomics-free and bit-reproducible: the id table
 is sorted once (`csr`, cached per table and step) and each target row sums its contributions in a fixed order.
-All ops compute in fp32 (inputs are up-cast under autocast).
+All ops compute in fp32; gather_rows, neighbour_contract (matrix-pipe shapes), bn_act and the attention ops read and write 16-bit activations as they
+are, the others up-cast them.
 """
 import torch
 
@@ -206,35 +207,40 @@ class _NeighbourMax(torch.autograd.Function):
 
 
 class _NeighbourContract(torch.autograd.Function):
+    """x [n,c] in fp32 or, when the matrix-pipe kernels take the shape (c % 16 == 0, k <= 16), in the 16-bit type it arrives in: the output has x's
+    type and the incoming gradient is read in it (no cast kernels around the op in an autocast step); g, dg and the arithmetic are fp32."""
+
     @staticmethod
-    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, x, idx, g):
         _need_cuda(x, idx, g)
-        x, idx, g = x.contiguous(), idx.contiguous(), g.contiguous()
         m, k = idx.shape
         c = x.shape[1]
+        low = x.dtype in LOW and bool(_lib.lib().pps_neighbour_contract_16_supported(k, c))
+        if not low:
+            x = x.float()
+        x, idx, g = x.contiguous(), idx.contiguous(), g.float().contiguous()
         if g.shape != (m, k, 16):
             raise ValueError('neighbour_contract: g must be [m, k, 16], got {}'.format(tuple(g.shape)))
-        out = torch.empty((m, c * 16), device=x.device, dtype=torch.float32)
-        _lib.check(_lib.lib().pps_neighbour_contract_fwd_f32(x.data_ptr(), idx.data_ptr(), g.data_ptr(), m, k, c, out.data_ptr(),
-                                                             _stream()), 'pps_neighbour_contract_fwd_f32')
+        out = torch.empty((m, c * 16), device=x.device, dtype=x.dtype)
+        _lib.check(_lib.lib().pps_neighbour_contract_fwd(x.data_ptr(), idx.data_ptr(), g.data_ptr(), m, k, c, _code(x.dtype) if low else 0,
+                                                         out.data_ptr(), _stream()), 'pps_neighbour_contract_fwd')
         ctx.save_for_backward(x, idx, g)
+        ctx.low = low
         return out
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, dout):
         x, idx, g = ctx.saved_tensors
         m, k = idx.shape
         n, c = x.shape
-        dout = dout.contiguous().float()
+        dout = dout.to(x.dtype).contiguous()
         need_x, _, need_g = ctx.needs_input_grad
         dxg = torch.empty((m * k, c), device=x.device, dtype=torch.float32) if need_x else None
         dg = torch.empty((m, k, 16), device=x.device, dtype=torch.float32) if need_g else None
         if need_x or need_g:
-            _lib.check(_lib.lib().pps_neighbour_contract_bwd_f32(x.data_ptr(), idx.data_ptr(), g.data_ptr(), dout.data_ptr(), m, k, c,
-                                                                 dxg.data_ptr() if need_x else None, dg.data_ptr() if need_g else None,
-                                                                 _stream()), 'pps_neighbour_contract_bwd_f32')
+            _lib.check(_lib.lib().pps_neighbour_contract_bwd(x.data_ptr(), idx.data_ptr(), g.data_ptr(), dout.data_ptr(), m, k, c,
+                                                             _code(x.dtype) if ctx.low else 0, dxg.data_ptr() if need_x else None,
+                                                             dg.data_ptr() if need_g else None, _stream()), 'pps_neighbour_contract_bwd')
         dx = None
         if need_x:
             order, offsets = csr(idx.view(-1), n)
@@ -723,4 +729,4 @@ def neighbour_max(x, idx):
 
 
 def neighbour_contract(x, idx, g):
-    return _NeighbourContract.apply(x.float(), idx, g.float())
+    return _NeighbourContract.apply(x, idx, g)

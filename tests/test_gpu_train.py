@@ -73,6 +73,31 @@ def test_neighbour_contract_fwd_bwd(n, m, k, c, xgrad):
         torch.testing.assert_close(gx, x.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('n,m,k,c', [(800, 200, 16, 32), (64, 16, 4, 256), (500, 333, 9, 64), (50, 20, 16, 24)])
+def test_neighbour_contract_16_bit_storage(n, m, k, c, dt):
+    """x, out and the incoming gradient in the autocast type (c % 16 == 0: read and written as they are; c = 24: up-cast, fp32 out), fp32 products:
+    against the double-precision op on the SAME stored values, the result rounded once."""
+    from ppsurf_amd import train_ops
+    rng = np.random.default_rng(c + k)
+    x = torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32)).to(DEV).to(dt).requires_grad_(True)
+    g = torch.from_numpy(rng.standard_normal((m, k, 16)).astype(np.float32)).to(DEV).requires_grad_(True)
+    idx = _rand_table(rng, m, k, n)
+    out = train_ops.neighbour_contract(x, idx, g)
+    native = c % 16 == 0
+    assert out.dtype == (dt if native else torch.float32)
+    xd, gd = x.detach().double().requires_grad_(True), g.detach().double().requires_grad_(True)
+    want = ref.neighbour_contract(xd, idx, gd)
+    ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    torch.testing.assert_close(out.double(), want, rtol=1.01 * ulp if native else 1e-5, atol=1e-5)
+    w = torch.from_numpy(rng.standard_normal((m, c * 16)).astype(np.float32)).to(DEV).to(out.dtype)
+    (out.float() * w.float()).sum().backward()
+    (want * w.double()).sum().backward()
+    torch.testing.assert_close(g.grad.double(), gd.grad, rtol=1e-4, atol=1e-4 * float(gd.grad.abs().max()))
+    assert x.grad.dtype == dt
+    torch.testing.assert_close(x.grad.double(), xd.grad, rtol=2 * ulp, atol=ulp * float(xd.grad.abs().max()))
+
+
 @pytest.mark.parametrize('act,b,n,m,k,mom', [(2.0, 3, 400, 150, 16, 0.1), (1.0, 1, 200, 200, 16, 0.0), (2.0, 2, 90, 37, 4, 0.1),
                                              (1.0, 2, 64, 256, 1, 0.1), (2.0, 10, 2000, 500, 16, 0.1)])
 def test_fka_geometry_fwd_bwd(act, b, n, m, k, mom):
