@@ -52,19 +52,22 @@ def main():
         net = modules.PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=50, pointnet_latent_size=256)
         net.load_state_dict(network_state_dict('ppsurf'))
     net = net.to(dev).train()
-    opt = torch.optim.AdamW(net.parameters(), lr=1e-3, eps=1e-5, weight_decay=1e-2, fused=True)       # like ppsurf_amd.fit
+    from ppsurf_amd import optim, sharding
+    opt = optim.AdamW(net.parameters(), lr=1e-3, eps=1e-5, weight_decay=1e-2)                         # like ppsurf_amd.fit: one-launch AdamW on the
+    buckets = sharding.GradBuckets([p for p in net.parameters() if p.requires_grad])                  # gradients kept in flat buffers
 
     def step(i, times=None):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record()
         batch = prepare(make_batch_cached[i % len(make_batch_cached)].copy(), 0 if a.poco else 50)
         ev[1].record()
-        opt.zero_grad(set_to_none=True)
+        buckets.zero()
         with torch.autocast('cuda', dtype=torch.bfloat16, enabled=a.bf16):
             logits = net.forward(batch)
             loss = torch.nn.functional.cross_entropy(logits.float(), batch['occ'], reduction='none').mean()
         ev[2].record()
         loss.backward()
+        buckets.finish()
         ev[3].record()
         opt.step()
         ev[4].record()
