@@ -50,6 +50,31 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// ---- value of lane (l ^ st) without the LDS crossbar -------------------------------------------------
+// A bitonic network over the 64 lanes is a chain of dependent exchanges; as ds_bpermute each costs an LDS round trip (the kNN kernels spend
+// more time in their merge networks than in the distance tests).  Strides 1 and 2 are quad permutations, 4 and 8 two DPP moves
+// (l ^ 4 = (l ^ 7) ^ 3: row_half_mirror, then the quad reversed;  l ^ 8 = (l ^ 15) ^ 7: row_mirror, then row_half_mirror), 16 and 32 the
+// gfx950 row / half swaps (v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second,
+// v_permlane32_swap the upper half of the first with the lower half of the second: with the same value in both, the partner's value is in
+// the second result for lanes whose stride bit is clear and in the first for the others).  `st` must be a compile-time constant after
+// unrolling for the switch to fold.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_mov_u32(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned lane_xor_u32(unsigned v, int st, int lane) {
+    switch (st) {
+    case 1: return dpp_mov_u32<0xB1>(v);
+    case 2: return dpp_mov_u32<0x4E>(v);
+    case 4: return dpp_mov_u32<0x1B>(dpp_mov_u32<0x141>(v));
+    case 8: return dpp_mov_u32<0x141>(dpp_mov_u32<0x140>(v));
+    case 16: { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return (lane & 16) ? r[0] : r[1]; }
+    case 32: { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (lane & 32) ? r[0] : r[1]; }
+    default: return (unsigned)__shfl_xor((int)v, st);
+    }
+}
+__device__ __forceinline__ unsigned long long lane_xor_u64(unsigned long long v, int st, int lane) {
+    return ((unsigned long long)lane_xor_u32((unsigned)(v >> 32), st, lane) << 32) | lane_xor_u32((unsigned)v, st, lane);
+}
+
 // Sum over the 16 rows of EVERY channel of a 16-block tile (64 registers) in 240 instead of 576 VALU ops: a butterfly in
 // which each step halves the number of live registers (lanes with the step's bit set keep the upper half of the blocks and
 // hand the lower half to their partner, and vice versa).  On return lane (n,g) holds in v[0] the sums of block n:

@@ -37,7 +37,7 @@ __device__ __forceinline__ u64 wave_sort64(u64 key, int lane) {
     for (int size = 2; size <= 64; size <<= 1) {
 #pragma unroll
         for (int st = size >> 1; st > 0; st >>= 1) {
-            const u64 other = shfl_xor_u64(key, st);
+            const u64 other = pps::lane_xor_u64(key, st, lane);
             const bool up = ((lane & size) == 0);          // ascending block
             const bool lower = ((lane & st) == 0);
             const bool take_min = (up == lower);
@@ -51,7 +51,7 @@ __device__ __forceinline__ u64 wave_sort64(u64 key, int lane) {
 __device__ __forceinline__ u64 wave_bitonic_merge64(u64 key, int lane) {
 #pragma unroll
     for (int st = 32; st > 0; st >>= 1) {
-        const u64 other = shfl_xor_u64(key, st);
+        const u64 other = pps::lane_xor_u64(key, st, lane);
         const bool lower = ((lane & st) == 0);
         const u64 mn = key < other ? key : other, mx = key < other ? other : key;
         key = lower ? mn : mx;

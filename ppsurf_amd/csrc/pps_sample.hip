@@ -232,7 +232,7 @@ __device__ __forceinline__ u64 km_sort64(u64 key, int lane) {
     for (int size = 2; size <= 64; size <<= 1)
 #pragma unroll
         for (int st = size >> 1; st > 0; st >>= 1) {
-            const u64 other = km_shfl_xor(key, st);
+            const u64 other = pps::lane_xor_u64(key, st, lane);
             const bool take_min = (((lane & size) == 0) == ((lane & st) == 0));
             const u64 mn = key < other ? key : other, mx = key < other ? other : key;
             key = take_min ? mn : mx;
@@ -242,7 +242,7 @@ __device__ __forceinline__ u64 km_sort64(u64 key, int lane) {
 __device__ __forceinline__ u64 km_merge64(u64 key, int lane) {
 #pragma unroll
     for (int st = 32; st > 0; st >>= 1) {
-        const u64 other = km_shfl_xor(key, st);
+        const u64 other = pps::lane_xor_u64(key, st, lane);
         const u64 mn = key < other ? key : other, mx = key < other ? other : key;
         key = ((lane & st) == 0) ? mn : mx;
     }
@@ -260,6 +260,7 @@ __device__ __forceinline__ u64 km_flush(u64 list, const u64* cand, int cnt, int 
     return list;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define KM_QW 8
 #define KM_WAVES 4
 #define KM_CAP 128
@@ -289,10 +290,21 @@ __global__ __launch_bounds__(KM_WAVES * 64) void knn_multi_kernel(const KnnMulti
             const bool pv = p < n;
             const int pc = pv ? p : n - 1;
             const float px = pts[3 * pc], py = pts[3 * pc + 1], pz = pts[3 * pc + 2];
+            // squared distances of the wave's 8 queries to this lane's point, TWO queries per instruction (v_pk_add_f32 / v_pk_mul_f32: the
+            // scan, not the merge networks, is 2/3 of this kernel for k = 16).  Same operations in the same order as the scalar form
+            // ((dx dx + dy dy) + dz dz, every step rounded: the build has -ffp-contract=off), so the keys -- and the tables -- are unchanged.
+            float d2s[KM_QW];
+#pragma unroll
+            for (int j = 0; j < KM_QW; j += 2) {
+                const f32x2 dx = f32x2{qx[j], qx[j + 1]} - f32x2{px, px}, dy = f32x2{qy[j], qy[j + 1]} - f32x2{py, py},
+                            dz = f32x2{qz[j], qz[j + 1]} - f32x2{pz, pz};
+                const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+                d2s[j] = d.x;
+                d2s[j + 1] = d.y;
+            }
 #pragma unroll
             for (int j = 0; j < KM_QW; ++j) {
-                const float dx = __fsub_rn(qx[j], px), dy = __fsub_rn(qy[j], py), dz = __fsub_rn(qz[j], pz);
-                const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                const float d2 = d2s[j];
                 const bool pass = pv && (d2 < tau[j]);
                 const u64 mask = __ballot(pass);
                 if (mask != 0ull) {

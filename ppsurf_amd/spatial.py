@@ -173,8 +173,12 @@ def sampling_quantized(pts_batch, ratio=None, n_support=None, support_points=Non
 BLOCKED_MIN_POINTS = 16384
 
 
-def _tables_batch(levels, segmentation=True):
+def _tables_batch(levels, segmentation=True, picks=None):
     """The 9 (+4) kNN tables of a batch of equally sized clouds from its 5 levels ([B,n_a,3] each) -> {name: int64 [B,m,k]}.
+    picks[a] (int64 [B,n_{a+1}], or None): which points of level a became level a+1.  A support point IS a point of its level (same
+    coordinates, bit for bit), so its neighbours within that level are the row of the level's own table: ids{a}{a+1} = ids{a}{a}[picks[a]]
+    is a gather instead of a search (the reference searches again, poco_data_loader.py:171-186, and finds the same rows) -- 17 % of the
+    distance tests of the 13 tables.
     Tables over large levels (>= BLOCKED_MIN_POINTS points per cloud) go through the block-culling
     search in ONE launch (pps_knn_blocked_batch_f32; their query sets are visited in Morton order), the small ones through the
     exhaustive pps_knn_multi_f32.  Same results either way (bit-identical indices, tests/test_gpu_sampling.py)."""
@@ -186,6 +190,11 @@ def _tables_batch(levels, segmentation=True):
             todo.append(('ids{}{}'.format(a, a + 1), a, a + 1, 16))
             if segmentation:
                 todo.append(('ids{}{}'.format(a + 1, a), a + 1, a, 1))
+    derived = []
+    if picks is not None:
+        derived = [(a, name) for name, pa, qa, k in todo for a in [pa] if qa == pa + 1 and k == 16 and picks[a] is not None]
+        names = {name for _, name in derived}
+        todo = [t for t in todo if t[0] not in names]
     blocked = {a: ops.BlockedLevel(levels[a]) for a in range(5) if levels[a].shape[1] >= BLOCKED_MIN_POINTS}
     big = [(name, pa, qa, k) for name, pa, qa, k in todo if pa in blocked]
     small = [(name, pa, qa, k) for name, pa, qa, k in todo if pa not in blocked]
@@ -202,6 +211,9 @@ def _tables_batch(levels, segmentation=True):
         outs = ops.knn_batch_point_major(ps, qs, ks)
         for i, (name, _, _, _) in enumerate(small):
             ret[name] = torch.stack(outs[i * nb:(i + 1) * nb], dim=0)
+    for a, name in derived:
+        own = ret['ids{}{}'.format(a, a)]
+        ret[name] = torch.gather(own, 1, picks[a].unsqueeze(-1).expand(-1, -1, own.shape[2]))
     return ret
 
 
@@ -216,17 +228,20 @@ def get_fkaconv_ids(data, segmentation: bool = True):
         # the 13 tables of up to 4 clouds per kNN launch
         nb = pts.shape[0]
         levels = [pts.transpose(1, 2).contiguous().float()]                  # [B,n,3]
+        picks = []
         for _ in range(4):
             cur = levels[-1]
             n = cur.shape[1]
             target = max(1, int(n * 0.25))
             if target == n or n < 2:
                 levels.append(cur)
+                picks.append(None)
             else:
                 ids = voxel_sample_batch_point_major(cur, target)
                 levels.append(torch.gather(cur, 1, ids.unsqueeze(-1).expand(nb, target, 3)).contiguous())
+                picks.append(ids)
         ret = {}
-        for name, t in _tables_batch(levels, segmentation).items():
+        for name, t in _tables_batch(levels, segmentation, picks).items():
             ret[name] = t.squeeze(0) if unbatched else t
         for a in range(1, 5):
             t = levels[a].transpose(1, 2).contiguous()

@@ -116,14 +116,19 @@ def test_batched_block_culling_tables_equal_exhaustive_search(n, b, monkeypatch)
     including level sizes that are no multiple of 64 and levels just above / below the switch-over."""
     rng = np.random.default_rng(n)
     levels = [torch.from_numpy(np.stack([make_cloud(n, seed=100 * n + i) for i in range(b)])).to(DEV)]
+    picks = []
     for _ in range(4):
         cur = levels[-1]
         m = max(1, int(cur.shape[1] * 0.25))
-        sel = torch.from_numpy(np.stack([np.sort(rng.choice(cur.shape[1], m, replace=False)) for _ in range(b)])).to(DEV)
+        sel = torch.from_numpy(np.stack([rng.choice(cur.shape[1], m, replace=False) for _ in range(b)])).to(DEV)
         levels.append(torch.gather(cur, 1, sel.unsqueeze(-1).expand(b, m, 3)).contiguous())
+        picks.append(sel)
     monkeypatch.setattr(spatial, 'BLOCKED_MIN_POINTS', 1024)
     tables = spatial._tables_batch(levels)
     assert len(tables) == 13
+    # the tables from a level to its support points taken as rows of the level's own table (picks given) are the searched ones
+    short = spatial._tables_batch(levels, picks=picks)
+    assert set(short) == set(tables) and all(torch.equal(short[k], tables[k]) for k in tables)
     for name, t in tables.items():
         pa, qa = int(name[3]), int(name[4])
         k = min(1 if pa == qa + 1 else 16, levels[pa].shape[1])
