@@ -5,8 +5,9 @@
 `torch.amp.GradScaler` (`grad_scale` / `found_inf` are honoured inside the kernel, nothing is read back) and with HIP-graph capture
 (`capturable=True`: learning rate and step counts live on the device).  Only `step()` differs: instead of torch's multi-tensor kernels
 (nine launches, 0.78 ms for the 298 tensors / 13.7 M parameters of PPSurf) it launches one kernel over a device table of 4096-element
-pieces of all parameters (0.15 ms).  The table holds raw pointers, so it is rebuilt whenever a parameter, gradient or state tensor moved;
-ppsurf_amd.fit keeps the gradients in the flat buffers of sharding.GradBuckets, where they do not move.  Whatever the fast path does not
+pieces of all parameters (0.064 ms).  The table holds raw pointers, so it is rebuilt whenever a parameter, gradient or state tensor moved;
+ppsurf_amd.fit keeps the gradients in the flat buffers of sharding.GradBuckets, where they do not move (a caller whose gradients are allocated
+anew by every backward pass is handed to torch's step after eight rebuilds in a row: the host-side rebuild costs more than it saves).  Whatever the fast path does not
 take (CPU tensors, non-fp32 or non-contiguous parameters, amsgrad / maximize, a table that would have to be rebuilt while a graph is being
 captured) goes through torch's own step.
 
@@ -26,6 +27,7 @@ class AdamW(torch.optim.AdamW):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, maximize=maximize, foreach=None,
                          capturable=capturable, differentiable=differentiable, fused=True)
         self._tables = {}        # group index -> (signature, pieces tensor, step-pointer tensor, n_pieces, n_steps, (param, grad) pointers)
+        self._moved = 0          # consecutive steps that had to rebuild a table (gradients allocated anew by every backward pass)
         self.fast_steps = 0      # steps taken by the HIP kernel (tests / diagnostics)
 
     # ---- fast path ------------------------------------------------------------------------------------------------------------------
@@ -59,7 +61,13 @@ class AdamW(torch.optim.AdamW):
         quick = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
         cached = self._tables.get(gi)
         if cached is not None and cached[5] == quick:               # state tensors only move through load_state_dict(), which drops the tables
+            self._moved = 0
             return cached
+        if cached is not None:
+            self._moved += 1
+            if self._moved > 8:
+                return None                                          # gradients never stay put (no flat gradient buffers): building a 3600-row
+                                                                     # table on the host every step costs more than torch's nine launches
         sig, rows, step_ptrs = [], [], []
         for p in ps:
             st = self.state[p]

@@ -52,6 +52,16 @@ def test_steps_equal_torchs_fused_adamw_including_parameters_that_skip_steps():
     assert float(mine.state[a[2]]['step']) == 5.0 and float(mine.state[a[0]]['step']) == 6.0 and float(mine.state[a[1]]['step']) == 7.0
 
 
+def test_gradients_that_never_stay_put_end_up_with_torchs_step():
+    a, b, mine, ref = _pair()
+    for step in range(12):
+        _set_grads(a, b, step)                            # fresh gradient tensors every step: the pointer table is rebuilt each time
+        mine.step()
+        ref.step()
+    assert mine.fast_steps == 9                           # the first build + eight rebuilds, then torch's own step
+    _same(a, b, mine, ref)
+
+
 def test_grad_scale_and_found_inf_like_a_fused_optimizer_under_gradscaler():
     a, b, mine, ref = _pair()
     for step, (scale, inf) in enumerate([(1024.0, 0.0), (512.0, 1.0), (512.0, 0.0)]):
