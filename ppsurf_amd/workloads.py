@@ -146,6 +146,7 @@ class FitStep:
         self.opt = optim.AdamW(self.net.parameters(), lr=1e-3, eps=1e-5, weight_decay=1e-2, capturable=graph)   # configs/poco.yaml:60-69, the class ppsurf_amd.fit puts in for torch.optim.AdamW
         self.buckets = sharding.GradBuckets([q for q in self.net.parameters() if q.requires_grad])      # as ppsurf_amd.fit (one rank: no collective)
         self.autocast = {'bf16-mixed': torch.bfloat16, '16-mixed': torch.float16}.get(precision)
+        self.scaler = torch.amp.GradScaler('cuda') if precision == '16-mixed' else None
         self.batches = [self._raw_batch(batch, n, q, s) for s in range(n_batches)]
         self.i = 0
         self.loss = None
@@ -177,9 +178,15 @@ class FitStep:
         with torch.autocast('cuda', dtype=self.autocast or torch.bfloat16, enabled=self.autocast is not None):
             logits = self.net.forward(batch)
             loss = torch.nn.functional.cross_entropy(logits.float(), batch['occ'], reduction='none').mean()
-        loss.backward()
-        self.buckets.finish()
-        self.opt.step()
+        if self.scaler is not None:                     # 16-mixed: loss scaling as ppsurf_amd.fit does it (scale / overflow flag stay on the device)
+            self.scaler.scale(loss).backward()
+            self.buckets.finish()
+            self.scaler.step(self.opt)
+            self.scaler.update()
+        else:
+            loss.backward()
+            self.buckets.finish()
+            self.opt.step()
         train_graph.release_step_caches()
         self.stepper.metrics.values = {'loss': loss.detach()}
 

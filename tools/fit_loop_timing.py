@@ -10,7 +10,7 @@ cfg = dict(BASE); cfg.update(OPT)
 files = []
 for name, c in (('poco', cfg), ('pps', PPS), ('run', {'model': {'init_args': {'name': 'demo'}},
         'data': {'init_args': {'in_file': in_file, 'batch_size': 10, 'manifold_points': 10000}},
-        'trainer': {'max_epochs': NE, 'precision': 'bf16-mixed', 'check_val_every_n_epoch': 0}})):
+        'trainer': {'max_epochs': NE, 'precision': os.environ.get('PRECISION', 'bf16-mixed'), 'check_val_every_n_epoch': 0}})):
     files += ['-c', os.path.join(tmp, name + '.yaml')]; yaml.safe_dump(c, open(files[-1], 'w'))
 t0 = time.time(); runner.main(['pps.py', 'fit'] + files); dt = time.time() - t0
 steps = NS // 10 * NE
