@@ -378,6 +378,17 @@ int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t row
                        void* dx, const void* dx_add, float* d_in_affine, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws,
                        void* stream);
 
+/* pps_rows_layer_bwd for a layer whose raw output only feeds a max over the p rows of every group (the last layer of PointNet's STN before
+ * `torch.max(x, 2)`, source/base/nn.py:181): the incoming gradient is ONE value per (group, channel) -- gval [rows / pool_p, cout] in the storage type --
+ * placed in the winning row garg [rows / pool_p, cout] (uint8, 0 <= garg < pool_p) and zero elsewhere; the kernels rebuild the rows of that 98 %-zero
+ * tensor on load instead of reading it from memory (it is never written either).  Same results as pps_rows_layer_bwd on the scattered tensor.
+ * Shapes: pps_rows_layer_pooled_supported(cin, cout, pool_p) (128 -> 256 with BatchNorm, 2 <= pool_p <= 255, rows % pool_p == 0, rows * pool_p < 2^32). */
+int pps_rows_layer_pooled_supported(int cin, int cout, int pool_p);
+int pps_rows_layer_bwd_pooled(const void* x, const void* y, const void* gval, const uint8_t* garg, int pool_p, int64_t rows, int cin, int cout,
+                              int dtype, const float* in_scale, const float* in_shift, int in_relu, const float* w, const float* gamma,
+                              const float* save, const float* d_affine, void* dx, float* d_in_affine, float* dw, float* dbias, float* dgamma,
+                              float* dbeta, void* ws, void* stream);
+
 /* AdamW step over all parameter tensors of a group in one launch: replaces the optimizer step of the reference's trainer
  * (configs/poco.yaml:60-69 torch.optim.AdamW; arithmetic of torch's fused implementation, amsgrad and maximize off).
  * pieces: device array of n_pieces records of pps_adamw_piece_bytes() = 48 bytes {float* param, float* grad, float* exp_avg, float* exp_avg_sq,

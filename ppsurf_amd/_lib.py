@@ -82,6 +82,8 @@ SIGNATURES = {
     'pps_rows_layer_ws_bytes': (_SZ, [_I, _I]),
     'pps_rows_layer_fwd': (_I, [_P, _I64, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _c.c_float, _c.c_float, _P, _P, _P, _P]),
     'pps_rows_layer_bwd': (_I, [_P, _P, _P, _I64, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'pps_rows_layer_pooled_supported': (_I, [_I, _I, _I]),
+    'pps_rows_layer_bwd_pooled': (_I, [_P, _P, _P, _P, _I, _I64, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pps_bn_train_ws_bytes': (_SZ, [_I64, _I]),
     'pps_bn_train_fwd': (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _c.c_float, _c.c_float, _I, _P, _P, _P, _P]),
     'pps_bn_train_bwd': (_I, [_P, _P, _I64, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),

@@ -96,5 +96,13 @@ int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t row
     return PPS_BY_TYPE(pps_rows_layer_bwd(x, y, gy, rows, cin, cout, in_scale, in_shift, in_relu, w, gamma, save, d_affine, dx, dx_add, d_in_affine, dw, dbias,
                                           dgamma, dbeta, ws, stream));
 }
+int pps_rows_layer_pooled_supported(int cin, int cout, int pool_p) { return rt_bf16::pps_rows_layer_pooled_supported(cin, cout, pool_p); }
+int pps_rows_layer_bwd_pooled(const void* x, const void* y, const void* gval, const uint8_t* garg, int pool_p, int64_t rows, int cin, int cout,
+                              int dtype, const float* in_scale, const float* in_shift, int in_relu, const float* w, const float* gamma,
+                              const float* save, const float* d_affine, void* dx, float* d_in_affine, float* dw, float* dbias, float* dgamma,
+                              float* dbeta, void* ws, void* stream) {
+    return PPS_BY_TYPE(pps_rows_layer_bwd_pooled(x, y, gval, garg, pool_p, rows, cin, cout, in_scale, in_shift, in_relu, w, gamma, save, d_affine, dx,
+                                                 d_in_affine, dw, dbias, dgamma, dbeta, ws, stream));
+}
 
 }  // extern "C"

@@ -81,14 +81,34 @@ struct LayerArgs {
     uint16_t* dst;                // fwd: y [rows, CO]            dx: dx [rows, CO]
     float* partials;              // [gridDim.x][2][CO] or NULL: fwd (sum y, sum y^2); dx (sum d * x, sum d)
     int64_t rows;
+    const uint8_t* garg;          // dx, POOL: winning row of every (group, channel) [rows / pool_p, CK]; src is then the gradient per GROUP
+    int pool_p;                   // dx, POOL: rows per group
+    unsigned pool_magic;          // floor(2^32 / pool_p) + 1
 };
+
+// The incoming gradient of a layer whose output only feeds a max over the p rows of every group (the STN of PointNet, source/base/nn.py:181) is
+// one value per (group, channel), placed in the winning row: 8 channels of row `row` are rebuilt from the group's 16 bytes of gradient and
+// 8 bytes of winners (both stay in the caches: every group is read by its p rows) instead of streaming a [rows, C] tensor that is 98 % zeros.
+// row / pool_p as a multiply-high with magic = floor(2^32 / p) + 1: exact while rows * p < 2^32 (checked by the host), no division sequence
+// in the load path of a kernel whose staging arithmetic is what limits it
+__device__ __forceinline__ u32x4 pooled_grad8(const uint16_t* gval, const uint8_t* garg, int pool_p, unsigned magic, int64_t row, int c, int col8) {
+    const unsigned grp = __umulhi((unsigned)row, magic), r = (unsigned)row - grp * (unsigned)pool_p;
+    const u32x4 d = *(const u32x4*)(gval + (int64_t)grp * c + col8);
+    const u32x2 w = *(const u32x2*)(garg + (int64_t)grp * c + col8);
+    u32x4 o;
+    o.x = ((w.x & 0xffu) == r ? d.x & 0xffffu : 0u) | (((w.x >> 8) & 0xffu) == r ? d.x & 0xffff0000u : 0u);
+    o.y = (((w.x >> 16) & 0xffu) == r ? d.y & 0xffffu : 0u) | ((w.x >> 24) == r ? d.y & 0xffff0000u : 0u);
+    o.z = ((w.y & 0xffu) == r ? d.z & 0xffffu : 0u) | (((w.y >> 8) & 0xffu) == r ? d.z & 0xffff0000u : 0u);
+    o.w = (((w.y >> 16) & 0xffu) == r ? d.w & 0xffffu : 0u) | ((w.y >> 24) == r ? d.w & 0xffff0000u : 0u);
+    return o;
+}
 
 // R = 16-row tiles a wave carries through the weights together: 2, except 1 in the input-gradient kernel with 128 channels per wave,
 // whose epilogue (x, scale, shift, two sums per channel) would not fit the registers next to two tiles of accumulators
 template <int CO, bool DX>
 constexpr int tiles_of() { return (DX && CO >= 128) ? 1 : 2; }
 
-template <int CK, int CO, bool DX>
+template <int CK, int CO, bool DX, bool POOL = false>
 __global__ __launch_bounds__(NT, 1) void rows_layer_kernel(const LayerArgs a) {
     constexpr int R = tiles_of<CO, DX>();
     constexpr int KS = CK / 32;                     // k-steps of 32 channels
@@ -168,7 +188,8 @@ __global__ __launch_bounds__(NT, 1) void rows_layer_kernel(const LayerArgs a) {
             for (int sc = 0; sc < KC; ++sc)
 #pragma unroll
                 for (int t = 0; t < R; ++t) {
-                    raw[sc][t] = *(const u32x4*)(a.src + rowc[t] * CK + 32 * (s0 + sc) + 8 * g);
+                    if constexpr (POOL) raw[sc][t] = pooled_grad8(a.src, a.garg, a.pool_p, a.pool_magic, rowc[t], CK, 32 * (s0 + sc) + 8 * g);
+                    else raw[sc][t] = *(const u32x4*)(a.src + rowc[t] * CK + 32 * (s0 + sc) + 8 * g);
                     if (dx_y) raw2[sc][t] = *(const u32x4*)(a.src2 + rowc[t] * CK + 32 * (s0 + sc) + 8 * g);
                 }
 #pragma unroll
@@ -322,6 +343,9 @@ struct DwArgs {
     float* dw_part;               // [gridDim.x][CO][CI]
     float* db_part;               // [gridDim.x][CO]
     int64_t rows;
+    const uint8_t* garg;          // POOL: gy is the gradient per group [rows / pool_p, CO], garg the winning rows (see pooled_grad8)
+    int pool_p;
+    unsigned pool_magic;
 };
 
 __device__ __forceinline__ u32x2 lds_tr_read(const uint16_t* p) {
@@ -335,7 +359,7 @@ __device__ __forceinline__ void lds_tr_wait(u32x2& v) { asm volatile("s_waitcnt 
 template <int CI, int CO>
 constexpr int dw_ksteps() { return CI + CO <= 128 ? 4 : (CI + CO <= 384 ? 2 : 1); }
 
-template <int CI, int CO, bool HAS_Y>
+template <int CI, int CO, bool HAS_Y, bool POOL = false>
 __global__ __launch_bounds__(NT, 1) void rows_dw_kernel(const DwArgs a) {
     constexpr int KRS = dw_ksteps<CI, CO>();        // MFMA contraction steps (32 rows each) per staged tile: narrow layers stage more rows per barrier
     constexpr int KR = 32 * KRS;                    // rows per step
@@ -393,7 +417,8 @@ __global__ __launch_bounds__(NT, 1) void rows_dw_kernel(const DwArgs a) {
             const int row = id / (CO / 8), ch = id % (CO / 8);
             const int64_t rr = r0 + row < a.rows ? r0 + row : a.rows - 1;     // rows past the end re-read the last row (zeroed when staged): no
             if (id < GCH) {                                                  // lane-dependent branch around the loads, they all issue back to back
-                rg[it] = *(const u32x4*)(a.gy + rr * CO + 8 * ch);
+                if constexpr (POOL) rg[it] = pooled_grad8(a.gy, a.garg, a.pool_p, a.pool_magic, rr, CO, 8 * ch);
+                else rg[it] = *(const u32x4*)(a.gy + rr * CO + 8 * ch);
                 if constexpr (HAS_Y) ry[it] = *(const u32x4*)(a.y + rr * CO + 8 * ch);
             }
         }
@@ -1022,20 +1047,20 @@ int grid_for(int64_t units) {
 template <typename K>
 bool allow_lds(K kernel, size_t bytes) { return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess; }
 
-template <int CK, int CO, bool DX>
+template <int CK, int CO, bool DX, bool POOL = false>
 int launch_layer(const LayerArgs& a, int grid, hipStream_t st) {
-    static bool ok = allow_lds(rows_layer_kernel<CK, CO, DX>, layer_lds<CK, CO>());
+    static bool ok = allow_lds(rows_layer_kernel<CK, CO, DX, POOL>, layer_lds<CK, CO>());
     if (!ok) return PPS_ERR_LAUNCH;
     constexpr size_t lds = layer_lds<CK, CO>();
-    hipLaunchKernelGGL((rows_layer_kernel<CK, CO, DX>), dim3(grid), dim3(NT), lds, st, a);
+    hipLaunchKernelGGL((rows_layer_kernel<CK, CO, DX, POOL>), dim3(grid), dim3(NT), lds, st, a);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
-template <int CI, int CO, bool HAS_Y>
+template <int CI, int CO, bool HAS_Y, bool POOL = false>
 int launch_dw_y(const DwArgs& a, int grid, hipStream_t st) {
-    static bool ok = allow_lds(rows_dw_kernel<CI, CO, HAS_Y>, dw_lds<CI, CO>());
+    static bool ok = allow_lds(rows_dw_kernel<CI, CO, HAS_Y, POOL>, dw_lds<CI, CO>());
     if (!ok) return PPS_ERR_LAUNCH;
     constexpr size_t lds = dw_lds<CI, CO>();
-    hipLaunchKernelGGL((rows_dw_kernel<CI, CO, HAS_Y>), dim3(grid), dim3(NT), lds, st, a);
+    hipLaunchKernelGGL((rows_dw_kernel<CI, CO, HAS_Y, POOL>), dim3(grid), dim3(NT), lds, st, a);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 template <int CI, int CO>
@@ -1219,14 +1244,21 @@ int pps_rows_layer_fwd(const void* x, int64_t rows, int cin, const float* in_sca
     return PPS_OK;
 }
 
-int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t rows, int cin, int cout, const float* in_scale,
-                       const float* in_shift, int in_relu, const float* w, const float* gamma, const float* save, const float* d_affine,
-                       void* dx, const void* dx_add, float* d_in_affine, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws,
-                       void* stream) {
+// the shapes whose gradient may arrive per group (pps_rows_layer_bwd_pooled): the last layer of PointNet's STN, 128 -> 256 with BatchNorm
+bool pooled_ok(int cin, int cout, bool bn, int pool_p, int64_t rows) {
+    return cin == 128 && cout == 256 && bn && pool_p >= 2 && pool_p <= 255 && rows % pool_p == 0 && rows * pool_p < (int64_t)1 << 32;
+}
+
+int rows_layer_bwd_any(const void* x, const void* y, const void* gy, const uint8_t* garg, int pool_p, int64_t rows, int cin, int cout,
+                       const float* in_scale, const float* in_shift, int in_relu, const float* w, const float* gamma, const float* save,
+                       const float* d_affine, void* dx, const void* dx_add, float* d_in_affine, float* dw, float* dbias, float* dgamma, float* dbeta,
+                       void* ws, void* stream) {
     if (rows < 1 || !dim_ok(cin) || !dim_ok(cout)) return PPS_ERR_ARG;
     if (!x || !gy || !w || !ws || ((in_scale == nullptr) != (in_shift == nullptr))) return PPS_ERR_ARG;
     const bool bn = gamma != nullptr;
     if (bn && (!y || !save || !d_affine || !dgamma || !dbeta)) return PPS_ERR_ARG;
+    const bool pool = pool_p != 0;
+    if (pool && (!garg || !pooled_ok(cin, cout, bn, pool_p, rows))) return PPS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const size_t big = (size_t)(cin > cout ? cin : cout);
     float* part_aff = (float*)ws;                                       // [MAXP][2][big]
@@ -1255,7 +1287,11 @@ int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t row
         a.addend = (const uint16_t*)dx_add;
         a.partials = d_in_affine ? part_aff : nullptr;
         a.rows = rows;
-        PPS_DISPATCH(cin, cout, rc = (launch_layer<O, I, true>(a, grid, st)));
+        a.garg = garg;
+        a.pool_p = pool_p;
+        a.pool_magic = pool ? (unsigned)(0x100000000ull / (unsigned)pool_p) + 1u : 0u;
+        if (pool) rc = launch_layer<256, 128, true, true>(a, grid, st);
+        else PPS_DISPATCH(cin, cout, rc = (launch_layer<O, I, true>(a, grid, st)));
         if (rc != PPS_OK) return rc;
         if (d_in_affine) {
             launch_sum_partials(part_aff, grid, (int64_t)2 * cin, d_in_affine, st);
@@ -1281,7 +1317,11 @@ int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t row
         a.dw_part = part_dw;
         a.db_part = dbias ? part_db : nullptr;
         a.rows = rows;
-        PPS_DISPATCH(cin, cout, rc = (launch_dw<I, O>(a, grid, st)));
+        a.garg = garg;
+        a.pool_p = pool_p;
+        a.pool_magic = pool ? (unsigned)(0x100000000ull / (unsigned)pool_p) + 1u : 0u;
+        if (pool) rc = launch_dw_y<128, 256, true, true>(a, grid, st);
+        else PPS_DISPATCH(cin, cout, rc = (launch_dw<I, O>(a, grid, st)));
         if (rc != PPS_OK) return rc;
         const int64_t nw = (int64_t)cin * cout;
         launch_sum_partials(part_dw, grid, nw, dw, st);
@@ -1290,6 +1330,25 @@ int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t row
     }
     return PPS_OK;
 }
+
+int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t rows, int cin, int cout, const float* in_scale,
+                       const float* in_shift, int in_relu, const float* w, const float* gamma, const float* save, const float* d_affine,
+                       void* dx, const void* dx_add, float* d_in_affine, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws,
+                       void* stream) {
+    return rows_layer_bwd_any(x, y, gy, nullptr, 0, rows, cin, cout, in_scale, in_shift, in_relu, w, gamma, save, d_affine, dx, dx_add, d_in_affine, dw,
+                              dbias, dgamma, dbeta, ws, stream);
+}
+
+int pps_rows_layer_bwd_pooled(const void* x, const void* y, const void* gval, const uint8_t* garg, int pool_p, int64_t rows, int cin, int cout,
+                              const float* in_scale, const float* in_shift, int in_relu, const float* w, const float* gamma, const float* save,
+                              const float* d_affine, void* dx, float* d_in_affine, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws,
+                              void* stream) {
+    if (pool_p == 0) return PPS_ERR_ARG;
+    return rows_layer_bwd_any(x, y, gval, garg, pool_p, rows, cin, cout, in_scale, in_shift, in_relu, w, gamma, save, d_affine, dx, nullptr, d_in_affine,
+                              dw, dbias, dgamma, dbeta, ws, stream);
+}
+
+int pps_rows_layer_pooled_supported(int cin, int cout, int pool_p) { return pooled_ok(cin, cout, true, pool_p, (int64_t)pool_p) ? 1 : 0; }
 
 
 #undef PPS_MFMA16

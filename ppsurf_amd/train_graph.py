@@ -453,8 +453,13 @@ def _stn_fused(t, act, nq, p):
     d = t.dim
     z = _layer(act, t.conv1, t.bn1, True)
     z = _layer(z, t.conv2, t.bn2, True)
-    z = _layer(z, t.conv3, t.bn3, True)
-    z = train_ops.act_max(z, nq, p)
+    w3 = _w2d(t.conv3)
+    if train_ops.rows_layer_max_supported(z.raw.shape[0], w3.shape[1], w3.shape[0], nq, p):
+        _count_batch(t.bn3)
+        z = train_ops.rows_layer_max(z, w3, t.conv3.bias, t.bn3, True, nq, p)      # conv3 + bn3 + relu + max over the patch: the gradient goes back per patch
+    else:
+        z = _layer(z, t.conv3, t.bn3, True)
+        z = train_ops.act_max(z, nq, p)
     z = batch_norm(t.bn4, dense(t.fc1, z), relu=True)
     z = batch_norm(t.bn5, dense(t.fc2, z), relu=True)
     return dense(t.fc3, z).view(nq, d, d)                  # WITHOUT the identity (:188): the feature transform adds it on load

@@ -453,6 +453,77 @@ class _RowsLayer(torch.autograd.Function):
         return (dx if need_dx else None, d_in, None, dw.to(wdt), None if db is None else db.to(bdt), dgamma, dbeta, None, None, None, None)
 
 
+class _RowsLayerMax(torch.autograd.Function):
+    """rows_layer (with BatchNorm statistics) followed by act_max over the p rows of every group, as ONE node: the raw output is stored (its
+    own backward needs it), but the gradient that comes back is one value per (group, channel) in the winning row -- pps_rows_layer_bwd_pooled
+    rebuilds those rows on load, so the [rows, cout] gradient tensor (98 % zeros at p = 50) is neither written nor read (three passes over
+    512 MB per step for the STN of PointNet).  Returns the activated maxima [groups, cout] fp32."""
+
+    @staticmethod
+    def forward(ctx, x, in_affine, in_relu, w, b, gamma, beta, running_mean, running_var, momentum, eps, relu, groups, p):
+        _need_cuda(x, w)
+        L = _lib.lib()
+        x = _low(x)
+        rows, cin = x.shape
+        cout = w.shape[0]
+        dev = x.device
+        w32 = w.detach().float().contiguous()
+        b32 = None if b is None else b.detach().float().contiguous()
+        aff = None if in_affine is None else in_affine.detach().float().contiguous()
+        g32, be32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        y = torch.empty((rows, cout), device=dev, dtype=x.dtype)
+        out_affine = torch.empty((2, cout), device=dev, dtype=torch.float32)
+        save = torch.empty((2, cout), device=dev, dtype=torch.float32)
+        ws = torch.empty((L.pps_rows_layer_ws_bytes(cin, cout),), device=dev, dtype=torch.uint8)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        _lib.check(L.pps_rows_layer_fwd(x.data_ptr(), rows, cin, _code(x.dtype), ptr(aff), None if aff is None else aff.data_ptr() + 4 * cin, int(bool(in_relu)),
+                                        w32.data_ptr(), ptr(b32), cout, y.data_ptr(), g32.data_ptr(), be32.data_ptr(), ptr(running_mean), ptr(running_var),
+                                        float(momentum or 0.0), float(eps or 0.0), out_affine.data_ptr(), save.data_ptr(), ws.data_ptr(), _stream()),
+                   'pps_rows_layer_fwd')
+        mx, mn = torch.empty((groups, cout), device=dev), torch.empty((groups, cout), device=dev)
+        amx, amn = torch.empty((groups, cout), device=dev, dtype=torch.int32), torch.empty((groups, cout), device=dev, dtype=torch.int32)
+        _lib.check(L.pps_rows_extrema_16(y.data_ptr(), groups, p, cout, _code(y.dtype), mx.data_ptr(), mn.data_ptr(), amx.data_ptr(), amn.data_ptr(), _stream()),
+                   'pps_rows_extrema_16')
+        scale, shift = out_affine[0], out_affine[1]
+        up = scale >= 0
+        ext, arg = torch.where(up, mx, mn), torch.where(up, amx, amn).to(torch.uint8)
+        out = ext * scale + shift
+        live = None
+        if relu:
+            live = out > 0
+            out = torch.relu(out)
+        ctx.save_for_backward(x, aff, w32, g32, save, y, ext, arg, scale.clone(), live)
+        ctx.meta = (bool(in_relu), b is not None, w.dtype, None if b is None else b.dtype, int(p))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, aff, w32, g32, save, y, ext, arg, scale, live = ctx.saved_tensors
+        in_relu, has_b, wdt, bdt, p = ctx.meta
+        L = _lib.lib()
+        rows, cin = x.shape
+        cout = w32.shape[0]
+        dev = x.device
+        d = dout.float()
+        if live is not None:
+            d = d * live
+        g_affine = torch.stack([(d * ext).sum(0), d.sum(0)]).contiguous()            # gradient of (scale, shift) of this layer's BatchNorm
+        gval = (d * scale).to(x.dtype).contiguous()                                    # gradient of the raw output, per (group, channel)
+        need_dx, need_daff = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and aff is not None
+        dx = torch.empty_like(x) if (need_dx or need_daff) else None
+        d_in = torch.empty((2, cin), device=dev, dtype=torch.float32) if need_daff else None
+        dw = torch.empty((cout, cin), device=dev, dtype=torch.float32)
+        db = torch.empty((cout,), device=dev, dtype=torch.float32) if has_b else None
+        dgamma, dbeta = torch.empty((cout,), device=dev, dtype=torch.float32), torch.empty((cout,), device=dev, dtype=torch.float32)
+        ws = torch.empty((L.pps_rows_layer_ws_bytes(cin, cout),), device=dev, dtype=torch.uint8)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        _lib.check(L.pps_rows_layer_bwd_pooled(x.data_ptr(), y.data_ptr(), gval.data_ptr(), arg.data_ptr(), p, rows, cin, cout, _code(x.dtype), ptr(aff),
+                                               None if aff is None else aff.data_ptr() + 4 * cin, int(in_relu), w32.data_ptr(), g32.data_ptr(), save.data_ptr(),
+                                               g_affine.data_ptr(), ptr(dx), ptr(d_in), dw.data_ptr(), ptr(db), dgamma.data_ptr(), dbeta.data_ptr(),
+                                               ws.data_ptr(), _stream()), 'pps_rows_layer_bwd_pooled')
+        return (dx if need_dx else None, d_in, None, dw.to(wdt), None if db is None else db.to(bdt), dgamma, dbeta, None, None, None, None, None, None, None)
+
+
 class _Rows3Layer(torch.autograd.Function):
     """conv0a of PointNet in train(): x [rows, 3] fp32 -> (y [rows, 64] bf16, out_affine [2, 64] of the BatchNorm on y); x gets no gradient."""
 
@@ -635,6 +706,16 @@ def act_max(act, groups, p):
 
 def rows_layer_supported(rows, cin, cout):
     return rows >= 1 and bool(_lib.lib().pps_rows_layer_supported(int(cin), int(cout)))
+
+
+def rows_layer_max_supported(rows, cin, cout, groups, p):
+    return rows == groups * p and bool(_lib.lib().pps_rows_layer_pooled_supported(int(cin), int(cout), int(p)))
+
+
+def rows_layer_max(act, w, b, bn, relu, groups, p):
+    """act_max(rows_layer(act, w, b, bn, relu), groups, p) as one autograd node (see _RowsLayerMax): -> [groups, cout] fp32."""
+    return _RowsLayerMax.apply(act.raw, act.affine, act.relu, w, b, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                               bool(relu), int(groups), int(p))
 
 
 def rows_layer(act, w, b, bn=None, relu=False):

@@ -253,6 +253,43 @@ def test_act_max_matches_the_materialised_maximum(dt):
 
 
 @pytest.mark.parametrize('dt', DT16)
+@pytest.mark.parametrize('groups,p', [(90, 50), (333, 20), (7, 2), (40, 64), (20000, 50), (1000, 255)])
+def test_layer_and_patch_maximum_as_one_node_equal_the_two_nodes(dt, groups, p):
+    """train_ops.rows_layer_max (the gradient comes back per patch; pps_rows_layer_bwd_pooled rebuilds its rows on load) against
+    act_max(rows_layer(...)) with the scattered [rows, 256] gradient tensor: the same kernels on the same values -- equal outputs and gradients."""
+    from ppsurf_amd import train_ops
+    g = torch.Generator().manual_seed(groups + p)
+    rows = groups * p
+    assert train_ops.rows_layer_max_supported(rows, 128, 256, groups, p) and not train_ops.rows_layer_max_supported(rows, 64, 256, groups, p)
+    assert not train_ops.rows_layer_max_supported(groups, 128, 256, groups, 1) and not train_ops.rows_layer_max_supported(rows + 1, 128, 256, groups, p)
+    x = (torch.randn(rows, 128, generator=g) * 0.7).to(DEV).to(dt)
+    in_aff = torch.stack([torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.3]).to(DEV)
+    bn = torch.nn.BatchNorm1d(256).to(DEV).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(256, generator=g))                     # negative scales: the minimum wins there
+        bn.bias.copy_(torch.randn(256, generator=g) * 0.2)
+    w = (torch.randn(256, 128, generator=g) * 0.1).to(DEV)
+    b = (torch.randn(256, generator=g) * 0.1).to(DEV)
+    go = torch.randn(groups, 256, generator=g).to(DEV)
+    res = []
+    for fused in (True, False):
+        xs, affs, ws, bs = x.clone().requires_grad_(True), in_aff.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        bn.zero_grad(set_to_none=True)
+        bn.running_mean.zero_()
+        bn.running_var.fill_(1.0)
+        act = train_ops.Act(xs, affs, True)
+        if fused:
+            out = train_ops.rows_layer_max(act, ws, bs, bn, True, groups, p)
+        else:
+            out = train_ops.act_max(train_ops.rows_layer(act, ws, bs, bn, True), groups, p)
+        (out * go).sum().backward()
+        res.append((out.detach(), xs.grad, affs.grad, ws.grad, bs.grad, bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(), bn.running_var.clone()))
+    names = ('out', 'dx', 'd_in_affine', 'dw', 'db', 'dgamma', 'dbeta', 'running_mean', 'running_var')
+    for name, a, c in zip(names, res[0], res[1]):
+        assert torch.equal(a, c), (name, float((a.float() - c.float()).abs().max()))
+
+
+@pytest.mark.parametrize('dt', DT16)
 def test_interpolation_head_with_fused_row_layers_is_as_close_to_fp32_as_the_separate_ops(dt):
     import contextlib
     import io
