@@ -261,13 +261,19 @@ __device__ __forceinline__ float4 row4(const T* __restrict__ src, int j, int lan
 
 // lane j: softmax weight of row j (0 beyond k).  The rows are read here for the logits and AGAIN by the caller for the pooling (the
 // 25 KB of a group come from L2 the second time): keeping them in registers costs more in occupancy than the second read.
-template <typename T>
+// KP: rows actually loaded (k <= KP <= 64, a compile-time bound of 16 / 32 / 50 / 64 rows): the re-reads of the last row that fill up to KP all
+// hit ONE address from one wave and serialise in the memory pipeline -- 14 of them (k = 50 under the old fixed bound of 64) cost a quarter of the kernel
+template <typename T, int KP>
 __device__ __forceinline__ float patch_softmax(const T* __restrict__ src, int k, const float4 v4, int lane) {
     float p[PA_K];
 #pragma unroll
     for (int j = 0; j < PA_K; ++j) {                               // no branch around the loads: rows beyond k re-read the last row and are zeroed
-        const float d = dot4(row4(src, j < k ? j : k - 1, lane), v4);
-        p[j] = j < k ? d : 0.f;
+        if (j < KP) {
+            const float d = dot4(row4(src, j < k ? j : k - 1, lane), v4);
+            p[j] = j < k ? d : 0.f;
+        } else {
+            p[j] = 0.f;
+        }
     }
     const float d = rows_to_lanes(p, lane);
     const float logit = lane < k ? d : -INFINITY;
@@ -276,14 +282,14 @@ __device__ __forceinline__ float patch_softmax(const T* __restrict__ src, int k,
     return e / wave_sum(e);
 }
 
-template <typename T>
+template <typename T, int KP>
 __global__ __launch_bounds__(PA_WAVES * 64, 2) void patch_attn_fwd_kernel(const T* __restrict__ h, const float* __restrict__ v, int64_t Q, int k,
                                                                          float* __restrict__ pooled) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4 v4 = *(const float4*)(v + 4 * lane);
     for (int64_t q = (int64_t)blockIdx.x * PA_WAVES + wave; q < Q; q += (int64_t)gridDim.x * PA_WAVES) {
         const T* src = h + q * (int64_t)k * 256;
-        const float a = patch_softmax(src, k, v4, lane);
+        const float a = patch_softmax<T, KP>(src, k, v4, lane);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
         for (int j = 0; j < k; ++j) {
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(PA_WAVES * 64, 2) void patch_attn_fwd_kernel(const 
     }
 }
 
-template <typename T>
+template <typename T, int KP>
 __global__ __launch_bounds__(PA_WAVES * 64, 2) void patch_attn_bwd_kernel(const T* __restrict__ h, const float* __restrict__ v,
                                                                          const float* __restrict__ dpooled, int64_t Q, int k, T* __restrict__ dh,
                                                                          float* __restrict__ dv_part) {
@@ -308,9 +314,13 @@ __global__ __launch_bounds__(PA_WAVES * 64, 2) void patch_attn_bwd_kernel(const 
         float p[PA_K], pt[PA_K];
 #pragma unroll
         for (int j = 0; j < PA_K; ++j) {
-            const float4 x = row4(src, j < k ? j : k - 1, lane);      // no branch around the loads
-            p[j] = j < k ? dot4(x, v4) : 0.f;
-            pt[j] = j < k ? dot4(x, dp) : 0.f;
+            if (j < KP) {
+                const float4 x = row4(src, j < k ? j : k - 1, lane);      // no branch around the loads
+                p[j] = j < k ? dot4(x, v4) : 0.f;
+                pt[j] = j < k ? dot4(x, dp) : 0.f;
+            } else {
+                p[j] = pt[j] = 0.f;
+            }
         }
         const float d = rows_to_lanes(p, lane);
         const float t = rows_to_lanes(pt, lane);                 // lane j: dP . h_j
@@ -390,11 +400,13 @@ int pps_patch_attn_fwd(const void* h, const float* v, int64_t q, int k, int c, i
     if (q < 0 || k < 1 || k > PA_K || c != 256 || (dtype != 1 && dtype != 2)) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
     if (!h || !v || !pooled) return PPS_ERR_ARG;
-    if (dtype == 2)
-        hipLaunchKernelGGL(patch_attn_fwd_kernel<half_t>, dim3(patch_grid(q)), dim3(PA_WAVES * 64), 0, (hipStream_t)stream, (const half_t*)h, v, q, k, pooled);
-    else
-        hipLaunchKernelGGL(patch_attn_fwd_kernel<uint16_t>, dim3(patch_grid(q)), dim3(PA_WAVES * 64), 0, (hipStream_t)stream, (const uint16_t*)h, v, q, k,
-                           pooled);
+    const dim3 grid(patch_grid(q)), block(PA_WAVES * 64);
+    hipStream_t st = (hipStream_t)stream;
+#define PPS_PA_FWD(T, KP) hipLaunchKernelGGL((patch_attn_fwd_kernel<T, KP>), grid, block, 0, st, (const T*)h, v, q, k, pooled)
+#define PPS_PA_BY_K(CALL, T) do { if (k <= 16) CALL(T, 16); else if (k <= 32) CALL(T, 32); else if (k <= 50) CALL(T, 50); else CALL(T, 64); } while (0)
+    if (dtype == 2) PPS_PA_BY_K(PPS_PA_FWD, half_t);
+    else PPS_PA_BY_K(PPS_PA_FWD, uint16_t);
+#undef PPS_PA_FWD
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 
@@ -402,12 +414,13 @@ int pps_patch_attn_bwd(const void* h, const float* v, const float* dpooled, int6
     if (q < 0 || k < 1 || k > PA_K || c != 256 || (dtype != 1 && dtype != 2)) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
     if (!h || !v || !dpooled || !dh || !dv_part) return PPS_ERR_ARG;
-    if (dtype == 2)
-        hipLaunchKernelGGL(patch_attn_bwd_kernel<half_t>, dim3(patch_grid(q)), dim3(PA_WAVES * 64), 0, (hipStream_t)stream, (const half_t*)h, v, dpooled, q, k,
-                           (half_t*)dh, dv_part);
-    else
-        hipLaunchKernelGGL(patch_attn_bwd_kernel<uint16_t>, dim3(patch_grid(q)), dim3(PA_WAVES * 64), 0, (hipStream_t)stream, (const uint16_t*)h, v, dpooled, q,
-                           k, (uint16_t*)dh, dv_part);
+    const dim3 grid(patch_grid(q)), block(PA_WAVES * 64);
+    hipStream_t st = (hipStream_t)stream;
+#define PPS_PA_BWD(T, KP) hipLaunchKernelGGL((patch_attn_bwd_kernel<T, KP>), grid, block, 0, st, (const T*)h, v, dpooled, q, k, (T*)dh, dv_part)
+    if (dtype == 2) PPS_PA_BY_K(PPS_PA_BWD, half_t);
+    else PPS_PA_BY_K(PPS_PA_BWD, uint16_t);
+#undef PPS_PA_BWD
+#undef PPS_PA_BY_K
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 
