@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pps_common.h"
 #include "../../include/ppsurf_amd.h"
 
 #define PPS_OK 0
@@ -61,9 +62,15 @@ __device__ __forceinline__ void st4(uint16_t* p, int64_t i, float4 v) {
     *(uint2*)(p + i) = make_uint2((unsigned)t[0] | ((unsigned)t[1] << 16), (unsigned)t[2] | ((unsigned)t[3] << 16));
 }
 
+// reductions over the 64 lanes, every lane gets the result: DPP row reduction (4 moves), then the row and half swaps of gfx950
+// (pps_common.h lane_xor_u32) instead of six ds_bpermute round trips -- these kernels reduce once per neighbour row
+__device__ __forceinline__ float lane_xor_f32(float v, int st) {
+    return __uint_as_float(pps::lane_xor_u32(__float_as_uint(v), st, (int)(threadIdx.x & 63)));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+    v = pps::row16_sum(v);
+    v += lane_xor_f32(v, 16);
+    v += lane_xor_f32(v, 32);
     return v;
 }
 
@@ -231,8 +238,9 @@ __device__ __forceinline__ float4 unpack4(const uint2 u) {
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
+    v = pps::row16_max(v);
+    v = fmaxf(v, lane_xor_f32(v, 16));
+    v = fmaxf(v, lane_xor_f32(v, 32));
     return v;
 }
 
@@ -245,7 +253,7 @@ __device__ __forceinline__ void halve_rows(float (&p)[PA_K], int lane) {
     for (int i = 0; i < HALF; ++i) {
         const float send = up ? p[i] : p[i + HALF];
         const float keep = up ? p[i + HALF] : p[i];
-        p[i] = keep + __shfl_xor(send, HALF);
+        p[i] = keep + lane_xor_f32(send, HALF);
     }
     if constexpr (HALF > 1) halve_rows<HALF / 2>(p, lane);
 }

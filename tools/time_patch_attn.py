@@ -43,3 +43,15 @@ fwd = timed(lambda st: _lib.check(L.pps_patch_attn_fwd(h.data_ptr(), v.data_ptr(
 bwd = timed(lambda st: _lib.check(L.pps_patch_attn_bwd(h.data_ptr(), v.data_ptr(), dp.data_ptr(), Q, K, C, 1, dh.data_ptr(), dv_part.data_ptr(), st), 'bwd'))
 gb = Q * K * C * 2 / 1e9
 print('patch_attn fwd {:.3f} ms ({:.2f} TB/s of h), bwd {:.3f} ms ({:.2f} TB/s of h + dh)'.format(fwd, gb / fwd, bwd, 2 * gb / bwd))
+
+# attention pooling of the interpolation head: 20 000 queries x 64 neighbours, 64 heads, 256 channels, h stored before its ReLU
+K2, H = 64, 64
+qy = torch.randn(Q, K2, H, device=DEV).to(torch.bfloat16)
+h2 = torch.randn(Q, K2, C, device=DEV).to(torch.bfloat16)
+dp2 = torch.randn(Q, C, device=DEV).to(torch.bfloat16)
+pooled2 = torch.empty(Q, C, device=DEV, dtype=torch.bfloat16)
+dqy, dh2 = torch.empty_like(qy), torch.empty_like(h2)
+fwd = timed(lambda st: _lib.check(L.pps_attn_pool_fwd(qy.data_ptr(), h2.data_ptr(), Q, K2, H, C, 1, 1, pooled2.data_ptr(), st), 'fwd'))
+bwd = timed(lambda st: _lib.check(L.pps_attn_pool_bwd(qy.data_ptr(), h2.data_ptr(), dp2.data_ptr(), Q, K2, H, C, 1, 1, dqy.data_ptr(), dh2.data_ptr(), st), 'bwd'))
+gf = Q * K2 * (C + H) * 2 / 1e9
+print('attn_pool fwd {:.3f} ms ({:.2f} TB/s of qy + h), bwd {:.3f} ms ({:.2f} TB/s of qy + h + dqy + dh)'.format(fwd, gf / fwd, bwd, 2 * gf / bwd))
