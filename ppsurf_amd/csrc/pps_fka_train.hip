@@ -352,9 +352,10 @@ __device__ __forceinline__ void outer_acc(const f32x4& dz, const f32x4& in_a, co
 }
 
 // sum over the four channel quarters of a per-neighbour value (lanes j, j + 16, j + 32, j + 48)
-__device__ __forceinline__ float quarters_sum(float v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
+__device__ __forceinline__ float quarters_sum(float v) {            // row and half swaps of gfx950 instead of two ds_bpermute round trips
+    const int lane = threadIdx.x & 63;
+    v += __uint_as_float(pps::lane_xor_u32(__float_as_uint(v), 16, lane));
+    v += __uint_as_float(pps::lane_xor_u32(__float_as_uint(v), 32, lane));
     return v;
 }
 
