@@ -244,10 +244,13 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// 64 per-lane partial sums (one per row) -> lane l holds the total of row l: recursive halving, 63 shuffles instead of 64 x 6.
+// 32 per-lane partial sums (one per row of a half patch) -> lanes l and l + 32 hold the total of row l: recursive halving within each half of
+// the wave (31 exchanges instead of 32 x 6), then the two halves are added.  The patch is reduced as two half patches of 32 rows so that only
+// 32 (forward) / 64 (backward) partial sums are live at a time (61 instead of 91 VGPRs forward, 166 instead of 172 backward; measured: the
+// extra resident waves change nothing, neither kernel is bound by occupancy).
 // (template recursion: every array index is a compile-time constant, the array stays in registers)
 template <int HALF>
-__device__ __forceinline__ void halve_rows(float (&p)[PA_K], int lane) {
+__device__ __forceinline__ void halve_rows(float (&p)[32], int lane) {
     const bool up = (lane & HALF) != 0;
 #pragma unroll
     for (int i = 0; i < HALF; ++i) {
@@ -257,9 +260,9 @@ __device__ __forceinline__ void halve_rows(float (&p)[PA_K], int lane) {
     }
     if constexpr (HALF > 1) halve_rows<HALF / 2>(p, lane);
 }
-__device__ __forceinline__ float rows_to_lanes(float (&p)[PA_K], int lane) {
-    halve_rows<32>(p, lane);
-    return p[0];
+__device__ __forceinline__ float rows_to_lanes32(float (&p)[32], int lane) {
+    halve_rows<16>(p, lane);
+    return p[0] + lane_xor_f32(p[0], 32);
 }
 
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
@@ -273,18 +276,24 @@ __device__ __forceinline__ float4 row4(const T* __restrict__ src, int j, int lan
 // hit ONE address from one wave and serialise in the memory pipeline -- 14 of them (k = 50 under the old fixed bound of 64) cost a quarter of the kernel
 template <typename T, int KP>
 __device__ __forceinline__ float patch_softmax(const T* __restrict__ src, int k, const float4 v4, int lane) {
-    float p[PA_K];
+    float d[2];
 #pragma unroll
-    for (int j = 0; j < PA_K; ++j) {                               // no branch around the loads: rows beyond k re-read the last row and are zeroed
-        if (j < KP) {
-            const float d = dot4(row4(src, j < k ? j : k - 1, lane), v4);
-            p[j] = j < k ? d : 0.f;
-        } else {
-            p[j] = 0.f;
+    for (int half = 0; half < 2; ++half) {
+        float p[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {                             // no branch around the loads: rows beyond k re-read the last row and are zeroed
+            const int j = 32 * half + i;
+            if (j < KP) {
+                const float t = dot4(row4(src, j < k ? j : k - 1, lane), v4);
+                p[i] = j < k ? t : 0.f;
+            } else {
+                p[i] = 0.f;
+            }
         }
+        d[half] = (32 * half < KP) ? rows_to_lanes32(p, lane) : 0.f;
     }
-    const float d = rows_to_lanes(p, lane);
-    const float logit = lane < k ? d : -INFINITY;
+    const float dd = lane < 32 ? d[0] : d[1];                      // lane j: logit of row j
+    const float logit = lane < k ? dd : -INFINITY;
     const float m = wave_max(logit);
     const float e = lane < k ? __expf(logit - m) : 0.f;
     return e / wave_sum(e);
@@ -319,19 +328,26 @@ __global__ __launch_bounds__(PA_WAVES * 64, 2) void patch_attn_bwd_kernel(const 
     for (int64_t q = (int64_t)blockIdx.x * PA_WAVES + wave; q < Q; q += (int64_t)gridDim.x * PA_WAVES) {
         const T* src = h + q * (int64_t)k * 256;
         const float4 dp = *(const float4*)(dpooled + q * 256 + 4 * lane);
-        float p[PA_K], pt[PA_K];
+        float dh2[2], th2[2];
 #pragma unroll
-        for (int j = 0; j < PA_K; ++j) {
-            if (j < KP) {
-                const float4 x = row4(src, j < k ? j : k - 1, lane);      // no branch around the loads
-                p[j] = j < k ? dot4(x, v4) : 0.f;
-                pt[j] = j < k ? dot4(x, dp) : 0.f;
-            } else {
-                p[j] = pt[j] = 0.f;
+        for (int half = 0; half < 2; ++half) {
+            float p[32], pt[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int j = 32 * half + i;
+                if (j < KP) {
+                    const float4 x = row4(src, j < k ? j : k - 1, lane);      // no branch around the loads
+                    p[i] = j < k ? dot4(x, v4) : 0.f;
+                    pt[i] = j < k ? dot4(x, dp) : 0.f;
+                } else {
+                    p[i] = pt[i] = 0.f;
+                }
             }
+            dh2[half] = (32 * half < KP) ? rows_to_lanes32(p, lane) : 0.f;
+            th2[half] = (32 * half < KP) ? rows_to_lanes32(pt, lane) : 0.f;
         }
-        const float d = rows_to_lanes(p, lane);
-        const float t = rows_to_lanes(pt, lane);                 // lane j: dP . h_j
+        const float d = lane < 32 ? dh2[0] : dh2[1];
+        const float t = lane < 32 ? th2[0] : th2[1];             // lane j: dP . h_j
         const float logit = lane < k ? d : -INFINITY;
         const float m = wave_max(logit);
         const float e = lane < k ? __expf(logit - m) : 0.f;
