@@ -44,6 +44,8 @@ class AdamW(torch.optim.AdamW):
             if (not p.is_cuda or p.dtype != torch.float32 or g.dtype != torch.float32 or g.is_sparse or not p.is_contiguous()
                     or not g.is_contiguous() or g.device != p.device):
                 return None
+        if len({p.device for p in ps}) > 1:                          # one table, one launch: a group spread over devices is torch's business
+            return None
         return ps
 
     def _init_state(self, ps):
