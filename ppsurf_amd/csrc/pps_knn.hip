@@ -31,6 +31,17 @@ __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
     return ((u64)(unsigned)hi << 32) | (unsigned)lo;
 }
 
+// minimum over the 64 lanes, in every lane: DPP row reduction + the row / half swaps of gfx950 (pps_common.h)
+__device__ __forceinline__ float wave_min_f32(float v, int lane) {
+    v = fminf(v, pps::dpp_mov<0xB1>(v));
+    v = fminf(v, pps::dpp_mov<0x4E>(v));
+    v = fminf(v, pps::dpp_mov<0x141>(v));
+    v = fminf(v, pps::dpp_mov<0x140>(v));
+    v = fminf(v, __uint_as_float(pps::lane_xor_u32(__float_as_uint(v), 16, lane)));
+    v = fminf(v, __uint_as_float(pps::lane_xor_u32(__float_as_uint(v), 32, lane)));
+    return v;
+}
+
 // ascending bitonic sort of one key per lane over the 64 lanes
 __device__ __forceinline__ u64 wave_sort64(u64 key, int lane) {
 #pragma unroll
@@ -194,12 +205,13 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_blocked_kernel(const float
                 const float fx = fmaxf(fabsf(__fsub_rn(qx[j], lx)), fabsf(__fsub_rn(qx[j], hx)));
                 const float fy = fmaxf(fabsf(__fsub_rn(qy[j], ly)), fabsf(__fsub_rn(qy[j], hy)));
                 const float fz = fmaxf(fabsf(__fsub_rn(qz[j], lz)), fabsf(__fsub_rn(qz[j], hz)));
-                float far2 = bv ? __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz)) : INFINITY;
-#pragma unroll
-                for (int s = 32; s > 0; s >>= 1) far2 = fminf(far2, __shfl_xor(far2, s));
-                tau[j] = fminf(tau[j], far2);
+                const float far2 = bv ? __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz)) : INFINITY;
+                tau[j] = fminf(tau[j], far2);                      // per lane: the minimum over its windows ...
             }
         }
+#pragma unroll
+        for (int j = 0; j < KNN_QW; ++j) tau[j] = wave_min_f32(tau[j], lane);      // ... and ONE reduction over the lanes per query (it used to sit
+                                                                                   // inside the window loop: 48 ds_bpermute per 64 windows)
         // ---- scan: 64 boxes per culling step, surviving blocks point by point ---------------------------------------
         for (int b0 = 0; b0 < nb; b0 += 64) {
             const int b = b0 + lane;
@@ -315,12 +327,13 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_blocked_batch_kernel(const
                 const float fx = fmaxf(fabsf(__fsub_rn(qx[j], lx)), fabsf(__fsub_rn(qx[j], hx)));
                 const float fy = fmaxf(fabsf(__fsub_rn(qy[j], ly)), fabsf(__fsub_rn(qy[j], hy)));
                 const float fz = fmaxf(fabsf(__fsub_rn(qz[j], lz)), fabsf(__fsub_rn(qz[j], hz)));
-                float far2 = bv ? __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz)) : INFINITY;
-#pragma unroll
-                for (int s = 32; s > 0; s >>= 1) far2 = fminf(far2, __shfl_xor(far2, s));
-                tau[j] = fminf(tau[j], far2);
+                const float far2 = bv ? __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz)) : INFINITY;
+                tau[j] = fminf(tau[j], far2);                      // per lane: the minimum over its windows ...
             }
         }
+#pragma unroll
+        for (int j = 0; j < KNN_QW; ++j) tau[j] = wave_min_f32(tau[j], lane);      // ... and ONE reduction over the lanes per query (it used to sit
+                                                                                   // inside the window loop: 48 ds_bpermute per 64 windows)
         for (int b0 = 0; b0 < nb; b0 += 64) {
             const int b = b0 + lane;
             const bool bv = b < nb;
