@@ -1009,13 +1009,32 @@ __global__ __launch_bounds__(256) void head_input_dwx_kernel(const uint16_t* __r
     float acc[8][3];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j][0] = acc[j][1] = acc[j][2] = 0.f;
-    for (int64_t row = (int64_t)blockIdx.x * rpb + rl; row < rows; row += (int64_t)gridDim.x * rpb) {
-        const int64_t n = ids[row], q = row / k;
-        const float r0 = query[q * 3] - pts[n * 3], r1 = query[q * 3 + 1] - pts[n * 3 + 1], r2 = query[q * 3 + 2] - pts[n * 3 + 2];
-        const u32x4 t = *(const u32x4*)(dh1 + row * c + 8 * ch);
-        const float g[8] = {lo16(t.x), hi16(t.x), lo16(t.y), hi16(t.y), lo16(t.z), hi16(t.z), lo16(t.w), hi16(t.w)};
+    constexpr int U = 4;                                       // four rows per thread in flight (the id, then the point it names: two dependent
+                                                               // latencies per row; 0.20 -> 0.18 ms -- the forward kernel gains nothing from it); the sums keep their row order
+    const int64_t stride = (int64_t)gridDim.x * rpb;
+    for (int64_t row0 = (int64_t)blockIdx.x * rpb + rl; row0 < rows; row0 += U * stride) {
+        int64_t rw[U], n[U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { acc[j][0] += g[j] * r0; acc[j][1] += g[j] * r1; acc[j][2] += g[j] * r2; }
+        for (int u = 0; u < U; ++u) {
+            rw[u] = row0 + u * stride;
+            n[u] = ids[rw[u] < rows ? rw[u] : row0];
+        }
+        u32x4 t[U];
+        float rel[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t rr = rw[u] < rows ? rw[u] : row0, q = rr / k;
+            t[u] = *(const u32x4*)(dh1 + rr * c + 8 * ch);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) rel[u][d] = query[q * 3 + d] - pts[n[u] * 3 + d];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (rw[u] >= rows) break;
+            const float g[8] = {lo16(t[u].x), hi16(t[u].x), lo16(t[u].y), hi16(t[u].y), lo16(t[u].z), hi16(t[u].z), lo16(t[u].w), hi16(t[u].w)};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { acc[j][0] += g[j] * rel[u][0]; acc[j][1] += g[j] * rel[u][1]; acc[j][2] += g[j] * rel[u][2]; }
+        }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) { red[threadIdx.x][3 * j] = acc[j][0]; red[threadIdx.x][3 * j + 1] = acc[j][1]; red[threadIdx.x][3 * j + 2] = acc[j][2]; }
