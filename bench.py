@@ -1,6 +1,10 @@
 """Headline benchmark: occupancy query-points/sec of the PPSurf 50NN decoder path at gen_resolution_global=257.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+(RANK / LOCAL_RANK / WORLD_SIZE in the environment), or plainly as `python bench.py --gpus N`: the script then re-executes itself under
+torch.distributed.run (127.0.0.1, a free port) and passes the ranks' output and exit code through.
 
 One STEP = one pass of the hot path over one chunk of Q = rec_batch_size = 50000 queries of the Marching-Cubes band of a
 synthetic 100k-point cloud (configs/poco.yaml:51-52, configs/ppsurf_50nn.yaml): exact 64-NN -> 50-NN patch gather +
@@ -15,12 +19,19 @@ in HBM before the timed region.
 into contiguous query ranges + one all-gather of 4 B/query per round, encoder passes dealt round-robin + one all-reduce of the
 latent sums per wave); value = the shape's decoder queries / wall time, plus shapes_per_hour and the collective time share.
 
-Extra keys on the same JSON line (N=1 weak only, skipped with --quick): `shapes_per_hour` (one whole R=257 reconstruction, first
-shape and steady state), `fit_ms_per_step` (BASELINE config 3, bf16-mixed, B=10), `cpu_baseline`.
+Extra keys on the same JSON line (skipped with --quick): `shapes_per_hour` (whole R=257 reconstructions by the product driver; N=1: first
+shape and steady state, N>1: every rank reconstructs its own shapes, the figure is all shapes of all ranks / the slowest rank's time),
+and at N=1 only `fit_ms_per_step` (BASELINE config 3, bf16-mixed, B=10) and `cpu_baseline`.
+
+The timed region is at least MIN_TIMED_S long: when `steps` distinct chunks take less, the same chunk list is decoded `repeats` times
+(`steps` is reported as given, `repeats` and `timed_s` next to it; ms_per_step and value are per chunk over all repeats).
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,6 +46,7 @@ Q_CHUNK = 50_000
 K_PROJ = 64
 P_LOCAL = 50
 RES = 257
+MIN_TIMED_S = 2.0                              # the timed region is stretched to this by repeating the chunk list (see `repeats`)
 ALG_MFLOP_PER_QUERY = 53.21                    # conv+matmul FLOPs of the reference's from_latent at P=50
 # dominant kernel (interp_pool_kernel).  Reference work it replaces per query, poco_model.py:400-414:
 # 64 neighbours x (fc1 66304 + fc2 65536 + fc3 65536 + fc_query 16384 + fc_value 65536) MAC + 16384 MAC pooling
@@ -85,6 +97,155 @@ def cpu_baseline(sd, cloud, qry, lat, q_call=20_000, reps=3):
                       'median of {} s per call'.format(reps, q_call, cloud.shape[0], ', '.join('{:.1f}'.format(t) for t in times))}
 
 
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def launch_cmd(n, argv, port):
+    """The command line `python bench.py --gpus n ...` turns itself into when no launcher set WORLD_SIZE: one rank per GPU of this node."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__)] + [a for a in argv if a != '--spawn']
+
+
+def self_spawn(n, argv):
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '8')
+    return subprocess.call(launch_cmd(n, argv, free_port()), env=env)
+
+
+HEADLINE_DTYPE = 'f32'       # decoder dtype of `value`; the other dtype travels as an extra key of the N=1 line
+
+
+def rank_values(x, rank, world, dist, red_dev):
+    """[x of rank 0, ..., x of rank world-1] on every rank."""
+    if dist is None:
+        return [float(x)]
+    t = torch.zeros(world, dtype=torch.float64, device=red_dev)
+    t[rank] = float(x)
+    dist.all_reduce(t)
+    return [float(v) for v in t.cpu()]
+
+
+def build_work(plan, n_chunks, rank, dev):
+    """Resident inputs: as many synthetic shapes as it takes to give every step its own chunk of a real first-round band."""
+    import bench_workloads as workloads
+    from ppsurf_amd.decoder import ChunkPipeline
+    from ppsurf_amd.synthetic import make_cloud, make_latents
+    shapes, work = [], []                                        # work: (pipeline, chunk) per step
+    s = 0
+    while len(work) < n_chunks:
+        cloud = make_cloud(N_POINTS, seed=42 + 1000 * rank + s)
+        pts = torch.from_numpy(cloud).to(dev)
+        lat = make_latents(256, N_POINTS, seed=77 + s)
+        table = plan.point_table(torch.from_numpy(lat[0]).to(dev))       # per-shape, outside the per-chunk step
+        chunks, n_band = workloads.band_chunks(cloud, RES, Q_CHUNK, dev)
+        pipe = ChunkPipeline(plan, table, pts, pts, K_PROJ, P_LOCAL, same_cloud=True, max_chunk=Q_CHUNK)
+        shapes.append({'cloud': cloud, 'lat': lat, 'band': n_band, 'chunks': len(chunks)})
+        work += [(pipe, c) for c in chunks]
+        s += 1
+    return shapes, work[:n_chunks]
+
+
+def chunk_loop(work, steps, warmup, rank, world, dist, red_dev, min_timed_s=MIN_TIMED_S):
+    """`warmup` untimed chunks, then `repeats` passes over the next `steps` DISTINCT chunks between barrier + synchronize on both sides.
+    Returns the max-over-ranks wall time, this rank's own time, repeats, per-stage HIP-event means (ms) and the last occupancy."""
+    import bench_workloads as workloads
+    from ppsurf_amd import sharding
+    torch.cuda.synchronize()
+    tw = time.perf_counter()
+    for pipe, c in work[:warmup]:
+        pipe.run([c])
+    torch.cuda.synchronize()
+    est = (time.perf_counter() - tw) / max(warmup, 1)              # s per chunk, first-call overheads included: an over-estimate
+    timed = work[warmup:warmup + steps]
+    repeats = 1
+    if warmup > 0 and min_timed_s > 0:
+        # one more untimed pass over a few timed chunks gives a steady-state estimate
+        probe = timed[:min(len(timed), 4)]
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
+        for pipe, c in probe:
+            pipe.run([c])
+        torch.cuda.synchronize()
+        est = (time.perf_counter() - tw) / len(probe)
+        repeats = max(1, int(math.ceil(min_timed_s / (est * steps))))
+    repeats = int(round(sharding.max_over_ranks(float(repeats), red_dev)))
+    ev = [workloads.HipEvents(6) for _ in range(steps * repeats)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    i = 0
+    for _ in range(repeats):
+        for pipe, c in timed:                                     # `steps` distinct chunks of Q_CHUNK queries, `repeats` times
+            res = pipe.run([c], want_occ=True, stage_events=[ev[i].arr])
+            i += 1
+    torch.cuda.synchronize()
+    mine = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    dt = sharding.max_over_ranks(time.perf_counter() - t0, red_dev)
+    occ = res[-1][1]
+    assert bool(torch.isfinite(occ).all())
+    stage_ms = {name: float(np.mean([e.elapsed_ms(j, j + 1) for e in ev])) for j, name in enumerate(STAGES)}
+    return {'dt': dt, 'mine': mine, 'repeats': repeats, 'stage_ms': stage_ms, 'occ': occ, 'chunks': steps * repeats}
+
+
+def pmc_traffic(dtype):
+    """HBM bytes per launch of the dominant kernel from the committed counter passes of this bench (a previous run of the same command,
+    labelled with the commit it was taken at -- never measured inside this run)."""
+    for tag in ('round3', 'round2'):
+        path = os.path.join(REPO, 'profiles', '{}_{}_pmc.json'.format(tag, dtype))
+        if os.path.isfile(path):
+            d = json.load(open(path))
+            src = 'profiles/{}: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes of this bench at commit {} (a previous run, NOT measured in this run)'.format(
+                os.path.basename(path), d.get('git_head', 'unrecorded'))
+            return d.get('interp_pool_hbm_bytes_per_launch'), src
+    return None, None
+
+
+def roofline_block(dtype, stage_ms):
+    f16 = dtype == 'f16x3'
+    peak, mult = (PEAK_F16_MFMA_TFLOPS, 3.0) if f16 else (PEAK_F32_MFMA_TFLOPS, 1.0)
+    k_ms = stage_ms['interp_pool']
+    executed = mult * INTERP_EXEC_FLOP_PER_QUERY * Q_CHUNK / (k_ms * 1e-3) / 1e12
+    traffic, traffic_src = pmc_traffic(dtype)
+    return {'kernel': ('interp_pool_f16x3_kernel' if f16 else 'interp_pool_kernel') + ' (inside pps_decode_fwd_events_f32)', 'bound': 'mfma',
+            'achieved': executed, 'peak': peak, 'unit': 'TFLOP/s', 'frac': executed / peak,
+            'traffic': traffic, 'traffic_source': traffic_src, 'avg_kernel_ms': k_ms,
+            'algorithmic_tflops': INTERP_ALG_FLOP_PER_QUERY * Q_CHUNK / (k_ms * 1e-3) / 1e12,
+            'note': ('achieved / frac = f16 MFMA flops the split-precision kernel executes (3 f16 products per fp32 product of the 9280 x 2048 '
+                     'flop per query) / its HIP-event duration / the dense f16 matrix peak (DESIGN.md section 4.1b)' if f16 else
+                     'achieved / frac = MFMA flops the kernel EXECUTES (9280 v_mfma_f32_16x16x4_f32 per query x 2048) / its HIP-event '
+                     'duration / the fp32 matrix peak; algorithmic_tflops prices the reference work it replaces (two exact identities '
+                     'remove 47 % of it, DESIGN.md section 2) and is not a hardware fraction')}
+
+
+def dtype_stats(dtype, r, world):
+    """Per-dtype figures of one chunk_loop result `r`."""
+    f16 = dtype == 'f16x3'
+    peak, mult = (PEAK_F16_MFMA_TFLOPS, 3.0) if f16 else (PEAK_F32_MFMA_TFLOPS, 1.0)
+    value = world * Q_CHUNK * r['chunks'] / r['dt']
+    ms_step = r['dt'] / r['chunks'] * 1e3
+    sm = r['stage_ms']
+    return {'value': value, 'unit': 'queries/s', 'ms_per_step': ms_step, 'repeats': r['repeats'], 'timed_s': r['dt'], 'stage_ms': sm,
+            'stage_mfma_frac': {n: mult * STAGE_EXEC_MFMA_PER_QUERY[n] * 2048.0 * Q_CHUNK / (sm[n] * 1e-3) / 1e12 / peak for n in STAGES},
+            'spatial_ms': ms_step - sum(sm.values()),
+            'whole_path_algorithmic_tflops': ALG_MFLOP_PER_QUERY * 1e6 * value / world / 1e12,
+            'whole_path_executed_mfma_frac': mult * sum(STAGE_EXEC_MFMA_PER_QUERY.values()) * 2048.0 * value / world / 1e12 / peak}
+
+
+DTYPE_NOTE = {
+    'f32': 'every product an fp32 MFMA (v_mfma_f32_16x16x4_f32, bit-for-bit an fp32 fmaf chain)',
+    'f16x3': 'split precision: every fp32 product of the dense layers is carried as 3 f16 MFMAs (hi.hi + hi.lo + lo.hi of x = hi + lo, f16 parts, '
+             '~21 significand bits) with fp32 accumulation -- wider than the 16-mixed autocast arithmetic the reference runs its GPU predict in '
+             '(configs/poco.yaml:10); per-point table, xyz layers, softmax / pooling and tail stay fp32; parity held at the same 1e-4 bar as fp32 '
+             '(tests/test_gpu_decoder.py, test_gpu_api.py, test_gpu_configs.py)'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -93,21 +254,26 @@ def main():
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
     ap.add_argument('--quick', action='store_true', help='query throughput only: no shapes/hour, fit step or CPU baseline legs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--dtype', choices=['f32', 'f16x3'], default='f32', help="decoder dtype of the timed loop; 'f16x3' (opt-in split precision) is for profiling "
-                    'runs -- the headline value is the f32 run')
+    ap.add_argument('--dtype', choices=['f32', 'f16x3'], default=HEADLINE_DTYPE, help='decoder dtype of the timed loop and of `value`')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1 ('nccl' = RCCL; 'gloo' only for single-GPU rehearsals)")
     ap.add_argument('--same-gpu', action='store_true', help='rehearsal: every rank uses cuda:0 (needs --backend gloo)')
+    ap.add_argument('--spawn', action='store_true', help='re-execute under torch.distributed.run even for --gpus 1 (what --gpus N>1 does by itself)')
+    ap.add_argument('--shapes', type=int, default=2, help='timed whole reconstructions per rank of the shapes/hour leg')
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 200 if args.scaling == 'weak' else 3
     if args.warmup is None:
         args.warmup = 10 if args.scaling == 'weak' else 1
 
+    launched = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
+    if not launched and (args.gpus > 1 or args.spawn):
+        # plain `python bench.py --gpus N`: become N ranks (one per GPU) under torch.distributed.run and pass their result through
+        sys.exit(self_spawn(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit('--gpus {} needs torch.distributed.run with {} ranks (WORLD_SIZE={})'.format(args.gpus, args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit('--gpus {} but the launcher started {} ranks (WORLD_SIZE)'.format(args.gpus, world))
     if args.same_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -121,9 +287,10 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    from ppsurf_amd import sharding, workloads
-    from ppsurf_amd.decoder import DecoderPlan, ChunkPipeline
-    from ppsurf_amd.synthetic import make_cloud, make_latents, network_state_dict
+    from ppsurf_amd import sharding
+    import bench_workloads as workloads
+    from ppsurf_amd.decoder import DecoderPlan
+    from ppsurf_amd.synthetic import network_state_dict
 
     red_dev = dev if args.backend == 'nccl' else 'cpu'
     if args.scaling == 'strong':
@@ -131,135 +298,93 @@ def main():
 
     sd = network_state_dict('ppsurf')
     plan = DecoderPlan(sd, dev, dtype=args.dtype)
-    # ---- resident inputs: as many shapes as it takes to give every step its own chunk of a real first-round band ----------
-    total_chunks = args.warmup + args.steps
-    shapes, work = [], []                                        # work: (pipeline, chunk) per step
-    s = 0
-    while len(work) < total_chunks:
-        cloud = make_cloud(N_POINTS, seed=42 + 1000 * rank + s)
-        pts = torch.from_numpy(cloud).to(dev)
-        lat = make_latents(256, N_POINTS, seed=77 + s)
-        table = plan.point_table(torch.from_numpy(lat[0]).to(dev))       # per-shape, outside the per-chunk step
-        chunks, n_band = workloads.band_chunks(cloud, RES, Q_CHUNK, dev)
-        pipe = ChunkPipeline(plan, table, pts, pts, K_PROJ, P_LOCAL, same_cloud=True, max_chunk=Q_CHUNK)
-        shapes.append({'cloud': cloud, 'lat': lat, 'band': n_band, 'chunks': len(chunks)})
-        work += [(pipe, c) for c in chunks]
-        s += 1
-    work = work[:total_chunks]
-    ev = [workloads.HipEvents(6) for _ in range(args.steps)]
-
-    for pipe, c in work[:args.warmup]:
-        pipe.run([c])
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i, (pipe, c) in enumerate(work[args.warmup:]):            # EXACTLY `steps` distinct chunks of Q_CHUNK queries
-        res = pipe.run([c], want_occ=True, stage_events=[ev[i].arr])
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    occ = res[-1][1]
-    dt = sharding.max_over_ranks(dt, red_dev)
-    assert bool(torch.isfinite(occ).all())
+    shapes, work = build_work(plan, args.warmup + args.steps, rank, dev)
+    r = chunk_loop(work, args.steps, args.warmup, rank, world, dist, red_dev)
+    per_rank = [Q_CHUNK * r['chunks'] / t for t in rank_values(r['mine'], rank, world, dist, red_dev)]
 
     out = None
     if rank == 0:
-        ms_step = dt / args.steps * 1e3
-        value = world * Q_CHUNK * args.steps / dt
-        stage_ms = {name: float(np.mean([e.elapsed_ms(j, j + 1) for e in ev])) for j, name in enumerate(STAGES)}
-        k_ms = stage_ms['interp_pool']
-        executed = INTERP_EXEC_FLOP_PER_QUERY * Q_CHUNK / (k_ms * 1e-3) / 1e12
-        traffic, traffic_src = None, None
-        pmc = os.path.join(REPO, 'profiles', 'round2_f32_pmc.json')
-        if os.path.isfile(pmc):
-            traffic = json.load(open(pmc)).get('interp_pool_hbm_bytes_per_launch')
-            traffic_src = 'profiles/round2_f32_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes of this bench (a previous run, NOT measured in this run)'
-        # --dtype f16x3: the dense layers run as three f16 MFMA products per fp32 product -> executed flops x 3, priced against the dense f16 peak
-        f16 = args.dtype == 'f16x3'
-        peak, mult = (PEAK_F16_MFMA_TFLOPS, 3.0) if f16 else (PEAK_F32_MFMA_TFLOPS, 1.0)
-        executed *= mult
-        stage_frac = {n: mult * STAGE_EXEC_MFMA_PER_QUERY[n] * 2048.0 * Q_CHUNK / (stage_ms[n] * 1e-3) / 1e12 / peak for n in STAGES}
+        st = dtype_stats(args.dtype, r, world)
         out = {
-            'metric': 'occupancy query-points/sec @ res=257, 50NN', 'value': value, 'unit': 'queries/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
+            'metric': 'occupancy query-points/sec @ res=257, 50NN', 'value': st['value'], 'unit': 'queries/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': st['ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'repeats': r['repeats'], 'timed_s': r['dt'], 'world_size_seen': world,
+            'backend': ('RCCL (torch.distributed nccl)' if args.backend == 'nccl' else args.backend) if world > 1 else None,
+            'per_rank_queries_per_s': {'min': min(per_rank), 'max': max(per_rank), 'all': per_rank},
+            'dtype_note': DTYPE_NOTE[args.dtype],
             'config': {'workload': 'ppsurf_50nn predict, R=257: {} distinct first-growth-round band chunks of {} queries '
                                    '(rec_batch_size) over {} synthetic 100k-point clouds per GPU, k=64, P=50'.format(args.steps, Q_CHUNK, len(shapes)),
                        'parallelism': 'query-block sharding x{}'.format(world), 'weights': 'formula-filled (no checkpoint offline)',
                        'entry': 'ChunkPipeline.run -> pps_knn_blocked_f32, pps_patch_normalize_f32, pps_decode_fwd_events_f32'},
-            'roofline': {'kernel': ('interp_pool_f16x3_kernel' if f16 else 'interp_pool_kernel') + ' (inside pps_decode_fwd_events_f32)', 'bound': 'mfma',
-                         'achieved': executed, 'peak': peak, 'unit': 'TFLOP/s', 'frac': executed / peak,
-                         'traffic': traffic, 'traffic_source': traffic_src, 'avg_kernel_ms': k_ms,
-                         'algorithmic_tflops': INTERP_ALG_FLOP_PER_QUERY * Q_CHUNK / (k_ms * 1e-3) / 1e12,
-                         'note': ('achieved / frac = f16 MFMA flops the split-precision kernel executes (3 f16 products per fp32 product of the 9280 x 2048 '
-                                  'flop per query) / its HIP-event duration / the dense f16 matrix peak; the kernel is bound by its 576 KB weight stream '
-                                  'per pass (LDS-DMA), not by the f16 pipe (DESIGN.md section 4.1b)' if f16 else
-                                  'achieved / frac = MFMA flops the kernel EXECUTES (9280 v_mfma_f32_16x16x4_f32 per query x 2048) / its HIP-event '
-                                  'duration / the fp32 matrix peak; algorithmic_tflops prices the reference work it replaces (two exact identities '
-                                  'remove 47 % of it, DESIGN.md section 2) and is not a hardware fraction')},
-            'stage_ms': stage_ms, 'stage_mfma_frac': stage_frac,
-            'spatial_ms': ms_step - sum(stage_ms.values()),
-            'whole_path_algorithmic_tflops': ALG_MFLOP_PER_QUERY * 1e6 * value / world / 1e12,
-            'whole_path_executed_mfma_frac': mult * sum(STAGE_EXEC_MFMA_PER_QUERY.values()) * 2048.0 * value / world / 1e12 / peak,
+            'roofline': roofline_block(args.dtype, r['stage_ms']),
+            'stage_ms': st['stage_ms'], 'stage_mfma_frac': st['stage_mfma_frac'], 'spatial_ms': st['spatial_ms'],
+            'whole_path_algorithmic_tflops': st['whole_path_algorithmic_tflops'],
+            'whole_path_executed_mfma_frac': st['whole_path_executed_mfma_frac'],
         }
-    extra = world == 1 and not args.quick and args.dtype == 'f32'
-    if extra:
-        # ---- opt-in split-precision decoder (dtype "f16x3": fc2 / fc3 / fc_query of the interpolation branch as 3 f16 MFMA products
-        # per fp32 product; logits within ~1e-5 of the fp32 path, tests/test_gpu_decoder.py).  NOT the headline value. ----------
-        plan16 = DecoderPlan(sd, dev, dtype='f16x3')
-        n16 = min(args.steps, 100)
-        w16 = [(ChunkPipeline(plan16, pipe.table, pipe.pts, pipe.pts, K_PROJ, P_LOCAL, same_cloud=True, max_chunk=Q_CHUNK), c)
-               for pipe, c in work[args.warmup:args.warmup + 1]]
-        pipes16 = {}
-        ev16 = [workloads.HipEvents(6) for _ in range(n16)]
-        seq = work[args.warmup:args.warmup + n16]
-        for pipe, c in seq:
-            if id(pipe) not in pipes16:
-                pipes16[id(pipe)] = ChunkPipeline(plan16, pipe.table, pipe.pts, pipe.pts, K_PROJ, P_LOCAL, same_cloud=True, max_chunk=Q_CHUNK)
-        for pipe, c in seq[:5]:
-            pipes16[id(pipe)].run([c])
+    if not args.quick:
+        other = 'f16x3' if args.dtype == 'f32' else 'f32'
+        if world == 1:
+            # ---- the other decoder dtype on the same chunks: an extra key, never `value` ----------------------------------------------
+            plan2 = DecoderPlan(sd, dev, dtype=other)
+            from ppsurf_amd.decoder import ChunkPipeline
+            pipes2, work2 = {}, []
+            for pipe, c in work:
+                if id(pipe) not in pipes2:
+                    pipes2[id(pipe)] = ChunkPipeline(plan2, pipe.table, pipe.pts, pipe.pts, K_PROJ, P_LOCAL, same_cloud=True, max_chunk=Q_CHUNK)
+                work2.append((pipes2[id(pipe)], c))
+            n2 = min(args.steps, 100)
+            r2 = chunk_loop(work2, n2, min(args.warmup, 5), rank, world, dist, red_dev, min_timed_s=1.0)
+            last_pipe, last_c = work[args.warmup + n2 - 1]
+            ref_occ = last_pipe.run([last_c], want_occ=True)[0][1]
+            out[other] = dict(dtype_stats(other, r2, world), steps=n2, note=DTYPE_NOTE[other], roofline=roofline_block(other, r2['stage_ms']))
+            out[other]['max_abs_occ_diff_vs_{}_last_chunk'.format(args.dtype)] = float((r2['occ'] - ref_occ).abs().max())
+            del plan2, pipes2, work2, r2
+        del work, r
+        torch.cuda.empty_cache()
+        # ---- shapes/hour: whole R=257 reconstructions by the product driver, every rank its own shapes ----------------------------------
+        model = workloads.make_model(RES, P_LOCAL, Q_CHUNK, dev)
+        model.network.decoder_dtype = args.dtype
+        first = workloads.reconstruct_steered(model, N_POINTS, seed=42 + 1000 * rank, device=dev)
+        if dist is not None:
+            dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i, (pipe, c) in enumerate(seq):
-            r16 = pipes16[id(pipe)].run([c], want_occ=True, stage_events=[ev16[i].arr])
+        runs = [workloads.reconstruct_steered(model, N_POINTS, seed=43 + 1000 * rank + i, device=dev) for i in range(args.shapes)]
         torch.cuda.synchronize()
-        dt16 = time.perf_counter() - t0
-        ref_occ = pipe.run([c], want_occ=True)[0][1]
-        f16_stats = {'value': Q_CHUNK * len(seq) / dt16, 'unit': 'queries/s', 'ms_per_step': dt16 / len(seq) * 1e3, 'steps': len(seq),
-                        'stage_ms': {name: float(np.mean([e.elapsed_ms(j, j + 1) for e in ev16])) for j, name in enumerate(STAGES)},
-                        'max_abs_occ_diff_vs_f32_last_chunk': float((r16[0][1] - ref_occ).abs().max()),
-                        'note': 'opt-in decoder dtype (DecoderPlan(dtype="f16x3") / network.decoder_dtype / PPS_DECODER_DTYPE): the dense layers of '
-                                'the interpolation and PointNet branches on the f16 matrix pipe in split precision (3 f16 products per fp32 product, '
-                                'fp32 accumulation); per-point table, xyz layers, softmax / pooling and tail fp32; same chunks as the fp32 run'}
-        out['f16x3'] = f16_stats
-        del plan16, pipes16, w16, ev16
-        del work, ev
-        torch.cuda.empty_cache()
-        model = workloads.make_model(RES, P_LOCAL, Q_CHUNK, dev)
-        runs = [workloads.reconstruct_steered(model, N_POINTS, seed=42 + i, device=dev) for i in range(3)]
-        steady = min(r['total_s'] for r in runs[1:])
-        out['shapes_per_hour'] = 3600.0 / steady
-        out['reconstruction'] = {'first_shape_s': runs[0]['total_s'], 'steady_s': steady, 'latent_loop_s': runs[-1]['latent_s'],
-                                 'surface_s': runs[-1]['surface_s'], 'decoder_queries': runs[-1]['decoder_queries'],
-                                 'vertices': runs[-1]['vertices'], 'first_shape_per_hour': 3600.0 / runs[0]['total_s'],
-                                 'encoder_passes_per_s': 10.0 * (N_POINTS // 10000) / runs[-1]['latent_s'],
-                                 'note': 'whole R=257 reconstruction of a 100k-point cloud by the product driver: latent loop (100 encoder '
-                                         'passes), region growing, Marching Cubes + clean-up, 10 refinement rounds; every query decoded by the real '
-                                         'kernels, growth steered by the analytic shape (formula-filled weights describe no surface)'}
-        model.network.decoder_dtype = 'f16x3'
-        runs16 = [workloads.reconstruct_steered(model, N_POINTS, seed=42 + i, device=dev) for i in range(2)]
-        out['f16x3']['shapes_per_hour'] = 3600.0 / runs16[-1]['total_s']
-        out['f16x3']['reconstruction_steady_s'] = runs16[-1]['total_s']
+        mine = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+        dt_shapes = sharding.max_over_ranks(time.perf_counter() - t0, red_dev)
+        rank_sph = [3600.0 * args.shapes / t for t in rank_values(mine, rank, world, dist, red_dev)]
+        if rank == 0:
+            steady = min(x['total_s'] for x in runs)
+            # N = 1: the steady-state shape (best of the timed ones, as in round 2); N > 1: all shapes of all ranks / the slowest rank's wall time
+            out['shapes_per_hour'] = 3600.0 / steady if world == 1 else 3600.0 * world * args.shapes / dt_shapes
+            out['reconstruction'] = {'first_shape_s': first['total_s'], 'steady_s': steady, 'latent_loop_s': runs[-1]['latent_s'],
+                                     'surface_s': runs[-1]['surface_s'], 'decoder_queries': runs[-1]['decoder_queries'],
+                                     'vertices': runs[-1]['vertices'], 'first_shape_per_hour': 3600.0 / first['total_s'],
+                                     'encoder_passes_per_s': 10.0 * (N_POINTS // 10000) / runs[-1]['latent_s'],
+                                     'shapes_timed_per_rank': args.shapes, 'timed_s': dt_shapes, 'decoder_dtype': args.dtype,
+                                     'per_rank_shapes_per_hour': {'min': min(rank_sph), 'max': max(rank_sph), 'all': rank_sph},
+                                     'note': 'whole R=257 reconstruction of a 100k-point cloud by the product driver: latent loop (100 encoder '
+                                             'passes), region growing, Marching Cubes + clean-up, 10 refinement rounds; every query decoded by the real '
+                                             'kernels, growth steered by the analytic shape (formula-filled weights describe no surface); N>1: shape-level '
+                                             'sharding (PPS_SHARD=shapes), no collective on the data path'}
+        if world == 1:
+            model.network.decoder_dtype = other
+            runs2 = [workloads.reconstruct_steered(model, N_POINTS, seed=42 + i, device=dev) for i in range(2)]
+            out[other]['shapes_per_hour'] = 3600.0 / runs2[-1]['total_s']
+            out[other]['reconstruction_steady_s'] = runs2[-1]['total_s']
         del model
         torch.cuda.empty_cache()
+    if world == 1 and not args.quick:
         fit = workloads.FitStep(batch=10, precision='bf16-mixed', device=dev, graph=True)      # as `pps.py fit` runs it: replayed HIP graph, loader thread
         for _ in range(6):
             fit()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n_fit = 20
+        n_fit = 60
         for _ in range(n_fit):
             loss = fit()
         torch.cuda.synchronize()
@@ -268,22 +393,39 @@ def main():
                                 'patches built on the device by the loader thread on a second stream, step replayed as a HIP graph (the defaults of pps.py fit)',
                       'steps_timed': n_fit, 'loss': float(loss),
                       'shapes_per_s': 10.0 / (out['fit_ms_per_step'] * 1e-3)}
+        out['fit'].update(fit_roofline(out['fit_ms_per_step']))
         fit.close()
         del fit
         if not args.no_cpu_baseline:
             qry = torch.cat(workloads.band_chunks(shapes[0]['cloud'], RES, Q_CHUNK, dev)[0][:2]).cpu().numpy()
             out['cpu_baseline'] = cpu_baseline(sd, shapes[0]['cloud'], qry, shapes[0]['lat'])
-    elif rank == 0 and world > 1:
-        out['shapes_per_hour'] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
 
+def fit_roofline(ms_per_step):
+    """Executed matrix flops and HBM bytes of one fit step from the committed counter passes (profiles/round3_train_pmc.json, written by
+    tools/profile_train.sh) against the step time measured in THIS run.  Absent file -> no object."""
+    path = os.path.join(REPO, 'profiles', 'round3_train_pmc.json')
+    if not os.path.isfile(path):
+        return {}
+    d = json.load(open(path))
+    s = ms_per_step * 1e-3
+    out = {'roofline': {'source': 'profiles/round3_train_pmc.json (rocprofv3 --pmc passes of tools/time_fit_graph.py at commit {}; per-step sums over all kernels '
+                                  'of the step incl. the data preparation on the second stream); step time from this run'.format(d.get('git_head', 'unrecorded')),
+                        'mfma_flops_per_step': d['mfma_flops_per_step'], 'hbm_bytes_per_step': d['hbm_bytes_per_step'],
+                        'achieved_tflops': d['mfma_flops_per_step'] / s / 1e12, 'mfma_frac_of_bf16_peak': d['mfma_flops_per_step'] / s / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                        'achieved_hbm_tb_s': d['hbm_bytes_per_step'] / s / 1e12, 'hbm_frac': d['hbm_bytes_per_step'] / s / 8e12,
+                        'bound': d.get('bound', 'hbm')}}
+    return out
+
+
 def strong(args, rank, world, dev, dist, red_dev):
     """One shape, all ranks: PPS_SHARD=queries.  `steps` = reconstructions timed, `warmup` = untimed ones."""
-    from ppsurf_amd import sharding, workloads
+    from ppsurf_amd import sharding
+    import bench_workloads as workloads
     sharding.set_query_sharding(world > 1)
     model = workloads.make_model(RES, P_LOCAL, Q_CHUNK, dev)
     model.shard_queries = world > 1

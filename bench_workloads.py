@@ -17,7 +17,7 @@ import time
 import numpy as np
 import torch
 
-from . import reconstruct, spatial, synthetic
+from ppsurf_amd import reconstruct, spatial, synthetic
 
 
 class HipEvents:
@@ -84,7 +84,7 @@ class SteeredField(reconstruct.OccupancyField):
 
 
 def make_model(resolution=257, p=50, chunk=50000, device='cuda:0'):
-    from .lightning_api import PPSurfModel
+    from ppsurf_amd.lightning_api import PPSurfModel
     with contextlib.redirect_stdout(io.StringIO()):
         model = PPSurfModel(pointnet_latent_size=256, output_names=['imp_surf_sign'], in_channels=3, out_channels=2, k=64, lambda_l1=0.0,
                             debug=False, in_file='x.npy', results_dir='/tmp/res', padding_factor=0.05, name='bench', network_latent_size=256,
@@ -136,13 +136,13 @@ class FitStep:
     loss, backward, AdamW -- the step body of ppsurf_amd.fit (fused AdamW; graph=True replays it as a HIP graph like fit does by default)."""
 
     def __init__(self, batch=10, n=10000, q=2000, p=50, precision='bf16-mixed', device='cuda:0', n_batches=2, graph=False, overlap_prep=True):
-        from . import modules, fit, sharding
+        from ppsurf_amd import modules, fit, sharding
         self.p, self.dev = p, torch.device(device)
         with contextlib.redirect_stdout(io.StringIO()):
             net = modules.PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=p, pointnet_latent_size=256)
         net.load_state_dict(synthetic.network_state_dict('ppsurf', num_pts_local=p))
         self.net = net.to(self.dev).train()
-        from . import optim
+        from ppsurf_amd import optim
         self.opt = optim.AdamW(self.net.parameters(), lr=1e-3, eps=1e-5, weight_decay=1e-2, capturable=graph)   # configs/poco.yaml:60-69, the class ppsurf_amd.fit puts in for torch.optim.AdamW
         self.buckets = sharding.GradBuckets([q for q in self.net.parameters() if q.requires_grad])      # as ppsurf_amd.fit (one rank: no collective)
         self.autocast = {'bf16-mixed': torch.bfloat16, '16-mixed': torch.float16}.get(precision)
@@ -155,7 +155,7 @@ class FitStep:
             values = {}
 
         self.stepper = fit.GraphedStep(self._body, _Log(), enabled=graph)
-        from . import data
+        from ppsurf_amd import data
         self.prefetch = data.DevicePrefetch(self.dev) if overlap_prep else None
         self.fut = None
         if self.prefetch is not None:
@@ -173,7 +173,7 @@ class FitStep:
                 'imp_surf_dist_ms': torch.from_numpy(np.stack(dist)).to(self.dev)}
 
     def _body(self, batch, bi):
-        from . import train_graph
+        from ppsurf_amd import train_graph
         self.buckets.zero()
         with torch.autocast('cuda', dtype=self.autocast or torch.bfloat16, enabled=self.autocast is not None):
             logits = self.net.forward(batch)
@@ -196,7 +196,7 @@ class FitStep:
         b = batch['pts_ms'].shape[0]
         batch['pts_local_ps'] = spatial.get_pts_local_ps_batch([batch['pts_ms'][j] for j in range(b)], batch['pts_query_ms'], self.p)
         batch = {k: v for k, v in spatial.get_data_poco(batch).items() if not k.startswith('_')}
-        from . import train_graph
+        from ppsurf_amd import train_graph
         with torch.no_grad():
             batch.update(train_graph.table_extras(batch))       # like data.TrainDataset.collate_on_device
         return batch

@@ -26,8 +26,8 @@ class AdamW(torch.optim.AdamW):
                  capturable=False, differentiable=False, fused=None):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, maximize=maximize, foreach=None,
                          capturable=capturable, differentiable=differentiable, fused=True)
-        self._tables = {}        # group index -> (signature, pieces tensor, step-pointer tensor, n_pieces, n_steps, (param, grad) pointers)
-        self._moved = 0          # consecutive steps that had to rebuild a table (gradients allocated anew by every backward pass)
+        self._tables = {}        # group index -> (signature, pieces tensor, step-pointer tensor, n_pieces, n_steps, quick key)
+        self._moved = {}         # group index -> consecutive steps that had to rebuild its table (gradients allocated anew by every backward pass)
         self.fast_steps = 0      # steps taken by the HIP kernel (tests / diagnostics)
 
     # ---- fast path ------------------------------------------------------------------------------------------------------------------
@@ -52,6 +52,7 @@ class AdamW(torch.optim.AdamW):
         fresh = [p for p in ps if len(self.state[p]) == 0]
         if not fresh:
             return
+        self._tables.clear()                                          # new state tensors: no cached table may point at what these replace
         steps = torch.zeros((len(fresh),), dtype=torch.float32, device=fresh[0].device)     # one allocation for the step counts of the batch
         for i, p in enumerate(fresh):
             st = self.state[p]
@@ -60,14 +61,18 @@ class AdamW(torch.optim.AdamW):
             st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
 
     def _table(self, gi, ps):
-        quick = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
+        # the table holds raw pointers: it is valid only while parameters, gradients AND state tensors are where they were (a caller may
+        # clear or reassign optimizer.state without going through load_state_dict)
+        state = self.state
+        quick = tuple((p.data_ptr(), p.grad.data_ptr(), state[p]['exp_avg'].data_ptr(), state[p]['exp_avg_sq'].data_ptr(), state[p]['step'].data_ptr())
+                      for p in ps)
         cached = self._tables.get(gi)
-        if cached is not None and cached[5] == quick:               # state tensors only move through load_state_dict(), which drops the tables
-            self._moved = 0
+        if cached is not None and cached[5] == quick:
+            self._moved[gi] = 0
             return cached
         if cached is not None:
-            self._moved += 1
-            if self._moved > 8:
+            self._moved[gi] = self._moved.get(gi, 0) + 1
+            if self._moved[gi] > 8:
                 return None                                          # gradients never stay put (no flat gradient buffers): building a 3600-row
                                                                      # table on the host every step costs more than torch's nine launches
         sig, rows, step_ptrs = [], [], []
@@ -135,5 +140,18 @@ class AdamW(torch.optim.AdamW):
         return loss
 
     def load_state_dict(self, state_dict):
-        super().load_state_dict(state_dict)
+        """Accepts the state of ANY AdamW of the same parameters -- in particular a checkpoint written by the reference's Lightning run or by a
+        non-fused torch.optim.AdamW (`fused` / `capturable` / `foreach` None or False in its param_groups, `step` counts saved as CPU scalars).
+        torch's load_state_dict takes those three keys from the SAVED groups, both for the groups themselves and for the decision whether the
+        `step` tensors follow the parameters to the device as float32; with the saved values this optimizer would come back as a foreach
+        implementation with host-side step counts, which neither GradScaler's fused hand-over nor graph capture accepts.  The implementation
+        flags are a property of this object, not of the checkpoint: they are put in front of the saved ones."""
+        own = self.param_groups
+        saved = state_dict['param_groups']
+        if len(saved) != len(own):
+            raise ValueError('loaded state dict has a different number of parameter groups')
+        patched = [dict(g, fused=o.get('fused'), capturable=o.get('capturable', False), foreach=o.get('foreach'), differentiable=o.get('differentiable', False))
+                   for g, o in zip(saved, own)]
+        super().load_state_dict({'state': state_dict['state'], 'param_groups': patched})
         self._tables.clear()                                          # the state tensors were replaced
+        self._moved.clear()

@@ -76,7 +76,7 @@ class OccupancyField:
         return torch.cat(out)
 
 
-FIELD_CLASS = OccupancyField          # measurement workloads substitute a subclass (ppsurf_amd/workloads.py)
+FIELD_CLASS = OccupancyField          # measurement workloads substitute a subclass (bench_workloads.py)
 
 
 def create_volume(field, pts_ids: torch.Tensor, resolution: int, step: float, bmin_pad: float, padding=1, dilation_size=2,

@@ -177,7 +177,7 @@ def test_config3_fit_step_at_full_batch_size(precision):
     the same graph on plain-torch twins of the HIP ops (tests/train_ref_ops.py), like for like: loss within 2e-4 (fp32) / the
     bf16 noise floor, gradients finite everywhere, no parameter without gradient besides the reference's own set."""
     import train_ref_ops as ref
-    from ppsurf_amd import workloads
+    import bench_workloads as workloads
     from ppsurf_amd import spatial
     step = workloads.FitStep(batch=10, precision=precision, device=DEV, n_batches=1)
     for m in step.net.modules():
@@ -212,7 +212,7 @@ def test_config5_ppsurf_200nn_chunk_at_size():
     product's chunk loop: exact 64-NN and 200-NN tables, finite outputs, permutation equivariance, 64 sampled queries vs the oracle."""
     from ppsurf_amd.decoder import DecoderPlan, ChunkPipeline
     from ppsurf_amd.synthetic import make_cloud, make_latents, network_state_dict
-    from ppsurf_amd import workloads
+    import bench_workloads as workloads
     n, p, qn = 250_000, 200, 25_000
     sd = network_state_dict('ppsurf', num_pts_local=p)
     plan = DecoderPlan(sd, DEV)
@@ -270,7 +270,7 @@ def test_f16x3_reconstruction_equals_fp32_reconstruction(trained):
         model.network.decoder_dtype = dt
         field = reconstruct.OccupancyField(model.network, shape, pts_cf.t().unsqueeze(0), 50000, 50)
         assert field.plan.dtype == dt
-        step, bmin_pad, pts_ids = __import__('ppsurf_amd.workloads', fromlist=['x']).grid_geometry(cloud, 65)
+        step, bmin_pad, pts_ids = __import__('bench_workloads').grid_geometry(cloud, 65)
         vol = reconstruct.create_volume(field, torch.from_numpy(pts_ids).to(DEV), 65, step, bmin_pad)
         mesh = reconstruct.export_mesh_and_refine_vertices_region_growing_v3(
             network=model.network, latent=shape, pts_raw_ms=pts_cf.t().unsqueeze(0), resolution=65, padding=1, mc_value=0, num_pts=50000,

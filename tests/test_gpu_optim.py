@@ -179,7 +179,7 @@ def test_what_the_kernel_does_not_take_goes_through_torch():
 def test_fit_step_trajectory_equals_torchs_optimizer():
     """workloads.FitStep (gradients in sharding.GradBuckets' flat buffers, parameters without a gradient skipped) for four steps with the HIP
     AdamW and with torch.optim.AdamW(fused=True) from the same start: same losses, same parameters, same optimizer state."""
-    from ppsurf_amd import workloads
+    import bench_workloads as workloads
     runs = []
     import random
     import numpy as np
@@ -218,3 +218,57 @@ def test_fit_step_trajectory_equals_torchs_optimizer():
     assert set(sa['state']) == set(sb['state'])
     for i in sa['state']:
         assert float(sa['state'][i]['step']) == float(sb['state'][i]['step'])
+
+
+@pytest.mark.parametrize('capturable', [False, True])
+def test_resume_from_a_non_fused_cpu_checkpoint_under_gradscaler(capturable, tmp_path):
+    """a checkpoint written by a plain (foreach) AdamW, read back with map_location='cpu' as fit() does, carries fused / capturable =
+    None / False and CPU `step` scalars.  Before the fix the loaded optimizer fell to torch's foreach step, which GradScaler's fused hand-over
+    (grad_scale / found_inf arguments) does not accept: AssertionError under 16-mixed.  Now the HIP step keeps running and follows a fused torch
+    AdamW that was resumed from the same file."""
+    import copy
+    from ppsurf_amd import optim
+    a = _params()
+    plain = torch.optim.AdamW(a, **KW)
+    for step in range(2):
+        _set_grads(a, a, step)
+        plain.step()
+    torch.save({'optimizer_states': [plain.state_dict()]}, tmp_path / 'last.ckpt')
+    state = torch.load(tmp_path / 'last.ckpt', map_location='cpu')['optimizer_states'][0]
+    assert not state['param_groups'][0].get('fused') and state['state'][0]['step'].device.type == 'cpu'
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    mine, ref = optim.AdamW(a, capturable=capturable, **KW), torch.optim.AdamW(b, fused=True, capturable=capturable, **KW)
+    mine.load_state_dict(copy.deepcopy(state))
+    patched = copy.deepcopy(state)
+    for g in patched['param_groups']:
+        g.update(fused=True, capturable=capturable, foreach=None)
+    ref.load_state_dict(patched)
+    assert mine.param_groups[0]['fused'] is True and mine.param_groups[0]['capturable'] is capturable
+    assert all(mine.state[p]['step'].is_cuda and mine.state[p]['step'].dtype == torch.float32 for p in a)
+    sa, sb = torch.amp.GradScaler('cuda', init_scale=64.0), torch.amp.GradScaler('cuda', init_scale=64.0)
+    for step in range(3):
+        for params, opt, sc in ((a, mine, sa), (b, ref, sb)):
+            opt.zero_grad(set_to_none=True)
+            loss = sum(((p * (1.5 + i)) ** 2).sum() for i, p in enumerate(params))
+            sc.scale(loss).backward()
+            sc.step(opt)                      # raised "Expected grad_scale and found_inf to be None" before the fix
+            sc.update()
+    assert mine.fast_steps == 3
+    _same(a, b, mine, ref, rtol=5e-6)
+    assert float(mine.state[a[0]]['step']) == 5.0
+
+
+def test_state_replaced_behind_the_optimizers_back_rebuilds_the_pointer_table():
+    """ADVICE r2 (optim.py:63): the cached device table holds raw pointers to exp_avg / exp_avg_sq / step; replacing those tensors without
+    load_state_dict must not leave the kernel writing through the old ones."""
+    a, b, mine, ref = _pair()
+    for step in range(2):
+        _set_grads(a, b, step)
+        mine.step(); ref.step()
+    for p in a:                                   # fresh tensors with the same contents
+        st = mine.state[p]
+        mine.state[p] = {'step': st['step'].clone(), 'exp_avg': st['exp_avg'].clone(), 'exp_avg_sq': st['exp_avg_sq'].clone()}
+    for step in range(2, 4):
+        _set_grads(a, b, step)
+        mine.step(); ref.step()
+    _same(a, b, mine, ref)

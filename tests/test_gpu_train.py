@@ -405,7 +405,8 @@ def test_step_uses_the_tables_built_with_the_batch(monkeypatch):
     """train_graph.table_extras builds flat ids + CSR of every id table with the batch; registered at the start of the forward pass, the
     backward pass must not sort anything (that is what keeps radix sorts out of the replayed HIP graph) -- and the gradients must be the
     ones of the step that builds its CSRs on the fly."""
-    from ppsurf_amd import workloads, train_ops, train_graph
+    from ppsurf_amd import train_ops, train_graph
+    import bench_workloads as workloads
     torch.manual_seed(0)
     step = workloads.FitStep(batch=2, n=1500, q=200, p=20, precision='32', overlap_prep=False)
     for m in step.net.modules():

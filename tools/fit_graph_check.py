@@ -1,6 +1,6 @@
 import sys, torch
 sys.path.insert(0, '.')
-from ppsurf_amd import workloads
+import bench_workloads as workloads
 import random
 res = {}
 for graph in (False, True):

@@ -4,7 +4,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = '''
 import sys, torch, os
 sys.path.insert(0, %r)
-from ppsurf_amd import workloads, train_graph, train_ops
+from ppsurf_amd import train_graph, train_ops
+import bench_workloads as workloads
 knob = %r
 if "nosplitk" in knob: train_graph.SPLITK_MIN_ROWS = 10**12
 if "s64" in knob: train_graph.SPLITK_SLABS = 10**9

@@ -4,7 +4,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = '''
 import sys, torch, os, gc
 sys.path.insert(0, %r)
-from ppsurf_amd import workloads
+import bench_workloads as workloads
 seq = %r
 for tok in seq.split():
     if tok == "empty":

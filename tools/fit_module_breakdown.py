@@ -9,7 +9,8 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ppsurf_amd import spatial, train_graph, workloads          # noqa: E402
+from ppsurf_amd import spatial, train_graph          # noqa: E402
+import bench_workloads as workloads
 
 
 def timed(step, n):

@@ -8,7 +8,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ppsurf_amd import workloads          # noqa: E402
+import bench_workloads as workloads          # noqa: E402
 
 
 def main():

@@ -1,7 +1,8 @@
 import sys, time
 sys.path.insert(0,'.')
 import numpy as np, torch
-from ppsurf_amd import ops, workloads
+from ppsurf_amd import ops
+import bench_workloads as workloads
 from ppsurf_amd.synthetic import make_cloud
 DEV='cuda:0'
 base = make_cloud(100000, seed=42)

@@ -1,7 +1,7 @@
 import os, sys
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch
-from ppsurf_amd import workloads
+import bench_workloads as workloads
 from ppsurf_amd.decoder import DecoderPlan, ChunkPipeline
 from ppsurf_amd.synthetic import make_cloud, make_latents, network_state_dict
 DEV='cuda:0'

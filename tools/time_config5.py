@@ -37,7 +37,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert bool(torch.isfinite(res[-1][1]).all())
-    from ppsurf_amd.workloads import HipEvents
+    from bench_workloads import HipEvents
     evs = [HipEvents(6) for _ in range(a.steps)]
     pipe.run([qd] * a.steps, want_occ=True, stage_events=[e.arr for e in evs])
     torch.cuda.synchronize()

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ppsurf_amd import workloads          # noqa: E402
+import bench_workloads as workloads          # noqa: E402
 from ppsurf_amd.decoder import DecoderPlan, ChunkPipeline          # noqa: E402
 from ppsurf_amd.synthetic import make_cloud, make_latents, network_state_dict          # noqa: E402
 

@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from ppsurf_amd import workloads
+import bench_workloads as workloads
 from ppsurf_amd.decoder import DecoderPlan, ChunkPipeline
 from ppsurf_amd.synthetic import make_cloud, make_latents, network_state_dict
 

@@ -3,7 +3,8 @@ analytic occupancy (no kernels of the network run) -- what the torch-op driver i
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from ppsurf_amd import reconstruct, workloads, synthetic, mcubes
+from ppsurf_amd import reconstruct, synthetic, mcubes
+import bench_workloads as workloads
 
 DEV = 'cuda:0'
 cloud, norm = synthetic.make_cloud(100000, seed=42, noise=0.0, return_norm=True)

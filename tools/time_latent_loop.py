@@ -2,7 +2,8 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from ppsurf_amd import workloads, spatial
+from ppsurf_amd import spatial
+import bench_workloads as workloads
 from ppsurf_amd.synthetic import make_cloud
 
 DEV = 'cuda:0'
