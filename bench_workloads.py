@@ -94,7 +94,7 @@ def make_model(resolution=257, p=50, chunk=50000, device='cuda:0'):
     return model.to(device).eval()
 
 
-def reconstruct_steered(model, n_points=100_000, seed=42, device='cuda:0'):
+def reconstruct_steered(model, n_points=100_000, seed=42, device='cuda:0', return_mesh=False):
     """One reconstruction with the product's own driver (encode_latents + export_mesh_and_refine_vertices_region_growing_v3),
     every query decoded by the real kernels, growth steered by the analytic shape.  Returns a dict of seconds / counts."""
     cloud, norm = synthetic.make_cloud(n_points, seed=seed, noise=0.0, return_norm=True)
@@ -126,8 +126,11 @@ def reconstruct_steered(model, n_points=100_000, seed=42, device='cuda:0'):
     torch.cuda.synchronize(device)
     t2 = time.perf_counter()
     verts, faces = mesh if mesh is not None else (np.zeros((0, 3)), np.zeros((0, 3)))
-    return {'latent_s': t1 - t0, 'surface_s': t2 - t1, 'total_s': t2 - t0, 'decoder_queries': fields[0].n_queries if fields else 0,
-            'vertices': int(verts.shape[0]), 'faces': int(faces.shape[0])}
+    out = {'latent_s': t1 - t0, 'surface_s': t2 - t1, 'total_s': t2 - t0, 'decoder_queries': fields[0].n_queries if fields else 0,
+           'vertices': int(verts.shape[0]), 'faces': int(faces.shape[0])}
+    if return_mesh:
+        out['mesh'] = (verts, faces)
+    return out
 
 
 class FitStep:

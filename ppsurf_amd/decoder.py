@@ -284,7 +284,14 @@ class PocoDecoderPlan:
     """Packed weights of POCO's projection head (source/poco_model.py:362-419; latent size 32 or 64, few output channels).
     fc1 is split like in DecoderPlan (per-point table G), fc8 . fc_value is composed on the host and applied after pooling."""
 
-    def __init__(self, sd, device, prefix='projection'):
+    def __init__(self, sd, device, prefix='projection', dtype=None):
+        """dtype: None / 'f32'.  There is no split-precision ('f16x3') plan for this head -- its layers are 32 or 64 wide (2 x 2 or 4 x 4 MFMA
+        blocks, all weights resident in LDS, never the bottleneck of a POCO reconstruction): asking for one is refused instead of silently
+        running fp32.  The PPS_DECODER_DTYPE default of the PPSurf decoder is not consulted here."""
+        if dtype not in (None, 'f32'):
+            raise NotImplementedError("POCO's projection head has no {!r} plan (decoder dtypes: 'f32'); 'f16x3' exists for the PPSurf decoder "
+                                      '(DecoderPlan) only'.format(dtype))
+        self.dtype = 'f32'
         p = prefix
         w1, b1 = _wb(sd, p + '.fc1')
         c = w1.shape[0]

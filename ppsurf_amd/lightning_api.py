@@ -259,7 +259,13 @@ class PocoModel(_Base):
         else:
             ids = valid_ids[torch.randperm(valid_ids.shape[0], generator=gen)[:m].to(dev)]
         if ids.shape[0] < m:
-            top = torch.randperm(n, device=dev) if gen is None else torch.randperm(n, generator=gen).to(dev)
+            # the reference draws the top-up with `torch.randperm(N, device=pts.device)` (:217-219): the generator of the cloud's device.  In
+            # 'device' mode that is what happens here; in 'reference' mode the stream to follow is the one the reference's CPU execution
+            # consumes (what the fixtures were recorded from), so the top-up comes from the CPU generator too
+            if gen is not None:
+                top = torch.randperm(n, generator=gen).to(dev)
+            else:
+                top = torch.randperm(n, device=dev) if device_rng else torch.randperm(n).to(dev)
             ids = torch.cat([ids, top[:m - ids.shape[0]]], dim=0)
         return ids
 

@@ -417,9 +417,10 @@ class PocoNetwork(_Base):
         print('Network -- projection -- {} parameters'.format(count_parameters(self.projection)))
 
     def decoder_plan(self, device) -> PocoDecoderPlan:
-        ver = _params_version(self.projection) + (self.training,)
+        ver = _params_version(self.projection) + (self.training, getattr(self, 'decoder_dtype', None))
         if self._dec is None or self._dec[0] != ver or self._dec[1].device != torch.device(device):
-            self._dec = (ver, PocoDecoderPlan({'projection.' + k: v for k, v in _sd(self.projection).items()}, device))
+            self._dec = (ver, PocoDecoderPlan({'projection.' + k: v for k, v in _sd(self.projection).items()}, device,
+                                              dtype=getattr(self, 'decoder_dtype', None)))          # 'f16x3' is refused there
             self._table = None
         return self._dec[1]
 

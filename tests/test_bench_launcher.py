@@ -1,0 +1,73 @@
+"""bench.py as the driver calls it: `python bench.py --gpus N` with no launcher around it must become N ranks by itself."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from golden_util import REPO
+
+
+def _bench():
+    sys.path.insert(0, REPO)
+    import bench
+    return bench
+
+
+def test_launch_command_is_one_rank_per_gpu_on_loopback():
+    bench = _bench()
+    cmd = bench.launch_cmd(4, ['--gpus', '4', '--steps', '7', '--spawn'], 29999)
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert '--nnodes=1' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[cmd.index('--master-port') + 1] == '29999'
+    i = cmd.index(os.path.join(REPO, 'bench.py'))
+    assert cmd[i + 1:] == ['--gpus', '4', '--steps', '7']            # the re-executed script gets the user's arguments, minus --spawn
+    assert 0 < bench.free_port() < 65536
+
+
+def test_self_spawn_starts_the_ranks_and_passes_their_exit_code_through(tmp_path, monkeypatch):
+    """The launcher itself, on the CPU: the re-executed script is replaced by a stub that reports what torch.distributed.run gave it."""
+    bench = _bench()
+    stub = tmp_path / 'stub.py'
+    stub.write_text("import os, sys\n"
+                    "open(os.path.join({!r}, 'rank' + os.environ['RANK']), 'w').write(' '.join([os.environ['WORLD_SIZE'], os.environ['LOCAL_RANK'], "
+                    "os.environ['MASTER_ADDR'], os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '')] + sys.argv[1:]))\n"
+                    "sys.exit(3 if '--fail' in sys.argv and os.environ['RANK'] == '1' else 0)\n".format(str(tmp_path)))
+    monkeypatch.setattr(bench, '__file__', str(stub))
+    assert bench.self_spawn(2, ['--gpus', '2', '--quick']) == 0
+    for r in (0, 1):
+        assert (tmp_path / 'rank{}'.format(r)).read_text().split() == ['2', str(r), '127.0.0.1', '0', '--gpus', '2', '--quick']
+    assert bench.self_spawn(2, ['--gpus', '2', '--fail']) != 0
+
+
+def test_a_mismatched_launcher_is_refused_not_ignored():
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='1')
+    p = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '4', '--quick'], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and 'WORLD_SIZE' in p.stderr
+
+
+@pytest.mark.gpu
+def test_plain_gpus_2_prints_one_line_with_per_rank_rates_and_shapes_per_hour():
+    """`python bench.py --gpus 2` exactly as the driver would type it (plus the single-GPU rehearsal switches): self-spawn, two ranks on
+    cuda:0 over gloo, ONE JSON line from rank 0 with n_gpus 2, per-rank rates and a shapes/hour figure."""
+    p = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--same-gpu', '--steps', '2', '--warmup', '1',
+                        '--shapes', '1'], capture_output=True, text=True, timeout=1500, cwd=REPO)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['world_size_seen'] == 2 and d['steps'] == 2 and d['scaling'] == 'weak'
+    assert len(d['per_rank_queries_per_s']['all']) == 2 and d['per_rank_queries_per_s']['min'] > 0
+    assert d['value'] > 0 and d['repeats'] >= 1 and d['timed_s'] >= 1.0
+    assert d['shapes_per_hour'] and d['shapes_per_hour'] > 0 and len(d['reconstruction']['per_rank_shapes_per_hour']['all']) == 2
+    assert 'cpu_baseline' not in d and 'fit_ms_per_step' not in d                    # rank 0 at N = 1 only
+
+
+@pytest.mark.gpu
+def test_self_spawned_single_rank_gives_the_same_kind_of_line():
+    p = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--spawn', '--quick', '--steps', '3', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+    assert d['n_gpus'] == 1 and d['roofline']['frac'] > 0.2 and d['value'] > 1e6

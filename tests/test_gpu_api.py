@@ -14,13 +14,17 @@ DEV = 'cuda:0'
 _net = None
 
 
-def network():
+DTYPES = ['f32', 'f16x3']          # every decoder dtype is held to the same 1e-4 bar
+
+
+def network(dtype='f32'):
     global _net
     if _net is None:
         from source.ppsurf_model import PPSurfNetwork
         net = PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=50, pointnet_latent_size=256)
         net.load_state_dict(filled_sd('', key='ppsurf'))
         _net = net.to(DEV).eval()
+    _net.decoder_dtype = dtype          # part of the plan cache key (modules.PPSurfNetwork.decoder_plan)
     return _net
 
 
@@ -76,19 +80,21 @@ def test_forward_with_precomputed_ids_vs_oracle():
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-4)
 
 
-def test_full_size_forward_matches_reference_fixture():
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_full_size_forward_matches_reference_fixture(dtype):
     """PPSurfNetwork.forward at full size -- FKAConvNetwork(hidden=64) on a 10000-point cloud, 64-NN interpolation, 50-NN
     patches -- against the REFERENCE's own output (tests/golden/ppsurf_forward.npz): logits within 1e-4 absolute, the
     north_star's tolerance, end to end through encoder and decoder."""
     from golden.cases_r2 import forward_case
     g = load_golden('ppsurf_forward')
-    net = network()
+    net = network(dtype)
+    assert net.decoder_plan(DEV).dtype == dtype
     data = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in forward_case(g).items()}
     out = net.forward(data)
     assert tuple(out.shape) == (1, 2, 256)
     lat = data['latents'][0, :, ::25].cpu().numpy()
     err_lat, err = np.abs(lat - g['latents_sub']).max(), np.abs(out.cpu().numpy() - g['logits']).max()
-    print('full-size forward: latents |max| {:.1f} err {:.2e}; logits err {:.2e}'.format(float(g['latents_absmax']), err_lat, err))
+    print(dtype, 'full-size forward: latents |max| {:.1f} err {:.2e}; logits err {:.2e}'.format(float(g['latents_absmax']), err_lat, err))
     assert err_lat < 1e-4 and err < 1e-4
 
 
@@ -173,9 +179,10 @@ def test_reconstruction_volume_matches_oracle_driver_and_writes_ply(tmp_path):
         assert v.shape[0] == model.last_prediction[0].shape[0] and np.isfinite(v).all()
 
 
-def test_from_latent_batch_of_two_and_empty_queries():
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_from_latent_batch_of_two_and_empty_queries(dtype):
     """B > 1 (fit / validation batches) and degenerate query counts."""
-    net = network()
+    net = network(dtype)
     sd = filled_sd('', key='ppsurf')
     rng = np.random.default_rng(8)
     clouds = [make_cloud(900, seed=s) for s in (1, 2)]
@@ -193,10 +200,11 @@ def test_from_latent_batch_of_two_and_empty_queries():
     assert tuple(net.from_latent(empty).shape) == (1, 2, 0)
 
 
-def test_tiny_cloud_clamps_k_everywhere():
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_tiny_cloud_clamps_k_everywhere(dtype):
     """A cloud with fewer points than k=64 / 16: every table clamps (poco_utils.py:259-260) and the decoder masks the
     missing neighbours."""
-    net = network()
+    net = network(dtype)
     sd = filled_sd('', key='ppsurf')
     cloud = make_cloud(50, seed=21)
     qry = (cloud[:9] + 0.01).astype(np.float32)
@@ -241,3 +249,13 @@ def test_poco_projection_head_and_network():
                              data['pts'].cpu(), data['pts_query'].cpu().transpose(1, 2))
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-4)
     assert tuple(data['proj_ids'].shape) == (1, 80, 64)
+    # POCO's head (latent 32: 2 x 2 MFMA blocks per layer, all weights resident in LDS) has no split-precision plan; asking for one is an
+    # error, not a silent fp32 run -- and the process-wide PPS_DECODER_DTYPE default of the PPSurf decoder does not reach it
+    with pytest.raises(NotImplementedError, match='f16x3'):
+        PocoDecoderPlan({k.replace('IA_c32.', 'projection.'): v for k, v in sd.items()}, DEV, dtype='f16x3')
+    net.decoder_dtype = 'f16x3'
+    net._dec = None
+    with pytest.raises(NotImplementedError, match='f16x3'):
+        net.from_latent(data)
+    net.decoder_dtype = 'f32'
+    np.testing.assert_allclose(net.from_latent(data).cpu().numpy(), ref.numpy(), rtol=0, atol=1e-4)

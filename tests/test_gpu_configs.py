@@ -171,11 +171,13 @@ def test_batch_dictionaries_match_the_reference_manifest(trained):
             assert type(fit[k]).__name__ == dt and len(fit[k]) == shape
 
 
-@pytest.mark.parametrize('precision', ['32', 'bf16-mixed'])
+@pytest.mark.parametrize('precision', ['32', 'bf16-mixed', '16-mixed'])
 def test_config3_fit_step_at_full_batch_size(precision):
-    """BASELINE config 3 on one GPU: B = 10 shapes x 10000 points, 2000 queries per shape, P = 50.  The HIP training step against
-    the same graph on plain-torch twins of the HIP ops (tests/train_ref_ops.py), like for like: loss within 2e-4 (fp32) / the
-    bf16 noise floor, gradients finite everywhere, no parameter without gradient besides the reference's own set."""
+    """BASELINE config 3 on one GPU: B = 10 shapes x 10000 points, 2000 queries per shape, P = 50 -- in fp32, bf16-mixed (BASELINE's dtype) and
+    16-mixed (fp16 autocast + loss scaling: the reference's own default, configs/poco.yaml:10).  The HIP training step against the same
+    graph on plain-torch twins of the HIP ops (tests/train_ref_ops.py), like for like: loss within 2e-4 (fp32) / the 16-bit noise floor,
+    gradients finite everywhere, no parameter without gradient, and the gradient NORM of every one of the parameter tensors equal to the
+    twin step's within the precision's noise (not only the loss)."""
     import train_ref_ops as ref
     import bench_workloads as workloads
     from ppsurf_amd import spatial
@@ -190,24 +192,37 @@ def test_config3_fit_step_at_full_batch_size(precision):
     batch = spatial.get_data_poco(batch)
     assert tuple(batch['pts'].shape) == (10, 3, 10000) and tuple(batch['pts_local_ps'].shape) == (10, 2000, 50, 3) and tuple(batch['ids00'].shape) == (10, 10000, 16)
     sd0 = {k: v.clone() for k, v in step.net.state_dict().items()}
-    losses = []
+    auto = {'32': None, 'bf16-mixed': torch.bfloat16, '16-mixed': torch.float16}[precision]
+    scale = 1024.0 if precision == '16-mixed' else 1.0            # a fixed loss scale (what GradScaler multiplies in), taken out of the norms again
+    losses, norms = [], []
     for twins in (False, True):
         step.net.load_state_dict(sd0)
         step.net.zero_grad(set_to_none=True)
         ctx = ref.patched() if twins else __import__('contextlib').nullcontext()
-        with ctx, torch.autocast('cuda', dtype=torch.bfloat16, enabled=precision != '32'):
+        with ctx, torch.autocast('cuda', dtype=auto or torch.bfloat16, enabled=auto is not None):
             logits = step.net.forward({k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()})
             loss = torch.nn.functional.cross_entropy(logits.float(), batch['occ'], reduction='none').mean()
-        loss.backward()
+        (loss * scale).backward()
         grads = {k: p.grad for k, p in step.net.named_parameters()}
         assert torch.isfinite(loss) and tuple(logits.shape) == (10, 2, 2000)
         assert all(torch.isfinite(g).all() for g in grads.values() if g is not None)
         losses.append((float(loss), sorted(k for k, g in grads.items() if g is None)))
+        norms.append({k: float(g.double().norm()) / scale for k, g in grads.items()})
     assert losses[0][1] == losses[1][1] == []
     assert abs(losses[0][0] - losses[1][0]) < (2e-4 if precision == '32' else 2e-2), losses
+    top = max(norms[1].values())
+    rel = {k: abs(norms[0][k] - norms[1][k]) / max(norms[1][k], 1e-4 * top) for k in norms[1]}
+    worst = max(rel, key=rel.get)
+    print(precision, 'per-parameter gradient norms, HIP step vs twin step: worst relative difference {:.3e} ({}), median {:.3e}'.format(
+        rel[worst], worst, float(np.median(list(rel.values())))))
+    # fp32: the two steps differ by summation order only.  16-bit: every activation is rounded to 8 (bf16) / 11 (fp16) bits once per
+    # layer in BOTH steps, at different places of the fused / unfused graphs; the norms of 298 tensors agree to a few per cent
+    assert rel[worst] < {'32': 2e-3, 'bf16-mixed': 0.2, '16-mixed': 0.1}[precision], (worst, norms[0][worst], norms[1][worst])
+    assert float(np.median(list(rel.values()))) < {'32': 1e-4, 'bf16-mixed': 2e-2, '16-mixed': 1e-2}[precision]
 
 
-def test_config5_ppsurf_200nn_chunk_at_size():
+@pytest.mark.parametrize('dtype', ['f32', 'f16x3'])
+def test_config5_ppsurf_200nn_chunk_at_size(dtype):
     """BASELINE config 5 chunk: N = 250 000 points, P = 200, rec_batch_size = 25 000, k = 64 (configs/ppsurf_200nn.yaml) through the
     product's chunk loop: exact 64-NN and 200-NN tables, finite outputs, permutation equivariance, 64 sampled queries vs the oracle."""
     from ppsurf_amd.decoder import DecoderPlan, ChunkPipeline
@@ -215,7 +230,7 @@ def test_config5_ppsurf_200nn_chunk_at_size():
     import bench_workloads as workloads
     n, p, qn = 250_000, 200, 25_000
     sd = network_state_dict('ppsurf', num_pts_local=p)
-    plan = DecoderPlan(sd, DEV)
+    plan = DecoderPlan(sd, DEV, dtype=dtype)
     cloud = make_cloud(n, seed=5)
     lat = make_latents(256, n, seed=6)
     pts = torch.from_numpy(cloud).to(DEV)
@@ -284,3 +299,167 @@ def test_f16x3_reconstruction_equals_fp32_reconstruction(trained):
     assert ma is not None and mb is not None and abs(ma[0].shape[0] - mb[0].shape[0]) <= 0.002 * ma[0].shape[0] + 2
     d = np.sqrt(((ma[0][::9, None, :] - mb[0][None, :, :]) ** 2).sum(-1)).min(axis=1)
     assert np.median(d) < 1e-4 and np.percentile(d, 99) < 0.05 / 64
+
+
+# ---- whole reconstructions at the configurations' own sizes ---------------------------------------------------------------
+def _trained_model(root, ckpt, resolution, iters=3):
+    from ppsurf_amd.lightning_api import PPSurfModel
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = PPSurfModel(pointnet_latent_size=256, output_names=['imp_surf_sign'], in_channels=3, out_channels=2, k=64, lambda_l1=0.0, debug=False,
+                            in_file='x.npy', results_dir=str(root / 'rw'), padding_factor=0.05, name='t', network_latent_size=256,
+                            gen_subsample_manifold_iter=iters, gen_subsample_manifold=10000, gen_resolution_global=resolution, num_pts_local=50,
+                            rec_batch_size=50000, gen_refine_iter=10, workers=1)
+    model.load_state_dict(torch.load(ckpt, map_location='cpu')['state_dict'])
+    return model.to(DEV).eval()
+
+
+def _abc_cloud(root, which=0):
+    from ppsurf_amd import meshio
+    names = [l.strip() for l in open(root / 'abc' / 'trainset.txt') if l.strip()]
+    return meshio.load_pts(str(root / 'abc' / '04_pts_vis' / (names[which] + '.xyz.ply')))[:, :3].astype(np.float32)
+
+
+def _closed_manifold_stats(faces):
+    e = np.sort(np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]]), axis=1)
+    _, cnt = np.unique(e[:, 0].astype(np.int64) * (int(faces.max()) + 1) + e[:, 1], return_counts=True)
+    return float((cnt == 2).mean()), int((cnt == 1).sum()), int((cnt > 2).sum())
+
+
+def test_config4_unit_of_work_one_abc_shape_at_r257_learned_weights(trained):
+    """BASELINE config 4's per-GPU unit of work: ONE whole reconstruction at gen_resolution_global = 257 (latent loop, region growing, Marching
+    Cubes, clean-up, 10 refinement rounds; source/poco_utils.py:26-254) of a real ABC shape with the learned checkpoint of the abc_mini4 fit.
+    Asserted against a stored band: vertex count, distance of the input cloud to the surface, closedness."""
+    from ppsurf_amd import reconstruct
+    root, ckpt = trained
+    model = _trained_model(root, ckpt, 257)
+    cloud = _abc_cloud(root)
+    pts_cf = torch.from_numpy(cloud).to(DEV).t().contiguous()
+    torch.manual_seed(11)
+    lat = model.encode_latents(pts_cf)
+    shape = {'pts': pts_cf.unsqueeze(0), 'latents': lat.t().unsqueeze(0)}
+    fields = []
+
+    class Field(reconstruct.OccupancyField):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            fields.append(self)
+
+    old, reconstruct.FIELD_CLASS = reconstruct.FIELD_CLASS, Field
+    try:
+        mesh = reconstruct.export_mesh_and_refine_vertices_region_growing_v3(
+            network=model.network, latent=shape, pts_raw_ms=pts_cf.t().unsqueeze(0), resolution=257, padding=1, mc_value=0, num_pts=50000,
+            num_pts_local=50, input_points=cloud, refine_iter=10, out_value=1)
+    finally:
+        reconstruct.FIELD_CLASS = old
+    assert mesh is not None
+    v, f = mesh
+    voxel = float(cloud.max() - cloud.min()) / 256
+    sub = cloud[::7]
+    d = np.concatenate([np.sqrt(((sub[s:s + 512, None, :] - v[None, ::3, :]) ** 2).sum(-1)).min(axis=1) for s in range(0, sub.shape[0], 512)])
+    two, open_e, multi = _closed_manifold_stats(f)
+    print('R=257 learned abc shape: {} vertices, {} faces, {} decoder queries, cloud->surface median {:.2f} voxels, p90 {:.2f}; edges with 2 faces {:.4f}, '
+          'open {}, >2 {}'.format(v.shape[0], f.shape[0], fields[0].n_queries, np.median(d) / voxel, np.percentile(d, 90) / voxel, two, open_e, multi))
+    assert np.isfinite(v).all() and f.min() >= 0 and f.max() < v.shape[0]
+    # band: a surface of this CAD part at R = 257 has some 10^5 vertices; the queries are the +-2 band of it plus 10 refinement rounds
+    assert 60_000 < v.shape[0] < 1_500_000 and 1.9 * v.shape[0] < f.shape[0] < 2.1 * v.shape[0]
+    assert 2_000_000 < fields[0].n_queries < 40_000_000
+    # the over-fitted shape's surface follows its input cloud (R = 129 with the same checkpoint: within 4 voxels of 1/128; here the voxel is half)
+    assert np.median(d) < 6 * voxel and np.percentile(d, 90) < 24 * voxel
+    assert two > 0.98                                            # closed 2-manifold up to where it leaves the band (open edges next to unseen voxels)
+
+
+def test_marching_cubes_and_clean_up_on_a_learned_volume_meet_the_specification(trained):
+    """f2: the volume of a LEARNED network (abc_mini4 fit) at R = 65 through the device Marching Cubes + clean-up against the independent
+    specification of oracle/mesh_oracle.py (vertex set = grid-edge crossings, closed oriented manifold, one cube per face, union-find
+    components) -- source/poco_utils.py:95, source/base/mesh.py:7-38."""
+    from oracle import mesh_oracle as M
+    from ppsurf_amd import reconstruct, mcubes
+    root, ckpt = trained
+    model = _trained_model(root, ckpt, 65)
+    cloud = _abc_cloud(root, 1)
+    pts_cf = torch.from_numpy(cloud).to(DEV).t().contiguous()
+    lat = model.encode_latents(pts_cf)
+    shape = {'pts': pts_cf.unsqueeze(0), 'latents': lat.t().unsqueeze(0)}
+    field = reconstruct.OccupancyField(model.network, shape, pts_cf.t().unsqueeze(0), 50000, 50)
+    step, bmin_pad, pts_ids = __import__('bench_workloads').grid_geometry(cloud, 65)
+    vol = reconstruct.create_volume(field, torch.from_numpy(pts_ids).to(DEV), 65, step, bmin_pad)
+    v, f = mcubes.marching_cubes_torch(vol, 0.0)
+    assert v.is_cuda
+    voln = vol.cpu().numpy()
+    info = M.check_marching_cubes(v.cpu().numpy(), f.cpu().numpy(), voln, 0.0, require_closed=False)
+    assert info['faces'] > 3000 and info['boundary_edges'] < 0.05 * 3 * info['faces']
+    v32 = v.to(torch.float32).to(torch.float64)                                # as reconstruct.py hands them to the clean-up (skimage returns float32)
+    vc, fc = mcubes.clean_mesh_torch(v32, f, min_component_faces=6)
+    M.check_clean_mesh(v32.cpu().numpy(), f.cpu().numpy(), vc.cpu().numpy(), fc.cpu().numpy(), 6)
+    print('learned volume R=65: {} faces ({} open edges next to unseen voxels), {} after clean-up'.format(info['faces'], info['boundary_edges'], fc.shape[0]))
+
+
+RANK_SCRIPT = r'''
+import os, sys
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, 'tests'))
+import numpy as np, torch, torch.distributed as dist
+from ppsurf_amd import reconstruct, sharding, meshio
+from test_gpu_configs import _trained_model
+import pathlib
+rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+if world > 1:
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sharding.set_query_sharding(True)
+root = pathlib.Path({root!r})
+model = _trained_model(root, {ckpt!r}, 65)
+model.shard_queries = world > 1
+cloud = np.load({cloud!r})
+pts_cf = torch.from_numpy(cloud).to('cuda:0').t().contiguous()
+lat = torch.from_numpy(np.load({lat!r})).to('cuda:0')                      # fixed latents: the latent loop is stochastic
+shape = {{'pts': pts_cf.unsqueeze(0), 'latents': lat.t().unsqueeze(0)}}
+field = reconstruct.OccupancyField(model.network, shape, pts_cf.t().unsqueeze(0), 50000, 50)
+bmin, bmax = cloud.min(), cloud.max(); step = (bmax - bmin) / 64
+ids = torch.from_numpy(((cloud - bmin) / step + 1).astype(np.int32).astype(np.int64)).to('cuda:0')
+vol = reconstruct.create_volume(field, ids, 65, step, bmin - step).cpu().numpy()
+np.save(os.path.join({out!r}, 'vol_w{{}}_r{{}}.npy'.format(world, rank)), vol)
+np.save(os.path.join({out!r}, 'nq_w{{}}_r{{}}.npy'.format(world, rank)), np.array([field.n_queries]))
+'''
+
+
+def test_query_sharded_learned_shape_at_r65_equals_the_single_rank_volume(trained, tmp_path):
+    """PPS_SHARD=queries (SURVEY.md 8e) on a real shape with learned weights at R = 65: two ranks (gloo, one GPU) decode disjoint query
+    ranges of every growth round and exchange them; each rank's volume must EQUAL the single-rank volume."""
+    import subprocess, sys
+    from golden_util import REPO
+    root, ckpt = trained
+    model = _trained_model(root, ckpt, 65)
+    cloud = _abc_cloud(root, 2)
+    lat = model.encode_latents(torch.from_numpy(cloud).to(DEV).t().contiguous())
+    np.save(tmp_path / 'cloud.npy', cloud)
+    np.save(tmp_path / 'lat.npy', lat.cpu().numpy())
+    script = tmp_path / 'run.py'
+    script.write_text(RANK_SCRIPT.format(repo=REPO, root=str(root), ckpt=ckpt, cloud=str(tmp_path / 'cloud.npy'), lat=str(tmp_path / 'lat.npy'), out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    subprocess.check_call([sys.executable, str(script)], env=env, timeout=900)
+    subprocess.check_call([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                           '--master-port', str(29300 + os.getpid() % 300), str(script)], env=env, timeout=900)
+    v1 = np.load(tmp_path / 'vol_w1_r0.npy')
+    a, b = np.load(tmp_path / 'vol_w2_r0.npy'), np.load(tmp_path / 'vol_w2_r1.npy')
+    assert np.array_equal(np.isnan(a), np.isnan(v1)) and np.array_equal(a, b, equal_nan=True)
+    assert np.array_equal(a, v1, equal_nan=True)                             # the same kernels on the same queries: equal, not close
+    n1 = int(np.load(tmp_path / 'nq_w1_r0.npy')[0])
+    n2 = [int(np.load(tmp_path / 'nq_w2_r{}.npy'.format(r))[0]) for r in (0, 1)]
+    assert (~np.isnan(v1)).sum() > 50_000 and sum(n2) == n1 and min(n2) > 0.3 * n1
+
+
+def test_config5_whole_reconstruction_r513_n250k_p200_smoke():
+    """BASELINE config 5 end to end on one GPU: a 250 000-point synthetic cloud, P = 200, rec_batch_size 25 000, R = 513 -- latent loop (250
+    encoder passes), region growing over the (515)^3 float64 volume, Marching Cubes, clean-up, 10 refinement rounds, every query decoded
+    by the real kernels (growth steered by the analytic shape: formula-filled weights describe no surface).  Finite, closed mesh."""
+    import bench_workloads as workloads
+    model = workloads.make_model(513, 200, 25000, DEV)
+    r = workloads.reconstruct_steered(model, 250_000, seed=5, device=DEV, return_mesh=True)
+    v, f = r['mesh']
+    two, open_e, multi = _closed_manifold_stats(f)
+    print('config 5 reconstruction: {:.1f} s, {} decoder queries, {} vertices, {} faces; edges with 2 faces {:.5f}, open {}, >2 {}'.format(
+        r['total_s'], r['decoder_queries'], v.shape[0], f.shape[0], two, open_e, multi))
+    assert np.isfinite(v).all() and v.shape[0] > 500_000 and f.shape[0] > 1_000_000
+    assert r['decoder_queries'] > 10_000_000
+    assert open_e == 0 and multi == 0                                        # the analytic shape's band is complete: a closed 2-manifold
+    assert np.abs(np.linalg.norm(v, axis=1) - 0.45).max() < 0.2              # a bumpy sphere of radius 0.45 (synthetic.make_cloud)

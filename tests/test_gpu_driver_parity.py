@@ -24,13 +24,15 @@ def _stub_latent(pts_cf, c=8):
 
 
 @pytest.mark.parametrize('batch', [1, 10])
-def test_latent_loop_on_the_device_follows_the_reference_stream(batch):
-    """latent_rng='reference' on the GPU: the subset permutations come from torch's CPU generator like in the reference, so for a cloud
-    whose size is a multiple of the subset size (no top-up draw on the device generator) the subsets, counts and latents of the
-    reference's loop (poco_model.py:203-236) are reproduced exactly -- pass by pass and with subsets drawn ahead."""
+@pytest.mark.parametrize('tag', ['exact', 'topup', 'small'])
+def test_latent_loop_on_the_device_follows_the_reference_stream(tag, batch):
+    """latent_rng='reference' on the GPU: the subset permutations AND the top-up permutation (poco_model.py:217-219) come from torch's CPU
+    generator, the stream the reference's recorded run consumed, so the subsets, counts and latents of the reference's loop
+    (poco_model.py:203-236) are reproduced exactly on device tensors -- pass by pass and with subsets drawn ahead -- for a cloud that is a
+    multiple of the subset size ('exact'), one that needs the top-up branch ('topup') and one smaller than a subset ('small')."""
     from ppsurf_amd.lightning_api import PocoModel
     g = load_golden('latent_loop')
-    n, m, iters, seed = (int(x) for x in g['exact_cfg'])
+    n, m, iters, seed = (int(x) for x in g[tag + '_cfg'])
     with contextlib.redirect_stdout(io.StringIO()):
         model = PocoModel(output_names=['x'], in_channels=3, out_channels=2, k=64, lambda_l1=0.0, debug=False, in_file='x.xyz', results_dir='/tmp/x',
                           padding_factor=0.05, name='x', network_latent_size=8, gen_subsample_manifold_iter=iters, gen_subsample_manifold=m,
@@ -41,9 +43,13 @@ def test_latent_loop_on_the_device_follows_the_reference_stream(batch):
     torch.manual_seed(seed)
     lat = model.encode_latents(cloud.t().contiguous(), trace=trace,
                                encode_subsets=lambda pts_cf, subsets: torch.stack([_stub_latent(pts_cf[:, i].unsqueeze(0), 8)[0].t() for i in subsets]))
-    assert lat.is_cuda and len(trace) == g['exact_trace'].shape[0]
-    assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(trace, g['exact_trace']))
-    np.testing.assert_allclose(lat.cpu().numpy(), g['exact_latents'], rtol=0, atol=2e-6)        # sin / cos of the device vs the host
+    assert lat.is_cuda and len(trace) == g[tag + '_trace'].shape[0]
+    assert all(a.is_cuda and np.array_equal(a.cpu().numpy(), b) for a, b in zip(trace, g[tag + '_trace']))
+    counts = np.zeros(n, dtype=np.float32)
+    for ids in trace:
+        counts[np.unique(ids.cpu().numpy())] += 1
+    assert np.array_equal(counts, g[tag + '_counts'])
+    np.testing.assert_allclose(lat.cpu().numpy(), g[tag + '_latents'], rtol=0, atol=2e-6)        # sin / cos of the device vs the host
 
 
 def test_default_device_rng_latent_loop_covers_every_point_equally():

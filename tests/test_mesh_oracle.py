@@ -1,0 +1,169 @@
+"""Marching Cubes + mesh clean-up (ppsurf_amd/mcubes.py; source/poco_utils.py:95, source/base/mesh.py:7-38) against the INDEPENDENT specification
+in oracle/mesh_oracle.py (no triangle table there: grid-edge enumeration, manifold / orientation properties, union-find components).
+CPU tests check the specification itself (it must reject broken meshes) and both product twins; the -m gpu tests run the device path."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import load_golden
+from oracle import mesh_oracle as M
+from ppsurf_amd import mcubes
+
+
+def _field(n=26, seed=0):
+    g = np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing='ij'), -1).astype(np.float64)
+    rng = np.random.default_rng(seed)
+    c = n / 2 - 0.6 + rng.uniform(-1, 1, 3)
+    return 0.3 * n - np.linalg.norm(g - c, axis=-1) + 0.9 * np.sin(g[..., 0] * 0.9 + seed) * np.cos(g[..., 1] * 0.7) + 0.5 * np.sin(g[..., 2] * 1.3)
+
+
+def _volumes():
+    vol = _field()
+    band = vol.copy()
+    band[np.abs(vol) > 3.5] = np.nan                      # what region growing leaves: a band around the surface, NaN elsewhere
+    ties = np.round(vol)                                   # values exactly AT the level: crossings that sit on grid corners
+    cut = vol.copy()
+    cut[:, :, 14:] = np.nan                                # the surface runs into unseen voxels: open boundary next to NaN only
+    blobs = _field(seed=3)
+    blobs[2, 2, 2] = 5.0                                   # an isolated one-voxel component (8 faces)
+    blobs[22:24, 3, 3] = 4.0
+    neg = -_field(seed=5)                                  # inside / outside swapped
+    return {'smooth': (vol, True), 'band': (band, True), 'ties': (ties, True), 'cut': (cut, False), 'blobs': (blobs, True), 'neg': (neg, True)}
+
+
+@pytest.mark.parametrize('name', sorted(_volumes()))
+def test_numpy_and_torch_marching_cubes_meet_the_specification(name):
+    vol, closed = _volumes()[name]
+    v, f = mcubes.marching_cubes(vol, 0.0)
+    info = M.check_marching_cubes(v, f, vol, 0.0, require_closed=closed)
+    assert info['faces'] > 500 and (info['boundary_edges'] == 0) == closed
+    vt, ft = mcubes.marching_cubes_torch(torch.from_numpy(vol), 0.0)
+    M.check_marching_cubes(vt.numpy(), ft.numpy(), vol, 0.0, require_closed=closed)
+
+
+def test_level_other_than_zero_and_empty_volume():
+    vol = _field(seed=2)
+    v, f = mcubes.marching_cubes(vol, 1.25)
+    M.check_marching_cubes(v, f, vol, 1.25)
+    v, f = mcubes.marching_cubes(np.full((6, 6, 6), -1.0), 0.0)
+    assert M.check_marching_cubes(v, f, np.full((6, 6, 6), -1.0), 0.0)['faces'] == 0
+
+
+def test_the_specification_rejects_broken_meshes():
+    """Negative controls: the checker must notice a flipped face, a displaced vertex, a missing face, an extra vertex and a face that
+    joins crossings of different cubes -- otherwise agreeing with it would mean nothing."""
+    vol = _field(seed=1)
+    v, f = mcubes.marching_cubes(vol, 0.0)
+    M.check_marching_cubes(v, f, vol, 0.0)
+    bad = f.copy(); bad[10] = bad[10][::-1]
+    with pytest.raises(AssertionError, match='directed edge'):
+        M.check_marching_cubes(v, bad, vol, 0.0)
+    moved = v.copy(); moved[7, 1] += 1e-4
+    with pytest.raises(AssertionError, match='vertex positions'):
+        M.check_marching_cubes(moved, f, vol, 0.0)
+    with pytest.raises(AssertionError, match='open edges'):
+        M.check_marching_cubes(v, f[1:], vol, 0.0)
+    with pytest.raises(AssertionError, match='vertex count'):
+        M.check_marching_cubes(np.concatenate([v, v[:1]]), f, vol, 0.0)
+    far = f.copy()
+    far[0, 2] = int(np.argmax(np.abs(v - v[far[0, 0]]).sum(axis=1)))
+    with pytest.raises(AssertionError):
+        M.check_marching_cubes(v, far, vol, 0.0)
+    allflip = f[:, ::-1].copy()
+    with pytest.raises(AssertionError, match='HIGHER'):
+        M.check_marching_cubes(v, allflip, vol, 0.0)
+
+
+def _dirty_mesh(seed=0):
+    """A Marching-Cubes mesh plus everything the clean-up has to remove: duplicated vertices (unmerged), degenerate faces, duplicate faces
+    (same corners, any rotation), a 4-face and a 6-face component, one 7-face component that must survive, unreferenced vertices."""
+    rng = np.random.default_rng(seed)
+    vol = _field(seed=seed)
+    v, f = mcubes.marching_cubes(vol, 0.0)
+    nv = v.shape[0]
+    dup = rng.choice(nv, 60, replace=False)                               # unmerge: some faces use a copy of their vertex
+    v = np.concatenate([v, v[dup]])
+    remap = {int(a): nv + i for i, a in enumerate(dup)}
+    f = f.copy()
+    for row in rng.choice(f.shape[0], 300, replace=False):
+        c = rng.integers(3)
+        f[row, c] = remap.get(int(f[row, c]), f[row, c])
+    base = v.shape[0]
+    tet = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], dtype=np.float64) + 100.0
+    tet_f = np.array([[0, 2, 1], [0, 1, 3], [1, 2, 3], [0, 3, 2]]) + base                      # 4 faces
+    fan6 = np.concatenate([[[0.0, 0.0, 0.0]], [[np.cos(a), np.sin(a), 0.0] for a in np.linspace(0, 2 * np.pi, 7)[:-1]]]) + 200.0
+    fan6_f = np.array([[0, 1 + i, 1 + (i + 1) % 6] for i in range(6)]) + base + 4              # 6 faces: dropped (<= 6)
+    fan7 = np.concatenate([[[0.0, 0.0, 0.0]], [[np.cos(a), np.sin(a), 0.0] for a in np.linspace(0, 2 * np.pi, 8)[:-1]]]) + 300.0
+    fan7_f = np.array([[0, 1 + i, 1 + (i + 1) % 7] for i in range(7)]) + base + 11             # 7 faces: kept
+    v = np.concatenate([v, tet, fan6, fan7, rng.normal(size=(5, 3)) + 400.0])                  # + 5 unreferenced vertices
+    degenerate = np.array([[3, 3, 9], [5, 8, 5]])
+    duplicates = np.concatenate([f[:20][:, [1, 2, 0]], f[20:30][:, [0, 2, 1]]])                # rotations and a reflection
+    f = np.concatenate([f, tet_f, fan6_f, degenerate, duplicates, fan7_f])
+    return v, f[rng.permutation(f.shape[0])]
+
+
+@pytest.mark.parametrize('seed', [0, 1])
+def test_clean_up_twins_equal_the_union_find_specification(seed):
+    v, f = _dirty_mesh(seed)
+    vc, fc = mcubes.clean_mesh(v, f, min_component_faces=6)
+    info = M.check_clean_mesh(v, f, vc, fc, min_component_faces=6)
+    assert info['faces'] < f.shape[0] - 30
+    vt, ft = mcubes.clean_mesh_torch(torch.from_numpy(v), torch.from_numpy(f), min_component_faces=6)
+    M.check_clean_mesh(v, f, vt.numpy(), ft.numpy(), min_component_faces=6)
+    kept = M.clean_mesh_spec(v, f, 6)[0]
+    assert (kept[:, 0] > 299).sum() == 7 and not ((kept[:, 0] > 99) & (kept[:, 0] < 299)).any()      # the 7-fan survives, the 4- and 6-face pieces do not
+    lab = M.components_union_find(fc)
+    assert np.bincount(np.unique(lab, return_inverse=True)[1]).min() > 6
+
+
+def test_union_find_components_against_a_hand_made_case():
+    faces = np.array([[0, 1, 2], [2, 1, 3], [4, 5, 6], [3, 1, 7], [6, 5, 8], [9, 10, 11]])
+    lab = M.components_union_find(faces)
+    assert lab[0] == lab[1] == lab[3] and lab[2] == lab[4] and len({lab[0], lab[2], lab[5]}) == 3
+
+
+def test_fixture_volume_of_the_reference_driver_on_cpu():
+    """The volume the REFERENCE's region-growing driver produced for the refinement fixture (tests/golden/refine.npz): the product's Marching
+    Cubes of it meets the specification, and the fixture's stored vertices (the input the reference's refinement loop received) are the
+    specification's crossings after clean-up."""
+    g = load_golden('refine')
+    v, f = mcubes.marching_cubes_torch(torch.from_numpy(g['volume']), 0.0)
+    # (the analytic field of that fixture leaves the +-2 band of the cloud in places: open edges exist, but only next to unseen voxels)
+    info = M.check_marching_cubes(v.numpy(), f.numpy(), g['volume'], 0.0, require_closed=False)
+    assert 0 < info['boundary_edges'] < 0.05 * 3 * info['faces']
+    vc, fc = mcubes.clean_mesh_torch(v, f, min_component_faces=6)
+    M.check_clean_mesh(v.numpy(), f.numpy(), vc.numpy(), fc.numpy(), 6)
+    want = M.edge_crossings(g['volume'], 0.0)[0].astype(np.float32)
+    a = np.unique(np.round(g['mc_verts'], 5), axis=0)
+    b = np.unique(np.round(want, 5), axis=0)
+    assert a.shape == b.shape and np.abs(a - b).max() <= 2e-5
+
+
+# ---- the device path ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['band', 'ties', 'cut', 'blobs'])
+def test_device_marching_cubes_and_clean_up_meet_the_specification(name):
+    vol, closed = _volumes()[name]
+    v, f = mcubes.marching_cubes_torch(torch.from_numpy(vol).to('cuda:0'), 0.0)
+    assert v.is_cuda and f.is_cuda
+    M.check_marching_cubes(v.cpu().numpy(), f.cpu().numpy(), vol, 0.0, require_closed=closed)
+    vc, fc = mcubes.clean_mesh_torch(v, f, min_component_faces=6)
+    M.check_clean_mesh(v.cpu().numpy(), f.cpu().numpy(), vc.cpu().numpy(), fc.cpu().numpy(), 6)
+
+
+@pytest.mark.gpu
+def test_device_clean_up_of_a_dirty_mesh_equals_the_specification():
+    v, f = _dirty_mesh(2)
+    vt, ft = mcubes.clean_mesh_torch(torch.from_numpy(v).to('cuda:0'), torch.from_numpy(f).to('cuda:0'), min_component_faces=6)
+    M.check_clean_mesh(v, f, vt.cpu().numpy(), ft.cpu().numpy(), 6)
+
+
+@pytest.mark.gpu
+def test_device_path_on_the_reference_drivers_fixture_volume():
+    g = load_golden('refine')
+    vol = torch.from_numpy(g['volume']).to('cuda:0')
+    v, f = mcubes.marching_cubes_torch(vol, 0.0)
+    M.check_marching_cubes(v.cpu().numpy(), f.cpu().numpy(), g['volume'], 0.0, require_closed=False)
+    vc, fc = mcubes.clean_mesh_torch(v.to(torch.float32).to(torch.float64), f, min_component_faces=6)      # as reconstruct.py hands them over
+    M.check_clean_mesh(v.to(torch.float32).to(torch.float64).cpu().numpy(), f.cpu().numpy(), vc.cpu().numpy(), fc.cpu().numpy(), 6)
+    assert vc.shape[0] == g['mc_verts'].shape[0] and fc.shape[0] == g['mc_faces'].shape[0]

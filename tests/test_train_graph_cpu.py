@@ -67,6 +67,32 @@ def _check_sigs(named, names, sigs, rtol, what, noise=1e-6, sigs32=None):
             '{} {}: leading entries differ'.format(what, k)
 
 
+def _check_samples(named, g, rtol, what, noise=1e-6, use32=True):
+    """Elementwise comparison of every parameter gradient at the fixture's seeded sample of <= 4096 flat indices per tensor (`gsamp_*`,
+    recorded from the reference's float64 run; tests/golden/make_golden_train.py) -- reaches the tail of every tensor, unlike the
+    signatures.  Tolerance per tensor as for the leading entries in _check_sigs: 4 x rtol x the tensor's scale, the noise floor of the
+    set, and (fp32 runs) 3 x the largest deviation of the reference's OWN fp32 gradient from its float64 gradient on that sample."""
+    named = dict(named)
+    names, off = [str(k) for k in g['gnames']], g['gsamp_off']
+    assert len(off) == len(names) + 1
+    floor = noise * max(float(s[2]) for s in g['gsigs'])
+    worst = (0.0, None)
+    for i, k in enumerate(names):
+        sl = slice(int(off[i]), int(off[i + 1]))
+        idx, ref = g['gsamp_idx'][sl], g['gsamp_val'][sl]
+        t = named[k].detach().double().reshape(-1)
+        assert idx.shape[0] == min(4096, t.numel()) and (idx.max() < t.numel())
+        got = t[torch.from_numpy(idx)].cpu().numpy()
+        own = 3 * float(np.abs(g['gsamp_val32'][sl] - ref).max()) if use32 else 0.0
+        rms = float(g['gsigs'][i][2]) / np.sqrt(t.numel())
+        tol = 4 * rtol * max(float(np.abs(ref).max()), rms) + floor + own
+        err = float(np.abs(got - ref).max())
+        assert err <= tol, '{} {}: sampled entries differ by {} (tolerance {}, worst at flat index {})'.format(what, k, err, tol, int(idx[np.argmax(np.abs(got - ref))]))
+        if tol > 0 and err / tol > worst[0]:
+            worst = (err / tol, k)
+    return worst
+
+
 @pytest.mark.parametrize('act', ['relu', 'silu'])
 def test_fkaconv_layer_train(act):
     g = load_golden('train_fkaconv_layer')
@@ -175,6 +201,7 @@ def test_training_step_fp32(which):
     assert abs(loss - float(g['loss'])) < 1e-5
     assert [k for k, p in net.named_parameters() if p.grad is None] == [str(k) for k in g['unused']]
     _check_sigs([(k, v.grad) for k, v in net.named_parameters()], g['gnames'], g['gsigs'], 1e-2, 'grad', sigs32=g['gsigs32'])
+    _check_samples([(k, v.grad) for k, v in net.named_parameters() if v.grad is not None], g, 1e-2, 'grad')
     _check_sigs([(k, v.float()) for k, v in net.named_buffers()], g['bnames'], g['bsigs'], 2e-5, 'buffer')
 
 
@@ -184,6 +211,8 @@ def test_training_step_fp64_is_the_same_function(which):
     logits, loss = _run_step(tg.ppsurf_forward if which == 'ppsurf' else tg.poco_forward, net, torch.float64)
     _close(logits, g['logits'], 5e-5, 'logits')                      # recorded in fp32
     _check_sigs([(k, v.grad) for k, v in net.named_parameters()], g['gnames'], g['gsigs'], 1e-7, 'grad', noise=1e-10)
+    # every sampled entry of every one of the parameter tensors, tails included: the float64 graph IS the reference's function
+    _check_samples([(k, v.grad) for k, v in net.named_parameters() if v.grad is not None], g, 1e-7, 'grad', noise=1e-10, use32=False)
 
 
 def test_ppsurf_training_step_dropout_same_generator():
