@@ -333,9 +333,9 @@ def main():
                 if id(pipe) not in pipes2:
                     pipes2[id(pipe)] = ChunkPipeline(plan2, pipe.table, pipe.pts, pipe.pts, K_PROJ, P_LOCAL, same_cloud=True, max_chunk=Q_CHUNK)
                 work2.append((pipes2[id(pipe)], c))
-            n2 = min(args.steps, 100)
-            r2 = chunk_loop(work2, n2, min(args.warmup, 5), rank, world, dist, red_dev, min_timed_s=1.0)
-            last_pipe, last_c = work[args.warmup + n2 - 1]
+            n2, w2 = min(args.steps, 100), min(args.warmup, 5)
+            r2 = chunk_loop(work2, n2, w2, rank, world, dist, red_dev, min_timed_s=1.0)
+            last_pipe, last_c = work[w2 + n2 - 1]                       # the chunk r2['occ'] belongs to, decoded by the headline dtype
             ref_occ = last_pipe.run([last_c], want_occ=True)[0][1]
             out[other] = dict(dtype_stats(other, r2, world), steps=n2, note=DTYPE_NOTE[other], roofline=roofline_block(other, r2['stage_ms']))
             out[other]['max_abs_occ_diff_vs_{}_last_chunk'.format(args.dtype)] = float((r2['occ'] - ref_occ).abs().max())

@@ -275,9 +275,17 @@ __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restr
 // weights: wxyz (floats) [xyz 1024]; w16 (half8 fragments) [fc2 16 ob x 8 kb][fc3 16 x 8][fcq 4 x 8], 2 KiB per (ob, kb);
 // bias (floats): [256][256][64]
 // =====================================================================================================
-#define IH_NT 512
+#ifndef IH_NT
+#define IH_NT 512              // threads per workgroup: 512 = one 8-wave workgroup per CU (2 queries per weight pass), 256 = two decoupled 4-wave workgroups
+#endif
+#ifndef IH_OB
+#define IH_OB 2                // output blocks per streamed weight chunk: 2 = 32 KiB chunks (18 barriers per pass), 4 = 64 KiB chunks (9)
+#endif
 #define IH_NW (IH_NT / 64)
-#define IH_LDS_BYTES (2 * CH4 * 16 + (IP_W_XYZ + IP_NBIAS + IH_NW * 64 * 3 + IH_NW * 256) * 4)
+#define IH_WG_PER_CU (512 / IH_NT)
+#define IH_CH4 (CH4 * IH_OB / 2)
+#define IH_NCH (32 / IH_OB + 4 / IH_OB)       // chunks per pass: fc2 and fc3 16 output blocks each, fc_query 4
+#define IH_LDS_BYTES (2 * IH_CH4 * 16 + (IP_W_XYZ + IP_NBIAS + IH_NW * 64 * 3 + IH_NW * 256) * 4)
 
 __global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float* __restrict__ G, const float* __restrict__ pts,
                                                                      const float* __restrict__ query, const int64_t* __restrict__ idx,
@@ -285,8 +293,8 @@ __global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float
                                                                      const f32x4* __restrict__ w16, const float* __restrict__ bias,
                                                                      float* __restrict__ pooled) {
     f32x4* buf0 = (f32x4*)pps_smem;
-    f32x4* buf1 = buf0 + CH4;
-    float* xyz_l = (float*)(buf1 + CH4);
+    f32x4* buf1 = buf0 + IH_CH4;
+    float* xyz_l = (float*)(buf1 + IH_CH4);
     float* bias_l = xyz_l + IP_W_XYZ;
     float* msm = bias_l + IP_NBIAS;
     float* mss = msm + IH_NW * 64;
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float
 
     lds_fill(xyz_l, wxyz, IP_W_XYZ);
     lds_fill(bias_l, bias, IP_NBIAS);
-    stream_prologue<CH4, IH_NT>(wg, buf0);
+    stream_prologue<IH_CH4, IH_NT>(wg, buf0);
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 
@@ -317,7 +325,11 @@ __global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float
         HiLo x[8], y[8];
         {
             f32x4 a[16];
+#ifdef PPS_ABL_IH_NOGATHER
+            const f32x4* grow = (const f32x4*)(G + (int64_t)(lane & 15) * 256) + g;
+#else
             const f32x4* grow = (const f32x4*)(G + i * 256) + g;
+#endif
 #pragma unroll
             for (int bb = 0; bb < 16; ++bb) a[bb] = grow[4 * bb];
             const float coord = (g < 3) ? (query[qc * 3 + g] - pts[i * 3 + g]) : 0.f;   // query minus neighbour (poco_model.py:402)
@@ -328,25 +340,34 @@ __global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float
         }
         __builtin_amdgcn_s_setprio(PPS_PRIO);
 #pragma unroll
-        for (int c = 0; c < 8; ++c)                                    // fc2: chunk c holds output blocks 2c, 2c+1 = k-block c of fc3
-            stream_step<CH4, IH_NT>(wg + (c + 1) * CH4, cur, nxt, [&](const f32x4* w) {
-                dense_blocks_f16x3<8, 2, 1>(x, (const half8*)w, bias4 + 8 * c, lane,
-                                            [&](int, const f32x4& o0, const f32x4& o1) { y[c] = split_f16(o0, o1); });
+        for (int c = 0; c < 16 / IH_OB; ++c)                           // fc2: output blocks IH_OB c .. = k-blocks IH_OB/2 c .. of fc3
+            stream_step<IH_CH4, IH_NT>(wg + (c + 1) * IH_CH4, cur, nxt, [&](const f32x4* w) {
+                dense_blocks_f16x3<8, IH_OB, 1>(x, (const half8*)w, bias4 + 4 * IH_OB * c, lane,
+                                                [&](int p, const f32x4& o0, const f32x4& o1) { y[IH_OB / 2 * c + p] = split_f16(o0, o1); });
             });
 #pragma unroll
-        for (int c = 0; c < 8; ++c)                                    // fc3
-            stream_step<CH4, IH_NT>(wg + (c + 9) * CH4, cur, nxt, [&](const f32x4* w) {
-                dense_blocks_f16x3<8, 2, 1>(y, (const half8*)w, bias4 + 64 + 8 * c, lane,
-                                            [&](int, const f32x4& o0, const f32x4& o1) { x[c] = split_f16(o0, o1); });
+        for (int c = 0; c < 16 / IH_OB; ++c)                           // fc3
+            stream_step<IH_CH4, IH_NT>(wg + (c + 16 / IH_OB + 1) * IH_CH4, cur, nxt, [&](const f32x4* w) {
+                dense_blocks_f16x3<8, IH_OB, 1>(y, (const half8*)w, bias4 + 64 + 4 * IH_OB * c, lane,
+                                                [&](int p, const f32x4& o0, const f32x4& o1) { x[IH_OB / 2 * c + p] = split_f16(o0, o1); });
             });
         f32x4 b[4];
 #pragma unroll
-        for (int c = 0; c < 2; ++c)                                    // fc_query: 64 heads
-            stream_step<CH4, IH_NT>(wg + ((c + 17) % 18) * CH4, cur, nxt, [&](const f32x4* w) {
-                dense_blocks_f16x3<8, 2, 0>(x, (const half8*)w, bias4 + 128 + 8 * c, lane,
-                                            [&](int, const f32x4& o0, const f32x4& o1) { b[2 * c] = o0; b[2 * c + 1] = o1; });
+        for (int c = 0; c < 4 / IH_OB; ++c)                            // fc_query: 64 heads
+            stream_step<IH_CH4, IH_NT>(wg + ((c + 32 / IH_OB + 1) % IH_NCH) * IH_CH4, cur, nxt, [&](const f32x4* w) {
+                dense_blocks_f16x3<8, IH_OB, 0>(x, (const half8*)w, bias4 + 128 + 4 * IH_OB * c, lane,
+                                                [&](int p, const f32x4& o0, const f32x4& o1) { b[IH_OB * c + 2 * p] = o0; b[IH_OB * c + 2 * p + 1] = o1; });
             });
         __builtin_amdgcn_s_setprio(0);
+#ifdef PPS_ABL_IH_NOSOFTMAX
+        {   // everything the MFMA phase produced stays live (static register indices only), nothing else is done with it
+            f32x4 s4 = b[0] + b[1] + b[2] + b[3];
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) { f32x4 t0, t1; join_f16(x[kb], t0, t1); s4 += t0 + t1; }
+            if (qv && wq == 0) ((f32x4*)(pooled + qi * 256))[lane] = s4;
+        }
+        continue;
+#endif
         // ---- softmax over the 64 neighbours (4 waves x 16 rows) for each of the 64 heads: as in interp_pool_kernel -------------
         float e[16];
         {
@@ -550,13 +571,18 @@ struct PatchPacking {
     int fb, lo, qg, tiles_per_query;      // full tiles, left-over rows, queries per wave group, tiles evaluated per query
     bool packed;
 };
-__host__ __device__ inline PatchPacking patch_packing(int P, bool allow = true) {
+// mode 0: padded tiles; 1: packed, QG = 16/LO queries per wave group; 2: the packed ARITHMETIC with one query per group (its LO left-over
+// rows alone in a tile, the other columns idle).  Modes 1 and 2 give bit-identical results per query -- the group reductions run over the
+// same aligned LO lanes, the per-query transform product only ever adds exact zeros for the other columns -- so the launch may use full
+// packed rounds for most queries and mode 2 for the remainder, and a query's logits do not depend on where in a chunk it sits or on how a
+// query list was cut into chunks / sharded over ranks (tests/test_gpu_decoder.py::test_logits_do_not_depend_on_the_chunking).
+__host__ __device__ inline PatchPacking patch_packing(int P, int mode = 1) {
     PatchPacking k;
     const int lo = P & 15;
-    k.packed = allow && (P >= 16) && (lo == 2 || lo == 4 || lo == 8);
+    k.packed = mode != 0 && (P >= 16) && (lo == 2 || lo == 4 || lo == 8);
     k.fb = k.packed ? P / 16 : (P + 15) / 16;
     k.lo = k.packed ? lo : 0;
-    k.qg = k.packed ? 16 / lo : 1;
+    k.qg = k.packed ? (mode == 2 ? 1 : 16 / lo) : 1;
     k.tiles_per_query = k.fb;
     return k;
 }
@@ -643,7 +669,7 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_stn_rows_kernel(const float* 
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 
-    const PatchPacking pk = patch_packing(P, pack != 0);
+    const PatchPacking pk = patch_packing(P, pack);
     const int64_t ngroups = (Q + pk.qg - 1) / pk.qg;
     const int ntiles = (int)((ngroups + PNW - 1) / PNW);
     int first, count, stride;
@@ -1023,7 +1049,7 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float*
     f32x4 *cur = buf0, *nxt = buf1;
     const float s0 = bias_l[576 + 256];                   // wq . b3 + bq
 
-    const PatchPacking pk = patch_packing(P, pack != 0);
+    const PatchPacking pk = patch_packing(P, pack);
     const int64_t ngroups = (Q + pk.qg - 1) / pk.qg;
     const int ntiles = (int)((ngroups + PNW - 1) / PNW);
     int first, count, stride;
@@ -1192,9 +1218,10 @@ static int grid_for(int64_t ntiles) {
 }
 
 // PointNet row kernels: PN_WG_PER_CU workgroups of PNW waves per CU.  Packed wave groups (qg queries, no padded rows) are used for as many
-// FULL rounds over all waves of the chip as the query count allows; the remainder runs one query per wave so that the last
-// round is short instead of a whole packed group (Q = 50000, P = 50: 3 x 25 + 4 tiles per wave instead of 100).
-struct PnSplit { int64_t q_packed; int grid_packed, grid_rest; };
+// FULL rounds over all waves of the chip as the query count allows; the remainder runs one query per wave (patch_packing mode 2: the packed
+// arithmetic, bit-identical per query) so that the last round is short instead of a whole packed group (Q = 50000, P = 50: 3 x 25 + 4 tiles
+// per wave instead of 100).
+struct PnSplit { int64_t q_packed; int grid_packed, grid_rest, rest_mode; };
 static PnSplit pn_split(int64_t q, int p) {
     int cus = cu_count();
     if (cus <= 0) cus = 256;
@@ -1205,6 +1232,7 @@ static PnSplit pn_split(int64_t q, int p) {
     sp.q_packed = pk.packed ? (q / per_round) * per_round : 0;
     if (pk.packed && getenv("PPS_PN_FORCE_PACK")) sp.q_packed = q;      // test hook: packed path for any query count
     sp.grid_packed = wgs;
+    sp.rest_mode = pk.packed ? 2 : 0;                // the remainder in the packed arithmetic, one query per wave group: same bits as a packed round
     const int64_t rest_tiles = (q - sp.q_packed + PNW - 1) / PNW;
     sp.grid_rest = (int)(rest_tiles < wgs ? rest_tiles : wgs);
     return sp;
@@ -1223,7 +1251,7 @@ static int launch_stn_rows(const float* patches, int64_t q, int p, const float* 
                            sp.q_packed, p, 1, wpack, (const f32x4*)wdense, bias, g);
     if (q > sp.q_packed)
         hipLaunchKernelGGL(pointnet_stn_rows_kernel<H>, dim3(sp.grid_rest), dim3(PNT), PA_LDS_BYTES, (hipStream_t)stream,
-                           patches + sp.q_packed * p * 3, q - sp.q_packed, p, 0, wpack, (const f32x4*)wdense, bias, g + sp.q_packed * 256);
+                           patches + sp.q_packed * p * 3, q - sp.q_packed, p, sp.rest_mode, wpack, (const f32x4*)wdense, bias, g + sp.q_packed * 256);
     return PPS_LAUNCH_CHECK();
 }
 
@@ -1238,7 +1266,7 @@ static int launch_feat_rows(const float* patches, const float* trans2, int64_t q
                            trans2, sp.q_packed, p, 1, wpack, (const f32x4*)wdense, bias, xbar);
     if (q > sp.q_packed)
         hipLaunchKernelGGL(pointnet_feat_rows_kernel<H>, dim3(sp.grid_rest), dim3(PNT), PC_LDS_BYTES, (hipStream_t)stream,
-                           patches + sp.q_packed * p * 3, trans2 + sp.q_packed * 4096, q - sp.q_packed, p, 0, wpack, (const f32x4*)wdense, bias,
+                           patches + sp.q_packed * p * 3, trans2 + sp.q_packed * 4096, q - sp.q_packed, p, sp.rest_mode, wpack, (const f32x4*)wdense, bias,
                            xbar + sp.q_packed * 256);
     return PPS_LAUNCH_CHECK();
 }
@@ -1293,7 +1321,8 @@ int pps_interp_pool_f16x3(const float* G, const float* pts, const float* query, 
     int cus = cu_count();
     if (cus <= 0) cus = 256;
     const int64_t ntiles = (q + IH_NW / 4 - 1) / (IH_NW / 4);
-    const int grid = (int)(ntiles < cus ? ntiles : cus);               // one 8-wave workgroup per CU
+    const int64_t wgs = (int64_t)cus * IH_WG_PER_CU;                  // one 8-wave workgroup per CU (IH_NT = 512)
+    const int grid = (int)(ntiles < wgs ? ntiles : wgs);
     hipLaunchKernelGGL(interp_pool_f16x3_kernel, dim3(grid), dim3(IH_NT), IH_LDS_BYTES, (hipStream_t)stream,
                        G, pts, query, idx, q, k, wxyz, (const f32x4*)w16, bias, pooled);
     return PPS_LAUNCH_CHECK();

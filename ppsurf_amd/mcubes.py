@@ -35,8 +35,42 @@ def _face_cycles():
     return faces
 
 
+def _triangulate(loop, edge_faces):
+    """Triangles (as index triples in loop order) of the polygon `loop` of cube-edge ids WITHOUT a diagonal that lies in a cube face: two
+    crossing points on edges of one face that are not joined by that face's own segment would give a triangle edge flush with the face, and
+    the cube across the face may draw the same chord -- four triangles on one edge, a non-manifold mesh (found by oracle/mesh_oracle.py on a
+    learned volume; a plain fan from loop[0] has such chords in 18 of the 256 cases).  All triangulations of the <= 12-gon are enumerated
+    (Catalan numbers) and the first one without an in-face chord is taken; every case has one."""
+    n = len(loop)
+
+    def chord_ok(i, j):
+        if (j - i) % n in (1, n - 1):
+            return True                                           # a polygon side: the face segment itself
+        return not (edge_faces[loop[i]] & edge_faces[loop[j]])
+
+    from functools import lru_cache
+
+    @lru_cache(maxsize=None)
+    def best(i, j):                                               # triangulations of the sub-polygon i..j (chord i-j given): (bad chords, triangles)
+        if j - i < 2:
+            return 0, ()
+        out = None
+        for k in range(i + 1, j):
+            bi, ti = best(i, k)
+            bj, tj = best(k, j)
+            cost = bi + bj + (0 if chord_ok(i, k) else 1) + (0 if chord_ok(k, j) else 1)
+            if out is None or cost < out[0]:
+                out = (cost, ti + tj + ((i, k, j),))
+        return out
+
+    cost, tris = best(0, n - 1)
+    assert cost == 0, 'no triangulation without an in-face chord for loop {}'.format(loop)
+    return [(loop[a], loop[b], loop[c]) for a, b, c in tris]
+
+
 def _build_table():
     faces = _face_cycles()
+    edge_faces = {i: frozenset(fi for fi, cyc in enumerate(faces) if a in cyc and b in cyc) for i, (a, b) in enumerate(_EDGES)}
     table = []
     for case in range(256):
         inside = [(case >> c) & 1 for c in range(8)]
@@ -61,8 +95,8 @@ def _build_table():
                 seen.add(e)
                 loop.append(e)
                 e = nxt[e]
-            for t in range(1, len(loop) - 1):
-                tris.append((loop[0], loop[t + 1], loop[t]))        # winding: normals point towards LOWER values
+            for a, b, c in _triangulate(loop, edge_faces):
+                tris.append((a, c, b))                              # winding: normals point towards LOWER values
         table.append(tris)
     width = max(len(t) for t in table)
     out = np.full((256, width, 3), -1, dtype=np.int64)

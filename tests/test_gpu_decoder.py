@@ -135,8 +135,8 @@ def test_decoder_full_chunk_properties(dtype, scale):
     assert np.isfinite(lg).all() and (np.abs(occ.cpu().numpy()) <= 1).all()
     perm = torch.randperm(50_000, device=DEV)
     lg2, _ = pl.decode(table, pts, qd[perm].contiguous(), idx[perm].contiguous(), patches[perm].contiguous())
-    # each query is independent of its tile neighbours (packed / unpacked PointNet tiles only re-associate sums)
-    assert float((lg2 - logits[perm]).abs().max()) < 2e-5
+    # each query is independent of its tile neighbours and of its position in the chunk: equal, not close
+    assert torch.equal(lg2, logits[perm])
     sel = np.random.default_rng(1).choice(50_000, 256, replace=False)
     data = {'latents': torch.from_numpy(lat), 'pts': torch.from_numpy(cloud.T.copy()).unsqueeze(0),
             'pts_query': torch.from_numpy(qry[sel]).unsqueeze(0), 'pts_local_ps': patches[torch.from_numpy(sel).to(DEV)].cpu().unsqueeze(0)}
@@ -171,6 +171,32 @@ def test_pointnet_branch_matches_reference_module_fixture(name, p):
     wv = pn[pre + 'att.fc_value.weight'].reshape(256, 256).double()
     got = inter['xbar'].double().cpu() @ wv.t() + pn[pre + 'att.fc_value.bias'].double()
     np.testing.assert_allclose(got.numpy(), feat, rtol=0, atol=5e-5)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('p', [50, 100, 40])
+def test_logits_do_not_depend_on_the_chunking(p, dtype):
+    """A query's logits are BIT-identical whether it is decoded in one chunk of 40 000, in two uneven chunks or among other neighbours:
+    the PointNet row kernels use full packed rounds for most of a chunk and the same arithmetic with one query per group for the remainder
+    (patch_packing mode 2); every other kernel works per query.  This is what makes a query-sharded reconstruction (PPS_SHARD=queries)
+    equal -- not close -- to the single-rank one.  P = 50 / 100 are packed patterns (2 / 4 left-over rows), P = 40 is not."""
+    from ppsurf_amd.synthetic import network_state_dict
+    pl = plan(dtype) if p == 50 else DecoderPlan(network_state_dict('ppsurf', num_pts_local=p), DEV, dtype=dtype)
+    cloud = make_cloud(30_000, seed=p)
+    qry = make_band_queries(cloud, 40_000, resolution=129, seed=2)
+    pts, qd = dev(cloud), dev(qry)
+    table = pl.point_table(dev(make_latents(256, cloud.shape[0], seed=9)[0] * np.float32(10.0)))
+    idx = ops.knn_point_major(pts, qd, max(64, p))
+    patches = ops.patch_normalize(pts, qd, idx, p)
+    idx = idx[:, :64].contiguous()
+    whole, _ = pl.decode(table, pts, qd, idx, patches)
+    whole = whole.clone()
+    for cut in (17_000, 16_384, 39_999):
+        parts = [pl.decode(table, pts, qd[a:b].contiguous(), idx[a:b].contiguous(), patches[a:b].contiguous())[0].clone() for a, b in ((0, cut), (cut, 40_000))]
+        assert torch.equal(torch.cat(parts), whole), (p, dtype, cut)
+    perm = torch.randperm(40_000, device=DEV)
+    shuffled, _ = pl.decode(table, pts, qd[perm].contiguous(), idx[perm].contiguous(), patches[perm].contiguous())
+    assert torch.equal(shuffled, whole[perm])
 
 
 # ---- opt-in split-precision decoder dtype ("f16x3"): same 1e-4 bar as the fp32 path -----------------------------------------

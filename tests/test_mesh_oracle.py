@@ -28,7 +28,13 @@ def _volumes():
     blobs[2, 2, 2] = 5.0                                   # an isolated one-voxel component (8 faces)
     blobs[22:24, 3, 3] = 4.0
     neg = -_field(seed=5)                                  # inside / outside swapped
-    return {'smooth': (vol, True), 'band': (band, True), 'ties': (ties, True), 'cut': (cut, False), 'blobs': (blobs, True), 'neg': (neg, True)}
+    # white noise: all 256 corner patterns, every ambiguous face and every multi-loop cube (found the in-face chords of a fan triangulation
+    # that smooth fields never exercise); the surface leaves the grid through its outer faces, which is not an open edge
+    noise = np.random.default_rng(0).standard_normal((14, 14, 14))
+    from scipy.ndimage import gaussian_filter
+    rough = gaussian_filter(np.random.default_rng(1).standard_normal((30, 30, 30)), 1.0)
+    return {'smooth': (vol, True), 'band': (band, True), 'ties': (ties, True), 'cut': (cut, False), 'blobs': (blobs, True), 'neg': (neg, True),
+            'noise': (noise, True), 'rough': (rough, True)}
 
 
 @pytest.mark.parametrize('name', sorted(_volumes()))
@@ -36,7 +42,7 @@ def test_numpy_and_torch_marching_cubes_meet_the_specification(name):
     vol, closed = _volumes()[name]
     v, f = mcubes.marching_cubes(vol, 0.0)
     info = M.check_marching_cubes(v, f, vol, 0.0, require_closed=closed)
-    assert info['faces'] > 500 and (info['boundary_edges'] == 0) == closed
+    assert info['faces'] > 500 and (info['boundary_edges'] == 0) == closed, info
     vt, ft = mcubes.marching_cubes_torch(torch.from_numpy(vol), 0.0)
     M.check_marching_cubes(vt.numpy(), ft.numpy(), vol, 0.0, require_closed=closed)
 
@@ -72,6 +78,22 @@ def test_the_specification_rejects_broken_meshes():
     allflip = f[:, ::-1].copy()
     with pytest.raises(AssertionError, match='HIGHER'):
         M.check_marching_cubes(v, allflip, vol, 0.0)
+
+
+def test_every_corner_pattern_is_exercised_and_no_triangle_edge_lies_in_a_cube_face():
+    """The white-noise volume contains all 256 corner patterns.  Independent of the specification's manifold test, count directly: no
+    undirected mesh edge may be used by more than two faces (the defect a fan triangulation with in-face chords produces)."""
+    vol = _volumes()['noise'][0]
+    n = vol.shape[0]
+    case = np.zeros((n - 1,) * 3, dtype=np.int64)
+    for c in range(8):
+        dx, dy, dz = c & 1, (c >> 1) & 1, (c >> 2) & 1
+        case |= (vol[dx:n - 1 + dx, dy:n - 1 + dy, dz:n - 1 + dz] > 0).astype(np.int64) << c
+    assert np.unique(case).shape[0] == 256
+    v, f = mcubes.marching_cubes(vol, 0.0)
+    e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), axis=1)
+    _, cnt = np.unique(e[:, 0] * v.shape[0] + e[:, 1], return_counts=True)
+    assert cnt.max() == 2
 
 
 def _dirty_mesh(seed=0):
@@ -141,7 +163,7 @@ def test_fixture_volume_of_the_reference_driver_on_cpu():
 
 # ---- the device path ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ['band', 'ties', 'cut', 'blobs'])
+@pytest.mark.parametrize('name', ['band', 'ties', 'cut', 'blobs', 'noise', 'rough'])
 def test_device_marching_cubes_and_clean_up_meet_the_specification(name):
     vol, closed = _volumes()[name]
     v, f = mcubes.marching_cubes_torch(torch.from_numpy(vol).to('cuda:0'), 0.0)
