@@ -188,8 +188,14 @@ int pps_interp_pool_f16x3(const float* G, const float* pts, const float* query, 
  * g [q,256], trans2 (q x 16 KiB: pre-split fragments of the per-query feature transform), xbar [q,256]; events: 3 hipEvent_t or NULL. */
 int pps_pointnet_f16x3(const float* patches, int64_t q, int p, const float* const* weights, const void* const* w16, float* g, float* trans2,
                        float* xbar, void* const* events, void* stream);
-/* pps_decode_fwd_events_f32 with branches in split precision: w16 [host] array of 4 image sets (interp, stn_rows, stn_fc, feat_rows);
- * w16[0] NULL keeps the fp32 interpolation branch, any of w16[1..3] NULL keeps the fp32 PointNet branch.  events may be NULL. */
+/* The tail (pps_decode_tail_f32: source/ppsurf_model.py:100, source/base/nn.py:376-417 composed with fc8 . fc_value | att.fc_value) in split
+ * precision: w16 = pps_pack_dense_f16x3 images of Wa 256x256 and Wb 256x256 interleaved in 32 KiB chunks (chunk 2c: output blocks 2c, 2c+1 of Wa,
+ * chunk 2c+1: the same blocks of Wb), then [L2 256x256][L3 2x256]; bias as for the fp32 entry. */
+int pps_decode_tail_f16x3(const float* pooled, const float* xbar, int64_t q, const void* w16, const float* bias, float* logits, float* occ,
+                          void* stream);
+/* pps_decode_fwd_events_f32 with branches in split precision: w16 [host] array of 5 image sets (interp, stn_rows, stn_fc, feat_rows, tail);
+ * w16[0] NULL keeps the fp32 interpolation branch, any of w16[1..3] NULL keeps the fp32 PointNet branch, w16[4] NULL the fp32 tail.
+ * events may be NULL. */
 int pps_decode_fwd_mixed_f32(const float* table, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
                              const float* patches, int p, const float* const* weights, const void* const* w16, float* logits, float* occ,
                              void* ws, void* const* events, void* stream);

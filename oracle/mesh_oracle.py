@@ -151,6 +151,12 @@ def check_marching_cubes(verts, faces, volume, level=0.0, atol=1e-9, require_clo
     big = area > 1e-3 * np.median(area[area > 0]) if (area > 0).any() else area > 0
     nn = n / np.maximum(area, 1e-300)[:, None]
     cen = tri.mean(axis=1)
+    # faces whose probe would read an unseen voxel do not vote (the trilinear field is undefined there)
+    ci = np.clip(np.floor(cen).astype(np.int64), 0, np.array(vol.shape) - 2)
+    for dx in (0, 1):
+        for dy in (0, 1):
+            for dz in (0, 1):
+                big &= np.isfinite(vol[ci[:, 0] + dx, ci[:, 1] + dy, ci[:, 2] + dz])
     fin = np.nan_to_num(vol, nan=level)
     d = _trilinear(fin, cen + 0.05 * nn) - _trilinear(fin, cen - 0.05 * nn)
     wrong = big & (d > 1e-12)

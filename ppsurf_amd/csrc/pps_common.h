@@ -163,6 +163,9 @@ __device__ __forceinline__ void dense_blocks(const f32x4 (&in)[KB], f32x4* out, 
 // 16 ob + 4 g + r), so two finished output blocks (2 kb, 2 kb + 1) ARE the B operand of k-block kb of the next layer once
 // split: element j of lane (n,g) is channel 32 kb + 16 (j >> 2) + 4 g + (j & 3).  The packed weights use the same map:
 //     packed[ob][kb][part][lane][j] = f16 part (0: hi, 1: lo) of W[16 ob + (l & 15)][32 kb + 16 (j >> 2) + 4 (l >> 4) + (j & 3)].
+#ifndef PPS_F16X3_PREFETCH
+#define PPS_F16X3_PREFETCH 1     // k-steps the A fragments of the split-precision layers are requested ahead (1 or 2)
+#endif
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct HiLo { half8 hi, lo; };
@@ -195,17 +198,34 @@ __device__ __forceinline__ void join_f16(const HiLo& x, f32x4& y0, f32x4& y1) {
 // terms are summed among themselves before they meet the large ones.
 // FENCE = false drops the scheduling fence after each k-step: for short contractions (KB = 2) the epilogue of one pair (split +
 // stores) then overlaps the MFMAs of the next pair instead of running alone.
-template <int KB, int NOB, int ACT, bool FENCE = true, class Sink>
+// INIT = true: the main accumulators start from init[ob] (fp32 blocks of an earlier partial product over other input channels) instead of
+// the bias -- a layer whose input is the concatenation of two tensors is evaluated half by half.
+template <int KB, int NOB, int ACT, bool FENCE = true, bool INIT = false, class Sink>
 __device__ __forceinline__ void dense_blocks_f16x3(const HiLo (&in)[KB], const half8* __restrict__ w, const f32x4* __restrict__ bias, int lane,
-                                                   Sink&& sink) {
+                                                   Sink&& sink, const f32x4* init = nullptr) {
     static_assert(NOB % 2 == 0, "output blocks are processed in pairs");
     const int g = lane >> 4;
 #pragma unroll
     for (int ob = 0; ob < NOB; ob += 2) {
-        f32x4 m0 = bias[(ob) * 4 + g], m1 = bias[(ob + 1) * 4 + g];
+        f32x4 m0 = INIT ? init[ob] : bias[(ob) * 4 + g], m1 = INIT ? init[ob + 1] : bias[(ob + 1) * 4 + g];
         f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
         const half8* w0 = w + ((ob) * KB) * 128 + lane;
         const half8* w1 = w + ((ob + 1) * KB) * 128 + lane;
+#if PPS_F16X3_PREFETCH == 2
+        // fragments of step kb are requested during step kb-2 (16 more VGPRs: hides an LDS round trip that is longer than one k-step when eight
+        // waves read 32 KiB per k-step between them)
+        half8 ph0 = w0[0], pl0 = w0[64], ph1 = w1[0], pl1 = w1[64];
+        half8 qh0 = ph0, ql0 = pl0, qh1 = ph1, ql1 = pl1;
+        if (KB > 1) { qh0 = w0[128]; ql0 = w0[128 + 64]; qh1 = w1[128]; ql1 = w1[128 + 64]; }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const half8 ah0 = ph0, al0 = pl0, ah1 = ph1, al1 = pl1;
+            ph0 = qh0; pl0 = ql0; ph1 = qh1; pl1 = ql1;
+            if (kb + 2 < KB) {
+                qh0 = w0[(kb + 2) * 128]; ql0 = w0[(kb + 2) * 128 + 64];
+                qh1 = w1[(kb + 2) * 128]; ql1 = w1[(kb + 2) * 128 + 64];
+            }
+#else
         half8 ph0 = w0[0], pl0 = w0[64], ph1 = w1[0], pl1 = w1[64];          // fragments of step kb are requested during step kb-1
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
@@ -214,6 +234,7 @@ __device__ __forceinline__ void dense_blocks_f16x3(const HiLo (&in)[KB], const h
                 ph0 = w0[(kb + 1) * 128]; pl0 = w0[(kb + 1) * 128 + 64];
                 ph1 = w1[(kb + 1) * 128]; pl1 = w1[(kb + 1) * 128 + 64];
             }
+#endif
             m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, in[kb].hi, m0, 0, 0, 0);
             m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, in[kb].hi, m1, 0, 0, 0);
             c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, in[kb].lo, c0, 0, 0, 0);

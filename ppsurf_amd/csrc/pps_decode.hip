@@ -1191,6 +1191,71 @@ __global__ __launch_bounds__(NT, 2) void decode_tail_kernel(const float* __restr
     }
 }
 
+// The tail in split precision ("f16x3"): the three dense layers as f16 hi/lo products (dense_blocks_f16x3); the 512 -> 256 layer is the sum of
+// two 256 -> 256 halves ([pooled | xbar] are two tensors), the second starts from the fp32 accumulators of the first.
+// w16 (half8 fragments): pps_pack_dense_f16x3 images, 32 KiB chunks (two output blocks each): Wa and Wb ALTERNATING chunk by chunk (the pair of
+// output blocks 2c, 2c+1 is finished before the next one starts: two live accumulator blocks instead of sixteen), then [L2][L3].
+__global__ __launch_bounds__(NT, 2) void decode_tail_h_kernel(const float* __restrict__ pooled, const float* __restrict__ xbar, int64_t Q,
+                                                              const f32x4* __restrict__ w16, const float* __restrict__ bias,
+                                                              float* __restrict__ logits, float* __restrict__ occ) {
+    f32x4* buf0 = (f32x4*)pps_smem;
+    f32x4* buf1 = buf0 + CH4;
+    float* bias_l = (float*)(buf1 + CH4);
+    const f32x4* bias4 = (const f32x4*)bias_l;
+    const f32x4* wg = w16;
+    const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
+
+    lds_fill(bias_l, bias, TL_NBIAS);
+    stream_prologue<CH4>(wg, buf0);
+    __syncthreads();
+    f32x4 *cur = buf0, *nxt = buf1;
+
+    const int ntiles = (int)((Q + NW * 16 - 1) / (NW * 16));
+    int first, count, stride;
+    xcd_tile_range(ntiles, first, count, stride);
+    for (int it = 0; it < count; ++it) {
+        const int64_t qi = (int64_t)(first + it * stride) * (NW * 16) + wave * 16 + n;
+        const bool qv = qi < Q;
+        const int64_t qc = qv ? qi : Q - 1;
+        HiLo p[8], x[8];
+        {
+            const f32x4* sp = (const f32x4*)(pooled + qc * 256) + g;
+            const f32x4* sx = (const f32x4*)(xbar + qc * 256) + g;
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                p[kb] = split_f16(sp[4 * (2 * kb)], sp[4 * (2 * kb + 1)]);
+                x[kb] = split_f16(sx[4 * (2 * kb)], sx[4 * (2 * kb + 1)]);
+            }
+        }
+        HiLo y[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {                                  // output blocks 2c, 2c+1 of the 512 -> 256 layer: the chunks of Wa and Wb alternate
+            f32x4 h[2];
+            stream_step<CH4>(wg + (2 * c + 1) * CH4, cur, nxt, [&](const f32x4* w) {             // Wa . pooled + bias, no activation yet
+                dense_blocks_f16x3<8, 2, 0>(p, (const half8*)w, bias4 + 8 * c, lane, [&](int, const f32x4& o0, const f32x4& o1) { h[0] = o0; h[1] = o1; }); });
+            stream_step<CH4>(wg + (2 * c + 2) * CH4, cur, nxt, [&](const f32x4* w) {             // + Wb . xbar, ReLU
+                dense_blocks_f16x3<8, 2, 1, true, true>(x, (const half8*)w, bias4, lane, [&](int, const f32x4& o0, const f32x4& o1) { y[c] = split_f16(o0, o1); }, h); });
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            stream_step<CH4>(wg + (c + 17) * CH4, cur, nxt, [&](const f32x4* w) {
+                dense_blocks_f16x3<8, 2, 1>(y, (const half8*)w, bias4 + 64 + 8 * c, lane, [&](int, const f32x4& o0, const f32x4& o1) { p[c] = split_f16(o0, o1); }); });
+        f32x4 o[2];
+        stream_step<CH4>(wg, cur, nxt, [&](const f32x4* w) {
+            dense_blocks_f16x3<8, 2, 0>(p, (const half8*)w, bias4 + 128, lane, [&](int, const f32x4& o0, const f32x4& o1) { o[0] = o0; o[1] = o1; }); });
+        if (qv && g == 0) {
+            const float l0 = o[0].x, l1 = o[0].y;
+            logits[qi * 2] = l0;
+            logits[qi * 2 + 1] = l1;
+            if (occ) {
+                const float mx = fmaxf(l0, l1);
+                const float e0 = __expf(l0 - mx), e1 = __expf(l1 - mx);
+                occ[qi] = (e0 - e1) / (e0 + e1);
+            }
+        }
+    }
+}
+
 // =====================================================================================================
 // host side
 // =====================================================================================================
@@ -1403,6 +1468,18 @@ int pps_decode_tail_f32(const float* pooled, const float* xbar, int64_t q, const
     return PPS_LAUNCH_CHECK();
 }
 
+int pps_decode_tail_f16x3(const float* pooled, const float* xbar, int64_t q, const void* w16, const float* bias, float* logits, float* occ,
+                          void* stream) {
+    if (q < 0) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    if (!pooled || !xbar || !w16 || !bias || !logits) return PPS_ERR_ARG;
+    static int once = set_lds(decode_tail_h_kernel, TL_LDS_BYTES);
+    (void)once;
+    hipLaunchKernelGGL(decode_tail_h_kernel, dim3(grid_for((q + NW * 16 - 1) / (NW * 16))), dim3(NT), TL_LDS_BYTES, (hipStream_t)stream,
+                       pooled, xbar, q, (const f32x4*)w16, bias, logits, occ);
+    return PPS_LAUNCH_CHECK();
+}
+
 /* The whole decoder of one query chunk in one call: the five launches above on `stream`, intermediates in caller scratch. */
 size_t pps_decode_ws_bytes(int64_t q) { return q < 0 ? 0 : (size_t)q * (256 + 256 + 4096 + 256) * sizeof(float); }
 
@@ -1436,7 +1513,9 @@ static int decode_fwd(const float* table, const float* pts, const float* query, 
         if (rc == PPS_OK) rc = pps_pointnet_feat_rows_f32(patches, trans2, q, p, weights[6], weights[7], xbar, stream);
         PPS_MARK(4);
     }
-    if (rc == PPS_OK) rc = pps_decode_tail_f32(pooled, xbar, q, weights[8], weights[9], logits, occ, stream);
+    if (rc == PPS_OK)
+        rc = (w16 && w16[4]) ? pps_decode_tail_f16x3(pooled, xbar, q, w16[4], weights[9], logits, occ, stream)
+                             : pps_decode_tail_f32(pooled, xbar, q, weights[8], weights[9], logits, occ, stream);
     PPS_MARK(5);
 #undef PPS_MARK
     return rc;

@@ -78,8 +78,8 @@ class DecoderPlan:
     def __init__(self, sd, device, prefix='', dtype=None):
         """dtype 'f32' (default; exact fp32 MFMA everywhere -- the parity path) or 'f16x3' (opt-in, also through the environment
         variable PPS_DECODER_DTYPE): the dense layers of the interpolation branch (fc2, fc3, fc_query) and of the PointNet branch (all but
-        the xyz layers) run on the f16 matrix pipe in split precision (three f16 products per fp32 product, fp32 accumulation;
-        csrc/pps_common.h); the per-point table, the xyz layers, softmax / pooling and the tail stay fp32.  Logits agree with the fp32
+        the xyz layers) and the tail run on the f16 matrix pipe in split precision (three f16 products per fp32 product, fp32 accumulation;
+        csrc/pps_common.h); the per-point table, the xyz layers and softmax / pooling stay fp32.  Logits agree with the fp32
         path to ~1e-5 (tests/test_gpu_decoder.py)."""
         import os
         p = prefix
@@ -153,9 +153,12 @@ class DecoderPlan:
         if self.dtype == 'f16x3':
             sets = [[w2, w3, wq], [c0b[0], s1[0], s2[0], s3[0]], [f1[0], f2[0], f3w], [c0b[0], c1[0], c2[0], c3[0]]]
             imgs = [np.concatenate([pack_dense_f16x3(m) for m in ms]) for ms in sets]
-            assert [i.shape[0] for i in imgs] == [2 * (65536 * 2 + 16384), 2 * 49152, 2 * (32768 + 8192 + 262144), 2 * 49152]
+            # tail: the two halves of the 512 -> 256 layer alternate in 32 KiB chunks (two output blocks each), then L2, L3 (pps_decode_tail_f16x3)
+            ab = np.stack([pack_dense_f16x3(wa).reshape(8, -1), pack_dense_f16x3(wb).reshape(8, -1)], axis=1).reshape(-1)
+            imgs.append(np.concatenate([ab, pack_dense_f16x3(l2[0]), pack_dense_f16x3(l3w)]))
+            assert [i.shape[0] for i in imgs] == [2 * (65536 * 2 + 16384), 2 * 49152, 2 * (32768 + 8192 + 262144), 2 * 49152, 2 * (65536 * 3 + 8192)]
             self._w16_t = [torch.from_numpy(i.view(np.int16)).to(self.device) for i in imgs]
-            self.w16 = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in self._w16_t])
+            self.w16 = (ctypes.c_void_p * 5)(*[t.data_ptr() for t in self._w16_t])
         self._scratch = {}
 
     # ---- scratch management: caller-owned buffers, reused across chunks -------------------------------------

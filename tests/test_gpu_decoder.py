@@ -186,7 +186,7 @@ def test_logits_do_not_depend_on_the_chunking(p, dtype):
     qry = make_band_queries(cloud, 40_000, resolution=129, seed=2)
     pts, qd = dev(cloud), dev(qry)
     table = pl.point_table(dev(make_latents(256, cloud.shape[0], seed=9)[0] * np.float32(10.0)))
-    idx = ops.knn_point_major(pts, qd, max(64, p))
+    idx = ops.KnnBlocks(pts).query(qd, max(64, p))                           # the P nearest in (distance, index) order: the 64 nearest are its prefix
     patches = ops.patch_normalize(pts, qd, idx, p)
     idx = idx[:, :64].contiguous()
     whole, _ = pl.decode(table, pts, qd, idx, patches)

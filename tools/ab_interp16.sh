@@ -1,11 +1,11 @@
 #!/bin/bash
 # A/B of interp_pool_f16x3_kernel build variants (python -m ppsurf_amd.build --variant ...), timed with tools/time_decoder_stages.py:
 #   base      product build (IH_NT=512, IH_OB=2: one 8-wave workgroup per CU, 32 KiB chunks)
-#   ih256     two decoupled 4-wave workgroups per CU (the weight stream doubles, the VALU phases of one overlap the MFMA phase of the other)
-#   ihob4     64 KiB chunks (9 instead of 18 barriers per pass)
+#   pf2       A fragments of the split-precision layers requested two k-steps ahead (ih256 = two decoupled 4-wave workgroups and ihob4 = 64 KiB chunks
+#             were measured in round 3: 2.74 and 2.67 ms against 2.65 -- neither the barrier count nor the phase lock is what bounds the kernel)
 #   *nosm     softmax + pooling ablated, *nosmg: and the gather -> what the MFMA phase alone costs
 # build here (CPU container):  tools/ab_interp16.sh build        run on the GPU box:  tools/ab_interp16.sh
-VARIANTS="ih256:-DIH_NT=256 ihob4:-DIH_OB=4 ihnosm:-DPPS_ABL_IH_NOSOFTMAX ihnosmg:-DPPS_ABL_IH_NOSOFTMAX,-DPPS_ABL_IH_NOGATHER ih256nosm:-DIH_NT=256,-DPPS_ABL_IH_NOSOFTMAX ih256nosmg:-DIH_NT=256,-DPPS_ABL_IH_NOSOFTMAX,-DPPS_ABL_IH_NOGATHER"
+VARIANTS="pf2:-DPPS_F16X3_PREFETCH=2 ihnosmg:-DPPS_ABL_IH_NOSOFTMAX,-DPPS_ABL_IH_NOGATHER pf2nosmg:-DPPS_F16X3_PREFETCH=2,-DPPS_ABL_IH_NOSOFTMAX,-DPPS_ABL_IH_NOGATHER"
 if [ "$1" = build ]; then
   for v in $VARIANTS; do name=${v%%:*}; flags=${v#*:}; python -m ppsurf_amd.build --variant $name ${flags//,/ } > /dev/null || exit 1; echo built $name; done
   exit 0
