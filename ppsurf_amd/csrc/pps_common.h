@@ -271,6 +271,18 @@ __device__ __forceinline__ void xyz_blocks(float coord, f32x4* acc, const float*
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
+// The copy instruction is written as inline assembly on purpose.  hipcc models `global_load_lds` (a FLAT-encoded instruction that touches both
+// the vector-memory and the LDS counters) as a "pending flat" access: while one is in flight EVERY later `s_waitcnt` on vmcnt or lgkmcnt is
+// emitted with count 0.  The weight stream is always in flight, so every A-fragment wait of the MFMA loops became `s_waitcnt lgkmcnt(0)` -- it
+// also drained the fragments just requested for the NEXT k-step, i.e. the LDS latency was exposed once per k-step instead of hidden two steps
+// ahead (105 of 116 waits in interp_pool_f16x3_kernel; with the stream compiled out the same source gets lgkmcnt(4..7)).  That, not the stream's
+// bandwidth, held the f16x3 kernels at ~50 % and the fp32 kernels at ~83 % of the matrix pipe (round 3).  As inline asm the
+// compiler does not see a FLAT LDS access; the counters stay in order for its own bookkeeping: its vmcnt waits for ordinary loads only ever wait
+// LONGER with unknown older/younger VMEM operations in flight (returns are in order), and the stream itself is waited for explicitly
+// (stream_wait(), before the barrier that publishes a chunk).
+#ifndef PPS_DMA_ASM
+#define PPS_DMA_ASM 1
+#endif
 template <int NF4, int NTHREADS>
 __device__ __forceinline__ void chunk_copy_async(const f32x4* __restrict__ src, f32x4* dst) {
     // `src` is workgroup-uniform (SGPR base); the only per-lane part is one 32-bit byte offset
@@ -278,11 +290,27 @@ __device__ __forceinline__ void chunk_copy_async(const f32x4* __restrict__ src, 
     asm volatile("" : "+v"(lane_off));     // opaque: keeps hipcc from hoisting (and then spilling) one 64-bit address per chunk
     const int wave_base = threadIdx.x & ~63;
     const char* sbase = (const char*)src;
+#if PPS_DMA_ASM
+    asm volatile("" : "+s"(sbase));        // opaque as well: otherwise one SGPR pair per piece of every chunk is hoisted out of the persistent loop
+#endif
 #pragma unroll
     for (int i = 0; i < NF4; ++i) {
         f32x4* d = dst + i * NTHREADS + wave_base;
+#if PPS_DMA_ASM
+        // wave-uniform LDS byte address -> M0 (the low half of a generic pointer into the LDS aperture is the LDS offset)
+        const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)d);
+        const char* piece = sbase + (size_t)(i * NTHREADS * 16);
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_addr), "v"(lane_off), "s"(piece) : "memory", "m0");
+#else
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(sbase + (size_t)(i * NTHREADS * 16) + lane_off), (lds_ptr_t)(uintptr_t)d, 16, 0, 0);
+#endif
     }
+}
+// all outstanding pieces of this wave have landed in LDS (call before the barrier that hands the chunk to the other waves)
+__device__ __forceinline__ void stream_wait() {
+#if PPS_DMA_ASM
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+#endif
 }
 
 // XCD-aware persistent tile order: workgroup b runs on XCD b % 8 (observed, speed only); each XCD walks a

@@ -40,6 +40,7 @@ __device__ __forceinline__ void stream_step(const f32x4* __restrict__ gnext, f32
 #endif
     compute((const f32x4*)cur);
 #ifndef PPS_ABL_NOBARRIER
+    stream_wait();
     __syncthreads();
 #endif
 #ifndef PPS_ABL_NOSTREAM
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(NT, 2) void rows_dense256_kernel(const float* __res
 
     lds_fill(bias_l, bias, 256);
     stream_prologue<CH4>(wg, buf0);
+    stream_wait();
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 
@@ -158,6 +160,7 @@ __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restr
     lds_fill(xyz_l, wpack, IP_W_XYZ);
     lds_fill(bias_l, bias, IP_NBIAS);
     stream_prologue<CH4>(wg, buf0);
+    stream_wait();
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 
@@ -307,6 +310,7 @@ __global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float
     lds_fill(xyz_l, wxyz, IP_W_XYZ);
     lds_fill(bias_l, bias, IP_NBIAS);
     stream_prologue<IH_CH4, IH_NT>(wg, buf0);
+    stream_wait();
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 
@@ -666,6 +670,7 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_stn_rows_kernel(const float* 
     lds_fill(xyz_l, wpack, PA_W_XYZ);
     lds_fill(bias_l, bias, PA_NBIAS);
     stream_prologue<1024, PNT>(wg, buf0);
+    stream_wait();
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 
@@ -742,6 +747,7 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_kernel(const float* __r
 
     lds_fill(bias_l, bias, PB_NBIAS);
     stream_prologue<CH4>(wg, buf0);
+    stream_wait();
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 
@@ -813,6 +819,7 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_h_kernel(const float* _
 
     lds_fill(bias_l, bias, PB_NBIAS);
     stream_prologue<CH4>(wg, buf0);
+    stream_wait();
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
     const int ntiles = (int)((Q + NW * 16 - 1) / (NW * 16));
@@ -1045,6 +1052,7 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float*
     lds_fill(xyz_l, wpack, PC_W_XYZ);
     lds_fill(bias_l, bias, PC_NBIAS);
     stream_prologue<1024, PNT>(wg, buf0);
+    stream_wait();
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
     const float s0 = bias_l[576 + 256];                   // wq . b3 + bq
@@ -1147,6 +1155,7 @@ __global__ __launch_bounds__(NT, 2) void decode_tail_kernel(const float* __restr
 
     lds_fill(bias_l, bias, TL_NBIAS);
     stream_prologue<CH4>(wg, buf0);
+    stream_wait();
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 
@@ -1207,6 +1216,7 @@ __global__ __launch_bounds__(NT, 2) void decode_tail_h_kernel(const float* __res
 
     lds_fill(bias_l, bias, TL_NBIAS);
     stream_prologue<CH4>(wg, buf0);
+    stream_wait();
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
 

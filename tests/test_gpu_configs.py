@@ -362,11 +362,13 @@ def test_config4_unit_of_work_one_abc_shape_at_r257_learned_weights(trained):
           'open {}, >2 {}'.format(v.shape[0], f.shape[0], fields[0].n_queries, np.median(d) / voxel, np.percentile(d, 90) / voxel, two, open_e, multi))
     assert np.isfinite(v).all() and f.min() >= 0 and f.max() < v.shape[0]
     # band: a surface of this CAD part at R = 257 has some 10^5 vertices; the queries are the +-2 band of it plus 10 refinement rounds
-    assert 60_000 < v.shape[0] < 1_500_000 and 1.9 * v.shape[0] < f.shape[0] < 2.1 * v.shape[0]
-    assert 2_000_000 < fields[0].n_queries < 40_000_000
+    # stored band (measured on an MI355X with this 30-epoch checkpoint: 133 643 vertices, 266 706 faces, 2.31 M decoder queries, cloud -> surface
+    # median 3.1 / p90 9.7 voxels, every edge shared by exactly two faces); the fit that makes the checkpoint draws a dropout stream, hence a band
+    assert 70_000 < v.shape[0] < 300_000 and 1.95 * v.shape[0] < f.shape[0] < 2.05 * v.shape[0]
+    assert 1_200_000 < fields[0].n_queries < 6_000_000
     # the over-fitted shape's surface follows its input cloud (R = 129 with the same checkpoint: within 4 voxels of 1/128; here the voxel is half)
-    assert np.median(d) < 6 * voxel and np.percentile(d, 90) < 24 * voxel
-    assert two > 0.98                                            # closed 2-manifold up to where it leaves the band (open edges next to unseen voxels)
+    assert np.median(d) < 5 * voxel and np.percentile(d, 90) < 16 * voxel
+    assert two > 0.999 and multi == 0                           # closed 2-manifold (open edges only where the surface leaves the evaluated band)
 
 
 def test_marching_cubes_and_clean_up_on_a_learned_volume_meet_the_specification(trained):
@@ -387,6 +389,9 @@ def test_marching_cubes_and_clean_up_on_a_learned_volume_meet_the_specification(
     v, f = mcubes.marching_cubes_torch(vol, 0.0)
     assert v.is_cuda
     voln = vol.cpu().numpy()
+    dump = os.environ.get('PPS_DUMP_DIR')                          # development aid: keep the volume for a CPU post-mortem
+    if dump:
+        np.save(os.path.join(dump, 'learned_volume_r65.npy'), voln)
     info = M.check_marching_cubes(v.cpu().numpy(), f.cpu().numpy(), voln, 0.0, require_closed=False)
     assert info['faces'] > 3000 and info['boundary_edges'] < 0.05 * 3 * info['faces']
     v32 = v.to(torch.float32).to(torch.float64)                                # as reconstruct.py hands them to the clean-up (skimage returns float32)

@@ -5,10 +5,10 @@
 #             were measured in round 3: 2.74 and 2.67 ms against 2.65 -- neither the barrier count nor the phase lock is what bounds the kernel)
 #   *nosm     softmax + pooling ablated, *nosmg: and the gather -> what the MFMA phase alone costs
 # build here (CPU container):  tools/ab_interp16.sh build        run on the GPU box:  tools/ab_interp16.sh
-VARIANTS="pf2:-DPPS_F16X3_PREFETCH=2 ihnosmg:-DPPS_ABL_IH_NOSOFTMAX,-DPPS_ABL_IH_NOGATHER pf2nosmg:-DPPS_F16X3_PREFETCH=2,-DPPS_ABL_IH_NOSOFTMAX,-DPPS_ABL_IH_NOGATHER"
+VARIANTS="dmabuiltin:-DPPS_DMA_ASM=0"
 if [ "$1" = build ]; then
   for v in $VARIANTS; do name=${v%%:*}; flags=${v#*:}; python -m ppsurf_amd.build --variant $name ${flags//,/ } > /dev/null || exit 1; echo built $name; done
   exit 0
 fi
-echo base; python tools/time_decoder_stages.py 30 | grep f16x3
-for v in $VARIANTS; do name=${v%%:*}; echo $name; PPS_LIB_VARIANT=$name python tools/time_decoder_stages.py 30 | grep f16x3; done
+echo base; python tools/time_decoder_stages.py 30
+for v in $VARIANTS; do name=${v%%:*}; echo $name; PPS_LIB_VARIANT=$name python tools/time_decoder_stages.py 30 ; done

@@ -42,7 +42,8 @@ def main(src, dst):
             out.setdefault(short(name), {})[counter] = avg
     open(dst + '_rocprof_summary.txt', 'w').write('\n'.join(lines) + '\n')
     k = out.get('interp_pool_kernel', out.get('interp_pool_f16x3_kernel', {}))
-    pmc = {'source': os.path.basename(src.rstrip('/')), 'kernels': out}
+    # the GPU box has no .git: the caller passes the commit the snapshot was taken at (PPS_GIT_HEAD=$(git rev-parse --short=12 HEAD))
+    pmc = {'source': os.path.basename(src.rstrip('/')), 'git_head': os.environ.get('PPS_GIT_HEAD', 'unrecorded'), 'kernels': out}
     if 'FETCH_SIZE' in k and 'WRITE_SIZE' in k:
         # MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide
         # coalesced read stream -> doubled; WRITE_SIZE is uncalibrated and taken as is.
