@@ -116,7 +116,7 @@ def self_spawn(n, argv):
     return subprocess.call(launch_cmd(n, argv, free_port()), env=env)
 
 
-HEADLINE_DTYPE = 'f32'       # decoder dtype of `value`; the other dtype travels as an extra key of the N=1 line
+HEADLINE_DTYPE = 'f16x3'     # decoder dtype of `value` = the product default (ppsurf_amd.decoder.DecoderPlan); the fp32 run travels as an extra key of the N=1 line
 
 
 def rank_values(x, rank, world, dist, red_dev):

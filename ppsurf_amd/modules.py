@@ -332,8 +332,8 @@ class PPSurfNetwork(_Base):
     # -- plans / caches ------------------------------------------------------------------------------------------
     def decoder_plan(self, device) -> DecoderPlan:
         mods = nn.ModuleList([self.projection, self.point_net, self.mlp])
-        # decoder_dtype: None / 'f32' = exact fp32 MFMA (the parity path), 'f16x3' = opt-in split precision (decoder.DecoderPlan);
-        # unset, the environment variable PPS_DECODER_DTYPE decides
+        # decoder_dtype: 'f16x3' (split precision, the default of decoder.DecoderPlan) or 'f32' (exact fp32 MFMA); unset, the environment
+        # variable PPS_DECODER_DTYPE decides, then the default
         ver = _params_version(mods) + (self.training, getattr(self, 'decoder_dtype', None))
         if self._dec is None or self._dec[0] != ver or self._dec[1].device != torch.device(device):
             sd = {k: v for k, v in _sd(self).items() if not k.startswith('encoder.')}

@@ -41,7 +41,7 @@ def test_pack_roundtrip_and_padding():
 
 def test_folded_weights_reproduce_reference_from_latent():
     g = load_golden('ppsurf_from_latent')
-    plan = DecoderPlan(filled_sd('', key='ppsurf'), 'cpu')
+    plan = DecoderPlan(filled_sd('', key='ppsurf'), 'cpu', dtype='f32')
     w = {k: v.numpy() for k, v in plan.w.items()}
     cloud = g['cloud']
     logits, _ = emulate.decode(w, make_latents(256, cloud.shape[0], 77)[0], cloud, g['query'], g['proj_ids'][0], g['patches'])

@@ -145,8 +145,9 @@ def test_decoder_full_chunk_properties(dtype, scale):
     np.testing.assert_allclose(lg[sel], ref, rtol=0, atol=1e-4)
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('name,p', [('pointnet', 10), ('pointnet', 50), ('pointnet_p200', 200)])
-def test_pointnet_branch_matches_reference_module_fixture(name, p):
+def test_pointnet_branch_matches_reference_module_fixture(name, p, dtype):
     """The HIP PointNet kernels against the REFERENCE's PointNetfeat outputs (feature STN matrix `trans2` and the attention-pooled
     feature), P = 10 / 50 / 200: the branch's intermediates are read back from the decoder workspace; the reference's
     `feat = att.fc_value(sum_p w_p x_p)` is finished on the host from the pooled vector the kernels hand to the fused tail."""
@@ -159,7 +160,7 @@ def test_pointnet_branch_matches_reference_module_fixture(name, p):
     sd = {k: v for k, v in filled_sd('', key='ppsurf').items() if not k.startswith('point_net.')}
     sd.update({'point_net.' + k[len(pre):]: v for k, v in pn.items()})
     from ppsurf_amd.decoder import DecoderPlan
-    pl = DecoderPlan(sd, DEV)
+    pl = DecoderPlan(sd, DEV, dtype=dtype)
     q = x.shape[0]
     patches = np.ascontiguousarray(x.transpose(0, 2, 1))                               # [Q,3,P] -> [Q,P,3]
     cloud = make_cloud(500, seed=1)
@@ -167,7 +168,8 @@ def test_pointnet_branch_matches_reference_module_fixture(name, p):
     ids = O.knn_point_major(cloud, qry, 64)
     pl.decode(pl.point_table(dev(make_latents(256, 500, seed=2)[0])), dev(cloud), dev(qry), dev(ids), dev(patches))
     inter = pl.intermediates(q)
-    np.testing.assert_allclose(inter['trans2'][:trans2.shape[0]].cpu().numpy().reshape(-1, 64, 64), trans2, rtol=0, atol=2e-5)
+    if dtype == 'f32':                 # (f16x3 keeps the matrix as pre-split hi / lo fragments in the order its consumer reads them: checked through xbar)
+        np.testing.assert_allclose(inter['trans2'][:trans2.shape[0]].cpu().numpy().reshape(-1, 64, 64), trans2, rtol=0, atol=2e-5)
     wv = pn[pre + 'att.fc_value.weight'].reshape(256, 256).double()
     got = inter['xbar'].double().cpu() @ wv.t() + pn[pre + 'att.fc_value.bias'].double()
     np.testing.assert_allclose(got.numpy(), feat, rtol=0, atol=5e-5)
