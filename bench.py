@@ -413,7 +413,7 @@ def fit_roofline(ms_per_step):
         return {}
     d = json.load(open(path))
     s = ms_per_step * 1e-3
-    out = {'roofline': {'source': 'profiles/round3_train_pmc.json (rocprofv3 --pmc passes of tools/time_fit_graph.py at commit {}; per-step sums over all kernels '
+    out = {'roofline': {'source': 'profiles/round3_train_pmc.json (tools/profile_train_pmc.sh: rocprofv3 --pmc passes of the eager fit step, tools/time_train_step.py --bf16, at commit {}; per-step sums over all kernels '
                                   'of the step incl. the data preparation on the second stream); step time from this run'.format(d.get('git_head', 'unrecorded')),
                         'mfma_flops_per_step': d['mfma_flops_per_step'], 'hbm_bytes_per_step': d['hbm_bytes_per_step'],
                         'achieved_tflops': d['mfma_flops_per_step'] / s / 1e12, 'mfma_frac_of_bf16_peak': d['mfma_flops_per_step'] / s / 1e12 / PEAK_F16_MFMA_TFLOPS,

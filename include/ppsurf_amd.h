@@ -89,6 +89,18 @@ int pps_voxel_sample_batch_f32(const float* pts, int64_t b, int64_t n, int64_t t
 int pps_patch_normalize_f32(const float* raw, const float* query, const int64_t* idx, int64_t idx_stride,
                             int64_t q, int p, float* out, void* stream);
 
+/* ---- region-growing driver on byte masks (source/poco_utils.py:178-254) ---------------------------------- */
+/* Binary dilation with the box [-r, r]^3, clipped at the volume border: dst = dilate(src).
+ * replaces: source/poco_utils.py:181-196 `_dilate_binary` (a Python loop over points marking arr[p - r : p + r + 1] per axis).
+ * src, dst, tmp: uint8 [nx, ny, nz] (0 / non-zero; torch.bool storage), three distinct buffers; tmp is scratch. */
+int pps_dilate_box_u8(const uint8_t* src, uint8_t* dst, uint8_t* tmp, int64_t nx, int64_t ny, int64_t nz, int r, void* stream);
+/* Frontier of one growth round: out[i] = to_see[i] && ((neg[i] && vol[i] >= 0) || (pos[i] && vol[i] <= 0)); NaN (never evaluated) is neither.
+ * replaces: source/poco_utils.py:245-246 `new_mask = (mask_neg & (volume >= 0) & mask_to_see) | (mask_pos & (volume <= 0) & mask_to_see)`. */
+int pps_grow_frontier_f64(const double* vol, const uint8_t* neg, const uint8_t* pos, const uint8_t* to_see, uint8_t* out, int64_t total, void* stream);
+/* Voxels of the dilated band that still need a value: out[i] = band[i] && isnan(vol[i]) (the reference evaluates the whole band again,
+ * source/poco_utils.py:198-232; the decoder is deterministic, so skipping known voxels gives the same volume). */
+int pps_grow_band_todo_f64(const double* vol, const uint8_t* band, uint8_t* out, int64_t total, void* stream);
+
 /* ---- decoder weights: host-side packing into MFMA operand order --------------------------------- */
 /* All `W` are dense [out,in] row-major fp32 [host], already BatchNorm-folded / composed by the caller
  * (ppsurf_amd/decoder.py).  Packed images are plain float arrays the caller uploads to the device. */

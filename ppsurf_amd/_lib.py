@@ -25,6 +25,9 @@ SIGNATURES = {
     'pps_voxel_sample_f32': (_I, [_P, _I64, _I64, _c.c_float, _P, _I, _c.c_uint32, _P, _P, _P, _P]),
     'pps_voxel_sample_batch_f32': (_I, [_P, _I64, _I64, _I64, _P, _I, _c.c_uint32, _P, _P, _P, _P]),
     'pps_patch_normalize_f32': (_I, [_P, _P, _P, _I64, _I64, _I, _P, _P]),
+    'pps_dilate_box_u8': (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _P]),
+    'pps_grow_frontier_f64': (_I, [_P, _P, _P, _P, _P, _I64, _P]),
+    'pps_grow_band_todo_f64': (_I, [_P, _P, _P, _I64, _P]),
     'pps_packed_dense_floats': (_SZ, [_I, _I]),
     'pps_pack_dense_f32': (_I, [_P, _I, _I, _P]),
     'pps_packed_dense_f16x3_halfs': (_SZ, [_I, _I]),

@@ -222,8 +222,33 @@ def marching_cubes_torch(volume, level: float = 0.0):
     return verts, faces
 
 
+def _small_component_faces(a, b, nf, k):
+    """bool [nf]: faces that lie in a connected component of at most k faces; (a, b) = pairs of faces sharing an edge.
+    EXACT without iterating to convergence: a component of <= k faces has diameter <= k - 1, so after k rounds of min-label propagation (each
+    round one hop) all its faces carry the component's smallest face id -- its label class is the whole component and no adjacency leaves the
+    class.  Conversely a label class that no adjacency leaves is a union of whole components, hence the component itself; so
+    "class size <= k and closed" holds exactly for the faces of small components, while the unconverged classes inside large components are
+    either open or larger than k.  k rounds, two scatters each, no host synchronisation (round 2 iterated pointer jumping to a fixed point --
+    ~75 rounds with a device-to-host comparison each at R = 257 -- and counted sizes with a histogram kernel: 17 of the 18 ms of a clean-up)."""
+    import torch
+    dev = a.device
+    label = torch.arange(nf, device=dev)
+    for _ in range(max(int(k), 1)):
+        new = label.clone()
+        new.scatter_reduce_(0, a, label[b], reduce='amin')
+        new.scatter_reduce_(0, b, label[a], reduce='amin')
+        label = new
+    size = torch.zeros(nf, dtype=torch.int64, device=dev).scatter_add_(0, label, torch.ones(nf, dtype=torch.int64, device=dev))
+    la, lb = label[a], label[b]
+    diff = la != lb
+    is_open = torch.zeros(nf, dtype=torch.bool, device=dev)
+    is_open[la[diff]] = True
+    is_open[lb[diff]] = True
+    return (size[label] <= k) & ~is_open[label]
+
+
 def clean_mesh_torch(verts, faces, min_component_faces=6, digits=8):
-    """Same as clean_mesh on torch tensors (connected components by min-label propagation with pointer jumping)."""
+    """Same as clean_mesh on torch tensors (small components by a fixed number of label-propagation rounds, _small_component_faces)."""
     import torch
     if faces.shape[0] == 0:
         return verts, faces
@@ -254,16 +279,8 @@ def clean_mesh_torch(verts, faces, min_component_faces=6, digits=8):
         ow = owner[order]
         same = skey[1:] == skey[:-1]
         a, b = ow[:-1][same], ow[1:][same]
-        label = torch.arange(nf, device=dev)
-        while True:
-            new = label.clone()
-            new.scatter_reduce_(0, a, label[b], reduce='amin')
-            new.scatter_reduce_(0, b, label[a], reduce='amin')
-            new = new[new]
-            if torch.equal(new, label):
-                break
-            label = new
-        size = torch.bincount(label, minlength=nf)
-        faces = faces[size[label] > min_component_faces]
-    used, finv = torch.unique(faces.reshape(-1), return_inverse=True)
-    return verts[used], finv.reshape(-1, 3)
+        faces = faces[~_small_component_faces(a, b, nf, int(min_component_faces))]
+    used = torch.zeros(verts.shape[0], dtype=torch.bool, device=dev)           # compaction of the referenced vertices, order kept
+    used[faces.reshape(-1)] = True
+    remap = torch.cumsum(used, 0) - 1
+    return verts[used], remap[faces]

@@ -173,3 +173,33 @@ class KnnBlocks:
                                                   query.data_ptr(), m, int(k), idx.data_ptr(), d2.data_ptr() if return_d2 else None,
                                                   _stream(query)), 'pps_knn_blocked_f32')
         return (idx, d2) if return_d2 else idx
+
+
+# ---- region-growing driver on byte masks (csrc/pps_grow.hip) ---------------------------------------------------------------------------------
+def dilate_box(mask: torch.Tensor, r: int) -> torch.Tensor:
+    """Binary dilation of a bool volume [nx,ny,nz] on the device with the box [-r, r]^3, clipped at the border (source/poco_utils.py:181-196)."""
+    assert mask.dtype == torch.bool and mask.dim() == 3 and mask.is_cuda
+    src = mask.contiguous()
+    dst, tmp = torch.empty_like(src), torch.empty_like(src)
+    _lib.check(_lib.lib().pps_dilate_box_u8(src.data_ptr(), dst.data_ptr(), tmp.data_ptr(), src.shape[0], src.shape[1], src.shape[2], int(r), _stream(src)),
+               'pps_dilate_box_u8')
+    return dst
+
+
+def grow_frontier(volume: torch.Tensor, neg: torch.Tensor, pos: torch.Tensor, to_see: torch.Tensor) -> torch.Tensor:
+    """to_see & ((neg & volume >= 0) | (pos & volume <= 0)) in one pass (source/poco_utils.py:245-246); volume float64, masks bool, same shape."""
+    assert volume.dtype == torch.float64 and volume.is_cuda and volume.is_contiguous()
+    for m in (neg, pos, to_see):
+        assert m.dtype == torch.bool and m.shape == volume.shape and m.is_contiguous()
+    out = torch.empty_like(to_see)
+    _lib.check(_lib.lib().pps_grow_frontier_f64(volume.data_ptr(), neg.data_ptr(), pos.data_ptr(), to_see.data_ptr(), out.data_ptr(), volume.numel(),
+                                                _stream(volume)), 'pps_grow_frontier_f64')
+    return out
+
+
+def grow_band_todo(volume: torch.Tensor, band: torch.Tensor) -> torch.Tensor:
+    """band & isnan(volume) in one pass."""
+    assert volume.dtype == torch.float64 and volume.is_cuda and volume.is_contiguous() and band.dtype == torch.bool and band.is_contiguous()
+    out = torch.empty_like(band)
+    _lib.check(_lib.lib().pps_grow_band_todo_f64(volume.data_ptr(), band.data_ptr(), out.data_ptr(), volume.numel(), _stream(volume)), 'pps_grow_band_todo_f64')
+    return out

@@ -22,7 +22,11 @@ from . import ops, mcubes, sharding
 
 
 def _dilate(mask: torch.Tensor, r: int) -> torch.Tensor:
-    """Binary dilation with a (2r+1)^3 box, clipped at the volume border (poco_utils.py:181-196)."""
+    """Binary dilation with a (2r+1)^3 box, clipped at the volume border (poco_utils.py:181-196).  Device masks: the HIP byte-mask kernel
+    (pps_dilate_box_u8; 12 calls per R = 257 shape, 1.1 ms each as max_pool3d over a float copy in round 2).  Masks on the host only occur in the
+    CPU tests of the driver logic (stub decoder); they take the torch op."""
+    if mask.is_cuda:
+        return ops.dilate_box(mask, r)
     m = mask[None, None].float()
     m = torch.nn.functional.max_pool3d(m, kernel_size=2 * r + 1, stride=1, padding=r)
     return m[0, 0] > 0
@@ -92,7 +96,7 @@ def create_volume(field, pts_ids: torch.Tensor, resolution: int, step: float, bm
         seeds = torch.zeros((n, n, n), dtype=torch.bool, device=dev)
         seeds[pts_ids[:, 0], pts_ids[:, 1], pts_ids[:, 2]] = True
         band = _dilate(seeds, dilation_size)
-        todo = band & torch.isnan(volume)                                  # skip voxels already evaluated
+        todo = ops.grow_band_todo(volume, band) if volume.is_cuda else band & torch.isnan(volume)      # skip voxels already evaluated
         coords = torch.nonzero(todo)
         if coords.shape[0] > 0:
             q = coords.to(torch.float32) * np.float32(step) + np.float32(bmin_pad)      # :212-213 (float32 arithmetic)
@@ -105,7 +109,8 @@ def create_volume(field, pts_ids: torch.Tensor, resolution: int, step: float, bm
         neg_seeds[s[:, 0], s[:, 1], s[:, 2]] = True
         s = pts_ids[v >= 0]
         pos_seeds[s[:, 0], s[:, 1], s[:, 2]] = True
-        new_mask = (_dilate(neg_seeds, dilation_size) & (volume >= 0) & to_see) | (_dilate(pos_seeds, dilation_size) & (volume <= 0) & to_see)
+        neg, pos = _dilate(neg_seeds, dilation_size), _dilate(pos_seeds, dilation_size)
+        new_mask = ops.grow_frontier(volume, neg, pos, to_see) if volume.is_cuda else (neg & (volume >= 0) & to_see) | (pos & (volume <= 0) & to_see)
         pts_ids = torch.nonzero(new_mask)
         it += 1
         if progress is not None:

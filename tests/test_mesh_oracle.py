@@ -189,3 +189,41 @@ def test_device_path_on_the_reference_drivers_fixture_volume():
     vc, fc = mcubes.clean_mesh_torch(v.to(torch.float32).to(torch.float64), f, min_component_faces=6)      # as reconstruct.py hands them over
     M.check_clean_mesh(v.to(torch.float32).to(torch.float64).cpu().numpy(), f.cpu().numpy(), vc.cpu().numpy(), fc.cpu().numpy(), 6)
     assert vc.shape[0] == g['mc_verts'].shape[0] and fc.shape[0] == g['mc_faces'].shape[0]
+
+
+def _strips_and_fans():
+    """Separate components with known sizes and large diameters: triangle strips of 1..9, 30 and 200 faces (a strip of n faces has diameter
+    n - 1 in the face-adjacency graph), two fans, placed far apart."""
+    verts, faces, off = [], [], 0
+    for ci, n in enumerate([1, 2, 3, 4, 5, 6, 7, 8, 9, 30, 200]):
+        v = np.array([[i * 0.5, (i & 1) * 1.0, 10.0 * ci] for i in range(n + 2)])
+        f = np.array([[i, i + 1, i + 2] if i % 2 == 0 else [i + 1, i, i + 2] for i in range(n)]) + off
+        verts.append(v); faces.append(f); off += v.shape[0]
+    for ci, n in enumerate([6, 7, 20]):
+        v = np.concatenate([[[0.0, 0.0, 0.0]], [[np.cos(a), np.sin(a), 0.0] for a in np.linspace(0, 2 * np.pi, n + 1)[:-1]]]) + [100.0 * (ci + 1), 0, 0]
+        f = np.array([[0, 1 + i, 1 + (i + 1) % n] for i in range(n)]) + off
+        verts.append(v); faces.append(f); off += v.shape[0]
+    return np.concatenate(verts), np.concatenate(faces)
+
+
+@pytest.mark.parametrize('k', [1, 3, 6, 8])
+def test_fixed_round_small_component_filter_is_exact(k):
+    """mcubes._small_component_faces runs k propagation rounds, not to convergence: components of exactly k, k + 1 faces with the largest
+    possible diameter (strips), and large components whose unconverged label classes are small, against the union-find specification."""
+    v, f = _strips_and_fans()
+    rng = np.random.default_rng(k)
+    f = f[rng.permutation(f.shape[0])]                       # face ids unrelated to the geometry: minima sit anywhere in a component
+    for twin in (lambda: mcubes.clean_mesh(v, f, min_component_faces=k),
+                 lambda: tuple(t.numpy() for t in mcubes.clean_mesh_torch(torch.from_numpy(v), torch.from_numpy(f), min_component_faces=k))):
+        vc, fc = twin()
+        M.check_clean_mesh(v, f, vc, fc, min_component_faces=k)
+    sizes = np.bincount(np.unique(M.components_union_find(fc), return_inverse=True)[1])
+    assert sizes.min() == k + 1 or k == 8 and sizes.min() == 9
+
+
+@pytest.mark.gpu
+def test_device_small_component_filter_is_exact():
+    v, f = _strips_and_fans()
+    f = f[np.random.default_rng(0).permutation(f.shape[0])]
+    vt, ft = mcubes.clean_mesh_torch(torch.from_numpy(v).to('cuda:0'), torch.from_numpy(f).to('cuda:0'), min_component_faces=6)
+    M.check_clean_mesh(v, f, vt.cpu().numpy(), ft.cpu().numpy(), 6)
