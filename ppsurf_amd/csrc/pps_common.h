@@ -200,12 +200,9 @@ __device__ __forceinline__ void join_f16(const HiLo& x, f32x4& y0, f32x4& y1) {
 // stores) then overlaps the MFMAs of the next pair instead of running alone.
 // INIT = true: the main accumulators start from init[ob] (fp32 blocks of an earlier partial product over other input channels) instead of
 // the bias -- a layer whose input is the concatenation of two tensors is evaluated half by half.
-// `mid()` is called once, after the MFMAs of the first k-step of the first output-block pair have been issued: the place for VALU work that does
-// not depend on this call (the activation + hi/lo split of the PREVIOUS call's result, see interp_pool_f16x3_kernel) -- it then issues while the
-// matrix pipe works through the MFMAs just queued instead of after the last MFMA of a chunk with the pipe idle.
-template <int KB, int NOB, int ACT, bool FENCE = true, bool INIT = false, class Sink, class Mid>
-__device__ __forceinline__ void dense_blocks_f16x3_mid(const HiLo (&in)[KB], const half8* __restrict__ w, const f32x4* __restrict__ bias, int lane,
-                                                       Sink&& sink, Mid&& mid, const f32x4* init = nullptr) {
+template <int KB, int NOB, int ACT, bool FENCE = true, bool INIT = false, class Sink>
+__device__ __forceinline__ void dense_blocks_f16x3(const HiLo (&in)[KB], const half8* __restrict__ w, const f32x4* __restrict__ bias, int lane,
+                                                   Sink&& sink, const f32x4* init = nullptr) {
     static_assert(NOB % 2 == 0, "output blocks are processed in pairs");
     const int g = lane >> 4;
 #pragma unroll
@@ -244,7 +241,6 @@ __device__ __forceinline__ void dense_blocks_f16x3_mid(const HiLo (&in)[KB], con
             c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, in[kb].lo, c1, 0, 0, 0);
             c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, in[kb].hi, c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, in[kb].hi, c1, 0, 0, 0);
-            if (ob == 0 && kb == 0) mid();
             if (FENCE) {
                 __builtin_amdgcn_sched_group_barrier(PPS_SG_DSREAD, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(PPS_SG_MFMA, 6, 0);
@@ -258,11 +254,6 @@ __device__ __forceinline__ void dense_blocks_f16x3_mid(const HiLo (&in)[KB], con
         }
         sink(ob >> 1, o0, o1);
     }
-}
-template <int KB, int NOB, int ACT, bool FENCE = true, bool INIT = false, class Sink>
-__device__ __forceinline__ void dense_blocks_f16x3(const HiLo (&in)[KB], const half8* __restrict__ w, const f32x4* __restrict__ bias, int lane,
-                                                   Sink&& sink, const f32x4* init = nullptr) {
-    dense_blocks_f16x3_mid<KB, NOB, ACT, FENCE, INIT>(in, w, bias, lane, sink, [] {}, init);
 }
 
 // first layer for xyz inputs (K = 3 padded to 4): B operand of lane (n,g) is coordinate g of row n (0 for g = 3).

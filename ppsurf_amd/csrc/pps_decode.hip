@@ -284,9 +284,6 @@ __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restr
 #ifndef IH_OB
 #define IH_OB 2                // output blocks per streamed weight chunk: 2 = 32 KiB chunks (18 barriers per pass), 4 = 64 KiB chunks (9)
 #endif
-#ifndef IH_DEFER
-#define IH_DEFER 1             // 1: activation + split of a chunk's result issued under the first MFMAs of the next chunk (see the kernel)
-#endif
 #define IH_NW (IH_NT / 64)
 #define IH_WG_PER_CU (512 / IH_NT)
 #define IH_CH4 (CH4 * IH_OB / 2)
@@ -346,32 +343,6 @@ __global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float
             for (int kb = 0; kb < 8; ++kb) x[kb] = split_f16(a[2 * kb], a[2 * kb + 1]);
         }
         __builtin_amdgcn_s_setprio(PPS_PRIO);
-#if IH_DEFER && IH_OB == 2
-        // The activation + hi/lo split of a chunk's result (~40 VALU instructions per wave) is DEFERRED into the next chunk of the same layer: it
-        // issues right after that chunk's first six MFMAs, under their shadow, instead of behind the last MFMA of its own chunk where both waves of
-        // a SIMD (phase-locked by the chunk barrier) would run it with the matrix pipe idle.  Only the last chunk of a layer finishes its own.
-        {
-            f32x4 p0, p1;
-#pragma unroll
-            for (int c = 0; c < 8; ++c)                                // fc2: chunk c holds output blocks 2c, 2c+1 = k-block c of fc3
-                stream_step<IH_CH4, IH_NT>(wg + (c + 1) * IH_CH4, cur, nxt, [&](const f32x4* w) {
-                    f32x4 q0, q1;
-                    dense_blocks_f16x3_mid<8, 2, 1>(x, (const half8*)w, bias4 + 8 * c, lane, [&](int, const f32x4& o0, const f32x4& o1) { q0 = o0; q1 = o1; },
-                                                    [&] { if (c > 0) y[c - 1] = split_f16(p0, p1); });
-                    p0 = q0; p1 = q1;
-                });
-            y[7] = split_f16(p0, p1);
-#pragma unroll
-            for (int c = 0; c < 8; ++c)                                // fc3
-                stream_step<IH_CH4, IH_NT>(wg + (c + 9) * IH_CH4, cur, nxt, [&](const f32x4* w) {
-                    f32x4 q0, q1;
-                    dense_blocks_f16x3_mid<8, 2, 1>(y, (const half8*)w, bias4 + 64 + 8 * c, lane, [&](int, const f32x4& o0, const f32x4& o1) { q0 = o0; q1 = o1; },
-                                                    [&] { if (c > 0) x[c - 1] = split_f16(p0, p1); });
-                    p0 = q0; p1 = q1;
-                });
-            x[7] = split_f16(p0, p1);
-        }
-#else
 #pragma unroll
         for (int c = 0; c < 16 / IH_OB; ++c)                           // fc2: output blocks IH_OB c .. = k-blocks IH_OB/2 c .. of fc3
             stream_step<IH_CH4, IH_NT>(wg + (c + 1) * IH_CH4, cur, nxt, [&](const f32x4* w) {
@@ -384,7 +355,6 @@ __global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float
                 dense_blocks_f16x3<8, IH_OB, 1>(y, (const half8*)w, bias4 + 64 + 4 * IH_OB * c, lane,
                                                 [&](int p, const f32x4& o0, const f32x4& o1) { x[IH_OB / 2 * c + p] = split_f16(o0, o1); });
             });
-#endif
         f32x4 b[4];
 #pragma unroll
         for (int c = 0; c < 4 / IH_OB; ++c)                            // fc_query: 64 heads
