@@ -77,6 +77,12 @@ int pps_knn_blocked_batch_f32(int nkinds, int64_t nclouds, const float* const* p
 int pps_voxel_sample_max_points(void);
 int pps_voxel_sample_f32(const float* pts, int64_t n, int64_t target, float vox, const float* rots, int nrot, uint32_t seed,
                          const uint32_t* priority, int64_t* out_ids, int32_t* out_rounds, void* stream);
+/* The same for clouds of ANY size (n > pps_voxel_sample_max_points(): fit with manifold_points above 10240, whole clouds): hash table, state bytes
+ * and compaction counts in a caller workspace `ws` (8-byte aligned, >= pps_voxel_sample_large_ws_bytes(n) bytes) instead of LDS; one workgroup,
+ * identical selections. */
+size_t pps_voxel_sample_large_ws_bytes(int64_t n);
+int pps_voxel_sample_large_f32(const float* pts, int64_t n, int64_t target, float vox, const float* rots, int nrot, uint32_t seed,
+                               const uint32_t* priority, int64_t* out_ids, int32_t* out_rounds, void* ws, size_t ws_bytes, void* stream);
 /* The same for a batch of b equally sized clouds pts [b,n,3] in ONE launch (one workgroup per cloud; default voxel edge;
  * rots [b,nrot,3,9]; priority [b,n] or NULL; cloud i uses seed + i * 0x9e3779b9): out_ids int64 [b,target], out_rounds int32 [b] or NULL. */
 int pps_voxel_sample_batch_f32(const float* pts, int64_t b, int64_t n, int64_t target, const float* rots, int nrot, uint32_t seed,

@@ -23,6 +23,8 @@ SIGNATURES = {
     'pps_knn_blocked_batch_f32': (_I, [_I, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pps_voxel_sample_max_points': (_I, []),
     'pps_voxel_sample_f32': (_I, [_P, _I64, _I64, _c.c_float, _P, _I, _c.c_uint32, _P, _P, _P, _P]),
+    'pps_voxel_sample_large_ws_bytes': (_SZ, [_I64]),
+    'pps_voxel_sample_large_f32': (_I, [_P, _I64, _I64, _c.c_float, _P, _I, _c.c_uint32, _P, _P, _P, _P, _SZ, _P]),
     'pps_voxel_sample_batch_f32': (_I, [_P, _I64, _I64, _I64, _P, _I, _c.c_uint32, _P, _P, _P, _P]),
     'pps_patch_normalize_f32': (_I, [_P, _P, _P, _I64, _I64, _I, _P, _P]),
     'pps_dilate_box_u8': (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _P]),

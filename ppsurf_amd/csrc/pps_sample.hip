@@ -208,6 +208,142 @@ __global__ __launch_bounds__(VS_NT) void voxel_sample_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The same procedure for clouds beyond the LDS tables of voxel_sample_kernel (n > VS_MAXN: `pps.py fit` with manifold_points above 10240,
+// whole clouds): the voxel hash table (key + representative in two arrays: the representative no longer has to fit beside the key in one
+// 64-bit word), the state bytes and the compaction counts live in a caller workspace in global memory (L2-resident: 250 000 points need 7 MB).
+// Still ONE workgroup per cloud -- the rounds are sequential and every step is a barrier-separated pass over the points, so the kernel is
+// latency-bound (a few milliseconds at 250 000 points); it exists so that no cloud size leaves the device for the torch-op loop.
+// Selections are identical to voxel_sample_kernel / the oracle given the same rotations and priorities (tests/test_gpu_sampling.py).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(VS_NT) void voxel_sample_big_kernel(const float* __restrict__ pts, int n, int target, float vox,
+                                                                 const float* __restrict__ rots, int nrot, unsigned seed,
+                                                                 const unsigned* __restrict__ prio, int64_t* __restrict__ out_ids,
+                                                                 int* __restrict__ out_rounds, vs_u64* __restrict__ tkey, int* __restrict__ trep,
+                                                                 unsigned table_mask, unsigned char* __restrict__ state, int* __restrict__ offs) {
+    __shared__ int red_i[VS_NT / 64 + 1];
+    __shared__ float red_f[VS_NT / 64 + 1];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += VS_NT) state[i] = 1;
+    __syncthreads();
+    if (!(vox > 0.f)) {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {INFINITY, INFINITY, INFINITY};
+        for (int i = tid; i < n; i += VS_NT)
+            for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], pts[3 * i + c]); hi[c] = fminf(hi[c], -pts[3 * i + c]); }
+        float e[3];
+        for (int c = 0; c < 3; ++c) e[c] = __fsub_rn(-block_min_float(hi[c], red_f), block_min_float(lo[c], red_f));
+        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(e[0], e[0]), __fmul_rn(e[1], e[1])), __fmul_rn(e[2], e[2]));
+        vox = __fdiv_rn(__fsqrt_rn(d2), __fsqrt_rn((float)target));
+    }
+    int count = 0, rounds = 0;
+    bool done = false;
+    for (int r = 0; r < nrot && !done; ++r, ++rounds) {
+        const float* R = rots + r * 27;
+        float mx = INFINITY, my = INFINITY, mz = INFINITY;
+        for (int i = tid; i < n; i += VS_NT)
+            if (state[i] & 1) {
+                float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+                vs_rotate3(R, x, y, z);
+                mx = fminf(mx, x); my = fminf(my, y); mz = fminf(mz, z);
+            }
+        mx = block_min_float(mx, red_f); my = block_min_float(my, red_f); mz = block_min_float(mz, red_f);
+        for (unsigned s = tid; s <= table_mask; s += VS_NT) { tkey[s] = VS_EMPTY64; trep[s] = -1; }
+        __threadfence_block();
+        __syncthreads();
+        for (int i = tid; i < n; i += VS_NT)
+            if (state[i] & 1) {
+                float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+                vs_rotate3(R, x, y, z);
+                const int cx = min(VS_CELL_MAX, (int)__fdiv_rn(__fsub_rn(x, mx), vox));
+                const int cy = min(VS_CELL_MAX, (int)__fdiv_rn(__fsub_rn(y, my), vox));
+                const int cz = min(VS_CELL_MAX, (int)__fdiv_rn(__fsub_rn(z, mz), vox));
+                const vs_u64 key = (vs_u64)cx | ((vs_u64)cy << 16) | ((vs_u64)cz << 32);
+                unsigned slot = vs_hash((unsigned)key ^ vs_hash((unsigned)(key >> 24))) & table_mask;
+                for (;;) {
+                    vs_u64 old = atomicCAS(&tkey[slot], VS_EMPTY64, key);       // claim an empty slot or find the voxel's slot
+                    if (old == VS_EMPTY64 || old == key) { atomicMax(&trep[slot], i); break; }     // the LARGEST index represents the voxel
+                    slot = (slot + 1) & table_mask;
+                }
+            }
+        __threadfence_block();
+        __syncthreads();
+        int mine_n = 0;
+        for (unsigned s = tid; s <= table_mask; s += VS_NT)
+            if (tkey[s] != VS_EMPTY64) { state[trep[s]] |= 2; ++mine_n; }       // distinct slots hold distinct representatives: no write conflicts
+        const int nrep = block_sum_int(mine_n, red_i);
+        if (count + nrep < target) {
+            for (int i = tid; i < n; i += VS_NT)
+                if (state[i] & 2) state[i] = 4;
+            count += nrep;
+            vox *= 0.5f;
+            __syncthreads();
+        } else {
+            const int need = target - count;
+#define VS_PRIO(i) (prio ? prio[i] : vs_hash(seed ^ (unsigned)((i) * 2654435761u)))
+            unsigned lo = 0u, hi = 0xffffffffu;
+            while (lo < hi) {
+                const unsigned mid = lo + ((hi - lo) >> 1);
+                int c = 0;
+                for (int i = tid; i < n; i += VS_NT)
+                    if ((state[i] & 2) && VS_PRIO(i) <= mid) ++c;
+                c = block_sum_int(c, red_i);
+                if (c >= need) hi = mid; else lo = mid + 1;
+            }
+            int below = 0;
+            for (int i = tid; i < n; i += VS_NT)
+                if ((state[i] & 2) && VS_PRIO(i) < lo) ++below;
+            below = block_sum_int(below, red_i);
+            __shared__ int tie_left;
+            if (tid == 0) tie_left = need - below;
+            __syncthreads();
+            for (int i = tid; i < n; i += VS_NT)
+                if (state[i] & 2) {
+                    const unsigned h = VS_PRIO(i);
+                    if (h < lo) state[i] = 4;
+                    else if (h > lo) state[i] &= 1;
+                }
+            __syncthreads();
+            if (tid == 0)
+                for (int i = 0; i < n; ++i)
+                    if ((state[i] & 2) && !(state[i] & 4)) {
+                        if (tie_left > 0) { state[i] = 4; --tie_left; } else state[i] &= 1;
+                    }
+            __syncthreads();
+#undef VS_PRIO
+            count = target;
+            done = true;
+        }
+    }
+    __shared__ int fill_left;
+    if (tid == 0) fill_left = target - count;
+    __syncthreads();
+    if (!done)
+        for (int i = tid; i < n; i += VS_NT)
+            if ((state[i] & 1) && atomicSub(&fill_left, 1) > 0) state[i] = 4;
+    __syncthreads();
+    const int per = (n + VS_NT - 1) / VS_NT, b0 = min(n, tid * per), b1 = min(n, b0 + per);
+    int c = 0;
+    for (int i = b0; i < b1; ++i) c += (state[i] & 4) ? 1 : 0;
+    offs[tid + 1] = c;
+    if (tid == 0) offs[0] = 0;
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0)
+        for (int i = 1; i <= VS_NT; ++i) offs[i] += offs[i - 1];
+    __threadfence_block();
+    __syncthreads();
+    int o = offs[tid];
+    for (int i = b0; i < b1; ++i)
+        if (state[i] & 4) { if (o < target) out_ids[o] = i; ++o; }
+    if (tid == 0 && out_rounds) *out_rounds = rounds;
+}
+
+static unsigned vs_big_slots(int64_t n) {
+    unsigned s = 1u << 14;
+    while ((int64_t)s < 2 * n) s <<= 1;                 // load factor <= 0.5
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // batched exhaustive kNN (same selection code as knn_kernel of pps_knn.hip, one wave per 8 queries of some table)
 // ---------------------------------------------------------------------------------------------------------------
 #define KM_MAX_TASKS 64
@@ -337,6 +473,26 @@ int pps_voxel_sample_f32(const float* pts, int64_t n, int64_t target, float vox,
     if (!pts || !rots || !out_ids || n < 2 || n > VS_MAXN || target < 1 || target >= n || nrot < 1) return PPS_ERR_ARG;
     hipLaunchKernelGGL(voxel_sample_kernel, dim3(1), dim3(VS_NT), 0, (hipStream_t)stream, pts, (int)n, (int)target, vox, rots, nrot, seed,
                        priority, out_ids, out_rounds);
+    return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+size_t pps_voxel_sample_large_ws_bytes(int64_t n) {
+    if (n < 2) return 0;
+    const size_t slots = vs_big_slots(n);
+    return slots * 8 + slots * 4 + (((size_t)n + 15) & ~(size_t)15) + (VS_NT + 1 + 3) * 4;
+}
+
+int pps_voxel_sample_large_f32(const float* pts, int64_t n, int64_t target, float vox, const float* rots, int nrot, uint32_t seed,
+                               const uint32_t* priority, int64_t* out_ids, int32_t* out_rounds, void* ws, size_t ws_bytes, void* stream) {
+    if (!pts || !rots || !out_ids || !ws || n < 2 || n > 0x3fffffff || target < 1 || target >= n || nrot < 1) return PPS_ERR_ARG;
+    if (ws_bytes < pps_voxel_sample_large_ws_bytes(n) || ((uintptr_t)ws & 7) != 0) return PPS_ERR_ARG;
+    const size_t slots = vs_big_slots(n);
+    vs_u64* tkey = (vs_u64*)ws;
+    int* trep = (int*)(tkey + slots);
+    unsigned char* state = (unsigned char*)(trep + slots);
+    int* offs = (int*)(state + (((size_t)n + 15) & ~(size_t)15));
+    hipLaunchKernelGGL(voxel_sample_big_kernel, dim3(1), dim3(VS_NT), 0, (hipStream_t)stream, pts, (int)n, (int)target, vox, rots, nrot, seed, priority,
+                       out_ids, out_rounds, tkey, trep, (unsigned)(slots - 1), state, offs);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 

@@ -88,9 +88,19 @@ def voxel_sample_point_major(pts_pm: torch.Tensor, target: int, rotations: torch
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
     pr = _prio(priority, pts_pm.device)
     out = torch.empty((target,), dtype=torch.int64, device=pts_pm.device)
-    _lib.check(_lib.lib().pps_voxel_sample_f32(pts_pm.data_ptr(), n, int(target), ctypes.c_float(-1.0), rot.data_ptr(), rot.shape[0],
-                                               ctypes.c_uint32(seed & 0xffffffff), pr.data_ptr() if pr is not None else None, out.data_ptr(), None,
-                                               torch.cuda.current_stream(pts_pm.device).cuda_stream), 'pps_voxel_sample_f32')
+    L = _lib.lib()
+    st = torch.cuda.current_stream(pts_pm.device).cuda_stream
+    if n > L.pps_voxel_sample_max_points():
+        # beyond the LDS tables of the one-launch kernel: the same procedure with its tables in a device workspace (any cloud size stays on the GPU)
+        nbytes = L.pps_voxel_sample_large_ws_bytes(n)
+        ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=pts_pm.device)
+        _lib.check(L.pps_voxel_sample_large_f32(pts_pm.data_ptr(), n, int(target), ctypes.c_float(-1.0), rot.data_ptr(), rot.shape[0],
+                                                ctypes.c_uint32(seed & 0xffffffff), pr.data_ptr() if pr is not None else None, out.data_ptr(), None,
+                                                ws.data_ptr(), nbytes, st), 'pps_voxel_sample_large_f32')
+        return out
+    _lib.check(L.pps_voxel_sample_f32(pts_pm.data_ptr(), n, int(target), ctypes.c_float(-1.0), rot.data_ptr(), rot.shape[0],
+                                      ctypes.c_uint32(seed & 0xffffffff), pr.data_ptr() if pr is not None else None, out.data_ptr(), None, st),
+               'pps_voxel_sample_f32')
     return out
 
 
@@ -110,8 +120,8 @@ def sampling_quantized(pts_batch, ratio=None, n_support=None, support_points=Non
     """Voxel-stratified random sub-sampling to exactly max(1, int(N*ratio)) points (poco_data_loader.py:59-134):
     voxel edge = bbox diagonal / sqrt(n), three random axis rotations, one point per occupied voxel, remove, halve, repeat;
     the last round is truncated at random.  Stochastic (python `random`, torch RNG) like the reference.
-    GPU clouds of up to pps_voxel_sample_max_points() points go through the HIP kernel (ids ascending); anything else through
-    the torch-op loop below, which on CPU tensors consumes `random` / the torch generator exactly like the reference and
+    GPU clouds go through the HIP kernels (ids ascending; one launch with LDS tables up to pps_voxel_sample_max_points() points, the
+    workspace variant beyond); CPU tensors (host-logic tests) through the torch-op loop below, which consumes `random` / the torch generator exactly like the reference and
     returns its ids in its order (tests/test_driver_parity_cpu.py against tests/golden/sampling.npz).
     Test hooks shared by both paths: `_rotations` [R,3,3,3]; `_priority` integer [N] (< 2^32): the last round keeps the
     representatives with the smallest priority instead of drawing a permutation."""
@@ -125,7 +135,7 @@ def sampling_quantized(pts_batch, ratio=None, n_support=None, support_points=Non
         return pts_batch, ids
     if not 0 < target < n:
         raise ValueError('Search Quantized - ratio value error {} should be in ]0,1]'.format(ratio))
-    if pts_batch.is_cuda and 2 <= n <= _lib.lib().pps_voxel_sample_max_points():
+    if pts_batch.is_cuda and n >= 2:                 # every cloud size on the device (LDS kernel up to 10240 points, workspace kernel beyond)
         ids = torch.stack([voxel_sample_point_major(_point_major(pts_batch[i]), target, _rotations, priority=_priority) for i in range(b)], dim=0)
         return torch.gather(pts_batch, 2, ids.unsqueeze(1).expand(b, 3, target)), ids
     extent = pts_batch.max(dim=2)[0] - pts_batch.min(dim=2)[0]

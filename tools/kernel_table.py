@@ -4,7 +4,7 @@ import sys
 
 ORDER = ['interp_pool_kernel', 'interp_pool_f16x3_kernel', 'pointnet_feat_rows_kernel<false>', 'pointnet_feat_rows_kernel<true>',
          'pointnet_stn_rows_kernel<false>', 'pointnet_stn_rows_kernel<true>', 'pointnet_stn_fc_kernel', 'pointnet_stn_fc_h_kernel',
-         'pointnet_feat_rows_kernel', 'pointnet_stn_rows_kernel', 'knn_blocked_kernel<1>', 'decode_tail_kernel', 'patch_normalize_kernel',
+         'pointnet_feat_rows_kernel', 'pointnet_stn_rows_kernel', 'knn_blocked_kernel<1>', 'decode_tail_kernel', 'decode_tail_h_kernel', 'patch_normalize_kernel',
          'rows_dense256_kernel']
 
 
