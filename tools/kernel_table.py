@@ -10,6 +10,8 @@ ORDER = ['interp_pool_kernel', 'interp_pool_f16x3_kernel', 'pointnet_feat_rows_k
 
 def main(prefix):
     k = json.load(open(prefix + '_pmc.json'))['kernels']
+    # a kernel whose name the profiler did not demangle (half8 arguments) is listed under its mangled name
+    k = dict(k, **{'pointnet_stn_fc_h_kernel': v for n, v in k.items() if 'pointnet_stn_fc_h_kernel' in n})
     import os
     tag = os.path.basename(prefix)
     lines = ['# Per-kernel HBM traffic and MFMA utilisation ({}, one MI355X)'.format(tag), '',
