@@ -161,8 +161,10 @@ class TrainDataset(ReconstructionDataset):
         return {'pts_ms': pts, 'normals_ms': normals, 'pts_query_ms': q, 'imp_surf_dist_ms': dist_, 'pts_raw_ms': raw,
                 'pc_file_in': data['pc_file_in'], 'shape_id': i}
 
-    def collate_on_device(self, items, device):
-        """default_collate + the per-shape work of the reference's __getitem__ (patches, get_data_poco), on the device."""
+    def collate_on_device(self, items, device, extras=True):
+        """default_collate + the per-shape work of the reference's __getitem__ (patches, get_data_poco), on the device.
+        extras: also the flat ids + CSR of the id tables that the BACKWARD pass of a training step uses (14 sorts) -- validation batches go through
+        the fused inference path and never read them."""
         batch = {k: torch.from_numpy(np.stack([it[k] for it in items])).to(device, non_blocking=True)
                  for k in ('pts_ms', 'normals_ms', 'pts_query_ms', 'imp_surf_dist_ms')}
         batch['shape_id'] = torch.tensor([it['shape_id'] for it in items], device=device)
@@ -172,9 +174,10 @@ class TrainDataset(ReconstructionDataset):
             batch['pts_local_ps'], batch['pts_local_ms'] = spatial.get_pts_local_ps_batch(raws, batch['pts_query_ms'], self.num_pts_local,
                                                                                           return_ms=True)
         batch = spatial.get_data_poco(batch)
-        from . import train_graph
-        with torch.no_grad():
-            batch.update(train_graph.table_extras(batch))       # flat ids + CSR of the id tables: built with the batch, not inside backward
+        if extras:
+            from . import train_graph
+            with torch.no_grad():
+                batch.update(train_graph.table_extras(batch))   # flat ids + CSR of the id tables: built with the batch, not inside backward
         return batch
 
 
@@ -276,6 +279,7 @@ class DeviceBatchLoader:
     def __init__(self, dataset, batch_size, shuffle, device, rank=0, world_size=1):
         self.dataset, self.batch_size, self.shuffle, self.device = dataset, int(batch_size), shuffle, device
         self.rank, self.world_size, self.epoch = rank, world_size, 0
+        self.table_extras = True                # build the backward pass's CSR tables with the batch (PocoDataModule switches it off for validation)
 
     def set_epoch(self, epoch):
         self.epoch = int(epoch)
@@ -309,13 +313,18 @@ class DeviceBatchLoader:
         import os
         dev = torch.device(self.device)
         prefetch = DevicePrefetch(dev) if (dev.type == 'cuda' and os.environ.get('PPS_PREP_STREAM', '1') != '0') else None
+        if not starts:                                   # a rank without batches (fewer shapes than ranks)
+            return
+        thread_build = prefetch is not None and getattr(self, 'thread_collate', True)
         with concurrent.futures.ThreadPoolExecutor(max_workers=1) as pool:
-            nxt = pool.submit(load, starts[0]) if starts else None
+            # the plain file read of the first batch is submitted only by the branches that consume it: the loader-thread branch below reads
+            # inside its own build job (a second read of batch 0 would also advance the dataset's random stream twice)
+            nxt = None if thread_build else pool.submit(load, starts[0])
             if prefetch is None:
                 for k, s in enumerate(starts):
                     items = nxt.result()
                     nxt = pool.submit(load, starts[k + 1]) if k + 1 < len(starts) else None
-                    yield self.dataset.collate_on_device(items, self.device)
+                    yield self.dataset.collate_on_device(items, self.device, self.table_extras)
                 return
             # the loader thread also issues the device side of its batch (patches, support levels, id tables, their CSR) -- on a second stream,
             # so that it runs beside the optimisation step of the previous batch and its ~10 ms of host work are off the training thread.  The
@@ -331,11 +340,10 @@ class DeviceBatchLoader:
                     if k + 2 < len(starts):
                         futs[k + 2] = pool.submit(load, starts[k + 2])
                     cur, nxt_f = futs.pop(k), futs.get(k + 1)
-                    yield prefetch.take(lambda: self.dataset.collate_on_device(cur.result(), self.device),
-                                        (lambda f=nxt_f: self.dataset.collate_on_device(f.result(), self.device)) if nxt_f is not None else None)
+                    yield prefetch.take(lambda: self.dataset.collate_on_device(cur.result(), self.device, self.table_extras),
+                                        (lambda f=nxt_f: self.dataset.collate_on_device(f.result(), self.device, self.table_extras)) if nxt_f is not None else None)
                 return
-            nxt.cancel()
-            build = lambda s: prefetch.launch(lambda: self.dataset.collate_on_device(load(s), self.device), after_main=False)
+            build = lambda s: prefetch.launch(lambda: self.dataset.collate_on_device(load(s), self.device, self.table_extras), after_main=False)
             futs = {k: pool.submit(build, starts[k]) for k in range(min(2, len(starts)))}
             for k, s in enumerate(starts):
                 batch, ev = futs.pop(k).result()
@@ -372,7 +380,9 @@ class PocoDataModule:
         ddp = bool(self.use_ddp) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         ds = TrainDataset(set_file, self.padding_factor, self.seed, self.use_ddp, self.manifold_points, self.patches_per_shape, augment,
                           self.num_pts_local)
-        return DeviceBatchLoader(ds, self.batch_size, shuffle, self.device, dist.get_rank() if ddp else 0, dist.get_world_size() if ddp else 1)
+        loader = DeviceBatchLoader(ds, self.batch_size, shuffle, self.device, dist.get_rank() if ddp else 0, dist.get_world_size() if ddp else 1)
+        loader.table_extras = bool(augment or shuffle)          # the training loader; validation batches need no backward-pass tables
+        return loader
 
     def train_dataloader(self):
         return self._fit_loader(self.trainset, self.do_data_augmentation, True)

@@ -56,9 +56,10 @@ class GraphedStep:
     (it is: metrics are device tensors, id tables are inputs, the optimizer is fused + capturable)."""
     WARMUP = 3
 
-    def __init__(self, eager, metrics, enabled=True, max_graphs=2, after_capture=None, after_replay=None):
+    def __init__(self, eager, metrics, enabled=True, max_graphs=2, after_capture=None, after_replay=None, on_capture_failed=None):
         self.eager, self.metrics, self.enabled, self.max_graphs = eager, metrics, enabled, max_graphs
         self.after_capture, self.after_replay = after_capture, after_replay      # host-side state a replay cannot reproduce (hooks that fired)
+        self.on_capture_failed = on_capture_failed      # puts host-side state a half-recorded step left behind (loss scaler stage, gradient buckets) back
         self.seen, self.graphs, self.failed, self._done = {}, {}, False, None
         self.replayed = False
 
@@ -80,7 +81,12 @@ class GraphedStep:
 
     @staticmethod
     def signature(batch):
-        return tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in batch.items() if torch.is_tensor(v)))
+        """What a recorded step is valid for: names, shapes and types of the tensors, and the VALUES of scalar entries (a number / string / bool a
+        step may branch on is baked into its graph).  List entries (`pc_file_in`: file names, different for every batch) are neither part of the
+        signature nor handed to the recorded step -- a step that read them would fail at capture time instead of silently replaying stale ones."""
+        sig = [(k, tuple(v.shape), str(v.dtype)) for k, v in batch.items() if torch.is_tensor(v)]
+        sig += [(k, 'value', repr(v)) for k, v in batch.items() if isinstance(v, (int, float, bool, str)) and not k.startswith('_')]
+        return tuple(sorted(sig))
 
     def run(self, batch, bi):
         """Executes the step (eagerly, or by replaying the captured graph) and leaves the logged values in self.metrics.values."""
@@ -119,7 +125,8 @@ class GraphedStep:
 
     def _capture(self, batch, bi):
         static = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
-        rest = {k: v for k, v in batch.items() if not torch.is_tensor(v) and not k.startswith('_')}      # '_...' entries are caches of device tensors
+        # scalar entries are part of the signature and may be read; lists (file names) and '_...' caches of device tensors are withheld
+        rest = {k: v for k, v in batch.items() if isinstance(v, (int, float, bool, str)) and not k.startswith('_')}
         graph = torch.cuda.CUDAGraph()
         try:
             torch.cuda.synchronize()
@@ -133,6 +140,8 @@ class GraphedStep:
                 traceback.print_exc()
             print('fit: HIP-graph capture of the step failed ({}: {}); continuing eagerly'.format(type(exc).__name__, str(exc).split('\n')[0]))
             torch.cuda.synchronize()
+            if self.on_capture_failed is not None:
+                self.on_capture_failed()                        # the eager re-run of this step starts from clean host-side state
             return None
         return static, graph, logged, (self.after_capture() if self.after_capture is not None else None)
 
@@ -243,6 +252,14 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
         if mfile is not None:
             mfile.write(json.dumps(rec) + '\n')
 
+    def reset_host_state():
+        """After a capture that failed part-way: the loss scaler may be left in its 'unscaled' / 'stepped' stage for this optimizer and the gradient
+        buckets half filled; the step is re-run eagerly right after, from a clean slate."""
+        buckets.zero()
+        per_opt = getattr(scaler, '_per_optimizer_states', None)
+        if per_opt is not None:
+            per_opt.clear()
+
     def eager_step(batch, bi):
         sharding.broadcast_buffers(model)
         compute_step(batch, bi)
@@ -265,7 +282,8 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
     if split_graph:
         # several ranks: the gradient all-reduces (and the buffer broadcast) stay ordinary eager collectives AROUND a replayed forward +
         # backward; they lose their overlap with the backward pass (~1 ms for 55 MB over xGMI) and the rank its ~25 ms of Python per step
-        core = GraphedStep(compute_step, metrics, enabled=True, after_capture=lambda: set(buckets.touched), after_replay=buckets.replayed)
+        core = GraphedStep(compute_step, metrics, enabled=True, after_capture=lambda: set(buckets.touched), after_replay=buckets.replayed,
+                           on_capture_failed=reset_host_state)
 
         class _Split:
             graphs, failed = core.graphs, False
@@ -280,7 +298,7 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
             touch = staticmethod(core.touch)
         stepper = _Split
     else:
-        stepper = GraphedStep(eager_step, metrics, enabled=use_graph)
+        stepper = GraphedStep(eager_step, metrics, enabled=use_graph, on_capture_failed=reset_host_state)
     for epoch in range(start_epoch, max_epochs):
         host_lr = float(optimizer.param_groups[0]['lr'])        # once per epoch (the scheduler steps per epoch): no per-step read of a device value
         model.train()

@@ -200,13 +200,20 @@ class GradBuckets:
         self.handles = []
         self.launched = [False] * len(self.buckets)
         self.touched = set()
+        self._replay = False
+        self._next = 0                              # first bucket whose collective has not been issued yet
 
     def _hook(self, bi):
         def fn(p):
             self.touched.add(id(p))
             self.pending[bi] -= 1
             if self.pending[bi] == 0:
-                self._launch(bi)
+                # collectives are issued in bucket order 0, 1, 2 on EVERY rank, whatever the order in which a rank's buckets fill up (a rank
+                # that misses a gradient of bucket 0 must not start with bucket 1 while the others start with bucket 0): a complete bucket
+                # waits for its predecessors, finish() issues what is left, in order
+                while self._next < len(self.buckets) and self.pending[self._next] == 0:
+                    self._launch(self._next)
+                    self._next += 1
         return fn
 
     def _launch(self, bi):
@@ -226,6 +233,7 @@ class GradBuckets:
         self.touched = set(touched)
         self.launched = [True] * len(self.buckets)
         self.handles = []
+        self._replay = True                         # the set was fixed at capture time, identically on every rank (same graph everywhere)
 
     def zero(self):
         """Replaces optimizer.zero_grad(): flat buffers cleared (slots of parameters without a gradient stay zero), every p.grad None."""
@@ -247,6 +255,19 @@ class GradBuckets:
         if ws > 1:
             for flat in self.flat:
                 flat.div_(ws)
+        touched = self.touched
+        if ws > 1 and not self._replay:
+            # the decision "this parameter got a gradient" must be the same on every rank, or some replicas would step the parameter (averaged
+            # gradient, weight decay, step count) and others skip it: one tiny MAX all-reduce of a per-parameter mask per step.  A
+            # parameter touched on ANY rank keeps its averaged gradient everywhere (ranks that did not touch it contributed zeros).
+            mask = torch.tensor([1 if id(p) in touched else 0 for p in self.params], dtype=torch.int32, device=self.flat[0].device)
+            self.dist.all_reduce(mask, op=self.dist.ReduceOp.MAX)
+            keep = mask.cpu().numpy() > 0
+            touched = {id(p) for p, k in zip(self.params, keep) if k}
+            for views, bucket in zip(self.views, self.buckets):
+                for v, p in zip(views, bucket):
+                    if id(p) in touched and p.grad is None:
+                        p.grad = v                   # touched elsewhere only: the averaged gradient sits in this rank's bucket slot
         for p in self.params:                       # like plain autograd: no gradient -> the optimizer skips the parameter
-            if id(p) not in self.touched:           # (AdamW would otherwise still apply weight decay to it)
+            if id(p) not in touched:                # (AdamW would otherwise still apply weight decay to it)
                 p.grad = None

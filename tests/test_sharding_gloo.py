@@ -87,6 +87,19 @@ def _grad_worker(rank, world, port, out_dir):
         out['g{}'.format(step)] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy().copy()
         out['unused_none{}'.format(step)] = np.array([p.grad is None for p in unused.parameters()])
         opt.step()
+    # a parameter that only SOME ranks touch: every rank must keep the same averaged gradient for it, none may skip it
+    half = torch.nn.Linear(6, 2)
+    with torch.no_grad():
+        half.weight.fill_(0.5); half.bias.fill_(0.1)
+    b2 = GradBuckets(list(net.parameters()) + list(half.parameters()), n_buckets=2)
+    b2.zero()
+    loss = torch.nn.functional.cross_entropy(net(x[:4]), y[:4])
+    if rank == 0:
+        loss = loss + half(x[:4]).pow(2).sum()
+    loss.backward()
+    b2.finish()
+    out['half_none'] = np.array([p.grad is None for p in half.parameters()])
+    out['half_g'] = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in half.parameters()]).numpy().copy()
     out['w'] = torch.cat([p.detach().reshape(-1) for p in params]).numpy()
     np.savez(os.path.join(out_dir, 'g{}.npz'.format(rank)), **out)
     dist.destroy_process_group()
@@ -109,6 +122,13 @@ def test_two_rank_gradient_buckets_equal_full_batch_gradients(tmp_path):
     np.testing.assert_allclose(r0['g0'], full, rtol=1e-5, atol=1e-7)
     assert np.array_equal(r0['g0'], r1['g0']) and np.array_equal(r0['g1'], r1['g1']) and np.array_equal(r0['w'], r1['w'])
     assert r0['unused_none0'].all() and r0['unused_none1'].all()
+    # touched on rank 0 only: kept on BOTH ranks with the same averaged value (rank 0's gradient / 2)
+    assert not r0['half_none'].any() and not r1['half_none'].any() and np.array_equal(r0['half_g'], r1['half_g']) and np.abs(r0['half_g']).max() > 0
+    half = torch.nn.Linear(6, 2)
+    with torch.no_grad():
+        half.weight.fill_(0.5); half.bias.fill_(0.1)
+    half(x[:4]).pow(2).sum().backward()
+    np.testing.assert_allclose(r0['half_g'], torch.cat([p.grad.reshape(-1) for p in half.parameters()]).numpy() / 2, rtol=1e-6, atol=1e-7)
     assert np.array_equal(r0['w'][-w_unused0.size:], w_unused0)              # untouched by AdamW's weight decay
 
 
