@@ -940,18 +940,20 @@ __device__ __forceinline__ void feat_chain(float coord, const float* __restrict_
         s += __shfl_xor(s, 32);
         on_logit(s + s0);
     }
-    static_assert(PN_C3OB == 2, "conv3 is streamed two output blocks per chunk");
+    static_assert(PN_C3OB % 2 == 0, "conv3 is streamed in pairs of output blocks");
 #pragma unroll
     for (int c = 0; c < PN_C3N - 1; ++c)
         stream_step<PCH4, PNT>(wg + 4096 + (c + 1) * PCH4, cur, nxt, [&](const f32x4* w) {
-            f32x4 zz[2];
-            dense_blocks<8, 2, 0>(y, zz, w, bias4 + 80 + 8 * c, lane);
-            on_block(2 * c, zz[0], zz[1]);
+            f32x4 zz[PN_C3OB];
+            dense_blocks<8, PN_C3OB, 0>(y, zz, w, bias4 + 80 + 4 * PN_C3OB * c, lane);
+#pragma unroll
+            for (int i = 0; i < PN_C3OB; i += 2) on_block(PN_C3OB * c + i, zz[i], zz[i + 1]);
         });
     stream_step<1024, PNT>(wg, cur, nxt, [&](const f32x4* w) {
-        f32x4 zz[2];
-        dense_blocks<8, 2, 0>(y, zz, w, bias4 + 80 + 8 * (PN_C3N - 1), lane);
-        on_block(2 * (PN_C3N - 1), zz[0], zz[1]);
+        f32x4 zz[PN_C3OB];
+        dense_blocks<8, PN_C3OB, 0>(y, zz, w, bias4 + 80 + 4 * PN_C3OB * (PN_C3N - 1), lane);
+#pragma unroll
+        for (int i = 0; i < PN_C3OB; i += 2) on_block(PN_C3OB * (PN_C3N - 1) + i, zz[i], zz[i + 1]);
     });
     __builtin_amdgcn_s_setprio(0);
 }
@@ -1025,11 +1027,11 @@ __device__ __forceinline__ void feat_chain_h(float coord, const float* __restric
 #pragma unroll
     for (int c = 0; c < PN_C3N - 1; ++c)
         stream_step<PCH4, PNT>(wg + 4096 + (c + 1) * PCH4, cur, nxt, [&](const f32x4* w) {
-            dense_blocks_f16x3<4, 2, 0>(y, (const half8*)w, bias4 + 80 + 8 * c, lane,
-                                        [&](int, const f32x4& o0, const f32x4& o1) { on_block(2 * c, o0, o1); }); });
+            dense_blocks_f16x3<4, PN_C3OB, 0>(y, (const half8*)w, bias4 + 80 + 4 * PN_C3OB * c, lane,
+                                              [&](int i, const f32x4& o0, const f32x4& o1) { on_block(PN_C3OB * c + 2 * i, o0, o1); }); });
     stream_step<1024, PNT>(wg, cur, nxt, [&](const f32x4* w) {
-        dense_blocks_f16x3<4, 2, 0>(y, (const half8*)w, bias4 + 80 + 8 * (PN_C3N - 1), lane,
-                                    [&](int, const f32x4& o0, const f32x4& o1) { on_block(2 * (PN_C3N - 1), o0, o1); }); });
+        dense_blocks_f16x3<4, PN_C3OB, 0>(y, (const half8*)w, bias4 + 80 + 4 * PN_C3OB * (PN_C3N - 1), lane,
+                                          [&](int i, const f32x4& o0, const f32x4& o1) { on_block(PN_C3OB * (PN_C3N - 1) + 2 * i, o0, o1); }); });
     __builtin_amdgcn_s_setprio(0);
 }
 
