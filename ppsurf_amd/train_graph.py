@@ -529,36 +529,15 @@ def _point_major(t):
     return t.transpose(1, 2) if t.shape[1] == 3 and t.shape[2] != 3 else t
 
 
-_side_streams = {}
-
-
-def _branch_stream(device):
-    """A second HIP stream per device for the PointNet branch of a training step (PPS_FIT_STREAMS=0 switches it off)."""
-    import os
-    if device.type != 'cuda' or os.environ.get('PPS_FIT_STREAMS', '1') == '0':
-        return None
-    s = _side_streams.get(device.index)
-    if s is None:
-        s = _side_streams[device.index] = torch.cuda.Stream(device=device)
-    return s
-
-
-def _pointnet_branch(net, data):
-    pl = data['pts_local_ps']
-    b, q = pl.shape[0], pl.shape[1]
-    return pointnet(net.point_net, pl.reshape(b * q, pl.shape[2], 3), need_trans=False)[0]
-
-
 @_counted
-def ppsurf_from_latent(net, latents, data, proj_ids, feat_pn=None):
-    """latents [B,N,C] point-major; data{pts, pts_query, pts_local_ps [B,Q,P,3]}; proj_ids [B,Q,k] -> logits [B,2,Q].
-    feat_pn: the PointNet branch's output if the caller already started it (ppsurf_forward, on a second stream)."""
+def ppsurf_from_latent(net, latents, data, proj_ids):
+    """latents [B,N,C] point-major; data{pts, pts_query, pts_local_ps [B,Q,P,3]}; proj_ids [B,Q,k] -> logits [B,2,Q]."""
     pts = _point_major(data['pts']).contiguous()
     query = _point_major(data['pts_query']).contiguous()
     b, q = query.shape[0], query.shape[1]
     feat_proj = interp_attention(net.projection, latents, pts, query, proj_ids)
-    if feat_pn is None:
-        feat_pn = _pointnet_branch(net, data)
+    pl = data['pts_local_ps']
+    feat_pn, _ = pointnet(net.point_net, pl.reshape(b * q, pl.shape[2], 3), need_trans=False)
     out = mlp(net.mlp, feat_proj.reshape(b * q, -1) + feat_pn)
     return out.view(b, q, -1).transpose(1, 2)
 
@@ -573,25 +552,8 @@ def _prepare(net, data):
 
 @_counted
 def ppsurf_forward(net, data, proj_ids):
-    """One forward pass in train().  The PointNet branch depends on the patches only, the encoder + interpolation head on the cloud only; they
-    meet in the MLP.  On the GPU the PointNet branch is issued on a SECOND STREAM before the encoder: its few large bandwidth-bound kernels
-    (1 M patch rows) then run beside the encoder's ~600 short latency-bound launches (10 k ... 390 rows per level) instead of in front of
-    them, and autograd runs each branch's backward on the stream of its forward, so the backward passes overlap the same way.  Both streams
-    are forked from and joined into the calling stream, so the step is still captured / replayed as one HIP graph."""
     _prepare(net, data)
-    dev = data['pts'].device
-    side = _branch_stream(dev) if (net.training and torch.is_grad_enabled()) else None
-    feat_pn = None
-    if side is not None:
-        main = torch.cuda.current_stream(dev)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            feat_pn = _pointnet_branch(net, data)
-    latents = encoder(net.encoder, data)
-    if side is not None:
-        main.wait_stream(side)
-        feat_pn.record_stream(main)               # allocated on the side stream, consumed (and possibly freed) on the main one
-    return ppsurf_from_latent(net, latents, data, proj_ids, feat_pn)
+    return ppsurf_from_latent(net, encoder(net.encoder, data), data, proj_ids)
 
 
 @_counted
