@@ -158,7 +158,10 @@ def check_marching_cubes(verts, faces, volume, level=0.0, atol=1e-9, require_clo
             for dz in (0, 1):
                 big &= np.isfinite(vol[ci[:, 0] + dx, ci[:, 1] + dy, ci[:, 2] + dz])
     fin = np.nan_to_num(vol, nan=level)
-    d = _trilinear(fin, cen + 0.05 * nn) - _trilinear(fin, cen - 0.05 * nn)
+    # probe step: 0.05 voxel, but never more than a fraction of the face's own size (a one-voxel blob whose value barely crosses the level is an
+    # octahedron of 1e-3 voxel: a fixed step would probe the far side of it)
+    eps = np.minimum(0.05, 0.2 * np.sqrt(area))[:, None]
+    d = _trilinear(fin, cen + eps * nn) - _trilinear(fin, cen - eps * nn)
     wrong = big & (d > 1e-12)
     assert wrong.sum() <= 0.05 * max(1, big.sum()), '{} of {} faces are oriented towards HIGHER values'.format(int(wrong.sum()), int(big.sum()))
     if wrong.any():
