@@ -98,6 +98,20 @@ def _grad_worker(rank, world, port, out_dir):
         loss = loss + half(x[:4]).pow(2).sum()
     loss.backward()
     b2.finish()
+    # buckets summed over the ranks in bfloat16 (PPS_GRAD_BUCKET_DTYPE=bf16): half the bytes on the wire, fp32 buffers for the optimizer
+    import copy
+    net3 = copy.deepcopy(net)                                        # its own parameters: the hooks of the bucket sets above stay out of it
+    b3 = GradBuckets(list(net3.parameters()), n_buckets=2, comm_dtype=torch.bfloat16)
+    b3.zero()
+    torch.nn.functional.cross_entropy(net3(x[lo:hi]), y[lo:hi]).backward()
+    b3.finish()
+    out['g_bf16'] = torch.cat([p.grad.reshape(-1) for p in net3.parameters()]).numpy().copy()
+    net4 = copy.deepcopy(net)
+    b4 = GradBuckets(list(net4.parameters()), n_buckets=2)
+    b4.zero()
+    torch.nn.functional.cross_entropy(net4(x[lo:hi]), y[lo:hi]).backward()
+    b4.finish()
+    out['g_f32'] = torch.cat([p.grad.reshape(-1) for p in net4.parameters()]).numpy().copy()
     out['half_none'] = np.array([p.grad is None for p in half.parameters()])
     out['half_g'] = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in half.parameters()]).numpy().copy()
     out['w'] = torch.cat([p.detach().reshape(-1) for p in params]).numpy()
@@ -122,6 +136,10 @@ def test_two_rank_gradient_buckets_equal_full_batch_gradients(tmp_path):
     np.testing.assert_allclose(r0['g0'], full, rtol=1e-5, atol=1e-7)
     assert np.array_equal(r0['g0'], r1['g0']) and np.array_equal(r0['g1'], r1['g1']) and np.array_equal(r0['w'], r1['w'])
     assert r0['unused_none0'].all() and r0['unused_none1'].all()
+    assert np.array_equal(r0['g_bf16'], r1['g_bf16'])                       # identical replicas ...
+    # ... and the fp32 buckets of the same weights to bfloat16 precision (each rank's bucket is rounded once, the sum once more)
+    assert r0['g_bf16'].dtype == np.float32 and np.abs(r0['g_bf16'] - r0['g_f32']).max() <= 2.0 ** -7 * np.abs(r0['g_f32']).max()
+    assert not np.array_equal(r0['g_bf16'], r0['g_f32'])
     # touched on rank 0 only: kept on BOTH ranks with the same averaged value (rank 0's gradient / 2)
     assert not r0['half_none'].any() and not r1['half_none'].any() and np.array_equal(r0['half_g'], r1['half_g']) and np.abs(r0['half_g']).max() > 0
     half = torch.nn.Linear(6, 2)
