@@ -166,20 +166,18 @@ class GradBuckets:
     messages: a ring all-reduce over xGMI is per-link bound (~153 GB/s), so 55 MB of fp32 gradients cost ~1 ms as 3 buckets
     and far more as 455 per-tensor collectives."""
 
-    def __init__(self, params, n_buckets=3, defer=False, overlap_events=None, comm_dtype=None):
-        """defer: no collective inside backward (fit with the forward / backward replayed as a HIP graph; hooks do not fire in a replay).
-        overlap_events (default: environment PPS_FIT_OVERLAP=1; needs defer): the moment a bucket is complete is marked with an EXTERNAL event
-            -- recorded by the hook in an eager backward, an event-record node inside the captured graph -- and finish() issues the bucket's
-            all-reduce on a communication stream that waits for that event only: bucket 0 (the decoder's gradients) travels while the rest of
-            the replayed backward still runs, which `defer` alone gives up.  Opt-in until it has run on real multi-GPU RCCL.
+    def __init__(self, params, n_buckets=3, defer=False, comm_dtype=None):
+        """defer: no collective inside backward (fit with the forward / backward replayed as a HIP graph; hooks do not fire in a replay): all
+            buckets are all-reduced behind the replay.  Starting bucket 0's collective while the replayed backward still produces buckets 1, 2
+            would need an event recorded INSIDE the graph that another stream can wait on (an "external" event); torch-ROCm 2.10 refuses those
+            ("External events are disallowed in rocm", tried in round 3), and RCCL collectives captured into the graph cannot be exercised on
+            the single-GPU boxes available here -- so the deferred collectives stay serial behind the step (~1 ms for 55 MB over xGMI).
         comm_dtype (default: environment PPS_GRAD_BUCKET_DTYPE, e.g. 'bf16'): the buckets are summed over the ranks in this type (half the xGMI
             bytes, 27.5 instead of 55 MB per step); the flat fp32 buffers the optimizer reads stay fp32."""
         import os
         import torch.distributed as dist
         self.dist = dist
         self.defer = bool(defer)                    # True: no collective inside backward (fit with the forward / backward replayed as a HIP graph)
-        if overlap_events is None:
-            overlap_events = os.environ.get('PPS_FIT_OVERLAP', '0') == '1'
         if comm_dtype is None:
             comm_dtype = {'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16, 'f16': torch.float16, '': None, 'f32': None}[os.environ.get('PPS_GRAD_BUCKET_DTYPE', '')]
         self.comm_dtype = comm_dtype
@@ -206,10 +204,6 @@ class GradBuckets:
                 p.register_post_accumulate_grad_hook(self._hook(bi))
             self.flat.append(flat)
             self.views.append(views)
-        dev = self.flat[0].device
-        self.overlap = bool(overlap_events) and self.defer and dev.type == 'cuda'
-        self.ready = [torch.cuda.Event(external=True) for _ in self.buckets] if self.overlap else None
-        self.comm = torch.cuda.Stream(device=dev) if self.overlap else None
         self.low = [torch.empty_like(f, dtype=comm_dtype) for f in self.flat] if comm_dtype is not None else None
         self._reset()
 
@@ -242,8 +236,6 @@ class GradBuckets:
             torch._foreach_copy_([v for v, _ in pairs], [p.grad for _, p in pairs])
             for v, p in pairs:
                 p.grad = v
-        if self.overlap:
-            self.ready[bi].record()                 # eager backward: a plain record; under capture: an event-record node of the graph
         if ws > 1 and not self.defer:
             self.handles.append(self._all_reduce(bi))
 
@@ -285,20 +277,7 @@ class GradBuckets:
             if not self.launched[bi]:
                 self._launch(bi)
         if ws > 1 and self.defer:                   # collectives kept out of a captured forward / backward: all buckets now
-            if self.overlap:
-                # on the communication stream, each behind its bucket's own event: the collective of bucket 0 starts while the (replayed)
-                # backward pass is still producing buckets 1, 2 on the main stream
-                main = torch.cuda.current_stream(self.flat[0].device)
-                with torch.cuda.stream(self.comm):
-                    for bi in range(len(self.buckets)):
-                        self.comm.wait_event(self.ready[bi])
-                        self.handles.append(self._all_reduce(bi))
-                    for h in self.handles:
-                        h.wait()
-                self.handles = []
-                main.wait_stream(self.comm)
-            else:
-                self.handles = [self._all_reduce(bi) for bi in range(len(self.buckets))]
+            self.handles = [self._all_reduce(bi) for bi in range(len(self.buckets))]
         for h in self.handles:
             h.wait()
         if ws > 1:
