@@ -200,9 +200,11 @@ __device__ __forceinline__ void join_f16(const HiLo& x, f32x4& y0, f32x4& y1) {
 // stores) then overlaps the MFMAs of the next pair instead of running alone.
 // INIT = true: the main accumulators start from init[ob] (fp32 blocks of an earlier partial product over other input channels) instead of
 // the bias -- a layer whose input is the concatenation of two tensors is evaluated half by half.
-template <int KB, int NOB, int ACT, bool FENCE = true, bool INIT = false, class Sink>
-__device__ __forceinline__ void dense_blocks_f16x3(const HiLo (&in)[KB], const half8* __restrict__ w, const f32x4* __restrict__ bias, int lane,
-                                                   Sink&& sink, const f32x4* init = nullptr) {
+// `hook(ob, kb)` is called after the six MFMAs of every k-step have been issued: the place to issue ONE piece of the next weight chunk's copy
+// (see stream_step_spread in pps_decode.hip) -- the wave's own MFMAs are queued in the matrix pipe while the memory pipeline accepts the piece.
+template <int KB, int NOB, int ACT, bool FENCE = true, bool INIT = false, class Sink, class Hook>
+__device__ __forceinline__ void dense_blocks_f16x3_hook(const HiLo (&in)[KB], const half8* __restrict__ w, const f32x4* __restrict__ bias, int lane,
+                                                        Sink&& sink, Hook&& hook, const f32x4* init = nullptr) {
     static_assert(NOB % 2 == 0, "output blocks are processed in pairs");
     const int g = lane >> 4;
 #pragma unroll
@@ -241,6 +243,7 @@ __device__ __forceinline__ void dense_blocks_f16x3(const HiLo (&in)[KB], const h
             c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, in[kb].lo, c1, 0, 0, 0);
             c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, in[kb].hi, c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, in[kb].hi, c1, 0, 0, 0);
+            hook(ob, kb);
             if (FENCE) {
                 __builtin_amdgcn_sched_group_barrier(PPS_SG_DSREAD, 4, 0);
                 __builtin_amdgcn_sched_group_barrier(PPS_SG_MFMA, 6, 0);
@@ -254,6 +257,11 @@ __device__ __forceinline__ void dense_blocks_f16x3(const HiLo (&in)[KB], const h
         }
         sink(ob >> 1, o0, o1);
     }
+}
+template <int KB, int NOB, int ACT, bool FENCE = true, bool INIT = false, class Sink>
+__device__ __forceinline__ void dense_blocks_f16x3(const HiLo (&in)[KB], const half8* __restrict__ w, const f32x4* __restrict__ bias, int lane,
+                                                   Sink&& sink, const f32x4* init = nullptr) {
+    dense_blocks_f16x3_hook<KB, NOB, ACT, FENCE, INIT>(in, w, bias, lane, sink, [](int, int) {}, init);
 }
 
 // first layer for xyz inputs (K = 3 padded to 4): B operand of lane (n,g) is coordinate g of row n (0 for g = 3).
@@ -305,6 +313,17 @@ __device__ __forceinline__ void chunk_copy_async(const f32x4* __restrict__ src, 
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(sbase + (size_t)(i * NTHREADS * 16) + lane_off), (lds_ptr_t)(uintptr_t)d, 16, 0, 0);
 #endif
     }
+}
+// one 1 KiB-per-wave piece (index i of NF4) of the same copy: lets a caller spread the pieces of a chunk over its compute phase
+template <int NTHREADS>
+__device__ __forceinline__ void chunk_copy_piece(const f32x4* __restrict__ src, f32x4* dst, int i) {
+    unsigned lane_off = threadIdx.x * 16u;
+    asm volatile("" : "+v"(lane_off));
+    const int wave_base = threadIdx.x & ~63;
+    const char* piece = (const char*)src + (size_t)i * (NTHREADS * 16);
+    asm volatile("" : "+s"(piece));
+    const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(dst + i * NTHREADS + wave_base));
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_addr), "v"(lane_off), "s"(piece) : "memory", "m0");
 }
 // all outstanding pieces of this wave have landed in LDS (call before the barrier that hands the chunk to the other waves)
 __device__ __forceinline__ void stream_wait() {

@@ -33,19 +33,62 @@ using namespace pps;
 // One pipeline step: request the NEXT chunk, compute on the CURRENT one, publish the next, barrier.
 // PPS_ABL_* macros are ablation switches for tools/ablate_interp.sh (never defined in the product build)
 // CHUNK_F4_NEXT: size of the next chunk in f32x4; NTH: threads of the workgroup (all of them copy)
+#ifdef PPS_TRACE
+// development aid (tools/trace_interp16.py): where one wave's cycles of a pipeline step go -- issue of the next chunk's copy | compute on the current
+// chunk | wait for the own copies | barrier -- summed over all steps of wave 0 of workgroup 0; [4] counts the steps.  Never in the product build.
+__device__ unsigned long long pps_trace_acc[8];
+#define PPS_TRACE_T(i) const unsigned long long pps_t##i = __builtin_readcyclecounter()
+#define PPS_TRACE_ADD(slot, a, b) do { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pps_trace_acc[slot], pps_t##b - pps_t##a); } while (0)
+#else
+#define PPS_TRACE_T(i)
+#define PPS_TRACE_ADD(slot, a, b)
+#endif
+
 template <int CHUNK_F4_NEXT, int NTH = NT, class F>
 __device__ __forceinline__ void stream_step(const f32x4* __restrict__ gnext, f32x4*& cur, f32x4*& nxt, F&& compute) {
+    PPS_TRACE_T(0);
 #ifndef PPS_ABL_NOSTREAM
     chunk_copy_async<CHUNK_F4_NEXT / NTH, NTH>(gnext, nxt);
 #endif
+    PPS_TRACE_T(1);
     compute((const f32x4*)cur);
+    PPS_TRACE_T(2);
 #ifndef PPS_ABL_NOBARRIER
     stream_wait();
+    PPS_TRACE_T(3);
     __syncthreads();
+    PPS_TRACE_T(4);
+    PPS_TRACE_ADD(0, 0, 1); PPS_TRACE_ADD(1, 1, 2); PPS_TRACE_ADD(2, 2, 3); PPS_TRACE_ADD(3, 3, 4);
+#ifdef PPS_TRACE
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pps_trace_acc[4], 1ull);
+#endif
 #endif
 #ifndef PPS_ABL_NOSTREAM
     f32x4* t = cur; cur = nxt; nxt = t;
 #endif
+}
+
+// The same pipeline step with the copy of the next chunk SPREAD over the compute phase: `compute(w, piece)` calls piece(i), i = 0 .. NPIECES-1, at
+// points of its own choosing (dense_blocks_f16x3_hook: after the MFMAs of a k-step).  Issued in one burst at the head of the step, the pieces of all
+// waves of a workgroup queue up in the CU's memory pipeline (32 KiB at 64 B/clk = 512 cycles per chunk) while every wave sits in the issue and the
+// matrix pipe is idle -- a cycle trace of the split-precision interpolation kernel (tools/trace_interp16.py) showed 12 % of a step in the issue and
+// 20 % in the barrier behind it; spread out, a piece is accepted while the wave's own queued MFMAs execute.
+template <int CHUNK_F4_NEXT, int NTH = NT, class F>
+__device__ __forceinline__ void stream_step_spread(const f32x4* __restrict__ gnext, f32x4*& cur, f32x4*& nxt, F&& compute) {
+    PPS_TRACE_T(0);
+    PPS_TRACE_T(1);
+    f32x4* dst = nxt;
+    compute((const f32x4*)cur, [&](int i) { if (i < CHUNK_F4_NEXT / NTH) chunk_copy_piece<NTH>(gnext, dst, i); });
+    PPS_TRACE_T(2);
+    stream_wait();
+    PPS_TRACE_T(3);
+    __syncthreads();
+    PPS_TRACE_T(4);
+    PPS_TRACE_ADD(0, 0, 1); PPS_TRACE_ADD(1, 1, 2); PPS_TRACE_ADD(2, 2, 3); PPS_TRACE_ADD(3, 3, 4);
+#ifdef PPS_TRACE
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pps_trace_acc[4], 1ull);
+#endif
+    f32x4* t = cur; cur = nxt; nxt = t;
 }
 
 template <int CHUNK_F4, int NTH = NT>
@@ -284,6 +327,9 @@ __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restr
 #ifndef IH_OB
 #define IH_OB 2                // output blocks per streamed weight chunk: 2 = 32 KiB chunks (18 barriers per pass), 4 = 64 KiB chunks (9)
 #endif
+#ifndef IH_SPREAD
+#define IH_SPREAD 1            // 1: the next chunk's copy is issued piece by piece between the k-steps (stream_step_spread), 0: in one burst
+#endif
 #define IH_NW (IH_NT / 64)
 #define IH_WG_PER_CU (512 / IH_NT)
 #define IH_CH4 (CH4 * IH_OB / 2)
@@ -343,25 +389,28 @@ __global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float
             for (int kb = 0; kb < 8; ++kb) x[kb] = split_f16(a[2 * kb], a[2 * kb + 1]);
         }
         __builtin_amdgcn_s_setprio(PPS_PRIO);
+#if IH_SPREAD
+        // the 4 (8-wave workgroup) pieces of the next chunk's copy go out after k-steps 0, 2, 4, 6 of the first output-block pair
+#define IH_STEP(GNEXT, IN, BIAS, ACTV, SINK)                                                                                          \
+        stream_step_spread<IH_CH4, IH_NT>(GNEXT, cur, nxt, [&](const f32x4* w, auto&& piece) {                                         \
+            dense_blocks_f16x3_hook<8, IH_OB, ACTV>(IN, (const half8*)w, BIAS, lane, SINK,                                             \
+                                                    [&](int ob, int kb) { if (ob == 0 && (kb & 1) == 0) piece(kb >> 1); if (IH_CH4 / IH_NT > 4 && ob == 0 && (kb & 1)) piece(4 + (kb >> 1)); }); })
+#else
+#define IH_STEP(GNEXT, IN, BIAS, ACTV, SINK)                                                                                          \
+        stream_step<IH_CH4, IH_NT>(GNEXT, cur, nxt, [&](const f32x4* w) { dense_blocks_f16x3<8, IH_OB, ACTV>(IN, (const half8*)w, BIAS, lane, SINK); })
+#endif
 #pragma unroll
         for (int c = 0; c < 16 / IH_OB; ++c)                           // fc2: output blocks IH_OB c .. = k-blocks IH_OB/2 c .. of fc3
-            stream_step<IH_CH4, IH_NT>(wg + (c + 1) * IH_CH4, cur, nxt, [&](const f32x4* w) {
-                dense_blocks_f16x3<8, IH_OB, 1>(x, (const half8*)w, bias4 + 4 * IH_OB * c, lane,
-                                                [&](int p, const f32x4& o0, const f32x4& o1) { y[IH_OB / 2 * c + p] = split_f16(o0, o1); });
-            });
+            IH_STEP(wg + (c + 1) * IH_CH4, x, bias4 + 4 * IH_OB * c, 1, ([&](int p, const f32x4& o0, const f32x4& o1) { y[IH_OB / 2 * c + p] = split_f16(o0, o1); }));
 #pragma unroll
         for (int c = 0; c < 16 / IH_OB; ++c)                           // fc3
-            stream_step<IH_CH4, IH_NT>(wg + (c + 16 / IH_OB + 1) * IH_CH4, cur, nxt, [&](const f32x4* w) {
-                dense_blocks_f16x3<8, IH_OB, 1>(y, (const half8*)w, bias4 + 64 + 4 * IH_OB * c, lane,
-                                                [&](int p, const f32x4& o0, const f32x4& o1) { x[IH_OB / 2 * c + p] = split_f16(o0, o1); });
-            });
+            IH_STEP(wg + (c + 16 / IH_OB + 1) * IH_CH4, y, bias4 + 64 + 4 * IH_OB * c, 1, ([&](int p, const f32x4& o0, const f32x4& o1) { x[IH_OB / 2 * c + p] = split_f16(o0, o1); }));
         f32x4 b[4];
 #pragma unroll
         for (int c = 0; c < 4 / IH_OB; ++c)                            // fc_query: 64 heads
-            stream_step<IH_CH4, IH_NT>(wg + ((c + 32 / IH_OB + 1) % IH_NCH) * IH_CH4, cur, nxt, [&](const f32x4* w) {
-                dense_blocks_f16x3<8, IH_OB, 0>(x, (const half8*)w, bias4 + 128 + 4 * IH_OB * c, lane,
-                                                [&](int p, const f32x4& o0, const f32x4& o1) { b[IH_OB * c + 2 * p] = o0; b[IH_OB * c + 2 * p + 1] = o1; });
-            });
+            IH_STEP(wg + ((c + 32 / IH_OB + 1) % IH_NCH) * IH_CH4, x, bias4 + 128 + 4 * IH_OB * c, 0,
+                    ([&](int p, const f32x4& o0, const f32x4& o1) { b[IH_OB * c + 2 * p] = o0; b[IH_OB * c + 2 * p + 1] = o1; }));
+#undef IH_STEP
         __builtin_amdgcn_s_setprio(0);
 #ifdef PPS_ABL_IH_NOSOFTMAX
         {   // everything the MFMA phase produced stays live (static register indices only), nothing else is done with it
@@ -1362,6 +1411,14 @@ int pps_debug_occupancy(int which) {
     return n;
 }
 int pps_device_cu_count(void) { return cu_count(); }
+#ifdef PPS_TRACE
+// development aid: read (and clear) the cycle sums of PPS_TRACE builds
+int pps_debug_trace_read(unsigned long long* host8) {
+    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(pps_trace_acc), 64) != hipSuccess) return 1;
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(pps_trace_acc), z, 64) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int pps_rows_dense256_f32(const float* in, int64_t rs, int64_t cs, int64_t m, const float* wpack, const float* bias,
                           float* out, void* stream) {

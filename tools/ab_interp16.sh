@@ -5,7 +5,7 @@
 #             were measured in round 3: 2.74 and 2.67 ms against 2.65 -- neither the barrier count nor the phase lock is what bounds the kernel)
 #   *nosm     softmax + pooling ablated, *nosmg: and the gather -> what the MFMA phase alone costs
 # build here (CPU container):  tools/ab_interp16.sh build        run on the GPU box:  tools/ab_interp16.sh
-VARIANTS="pn512:-DPNT=512,-DPCH4=2048"
+VARIANTS="burst:-DIH_SPREAD=0"
 if [ "$1" = build ]; then
   for v in $VARIANTS; do name=${v%%:*}; flags=${v#*:}; python -m ppsurf_amd.build --variant $name ${flags//,/ } > /dev/null || exit 1; echo built $name; done
   exit 0
