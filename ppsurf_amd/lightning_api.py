@@ -286,13 +286,14 @@ class PocoModel(_Base):
         """Latent loop of poco_model.py:203-236 for one cloud.  pts_cf [3,N] on the device -> latents POINT-MAJOR [N,C]:
         coverage-balanced random subsets of gen_subsample_manifold points until every point has been encoded
         gen_subsample_manifold_iter times; latents are averaged.  Parity with the reference's loop (same torch seed -> same
-        subsets, counts and latents, for `latent_batch` 1 and 10): tests/test_driver_parity_cpu.py against
+        subsets, counts and latents, for `latent_batch` 1, 3 and 10): tests/test_driver_parity_cpu.py against
         tests/golden/latent_loop.npz.
 
-        Which points a pass covers depends only on the coverage COUNTS, never on latents, so up to `latent_batch` (default 10)
-        consecutive subsets are drawn exactly like the reference draws them one after the other and then encoded as ONE batch
-        (batched sampling / kNN tables / FKAConv geometry and aggregation kernels, MFMA GEMMs with the folded BatchNorm over the
-        rows of all subsets at once): a 10k-point pass alone cannot fill 256 CUs.
+        Which points a pass covers depends only on the coverage COUNTS, never on latents, so up to `latent_batch` (default 25)
+        consecutive subsets -- across the boundaries of the coverage rounds -- are drawn exactly like the reference draws them one
+        after the other and then encoded as ONE batch (batched sampling / kNN tables / FKAConv geometry and aggregation kernels,
+        MFMA GEMMs with the folded BatchNorm over the rows of all subsets at once): a 10k-point pass alone cannot fill 256 CUs
+        (tools/time_latent_batch.py: 106 / 93 / 89 / 91 ms per 100k-point cloud at 10 / 20 / 25 / 100 subsets per batch).
 
         With torch.distributed initialised and `shard_queries` set, the subsets of a batch are dealt round-robin to the ranks
         (the selection comes from a generator seeded identically on every rank) and the partial sums / counts are all-reduced
@@ -309,45 +310,44 @@ class PocoModel(_Base):
             gen = torch.Generator(device='cpu')
             gen.manual_seed(int(n) * 1000003 + 12345)
         encode = encode_subsets if encode_subsets is not None else self._encode_subsets
-        batch = max(1, int(getattr(self, 'latent_batch', 10)))
+        batch = max(1, int(getattr(self, 'latent_batch', 25)))
         # 'reference': subsets follow torch's CPU generator like the reference (same seed -> same subsets; the parity tests);
         # 'device' (default on a GPU): the permutation is drawn where the counts live
         device_rng = getattr(self, 'latent_rng', 'device') == 'device' and dev.type == 'cuda'
         if world > 1:
             batch = -(-batch // world) * world                               # whole waves: every rank encodes batch / world subsets
         iteration = 0
-        for current_value in range(self.gen_subsample_manifold_iter):
-            round_done = False
-            while not round_done:
-                covered, subsets = counts.clone() if batch > 1 else counts, []
-                while len(subsets) < batch:
-                    ids = self._draw_subset(covered, current_value, m, gen, device_rng)
-                    if ids is None:
-                        round_done = True
-                        break
-                    subsets.append(ids)
-                    if batch > 1:
-                        covered[ids] += 1                                    # what `counts[ids] += 1` will have done by the next draw
-                    else:
-                        break
-                if not subsets:
-                    break
-                mine = subsets[rank::world] if world > 1 else subsets
-                part, cnt = (torch.zeros_like(latent), torch.zeros_like(counts)) if world > 1 else (latent, counts)
-                if mine:
-                    lat_b = encode(pts_cf, mine)
-                    for i, ids in enumerate(mine):
-                        part[ids] += lat_b[i].float()                        # duplicate ids (top-up): one write wins, counted once, like the reference
-                        cnt[ids] += 1
-                if world > 1:
-                    sharding.allreduce_latents(part, cnt)
-                    latent += part
-                    counts += cnt
-                if trace is not None:
-                    trace.extend(subsets)
-                iteration += len(subsets)
-                if progress is not None:
-                    progress('get_latent iter: {}'.format(iteration))
+        current_value, n_rounds = 0, self.gen_subsample_manifold_iter
+        while current_value < n_rounds:
+            # the next `batch` subsets exactly as the reference's loop draws them one after the other: `covered` is what its `counts` will hold
+            # by each draw; when a round is complete (no point left at `current_value`) the drawing goes on in the next round with the same counts
+            covered, subsets = counts.clone() if batch > 1 else counts, []
+            while len(subsets) < batch and current_value < n_rounds:
+                ids = self._draw_subset(covered, current_value, m, gen, device_rng)
+                if ids is None:
+                    current_value += 1
+                    continue
+                subsets.append(ids)
+                if batch > 1:
+                    covered[ids] += 1                                        # what `counts[ids] += 1` will have done by the next draw
+            if not subsets:
+                break
+            mine = subsets[rank::world] if world > 1 else subsets
+            part, cnt = (torch.zeros_like(latent), torch.zeros_like(counts)) if world > 1 else (latent, counts)
+            if mine:
+                lat_b = encode(pts_cf, mine)
+                for i, ids in enumerate(mine):
+                    part[ids] += lat_b[i].float()                            # duplicate ids (top-up): one write wins, counted once, like the reference
+                    cnt[ids] += 1
+            if world > 1:
+                sharding.allreduce_latents(part, cnt)
+                latent += part
+                counts += cnt
+            if trace is not None:
+                trace.extend(subsets)
+            iteration += len(subsets)
+            if progress is not None:
+                progress('get_latent iter: {}'.format(iteration))
         return latent / counts.unsqueeze(1)
 
     @torch.no_grad()

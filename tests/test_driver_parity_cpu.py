@@ -65,7 +65,7 @@ def _model(n_latent, m, iters, batch):
     return model
 
 
-@pytest.mark.parametrize('batch', [1, 10, 3])
+@pytest.mark.parametrize('batch', [1, 10, 3, 25])
 @pytest.mark.parametrize('tag', ['topup', 'exact', 'small'])
 def test_latent_loop_equals_reference(tag, batch):
     """Same torch seed -> the same subsets in the same order, the same coverage counts and the same averaged latents as the

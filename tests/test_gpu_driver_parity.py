@@ -23,7 +23,7 @@ def _stub_latent(pts_cf, c=8):
     return torch.sin(freq * pts_cf[:, 0:1]) + torch.cos(freq * pts_cf[:, 1:2]) * pts_cf[:, 2:3] + centre.sum(dim=1, keepdim=True)
 
 
-@pytest.mark.parametrize('batch', [1, 10])
+@pytest.mark.parametrize('batch', [1, 3, 10, 25])
 @pytest.mark.parametrize('tag', ['exact', 'topup', 'small'])
 def test_latent_loop_on_the_device_follows_the_reference_stream(tag, batch):
     """latent_rng='reference' on the GPU: the subset permutations AND the top-up permutation (poco_model.py:217-219) come from torch's CPU

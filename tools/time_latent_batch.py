@@ -1,0 +1,34 @@
+"""Latent loop of one 100k-point cloud (100 encoder passes) against `latent_batch` -- the subsets drawn ahead and encoded together.  Prints wall time per
+shape, peak memory, and checks that the latents do not depend on the batching (reference subset stream: same seed -> same subsets).
+    python tools/time_latent_batch.py [N]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench_workloads as workloads
+from ppsurf_amd.synthetic import make_cloud
+
+DEV = 'cuda:0'
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+model = workloads.make_model(device=DEV)
+pts = torch.from_numpy(make_cloud(N, seed=42)).to(DEV).t().contiguous()
+ref = None
+for batch in (10, 20, 25, 50, 100):
+    model.latent_batch = batch
+    model.latent_rng = 'reference'
+    torch.manual_seed(5)
+    lat = model.encode_latents(pts)
+    if ref is None:
+        ref = lat
+    same = torch.equal(lat, ref)
+    err = float((lat - ref).abs().max())
+    model.latent_rng = 'device'
+    torch.cuda.reset_peak_memory_stats()
+    for _ in range(2):
+        model.encode_latents(pts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        model.encode_latents(pts)
+    torch.cuda.synchronize()
+    print('latent_batch {:3d}: {:6.1f} ms per shape, peak {:5.1f} GB, latents equal to batch 10: {} (max diff {:.2e})'.format(
+        batch, (time.perf_counter() - t0) / 3 * 1e3, torch.cuda.max_memory_allocated() / 1e9, same, err), flush=True)
