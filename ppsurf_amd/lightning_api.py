@@ -269,6 +269,28 @@ class PocoModel(_Base):
             ids = torch.cat([ids, top[:m - ids.shape[0]]], dim=0)
         return ids
 
+    @staticmethod
+    def _draw_round(covered, current_value, m, gen=None):
+        """ALL remaining subsets of coverage round `current_value` from ONE permutation: drawing m of the valid points, then m of the rest, ... is
+        a uniformly random permutation of the valid points cut into consecutive pieces of m (the last piece topped up like _draw_subset does).
+        Same distribution as pass-by-pass drawing with one nonzero() + one randperm() per ROUND instead of per pass (100 -> 10 host
+        synchronisations and permutations per 100k-point cloud); not the reference's random stream, so only for the device / shared-generator
+        streams.  [] when the round is complete."""
+        n, dev = covered.shape[0], covered.device
+        valid_ids = torch.nonzero(covered == current_value)[:, 0]
+        v = valid_ids.shape[0]
+        if v == 0:
+            return []
+        if n < m:
+            return [torch.arange(n, device=dev)]
+        perm = torch.randperm(v, device=dev) if gen is None else torch.randperm(v, generator=gen).to(dev)
+        out = list(torch.split(valid_ids[perm], m))
+        short = m - out[-1].shape[0]
+        if short > 0:
+            top = torch.randperm(n, device=dev) if gen is None else torch.randperm(n, generator=gen).to(dev)
+            out[-1] = torch.cat([out[-1], top[:short]], dim=0)
+        return out
+
     def _encode_subsets(self, pts_cf, subsets):
         """Latents of several equally sized subsets of one cloud in batched HIP launches: [B, m, C] point-major."""
         enc = self.network.encoder
@@ -318,15 +340,28 @@ class PocoModel(_Base):
             batch = -(-batch // world) * world                               # whole waves: every rank encodes batch / world subsets
         iteration = 0
         current_value, n_rounds = 0, self.gen_subsample_manifold_iter
+        # device / shared-generator streams: the subsets of a whole coverage round come from one permutation (_draw_round); the reference stream
+        # is followed draw by draw
+        per_round, pending = batch > 1 and (device_rng or gen is not None), []
+        if getattr(self, 'latent_per_round', None) is not None:                  # tests: force either form
+            per_round = bool(self.latent_per_round) and batch > 1
         while current_value < n_rounds:
             # the next `batch` subsets exactly as the reference's loop draws them one after the other: `covered` is what its `counts` will hold
             # by each draw; when a round is complete (no point left at `current_value`) the drawing goes on in the next round with the same counts
             covered, subsets = counts.clone() if batch > 1 else counts, []
             while len(subsets) < batch and current_value < n_rounds:
-                ids = self._draw_subset(covered, current_value, m, gen, device_rng)
-                if ids is None:
-                    current_value += 1
-                    continue
+                if per_round:
+                    if not pending:
+                        pending.extend(self._draw_round(covered, current_value, m, gen))
+                        if not pending:
+                            current_value += 1
+                            continue
+                    ids = pending.pop(0)
+                else:
+                    ids = self._draw_subset(covered, current_value, m, gen, device_rng)
+                    if ids is None:
+                        current_value += 1
+                        continue
                 subsets.append(ids)
                 if batch > 1:
                     covered[ids] += 1                                        # what `counts[ids] += 1` will have done by the next draw
