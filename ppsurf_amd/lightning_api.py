@@ -339,32 +339,44 @@ class PocoModel(_Base):
         if world > 1:
             batch = -(-batch // world) * world                               # whole waves: every rank encodes batch / world subsets
         iteration = 0
-        current_value, n_rounds = 0, self.gen_subsample_manifold_iter
+        n_rounds = self.gen_subsample_manifold_iter
         # device / shared-generator streams: the subsets of a whole coverage round come from one permutation (_draw_round); the reference stream
         # is followed draw by draw
-        per_round, pending = batch > 1 and (device_rng or gen is not None), []
+        per_round = batch > 1 and (device_rng or gen is not None)
         if getattr(self, 'latent_per_round', None) is not None:                  # tests: force either form
             per_round = bool(self.latent_per_round) and batch > 1
-        while current_value < n_rounds:
-            # the next `batch` subsets exactly as the reference's loop draws them one after the other: `covered` is what its `counts` will hold
-            # by each draw; when a round is complete (no point left at `current_value`) the drawing goes on in the next round with the same counts
-            covered, subsets = counts.clone() if batch > 1 else counts, []
-            while len(subsets) < batch and current_value < n_rounds:
+
+        def draw(covered, limit, state):
+            """Up to `limit` further subsets exactly as the reference's loop draws them one after the other; `covered` is what its `counts` will hold
+            by each draw (advanced here).  state = [current round, subsets of that round drawn ahead]."""
+            out = []
+            while len(out) < limit and state[0] < n_rounds:
                 if per_round:
-                    if not pending:
-                        pending.extend(self._draw_round(covered, current_value, m, gen))
-                        if not pending:
-                            current_value += 1
+                    if not state[1]:
+                        state[1].extend(self._draw_round(covered, state[0], m, gen))
+                        if not state[1]:
+                            state[0] += 1                                    # round complete: on with the next one, same counts
                             continue
-                    ids = pending.pop(0)
+                    ids = state[1].pop(0)
                 else:
-                    ids = self._draw_subset(covered, current_value, m, gen, device_rng)
+                    ids = self._draw_subset(covered, state[0], m, gen, device_rng)
                     if ids is None:
-                        current_value += 1
+                        state[0] += 1
                         continue
-                subsets.append(ids)
-                if batch > 1:
+                out.append(ids)
+                if covered is not counts:
                     covered[ids] += 1                                        # what `counts[ids] += 1` will have done by the next draw
+            return out
+
+        state = [0, []]
+        # batch > 1: EVERY subset is drawn before the first encoder pass.  Each draw synchronises with the device (nonzero: the number of valid
+        # points); interleaved with the batches that wait drains the queue once per round and leaves the GPU idle while the host refills it.
+        ahead = draw(counts.clone(), 1 << 30, state) if batch > 1 else None
+        while True:
+            if ahead is not None:
+                subsets, ahead = ahead[:batch], ahead[batch:]
+            else:
+                subsets = draw(counts, 1, state)                             # pass by pass: counts are up to date, nothing is simulated
             if not subsets:
                 break
             mine = subsets[rank::world] if world > 1 else subsets

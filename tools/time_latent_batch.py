@@ -12,7 +12,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 model = workloads.make_model(device=DEV)
 pts = torch.from_numpy(make_cloud(N, seed=42)).to(DEV).t().contiguous()
 ref = None
-for batch in (10, 20, 25, 50, 100):
+for batch in [int(b) for b in os.environ.get("BATCHES", "10,20,25,50,100").split(",")]:
     model.latent_batch = batch
     model.latent_rng = 'reference'
     torch.manual_seed(5)
