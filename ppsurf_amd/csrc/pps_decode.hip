@@ -1035,7 +1035,11 @@ __device__ __forceinline__ void feat_chain_h(float coord, const float* __restric
 #pragma unroll 1
     for (int qi = 0; qi < nq; ++qi) {
         const int64_t qq = (q0 + qi < Q) ? q0 + qi : Q - 1;
+#ifdef PPS_ABL_T0
+        const half8* tq = (const half8*)trans2 + (qq & 63) * 1024 + 4 * n + g;  // ablation: every query reads one of 64 cache-resident matrices
+#else
         const half8* tq = (const half8*)trans2 + qq * 1024 + 4 * n + g;       // slot 4 m + g of each 1 KiB fragment block
+#endif
         const bool mine = (n / rows_per_query) == qi;
         HiLo xm[2];
 #pragma unroll
