@@ -70,6 +70,36 @@ def test_default_device_rng_latent_loop_covers_every_point_equally():
     assert len(trace) == 12 and bool((counts == 3).all())
 
 
+@pytest.mark.parametrize('n', [4300, 2500, 700])
+def test_default_device_rng_latent_loop_with_top_up_and_small_clouds(n):
+    """The device stream when N is NOT a multiple of the subset size (the last subset of a round is topped up from all points, poco_model.py:217-229)
+    and when the cloud is smaller than a subset: subsets of the right size, every point covered at least gen_subsample_manifold_iter times, the
+    pieces of a round disjoint before the top-up -- for batches that span rounds."""
+    from ppsurf_amd.lightning_api import PocoModel
+    m, iters = 1000, 3
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = PocoModel(output_names=['x'], in_channels=3, out_channels=2, k=64, lambda_l1=0.0, debug=False, in_file='x.xyz', results_dir='/tmp/x',
+                          padding_factor=0.05, name='x', network_latent_size=8, gen_subsample_manifold_iter=iters, gen_subsample_manifold=m,
+                          gen_resolution_global=33, rec_batch_size=1000, gen_refine_iter=0, workers=0)
+    model.latent_batch = 4
+    cloud = torch.from_numpy(make_cloud(n, seed=3)).to(DEV)
+    trace = []
+    lat = model.encode_latents(cloud.t().contiguous(), trace=trace,
+                               encode_subsets=lambda p, subs: torch.stack([_stub_latent(p[:, i].unsqueeze(0), 8)[0].t() for i in subs]))
+    counts = torch.zeros(n, device=DEV)
+    for ids in trace:
+        assert ids.shape[0] == min(n, m)
+        counts[ids.unique()] += 1
+    assert float(counts.min()) >= iters and bool(torch.isfinite(lat).all())
+    if n >= m:
+        per_round = -(-n // m)
+        assert len(trace) <= iters * per_round                                                   # top-ups may finish a round early, never late
+        first = torch.cat(trace[:n // m])                                                        # the full pieces of round 0: disjoint valid points
+        assert first.unique().shape[0] == first.shape[0]
+    else:
+        assert len(trace) == iters and all(torch.equal(ids, torch.arange(n, device=DEV)) for ids in trace)
+
+
 def test_refinement_on_the_device_equals_the_reference():
     g = load_golden('refine')
 
