@@ -285,10 +285,12 @@ class PocoModel(_Base):
             return [torch.arange(n, device=dev)]
         perm = torch.randperm(v, device=dev) if gen is None else torch.randperm(v, generator=gen).to(dev)
         out = list(torch.split(valid_ids[perm], m))
+        for piece in out:
+            piece.pps_round = current_value               # full pieces of one round: no duplicate ids within or between them (encode_latents adds them at once)
         short = m - out[-1].shape[0]
         if short > 0:
             top = torch.randperm(n, device=dev) if gen is None else torch.randperm(n, generator=gen).to(dev)
-            out[-1] = torch.cat([out[-1], top[:short]], dim=0)
+            out[-1] = torch.cat([out[-1], top[:short]], dim=0)             # may repeat ids: a new, untagged tensor
         return out
 
     def _encode_subsets(self, pts_cf, subsets):
@@ -383,9 +385,17 @@ class PocoModel(_Base):
             part, cnt = (torch.zeros_like(latent), torch.zeros_like(counts)) if world > 1 else (latent, counts)
             if mine:
                 lat_b = encode(pts_cf, mine)
-                for i, ids in enumerate(mine):
-                    part[ids] += lat_b[i].float()                            # duplicate ids (top-up): one write wins, counted once, like the reference
+                i = 0
+                while i < len(mine):
+                    # consecutive full pieces of one coverage round share no id: one indexed add for all of them (the same single addition per
+                    # element as subset by subset); anything else -- reference stream, topped-up pieces -- on its own
+                    tag, j = getattr(mine[i], 'pps_round', None), i + 1
+                    while tag is not None and j < len(mine) and getattr(mine[j], 'pps_round', None) == tag:
+                        j += 1
+                    ids = mine[i] if j == i + 1 else torch.cat(mine[i:j])
+                    part[ids] += lat_b[i:j].reshape(ids.shape[0], -1).float()       # duplicate ids (top-up): one write wins, counted once, like the reference
                     cnt[ids] += 1
+                    i = j
             if world > 1:
                 sharding.allreduce_latents(part, cnt)
                 latent += part
