@@ -228,6 +228,17 @@ __device__ __forceinline__ void dense_blocks_f16x3_hook(const HiLo (&in)[KB], co
                 qh1 = w1[(kb + 2) * 128]; ql1 = w1[(kb + 2) * 128 + 64];
             }
 #else
+#ifdef PPS_ABL_NOLO
+        // ablation (wrong numbers): the lo fragments are not read from LDS -- what do half the fragment reads cost?  
+        half8 ph0 = w0[0], pl0 = ph0, ph1 = w1[0], pl1 = ph1;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const half8 ah0 = ph0, al0 = pl0, ah1 = ph1, al1 = pl1;
+            if (kb + 1 < KB) {
+                ph0 = w0[(kb + 1) * 128]; pl0 = ph0;
+                ph1 = w1[(kb + 1) * 128]; pl1 = ph1;
+            }
+#else
         half8 ph0 = w0[0], pl0 = w0[64], ph1 = w1[0], pl1 = w1[64];          // fragments of step kb are requested during step kb-1
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
@@ -237,12 +248,15 @@ __device__ __forceinline__ void dense_blocks_f16x3_hook(const HiLo (&in)[KB], co
                 ph1 = w1[(kb + 1) * 128]; pl1 = w1[(kb + 1) * 128 + 64];
             }
 #endif
+#endif
             m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, in[kb].hi, m0, 0, 0, 0);
             m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, in[kb].hi, m1, 0, 0, 0);
             c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, in[kb].lo, c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, in[kb].lo, c1, 0, 0, 0);
+#ifndef PPS_ABL_NOLOMFMA       // ablation (wrong numbers): without the lo.hi products -- 4 instead of 6 MFMAs and half the fragment reads per k-step
             c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, in[kb].hi, c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, in[kb].hi, c1, 0, 0, 0);
+#endif
             hook(ob, kb);
             if (FENCE) {
                 __builtin_amdgcn_sched_group_barrier(PPS_SG_DSREAD, 4, 0);
