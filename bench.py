@@ -57,6 +57,7 @@ INTERP_EXEC_FLOP_PER_QUERY = 2320 * 4 * 2048.0
 STAGE_EXEC_MFMA_PER_QUERY = {'interp_pool': 9280, 'pointnet_stn_rows': 2413, 'pointnet_stn_fc': 296, 'pointnet_feat_rows': 2670, 'decode_tail': 200}
 PEAK_F32_MFMA_TFLOPS = 157.3                   # /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F16_MFMA_TFLOPS = 2500.0                  # dense f16 / bf16 matrix peak, same guide
+MEASURED_F16_MFMA_TFLOPS = 1800.0              # bare v_mfma_f32_16x16x32_f16 loop, random operands, measured (1797-1917; 2274 on zeros)
 STAGES = ('interp_pool', 'pointnet_stn_rows', 'pointnet_stn_fc', 'pointnet_feat_rows', 'decode_tail')
 
 
@@ -73,26 +74,39 @@ def cpu_model():
 
 def cpu_baseline(sd, cloud, qry, lat, q_call=20_000, reps=3):
     """The oracle (CPU restatement of the reference, kind 'port') on a bounded sample of the same workload: `reps` calls of
-    Q = 20 000 queries (SURVEY.md 8d / BASELINE.md 4), N = 100k cloud, kNN + patches + from_latent + occupancy."""
+    Q = 20 000 queries (SURVEY.md 8d / BASELINE.md 4), N = 100k cloud, kNN + patches + from_latent + occupancy.  SURVEY 8(d) says
+    os.cpu_count() threads; torch CPU ops on these tensors stop scaling (and collapse) beyond a few dozen threads, so a short probe (1000 queries
+    per thread count) is run first, its rates travel in the JSON (`threads_tried`) and the fastest count is the one the baseline is quoted on."""
     from oracle import ppsurf_oracle as O
-    # torch CPU ops on these tensors stop scaling (and collapse) beyond a few dozen threads; measured on the 256-core host:
-    # 50 queries/s at 256 threads, ~2100 at 32
-    threads = max(1, min(os.cpu_count() or 1, 32))
-    torch.set_num_threads(threads)
-    os.environ['OMP_NUM_THREADS'] = str(threads)
     pts_cf = torch.from_numpy(cloud.T.copy()).unsqueeze(0)
     latt = torch.from_numpy(lat)
-    times = []
-    for r in range(reps):
-        q = qry[r * q_call:(r + 1) * q_call]
+
+    def call(q):
         t0 = time.time()
         patches = O.get_pts_local_ps(cloud, q, P_LOCAL)
         data = {'latents': latt, 'pts': pts_cf, 'pts_query': torch.from_numpy(q).unsqueeze(0), 'pts_local_ps': torch.from_numpy(patches).unsqueeze(0)}
         with torch.no_grad():
             O.predict_from_latent(O.ppsurf_from_latent(sd, data, k=K_PROJ))
-        times.append(time.time() - t0)
+        return time.time() - t0
+
+    host = os.cpu_count() or 1
+    tried = {}
+    for th in sorted({t for t in (8, 32, 64, 128, host) if t <= host}):
+        torch.set_num_threads(th)
+        os.environ['OMP_NUM_THREADS'] = str(th)
+        call(qry[:200])                                          # thread pool warm-up
+        tried[th] = 1000 / call(qry[:1000])
+        if tried[th] < 0.25 * max(tried.values()):               # collapsing: larger counts only get slower, and each probe would take minutes
+            break
+    threads = max(tried, key=tried.get)
+    torch.set_num_threads(threads)
+    os.environ['OMP_NUM_THREADS'] = str(threads)
+    times = [call(qry[r * q_call:(r + 1) * q_call]) for r in range(reps)]
     return {'value': q_call / float(np.median(times)), 'unit': 'queries/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'cpu_model': cpu_model(), 'host_cores': os.cpu_count(),
+            'cpu_model': cpu_model(), 'host_cores': host,
+            'threads_tried': {str(k): round(v, 1) for k, v in tried.items()},
+            'threads_note': 'queries/s of a 1000-query call per torch/OpenMP thread count; `cores` = the fastest of them (SURVEY 8d asks for all host '
+                            'cores: torch CPU ops on [1,256,Q,64] tensors slow down beyond a few dozen threads on this host)',
             'sample': '{} calls of {} band queries (N={} cloud, k=64, P=50): torch fp32 from_latent + OpenMP C kNN/patches; '
                       'median of {} s per call'.format(reps, q_call, cloud.shape[0], ', '.join('{:.1f}'.format(t) for t in times))}
 
@@ -129,7 +143,7 @@ def rank_values(x, rank, world, dist, red_dev):
     return [float(v) for v in t.cpu()]
 
 
-def build_work(plan, n_chunks, rank, dev):
+def build_work(plan, n_chunks, rank, dev, queries='band'):
     """Resident inputs: as many synthetic shapes as it takes to give every step its own chunk of a real first-round band."""
     import bench_workloads as workloads
     from ppsurf_amd.decoder import ChunkPipeline
@@ -141,7 +155,11 @@ def build_work(plan, n_chunks, rank, dev):
         pts = torch.from_numpy(cloud).to(dev)
         lat = make_latents(256, N_POINTS, seed=77 + s)
         table = plan.point_table(torch.from_numpy(lat[0]).to(dev))       # per-shape, outside the per-chunk step
-        chunks, n_band = workloads.band_chunks(cloud, RES, Q_CHUNK, dev)
+        if queries == 'dense':
+            chunks, n_band = workloads.dense_chunks(cloud, RES, Q_CHUNK, dev, n_chunks=47)      # as many per shape as the band gives: same shape count
+            n_band *= Q_CHUNK
+        else:
+            chunks, n_band = workloads.band_chunks(cloud, RES, Q_CHUNK, dev)
         pipe = ChunkPipeline(plan, table, pts, pts, K_PROJ, P_LOCAL, same_cloud=True, max_chunk=Q_CHUNK)
         shapes.append({'cloud': cloud, 'lat': lat, 'band': n_band, 'chunks': len(chunks)})
         work += [(pipe, c) for c in chunks]
@@ -195,14 +213,20 @@ def chunk_loop(work, steps, warmup, rank, world, dist, red_dev, min_timed_s=MIN_
 
 
 def pmc_traffic(dtype):
-    """HBM bytes per launch of the dominant kernel from the committed counter passes of this bench (a previous run of the same command,
-    labelled with the commit it was taken at -- never measured inside this run)."""
-    for tag in ('round3', 'round2'):
+    """HBM bytes per launch of the dominant kernel from the committed counter passes of this bench -- a previous run of the same command, never
+    measured inside this run.  The file records a digest of the kernel sources it was measured on (bench_workloads.csrc_digest); if the sources
+    have changed since, the figure is NOT reported (traffic: null) instead of silently going stale."""
+    import bench_workloads as workloads
+    here = workloads.csrc_digest()
+    for tag in ('round4', 'round3', 'round2'):
         path = os.path.join(REPO, 'profiles', '{}_{}_pmc.json'.format(tag, dtype))
         if os.path.isfile(path):
             d = json.load(open(path))
-            src = 'profiles/{}: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes of this bench at commit {} (a previous run, NOT measured in this run)'.format(
-                os.path.basename(path), d.get('git_head', 'unrecorded'))
+            if d.get('csrc_digest') != here:
+                return None, 'profiles/{} was measured on other kernel sources (digest {} at commit {}, now {}): not reported'.format(
+                    os.path.basename(path), d.get('csrc_digest', 'unrecorded'), d.get('git_head', 'unrecorded'), here)
+            src = 'profiles/{}: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes of this bench at commit {}, same kernel sources (digest {}); a previous run, NOT measured in this run'.format(
+                os.path.basename(path), d.get('git_head', 'unrecorded'), here)
             return d.get('interp_pool_hbm_bytes_per_launch'), src
     return None, None
 
@@ -215,6 +239,13 @@ def roofline_block(dtype, stage_ms):
     traffic, traffic_src = pmc_traffic(dtype)
     return {'kernel': ('interp_pool_f16x3_kernel' if f16 else 'interp_pool_kernel') + ' (inside pps_decode_fwd_events_f32)', 'bound': 'mfma',
             'achieved': executed, 'peak': peak, 'unit': 'TFLOP/s', 'frac': executed / peak,
+            # SURVEY 8(d)'s quantity: the flops of the REFERENCE work this kernel replaces (35.78 MFLOP per query) / time / peak.  For f16x3 the
+            # executed figure counts the 3x of the split; for fp32 two exact identities remove 47 % of the reference's flops (so this can exceed 1)
+            'frac_algorithmic': INTERP_ALG_FLOP_PER_QUERY * Q_CHUNK / (k_ms * 1e-3) / 1e12 / peak,
+            # what a bare loop of the same MFMA instruction sustains on random operands on this chip (it clocks down under matrix load:
+            # tools/ubench/mfma_power_probe.hip, profiles/round4_mfma_power_probe.txt) -- the peak of the guide is reached on zero operands only
+            'peak_sustained_random_operands': MEASURED_F16_MFMA_TFLOPS if f16 else None,
+            'frac_of_sustained': executed / MEASURED_F16_MFMA_TFLOPS if f16 else None,
             'traffic': traffic, 'traffic_source': traffic_src, 'avg_kernel_ms': k_ms,
             'algorithmic_tflops': INTERP_ALG_FLOP_PER_QUERY * Q_CHUNK / (k_ms * 1e-3) / 1e12,
             'note': ('achieved / frac = f16 MFMA flops the split-precision kernel executes (3 f16 products per fp32 product of the 9280 x 2048 '
@@ -235,6 +266,7 @@ def dtype_stats(dtype, r, world):
             'stage_mfma_frac': {n: mult * STAGE_EXEC_MFMA_PER_QUERY[n] * 2048.0 * Q_CHUNK / (sm[n] * 1e-3) / 1e12 / peak for n in STAGES},
             'spatial_ms': ms_step - sum(sm.values()),
             'whole_path_algorithmic_tflops': ALG_MFLOP_PER_QUERY * 1e6 * value / world / 1e12,
+            'whole_path_algorithmic_frac': ALG_MFLOP_PER_QUERY * 1e6 * value / world / 1e12 / peak,
             'whole_path_executed_mfma_frac': mult * sum(STAGE_EXEC_MFMA_PER_QUERY.values()) * 2048.0 * value / world / 1e12 / peak}
 
 
@@ -258,6 +290,9 @@ def main():
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N>1 ('nccl' = RCCL; 'gloo' only for single-GPU rehearsals)")
     ap.add_argument('--same-gpu', action='store_true', help='rehearsal: every rank uses cuda:0 (needs --backend gloo)')
     ap.add_argument('--spawn', action='store_true', help='re-execute under torch.distributed.run even for --gpus 1 (what --gpus N>1 does by itself)')
+    ap.add_argument('--queries', choices=['band', 'dense'], default='band',
+                    help="band: the first region-growing round (what a reconstruction evaluates); dense: z-slab blocks of the whole (R+2)^3 grid "
+                         "(SURVEY 8d(i): 'every voxel of the Marching-Cubes grid')")
     ap.add_argument('--shapes', type=int, default=2, help='timed whole reconstructions per rank of the shapes/hour leg')
     args = ap.parse_args()
     if args.steps is None:
@@ -298,7 +333,7 @@ def main():
 
     sd = network_state_dict('ppsurf')
     plan = DecoderPlan(sd, dev, dtype=args.dtype)
-    shapes, work = build_work(plan, args.warmup + args.steps, rank, dev)
+    shapes, work = build_work(plan, args.warmup + args.steps, rank, dev, queries=args.queries)
     r = chunk_loop(work, args.steps, args.warmup, rank, world, dist, red_dev)
     per_rank = [Q_CHUNK * r['chunks'] / t for t in rank_values(r['mine'], rank, world, dist, red_dev)]
 
@@ -313,8 +348,11 @@ def main():
             'backend': ('RCCL (torch.distributed nccl)' if args.backend == 'nccl' else args.backend) if world > 1 else None,
             'per_rank_queries_per_s': {'min': min(per_rank), 'max': max(per_rank), 'all': per_rank},
             'dtype_note': DTYPE_NOTE[args.dtype],
-            'config': {'workload': 'ppsurf_50nn predict, R=257: {} distinct first-growth-round band chunks of {} queries '
-                                   '(rec_batch_size) over {} synthetic 100k-point clouds per GPU, k=64, P=50'.format(args.steps, Q_CHUNK, len(shapes)),
+            'config': {'workload': 'ppsurf_50nn predict, R=257: {} distinct {} chunks of {} queries '
+                                   '(rec_batch_size) over {} synthetic 100k-point clouds per GPU, k=64, P=50'.format(
+                                       args.steps, 'first-growth-round band' if args.queries == 'band' else 'dense z-slab (every voxel of the (R+2)^3 grid)',
+                                       Q_CHUNK, len(shapes)),
+                       'queries': args.queries,
                        'parallelism': 'query-block sharding x{}'.format(world), 'weights': 'formula-filled (no checkpoint offline)',
                        'entry': 'ChunkPipeline.run -> pps_knn_blocked_f32, pps_patch_normalize_f32, pps_decode_fwd_events_f32'},
             'roofline': roofline_block(args.dtype, r['stage_ms']),
@@ -340,6 +378,14 @@ def main():
             out[other] = dict(dtype_stats(other, r2, world), steps=n2, note=DTYPE_NOTE[other], roofline=roofline_block(other, r2['stage_ms']))
             out[other]['max_abs_occ_diff_vs_{}_last_chunk'.format(args.dtype)] = float((r2['occ'] - ref_occ).abs().max())
             del plan2, pipes2, work2, r2
+        if world == 1 and args.queries == 'band':
+            # ---- the north star's other reading of the workload: dense z-slab blocks of the whole grid, same step, same dtype ---------------
+            _, workd = build_work(plan, 5 + 40, rank, dev, queries='dense')
+            rd = chunk_loop(workd, 40, 5, rank, world, dist, red_dev, min_timed_s=0.5)
+            out['dense'] = dict(dtype_stats(args.dtype, rd, world), steps=40,
+                                note='z-slab blocks of the (R+2)^3 Marching-Cubes grid in index order, 50 000 voxels each, evenly spaced over the volume '
+                                     '(poco_utils.py:52-58,212-213): what a reconstruction WITHOUT region growing would evaluate')
+            del workd, rd
         del work, r
         torch.cuda.empty_cache()
         # ---- shapes/hour: whole R=257 reconstructions by the product driver, every rank its own shapes ----------------------------------
@@ -359,9 +405,11 @@ def main():
         rank_sph = [3600.0 * args.shapes / t for t in rank_values(mine, rank, world, dist, red_dev)]
         if rank == 0:
             steady = min(x['total_s'] for x in runs)
-            # N = 1: the steady-state shape (best of the timed ones, as in round 2); N > 1: all shapes of all ranks / the slowest rank's wall time
-            out['shapes_per_hour'] = 3600.0 / steady if world == 1 else 3600.0 * world * args.shapes / dt_shapes
-            out['reconstruction'] = {'first_shape_s': first['total_s'], 'steady_s': steady, 'latent_loop_s': runs[-1]['latent_s'],
+            # all timed shapes of all ranks / the slowest rank's wall time (N = 1: the mean over the timed shapes); the best single shape travels as
+            # reconstruction.steady_best_shapes_per_hour
+            out['shapes_per_hour'] = 3600.0 * world * args.shapes / dt_shapes
+            out['reconstruction'] = {'first_shape_s': first['total_s'], 'steady_s': steady, 'steady_best_shapes_per_hour': 3600.0 / steady,
+                                     'cloud_noise_sigma': 0.005, 'latent_loop_s': runs[-1]['latent_s'],
                                      'surface_s': runs[-1]['surface_s'], 'decoder_queries': runs[-1]['decoder_queries'],
                                      'vertices': runs[-1]['vertices'], 'first_shape_per_hour': 3600.0 / first['total_s'],
                                      'encoder_passes_per_s': 10.0 * (N_POINTS // 10000) / runs[-1]['latent_s'],
@@ -373,8 +421,8 @@ def main():
                                              'sharding (PPS_SHARD=shapes), no collective on the data path'}
         if world == 1:
             model.network.decoder_dtype = other
-            runs2 = [workloads.reconstruct_steered(model, N_POINTS, seed=42 + i, device=dev) for i in range(2)]
-            out[other]['shapes_per_hour'] = 3600.0 / runs2[-1]['total_s']
+            runs2 = [workloads.reconstruct_steered(model, N_POINTS, seed=42 + i, device=dev) for i in range(3)]      # the first warms the other dtype's plan
+            out[other]['shapes_per_hour'] = 3600.0 * len(runs2[1:]) / sum(x['total_s'] for x in runs2[1:])
             out[other]['reconstruction_steady_s'] = runs2[-1]['total_s']
         del model
         torch.cuda.empty_cache()
@@ -428,6 +476,7 @@ def strong(args, rank, world, dev, dist, red_dev):
     import bench_workloads as workloads
     sharding.set_query_sharding(world > 1)
     model = workloads.make_model(RES, P_LOCAL, Q_CHUNK, dev)
+    model.network.decoder_dtype = args.dtype
     model.shard_queries = world > 1
     steps, warm = args.steps, args.warmup
     for i in range(warm):
@@ -453,7 +502,7 @@ def strong(args, rank, world, dev, dist, red_dev):
         print(json.dumps({
             'metric': 'occupancy query-points/sec @ res=257, 50NN', 'value': total_q / dt, 'unit': 'queries/s', 'n_gpus': world,
             'steps': steps, 'warmup': warm, 'ms_per_step': dt / steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': args.dtype, 'dtype_note': DTYPE_NOTE[args.dtype], 'data': 'synthetic',
             'config': {'workload': 'ppsurf_50nn predict, ONE 100k-point synthetic shape at R=257 reconstructed by all ranks together '
                                    '(step = one whole reconstruction: latent loop, region growing, MC, 10 refinement rounds)',
                        'parallelism': 'PPS_SHARD=queries x{}: per growth/refinement round contiguous query ranges + all-gather of 4 B/query; '

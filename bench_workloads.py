@@ -75,6 +75,38 @@ def band_chunks(cloud: np.ndarray, resolution: int, chunk: int, device, full_onl
     return chunks, int(q.shape[0])
 
 
+def dense_chunks(cloud: np.ndarray, resolution: int, chunk: int, device, n_chunks: int):
+    """Dense-block queries ("evaluated at every voxel of the Marching-Cubes grid"): the (R+2)^3 grid of poco_utils.py:52-58 in
+    index order (x slowest, z fastest) is cut into consecutive blocks of `chunk` voxels -- z-slab runs of the volume -- and `n_chunks` of them,
+    evenly spaced over the volume, are returned as float32 coordinates `idx * step + bmin_pad` (poco_utils.py:212-213).  Returns (chunks, number
+    of blocks in the whole grid)."""
+    step, bmin_pad, _ = grid_geometry(cloud, resolution)
+    n = resolution + 2
+    total = n ** 3
+    nblocks = total // chunk
+    pick = np.unique(np.linspace(0, nblocks - 1, num=min(n_chunks, nblocks)).astype(np.int64))
+    out = []
+    for b in pick:
+        lin = torch.arange(int(b) * chunk, int(b) * chunk + chunk, device=device, dtype=torch.int64)
+        ijk = torch.stack([lin // (n * n), (lin // n) % n, lin % n], dim=1)
+        out.append((ijk.to(torch.float32) * np.float32(step) + np.float32(bmin_pad)).contiguous())
+    return out, nblocks
+
+
+def csrc_digest():
+    """sha1 over the kernel sources + headers: ties a committed counter file (profiles/*_pmc.json) to the code it was measured on."""
+    import hashlib
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha1()
+    d = os.path.join(here, 'ppsurf_amd', 'csrc')
+    for name in sorted(os.listdir(d)):
+        if name.endswith(('.hip', '.h', '.cpp')):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 class SteeredField(reconstruct.OccupancyField):
     norm = None                                     # (centre, scale) of the synthetic cloud, set by the caller
 
@@ -97,7 +129,7 @@ def make_model(resolution=257, p=50, chunk=50000, device='cuda:0'):
 def reconstruct_steered(model, n_points=100_000, seed=42, device='cuda:0', return_mesh=False):
     """One reconstruction with the product's own driver (encode_latents + export_mesh_and_refine_vertices_region_growing_v3),
     every query decoded by the real kernels, growth steered by the analytic shape.  Returns a dict of seconds / counts."""
-    cloud, norm = synthetic.make_cloud(n_points, seed=seed, noise=0.0, return_norm=True)
+    cloud, norm = synthetic.make_cloud(n_points, seed=seed, return_norm=True)          # Gaussian noise sigma = 0.005 (SURVEY.md 8d), like the chunk bench
     cloud_t = torch.from_numpy(cloud).to(device)
     pts_cf = cloud_t.t().contiguous()
     SteeredField.norm = norm

@@ -184,7 +184,9 @@ int pps_decode_tail_f32(const float* pooled, const float* xbar, int64_t q, const
  * table [n,256]; pts [n,3]; query [q,3]; idx int64 [q,k]; patches [q,p,3];
  * weights [host] array of 10 device pointers: interp (wpack, bias), stn_rows (wpack, bias), stn_fc (wpack, bias),
  * feat_rows (wpack, bias), tail (wpack, bias) -- layouts as documented at the single entry points;
- * logits out [q,2]; occ out [q] or NULL; ws: pps_decode_ws_bytes(q) bytes of device scratch. */
+ * logits out [q,2]; occ out [q] or NULL; ws: pps_decode_ws_bytes(q) bytes of device scratch, ZEROED once by the caller before its first use
+ * (its first 64 bytes hold the range-guard words of pps_decode_fwd_mixed_f32: int32 [0] = flag of the chunk in flight, [1] = number of chunks
+ * recomputed in fp32 so far). */
 size_t pps_decode_ws_bytes(int64_t q);
 int pps_decode_fwd_f32(const float* table, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
                        const float* patches, int p, const float* const* weights, float* logits, float* occ, void* ws, void* stream);
@@ -198,22 +200,29 @@ int pps_decode_fwd_events_f32(const float* table, const float* pts, const float*
 /* Opt-in split-precision interpolation branch (decoder dtype "f16x3"): same contract as pps_interp_pool_f32 with fc2 / fc3 / fc_query
  * evaluated as three f16 MFMA products per fp32 product (error ~1e-5 on logits of magnitude 30, tests/test_gpu_decoder.py).
  * wxyz: the 1024 packed floats of fc1's xyz part (front of the fp32 image); w16: pps_pack_dense_f16x3 images of fc2, fc3, fc_query
- * back to back (147456 halfs x 2); bias [256 | 256 | 64] floats. */
+ * back to back (147456 halfs x 2); bias [256 | 256 | 64] floats.
+ * range_flag (all three split-precision entries): device int32 or NULL.  x = hi + lo with hi = f16(x) needs |x| <= 65504; a kernel that splits an
+ * activation beyond that ORs 1 into *range_flag (its results are then wrong: the conversion saturates, no inf appears).  The caller zeroes the
+ * word, and on a non-zero value repeats the chunk with the fp32 entries -- pps_decode_fwd_mixed_f32 does both on the device.  The reference's
+ * own GPU path (fp16 autocast, configs/poco.yaml:10) has the same range and no guard. */
 int pps_interp_pool_f16x3(const float* G, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
-                          const float* wxyz, const void* w16, const float* bias, float* pooled, void* stream);
+                          const float* wxyz, const void* w16, const float* bias, float* pooled, int32_t* range_flag, void* stream);
 /* The PointNet branch in split precision: weights = the six fp32 images (stn_rows, stn_fc, feat_rows: wpack, bias each -- xyz layers and
  * biases are read from them), w16 [host] array of 3 pps_pack_dense_f16x3 image sets: (c0b, s1, s2, s3), (fc1, fc2, fc3), (c0b, c1, c2, c3);
  * g [q,256], trans2 (q x 16 KiB: pre-split fragments of the per-query feature transform), xbar [q,256]; events: 3 hipEvent_t or NULL. */
 int pps_pointnet_f16x3(const float* patches, int64_t q, int p, const float* const* weights, const void* const* w16, float* g, float* trans2,
-                       float* xbar, void* const* events, void* stream);
+                       float* xbar, int32_t* range_flag, void* const* events, void* stream);
 /* The tail (pps_decode_tail_f32: source/ppsurf_model.py:100, source/base/nn.py:376-417 composed with fc8 . fc_value | att.fc_value) in split
  * precision: w16 = pps_pack_dense_f16x3 images of Wa 256x256 and Wb 256x256 interleaved in 32 KiB chunks (chunk 2c: output blocks 2c, 2c+1 of Wa,
  * chunk 2c+1: the same blocks of Wb), then [L2 256x256][L3 2x256]; bias as for the fp32 entry. */
 int pps_decode_tail_f16x3(const float* pooled, const float* xbar, int64_t q, const void* w16, const float* bias, float* logits, float* occ,
-                          void* stream);
+                          int32_t* range_flag, void* stream);
 /* pps_decode_fwd_events_f32 with branches in split precision: w16 [host] array of 5 image sets (interp, stn_rows, stn_fc, feat_rows, tail);
  * w16[0] NULL keeps the fp32 interpolation branch, any of w16[1..3] NULL keeps the fp32 PointNet branch, w16[4] NULL the fp32 tail.
- * events may be NULL. */
+ * events may be NULL.
+ * Range guard: behind the split-precision kernels the call queues the five fp32 kernels of the same chunk, each returning at once unless a
+ * split-precision kernel raised the flag word in `ws` -- a chunk whose activations leave the f16 range (|x| > 65504) is recomputed in exact fp32
+ * on the device (bit-identical to pps_decode_fwd_f32), every other chunk pays five empty launches (~12 us). */
 int pps_decode_fwd_mixed_f32(const float* table, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
                              const float* patches, int p, const float* const* weights, const void* const* w16, float* logits, float* occ,
                              void* ws, void* const* events, void* stream);

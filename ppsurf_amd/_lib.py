@@ -47,9 +47,9 @@ SIGNATURES = {
     'pps_decode_fwd_f32': (_I, [_P, _P, _P, _P, _I64, _I, _P, _I, _P, _P, _P, _P, _P]),
     'pps_decode_fwd_events_f32': (_I, [_P, _P, _P, _P, _I64, _I, _P, _I, _P, _P, _P, _P, _P, _P]),
     'pps_decode_fwd_mixed_f32': (_I, [_P, _P, _P, _P, _I64, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
-    'pps_interp_pool_f16x3': (_I, [_P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P]),
-    'pps_pointnet_f16x3': (_I, [_P, _I64, _I, _P, _P, _P, _P, _P, _P, _P]),
-    'pps_decode_tail_f16x3': (_I, [_P, _P, _I64, _P, _P, _P, _P, _P]),
+    'pps_interp_pool_f16x3': (_I, [_P, _P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P]),
+    'pps_pointnet_f16x3': (_I, [_P, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'pps_decode_tail_f16x3': (_I, [_P, _P, _I64, _P, _P, _P, _P, _P, _P]),
     'pps_fkaconv_geo_floats': (_SZ, []),
     'pps_fkaconv_ws_bytes': (_SZ, [_I64, _I]),
     'pps_fkaconv_fwd_f32': (_I, [_P, _P, _P, _P, _I64, _I64, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P]),

@@ -163,9 +163,6 @@ __device__ __forceinline__ void dense_blocks(const f32x4 (&in)[KB], f32x4* out, 
 // 16 ob + 4 g + r), so two finished output blocks (2 kb, 2 kb + 1) ARE the B operand of k-block kb of the next layer once
 // split: element j of lane (n,g) is channel 32 kb + 16 (j >> 2) + 4 g + (j & 3).  The packed weights use the same map:
 //     packed[ob][kb][part][lane][j] = f16 part (0: hi, 1: lo) of W[16 ob + (l & 15)][32 kb + 16 (j >> 2) + 4 (l >> 4) + (j & 3)].
-#ifndef PPS_F16X3_PREFETCH
-#define PPS_F16X3_PREFETCH 1     // k-steps the A fragments of the split-precision layers are requested ahead (1 or 2)
-#endif
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct HiLo { half8 hi, lo; };
@@ -182,6 +179,27 @@ __device__ __forceinline__ HiLo split_f16(const f32x4& x0, const f32x4& x1) {
     }
     return HiLo{__builtin_bit_cast(half8, hp), __builtin_bit_cast(half8, lp)};
 }
+// Range guard of the split: hi = f16(x) needs |x| <= 65504 (v_cvt_pkrtz saturates silently beyond it, no inf appears anywhere).  Every kernel that splits
+// activations keeps the running maximum magnitude of what it split (4 v_max3_f32 per pair of blocks) and raises a flag in device memory when the
+// range was left; the host-side entry point (pps_decode_fwd_mixed_f32) queues the exact-fp32 kernels behind the split-precision ones, gated on
+// that flag, so a chunk that left the range is recomputed in fp32 without a host round trip.
+#define PPS_F16_MAX 65504.f
+__device__ __forceinline__ void range_track(float& amax, const f32x4& a, const f32x4& b) {
+    // as inline assembly on purpose: written with fmaxf the compiler turns the running maximum into a reduction tree evaluated at the END of the
+    // unrolled layer and keeps every fp32 output block alive until then (164 spilled VGPRs in interp_pool_f16x3_kernel)
+    asm volatile("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|" : "+v"(amax) : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w));
+    asm volatile("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|" : "+v"(amax) : "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+}
+__device__ __forceinline__ HiLo split_f16_r(float& amax, const f32x4& x0, const f32x4& x1) {
+    range_track(amax, x0, x1);
+    return split_f16(x0, x1);
+}
+__device__ __forceinline__ void range_commit(float amax, int* flag) {
+    if (flag != nullptr && !(amax <= PPS_F16_MAX)) atomicOr(flag, 1);
+}
+// gate of the fp32 fallback kernels: nothing to do unless a split-precision kernel of this chunk left the f16 range
+__device__ __forceinline__ bool gate_closed(const int* gate) { return gate != nullptr && __builtin_nontemporal_load(gate) == 0; }
+
 // back to fp32 (hi + lo), blocks 2 kb and 2 kb + 1
 __device__ __forceinline__ void join_f16(const HiLo& x, f32x4& y0, f32x4& y1) {
 #pragma unroll
@@ -213,32 +231,6 @@ __device__ __forceinline__ void dense_blocks_f16x3_hook(const HiLo (&in)[KB], co
         f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
         const half8* w0 = w + ((ob) * KB) * 128 + lane;
         const half8* w1 = w + ((ob + 1) * KB) * 128 + lane;
-#if PPS_F16X3_PREFETCH == 2
-        // fragments of step kb are requested during step kb-2 (16 more VGPRs: hides an LDS round trip that is longer than one k-step when eight
-        // waves read 32 KiB per k-step between them)
-        half8 ph0 = w0[0], pl0 = w0[64], ph1 = w1[0], pl1 = w1[64];
-        half8 qh0 = ph0, ql0 = pl0, qh1 = ph1, ql1 = pl1;
-        if (KB > 1) { qh0 = w0[128]; ql0 = w0[128 + 64]; qh1 = w1[128]; ql1 = w1[128 + 64]; }
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            const half8 ah0 = ph0, al0 = pl0, ah1 = ph1, al1 = pl1;
-            ph0 = qh0; pl0 = ql0; ph1 = qh1; pl1 = ql1;
-            if (kb + 2 < KB) {
-                qh0 = w0[(kb + 2) * 128]; ql0 = w0[(kb + 2) * 128 + 64];
-                qh1 = w1[(kb + 2) * 128]; ql1 = w1[(kb + 2) * 128 + 64];
-            }
-#else
-#ifdef PPS_ABL_NOLO
-        // ablation (wrong numbers): the lo fragments are not read from LDS -- what do half the fragment reads cost?  
-        half8 ph0 = w0[0], pl0 = ph0, ph1 = w1[0], pl1 = ph1;
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            const half8 ah0 = ph0, al0 = pl0, ah1 = ph1, al1 = pl1;
-            if (kb + 1 < KB) {
-                ph0 = w0[(kb + 1) * 128]; pl0 = ph0;
-                ph1 = w1[(kb + 1) * 128]; pl1 = ph1;
-            }
-#else
         half8 ph0 = w0[0], pl0 = w0[64], ph1 = w1[0], pl1 = w1[64];          // fragments of step kb are requested during step kb-1
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
@@ -247,16 +239,12 @@ __device__ __forceinline__ void dense_blocks_f16x3_hook(const HiLo (&in)[KB], co
                 ph0 = w0[(kb + 1) * 128]; pl0 = w0[(kb + 1) * 128 + 64];
                 ph1 = w1[(kb + 1) * 128]; pl1 = w1[(kb + 1) * 128 + 64];
             }
-#endif
-#endif
             m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, in[kb].hi, m0, 0, 0, 0);
             m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, in[kb].hi, m1, 0, 0, 0);
             c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, in[kb].lo, c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, in[kb].lo, c1, 0, 0, 0);
-#ifndef PPS_ABL_NOLOMFMA       // ablation (wrong numbers): without the lo.hi products -- 4 instead of 6 MFMAs and half the fragment reads per k-step
             c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, in[kb].hi, c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, in[kb].hi, c1, 0, 0, 0);
-#endif
             hook(ob, kb);
             if (FENCE) {
                 __builtin_amdgcn_sched_group_barrier(PPS_SG_DSREAD, 4, 0);
@@ -302,9 +290,6 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 // compiler does not see a FLAT LDS access; the counters stay in order for its own bookkeeping: its vmcnt waits for ordinary loads only ever wait
 // LONGER with unknown older/younger VMEM operations in flight (returns are in order), and the stream itself is waited for explicitly
 // (stream_wait(), before the barrier that publishes a chunk).
-#ifndef PPS_DMA_ASM
-#define PPS_DMA_ASM 1
-#endif
 template <int NF4, int NTHREADS>
 __device__ __forceinline__ void chunk_copy_async(const f32x4* __restrict__ src, f32x4* dst) {
     // `src` is workgroup-uniform (SGPR base); the only per-lane part is one 32-bit byte offset
@@ -312,20 +297,14 @@ __device__ __forceinline__ void chunk_copy_async(const f32x4* __restrict__ src, 
     asm volatile("" : "+v"(lane_off));     // opaque: keeps hipcc from hoisting (and then spilling) one 64-bit address per chunk
     const int wave_base = threadIdx.x & ~63;
     const char* sbase = (const char*)src;
-#if PPS_DMA_ASM
     asm volatile("" : "+s"(sbase));        // opaque as well: otherwise one SGPR pair per piece of every chunk is hoisted out of the persistent loop
-#endif
 #pragma unroll
     for (int i = 0; i < NF4; ++i) {
         f32x4* d = dst + i * NTHREADS + wave_base;
-#if PPS_DMA_ASM
         // wave-uniform LDS byte address -> M0 (the low half of a generic pointer into the LDS aperture is the LDS offset)
         const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)d);
         const char* piece = sbase + (size_t)(i * NTHREADS * 16);
         asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_addr), "v"(lane_off), "s"(piece) : "memory", "m0");
-#else
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(sbase + (size_t)(i * NTHREADS * 16) + lane_off), (lds_ptr_t)(uintptr_t)d, 16, 0, 0);
-#endif
     }
 }
 // one 1 KiB-per-wave piece (index i of NF4) of the same copy: lets a caller spread the pieces of a chunk over its compute phase
@@ -341,9 +320,7 @@ __device__ __forceinline__ void chunk_copy_piece(const f32x4* __restrict__ src, 
 }
 // all outstanding pieces of this wave have landed in LDS (call before the barrier that hands the chunk to the other waves)
 __device__ __forceinline__ void stream_wait() {
-#if PPS_DMA_ASM
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-#endif
 }
 
 // XCD-aware persistent tile order: workgroup b runs on XCD b % 8 (observed, speed only); each XCD walks a

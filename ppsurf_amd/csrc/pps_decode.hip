@@ -31,63 +31,27 @@ using namespace pps;
 #define CH4 2048               // f32x4 per 32 KiB weight chunk
 
 // One pipeline step: request the NEXT chunk, compute on the CURRENT one, publish the next, barrier.
-// PPS_ABL_* macros are ablation switches for tools/ablate_interp.sh (never defined in the product build)
 // CHUNK_F4_NEXT: size of the next chunk in f32x4; NTH: threads of the workgroup (all of them copy)
-#ifdef PPS_TRACE
-// development aid (tools/trace_interp16.py): where one wave's cycles of a pipeline step go -- issue of the next chunk's copy | compute on the current
-// chunk | wait for the own copies | barrier -- summed over all steps of wave 0 of workgroup 0; [4] counts the steps.  Never in the product build.
-__device__ unsigned long long pps_trace_acc[8];
-#define PPS_TRACE_T(i) const unsigned long long pps_t##i = __builtin_readcyclecounter()
-#define PPS_TRACE_ADD(slot, a, b) do { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pps_trace_acc[slot], pps_t##b - pps_t##a); } while (0)
-#else
-#define PPS_TRACE_T(i)
-#define PPS_TRACE_ADD(slot, a, b)
-#endif
-
 template <int CHUNK_F4_NEXT, int NTH = NT, class F>
 __device__ __forceinline__ void stream_step(const f32x4* __restrict__ gnext, f32x4*& cur, f32x4*& nxt, F&& compute) {
-    PPS_TRACE_T(0);
-#ifndef PPS_ABL_NOSTREAM
     chunk_copy_async<CHUNK_F4_NEXT / NTH, NTH>(gnext, nxt);
-#endif
-    PPS_TRACE_T(1);
     compute((const f32x4*)cur);
-    PPS_TRACE_T(2);
-#ifndef PPS_ABL_NOBARRIER
     stream_wait();
-    PPS_TRACE_T(3);
     __syncthreads();
-    PPS_TRACE_T(4);
-    PPS_TRACE_ADD(0, 0, 1); PPS_TRACE_ADD(1, 1, 2); PPS_TRACE_ADD(2, 2, 3); PPS_TRACE_ADD(3, 3, 4);
-#ifdef PPS_TRACE
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pps_trace_acc[4], 1ull);
-#endif
-#endif
-#ifndef PPS_ABL_NOSTREAM
     f32x4* t = cur; cur = nxt; nxt = t;
-#endif
 }
 
 // The same pipeline step with the copy of the next chunk SPREAD over the compute phase: `compute(w, piece)` calls piece(i), i = 0 .. NPIECES-1, at
 // points of its own choosing (dense_blocks_f16x3_hook: after the MFMAs of a k-step).  Issued in one burst at the head of the step, the pieces of all
 // waves of a workgroup queue up in the CU's memory pipeline (32 KiB at 64 B/clk = 512 cycles per chunk) while every wave sits in the issue and the
-// matrix pipe is idle -- a cycle trace of the split-precision interpolation kernel (tools/trace_interp16.py) showed 12 % of a step in the issue and
-// 20 % in the barrier behind it; spread out, a piece is accepted while the wave's own queued MFMAs execute.
+// matrix pipe is idle -- a cycle trace of the split-precision interpolation kernel (round 3, profiles/NOTES_r3.md) showed 12 % of a step in the issue
+// and 20 % in the barrier behind it; spread out, a piece is accepted while the wave's own queued MFMAs execute.
 template <int CHUNK_F4_NEXT, int NTH = NT, class F>
 __device__ __forceinline__ void stream_step_spread(const f32x4* __restrict__ gnext, f32x4*& cur, f32x4*& nxt, F&& compute) {
-    PPS_TRACE_T(0);
-    PPS_TRACE_T(1);
     f32x4* dst = nxt;
     compute((const f32x4*)cur, [&](int i) { if (i < CHUNK_F4_NEXT / NTH) chunk_copy_piece<NTH>(gnext, dst, i); });
-    PPS_TRACE_T(2);
     stream_wait();
-    PPS_TRACE_T(3);
     __syncthreads();
-    PPS_TRACE_T(4);
-    PPS_TRACE_ADD(0, 0, 1); PPS_TRACE_ADD(1, 1, 2); PPS_TRACE_ADD(2, 2, 3); PPS_TRACE_ADD(3, 3, 4);
-#ifdef PPS_TRACE
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pps_trace_acc[4], 1ull);
-#endif
     f32x4* t = cur; cur = nxt; nxt = t;
 }
 
@@ -187,7 +151,9 @@ __global__ __launch_bounds__(NT, 2) void rows_dense256_kernel(const float* __res
 __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restrict__ G, const float* __restrict__ pts,
                                                             const float* __restrict__ query, const int64_t* __restrict__ idx,
                                                             int64_t Q, int k, const float* __restrict__ wpack,
-                                                            const float* __restrict__ bias, float* __restrict__ pooled) {
+                                                            const float* __restrict__ bias, float* __restrict__ pooled,
+                                                            const int* __restrict__ gate) {
+    if (gate_closed(gate)) return;
     f32x4* buf0 = (f32x4*)pps_smem;
     f32x4* buf1 = buf0 + CH4;
     float* xyz_l = (float*)(buf1 + CH4);
@@ -221,11 +187,7 @@ __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restr
 
         f32x4 a[16], b[16];
         {
-#ifdef PPS_ABL_NOGATHER
-            const f32x4* grow = (const f32x4*)(G + (int64_t)(lane & 15) * 256) + g;
-#else
             const f32x4* grow = (const f32x4*)(G + i * 256) + g;
-#endif
 #pragma unroll
             for (int bb = 0; bb < 16; ++bb) a[bb] = grow[4 * bb];
             const float coord = (g < 3) ? (query[qc * 3 + g] - pts[i * 3 + g]) : 0.f;   // query minus neighbour (poco_model.py:402)
@@ -249,10 +211,6 @@ __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restr
                            [&](const f32x4* w) { dense_blocks<16, 2, 0>(a, &b[2 * c], w, bias4 + 128 + 8 * c, lane); });
 
         __builtin_amdgcn_s_setprio(0);
-#ifdef PPS_ABL_NOSOFTMAX
-        if (qv && wq == 0 && lane < 64) { f32x4 s4 = a[0] + b[0]; for (int bb = 1; bb < 16; ++bb) s4 += a[bb]; ((f32x4*)(pooled + qi * 256))[lane] = s4; }
-        continue;
-#endif
         // ---- softmax over the 64 neighbours (4 waves x 16 rows) for each of the 64 heads -------------
         // lane (n,g) holds heads 16*bb + 4*g + r of row n in b[bb][r]
         float e[16];
@@ -316,20 +274,14 @@ __global__ __launch_bounds__(NT, 2) void interp_pool_kernel(const float* __restr
 // =====================================================================================================
 // interp_pool_f16x3: the same branch with the three big layers (fc2, fc3, fc_query) on the f16 matrix pipe in split precision
 // (pps_common.h, dense_blocks_f16x3) -- opt-in decoder dtype "f16x3"; gather, the xyz part of fc1, softmax and pooling stay fp32.
-// One workgroup = 8 waves = 2 queries per weight pass (the 576 KB weight stream, not the matrix pipe, bounds this kernel:
-// twice the rows per pass halve it).
+// One workgroup = 8 waves = 2 queries (128 rows) per pass over the 576 KB of fc2 / fc3 / fc_query.  What bounds it: not the
+// weight stream and not the LDS port as such -- a bare loop of the same MFMAs on random operands sustains 1.8 PFLOP/s (the chip clocks down under
+// f16 matrix load, tools/ubench/mfma_power_probe.hip), 1.7 with the A fragments re-read from LDS; this kernel reaches 1.1.
 // weights: wxyz (floats) [xyz 1024]; w16 (half8 fragments) [fc2 16 ob x 8 kb][fc3 16 x 8][fcq 4 x 8], 2 KiB per (ob, kb);
 // bias (floats): [256][256][64]
 // =====================================================================================================
-#ifndef IH_NT
-#define IH_NT 512              // threads per workgroup: 512 = one 8-wave workgroup per CU (2 queries per weight pass), 256 = two decoupled 4-wave workgroups
-#endif
-#ifndef IH_OB
-#define IH_OB 2                // output blocks per streamed weight chunk: 2 = 32 KiB chunks (18 barriers per pass), 4 = 64 KiB chunks (9)
-#endif
-#ifndef IH_SPREAD
-#define IH_SPREAD 1            // 1: the next chunk's copy is issued piece by piece between the k-steps (stream_step_spread), 0: in one burst
-#endif
+#define IH_NT 512              // one 8-wave workgroup per CU: 2 queries (128 rows) per pass over the weights
+#define IH_OB 2                // output blocks per streamed weight chunk: 32 KiB chunks, 18 per pass
 #define IH_NW (IH_NT / 64)
 #define IH_WG_PER_CU (512 / IH_NT)
 #define IH_CH4 (CH4 * IH_OB / 2)
@@ -340,7 +292,8 @@ __global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float
                                                                      const float* __restrict__ query, const int64_t* __restrict__ idx,
                                                                      int64_t Q, int k, const float* __restrict__ wxyz,
                                                                      const f32x4* __restrict__ w16, const float* __restrict__ bias,
-                                                                     float* __restrict__ pooled) {
+                                                                     float* __restrict__ pooled, int* __restrict__ range) {
+    float amax = 0.f;
     f32x4* buf0 = (f32x4*)pps_smem;
     f32x4* buf1 = buf0 + IH_CH4;
     float* xyz_l = (float*)(buf1 + IH_CH4);
@@ -375,36 +328,27 @@ __global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float
         HiLo x[8], y[8];
         {
             f32x4 a[16];
-#ifdef PPS_ABL_IH_NOGATHER
-            const f32x4* grow = (const f32x4*)(G + (int64_t)(lane & 15) * 256) + g;
-#else
             const f32x4* grow = (const f32x4*)(G + i * 256) + g;
-#endif
 #pragma unroll
             for (int bb = 0; bb < 16; ++bb) a[bb] = grow[4 * bb];
             const float coord = (g < 3) ? (query[qc * 3 + g] - pts[i * 3 + g]) : 0.f;   // query minus neighbour (poco_model.py:402)
             xyz_blocks<16>(coord, a, xyz_l, lane);
             relu_blocks<16>(a);
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) x[kb] = split_f16(a[2 * kb], a[2 * kb + 1]);
+            for (int kb = 0; kb < 8; ++kb) x[kb] = split_f16_r(amax, a[2 * kb], a[2 * kb + 1]);
         }
         __builtin_amdgcn_s_setprio(PPS_PRIO);
-#if IH_SPREAD
         // the 4 (8-wave workgroup) pieces of the next chunk's copy go out after k-steps 0, 2, 4, 6 of the first output-block pair
 #define IH_STEP(GNEXT, IN, BIAS, ACTV, SINK)                                                                                          \
         stream_step_spread<IH_CH4, IH_NT>(GNEXT, cur, nxt, [&](const f32x4* w, auto&& piece) {                                         \
             dense_blocks_f16x3_hook<8, IH_OB, ACTV>(IN, (const half8*)w, BIAS, lane, SINK,                                             \
                                                     [&](int ob, int kb) { if (ob == 0 && (kb & 1) == 0) piece(kb >> 1); if (IH_CH4 / IH_NT > 4 && ob == 0 && (kb & 1)) piece(4 + (kb >> 1)); }); })
-#else
-#define IH_STEP(GNEXT, IN, BIAS, ACTV, SINK)                                                                                          \
-        stream_step<IH_CH4, IH_NT>(GNEXT, cur, nxt, [&](const f32x4* w) { dense_blocks_f16x3<8, IH_OB, ACTV>(IN, (const half8*)w, BIAS, lane, SINK); })
-#endif
 #pragma unroll
         for (int c = 0; c < 16 / IH_OB; ++c)                           // fc2: output blocks IH_OB c .. = k-blocks IH_OB/2 c .. of fc3
-            IH_STEP(wg + (c + 1) * IH_CH4, x, bias4 + 4 * IH_OB * c, 1, ([&](int p, const f32x4& o0, const f32x4& o1) { y[IH_OB / 2 * c + p] = split_f16(o0, o1); }));
+            IH_STEP(wg + (c + 1) * IH_CH4, x, bias4 + 4 * IH_OB * c, 1, ([&](int p, const f32x4& o0, const f32x4& o1) { y[IH_OB / 2 * c + p] = split_f16_r(amax, o0, o1); }));
 #pragma unroll
         for (int c = 0; c < 16 / IH_OB; ++c)                           // fc3
-            IH_STEP(wg + (c + 16 / IH_OB + 1) * IH_CH4, y, bias4 + 64 + 4 * IH_OB * c, 1, ([&](int p, const f32x4& o0, const f32x4& o1) { x[IH_OB / 2 * c + p] = split_f16(o0, o1); }));
+            IH_STEP(wg + (c + 16 / IH_OB + 1) * IH_CH4, y, bias4 + 64 + 4 * IH_OB * c, 1, ([&](int p, const f32x4& o0, const f32x4& o1) { x[IH_OB / 2 * c + p] = split_f16_r(amax, o0, o1); }));
         f32x4 b[4];
 #pragma unroll
         for (int c = 0; c < 4 / IH_OB; ++c)                            // fc_query: 64 heads
@@ -412,15 +356,6 @@ __global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float
                     ([&](int p, const f32x4& o0, const f32x4& o1) { b[IH_OB * c + 2 * p] = o0; b[IH_OB * c + 2 * p + 1] = o1; }));
 #undef IH_STEP
         __builtin_amdgcn_s_setprio(0);
-#ifdef PPS_ABL_IH_NOSOFTMAX
-        {   // everything the MFMA phase produced stays live (static register indices only), nothing else is done with it
-            f32x4 s4 = b[0] + b[1] + b[2] + b[3];
-#pragma unroll
-            for (int kb = 0; kb < 8; ++kb) { f32x4 t0, t1; join_f16(x[kb], t0, t1); s4 += t0 + t1; }
-            if (qv && wq == 0) ((f32x4*)(pooled + qi * 256))[lane] = s4;
-        }
-        continue;
-#endif
         // ---- softmax over the 64 neighbours (4 waves x 16 rows) for each of the 64 heads: as in interp_pool_kernel -------------
         float e[16];
         {
@@ -482,6 +417,7 @@ __global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float
             ((f32x4*)(pooled + qi * 256))[lane] = s;
         }
     }
+    range_commit(amax, range);
 }
 
 // =====================================================================================================
@@ -668,7 +604,7 @@ __device__ __forceinline__ void stn_chain(float coord, f32x4 (&z)[16], const flo
 // the same chain in split precision (decoder dtype "f16x3"): conv0a stays an fp32 MFMA (K = 3), the four dense layers run as
 // three f16 products each; `wg` -> pps_pack_dense_f16x3 images of c0b, s1, s2, s3 (same byte sizes and chunk boundaries as fp32)
 __device__ __forceinline__ void stn_chain_h(float coord, f32x4 (&z)[16], const float* xyz_l, const f32x4* bias4, const f32x4* wg,
-                                            f32x4*& cur, f32x4*& nxt, int lane) {
+                                            f32x4*& cur, f32x4*& nxt, int lane, float& amax) {
     const int g = lane >> 4;
     HiLo a[2], b[2], y[4];
     {
@@ -677,19 +613,19 @@ __device__ __forceinline__ void stn_chain_h(float coord, f32x4 (&z)[16], const f
         for (int bb = 0; bb < 4; ++bb) x0[bb] = bias4[4 * bb + g];
         xyz_blocks<4>(coord, x0, xyz_l, lane);
         relu_blocks<4>(x0);
-        a[0] = split_f16(x0[0], x0[1]);
-        a[1] = split_f16(x0[2], x0[3]);
+        a[0] = split_f16_r(amax, x0[0], x0[1]);
+        a[1] = split_f16_r(amax, x0[2], x0[3]);
     }
     __builtin_amdgcn_s_setprio(PPS_PRIO_PN);
     stream_step<1024, PNT>(wg + 1024, cur, nxt, [&](const f32x4* w) {
-        dense_blocks_f16x3<2, 4, 1>(a, (const half8*)w, bias4 + 16, lane, [&](int i, const f32x4& o0, const f32x4& o1) { b[i] = split_f16(o0, o1); }); });
+        dense_blocks_f16x3<2, 4, 1>(a, (const half8*)w, bias4 + 16, lane, [&](int i, const f32x4& o0, const f32x4& o1) { b[i] = split_f16_r(amax, o0, o1); }); });
     stream_step<PCH4, PNT>(wg + 2048, cur, nxt, [&](const f32x4* w) {
-        dense_blocks_f16x3<2, 4, 1>(b, (const half8*)w, bias4 + 32, lane, [&](int i, const f32x4& o0, const f32x4& o1) { a[i] = split_f16(o0, o1); }); });
+        dense_blocks_f16x3<2, 4, 1>(b, (const half8*)w, bias4 + 32, lane, [&](int i, const f32x4& o0, const f32x4& o1) { a[i] = split_f16_r(amax, o0, o1); }); });
 #pragma unroll
     for (int h = 0; h < PN_C2N; ++h)
         stream_step<PCH4, PNT>(wg + 2048 + (h + 1) * PCH4, cur, nxt, [&](const f32x4* w) {
             dense_blocks_f16x3<2, PN_C2OB, 1>(a, (const half8*)w, bias4 + 48 + 4 * PN_C2OB * h, lane,
-                                              [&](int i, const f32x4& o0, const f32x4& o1) { y[PN_C2OB / 2 * h + i] = split_f16(o0, o1); }); });
+                                              [&](int i, const f32x4& o0, const f32x4& o1) { y[PN_C2OB / 2 * h + i] = split_f16_r(amax, o0, o1); }); });
 #pragma unroll
     for (int c = 0; c < PN_C3N - 1; ++c)
         stream_step<PCH4, PNT>(wg + 4096 + (c + 1) * PCH4, cur, nxt, [&](const f32x4* w) {
@@ -705,7 +641,10 @@ __device__ __forceinline__ void stn_chain_h(float coord, f32x4 (&z)[16], const f
 template <bool H>
 __global__ __launch_bounds__(PNT, 2) void pointnet_stn_rows_kernel(const float* __restrict__ patches, int64_t Q, int P, int pack,
                                                                    const float* __restrict__ wpack, const f32x4* __restrict__ wdense,
-                                                                   const float* __restrict__ bias, float* __restrict__ gout) {
+                                                                   const float* __restrict__ bias, float* __restrict__ gout, int* __restrict__ flag) {
+    // flag: H -- where the range guard of the split reports (pps_common.h); !H -- gate of the fp32 fallback (may be null)
+    if (!H && gate_closed(flag)) return;
+    float amax = 0.f;
     f32x4* buf0 = (f32x4*)pps_smem;
     f32x4* buf1 = buf0 + PCH4;
     float* xyz_l = (float*)(buf1 + PCH4);
@@ -736,7 +675,7 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_stn_rows_kernel(const float* 
             const int ql = n / pk.lo;
             const int64_t qq = (q0 + ql < Q) ? q0 + ql : Q - 1;
             const float coord = (g < 3) ? patches[(qq * P + pk.fb * 16 + (n % pk.lo)) * 3 + g] : 0.f;
-            if (H) stn_chain_h(coord, z, xyz_l, bias4, wg, cur, nxt, lane); else stn_chain(coord, z, xyz_l, bias4, wg, cur, nxt, lane);
+            if (H) stn_chain_h(coord, z, xyz_l, bias4, wg, cur, nxt, lane, amax); else stn_chain(coord, z, xyz_l, bias4, wg, cur, nxt, lane);
 #pragma unroll
             for (int bb = 0; bb < 16; ++bb) {
                 f32x4 m;
@@ -757,7 +696,7 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_stn_rows_kernel(const float* 
                 const int row = rb * 16 + n;
                 const int rowc = row < P ? row : P - 1;       // padded rows repeat a valid point: max unaffected
                 const float coord = (g < 3) ? patches[(qc * P + rowc) * 3 + g] : 0.f;
-                if (H) stn_chain_h(coord, z, xyz_l, bias4, wg, cur, nxt, lane); else stn_chain(coord, z, xyz_l, bias4, wg, cur, nxt, lane);
+                if (H) stn_chain_h(coord, z, xyz_l, bias4, wg, cur, nxt, lane, amax); else stn_chain(coord, z, xyz_l, bias4, wg, cur, nxt, lane);
 #pragma unroll
                 for (int bb = 0; bb < 16; ++bb)
 #pragma unroll
@@ -772,6 +711,7 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_stn_rows_kernel(const float* 
             }
         }
     }
+    if (H) range_commit(amax, flag);
 }
 
 // =====================================================================================================
@@ -786,7 +726,8 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_stn_rows_kernel(const float* 
 
 __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_kernel(const float* __restrict__ gin, int64_t Q,
                                                                 const float* __restrict__ wpack, const float* __restrict__ bias,
-                                                                float* __restrict__ trans2) {
+                                                                float* __restrict__ trans2, const int* __restrict__ gate) {
+    if (gate_closed(gate)) return;
     f32x4* buf0 = (f32x4*)pps_smem;
     f32x4* buf1 = buf0 + CH4;
     float* bias_l = (float*)(buf1 + CH4);
@@ -838,11 +779,7 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_kernel(const float* __r
             });
 #pragma unroll
             for (int t = 0; t < PB_T; ++t) {
-#ifdef PPS_ABL_NOSTORE
-                if (qvs[t] && o[t][0].x == 123.456f) {
-#else
                 if (qvs[t]) {
-#endif
                     f32x4* dst = (f32x4*)(trans2 + qcs[t] * 4096) + g;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) dst[4 * (8 * c + j)] = o[t][j];
@@ -858,7 +795,8 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_kernel(const float* __r
 // element j of lane (m, g) = trans2[q][16 ob + m][32 kb + 16 (j >> 2) + 4 g + (j & 3)]  (16 KiB per query, like the fp32 matrix):
 // the pair of output blocks (4a + 2kb, 4a + 2kb + 1) of fc3 held by lane (query n, g) IS that fragment for row a = 16 ob + m.
 __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_h_kernel(const float* __restrict__ gin, int64_t Q, const f32x4* __restrict__ w16,
-                                                                  const float* __restrict__ bias, half8* __restrict__ trans2h) {
+                                                                  const float* __restrict__ bias, half8* __restrict__ trans2h, int* __restrict__ range) {
+    float amax = 0.f;
     f32x4* buf0 = (f32x4*)pps_smem;
     f32x4* buf1 = buf0 + CH4;
     float* bias_l = (float*)(buf1 + CH4);
@@ -885,14 +823,14 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_h_kernel(const float* _
 #pragma unroll
             for (int bb = 0; bb < 16; ++bb) a[bb] = src[4 * bb];
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) ah[kb] = split_f16(a[2 * kb], a[2 * kb + 1]);
+            for (int kb = 0; kb < 8; ++kb) ah[kb] = split_f16_r(amax, a[2 * kb], a[2 * kb + 1]);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             stream_step<CH4>(wg + (c + 1) * CH4, cur, nxt, [&](const f32x4* w) {
-                dense_blocks_f16x3<8, 2, 1>(ah, (const half8*)w, bias4 + 8 * c, lane, [&](int, const f32x4& o0, const f32x4& o1) { h[c] = split_f16(o0, o1); }); });
+                dense_blocks_f16x3<8, 2, 1>(ah, (const half8*)w, bias4 + 8 * c, lane, [&](int, const f32x4& o0, const f32x4& o1) { h[c] = split_f16_r(amax, o0, o1); }); });
         stream_step<CH4>(wg + 5 * CH4, cur, nxt, [&](const f32x4* w) {
-            dense_blocks_f16x3<4, 4, 1>(h, (const half8*)w, bias4 + 32, lane, [&](int i, const f32x4& o0, const f32x4& o1) { u[i] = split_f16(o0, o1); }); });
+            dense_blocks_f16x3<4, 4, 1>(h, (const half8*)w, bias4 + 32, lane, [&](int i, const f32x4& o0, const f32x4& o1) { u[i] = split_f16_r(amax, o0, o1); }); });
         half8* dst = trans2h + qc * 1024 + g;                         // + ((ob*2 + kb)*2 + part)*64 + 4*m
 #pragma unroll 1
         for (int c = 0; c < 32; ++c) {
@@ -901,12 +839,8 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_h_kernel(const float* _
                 dense_blocks_f16x3<2, 8, 0, false>(u, (const half8*)w, bias4 + 48 + 32 * c, lane, [&](int i, const f32x4& o0, const f32x4& o1) {
                     // blocks 8c + 2i, 8c + 2i + 1: row a = 2c + (i >> 1), k-block kb = i & 1
                     const int a = 2 * c + (i >> 1), kb = i & 1;
-                    const HiLo v = split_f16(o0, o1);
-#ifdef PPS_ABL_NOSTORE
-                    if (qv && o0.x == 123.456f) {
-#else
+                    const HiLo v = split_f16_r(amax, o0, o1);
                     if (qv) {
-#endif
                         half8* d = dst + (((a >> 4) * 2 + kb) * 2) * 64 + 4 * (a & 15);
                         d[0] = v.hi;
                         d[64] = v.lo;
@@ -914,6 +848,7 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_h_kernel(const float* _
                 }); });
         }
     }
+    range_commit(amax, range);
 }
 
 // =====================================================================================================
@@ -1012,7 +947,7 @@ __device__ __forceinline__ void feat_chain(float coord, const float* __restrict_
 template <class OnLogit, class OnBlock>
 __device__ __forceinline__ void feat_chain_h(float coord, const float* __restrict__ trans2, int64_t q0, int64_t Q, int nq, int rows_per_query,
                                              const float* xyz_l, const f32x4* bias4, const f32x4* u4, float s0,
-                                             const f32x4* wg, f32x4*& cur, f32x4*& nxt, int lane, OnLogit&& on_logit, OnBlock&& on_block) {
+                                             const f32x4* wg, f32x4*& cur, f32x4*& nxt, int lane, float& amax, OnLogit&& on_logit, OnBlock&& on_block) {
     const int n = lane & 15, g = lane >> 4;
     HiLo a[2], b[2], y[4];
     {
@@ -1021,12 +956,12 @@ __device__ __forceinline__ void feat_chain_h(float coord, const float* __restric
         for (int bb = 0; bb < 4; ++bb) x0[bb] = bias4[4 * bb + g];
         xyz_blocks<4>(coord, x0, xyz_l, lane);
         relu_blocks<4>(x0);
-        a[0] = split_f16(x0[0], x0[1]);
-        a[1] = split_f16(x0[2], x0[3]);
+        a[0] = split_f16_r(amax, x0[0], x0[1]);
+        a[1] = split_f16_r(amax, x0[2], x0[3]);
     }
     __builtin_amdgcn_s_setprio(PPS_PRIO_PN);
     stream_step<1024, PNT>(wg + 1024, cur, nxt, [&](const f32x4* w) {
-        dense_blocks_f16x3<2, 4, 1>(a, (const half8*)w, bias4 + 16, lane, [&](int i, const f32x4& o0, const f32x4& o1) { b[i] = split_f16(o0, o1); }); });
+        dense_blocks_f16x3<2, 4, 1>(a, (const half8*)w, bias4 + 16, lane, [&](int i, const f32x4& o0, const f32x4& o1) { b[i] = split_f16_r(amax, o0, o1); }); });
     // feature transform with the per-query 64 x 64 matrix: three f16 products per (output block, k-block)
     f32x4 t0[4];
 #pragma unroll
@@ -1035,11 +970,7 @@ __device__ __forceinline__ void feat_chain_h(float coord, const float* __restric
 #pragma unroll 1
     for (int qi = 0; qi < nq; ++qi) {
         const int64_t qq = (q0 + qi < Q) ? q0 + qi : Q - 1;
-#ifdef PPS_ABL_T0
-        const half8* tq = (const half8*)trans2 + (qq & 63) * 1024 + 4 * n + g;  // ablation: every query reads one of 64 cache-resident matrices
-#else
         const half8* tq = (const half8*)trans2 + qq * 1024 + 4 * n + g;       // slot 4 m + g of each 1 KiB fragment block
-#endif
         const bool mine = (n / rows_per_query) == qi;
         HiLo xm[2];
 #pragma unroll
@@ -1059,10 +990,10 @@ __device__ __forceinline__ void feat_chain_h(float coord, const float* __restric
             t0[ob] = o + c;
         }
     }
-    a[0] = split_f16(t0[0], t0[1]);
-    a[1] = split_f16(t0[2], t0[3]);
+    a[0] = split_f16_r(amax, t0[0], t0[1]);
+    a[1] = split_f16_r(amax, t0[2], t0[3]);
     stream_step<PCH4, PNT>(wg + 2048, cur, nxt, [&](const f32x4* w) {
-        dense_blocks_f16x3<2, 4, 1>(a, (const half8*)w, bias4 + 32, lane, [&](int i, const f32x4& o0, const f32x4& o1) { b[i] = split_f16(o0, o1); }); });
+        dense_blocks_f16x3<2, 4, 1>(a, (const half8*)w, bias4 + 32, lane, [&](int i, const f32x4& o0, const f32x4& o1) { b[i] = split_f16_r(amax, o0, o1); }); });
     float s = 0.f;                                   // attention logit, accumulated while conv2's output blocks are still fp32
 #pragma unroll
     for (int h = 0; h < PN_C2N; ++h)
@@ -1072,7 +1003,7 @@ __device__ __forceinline__ void feat_chain_h(float coord, const float* __restric
                 const f32x4 w0 = u4[4 * bb + g], w1 = u4[4 * (bb + 1) + g];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s += w0[r] * o0[r] + w1[r] * o1[r];
-                y[PN_C2OB / 2 * h + i] = split_f16(o0, o1);
+                y[PN_C2OB / 2 * h + i] = split_f16_r(amax, o0, o1);
             }); });
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
@@ -1092,7 +1023,9 @@ template <bool H>
 __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float* __restrict__ patches, const float* __restrict__ trans2,
                                                                     int64_t Q, int P, int pack, const float* __restrict__ wpack,
                                                                     const f32x4* __restrict__ wdense, const float* __restrict__ bias,
-                                                                    float* __restrict__ xbar) {
+                                                                    float* __restrict__ xbar, int* __restrict__ flag) {
+    if (!H && gate_closed(flag)) return;
+    float amax = 0.f;
     f32x4* buf0 = (f32x4*)pps_smem;
     f32x4* buf1 = buf0 + PCH4;
     float* xyz_l = (float*)(buf1 + PCH4);
@@ -1137,7 +1070,7 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float*
                 for (int r = 0; r < 4; ++r) { a0[r] = group_sum(e * z0[r], pk.lo); a1[r] = group_sum(e * z1[r], pk.lo); }
                 if ((n % pk.lo) == 0) { ((f32x4*)row)[4 * bb + g] = a0; ((f32x4*)row)[4 * (bb + 1) + g] = a1; }
             };
-            if (H) feat_chain_h(coord, trans2, q0, Q, pk.qg, pk.lo, xyz_l, bias4, u4, s0, wg, cur, nxt, lane, on_logit, on_block);
+            if (H) feat_chain_h(coord, trans2, q0, Q, pk.qg, pk.lo, xyz_l, bias4, u4, s0, wg, cur, nxt, lane, amax, on_logit, on_block);
             else feat_chain(coord, trans2, q0, Q, pk.qg, pk.lo, xyz_l, bias4, u4, s0, wg, cur, nxt, lane, on_logit, on_block);
         }
         for (int qi = 0; qi < pk.qg; ++qi) {
@@ -1181,7 +1114,7 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float*
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { acc[bb][r] += en * z0[r]; acc[bb + 1][r] += en * z1[r]; }
                 };
-                if (H) feat_chain_h(coord, trans2, qc, Q, 1, 16, xyz_l, bias4, u4, s0, wg, cur, nxt, lane, on_logit, on_block);
+                if (H) feat_chain_h(coord, trans2, qc, Q, 1, 16, xyz_l, bias4, u4, s0, wg, cur, nxt, lane, amax, on_logit, on_block);
                 else feat_chain(coord, trans2, qc, Q, 1, 16, xyz_l, bias4, u4, s0, wg, cur, nxt, lane, on_logit, on_block);
             }
             const float inv = 1.f / row16_sum(ssum);
@@ -1189,6 +1122,7 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float*
             if (qv) ((f32x4*)(xbar + q * 256))[4 * n + g] = acc[0] * inv;
         }
     }
+    if (H) range_commit(amax, flag);
 }
 
 // =====================================================================================================
@@ -1200,7 +1134,11 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float*
 
 __global__ __launch_bounds__(NT, 2) void decode_tail_kernel(const float* __restrict__ pooled, const float* __restrict__ xbar, int64_t Q,
                                                             const float* __restrict__ wpack, const float* __restrict__ bias,
-                                                            float* __restrict__ logits, float* __restrict__ occ) {
+                                                            float* __restrict__ logits, float* __restrict__ occ, int* __restrict__ gate) {
+    // gate (may be null): [0] = a split-precision kernel of this chunk left the f16 range -> this launch recomputes the chunk in fp32;
+    // [1] counts such chunks (read by DecoderPlan.range_fallbacks())
+    if (gate_closed(gate)) return;
+    if (gate != nullptr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(gate + 1, 1);
     f32x4* buf0 = (f32x4*)pps_smem;
     f32x4* buf1 = buf0 + CH4;
     float* bias_l = (float*)(buf1 + CH4);
@@ -1261,7 +1199,8 @@ __global__ __launch_bounds__(NT, 2) void decode_tail_kernel(const float* __restr
 // output blocks 2c, 2c+1 is finished before the next one starts: two live accumulator blocks instead of sixteen), then [L2][L3].
 __global__ __launch_bounds__(NT, 2) void decode_tail_h_kernel(const float* __restrict__ pooled, const float* __restrict__ xbar, int64_t Q,
                                                               const f32x4* __restrict__ w16, const float* __restrict__ bias,
-                                                              float* __restrict__ logits, float* __restrict__ occ) {
+                                                              float* __restrict__ logits, float* __restrict__ occ, int* __restrict__ range) {
+    float amax = 0.f;
     f32x4* buf0 = (f32x4*)pps_smem;
     f32x4* buf1 = buf0 + CH4;
     float* bias_l = (float*)(buf1 + CH4);
@@ -1288,8 +1227,8 @@ __global__ __launch_bounds__(NT, 2) void decode_tail_h_kernel(const float* __res
             const f32x4* sx = (const f32x4*)(xbar + qc * 256) + g;
 #pragma unroll
             for (int kb = 0; kb < 8; ++kb) {
-                p[kb] = split_f16(sp[4 * (2 * kb)], sp[4 * (2 * kb + 1)]);
-                x[kb] = split_f16(sx[4 * (2 * kb)], sx[4 * (2 * kb + 1)]);
+                p[kb] = split_f16_r(amax, sp[4 * (2 * kb)], sp[4 * (2 * kb + 1)]);
+                x[kb] = split_f16_r(amax, sx[4 * (2 * kb)], sx[4 * (2 * kb + 1)]);
             }
         }
         HiLo y[8];
@@ -1299,12 +1238,12 @@ __global__ __launch_bounds__(NT, 2) void decode_tail_h_kernel(const float* __res
             stream_step<CH4>(wg + (2 * c + 1) * CH4, cur, nxt, [&](const f32x4* w) {             // Wa . pooled + bias, no activation yet
                 dense_blocks_f16x3<8, 2, 0>(p, (const half8*)w, bias4 + 8 * c, lane, [&](int, const f32x4& o0, const f32x4& o1) { h[0] = o0; h[1] = o1; }); });
             stream_step<CH4>(wg + (2 * c + 2) * CH4, cur, nxt, [&](const f32x4* w) {             // + Wb . xbar, ReLU
-                dense_blocks_f16x3<8, 2, 1, true, true>(x, (const half8*)w, bias4, lane, [&](int, const f32x4& o0, const f32x4& o1) { y[c] = split_f16(o0, o1); }, h); });
+                dense_blocks_f16x3<8, 2, 1, true, true>(x, (const half8*)w, bias4, lane, [&](int, const f32x4& o0, const f32x4& o1) { y[c] = split_f16_r(amax, o0, o1); }, h); });
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c)
             stream_step<CH4>(wg + (c + 17) * CH4, cur, nxt, [&](const f32x4* w) {
-                dense_blocks_f16x3<8, 2, 1>(y, (const half8*)w, bias4 + 64 + 8 * c, lane, [&](int, const f32x4& o0, const f32x4& o1) { p[c] = split_f16(o0, o1); }); });
+                dense_blocks_f16x3<8, 2, 1>(y, (const half8*)w, bias4 + 64 + 8 * c, lane, [&](int, const f32x4& o0, const f32x4& o1) { p[c] = split_f16_r(amax, o0, o1); }); });
         f32x4 o[2];
         stream_step<CH4>(wg, cur, nxt, [&](const f32x4* w) {
             dense_blocks_f16x3<8, 2, 0>(p, (const half8*)w, bias4 + 128, lane, [&](int, const f32x4& o0, const f32x4& o1) { o[0] = o0; o[1] = o1; }); });
@@ -1319,6 +1258,7 @@ __global__ __launch_bounds__(NT, 2) void decode_tail_h_kernel(const float* __res
             }
         }
     }
+    range_commit(amax, range);
 }
 
 // =====================================================================================================
@@ -1372,35 +1312,73 @@ static PnSplit pn_split(int64_t q, int p) {
 
 template <bool H>
 static int launch_stn_rows(const float* patches, int64_t q, int p, const float* wpack, const void* wdense, const float* bias, float* g,
-                           void* stream) {
+                           int* flag, void* stream) {
     static int once = set_lds(pointnet_stn_rows_kernel<H>, PA_LDS_BYTES);
     (void)once;
     const PnSplit sp = pn_split(q, p);
     if (sp.q_packed > 0)
         hipLaunchKernelGGL(pointnet_stn_rows_kernel<H>, dim3(sp.grid_packed), dim3(PNT), PA_LDS_BYTES, (hipStream_t)stream, patches,
-                           sp.q_packed, p, 1, wpack, (const f32x4*)wdense, bias, g);
+                           sp.q_packed, p, 1, wpack, (const f32x4*)wdense, bias, g, flag);
     if (q > sp.q_packed)
         hipLaunchKernelGGL(pointnet_stn_rows_kernel<H>, dim3(sp.grid_rest), dim3(PNT), PA_LDS_BYTES, (hipStream_t)stream,
-                           patches + sp.q_packed * p * 3, q - sp.q_packed, p, sp.rest_mode, wpack, (const f32x4*)wdense, bias, g + sp.q_packed * 256);
+                           patches + sp.q_packed * p * 3, q - sp.q_packed, p, sp.rest_mode, wpack, (const f32x4*)wdense, bias, g + sp.q_packed * 256, flag);
     return PPS_LAUNCH_CHECK();
 }
 
 template <bool H>
 static int launch_feat_rows(const float* patches, const float* trans2, int64_t q, int p, const float* wpack, const void* wdense,
-                            const float* bias, float* xbar, void* stream) {
+                            const float* bias, float* xbar, int* flag, void* stream) {
     static int once = set_lds(pointnet_feat_rows_kernel<H>, PC_LDS_BYTES);
     (void)once;
     const PnSplit sp = pn_split(q, p);
     if (sp.q_packed > 0)
         hipLaunchKernelGGL(pointnet_feat_rows_kernel<H>, dim3(sp.grid_packed), dim3(PNT), PC_LDS_BYTES, (hipStream_t)stream, patches,
-                           trans2, sp.q_packed, p, 1, wpack, (const f32x4*)wdense, bias, xbar);
+                           trans2, sp.q_packed, p, 1, wpack, (const f32x4*)wdense, bias, xbar, flag);
     if (q > sp.q_packed)
         hipLaunchKernelGGL(pointnet_feat_rows_kernel<H>, dim3(sp.grid_rest), dim3(PNT), PC_LDS_BYTES, (hipStream_t)stream,
                            patches + sp.q_packed * p * 3, trans2 + sp.q_packed * 4096, q - sp.q_packed, p, sp.rest_mode, wpack, (const f32x4*)wdense, bias,
-                           xbar + sp.q_packed * 256);
+                           xbar + sp.q_packed * 256, flag);
     return PPS_LAUNCH_CHECK();
 }
 
+
+// ---- launchers with the range-guard plumbing (the extern "C" entry points below are thin wrappers) ----------------------------------------------
+// gate (fp32 kernels): null = run; otherwise the launch returns at once unless gate[0] != 0.  range (split-precision kernels): where a kernel reports
+// that an activation left the f16 range (null = not reported).
+static int interp_pool_f32_impl(const float* G, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
+                                const float* wpack, const float* bias, float* pooled, const int* gate, void* stream) {
+    if (q < 0 || k < 1 || k > 64) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    if (!G || !pts || !query || !idx || !wpack || !bias || !pooled) return PPS_ERR_ARG;
+    static int once = set_lds(interp_pool_kernel, IP_LDS_BYTES);
+    (void)once;
+    hipLaunchKernelGGL(interp_pool_kernel, dim3(grid_for((q + NW / 4 - 1) / (NW / 4))), dim3(NT), IP_LDS_BYTES, (hipStream_t)stream,
+                       G, pts, query, idx, q, k, wpack, bias, pooled, gate);
+    return PPS_LAUNCH_CHECK();
+}
+
+static int stn_fc_f32_impl(const float* g, int64_t q, const float* wpack, const float* bias, float* trans2, const int* gate, void* stream) {
+    if (q < 0) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    if (!g || !wpack || !bias || !trans2) return PPS_ERR_ARG;
+    static int once = set_lds(pointnet_stn_fc_kernel, PB_LDS_BYTES);
+    (void)once;
+    hipLaunchKernelGGL(pointnet_stn_fc_kernel, dim3(grid_for((q + NW * 16 * PB_T - 1) / (NW * 16 * PB_T))), dim3(NT), PB_LDS_BYTES, (hipStream_t)stream,
+                       g, q, wpack, bias, trans2, gate);
+    return PPS_LAUNCH_CHECK();
+}
+
+static int decode_tail_f32_impl(const float* pooled, const float* xbar, int64_t q, const float* wpack, const float* bias,
+                                float* logits, float* occ, int* gate, void* stream) {
+    if (q < 0) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    if (!pooled || !xbar || !wpack || !bias || !logits) return PPS_ERR_ARG;
+    static int once = set_lds(decode_tail_kernel, TL_LDS_BYTES);
+    (void)once;
+    hipLaunchKernelGGL(decode_tail_kernel, dim3(grid_for((q + NW * 16 - 1) / (NW * 16))), dim3(NT), TL_LDS_BYTES, (hipStream_t)stream,
+                       pooled, xbar, q, wpack, bias, logits, occ, gate);
+    return PPS_LAUNCH_CHECK();
+}
 
 extern "C" {
 
@@ -1415,14 +1393,6 @@ int pps_debug_occupancy(int which) {
     return n;
 }
 int pps_device_cu_count(void) { return cu_count(); }
-#ifdef PPS_TRACE
-// development aid: read (and clear) the cycle sums of PPS_TRACE builds
-int pps_debug_trace_read(unsigned long long* host8) {
-    if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(pps_trace_acc), 64) != hipSuccess) return 1;
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    return hipMemcpyToSymbol(HIP_SYMBOL(pps_trace_acc), z, 64) == hipSuccess ? 0 : 1;
-}
-#endif
 
 int pps_rows_dense256_f32(const float* in, int64_t rs, int64_t cs, int64_t m, const float* wpack, const float* bias,
                           float* out, void* stream) {
@@ -1439,18 +1409,11 @@ int pps_rows_dense256_f32(const float* in, int64_t rs, int64_t cs, int64_t m, co
 
 int pps_interp_pool_f32(const float* G, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
                         const float* wpack, const float* bias, float* pooled, void* stream) {
-    if (q < 0 || k < 1 || k > 64) return PPS_ERR_ARG;
-    if (q == 0) return PPS_OK;
-    if (!G || !pts || !query || !idx || !wpack || !bias || !pooled) return PPS_ERR_ARG;
-    static int once = set_lds(interp_pool_kernel, IP_LDS_BYTES);
-    (void)once;
-    hipLaunchKernelGGL(interp_pool_kernel, dim3(grid_for((q + NW / 4 - 1) / (NW / 4))), dim3(NT), IP_LDS_BYTES, (hipStream_t)stream,
-                       G, pts, query, idx, q, k, wpack, bias, pooled);
-    return PPS_LAUNCH_CHECK();
+    return interp_pool_f32_impl(G, pts, query, idx, q, k, wpack, bias, pooled, nullptr, stream);
 }
 
 int pps_interp_pool_f16x3(const float* G, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
-                          const float* wxyz, const void* w16, const float* bias, float* pooled, void* stream) {
+                          const float* wxyz, const void* w16, const float* bias, float* pooled, int32_t* range_flag, void* stream) {
     if (q < 0 || k < 1 || k > 64) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
     if (!G || !pts || !query || !idx || !wxyz || !w16 || !bias || !pooled) return PPS_ERR_ARG;
@@ -1462,7 +1425,7 @@ int pps_interp_pool_f16x3(const float* G, const float* pts, const float* query, 
     const int64_t wgs = (int64_t)cus * IH_WG_PER_CU;                  // one 8-wave workgroup per CU (IH_NT = 512)
     const int grid = (int)(ntiles < wgs ? ntiles : wgs);
     hipLaunchKernelGGL(interp_pool_f16x3_kernel, dim3(grid), dim3(IH_NT), IH_LDS_BYTES, (hipStream_t)stream,
-                       G, pts, query, idx, q, k, wxyz, (const f32x4*)w16, bias, pooled);
+                       G, pts, query, idx, q, k, wxyz, (const f32x4*)w16, bias, pooled, (int*)range_flag);
     return PPS_LAUNCH_CHECK();
 }
 
@@ -1485,18 +1448,11 @@ int pps_pointnet_stn_rows_f32(const float* patches, int64_t q, int p, const floa
     if (q < 0 || p < 1) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
     if (!patches || !wpack || !bias || !g) return PPS_ERR_ARG;
-    return launch_stn_rows<false>(patches, q, p, wpack, wpack + PA_W_XYZ, bias, g, stream);
+    return launch_stn_rows<false>(patches, q, p, wpack, wpack + PA_W_XYZ, bias, g, nullptr, stream);
 }
 
 int pps_pointnet_stn_fc_f32(const float* g, int64_t q, const float* wpack, const float* bias, float* trans2, void* stream) {
-    if (q < 0) return PPS_ERR_ARG;
-    if (q == 0) return PPS_OK;
-    if (!g || !wpack || !bias || !trans2) return PPS_ERR_ARG;
-    static int once = set_lds(pointnet_stn_fc_kernel, PB_LDS_BYTES);
-    (void)once;
-    hipLaunchKernelGGL(pointnet_stn_fc_kernel, dim3(grid_for((q + NW * 16 * PB_T - 1) / (NW * 16 * PB_T))), dim3(NT), PB_LDS_BYTES, (hipStream_t)stream,
-                       g, q, wpack, bias, trans2);
-    return PPS_LAUNCH_CHECK();
+    return stn_fc_f32_impl(g, q, wpack, bias, trans2, nullptr, stream);
 }
 
 int pps_pointnet_feat_rows_f32(const float* patches, const float* trans2, int64_t q, int p, const float* wpack,
@@ -1504,57 +1460,53 @@ int pps_pointnet_feat_rows_f32(const float* patches, const float* trans2, int64_
     if (q < 0 || p < 1) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
     if (!patches || !trans2 || !wpack || !bias || !xbar) return PPS_ERR_ARG;
-    return launch_feat_rows<false>(patches, trans2, q, p, wpack, wpack + PC_W_XYZ, bias, xbar, stream);
+    return launch_feat_rows<false>(patches, trans2, q, p, wpack, wpack + PC_W_XYZ, bias, xbar, nullptr, stream);
 }
 
 /* Split-precision PointNet branch ("f16x3"): w16[0..2] = f16x3 images of (c0b, s1, s2, s3), (fc1, fc2, fc3), (c0b, c1, c2, c3); the fp32
  * images supply the xyz layers and the biases.  trans2 (q x 16 KiB of scratch) holds the pre-split fragments between the kernels. */
 int pps_pointnet_f16x3(const float* patches, int64_t q, int p, const float* const* weights /* [2..7] of the decode array */,
-                       const void* const* w16, float* g, float* trans2, float* xbar, void* const* events, void* stream) {
+                       const void* const* w16, float* g, float* trans2, float* xbar, int32_t* range_flag, void* const* events, void* stream) {
     if (q < 0 || p < 1) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
     if (!patches || !weights || !w16 || !w16[0] || !w16[1] || !w16[2] || !g || !trans2 || !xbar) return PPS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    int rc = launch_stn_rows<true>(patches, q, p, weights[0], w16[0], weights[1], g, stream);
+    int* range = (int*)range_flag;
+    int rc = launch_stn_rows<true>(patches, q, p, weights[0], w16[0], weights[1], g, range, stream);
     if (events && events[0]) hipEventRecord((hipEvent_t)events[0], st);
     if (rc != PPS_OK) return rc;
     static int once = set_lds(pointnet_stn_fc_h_kernel, PB_LDS_BYTES);
     (void)once;
     hipLaunchKernelGGL(pointnet_stn_fc_h_kernel, dim3(grid_for((q + NW * 16 - 1) / (NW * 16))), dim3(NT), PB_LDS_BYTES, st, g, q,
-                       (const f32x4*)w16[1], weights[3], (half8*)trans2);
+                       (const f32x4*)w16[1], weights[3], (half8*)trans2, range);
     if (events && events[1]) hipEventRecord((hipEvent_t)events[1], st);
     if (hipGetLastError() != hipSuccess) return PPS_ERR_LAUNCH;
-    rc = launch_feat_rows<true>(patches, trans2, q, p, weights[4], w16[2], weights[5], xbar, stream);
+    rc = launch_feat_rows<true>(patches, trans2, q, p, weights[4], w16[2], weights[5], xbar, range, stream);
     if (events && events[2]) hipEventRecord((hipEvent_t)events[2], st);
     return rc;
 }
 
 int pps_decode_tail_f32(const float* pooled, const float* xbar, int64_t q, const float* wpack, const float* bias,
                         float* logits, float* occ, void* stream) {
-    if (q < 0) return PPS_ERR_ARG;
-    if (q == 0) return PPS_OK;
-    if (!pooled || !xbar || !wpack || !bias || !logits) return PPS_ERR_ARG;
-    static int once = set_lds(decode_tail_kernel, TL_LDS_BYTES);
-    (void)once;
-    hipLaunchKernelGGL(decode_tail_kernel, dim3(grid_for((q + NW * 16 - 1) / (NW * 16))), dim3(NT), TL_LDS_BYTES, (hipStream_t)stream,
-                       pooled, xbar, q, wpack, bias, logits, occ);
-    return PPS_LAUNCH_CHECK();
+    return decode_tail_f32_impl(pooled, xbar, q, wpack, bias, logits, occ, nullptr, stream);
 }
 
 int pps_decode_tail_f16x3(const float* pooled, const float* xbar, int64_t q, const void* w16, const float* bias, float* logits, float* occ,
-                          void* stream) {
+                          int32_t* range_flag, void* stream) {
     if (q < 0) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
     if (!pooled || !xbar || !w16 || !bias || !logits) return PPS_ERR_ARG;
     static int once = set_lds(decode_tail_h_kernel, TL_LDS_BYTES);
     (void)once;
     hipLaunchKernelGGL(decode_tail_h_kernel, dim3(grid_for((q + NW * 16 - 1) / (NW * 16))), dim3(NT), TL_LDS_BYTES, (hipStream_t)stream,
-                       pooled, xbar, q, (const f32x4*)w16, bias, logits, occ);
+                       pooled, xbar, q, (const f32x4*)w16, bias, logits, occ, (int*)range_flag);
     return PPS_LAUNCH_CHECK();
 }
 
-/* The whole decoder of one query chunk in one call: the five launches above on `stream`, intermediates in caller scratch. */
-size_t pps_decode_ws_bytes(int64_t q) { return q < 0 ? 0 : (size_t)q * (256 + 256 + 4096 + 256) * sizeof(float); }
+/* The whole decoder of one query chunk in one call: the five launches above on `stream`, intermediates in caller scratch (the first 64 bytes of it
+ * hold the range-guard words of the split-precision path: [0] flag of the current chunk, [1] number of chunks that fell back to fp32). */
+#define PPS_DECODE_WS_HEAD 64
+size_t pps_decode_ws_bytes(int64_t q) { return q < 0 ? 0 : (size_t)q * (256 + 256 + 4096 + 256) * sizeof(float) + PPS_DECODE_WS_HEAD; }
 
 static int decode_fwd(const float* table, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
                       const float* patches, int p, const float* const* weights, float* logits, float* occ, void* ws, void* const* events,
@@ -1566,18 +1518,22 @@ static int decode_fwd(const float* table, const float* pts, const float* query, 
     if (!weights || !ws || !logits) return PPS_ERR_ARG;
     for (int i = 0; i < 10; ++i)
         if (!weights[i]) return PPS_ERR_ARG;
-    float* pooled = (float*)ws;
+    int* guard = (int*)ws;
+    float* pooled = (float*)ws + PPS_DECODE_WS_HEAD / sizeof(float);
     float* g = pooled + q * 256;
     float* trans2 = g + q * 256;
     float* xbar = trans2 + q * 4096;
     hipStream_t st = (hipStream_t)stream;
+    const bool split = interp_w16 || pn16 || (w16 && w16[4]);
+    // split precision: the chunk's range flag starts at zero (the fall-back counter guard[1] is left alone)
+    if (split && hipMemsetAsync(guard, 0, sizeof(int), st) != hipSuccess) return PPS_ERR_LAUNCH;
 #define PPS_MARK(i) do { if (events && events[i] && hipEventRecord((hipEvent_t)events[i], st) != hipSuccess) return PPS_ERR_LAUNCH; } while (0)
     PPS_MARK(0);
-    int rc = interp_w16 ? pps_interp_pool_f16x3(table, pts, query, idx, q, k, weights[0], interp_w16, weights[1], pooled, stream)
+    int rc = interp_w16 ? pps_interp_pool_f16x3(table, pts, query, idx, q, k, weights[0], interp_w16, weights[1], pooled, guard, stream)
                         : pps_interp_pool_f32(table, pts, query, idx, q, k, weights[0], weights[1], pooled, stream);
     PPS_MARK(1);
     if (pn16) {
-        if (rc == PPS_OK) rc = pps_pointnet_f16x3(patches, q, p, weights + 2, w16 + 1, g, trans2, xbar, events ? events + 2 : nullptr, stream);
+        if (rc == PPS_OK) rc = pps_pointnet_f16x3(patches, q, p, weights + 2, w16 + 1, g, trans2, xbar, guard, events ? events + 2 : nullptr, stream);
     } else {
         if (rc == PPS_OK) rc = pps_pointnet_stn_rows_f32(patches, q, p, weights[2], weights[3], g, stream);
         PPS_MARK(2);
@@ -1587,10 +1543,20 @@ static int decode_fwd(const float* table, const float* pts, const float* query, 
         PPS_MARK(4);
     }
     if (rc == PPS_OK)
-        rc = (w16 && w16[4]) ? pps_decode_tail_f16x3(pooled, xbar, q, w16[4], weights[9], logits, occ, stream)
+        rc = (w16 && w16[4]) ? pps_decode_tail_f16x3(pooled, xbar, q, w16[4], weights[9], logits, occ, guard, stream)
                              : pps_decode_tail_f32(pooled, xbar, q, weights[8], weights[9], logits, occ, stream);
     PPS_MARK(5);
 #undef PPS_MARK
+    if (split && rc == PPS_OK) {
+        // Range guard: the exact-fp32 kernels of the same chunk, each returning at once unless a split-precision kernel above raised guard[0]
+        // (an activation beyond +-65504, which f16(x) cannot hold).  Normal chunks pay five empty launches (~12 us of 5 ms); a chunk that left
+        // the range is recomputed in fp32 on the device, no host round trip, and counted in guard[1].
+        rc = interp_pool_f32_impl(table, pts, query, idx, q, k, weights[0], weights[1], pooled, guard, stream);
+        if (rc == PPS_OK) rc = launch_stn_rows<false>(patches, q, p, weights[2], weights[2] + PA_W_XYZ, weights[3], g, guard, stream);
+        if (rc == PPS_OK) rc = stn_fc_f32_impl(g, q, weights[4], weights[5], trans2, guard, stream);
+        if (rc == PPS_OK) rc = launch_feat_rows<false>(patches, trans2, q, p, weights[6], weights[6] + PC_W_XYZ, weights[7], xbar, guard, stream);
+        if (rc == PPS_OK) rc = decode_tail_f32_impl(pooled, xbar, q, weights[8], weights[9], logits, occ, guard, stream);
+    }
     return rc;
 }
 

@@ -15,16 +15,14 @@ __global__ __launch_bounds__(256) void dilate_axis_kernel(const uint8_t* __restr
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i0 >= total) return;
     if (stride == 1) {
-        // the contiguous axis: the four voxels of this thread share their windows
-        const int c0 = (int)(i0 % extent);
-        const int64_t row = i0 - c0;
+        // the contiguous axis: row and column are taken per voxel (extent need not be a multiple of 4, and may be smaller than 4: the four
+        // voxels of a thread can then span more than two rows)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t i = i0 + j;
             if (i >= total) break;
-            // (extent need not be a multiple of 4: voxel i may sit in the next row)
-            const int c = (c0 + j) % extent;
-            const int64_t base = (c0 + j < extent) ? row : row + extent;
+            const int c = (int)(i % extent);
+            const int64_t base = i - c;
             const int lo = c - r < 0 ? 0 : c - r, hi = c + r >= extent ? extent - 1 : c + r;
             uint8_t v = 0;
             for (int k = lo; k <= hi; ++k) v |= src[base + k];
@@ -32,8 +30,9 @@ __global__ __launch_bounds__(256) void dilate_axis_kernel(const uint8_t* __restr
         }
         return;
     }
-    if (i0 + 3 < total && (stride & 3) == 0 && (i0 & 3) == 0) {
-        // strided axis, stride a multiple of 4: the four voxels are neighbours along z with the same coordinate on this axis -> 32-bit accesses
+    if (i0 + 3 < total && (stride & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 3) == 0) {
+        // strided axis, stride a multiple of 4, both masks 4-byte aligned (a bool tensor with a storage offset need not be): the four voxels are
+        // neighbours along z with the same coordinate on this axis -> 32-bit accesses
         const int c = (int)((i0 / stride) % extent);
         const int lo = c - r < 0 ? -c : -r, hi = c + r >= extent ? extent - 1 - c : r;
         unsigned v = 0;

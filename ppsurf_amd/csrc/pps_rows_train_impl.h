@@ -444,11 +444,7 @@ __global__ __launch_bounds__(NT, 1) void rows_dw_kernel(const DwArgs a) {
             const u32x4 q = live ? rg[it] : u32x4{0, 0, 0, 0};
             float e[8] = {lo16(q.x), hi16(q.x), lo16(q.y), hi16(q.y), lo16(q.z), hi16(q.z), lo16(q.w), hi16(q.w)};
             u32x4 p = q;
-#ifdef PPS_ABL_DW_NOMATH
-            if constexpr (false) {
-#else
             if constexpr (HAS_Y) {
-#endif
                 const u32x4 q2 = ry[it];
                 const float yv[8] = {lo16(q2.x), hi16(q2.x), lo16(q2.y), hi16(q2.y), lo16(q2.z), hi16(q2.z), lo16(q2.w), hi16(q2.w)};
 #pragma unroll
@@ -468,11 +464,7 @@ __global__ __launch_bounds__(NT, 1) void rows_dw_kernel(const DwArgs a) {
             const bool live = r0 + row < a.rows;
             u32x4 p = live ? rx[it] : u32x4{0, 0, 0, 0};
             if (relu_only) p = relu_bf16x8(p);
-#ifdef PPS_ABL_DW_NOMATH
-            if (false) {
-#else
             if (has_aff) {
-#endif
                 float e[8] = {lo16(p.x), hi16(p.x), lo16(p.y), hi16(p.y), lo16(p.z), hi16(p.z), lo16(p.w), hi16(p.w)};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) e[j] = live ? fmaxf(__builtin_fmaf(e[j], isc[j * (CI / 8) + ch], ish[j * (CI / 8) + ch]), in_floor) : 0.f;
@@ -535,16 +527,12 @@ __global__ __launch_bounds__(NT, 1) void rows_dw_kernel(const DwArgs a) {
         stage(ra, 0, step);
         if (step + 2 < s_end) fetch(ra, step + 2);
         __syncthreads();                                            // also orders: the products of the previous step (other buffer) precede the next stage into it
-#ifndef PPS_ABL_DW_NOPROD
         products(0);
-#endif
         if (step + 1 < s_end) {
             stage(rb, 1, step + 1);
             if (step + 3 < s_end) fetch(rb, step + 3);
             __syncthreads();
-#ifndef PPS_ABL_DW_NOPROD
             products(1);
-#endif
         }
     }
 

@@ -302,11 +302,28 @@ __global__ __launch_bounds__(VS_NT) void voxel_sample_big_kernel(const float* __
                     else if (h > lo) state[i] &= 1;
                 }
             __syncthreads();
-            if (tid == 0)
-                for (int i = 0; i < n; ++i)
+            {
+                // ties (priority == lo) are taken in index order until `tie_left` are found: a block-wide prefix count over contiguous index
+                // ranges instead of one thread walking all n state bytes
+                const int tper = (n + VS_NT - 1) / VS_NT, t0 = min(n, tid * tper), t1 = min(n, t0 + tper);
+                int c = 0;
+                for (int i = t0; i < t1; ++i) c += ((state[i] & 2) && !(state[i] & 4)) ? 1 : 0;
+                offs[tid + 1] = c;
+                if (tid == 0) offs[0] = 0;
+                __threadfence_block();
+                __syncthreads();
+                if (tid == 0)
+                    for (int i = 1; i <= VS_NT; ++i) offs[i] += offs[i - 1];
+                __threadfence_block();
+                __syncthreads();
+                int before = offs[tid];
+                const int left = tie_left;
+                for (int i = t0; i < t1; ++i)
                     if ((state[i] & 2) && !(state[i] & 4)) {
-                        if (tie_left > 0) { state[i] = 4; --tie_left; } else state[i] &= 1;
+                        if (before < left) state[i] = 4; else state[i] &= 1;
+                        ++before;
                     }
+            }
             __syncthreads();
 #undef VS_PRIO
             count = target;

@@ -153,6 +153,14 @@ class DecoderPlan:
         self.w = {k: torch.from_numpy(v).to(self.device) for k, v in host.items()}
         self.w16 = None
         if self.dtype == 'f16x3':
+            split_layers = [w2, w3, wq, c0b[0], s1[0], s2[0], s3[0], f1[0], f2[0], f3w, c1[0], c2[0], c3[0], wa, wb, l2[0], l3w]
+            wmax = max(float(np.abs(m_).max()) for m_ in split_layers)
+            if not wmax < 65504.0:
+                # a weight that f16 cannot hold: the split W = hi + lo does not exist.  (Activations are guarded on the device, see decode().)
+                import warnings
+                warnings.warn('decoder dtype f16x3 needs |weight| < 65504 (largest: {:.3g}); using the exact fp32 kernels'.format(wmax))
+                self.dtype = 'f32'
+        if self.dtype == 'f16x3':
             sets = [[w2, w3, wq], [c0b[0], s1[0], s2[0], s3[0]], [f1[0], f2[0], f3w], [c0b[0], c1[0], c2[0], c3[0]]]
             imgs = [np.concatenate([pack_dense_f16x3(m) for m in ms]) for ms in sets]
             # tail: the two halves of the 512 -> 256 layer alternate in 32 KiB chunks (two output blocks each), then L2, L3 (pps_decode_tail_f16x3)
@@ -168,7 +176,11 @@ class DecoderPlan:
         t = self._scratch.get(name)
         n = int(np.prod(shape))
         if t is None or t.numel() < n or t.dtype != dtype:
+            old = t
             t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+            t[:16].zero_()                                     # head of the decoder workspace: range-guard words (include/ppsurf_amd.h)
+            if old is not None and old.dtype == dtype and old.numel() >= 16 and t.numel() >= 16:
+                t[:16].copy_(old[:16])                         # the fall-back counter survives a growing workspace
             self._scratch[name] = t
         return t[:n].view(shape)
 
@@ -177,7 +189,7 @@ class DecoderPlan:
         trans2 [q,4096], xbar [q,256] -- for tests and debugging."""
         ws = self.scratch('decode_ws', (_lib.lib().pps_decode_ws_bytes(q) // 4,))
         sizes = (('pooled', C), ('g', C), ('trans2', 4096), ('xbar', C))
-        out, off = {}, 0
+        out, off = {}, 16                                      # 64 bytes of range-guard words first
         for name, width in sizes:
             out[name] = ws[off:off + q * width].view(q, width)
             off += q * width
@@ -222,6 +234,12 @@ class DecoderPlan:
         else:
             _lib.check(L.pps_decode_fwd_events_f32(*args, stage_events, st), 'pps_decode_fwd_events_f32')
         return logits, occ
+
+    def range_fallbacks(self):
+        """Number of chunks the split-precision path handed to the fp32 kernels so far because an activation left the f16 range (|x| > 65504);
+        always 0 for dtype 'f32'.  Reads one device word (synchronises)."""
+        ws = self._scratch.get('decode_ws')
+        return 0 if ws is None or self.w16 is None else int(ws[:16].view(torch.int32)[1])
 
 
 class ChunkPipeline:

@@ -272,6 +272,10 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
             loss = model.training_step(batch, bi)
         scaler.scale(loss).backward()
         model.on_after_backward()
+        if buckets.defer:
+            # this body may be recorded into a HIP graph: every bucket -> flat copy has to be part of the recording, also for buckets the hooks
+            # did not complete (a bucket holding a parameter without gradient), or a replay would all-reduce buffers nobody filled
+            buckets.pack_all()
 
     def apply_step():
         buckets.finish()

@@ -4,6 +4,7 @@ xGMI on the GPU box, 'gloo' in the CPU tests).
 Queries are independent given the replicated per-shape state (cloud + per-point table, ~104 MB), so the data path needs a
 single exchange per growth round: a variable-length all-gather of 4 bytes per query."""
 import contextlib
+import os
 
 import torch
 
@@ -174,7 +175,6 @@ class GradBuckets:
             the single-GPU boxes available here -- so the deferred collectives stay serial behind the step (~1 ms for 55 MB over xGMI).
         comm_dtype (default: environment PPS_GRAD_BUCKET_DTYPE, e.g. 'bf16'): the buckets are summed over the ranks in this type (half the xGMI
             bytes, 27.5 instead of 55 MB per step); the flat fp32 buffers the optimizer reads stay fp32."""
-        import os
         import torch.distributed as dist
         self.dist = dist
         self.defer = bool(defer)                    # True: no collective inside backward (fit with the forward / backward replayed as a HIP graph)
@@ -205,30 +205,60 @@ class GradBuckets:
             self.flat.append(flat)
             self.views.append(views)
         self.low = [torch.empty_like(f, dtype=comm_dtype) for f in self.flat] if comm_dtype is not None else None
+        self._expect = None                         # per bucket: parameters expected to get a gradient (known after the first finish())
+        self._use_expect = os.environ.get('PPS_GRAD_EXPECT', '1') != '0'
+        self._static = None                         # host copy of the first step's global "got a gradient" mask
+        self._static_dev = None
+        self._mismatch = None                       # device flag: a later step's global mask differed from the first step's
+        self._steps = 0
         self._reset()
 
     def _reset(self):
-        self.pending = [len(b) for b in self.buckets]
+        # a bucket is complete when every parameter of it that is EXPECTED to get a gradient has one.  Before the first finish() that is every
+        # parameter; afterwards the parameters no rank touched in the first step (POCO's encoder.cv5 / bn5 never get a gradient: the train_poco
+        # fixture lists them under 'unused') are no longer waited for -- otherwise their bucket would never complete inside backward and, with
+        # collectives issued in bucket order, neither would any bucket behind it
+        if self._expect is None:
+            self.pending = [len(b) for b in self.buckets]
+        else:
+            self.pending = list(self._expect)
         self.handles = []
         self.launched = [False] * len(self.buckets)
         self.touched = set()
         self._replay = False
         self._next = 0                              # first bucket whose collective has not been issued yet
+        self._armed = True
 
     def _hook(self, bi):
         def fn(p):
+            if not self._armed:                     # not between zero() and finish(): a backward pass this bucket set is not part of
+                return
+            if self.launched[bi]:
+                # the bucket went out without this gradient: it can only happen when a parameter that got no gradient on any rank in the first
+                # step gets one now.  Failing loudly beats stepping on a gradient that missed the all-reduce.
+                raise RuntimeError('GradBuckets: a gradient arrived for a parameter of bucket {} after the bucket was packed (the set of parameters '
+                                   'with gradients changed between steps); set PPS_GRAD_EXPECT=0 to wait for every parameter'.format(bi))
             self.touched.add(id(p))
             self.pending[bi] -= 1
-            if self.pending[bi] == 0:
+            if self.pending[bi] <= 0:
                 # collectives are issued in bucket order 0, 1, 2 on EVERY rank, whatever the order in which a rank's buckets fill up (a rank
                 # that misses a gradient of bucket 0 must not start with bucket 1 while the others start with bucket 0): a complete bucket
                 # waits for its predecessors, finish() issues what is left, in order
-                while self._next < len(self.buckets) and self.pending[self._next] == 0:
+                while self._next < len(self.buckets) and self.pending[self._next] <= 0:
                     self._launch(self._next)
                     self._next += 1
         return fn
 
-    def _launch(self, bi):
+    def pack_all(self):
+        """Copies every bucket that has not been packed yet into its flat buffer, in bucket order, WITHOUT any collective.  Called at the end of a
+        step body that is recorded into a HIP graph (defer=True): every bucket -> flat copy then is part of the graph, whichever buckets the hooks
+        completed during the recorded backward (a bucket holding a parameter without gradient never completes in the hooks)."""
+        for bi in range(len(self.buckets)):
+            if not self.launched[bi]:
+                self._launch(bi, collective=False)
+        self._next = len(self.buckets)
+
+    def _launch(self, bi, collective=True):
         _, ws = world()
         self.launched[bi] = True
         pairs = [(v, p) for v, p in zip(self.views[bi], self.buckets[bi]) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
@@ -236,7 +266,7 @@ class GradBuckets:
             torch._foreach_copy_([v for v, _ in pairs], [p.grad for _, p in pairs])
             for v, p in pairs:
                 p.grad = v
-        if ws > 1 and not self.defer:
+        if ws > 1 and not self.defer and collective:
             self.handles.append(self._all_reduce(bi))
 
     def _all_reduce(self, bi):
@@ -273,6 +303,7 @@ class GradBuckets:
 
     def finish(self):
         _, ws = world()
+        self._armed = False
         for bi in range(len(self.buckets)):
             if not self.launched[bi]:
                 self._launch(bi)
@@ -284,18 +315,38 @@ class GradBuckets:
             for flat in self.flat:
                 flat.div_(ws)
         touched = self.touched
-        if ws > 1 and not self._replay:
+        if ws > 1:
             # the decision "this parameter got a gradient" must be the same on every rank, or some replicas would step the parameter (averaged
             # gradient, weight decay, step count) and others skip it: one tiny MAX all-reduce of a per-parameter mask per step.  A
-            # parameter touched on ANY rank keeps its averaged gradient everywhere (ranks that did not touch it contributed zeros).
+            # parameter touched on ANY rank keeps its averaged gradient everywhere (ranks that did not touch it contributed zeros).  The collective
+            # is issued on EVERY step, replayed or not, so that a rank whose capture failed (eager) and a rank that replays still run the same
+            # sequence of collectives.  Only the first step reads the mask back (one host synchronisation per run); later steps
+            # compare it with the first step's mask on the device and the flag is read every CHECK_EVERY steps.
             mask = torch.tensor([1 if id(p) in touched else 0 for p in self.params], dtype=torch.int32, device=self.flat[0].device)
             self.dist.all_reduce(mask, op=self.dist.ReduceOp.MAX)
-            keep = mask.cpu().numpy() > 0
-            touched = {id(p) for p, k in zip(self.params, keep) if k}
+            if self._static is None:
+                self._static = [bool(k) for k in (mask.cpu().numpy() > 0)]
+                self._static_dev = mask.clone()
+                self._mismatch = torch.zeros((), dtype=torch.bool, device=mask.device)
+            else:
+                self._mismatch |= (mask != self._static_dev).any()
+                self._steps += 1
+                if self._steps % self.CHECK_EVERY == 0:
+                    self.check()
+            touched = {id(p) for p, k in zip(self.params, self._static) if k}
             for views, bucket in zip(self.views, self.buckets):
                 for v, p in zip(views, bucket):
                     if id(p) in touched and p.grad is None:
                         p.grad = v                   # touched elsewhere only: the averaged gradient sits in this rank's bucket slot
+        if self._expect is None and self._use_expect:
+            self._expect = [sum(1 for p in bucket if id(p) in touched) for bucket in self.buckets]
         for p in self.params:                       # like plain autograd: no gradient -> the optimizer skips the parameter
             if id(p) not in touched:                # (AdamW would otherwise still apply weight decay to it)
                 p.grad = None
+
+    CHECK_EVERY = 64
+
+    def check(self):
+        """Raises if the set of parameters with a gradient (on any rank) ever differed from the first step's (one host synchronisation)."""
+        if self._mismatch is not None and bool(self._mismatch):
+            raise RuntimeError('GradBuckets: the set of parameters that received a gradient changed after the first step')

@@ -224,7 +224,7 @@ def test_config3_fit_step_at_full_batch_size(precision):
 @pytest.mark.parametrize('dtype', ['f32', 'f16x3'])
 def test_config5_ppsurf_200nn_chunk_at_size(dtype):
     """BASELINE config 5 chunk: N = 250 000 points, P = 200, rec_batch_size = 25 000, k = 64 (configs/ppsurf_200nn.yaml) through the
-    product's chunk loop: exact 64-NN and 200-NN tables, finite outputs, permutation equivariance, 64 sampled queries vs the oracle."""
+    product's chunk loop: exact 64-NN and 200-NN tables, finite outputs, permutation equivariance, 1024 queries (incl. the 64 largest-|logit| ones) vs the oracle."""
     from ppsurf_amd.decoder import DecoderPlan, ChunkPipeline
     from ppsurf_amd.synthetic import make_cloud, make_latents, network_state_dict
     import bench_workloads as workloads
@@ -245,7 +245,14 @@ def test_config5_ppsurf_200nn_chunk_at_size(dtype):
     perm = torch.randperm(qn, device=DEV)
     (lg2, _), = pipe.run([q[perm].contiguous()])
     assert torch.equal(lg2, logits[perm])                                    # position in the chunk does not matter, bit for bit
-    sel = np.random.default_rng(2).choice(qn, 64, replace=False)
+    # 1024 queries against the oracle: the 64 largest-|logit| queries of the exact-fp32 kernels + 960 random ones
+    if dtype == 'f32':
+        lg32 = logits
+    else:
+        plan32 = DecoderPlan(sd, DEV, dtype='f32')
+        (lg32, _), = ChunkPipeline(plan32, plan32.point_table(torch.from_numpy(lat[0]).to(DEV)), pts, pts, 64, p, same_cloud=True, max_chunk=qn).run([q])
+    top = np.argsort(-np.abs(lg32.cpu().numpy()).max(axis=1))[:64]
+    sel = np.concatenate([top, np.random.default_rng(2).choice(np.setdiff1d(np.arange(qn), top), 1024 - 64, replace=False)])
     qs = q[torch.from_numpy(sel).to(DEV)].cpu().numpy()
     ids200 = O.knn_point_major(cloud, qs, 200)
     b = (pipe.n - 1) & 1

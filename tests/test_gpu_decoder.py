@@ -119,7 +119,7 @@ def test_packed_pointnet_tiles_match_oracle(p, q, dtype, monkeypatch):
 @pytest.mark.parametrize('dtype,scale', [('f32', 1.0), ('f32', 20.0), ('f16x3', 1.0), ('f16x3', 20.0)])
 def test_decoder_full_chunk_properties(dtype, scale):
     """BASELINE chunk (N=100k, Q=50k, k=64, P=50): finite outputs, permutation equivariance over queries, and a sampled comparison with
-    the ORACLE (256 queries) -- for both decoder dtypes, at latent magnitude 1 and at the magnitude the real encoder produces (x20:
+    the ORACLE (4096 queries incl. the 64 largest-|logit| ones) -- for both decoder dtypes, at latent magnitude 1 and at the magnitude the real encoder produces (x20:
     logits ~ 27, where the absolute 1e-4 bar is hardest)."""
     sd = filled_sd('', key='ppsurf')
     pl = plan(dtype)
@@ -137,12 +137,53 @@ def test_decoder_full_chunk_properties(dtype, scale):
     lg2, _ = pl.decode(table, pts, qd[perm].contiguous(), idx[perm].contiguous(), patches[perm].contiguous())
     # each query is independent of its tile neighbours and of its position in the chunk: equal, not close
     assert torch.equal(lg2, logits[perm])
-    sel = np.random.default_rng(1).choice(50_000, 256, replace=False)
+    # 4096 queries against the ORACLE: the 64 largest-|logit| queries of the exact-fp32 kernels (where an absolute bar is hardest) + 4032 random ones
+    lg32 = lg if dtype == 'f32' else plan('f32').decode(plan('f32').point_table(dev(lat[0])), pts, qd, idx, patches)[0].cpu().numpy()
+    top = np.argsort(-np.abs(lg32).max(axis=1))[:64]
+    rest = np.setdiff1d(np.arange(50_000), top)
+    sel = np.concatenate([top, np.random.default_rng(1).choice(rest, 4096 - 64, replace=False)])
     data = {'latents': torch.from_numpy(lat), 'pts': torch.from_numpy(cloud.T.copy()).unsqueeze(0),
             'pts_query': torch.from_numpy(qry[sel]).unsqueeze(0), 'pts_local_ps': patches[torch.from_numpy(sel).to(DEV)].cpu().unsqueeze(0)}
     ref = O.ppsurf_from_latent(sd, data, k=64)[0].T.numpy()
-    print(dtype, 'scale', scale, 'logits |max| {:.1f}, max |dlogit| vs oracle {:.2e}'.format(float(np.abs(ref).max()), float(np.abs(lg[sel] - ref).max())))
+    print(dtype, 'scale', scale, 'logits |max| {:.1f}, max |dlogit| vs oracle over {} queries {:.2e}'.format(float(np.abs(ref).max()), sel.size,
+                                                                                                        float(np.abs(lg[sel] - ref).max())))
     np.testing.assert_allclose(lg[sel], ref, rtol=0, atol=1e-4)
+    if dtype == 'f16x3':
+        assert pl.range_fallbacks() == 0                       # in range: the fp32 fall-back kernels returned at their gate
+
+
+@pytest.mark.parametrize('scale', [1.0e4, 1.0e5])
+def test_f16x3_range_guard_falls_back_to_fp32(scale):
+    """The default dtype splits every activation x = hi + lo with hi = f16(x): |x| must stay below 65504.  Latents scaled until the first hidden
+    layer leaves that range: the split-precision kernels raise the guard word and the fp32 kernels queued behind them recompute the chunk on the
+    device -- the result IS the fp32 path's (torch.equal), matches the oracle, and the plan counts the fall-back."""
+    sd = filled_sd('', key='ppsurf')
+    pl, pl32 = plan('f16x3'), plan('f32')
+    cloud = make_cloud(20_000, seed=5)
+    qry = make_band_queries(cloud, 3000, resolution=129, seed=2)
+    pts, qd = dev(cloud), dev(qry)
+    lat = make_latents(256, cloud.shape[0], seed=9) * np.float32(scale)
+    idx = ops.knn_point_major(pts, qd, 64)
+    patches = ops.patch_normalize(pts, qd, idx, 50)
+    before = pl.range_fallbacks()
+    logits, occ = pl.decode(pl.point_table(dev(lat[0])), pts, qd, idx, patches)
+    want, occ32 = pl32.decode(pl32.point_table(dev(lat[0])), pts, qd, idx, patches)
+    hmax = float(pl32.point_table(dev(lat[0])).abs().max())
+    print('scale', scale, 'max |G| {:.3g}  max |logit| {:.3g}'.format(hmax, float(want.abs().max())))
+    assert hmax > 65504.0                                       # the test really leaves the range
+    assert pl.range_fallbacks() == before + 1
+    assert torch.isfinite(logits).all() and torch.equal(logits, want) and torch.equal(occ, occ32)
+    sel = np.arange(0, 3000, 12)
+    data = {'latents': torch.from_numpy(lat), 'pts': torch.from_numpy(cloud.T.copy()).unsqueeze(0),
+            'pts_query': torch.from_numpy(qry[sel]).unsqueeze(0), 'pts_local_ps': patches[torch.from_numpy(sel).to(DEV)].cpu().unsqueeze(0)}
+    ref = O.ppsurf_from_latent(sd, data, k=64)[0].T.numpy()
+    got = logits.cpu().numpy()[sel]
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-4 * max(1.0, float(np.abs(ref).max())))      # 1e-4 relative to the (huge) logit scale
+    # the next, ordinary chunk runs in split precision again (the guard word is per chunk)
+    lat1 = make_latents(256, cloud.shape[0], seed=9)
+    l1, _ = pl.decode(pl.point_table(dev(lat1[0])), pts, qd, idx, patches)
+    l1_32, _ = pl32.decode(pl32.point_table(dev(lat1[0])), pts, qd, idx, patches)
+    assert pl.range_fallbacks() == before + 1 and not torch.equal(l1, l1_32) and float((l1 - l1_32).abs().max()) < 1e-4
 
 
 @pytest.mark.parametrize('dtype', DTYPES)

@@ -15,7 +15,7 @@ def _torch_dilate(mask, r):
     return m[0, 0] > 0
 
 
-@pytest.mark.parametrize('shape', [(259, 259, 259), (35, 35, 35), (5, 7, 3), (1, 1, 9), (64, 32, 16), (13, 4, 66)])
+@pytest.mark.parametrize('shape', [(259, 259, 259), (35, 35, 35), (5, 7, 3), (1, 1, 9), (64, 32, 16), (13, 4, 66), (7, 5, 2), (6, 6, 1), (9, 3, 3)])
 @pytest.mark.parametrize('r', [0, 1, 2, 3])
 def test_box_dilation_equals_max_pool(shape, r):
     g = torch.Generator().manual_seed(shape[0] * 7 + r)
@@ -27,6 +27,17 @@ def test_box_dilation_equals_max_pool(shape, r):
     dense = (torch.rand(shape, generator=g) < 0.4).to(DEV)
     assert torch.equal(ops.dilate_box(dense, r), _torch_dilate(dense, r))
     assert not ops.dilate_box(torch.zeros(shape, dtype=torch.bool, device=DEV), r).any()
+
+
+def test_dilation_of_a_mask_with_a_storage_offset():
+    """A contiguous bool tensor that starts 1 / 3 bytes into its storage is passed through unchanged by contiguous(): the kernel's 32-bit fast path
+    must not be taken for it."""
+    g = torch.Generator().manual_seed(3)
+    for off in (1, 3):
+        flat = (torch.rand(off + 20 * 12 * 8, generator=g) < 0.05).to(DEV)
+        mask = flat[off:].view(20, 12, 8)
+        assert mask.is_contiguous() and mask.data_ptr() % 4 == off % 4
+        assert torch.equal(ops.dilate_box(mask, 2), _torch_dilate(mask.clone(), 2))
 
 
 def test_point_list_semantics_of_the_reference():

@@ -62,11 +62,13 @@ def test_query_sharded_volume_equals_single_rank(tmp_path):
     assert n2 == n1                                                     # the two ranks decoded disjoint halves
 
 
-@pytest.mark.parametrize('mode', ['default', 'bf16'])
+@pytest.mark.parametrize('mode', ['default', 'bf16', 'poco'])
 def test_two_rank_fit_keeps_the_replicas_identical(tmp_path, mode):
     """pps.py fit launched as 2 ranks (gloo on one GPU here, RCCL on the 8-GPU node): shapes sharded by the DistributedSampler
     rule, bucketed gradient all-reduce; after training both replicas hold bit-identical parameters.
-    mode 'bf16' (PPS_GRAD_BUCKET_DTYPE=bf16): buckets summed over the ranks in bfloat16, replicas still identical."""
+    mode 'bf16' (PPS_GRAD_BUCKET_DTYPE=bf16): buckets summed over the ranks in bfloat16, replicas still identical.
+    mode 'poco': the POCO model -- its encoder.cv5 / bn5 never get a gradient and sit in the first gradient bucket, which therefore never completes
+    inside backward; the replayed step must still pack and average every bucket (before the fix the replicas diverged silently)."""
     import yaml
     import torch
     from ppsurf_amd.synthetic import write_dataset
@@ -74,7 +76,8 @@ def test_two_rank_fit_keeps_the_replicas_identical(tmp_path, mode):
     in_file = write_dataset(str(tmp_path / 'ds'), n_shapes=4, n_pts=2000, n_query=200)
     cfg = dict(BASE); cfg.update(OPT)
     paths = []
-    for name, c in (('poco', cfg), ('pps', PPS), ('mini', {'model': {'init_args': {'name': 'ppsurf_mini'}},
+    model_name = 'poco_mini' if mode == 'poco' else 'ppsurf_mini'
+    for name, c in (('poco', cfg), ('pps', {} if mode == 'poco' else PPS), ('mini', {'model': {'init_args': {'name': model_name}},
                                                           'data': {'init_args': {'in_file': in_file, 'batch_size': 1, 'use_ddp': True,
                                                                                  'manifold_points': 1000}},
                                                           'trainer': {'max_epochs': 4, 'precision': 'bf16-mixed'}})):
@@ -99,5 +102,5 @@ def test_two_rank_fit_keeps_the_replicas_identical(tmp_path, mode):
     params = [k for k in a if 'running_' not in k and 'num_batches' not in k and 'norm_radius' not in k]
     assert all(torch.equal(a[k], b[k]) for k in params)                    # same parameters on both replicas
     assert any(not torch.equal(a[k], b[k]) for k in a if 'running_mean' in k)     # buffers are rank-local (different shapes)
-    state = torch.load(tmp_path / 'models' / 'ppsurf_mini' / 'version_0' / 'checkpoints' / 'last.ckpt', map_location='cpu')
+    state = torch.load(tmp_path / 'models' / model_name / 'version_0' / 'checkpoints' / 'last.ckpt', map_location='cpu')
     assert state['global_step'] == 8                                       # 4 shapes / 2 ranks / batch 1 x 4 epochs

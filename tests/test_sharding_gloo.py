@@ -112,6 +112,25 @@ def _grad_worker(rank, world, port, out_dir):
     torch.nn.functional.cross_entropy(net4(x[lo:hi]), y[lo:hi]).backward()
     b4.finish()
     out['g_f32'] = torch.cat([p.grad.reshape(-1) for p in net4.parameters()]).numpy().copy()
+    # the split-graph fit (defer=True): the step body packs EVERY bucket itself (pack_all) so that the copies are part of the recorded graph, also when
+    # bucket 0 holds parameters that never get a gradient (POCO's cv5 / bn5) and therefore never completes in the hooks; a replay then
+    # only calls replayed() + finish()
+    net5, unused5 = copy.deepcopy(net), torch.nn.Linear(3, 3)
+    b5 = GradBuckets(list(net5.parameters()) + list(unused5.parameters()), n_buckets=3, defer=True)
+    assert any(id(p) in {id(q) for q in unused5.parameters()} for p in b5.buckets[0])
+    for step in range(3):
+        b5.zero()
+        torch.nn.functional.cross_entropy(net5(x[lo:hi]), y[lo:hi]).backward()
+        b5.pack_all()
+        assert all(b5.launched) and not b5.handles
+        views = {v.data_ptr() for vs in b5.views for v in vs}
+        assert all(p.grad is not None and p.grad.data_ptr() in views for p in net5.parameters())
+        assert all(float(f.abs().sum()) > 0 for f in b5.flat[1:])
+        if step == 2:
+            b5.replayed(set(b5.touched))                                 # what fit does behind a replayed graph
+        b5.finish()
+        out['g_defer{}'.format(step)] = torch.cat([p.grad.reshape(-1) for p in net5.parameters()]).numpy().copy()
+        out['defer_unused_none{}'.format(step)] = np.array([p.grad is None for p in unused5.parameters()])
     out['half_none'] = np.array([p.grad is None for p in half.parameters()])
     out['half_g'] = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in half.parameters()]).numpy().copy()
     out['w'] = torch.cat([p.detach().reshape(-1) for p in params]).numpy()
@@ -140,6 +159,9 @@ def test_two_rank_gradient_buckets_equal_full_batch_gradients(tmp_path):
     # ... and the fp32 buckets of the same weights to bfloat16 precision (each rank's bucket is rounded once, the sum once more)
     assert r0['g_bf16'].dtype == np.float32 and np.abs(r0['g_bf16'] - r0['g_f32']).max() <= 2.0 ** -7 * np.abs(r0['g_f32']).max()
     assert not np.array_equal(r0['g_bf16'], r0['g_f32'])
+    for step in range(3):                                                   # deferred collectives (split-graph fit), eager and "replayed"
+        assert np.array_equal(r0['g_defer{}'.format(step)], r0['g_f32']) and np.array_equal(r1['g_defer{}'.format(step)], r0['g_f32'])
+        assert r0['defer_unused_none{}'.format(step)].all() and r1['defer_unused_none{}'.format(step)].all()
     # touched on rank 0 only: kept on BOTH ranks with the same averaged value (rank 0's gradient / 2)
     assert not r0['half_none'].any() and not r1['half_none'].any() and np.array_equal(r0['half_g'], r1['half_g']) and np.abs(r0['half_g']).max() > 0
     half = torch.nn.Linear(6, 2)

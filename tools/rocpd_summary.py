@@ -27,6 +27,7 @@ def main(src, dst):
                 continue
             lines.append('{:60s} {:6d} {:12.1f} {:11.2f} {:7.2f}'.format(short(name), calls, total / 1e3 if total > 1e7 else total, avg / 1e3 if avg > 1e6 else avg, pct))
             out.setdefault(short(name), {})['avg_us'] = avg
+            out[short(name)]['calls'] = calls
     for sub in sorted(glob.glob(os.path.join(src, 'pmc_*'))):
         dbs = glob.glob(os.path.join(sub, '*.db'))
         if not os.path.isdir(sub) or not dbs:
@@ -40,10 +41,14 @@ def main(src, dst):
                 continue
             lines.append('{:60s} {:32s} n={:3d} avg={:.6g}'.format(short(name), counter, n, avg))
             out.setdefault(short(name), {})[counter] = avg
+            out[short(name)].setdefault('n', {})[counter] = n
     open(dst + '_rocprof_summary.txt', 'w').write('\n'.join(lines) + '\n')
     k = out.get('interp_pool_kernel', out.get('interp_pool_f16x3_kernel', {}))
     # the GPU box has no .git: the caller passes the commit the snapshot was taken at (PPS_GIT_HEAD=$(git rev-parse --short=12 HEAD))
-    pmc = {'source': os.path.basename(src.rstrip('/')), 'git_head': os.environ.get('PPS_GIT_HEAD', 'unrecorded'), 'kernels': out}
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    import bench_workloads
+    pmc = {'source': os.path.basename(src.rstrip('/')), 'git_head': os.environ.get('PPS_GIT_HEAD', 'unrecorded'),
+           'csrc_digest': bench_workloads.csrc_digest(), 'kernels': out}
     if 'FETCH_SIZE' in k and 'WRITE_SIZE' in k:
         # MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide
         # coalesced read stream -> doubled; WRITE_SIZE is uncalibrated and taken as is.
