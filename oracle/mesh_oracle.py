@@ -14,9 +14,18 @@ mesh of a volume must have, by plain enumeration over the grid, and a union-find
                             interpolation position -- restricted to edges of at least one cube with eight finite corners (cubes that touch
                             an unseen = NaN voxel produce no triangles: skimage emits NaN vertices there, which the reference's
                             clean_simple_inplace -> remove_infinite_values removes again)
-  check_marching_cubes      vertex multiset == edge_crossings; every face inside ONE grid cube; the faces form a closed, consistently
+  check_marching_cubes      vertices with >= 2 integer coordinates (on grid edges) == edge_crossings as a multiset; any OTHER vertex lies strictly inside
+                            one all-finite cube, at the mean of the vertices of its link (the extra vertex of Lewiner's tables: skimage's default
+                            method emits such vertices too, which is why the reference's refinement selects vertices with exactly one fractional
+                            coordinate, source/poco_utils.py:115-117); every face inside ONE grid cube; the faces form a closed, consistently
                             oriented 2-manifold (every directed edge once, its reverse once) wherever the surface does not run into unseen
                             voxels; normals point from values > level towards values <= level
+  check_face_decider        AMBIGUOUS cube faces (the two inside corners on a diagonal) are resolved by the asymptotic decider -- the sign of the
+                            bilinear interpolant at the face's saddle point (Nielson & Hamann 1991, "The asymptotic decider"; the face tests of
+                            Lewiner, Lopes, Vieira, Tavares 2003, "Efficient implementation of Marching Cubes' cases with topological guarantees",
+                            the algorithm behind skimage.measure.marching_cubes): the mesh segments lying in such a face cut off the two OUTSIDE
+                            corners when the saddle value is inside (> level) and the two INSIDE corners otherwise.  Two meshers that both satisfy
+                            this agree on every face segment, i.e. on the surface's topology up to what happens strictly inside a cube
   components_union_find     face components over shared (undirected) edges by union-find
   check_clean_mesh          the cleaned mesh == input with vertices merged by position, degenerate and duplicate faces dropped, components
                             of <= min faces dropped, unreferenced vertices dropped (compared as sets of face-corner positions)
@@ -95,7 +104,13 @@ def check_marching_cubes(verts, faces, volume, level=0.0, atol=1e-9, require_clo
     verts = np.asarray(verts, dtype=np.float64)
     faces = np.asarray(faces, dtype=np.int64)
     want, _, _ = edge_crossings(vol, level)
-    # 1. vertex multiset
+    all_verts = verts
+    # 1. vertex multiset.  A vertex on a grid edge has at least two integer coordinates; the others must be cube-interior extra vertices (1b)
+    n_int = (verts == np.floor(verts)).sum(axis=1)
+    interior = n_int < 2
+    if interior.any():
+        _check_interior_vertices(all_verts, faces, interior, vol)
+    verts = all_verts[~interior]
     assert verts.shape[0] == want.shape[0], 'vertex count {} != {} level crossings on edges of finite cubes'.format(verts.shape[0], want.shape[0])
     got = verts[np.lexsort((verts[:, 2], verts[:, 1], verts[:, 0]))]
     if want.shape[0]:
@@ -105,6 +120,7 @@ def check_marching_cubes(verts, faces, volume, level=0.0, atol=1e-9, require_clo
             key = lambda a: np.lexsort((np.round(a[:, 2], 6), np.round(a[:, 1], 6), np.round(a[:, 0], 6)))
             err = np.abs(verts[key(verts)] - want[key(want)]).max()
         assert err <= atol, 'vertex positions differ from the linear-interpolation crossings by {}'.format(err)
+    verts = all_verts
     if faces.shape[0] == 0:
         assert want.shape[0] == 0
         return {'vertices': 0, 'faces': 0, 'boundary_edges': 0}
@@ -169,7 +185,106 @@ def check_marching_cubes(verts, faces, volume, level=0.0, atol=1e-9, require_clo
         _, inv = np.unique(lab, return_inverse=True)
         bad = np.bincount(inv, weights=wrong.astype(np.float64)) > 0.5 * np.maximum(np.bincount(inv, weights=big.astype(np.float64)), 1)
         assert not bad.any(), '{} components are oriented towards HIGHER values'.format(int(bad.sum()))
-    return {'vertices': int(verts.shape[0]), 'faces': int(faces.shape[0]), 'boundary_edges': nb}
+    amb = check_face_decider(verts, faces, vol, level)
+    return {'vertices': int(verts.shape[0]), 'faces': int(faces.shape[0]), 'boundary_edges': nb, 'interior_vertices': int(interior.sum()),
+            'ambiguous_faces': amb}
+
+
+def _check_interior_vertices(verts, faces, interior, vol):
+    """1b: a vertex that is not on a grid edge lies strictly inside ONE cube with eight finite corners, all its faces lie in that cube, its link is
+    a single closed cycle of grid-edge vertices, and it sits at their mean."""
+    cube_ok = _cube_all_finite(vol)
+    ids = np.nonzero(interior)[0]
+    p = verts[ids]
+    c = np.floor(p).astype(np.int64)
+    assert ((p > c) & (p < c + 1)).all(), 'an extra vertex lies on a cube face, not strictly inside a cube'
+    assert (c >= 0).all() and (c < np.array(vol.shape) - 1).all() and cube_ok[c[:, 0], c[:, 1], c[:, 2]].all(), 'an extra vertex in a cube with an unseen corner'
+    assert np.unique((c[:, 0] * vol.shape[1] + c[:, 1]) * vol.shape[2] + c[:, 2]).shape[0] == ids.shape[0], 'two extra vertices in one cube'
+    where = {int(v): k for k, v in enumerate(ids)}
+    link = [[] for _ in ids]
+    for f in faces[interior[faces].any(axis=1)]:
+        hub = [v for v in f if interior[v]]
+        assert len(hub) == 1, 'a face joins two extra vertices'
+        i = list(f).index(hub[0])
+        link[where[int(hub[0])]].append((int(f[(i + 1) % 3]), int(f[(i + 2) % 3])))
+    for k, segs in enumerate(link):
+        assert len(segs) >= 3, 'an extra vertex with fewer than three faces'
+        nxt = dict(segs)
+        assert len(nxt) == len(segs), 'the link of an extra vertex is not a simple cycle'
+        start, e, n = segs[0][0], segs[0][0], 0
+        while True:
+            e = nxt[e]
+            n += 1
+            if e == start or n > len(segs):
+                break
+        assert n == len(segs), 'the link of an extra vertex is not one closed cycle'
+        ring = verts[[a for a, _ in segs]]
+        assert ((ring >= c[k]) & (ring <= c[k] + 1)).all(), 'the fan of an extra vertex leaves its cube'
+        assert np.abs(ring.mean(axis=0) - p[k]).max() <= 1e-9, 'an extra vertex is not at the mean of its link'
+
+
+def check_face_decider(verts, faces, volume, level=0.0):
+    """Every mesh segment that lies in an AMBIGUOUS grid face follows the asymptotic decider (module docstring).  Plain enumeration: a mesh edge lies
+    in the grid face (axis ax, plane x_ax = c, cell (u0, v0)) when both end points have x_ax == c and fall into that unit square; if one end point
+    sits on a u-edge of the square and the other on a v-edge, the segment cuts off the corner the two grid edges share.  For an ambiguous face the
+    corner that is cut off must be OUTSIDE (value <= level) exactly when  (f00 - L)(f11 - L) - (f10 - L)(f01 - L)  has the sign that puts the
+    saddle value inside.  Returns the number of ambiguous faces checked.  Segments with an end point ON a grid corner (a value exactly at the
+    level) are skipped: the corner belongs to several grid edges and the face's segment structure is degenerate there."""
+    vol = np.asarray(volume, dtype=np.float64)
+    verts = np.asarray(verts, dtype=np.float64)
+    faces = np.asarray(faces, dtype=np.int64)
+    if faces.shape[0] == 0:
+        return 0
+    e = np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]])
+    e = np.unique(np.sort(e, axis=1), axis=0)
+    pa, pb = verts[e[:, 0]], verts[e[:, 1]]
+    shape = np.array(vol.shape)
+    checked = set()
+    for ax in range(3):
+        u, v = (ax + 1) % 3, (ax + 2) % 3
+        flat = (pa[:, ax] == pb[:, ax]) & (pa[:, ax] == np.floor(pa[:, ax]))
+        a, b = pa[flat], pb[flat]
+        # one end point on a u-directed grid edge (v integer, u fractional), the other on a v-directed one
+        a_on_u = (a[:, v] == np.floor(a[:, v])) & (a[:, u] != np.floor(a[:, u]))
+        a_on_v = (a[:, u] == np.floor(a[:, u])) & (a[:, v] != np.floor(a[:, v]))
+        b_on_u = (b[:, v] == np.floor(b[:, v])) & (b[:, u] != np.floor(b[:, u]))
+        b_on_v = (b[:, u] == np.floor(b[:, u])) & (b[:, v] != np.floor(b[:, v]))
+        sel = (a_on_u & b_on_v) | (a_on_v & b_on_u)
+        a, b = a[sel], b[sel]
+        swap = ~(a_on_u & b_on_v)[sel]
+        pu = np.where(swap[:, None], b, a)                    # the end point on the u-directed edge: its v coordinate is the corner's v
+        pv = np.where(swap[:, None], a, b)                    # the end point on the v-directed edge: its u coordinate is the corner's u
+        cu, cv, cp = pv[:, u].astype(np.int64), pu[:, v].astype(np.int64), pu[:, ax].astype(np.int64)
+        u0, v0 = np.floor(pu[:, u]).astype(np.int64), np.floor(pv[:, v]).astype(np.int64)
+        for i in range(cu.shape[0]):
+            if not (u0[i] <= cu[i] <= u0[i] + 1 and v0[i] <= cv[i] <= v0[i] + 1) or u0[i] + 1 >= shape[u] or v0[i] + 1 >= shape[v]:
+                continue                                       # end points in different cells: not a segment of one grid face
+            idx = [0, 0, 0]
+            idx[ax] = cp[i]
+
+            def val(du, dv):
+                idx[u], idx[v] = u0[i] + du, v0[i] + dv
+                return vol[idx[0], idx[1], idx[2]]
+            f00, f10, f01, f11 = val(0, 0), val(1, 0), val(0, 1), val(1, 1)
+            if not np.isfinite([f00, f10, f01, f11]).all():
+                continue
+            i00, i10, i01, i11 = f00 > level, f10 > level, f01 > level, f11 > level
+            if not (i00 == i11 and i10 == i01 and i00 != i10):
+                continue                                       # not ambiguous
+            det = (f00 - level) * (f11 - level) - (f10 - level) * (f01 - level)
+            saddle_inside = det > 0 if i00 else det < 0
+            corner_inside = bool(vol[tuple(_set(idx, u, cu[i], v, cv[i]))] > level)
+            assert corner_inside != saddle_inside, ('ambiguous face (axis {}, plane {}, cell {},{}): the segment cuts off an {} corner but the saddle '
+                                                    'value is {}'.format(ax, cp[i], u0[i], v0[i], 'inside' if corner_inside else 'outside',
+                                                                         'inside' if saddle_inside else 'outside'))
+            checked.add((ax, int(cp[i]), int(u0[i]), int(v0[i])))
+    return len(checked)
+
+
+def _set(idx, u, cu, v, cv):
+    out = list(idx)
+    out[u], out[v] = int(cu), int(cv)
+    return out
 
 
 def components_union_find(faces):

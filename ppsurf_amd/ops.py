@@ -203,3 +203,39 @@ def grow_band_todo(volume: torch.Tensor, band: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(band)
     _lib.check(_lib.lib().pps_grow_band_todo_f64(volume.data_ptr(), band.data_ptr(), out.data_ptr(), volume.numel(), _stream(volume)), 'pps_grow_band_todo_f64')
     return out
+
+
+def marching_cubes(volume: torch.Tensor, level: float):
+    """Iso-surface of a float64 device volume [nx,ny,nz] (NaN = unseen) -> (verts float64 [V,3] in index space, faces int64 [F,3]): the four
+    streaming passes of csrc/pps_mc.hip with two block-level prefix sums in between (replaces skimage.measure.marching_cubes,
+    source/poco_utils.py:95-96).  One host synchronisation (the three totals size the outputs)."""
+    import ctypes
+    from . import mcubes
+    assert volume.dtype == torch.float64 and volume.dim() == 3 and volume.is_cuda and volume.is_contiguous()
+    L = _lib.lib()
+    nx, ny, nz = volume.shape
+    dev = volume.device
+    tri, ntri, amb = mcubes.device_tables(dev)
+    nbc, nbe = L.pps_mc_cube_blocks(nx, ny, nz), L.pps_mc_edge_blocks(nx, ny, nz)
+    if nbc < 0:
+        raise ValueError('volume of shape {} is outside the range of pps_mc'.format(tuple(volume.shape)))
+    nedge = 3 * nx * ny * nz
+    flags = torch.empty(nedge, dtype=torch.uint8, device=dev)
+    counts = torch.empty(2 * nbc + nbe, dtype=torch.int32, device=dev)
+    bt, bc, bv = counts[:nbc], counts[nbc:2 * nbc], counts[2 * nbc:]
+    st = _stream(volume)
+    lvl = ctypes.c_double(float(level))
+    _lib.check(L.pps_mc_count_f64(volume.data_ptr(), nx, ny, nz, lvl, tri.data_ptr(), mcubes.TABLE_WIDTH, ntri.data_ptr(), amb.data_ptr(),
+                                  flags.data_ptr(), bt.data_ptr(), bc.data_ptr(), bv.data_ptr(), st), 'pps_mc_count_f64')
+    inc = [torch.cumsum(x, 0, dtype=torch.int64) for x in (bt, bc, bv)]
+    n_tri, n_cen, n_vert = [int(v) for v in torch.stack([i[-1] for i in inc]).tolist()]
+    verts = torch.empty((n_vert + n_cen, 3), dtype=torch.float64, device=dev)
+    faces = torch.empty((n_tri, 3), dtype=torch.int64, device=dev)
+    if n_tri == 0:
+        return verts[:0], faces
+    off = [(i - x).contiguous() for i, x in zip(inc, (bt, bc, bv))]
+    vidx = torch.empty(nedge, dtype=torch.int32, device=dev)
+    _lib.check(L.pps_mc_emit_f64(volume.data_ptr(), nx, ny, nz, lvl, tri.data_ptr(), mcubes.TABLE_WIDTH, ntri.data_ptr(), amb.data_ptr(), flags.data_ptr(),
+                                 off[0].data_ptr(), off[1].data_ptr(), off[2].data_ptr(), n_vert, vidx.data_ptr(), verts.data_ptr(), faces.data_ptr(), st),
+               'pps_mc_emit_f64')
+    return verts, faces

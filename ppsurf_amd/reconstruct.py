@@ -181,10 +181,10 @@ def export_mesh_and_refine_vertices_region_growing_v3(network, latent: dict, pts
     seen = volume[~torch.isnan(volume)]
     if not (float(seen.max()) > mc_value > float(seen.min())):
         return None
-    # Marching Cubes, clean-up and the bisection refinement stay on the device (poco_utils.py:96-168)
+    # Marching Cubes (HIP kernels, csrc/pps_mc.hip), clean-up and the bisection refinement stay on the device (poco_utils.py:96-168)
     verts, faces = mcubes.marching_cubes_torch(volume, mc_value)
     verts = verts.to(torch.float32).to(torch.float64)            # skimage returns float32 vertices, trimesh stores them as float64
-    verts, faces = mcubes.clean_mesh_torch(verts, faces, min_component_faces=6)
+    verts, faces = mcubes.clean_mesh_torch(verts, faces, min_component_faces=6, welded=True, grid_coords=True)
     verts = refine_vertices(lambda q: sharding.sharded_map(field, q), verts, volume, step, bmin_pad, refine_iter, progress)
-    verts, faces = mcubes.clean_mesh_torch(verts, faces, min_component_faces=6)
+    verts, faces = mcubes.clean_mesh_torch(verts, faces, min_component_faces=6, welded=True, grid_coords=False)
     return verts.to(torch.float32).cpu().numpy(), faces.cpu().numpy()

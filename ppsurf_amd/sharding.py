@@ -33,7 +33,9 @@ def shard_range(n: int, rank: int, world_size: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-MIN_SHARD = 8192        # a rank never gets fewer queries than this: the persistent decoder kernels need ~8k queries to fill 256 CUs
+# a rank never gets fewer queries than this: the persistent decoder kernels need ~8k queries to fill 256 CUs.  PPS_MIN_SHARD overrides it (the first
+# runs on an 8-GPU node can sweep it against the real all-gather latency over xGMI without touching the code)
+MIN_SHARD = int(os.environ.get('PPS_MIN_SHARD', '8192'))
 STATS = {'collective_events': None, 'calls': 0, 'items': 0}
 
 

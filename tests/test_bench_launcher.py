@@ -71,3 +71,21 @@ def test_self_spawned_single_rank_gives_the_same_kind_of_line():
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
     assert d['n_gpus'] == 1 and d['roofline']['frac'] > 0.2 and d['value'] > 1e6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['f16x3', 'f32'])
+def test_strong_scaling_line_reports_the_dtype_it_ran_and_its_collectives(dtype):
+    """`bench.py --gpus 2 --scaling strong` (two gloo ranks on cuda:0): ONE shape reconstructed by both ranks together.  The line must carry the
+    decoder dtype that actually ran (it said 'f32' whatever ran), the collective count per shape, and a positive rate."""
+    env = dict(os.environ, PPS_MIN_SHARD='4096')                                    # the floor is an environment switch now
+    p = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--same-gpu', '--scaling', 'strong',
+                        '--steps', '1', '--warmup', '1', '--dtype', dtype], capture_output=True, text=True, timeout=1500, cwd=REPO, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['scaling'] == 'strong' and d['n_gpus'] == 2 and d['dtype'] == dtype and dtype in ('f32', 'f16x3')
+    assert d['value'] > 0 and d['shapes_per_hour'] > 0
+    assert 10 <= d['collectives_per_shape'] <= 40                                   # growth rounds + refinement rounds + the latent all-reduce
+    assert 0 <= d['collective_share_rank0'] < 1

@@ -19,7 +19,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define NPAIR 16
-#define NTH 512
 struct HiLo { half8 hi, lo; };
 
 template <int I, int N, class F>
@@ -58,8 +57,9 @@ __device__ __forceinline__ void signal(unsigned* p, int lane) {
     if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int SYNC, int NB, int D, int KPC, int XPF, int EPI>
-__global__ __launch_bounds__(NTH, 2) void probe(const char* __restrict__ w, const f32x4* __restrict__ xin, float* out, int passes) {
+template <int SYNC, int NB, int D, int KPC, int XPF, int EPI, int DMA = 1, int TL = 1, int PF = 1>
+__global__ __launch_bounds__(512 / TL, TL == 1 ? 2 : 1) void probe(const char* __restrict__ w, const f32x4* __restrict__ xin, float* out, int passes) {
+    constexpr int NTH = 512 / TL, NWV = NTH / 64;
     constexpr int CHB = KPC * 4096;                   // bytes per chunk (a k-step of an output-block pair is 4 KiB: 2 blocks x hi/lo x 1 KiB)
     constexpr int NCH = NPAIR * 8 / KPC;              // chunks per pass
     constexpr int PPC = CHB / (NTH * 16);             // 1 KiB-per-wave pieces per chunk and wave
@@ -85,16 +85,20 @@ __global__ __launch_bounds__(NTH, 2) void probe(const char* __restrict__ w, cons
     if (SYNC) { for (int j = 0; j < D; ++j) signal(&ready[j], lane); }
     __syncthreads();
 
-    HiLo x[8], y[8];
+    HiLo x[TL][8], y[TL][8];
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     const half8* fr = (const half8*)ring + lane;      // + k-step * 256 (4 KiB): [block 0 hi][block 0 lo][block 1 hi][block 1 lo]
     half8 ph0 = fr[0], pl0 = fr[64], ph1 = fr[128], pl1 = fr[192];
-    f32x4 m0, m1, c0, c1, e0, e1;
+    f32x4 m0[TL], m1[TL], c0[TL], c1[TL], e0[TL], e1[TL];
+    half8 qh0 = ph0, ql0 = pl0, qh1 = ph1, ql1 = pl1;              // second prefetch stage (PF = 2)
     for (int p = 0; p < passes; ++p) {
         {
-            const f32x4* src = xin + ((size_t)((p + blockIdx.x) & 7) * NTH + threadIdx.x) * 16;      // stands for the gather of the real kernel
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) x[kb] = split_f16(src[2 * kb], src[2 * kb + 1]);
+            for (int tl = 0; tl < TL; ++tl) {
+                const f32x4* src = xin + ((size_t)((p + blockIdx.x + 3 * tl) & 7) * 512 + threadIdx.x) * 16;      // stands for the gather of the real kernel
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) x[tl][kb] = split_f16(src[2 * kb], src[2 * kb + 1]);
+            }
         }
         const unsigned ubase = (unsigned)p * UPP;
         const bool more = p + 1 < passes;
@@ -102,14 +106,14 @@ __global__ __launch_bounds__(NTH, 2) void probe(const char* __restrict__ w, cons
             constexpr int t = decltype(tt)::value, pair = t / 8, kb = t % 8, ci = t / KPC, kk = t % KPC;
             constexpr int cb = ci % NB;
             constexpr int pi = ci + D, pb = pi % NB;                 // chunk copied during this chunk's steps
-            const HiLo (&in)[8] = (pair < 8) ? x : y;
+            const bool from_x = (pair < 8 || EPI == 2);
             const half8 ah0 = ph0, al0 = pl0, ah1 = ph1, al1 = pl1;
             if (kk == 0 && SYNC) {
                 // pieces issued during the previous chunk's steps have landed (they are a chunk old): publish that chunk
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (t > 0 || p > 0) signal(&ready[(pb + NB - 1) % NB], lane);
                 // buffer pb is free once every wave has issued its last read of the chunk that lived there
-                wait_ge(&done[pb], 8u * (ubase + pi / NB));
+                wait_ge(&done[pb], (unsigned)NWV * (ubase + pi / NB));
             }
             if (kk + 1 < KPC) {
                 const half8* f = fr + cb * (CHB / 16) + (kk + 1) * 256;
@@ -119,22 +123,26 @@ __global__ __launch_bounds__(NTH, 2) void probe(const char* __restrict__ w, cons
                 signal(&done[cb], lane);
                 if (t < 127 || more) {
                     constexpr int nb = (ci + 1) % NB;
-                    wait_ge(&ready[nb], 8u * (ubase + (ci + 1) / NB + 1));
+                    wait_ge(&ready[nb], (unsigned)NWV * (ubase + (ci + 1) / NB + 1));
                     const half8* f = fr + nb * (CHB / 16);
                     ph0 = f[0]; pl0 = f[64]; ph1 = f[128]; pl1 = f[192];
                 }
             }
-            if (kb == 0) {
-                if (EPI == 1 && pair > 0) { e0 = m0 + c0; e1 = m1 + c1; }
-                m0 = f32x4{0.1f, 0.1f, 0.1f, 0.1f}; m1 = m0; c0 = f32x4{0.f, 0.f, 0.f, 0.f}; c1 = c0;
+#pragma unroll
+            for (int tl = 0; tl < TL; ++tl) {
+                if (kb == 0 && (EPI != 2 || t == 0)) {
+                    if (EPI == 1 && pair > 0) { e0[tl] = m0[tl] + c0[tl]; e1[tl] = m1[tl] + c1[tl]; }
+                    m0[tl] = f32x4{0.1f, 0.1f, 0.1f, 0.1f}; m1[tl] = m0[tl]; c0[tl] = f32x4{0.f, 0.f, 0.f, 0.f}; c1[tl] = c0[tl];
+                }
+                const HiLo& in = from_x ? x[tl][kb] : y[tl][kb];
+                m0[tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, in.hi, m0[tl], 0, 0, 0);
+                m1[tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, in.hi, m1[tl], 0, 0, 0);
+                c0[tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, in.lo, c0[tl], 0, 0, 0);
+                c1[tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, in.lo, c1[tl], 0, 0, 0);
+                c0[tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, in.hi, c0[tl], 0, 0, 0);
+                c1[tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, in.hi, c1[tl], 0, 0, 0);
             }
-            m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, in[kb].hi, m0, 0, 0, 0);
-            m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, in[kb].hi, m1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, in[kb].lo, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, in[kb].lo, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, in[kb].hi, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, in[kb].hi, c1, 0, 0, 0);
-            if (kk < PPC) {
+            if (DMA && kk < PPC) {
                 const char* sb = w + (size_t)(pi % NCH) * CHB + kk * NTH * 16;
                 asm volatile("" : "+s"(sb));
                 piece(sb, my + pb * CHB + kk * NTH * 16, lane_off);
@@ -142,24 +150,32 @@ __global__ __launch_bounds__(NTH, 2) void probe(const char* __restrict__ w, cons
             if (EPI == 1 && kb == 0 && pair > 0) {
                 // deferred epilogue of the previous pair, under this k-step's MFMAs
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { e0[r] = fmaxf(e0[r], 0.f); e1[r] = fmaxf(e1[r], 0.f); }
-                if (pair - 1 < 8) y[(pair - 1) & 7] = split_f16(e0, e1); else x[(pair - 1) & 7] = split_f16(e0, e1);
+                for (int tl = 0; tl < TL; ++tl) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { e0[tl][r] = fmaxf(e0[tl][r], 0.f); e1[tl][r] = fmaxf(e1[tl][r], 0.f); }
+                    if (pair - 1 < 8) y[tl][(pair - 1) & 7] = split_f16(e0[tl], e1[tl]); else x[tl][(pair - 1) & 7] = split_f16(e0[tl], e1[tl]);
+                }
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
+                for (int i = 0; i < 6 * TL; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
                 }
             } else {
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6 * TL, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (kb == 7 && (EPI == 0 || pair == NPAIR - 1)) {
-                f32x4 o0 = m0 + c0, o1 = m1 + c1;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { o0[r] = fmaxf(o0[r], 0.f); o1[r] = fmaxf(o1[r], 0.f); }
-                if (pair < 8) y[pair & 7] = split_f16(o0, o1); else x[pair & 7] = split_f16(o0, o1);
+            for (int tl = 0; tl < TL; ++tl) {
+                if (kb == 7 && EPI == 2 && pair == NPAIR - 1) {
+                    x[tl][7] = split_f16(m0[tl] + c0[tl], m1[tl] + c1[tl]);
+                } else if (kb == 7 && (EPI == 0 || (EPI == 1 && pair == NPAIR - 1))) {
+                    f32x4 o0 = m0[tl] + c0[tl], o1 = m1[tl] + c1[tl];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { o0[r] = fmaxf(o0[r], 0.f); o1[r] = fmaxf(o1[r], 0.f); }
+                    if (pair < 8) y[tl][pair & 7] = split_f16(o0, o1); else x[tl][pair & 7] = split_f16(o0, o1);
+                }
             }
             if (kk == KPC - 1 && !(SYNC && XPF)) {
                 constexpr int nb = (ci + 1) % NB;
@@ -168,7 +184,7 @@ __global__ __launch_bounds__(NTH, 2) void probe(const char* __restrict__ w, cons
                     __syncthreads();
                 } else {
                     signal(&done[cb], lane);
-                    if (t < 127 || more) wait_ge(&ready[nb], 8u * (ubase + (ci + 1) / NB + 1));
+                    if (t < 127 || more) wait_ge(&ready[nb], (unsigned)NWV * (ubase + (ci + 1) / NB + 1));
                 }
                 const half8* f = fr + nb * (CHB / 16);
                 ph0 = f[0]; pl0 = f[64]; ph1 = f[128]; pl1 = f[192];
@@ -176,30 +192,32 @@ __global__ __launch_bounds__(NTH, 2) void probe(const char* __restrict__ w, cons
         };
         static_for<0, 128>(step);
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb)
+        for (int tl = 0; tl < TL; ++tl)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sum[j & 3] += (float)x[kb].hi[j] + (float)x[kb].lo[j];
+            for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum[j & 3] += (float)x[tl][kb].hi[j] + (float)x[tl][kb].lo[j];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA of this workgroup may be in flight when its LDS is handed on
-    out[blockIdx.x * NTH + threadIdx.x] = sum.x + sum.y + sum.z + sum.w;
+    out[blockIdx.x * 512 + threadIdx.x] = sum.x + sum.y + sum.z + sum.w;
 }
 
-template <int SYNC, int NB, int D, int KPC, int XPF, int EPI>
+template <int SYNC, int NB, int D, int KPC, int XPF, int EPI, int DMA = 1, int TL = 1, int PF = 1>
 void run(const char* w, const f32x4* xin, float* out, const char* name) {
     const int passes = 60, grid = 256, lds = NB * KPC * 4096 + 128;
-    (void)hipFuncSetAttribute((const void*)probe<SYNC, NB, D, KPC, XPF, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void*)probe<SYNC, NB, D, KPC, XPF, EPI, DMA, TL, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL((probe<SYNC, NB, D, KPC, XPF, EPI>), dim3(grid), dim3(NTH), lds, 0, w, xin, out, 2);
+    hipLaunchKernelGGL((probe<SYNC, NB, D, KPC, XPF, EPI, DMA, TL, PF>), dim3(grid), dim3(512 / TL), lds, 0, w, xin, out, 2);
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL((probe<SYNC, NB, D, KPC, XPF, EPI>), dim3(grid), dim3(NTH), lds, 0, w, xin, out, passes);
+        hipLaunchKernelGGL((probe<SYNC, NB, D, KPC, XPF, EPI, DMA, TL, PF>), dim3(grid), dim3(512 / TL), lds, 0, w, xin, out, passes);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
     }
     const hipError_t err = hipGetLastError();
-    std::vector<float> h(256 * NTH);
+    std::vector<float> h(256 * 512);
     (void)hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost);
     double cs = 0; for (float v : h) cs += v;
     const double mfma = (double)passes * NPAIR * 48.0 * 8 * 256;
@@ -221,8 +239,8 @@ int main() {
     }
     (void)hipMalloc(&w, nh * 2);
     (void)hipMemcpy(w, hw.data(), nh * 2, hipMemcpyHostToDevice);
-    (void)hipMalloc(&out, 256 * NTH * 4);
-    std::vector<float> hx((size_t)8 * NTH * 64);
+    (void)hipMalloc(&out, 256 * 512 * 4);
+    std::vector<float> hx((size_t)8 * 512 * 64);
     for (size_t i = 0; i < hx.size(); ++i) { st = st * 1664525u + 1013904223u; hx[i] = (float)(st >> 8) * (1.0f / 16777216.0f); }
     (void)hipMalloc(&xin, hx.size() * 4);
     (void)hipMemcpy(xin, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
@@ -235,5 +253,17 @@ int main() {
     run<1, 4, 2, 4, 1, 1>(w, xin, out, "flag ring 4 x 16 KiB, 2 ahead, prefetch across chunks, epilogue deferred");
     run<1, 8, 4, 4, 1, 1>(w, xin, out, "flag ring 8 x 16 KiB, 4 ahead, prefetch across chunks, epilogue deferred");
     run<1, 8, 5, 4, 1, 1>(w, xin, out, "flag ring 8 x 16 KiB, 5 ahead, prefetch across chunks, epilogue deferred");
+    // what each part costs on real operands (the ring of 4 stays resident: weights of the first 4 chunks re-read; timing only)
+    run<0, 2, 1, 8, 0, 2, 0>(w, xin, out, "barrier, NO weight stream, NO epilogue (MFMAs + fragment reads + barrier)");
+    run<0, 2, 1, 8, 0, 0, 0>(w, xin, out, "barrier, NO weight stream, epilogue at pair end");
+    run<0, 2, 1, 8, 0, 2, 1>(w, xin, out, "barrier, weight stream, NO epilogue");
+    run<1, 4, 2, 8, 0, 2, 1>(w, xin, out, "flag ring, weight stream, NO epilogue");
+    run<1, 4, 2, 8, 0, 2, 0>(w, xin, out, "flag ring sync only, NO weight stream, NO epilogue");
+    // two 16-row tiles per wave, 4 waves per CU (one per SIMD, 512-register budget): every A fragment feeds 3 MFMAs instead of 1.5
+    run<0, 2, 1, 8, 0, 0, 1, 2>(w, xin, out, "2 tiles/wave, 4 waves: barrier per chunk, epilogue at pair end");
+    run<0, 2, 1, 8, 0, 1, 1, 2>(w, xin, out, "2 tiles/wave, 4 waves: barrier per chunk, epilogue deferred");
+    run<1, 4, 2, 8, 0, 1, 1, 2>(w, xin, out, "2 tiles/wave, 4 waves: flag ring, epilogue deferred");
+    run<1, 4, 2, 8, 1, 1, 1, 2>(w, xin, out, "2 tiles/wave, 4 waves: flag ring, prefetch across chunks, epilogue deferred");
+    run<0, 2, 1, 8, 0, 2, 0, 2>(w, xin, out, "2 tiles/wave, 4 waves: barrier, NO weight stream, NO epilogue");
     return 0;
 }
