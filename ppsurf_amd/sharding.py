@@ -214,6 +214,7 @@ class GradBuckets:
         self._mismatch = None                       # device flag: a later step's global mask differed from the first step's
         self._steps = 0
         self._reset()
+        self._armed = False                         # hooks stay inert until the first zero(): a backward pass outside zero() ... finish() is not ours
 
     def _reset(self):
         # a bucket is complete when every parameter of it that is EXPECTED to get a gradient has one.  Before the first finish() that is every

@@ -22,7 +22,7 @@ for dtype in ('f32', 'f16x3'):
         pipe.run([c])
     torch.cuda.synchronize()
     for i in range(reps):
-        pipe.run([chunks[3 + i % 40]], stage_events=[ev[i].arr])
+        pipe.run([chunks[3 + i % (len(chunks) - 3)]], stage_events=[ev[i].arr])
     torch.cuda.synchronize()
     ms = {n: float(np.median([e.elapsed_ms(j, j + 1) for e in ev])) for j, n in enumerate(names)}
     print(dtype, ' '.join('{} {:.3f}'.format(k, v) for k, v in ms.items()), 'sum {:.3f} ms'.format(sum(ms.values())))

@@ -18,7 +18,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#define NPAIR 16
+#ifndef NPAIR
+#define NPAIR 16                      // 18: like a pass of the real kernel (fc2, fc3 + the two fc_query pairs) -- 18 chunks, divisible by 3
+#endif
 struct HiLo { half8 hi, lo; };
 
 template <int I, int N, class F>
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(512 / TL, TL == 1 ? 2 : 1) void probe(const char* _
     constexpr int NCH = NPAIR * 8 / KPC;              // chunks per pass
     constexpr int PPC = CHB / (NTH * 16);             // 1 KiB-per-wave pieces per chunk and wave
     constexpr int UPP = NCH / NB;                     // uses of a buffer per pass
-    static_assert(NCH % NB == 0 && D < NB && PPC <= KPC && (!XPF || (SYNC && D >= 2)), "ring geometry");
+    static_assert(NCH % NB == 0 && D < NB && PPC <= KPC && (!SYNC || D >= 2), "ring geometry");       // D = 1 with flags deadlocks: a chunk is published at the start of the NEXT step, its readers wait for it at the end of this one
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
     unsigned* ready = (unsigned*)(ring + NB * CHB);
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(512 / TL, TL == 1 ? 2 : 1) void probe(const char* _
             constexpr int t = decltype(tt)::value, pair = t / 8, kb = t % 8, ci = t / KPC, kk = t % KPC;
             constexpr int cb = ci % NB;
             constexpr int pi = ci + D, pb = pi % NB;                 // chunk copied during this chunk's steps
-            const bool from_x = (pair < 8 || EPI == 2);
+            const bool from_x = (pair < 8 || pair >= 16 || EPI == 2);
             const half8 ah0 = ph0, al0 = pl0, ah1 = ph1, al1 = pl1;
             if (kk == 0 && SYNC) {
                 // pieces issued during the previous chunk's steps have landed (they are a chunk old): publish that chunk
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(512 / TL, TL == 1 ? 2 : 1) void probe(const char* _
             } else if (SYNC && XPF) {
                 // last k-step of the chunk: all its reads are issued -> release the buffer; first fragments of the next chunk
                 signal(&done[cb], lane);
-                if (t < 127 || more) {
+                if (t < NPAIR * 8 - 1 || more) {
                     constexpr int nb = (ci + 1) % NB;
                     wait_ge(&ready[nb], (unsigned)NWV * (ubase + (ci + 1) / NB + 1));
                     const half8* f = fr + nb * (CHB / 16);
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(512 / TL, TL == 1 ? 2 : 1) void probe(const char* _
                 for (int tl = 0; tl < TL; ++tl) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { e0[tl][r] = fmaxf(e0[tl][r], 0.f); e1[tl][r] = fmaxf(e1[tl][r], 0.f); }
-                    if (pair - 1 < 8) y[tl][(pair - 1) & 7] = split_f16(e0[tl], e1[tl]); else x[tl][(pair - 1) & 7] = split_f16(e0[tl], e1[tl]);
+                    if (pair - 1 < 8 || pair - 1 >= 16) y[tl][(pair - 1) & 7] = split_f16(e0[tl], e1[tl]); else x[tl][(pair - 1) & 7] = split_f16(e0[tl], e1[tl]);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(512 / TL, TL == 1 ? 2 : 1) void probe(const char* _
                     f32x4 o0 = m0[tl] + c0[tl], o1 = m1[tl] + c1[tl];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { o0[r] = fmaxf(o0[r], 0.f); o1[r] = fmaxf(o1[r], 0.f); }
-                    if (pair < 8) y[tl][pair & 7] = split_f16(o0, o1); else x[tl][pair & 7] = split_f16(o0, o1);
+                    if (pair < 8 || pair >= 16) y[tl][pair & 7] = split_f16(o0, o1); else x[tl][pair & 7] = split_f16(o0, o1);
                 }
             }
             if (kk == KPC - 1 && !(SYNC && XPF)) {
@@ -184,13 +186,13 @@ __global__ __launch_bounds__(512 / TL, TL == 1 ? 2 : 1) void probe(const char* _
                     __syncthreads();
                 } else {
                     signal(&done[cb], lane);
-                    if (t < 127 || more) wait_ge(&ready[nb], (unsigned)NWV * (ubase + (ci + 1) / NB + 1));
+                    if (t < NPAIR * 8 - 1 || more) wait_ge(&ready[nb], (unsigned)NWV * (ubase + (ci + 1) / NB + 1));
                 }
                 const half8* f = fr + nb * (CHB / 16);
                 ph0 = f[0]; pl0 = f[64]; ph1 = f[128]; pl1 = f[192];
             }
         };
-        static_for<0, 128>(step);
+        static_for<0, NPAIR * 8>(step);
 #pragma unroll
         for (int tl = 0; tl < TL; ++tl)
 #pragma unroll
@@ -244,6 +246,16 @@ int main() {
     for (size_t i = 0; i < hx.size(); ++i) { st = st * 1664525u + 1013904223u; hx[i] = (float)(st >> 8) * (1.0f / 16777216.0f); }
     (void)hipMalloc(&xin, hx.size() * 4);
     (void)hipMemcpy(xin, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+#if NPAIR == 18
+    run<0, 2, 1, 8, 0, 0>(w, xin, out, "18 pairs: barrier per 32 KiB chunk, 2 buffers, epilogue at pair end (round 3)");
+    run<0, 2, 1, 8, 0, 1>(w, xin, out, "18 pairs: barrier, epilogue deferred");
+    run<1, 3, 2, 8, 0, 1>(w, xin, out, "18 pairs: flag ring 3 x 32 KiB, 2 ahead, epilogue deferred");
+    run<1, 3, 2, 8, 1, 1>(w, xin, out, "18 pairs: flag ring 3 x 32 KiB, 2 ahead, prefetch across chunks, epilogue deferred");
+    run<1, 4, 2, 4, 0, 1>(w, xin, out, "18 pairs: flag ring 4 x 16 KiB, 2 ahead, epilogue deferred");
+    run<1, 6, 3, 4, 0, 1>(w, xin, out, "18 pairs: flag ring 6 x 16 KiB, 3 ahead, epilogue deferred");
+    run<1, 6, 4, 4, 0, 1>(w, xin, out, "18 pairs: flag ring 6 x 16 KiB, 4 ahead, epilogue deferred");
+    run<1, 9, 6, 4, 0, 1>(w, xin, out, "18 pairs: flag ring 9 x 16 KiB, 6 ahead, epilogue deferred");
+#else
     run<0, 2, 1, 8, 0, 0>(w, xin, out, "barrier per 32 KiB chunk, 2 buffers, epilogue at pair end (round 3)");
     run<0, 2, 1, 8, 0, 1>(w, xin, out, "barrier per 32 KiB chunk, epilogue deferred under the next pair's first k-step");
     run<1, 4, 2, 8, 0, 0>(w, xin, out, "flag ring 4 x 32 KiB, 2 ahead, epilogue at pair end");
@@ -265,5 +277,6 @@ int main() {
     run<1, 4, 2, 8, 0, 1, 1, 2>(w, xin, out, "2 tiles/wave, 4 waves: flag ring, epilogue deferred");
     run<1, 4, 2, 8, 1, 1, 1, 2>(w, xin, out, "2 tiles/wave, 4 waves: flag ring, prefetch across chunks, epilogue deferred");
     run<0, 2, 1, 8, 0, 2, 0, 2>(w, xin, out, "2 tiles/wave, 4 waves: barrier, NO weight stream, NO epilogue");
+#endif
     return 0;
 }
