@@ -217,3 +217,29 @@ def test_four_ranks_uneven_ranges_and_chunk_floor(tmp_path):
     assert [int(r[i]['uneven_seen']) for i in range(4)] == [251, 251, 251, 250]
     assert [int(r[i]['floor_seen']) for i in range(4)] == [502, 501, 0, 0]
     assert [int(r[i]['one_seen']) for i in range(4)] == [50, 0, 0, 0]
+
+
+def test_dense_grid_blocks_shard_into_contiguous_z_slab_runs():
+    """dense z-slabs of the (R+2)^3 grid as the sharding unit.  The dense query list of bench_workloads.dense_chunks is the grid in index
+    order; sharding.shard_ranges cuts any list into contiguous ranges, so every rank owns a run of consecutive voxels (whole z-columns / x-slabs
+    plus at most two partial ones), the ranges tile the block, and the coordinates follow poco_utils.py:212-213."""
+    import bench_workloads as workloads
+    from ppsurf_amd import sharding
+    cloud = np.random.default_rng(0).uniform(-0.5, 0.5, (500, 3)).astype(np.float32)
+    res, chunk = 31, 4000
+    chunks, nblocks = workloads.dense_chunks(cloud, res, chunk, 'cpu', n_chunks=3)
+    n = res + 2
+    assert nblocks == n ** 3 // chunk and len(chunks) == 3 and all(c.shape == (chunk, 3) for c in chunks)
+    step, bmin_pad, _ = workloads.grid_geometry(cloud, res)
+    first = chunks[0]
+    lin = np.arange(chunk)
+    ijk = np.stack([lin // (n * n), (lin // n) % n, lin % n], axis=1).astype(np.float32)
+    assert np.array_equal(first.numpy(), ijk * np.float32(step) + np.float32(bmin_pad))          # block 0 starts at voxel (0, 0, 0), z fastest
+    for world in (2, 4, 8):
+        ranges = sharding.shard_ranges(chunk, world, min_shard=256)
+        assert ranges[0][0] == 0 and ranges[-1][1] == chunk and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        sizes = [hi - lo for lo, hi in ranges]
+        assert max(sizes) - min(sizes) <= 1
+        for lo, hi in ranges:                                        # consecutive voxels: the z index advances by one, wrapping at n
+            z = np.round((first[lo:hi, 2].numpy() - np.float32(bmin_pad)) / np.float32(step)).astype(np.int64)
+            assert np.all((np.diff(z) == 1) | (np.diff(z) == -(n - 1)))
