@@ -266,6 +266,57 @@ __device__ __forceinline__ void dense_blocks_f16x3(const HiLo (&in)[KB], const h
     dense_blocks_f16x3_hook<KB, NOB, ACT, FENCE, INIT>(in, w, bias, lane, sink, [](int, int) {}, init);
 }
 
+// The same layer for T row tiles of ONE wave at once (T = 2: 32 rows): every A fragment read from LDS feeds 3 T MFMAs instead of 3, and a streamed
+// weight chunk (with its barrier) is paid once per T tiles.  Possible where the per-tile state is small -- the PointNet row kernels: 64 / 128-channel
+// activations, 16 / 32 VGPRs per tile -- not in the 256-channel interpolation layers.  sink(tile, pair, o0, o1).
+template <int T, int KB, int NOB, int ACT, bool FENCE = true, class Sink>
+__device__ __forceinline__ void dense_blocks_f16x3_tiles(const HiLo (&in)[T][KB], const half8* __restrict__ w, const f32x4* __restrict__ bias, int lane,
+                                                         Sink&& sink) {
+    static_assert(NOB % 2 == 0, "output blocks are processed in pairs");
+    const int g = lane >> 4;
+#pragma unroll
+    for (int ob = 0; ob < NOB; ob += 2) {
+        f32x4 m0[T], m1[T], c0[T], c1[T];
+        const f32x4 b0 = bias[(ob) * 4 + g], b1 = bias[(ob + 1) * 4 + g];
+#pragma unroll
+        for (int t = 0; t < T; ++t) { m0[t] = b0; m1[t] = b1; c0[t] = f32x4{0.f, 0.f, 0.f, 0.f}; c1[t] = c0[t]; }
+        const half8* w0 = w + ((ob) * KB) * 128 + lane;
+        const half8* w1 = w + ((ob + 1) * KB) * 128 + lane;
+        half8 ph0 = w0[0], pl0 = w0[64], ph1 = w1[0], pl1 = w1[64];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const half8 ah0 = ph0, al0 = pl0, ah1 = ph1, al1 = pl1;
+            if (kb + 1 < KB) {
+                ph0 = w0[(kb + 1) * 128]; pl0 = w0[(kb + 1) * 128 + 64];
+                ph1 = w1[(kb + 1) * 128]; pl1 = w1[(kb + 1) * 128 + 64];
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                m0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, in[t][kb].hi, m0[t], 0, 0, 0);
+                m1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, in[t][kb].hi, m1[t], 0, 0, 0);
+                c0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, in[t][kb].lo, c0[t], 0, 0, 0);
+                c1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, in[t][kb].lo, c1[t], 0, 0, 0);
+                c0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, in[t][kb].hi, c0[t], 0, 0, 0);
+                c1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, in[t][kb].hi, c1[t], 0, 0, 0);
+            }
+            if (FENCE) {
+                __builtin_amdgcn_sched_group_barrier(PPS_SG_DSREAD, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(PPS_SG_MFMA, 6 * T, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            f32x4 o0 = m0[t] + c0[t], o1 = m1[t] + c1[t];
+            if (ACT == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { o0[r] = fmaxf(o0[r], 0.f); o1[r] = fmaxf(o1[r], 0.f); }
+            }
+            sink(t, ob >> 1, o0, o1);
+        }
+    }
+}
+
 // first layer for xyz inputs (K = 3 padded to 4): B operand of lane (n,g) is coordinate g of row n (0 for g = 3).
 // wxyz packed [ob][lane]:  W[16*ob + (l & 15)][l >> 4]  (0 for l >> 4 == 3).
 template <int NOB>

@@ -637,6 +637,46 @@ __device__ __forceinline__ void stn_chain_h(float coord, f32x4 (&z)[16], const f
     __builtin_amdgcn_s_setprio(0);
 }
 
+// The split-precision chain for T tiles of one wave at once (pps_common.h, dense_blocks_f16x3_tiles): one pass over the streamed weights and one set
+// of A-fragment reads serve T x 16 rows.  conv3's output blocks are handed to zsink(tile, first_block, o0, o1) as they leave the matrix pipe (the
+// callers reduce them at once: a tile's 256 channels are never held).  Per tile the arithmetic is exactly that of stn_chain_h: results do not
+// depend on how tiles are grouped.
+template <int T, class ZSink>
+__device__ __forceinline__ void stn_chain_h_tiles(const float (&coord)[T], const float* xyz_l, const f32x4* bias4, const f32x4* wg,
+                                                  f32x4*& cur, f32x4*& nxt, int lane, float& amax, ZSink&& zsink) {
+    const int g = lane >> 4;
+    HiLo a[T][2], b[T][2], y[T][4];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        f32x4 x0[4];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) x0[bb] = bias4[4 * bb + g];
+        xyz_blocks<4>(coord[t], x0, xyz_l, lane);
+        relu_blocks<4>(x0);
+        a[t][0] = split_f16_r(amax, x0[0], x0[1]);
+        a[t][1] = split_f16_r(amax, x0[2], x0[3]);
+    }
+    __builtin_amdgcn_s_setprio(PPS_PRIO_PN);
+    stream_step<1024, PNT>(wg + 1024, cur, nxt, [&](const f32x4* w) {
+        dense_blocks_f16x3_tiles<T, 2, 4, 1>(a, (const half8*)w, bias4 + 16, lane, [&](int t, int i, const f32x4& o0, const f32x4& o1) { b[t][i] = split_f16_r(amax, o0, o1); }); });
+    stream_step<PCH4, PNT>(wg + 2048, cur, nxt, [&](const f32x4* w) {
+        dense_blocks_f16x3_tiles<T, 2, 4, 1>(b, (const half8*)w, bias4 + 32, lane, [&](int t, int i, const f32x4& o0, const f32x4& o1) { a[t][i] = split_f16_r(amax, o0, o1); }); });
+#pragma unroll
+    for (int h = 0; h < PN_C2N; ++h)
+        stream_step<PCH4, PNT>(wg + 2048 + (h + 1) * PCH4, cur, nxt, [&](const f32x4* w) {
+            dense_blocks_f16x3_tiles<T, 2, PN_C2OB, 1>(a, (const half8*)w, bias4 + 48 + 4 * PN_C2OB * h, lane,
+                                                      [&](int t, int i, const f32x4& o0, const f32x4& o1) { y[t][PN_C2OB / 2 * h + i] = split_f16_r(amax, o0, o1); }); });
+#pragma unroll
+    for (int c = 0; c < PN_C3N - 1; ++c)
+        stream_step<PCH4, PNT>(wg + 4096 + (c + 1) * PCH4, cur, nxt, [&](const f32x4* w) {
+            dense_blocks_f16x3_tiles<T, 4, PN_C3OB, 1>(y, (const half8*)w, bias4 + 80 + 4 * PN_C3OB * c, lane,
+                                                      [&](int t, int i, const f32x4& o0, const f32x4& o1) { zsink(t, PN_C3OB * c + 2 * i, o0, o1); }); });
+    stream_step<1024, PNT>(wg, cur, nxt, [&](const f32x4* w) {
+        dense_blocks_f16x3_tiles<T, 4, PN_C3OB, 1>(y, (const half8*)w, bias4 + 80 + 4 * PN_C3OB * (PN_C3N - 1), lane,
+                                                  [&](int t, int i, const f32x4& o0, const f32x4& o1) { zsink(t, PN_C3OB * (PN_C3N - 1) + 2 * i, o0, o1); }); });
+    __builtin_amdgcn_s_setprio(0);
+}
+
 // H = false: fp32 (wdense = wpack + 256 floats of the same image); H = true: split precision (wdense = the f16x3 image)
 template <bool H>
 __global__ __launch_bounds__(PNT, 2) void pointnet_stn_rows_kernel(const float* __restrict__ patches, int64_t Q, int P, int pack,
@@ -669,6 +709,55 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_stn_rows_kernel(const float* 
     xcd_tile_range(ntiles, first, count, stride);
     for (int it = 0; it < count; ++it) {
         const int64_t q0 = ((int64_t)(first + it * stride) * PNW + wave) * pk.qg;
+        if constexpr (H) {
+            // split precision: conv3's blocks are reduced as they are produced, and the full tiles of a query go through the chain two at a time
+            if (pk.packed) {
+                const int ql = n / pk.lo;
+                const int64_t qq = (q0 + ql < Q) ? q0 + ql : Q - 1;
+                const float coord[1] = {(g < 3) ? patches[(qq * P + pk.fb * 16 + (n % pk.lo)) * 3 + g] : 0.f};
+                stn_chain_h_tiles<1>(coord, xyz_l, bias4, wg, cur, nxt, lane, amax, [&](int, int bb, const f32x4& o0, const f32x4& o1) {
+                    f32x4 m0, m1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { m0[r] = group_max(o0[r], pk.lo); m1[r] = group_max(o1[r], pk.lo); }
+                    if ((n % pk.lo) == 0) { ((f32x4*)(mypark + ql * PN_ROWF))[4 * bb + g] = m0; ((f32x4*)(mypark + ql * PN_ROWF))[4 * (bb + 1) + g] = m1; }
+                });
+            }
+            for (int qi = 0; qi < pk.qg; ++qi) {
+                const int64_t q = q0 + qi;
+                const bool qv = q < Q;
+                const int64_t qc = qv ? q : Q - 1;
+                f32x4 rmax[16];
+#pragma unroll
+                for (int bb = 0; bb < 16; ++bb)
+                    rmax[bb] = pk.packed ? ((const f32x4*)(mypark + qi * PN_ROWF))[4 * bb + g] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                auto zmax = [&](int, int bb, const f32x4& o0, const f32x4& o1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { rmax[bb][r] = fmaxf(rmax[bb][r], o0[r]); rmax[bb + 1][r] = fmaxf(rmax[bb + 1][r], o1[r]); }
+                };
+                auto row_coord = [&](int rb) {
+                    const int row = rb * 16 + n;
+                    const int rowc = row < P ? row : P - 1;       // padded rows repeat a valid point: max unaffected
+                    return (g < 3) ? patches[(qc * P + rowc) * 3 + g] : 0.f;
+                };
+                int rb = 0;
+                for (; rb + 1 < pk.fb; rb += 2) {
+                    const float coord[2] = {row_coord(rb), row_coord(rb + 1)};
+                    stn_chain_h_tiles<2>(coord, xyz_l, bias4, wg, cur, nxt, lane, amax, zmax);
+                }
+                if (rb < pk.fb) {
+                    const float coord[1] = {row_coord(rb)};
+                    stn_chain_h_tiles<1>(coord, xyz_l, bias4, wg, cur, nxt, lane, amax, zmax);
+                }
+#pragma unroll
+                for (int bb = 0; bb < 16; ++bb) {
+                    f32x4 p;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[r] = row16_max(rmax[bb][r]);
+                    if (n == 0 && qv) ((f32x4*)(gout + q * 256))[4 * bb + g] = p;
+                }
+            }
+            continue;
+        }
         f32x4 z[16];
         if (pk.packed) {
             // the LO left-over rows of the QG queries of this wave, one tile
@@ -877,8 +966,10 @@ __device__ __forceinline__ void feat_chain(float coord, const float* __restrict_
     xyz_blocks<4>(coord, x0, xyz_l, lane);
     relu_blocks<4>(x0);
     __builtin_amdgcn_s_setprio(PPS_PRIO_PN);
-    stream_step<1024, PNT>(wg + 1024, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 16, lane); });
-    // feature transform x0 = trans2[q] (64x64, row-major) @ x1, A operand straight from global.  The A operand is shared by
+    // (the chunk behind conv0b's in the image is conv1's: not streamed any more, conv1 is folded into the per-query matrix by the host)
+    stream_step<PCH4, PNT>(wg + 2048, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 16, lane); });
+    // feature transform AND conv1 in one product: x0 = M[q] @ x1 with M = W1 (trans2[q]) (64x64, row-major; the host composes conv1 into the
+    // last STN layer, ppsurf_amd/decoder.py), then conv1's bias and ReLU.  A operand straight from global.  The A operand is shared by
     // the 16 columns of an MFMA, so a tile holding rows of nq different queries is done as nq accumulating products with
     // the columns of the other queries zeroed (nq = 1 for the full tiles: one product, no masking cost).
 #pragma unroll
@@ -907,7 +998,12 @@ __device__ __forceinline__ void feat_chain(float coord, const float* __restrict_
             x0[ob] = o;
         }
     }
-    stream_step<PCH4, PNT>(wg + 2048, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 32, lane); });
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+        const f32x4 b1 = bias4[32 + 4 * ob + g];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x1[ob][r] = fmaxf(x0[ob][r] + b1[r], 0.f);
+    }
 #pragma unroll
     for (int h = 0; h < PN_C2N; ++h)
         stream_step<PCH4, PNT>(wg + 2048 + (h + 1) * PCH4, cur, nxt,
@@ -960,9 +1056,9 @@ __device__ __forceinline__ void feat_chain_h(float coord, const float* __restric
         a[1] = split_f16_r(amax, x0[2], x0[3]);
     }
     __builtin_amdgcn_s_setprio(PPS_PRIO_PN);
-    stream_step<1024, PNT>(wg + 1024, cur, nxt, [&](const f32x4* w) {
+    stream_step<PCH4, PNT>(wg + 2048, cur, nxt, [&](const f32x4* w) {            // conv0b; the next chunk needed is conv2's first (conv1 is folded, see feat_chain)
         dense_blocks_f16x3<2, 4, 1>(a, (const half8*)w, bias4 + 16, lane, [&](int i, const f32x4& o0, const f32x4& o1) { b[i] = split_f16_r(amax, o0, o1); }); });
-    // feature transform with the per-query 64 x 64 matrix: three f16 products per (output block, k-block)
+    // feature transform + conv1 with the per-query 64 x 64 matrix M = W1 trans2: three f16 products per (output block, k-block)
     f32x4 t0[4];
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) t0[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -990,10 +1086,14 @@ __device__ __forceinline__ void feat_chain_h(float coord, const float* __restric
             t0[ob] = o + c;
         }
     }
-    a[0] = split_f16_r(amax, t0[0], t0[1]);
-    a[1] = split_f16_r(amax, t0[2], t0[3]);
-    stream_step<PCH4, PNT>(wg + 2048, cur, nxt, [&](const f32x4* w) {
-        dense_blocks_f16x3<2, 4, 1>(a, (const half8*)w, bias4 + 32, lane, [&](int i, const f32x4& o0, const f32x4& o1) { b[i] = split_f16_r(amax, o0, o1); }); });
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {                 // conv1's bias and ReLU
+        const f32x4 b1 = bias4[32 + 4 * ob + g];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t0[ob][r] = fmaxf(t0[ob][r] + b1[r], 0.f);
+    }
+    b[0] = split_f16_r(amax, t0[0], t0[1]);
+    b[1] = split_f16_r(amax, t0[2], t0[3]);
     float s = 0.f;                                   // attention logit, accumulated while conv2's output blocks are still fp32
 #pragma unroll
     for (int h = 0; h < PN_C2N; ++h)

@@ -122,10 +122,15 @@ class DecoderPlan:
         c3 = _fold_bn(*_wb(sd, pn + 'conv3'), sd, pn + 'bn3')
         aq_w, aq_b = _wb(sd, pn + 'att.fc_query')
         av_w, av_b = _wb(sd, pn + 'att.fc_value')
+        # conv1 (with its folded BatchNorm) acts on  trans2 @ x  (nn.py:327-334): W1 (T x) = (W1 T) x.  The last STN layer is linear in its input, so
+        # it can emit M = W1 T directly: rows (o, b) of  f3m = sum_a W1[o, a] fc3[(a, b), :],  bias  W1 (mat(b3) + I).  The feature kernel then
+        # applies ONE 64 x 64 matrix per query and conv1's bias + ReLU (24 of its 312 MFMAs per tile and one streamed weight chunk less)
+        f3m = np.einsum('oa,abc->obc', c1[0], f3w.reshape(64, 64, 64)).reshape(4096, 64)
+        f3mb = (c1[0] @ (f3b.reshape(64, 64) + np.eye(64))).reshape(-1)
         host['pa_w'] = np.concatenate([pack_xyz(c0a[0]), pack_dense(c0b[0]), pack_dense(s1[0]), pack_dense(s2[0]), pack_dense(s3[0])])
         host['pa_b'] = f32(np.concatenate([c0a[1], c0b[1], s1[1], s2[1], s3[1]]))
-        host['pb_w'] = np.concatenate([pack_dense(f1[0]), pack_dense(f2[0]), pack_dense(f3w)])
-        host['pb_b'] = f32(np.concatenate([f1[1], f2[1], f3b + np.eye(64).reshape(-1)]))        # + identity (nn.py:187-188)
+        host['pb_w'] = np.concatenate([pack_dense(f1[0]), pack_dense(f2[0]), pack_dense(f3m)])
+        host['pb_b'] = f32(np.concatenate([f1[1], f2[1], f3mb]))                                # identity (nn.py:187-188) and conv1 inside
         host['pc_w'] = np.concatenate([pack_xyz(c0a[0]), pack_dense(c0b[0]), pack_dense(c1[0]), pack_dense(c2[0]), pack_dense(c3[0])])
         # the attention logit of a patch point is linear in conv3's input: wq.(W3 y + b3) + bq = (W3^T wq).y + (wq.b3 + bq) (nn.py:88,336);
         # the kernels take u = W3^T wq and the constant, so the logit is known before conv3 runs (pps_decode.hip, feat_chain)
@@ -153,7 +158,7 @@ class DecoderPlan:
         self.w = {k: torch.from_numpy(v).to(self.device) for k, v in host.items()}
         self.w16 = None
         if self.dtype == 'f16x3':
-            split_layers = [w2, w3, wq, c0b[0], s1[0], s2[0], s3[0], f1[0], f2[0], f3w, c1[0], c2[0], c3[0], wa, wb, l2[0], l3w]
+            split_layers = [w2, w3, wq, c0b[0], s1[0], s2[0], s3[0], f1[0], f2[0], f3m, c2[0], c3[0], wa, wb, l2[0], l3w]
             wmax = max(float(np.abs(m_).max()) for m_ in split_layers)
             if not wmax < 65504.0:
                 # a weight that f16 cannot hold: the split W = hi + lo does not exist.  (Activations are guarded on the device, see decode().)
@@ -161,7 +166,7 @@ class DecoderPlan:
                 warnings.warn('decoder dtype f16x3 needs |weight| < 65504 (largest: {:.3g}); using the exact fp32 kernels'.format(wmax))
                 self.dtype = 'f32'
         if self.dtype == 'f16x3':
-            sets = [[w2, w3, wq], [c0b[0], s1[0], s2[0], s3[0]], [f1[0], f2[0], f3w], [c0b[0], c1[0], c2[0], c3[0]]]
+            sets = [[w2, w3, wq], [c0b[0], s1[0], s2[0], s3[0]], [f1[0], f2[0], f3m], [c0b[0], c1[0], c2[0], c3[0]]]
             imgs = [np.concatenate([pack_dense_f16x3(m) for m in ms]) for ms in sets]
             # tail: the two halves of the 512 -> 256 layer alternate in 32 KiB chunks (two output blocks each), then L2, L3 (pps_decode_tail_f16x3)
             ab = np.stack([pack_dense_f16x3(wa).reshape(8, -1), pack_dense_f16x3(wb).reshape(8, -1)], axis=1).reshape(-1)
@@ -186,7 +191,8 @@ class DecoderPlan:
 
     def intermediates(self, q):
         """Views of the last decode() call's scratch (layout of pps_decode_fwd_f32): pooled [q,256], g [q,256],
-        trans2 [q,4096], xbar [q,256] -- for tests and debugging."""
+        trans2 [q,4096] (= conv1 @ trans2 of the reference, 64 x 64 row-major: conv1 is folded into the STN's last layer), xbar [q,256] -- for
+        tests and debugging."""
         ws = self.scratch('decode_ws', (_lib.lib().pps_decode_ws_bytes(q) // 4,))
         sizes = (('pooled', C), ('g', C), ('trans2', 4096), ('xbar', C))
         out, off = {}, 16                                      # 64 bytes of range-guard words first

@@ -77,8 +77,8 @@ def decode(w, latents_cn, pts, query, idx, patches):
     bc = _split(w['pc_b'].astype(np.float64), [64, 64, 64, 128, 256, 256, 4])
     y0 = relu(x @ unpack_xyz(xc, 64).T + bc[0])
     y1 = relu(y0 @ unpack_dense(c0b2, 64, 64).T + bc[1])
-    y = np.einsum('qab,qpb->qpa', trans2, y1)
-    y = relu(y @ unpack_dense(c1, 64, 64).T + bc[2])
+    # `trans2` of the packed images is M = conv1 @ trans2 (conv1 is folded into the STN's last layer by DecoderPlan): one product, then conv1's bias
+    y = relu(np.einsum('qab,qpb->qpa', trans2, y1) + bc[2])
     y = relu(y @ unpack_dense(c2, 128, 64).T + bc[3])
     wgt = softmax(y @ bc[5][:128] + bc[6][0], axis=1)          # attention logit from conv3's INPUT: u = W3^T wq, constant wq.b3 + bq
     y = y @ unpack_dense(c3, 256, 128).T + bc[4]

@@ -210,7 +210,11 @@ def test_pointnet_branch_matches_reference_module_fixture(name, p, dtype):
     pl.decode(pl.point_table(dev(make_latents(256, 500, seed=2)[0])), dev(cloud), dev(qry), dev(ids), dev(patches))
     inter = pl.intermediates(q)
     if dtype == 'f32':                 # (f16x3 keeps the matrix as pre-split hi / lo fragments in the order its consumer reads them: checked through xbar)
-        np.testing.assert_allclose(inter['trans2'][:trans2.shape[0]].cpu().numpy().reshape(-1, 64, 64), trans2, rtol=0, atol=2e-5)
+        # the kernels hold M = conv1 (with its eval BatchNorm folded) @ trans2: conv1 is composed into the STN's last layer (decoder.py)
+        from ppsurf_amd.decoder import _fold_bn, _wb
+        w1 = _fold_bn(*_wb(pn, pre + 'conv1'), pn, pre + 'bn1')[0]
+        want = np.einsum('oa,qab->qob', w1, trans2.astype(np.float64))
+        np.testing.assert_allclose(inter['trans2'][:trans2.shape[0]].cpu().numpy().reshape(-1, 64, 64), want, rtol=0, atol=5e-5)
     wv = pn[pre + 'att.fc_value.weight'].reshape(256, 256).double()
     got = inter['xbar'].double().cpu() @ wv.t() + pn[pre + 'att.fc_value.bias'].double()
     np.testing.assert_allclose(got.numpy(), feat, rtol=0, atol=5e-5)
