@@ -159,21 +159,26 @@ int pps_pointnet_stn_rows_f32(const float* patches, int64_t q, int p, const floa
 
 /* PointNet branch, phase B: STN fully connected part 256 -> 128 -> 64 -> 4096 (+identity, folded into the bias).
  * replaces: source/base/nn.py:183-189.   g [q,256]; trans2 out [q,64,64].
- * wpack = concat(dense fc1 [128,256], fc2 [64,128], fc3 [4096,64]); bias = concat(128,64,4096). */
+ * wpack = concat(dense fc1 [128,256], fc2 [64,128], fc3 [4096,64]); bias = concat(128,64,4096).
+ * The host may compose conv1 of phase C into fc3 (rows (o,b) = sum_a W1[o,a] fc3[(a,b),:], bias W1 (mat(b3) + I)): the kernel then emits
+ * M = W1 trans2, which is what pps_pointnet_feat_rows_f32 expects (ppsurf_amd/decoder.py does). */
 int pps_pointnet_stn_fc_f32(const float* g, int64_t q, const float* wpack, const float* bias, float* trans2, void* stream);
 
-/* PointNet branch, phase C: conv0a/0b (recomputed), feature transform, conv1..3, attention pooling weights,
- * pooled (pre fc_value) feature.   replaces: source/base/nn.py:323-336 and :84-96 (value conv applied in the tail).
- * patches [q,p,3]; trans2 [q,64,64]; xbar out [q,256].
- * wpack = concat(xyz conv0a, dense conv0b [64,64], conv1 [64,64], conv2 [128,64], conv3 [256,128]);
- * bias = concat(64,64,64,128,256, att.fc_query weight [256], att.fc_query bias [1] padded to 4). */
+/* PointNet branch, phase C: conv0a/0b (recomputed), feature transform + conv1 as ONE per-query matrix (trans2 = W1 T of phase B; conv1's bias and
+ * ReLU applied here), conv2, attention weights, and the attention-POOLED conv2 output.   replaces: source/base/nn.py:323-336 and :84-96 up to
+ * linear maps that commute with the pooling: conv3 + bn3 (no activation, nn.py:336) and att.fc_value act on the pooled vector inside the tail.
+ * patches [q,p,3]; trans2 [q,64,64]; xbar out [q,128].
+ * wpack = concat(xyz conv0a, dense conv0b [64,64], conv2 [128,64]);
+ * bias = concat(conv0a 64, conv0b 64, conv1 64, conv2 128, 256 unused, u = conv3^T att.fc_query weight [128] padded to 256,
+ *               att.fc_query.conv3 bias + att.fc_query bias [1] padded to 4). */
 int pps_pointnet_feat_rows_f32(const float* patches, const float* trans2, int64_t q, int p, const float* wpack,
                                const float* bias, float* xbar, void* stream);
 
-/* Tail: [pooled | xbar] (512) -> 256 (ReLU) -> 256 (ReLU) -> 2 logits.
+/* Tail: [pooled 256 | xbar 128] -> 256 (ReLU) -> 256 (ReLU) -> 2 logits (wpack = [Wa 256x256][Wb 256x128][L2 256x256][L3 2x256 padded]; Wb carries
+ * conv3 of the PointNet branch).
  * replaces: fc_value+fc8 (poco_model.py:410-417), att.fc_value (nn.py:89-93), the branch sum
  *           (source/ppsurf_model.py:100) and source/base/nn.py:415-417 `MLP.forward`, composed on the host.
- * wpack = concat(dense Wa [256,256], Wb [256,256], L2 [256,256], L3 [2,256] (padded to 32)); bias = concat(256,256,32).
+ * wpack = concat(dense Wa [256,256], Wb [256,128], L2 [256,256], L3 [2,256] (padded to 32)); bias = concat(256,256,32).  pooled [q,256], xbar [q,128].
  * logits out f32 [q,2]; occ out f32 [q] = softmax(logits)[0]-softmax(logits)[1] (poco_utils.py:78-81) or NULL. */
 int pps_decode_tail_f32(const float* pooled, const float* xbar, int64_t q, const float* wpack, const float* bias,
                         float* logits, float* occ, void* stream);
@@ -208,13 +213,13 @@ int pps_decode_fwd_events_f32(const float* table, const float* pts, const float*
 int pps_interp_pool_f16x3(const float* G, const float* pts, const float* query, const int64_t* idx, int64_t q, int k,
                           const float* wxyz, const void* w16, const float* bias, float* pooled, int32_t* range_flag, void* stream);
 /* The PointNet branch in split precision: weights = the six fp32 images (stn_rows, stn_fc, feat_rows: wpack, bias each -- xyz layers and
- * biases are read from them), w16 [host] array of 3 pps_pack_dense_f16x3 image sets: (c0b, s1, s2, s3), (fc1, fc2, fc3), (c0b, c1, c2, c3);
- * g [q,256], trans2 (q x 16 KiB: pre-split fragments of the per-query feature transform), xbar [q,256]; events: 3 hipEvent_t or NULL. */
+ * biases are read from them), w16 [host] array of 3 pps_pack_dense_f16x3 image sets: (c0b, s1, s2, s3), (fc1, fc2, fc3 with conv1 composed), (c0b, c2);
+ * g [q,256], trans2 (q x 16 KiB: pre-split fragments of the per-query feature transform), xbar [q,128]; events: 3 hipEvent_t or NULL. */
 int pps_pointnet_f16x3(const float* patches, int64_t q, int p, const float* const* weights, const void* const* w16, float* g, float* trans2,
                        float* xbar, int32_t* range_flag, void* const* events, void* stream);
 /* The tail (pps_decode_tail_f32: source/ppsurf_model.py:100, source/base/nn.py:376-417 composed with fc8 . fc_value | att.fc_value) in split
- * precision: w16 = pps_pack_dense_f16x3 images of Wa 256x256 and Wb 256x256 interleaved in 32 KiB chunks (chunk 2c: output blocks 2c, 2c+1 of Wa,
- * chunk 2c+1: the same blocks of Wb), then [L2 256x256][L3 2x256]; bias as for the fp32 entry. */
+ * precision: w16 = pps_pack_dense_f16x3 images of Wa 256x256 and Wb 256x128 interleaved per pair of output blocks (32 KiB of Wa for blocks 2c, 2c+1,
+ * then 16 KiB of Wb for the same blocks), then [L2 256x256][L3 2x256]; bias as for the fp32 entry. */
 int pps_decode_tail_f16x3(const float* pooled, const float* xbar, int64_t q, const void* w16, const float* bias, float* logits, float* occ,
                           int32_t* range_flag, void* stream);
 /* pps_decode_fwd_events_f32 with branches in split precision: w16 [host] array of 5 image sets (interp, stn_rows, stn_fc, feat_rows, tail);

@@ -98,6 +98,15 @@ __device__ __forceinline__ void rows16_sum_transposed(f32x4 (&v)[16], int lane) 
     butterfly_step<1, 0xB1>(v, (lane & 1) != 0);     // quad_perm [1,0,3,2]   partner n ^ 1
 }
 
+// the same for an 8-block tile (128 channels): lanes n and n ^ 8 are added first, then three halving steps; lane (n,g) ends with block n & 7
+__device__ __forceinline__ void rows16_sum_transposed8(f32x4 (&v)[8], int lane) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) v[b] += dpp_mov4<0x128>(v[b]);   // row_ror:8
+    butterfly_step<4, 0x141>(v, (lane & 4) != 0);
+    butterfly_step<2, 0x4E>(v, (lane & 2) != 0);
+    butterfly_step<1, 0xB1>(v, (lane & 1) != 0);
+}
+
 // ---- dense layer on a register tile ------------------------------------------------------------------
 // out[ob] = act( bias + sum_kb W[ob][kb] * in[kb] ),  weights read through `w` (LDS or global, packed layout,
 // pointing at the first f32x4 of (ob = OB0, kb = 0) for this lane's chunk), two output blocks in flight.

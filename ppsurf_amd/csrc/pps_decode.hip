@@ -942,19 +942,19 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_h_kernel(const float* _
 
 // =====================================================================================================
 // PointNet phase C: conv0a, conv0b, x <- trans2 x, conv1, conv2 (+ReLU), conv3 (no ReLU), attention pooling
-// weights (floats): [xyz 256][c0b 4096][c1 4096][c2 8192][c3 32768]   bias [64][64][64][128][256][u = W3^T wq 128 | pad 128][wq.b3 + bq, 0, 0, 0]
+// weights (floats): [xyz 256][c0b 4096][c2 8192]   bias [64][64][c1 64][128][c3 256: unused here][u = W3^T wq 128 | pad 128][wq.b3 + bq, 0, 0, 0]
+// output xbar [q,128]: the attention-pooled conv2 features (conv1 lives in the per-query matrix, conv3 in the tail: decoder.py)
 // Row packing as in phase A; the left-over tile parks, per query, the softmax partials (max m, sum S, weighted sum A[256]).
 // =====================================================================================================
 #define PC_W_XYZ 256
 #define PC_NBIAS (576 + 256 + 4)
 #define PC_LDS_BYTES (2 * PCH4 * 16 + (PC_W_XYZ + PC_NBIAS + PNW * PN_PARK_ROWS * PN_ROWF) * 4)
 
-// conv0a .. conv3 on one 16-row tile of query `tq` (per-row feature transform), then the attention logit of each row
+// conv0a, conv0b, the per-query transform (with conv1 folded in) and conv2 on one 16-row tile, then the attention logit of each row.
 // rows_per_query = 16 and nq = 1 for a tile of one query; a left-over tile holds nq queries x rows_per_query rows
-// The attention logit of a row (nn.py:88) is linear in conv3's INPUT: s = wq.(W3 y + b3) + bq = (W3^T wq).y + (wq.b3 + bq); the host
-// packs u = W3^T wq (128 values) and the constant, so s is known BEFORE conv3 runs: `on_logit(s)` updates the softmax state and the 16
-// output blocks of conv3 are handed to `on_block(first_block, z0, z1)` as they leave the matrix pipe -- the tile's 256 channels are
-// never held at once (64 VGPRs less than computing s from the finished tile).
+// The attention logit of a row (nn.py:88) is linear in conv3's INPUT y (conv2's 128-channel output): s = wq.(W3 y + b3) + bq = (W3^T wq).y +
+// (wq.b3 + bq); the host packs u = W3^T wq and the constant.  `on_logit(s)` updates the softmax state, then the 8 blocks of y are handed to
+// `on_block(first_block, y0, y1)`: conv3 itself runs once per query on the pooled y, composed into the tail (decoder.py).
 template <class OnLogit, class OnBlock>
 __device__ __forceinline__ void feat_chain(float coord, const float* __restrict__ trans2, int64_t q0, int64_t Q, int nq, int rows_per_query,
                                            const float* xyz_l, const f32x4* bias4, const f32x4* u4, float s0,
@@ -966,8 +966,7 @@ __device__ __forceinline__ void feat_chain(float coord, const float* __restrict_
     xyz_blocks<4>(coord, x0, xyz_l, lane);
     relu_blocks<4>(x0);
     __builtin_amdgcn_s_setprio(PPS_PRIO_PN);
-    // (the chunk behind conv0b's in the image is conv1's: not streamed any more, conv1 is folded into the per-query matrix by the host)
-    stream_step<PCH4, PNT>(wg + 2048, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 16, lane); });
+    stream_step<PCH4, PNT>(wg + 1024, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 16, lane); });      // conv0b; next: conv2
     // feature transform AND conv1 in one product: x0 = M[q] @ x1 with M = W1 (trans2[q]) (64x64, row-major; the host composes conv1 into the
     // last STN layer, ppsurf_amd/decoder.py), then conv1's bias and ReLU.  A operand straight from global.  The A operand is shared by
     // the 16 columns of an MFMA, so a tile holding rows of nq different queries is done as nq accumulating products with
@@ -1005,11 +1004,12 @@ __device__ __forceinline__ void feat_chain(float coord, const float* __restrict_
         for (int r = 0; r < 4; ++r) x1[ob][r] = fmaxf(x0[ob][r] + b1[r], 0.f);
     }
 #pragma unroll
-    for (int h = 0; h < PN_C2N; ++h)
-        stream_step<PCH4, PNT>(wg + 2048 + (h + 1) * PCH4, cur, nxt,
+    for (int h = 0; h < PN_C2N; ++h)                 // conv2 (64 -> 128, ReLU); its last chunk fetches conv0b for the next tile
+        stream_step<PCH4, PNT>(h + 1 < PN_C2N ? wg + 1024 + (h + 1) * PCH4 : wg, cur, nxt,
                                [&](const f32x4* w) { dense_blocks<4, PN_C2OB, 1>(x1, &y[PN_C2OB * h], w, bias4 + 48 + 4 * PN_C2OB * h, lane); });
+    __builtin_amdgcn_s_setprio(0);
     {
-        float s = 0.f;                               // attention logit of row n from conv3's input
+        float s = 0.f;                               // attention logit of row n: linear in conv2's output (u = W3^T wq packed by the host)
 #pragma unroll
         for (int bb = 0; bb < 8; ++bb) {
             const f32x4 w4 = u4[4 * bb + g];
@@ -1020,22 +1020,10 @@ __device__ __forceinline__ void feat_chain(float coord, const float* __restrict_
         s += __shfl_xor(s, 32);
         on_logit(s + s0);
     }
-    static_assert(PN_C3OB % 2 == 0, "conv3 is streamed in pairs of output blocks");
+    // conv3 is not evaluated per row: it is linear and followed by the (sum-to-one) attention pooling only, so the POOLED conv2 output goes
+    // through it once per query, inside the tail (decoder.py).  The row's 128 channels are handed to the pooling as they are.
 #pragma unroll
-    for (int c = 0; c < PN_C3N - 1; ++c)
-        stream_step<PCH4, PNT>(wg + 4096 + (c + 1) * PCH4, cur, nxt, [&](const f32x4* w) {
-            f32x4 zz[PN_C3OB];
-            dense_blocks<8, PN_C3OB, 0>(y, zz, w, bias4 + 80 + 4 * PN_C3OB * c, lane);
-#pragma unroll
-            for (int i = 0; i < PN_C3OB; i += 2) on_block(PN_C3OB * c + i, zz[i], zz[i + 1]);
-        });
-    stream_step<1024, PNT>(wg, cur, nxt, [&](const f32x4* w) {
-        f32x4 zz[PN_C3OB];
-        dense_blocks<8, PN_C3OB, 0>(y, zz, w, bias4 + 80 + 4 * PN_C3OB * (PN_C3N - 1), lane);
-#pragma unroll
-        for (int i = 0; i < PN_C3OB; i += 2) on_block(PN_C3OB * (PN_C3N - 1) + i, zz[i], zz[i + 1]);
-    });
-    __builtin_amdgcn_s_setprio(0);
+    for (int bb = 0; bb < 8; bb += 2) on_block(bb, y[bb], y[bb + 1]);
 }
 
 // split precision: `trans2` is the pre-split fragment image written by pointnet_stn_fc_h_kernel (A operands straight from global,
@@ -1045,7 +1033,7 @@ __device__ __forceinline__ void feat_chain_h(float coord, const float* __restric
                                              const float* xyz_l, const f32x4* bias4, const f32x4* u4, float s0,
                                              const f32x4* wg, f32x4*& cur, f32x4*& nxt, int lane, float& amax, OnLogit&& on_logit, OnBlock&& on_block) {
     const int n = lane & 15, g = lane >> 4;
-    HiLo a[2], b[2], y[4];
+    HiLo a[2], b[2];
     {
         f32x4 x0[4];
 #pragma unroll
@@ -1056,7 +1044,7 @@ __device__ __forceinline__ void feat_chain_h(float coord, const float* __restric
         a[1] = split_f16_r(amax, x0[2], x0[3]);
     }
     __builtin_amdgcn_s_setprio(PPS_PRIO_PN);
-    stream_step<PCH4, PNT>(wg + 2048, cur, nxt, [&](const f32x4* w) {            // conv0b; the next chunk needed is conv2's first (conv1 is folded, see feat_chain)
+    stream_step<PCH4, PNT>(wg + 1024, cur, nxt, [&](const f32x4* w) {            // conv0b; the next chunk is conv2's first
         dense_blocks_f16x3<2, 4, 1>(a, (const half8*)w, bias4 + 16, lane, [&](int i, const f32x4& o0, const f32x4& o1) { b[i] = split_f16_r(amax, o0, o1); }); });
     // feature transform + conv1 with the per-query 64 x 64 matrix M = W1 trans2: three f16 products per (output block, k-block)
     f32x4 t0[4];
@@ -1094,29 +1082,25 @@ __device__ __forceinline__ void feat_chain_h(float coord, const float* __restric
     }
     b[0] = split_f16_r(amax, t0[0], t0[1]);
     b[1] = split_f16_r(amax, t0[2], t0[3]);
-    float s = 0.f;                                   // attention logit, accumulated while conv2's output blocks are still fp32
+    float s = 0.f;                                   // attention logit, accumulated as conv2's output blocks arrive
+    f32x4 y[8];                                      // conv2's output stays fp32: nothing multiplies it any more (conv3 is behind the pooling)
 #pragma unroll
     for (int h = 0; h < PN_C2N; ++h)
-        stream_step<PCH4, PNT>(wg + 2048 + (h + 1) * PCH4, cur, nxt, [&](const f32x4* w) {
+        stream_step<PCH4, PNT>(h + 1 < PN_C2N ? wg + 1024 + (h + 1) * PCH4 : wg, cur, nxt, [&](const f32x4* w) {
             dense_blocks_f16x3<2, PN_C2OB, 1>(b, (const half8*)w, bias4 + 48 + 4 * PN_C2OB * h, lane, [&](int i, const f32x4& o0, const f32x4& o1) {
                 const int bb = PN_C2OB * h + 2 * i;
                 const f32x4 w0 = u4[4 * bb + g], w1 = u4[4 * (bb + 1) + g];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s += w0[r] * o0[r] + w1[r] * o1[r];
-                y[PN_C2OB / 2 * h + i] = split_f16_r(amax, o0, o1);
+                y[bb] = o0;
+                y[bb + 1] = o1;
             }); });
+    __builtin_amdgcn_s_setprio(0);
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
     on_logit(s + s0);
 #pragma unroll
-    for (int c = 0; c < PN_C3N - 1; ++c)
-        stream_step<PCH4, PNT>(wg + 4096 + (c + 1) * PCH4, cur, nxt, [&](const f32x4* w) {
-            dense_blocks_f16x3<4, PN_C3OB, 0>(y, (const half8*)w, bias4 + 80 + 4 * PN_C3OB * c, lane,
-                                              [&](int i, const f32x4& o0, const f32x4& o1) { on_block(PN_C3OB * c + 2 * i, o0, o1); }); });
-    stream_step<1024, PNT>(wg, cur, nxt, [&](const f32x4* w) {
-        dense_blocks_f16x3<4, PN_C3OB, 0>(y, (const half8*)w, bias4 + 80 + 4 * PN_C3OB * (PN_C3N - 1), lane,
-                                          [&](int i, const f32x4& o0, const f32x4& o1) { on_block(PN_C3OB * (PN_C3N - 1) + 2 * i, o0, o1); }); });
-    __builtin_amdgcn_s_setprio(0);
+    for (int bb = 0; bb < 8; bb += 2) on_block(bb, y[bb], y[bb + 1]);
 }
 
 template <bool H>
@@ -1130,7 +1114,7 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float*
     f32x4* buf1 = buf0 + PCH4;
     float* xyz_l = (float*)(buf1 + PCH4);
     float* bias_l = xyz_l + PC_W_XYZ;
-    float* park = bias_l + PC_NBIAS;                   // [PNW][PN_PARK_ROWS][PN_ROWF]: A[256], m, S of the left-over rows
+    float* park = bias_l + PC_NBIAS;                   // [PNW][PN_PARK_ROWS][PN_ROWF]: A[128] (+ 128 unused), m, S of the left-over rows
     const f32x4* bias4 = (const f32x4*)bias_l;
     const f32x4* u4 = bias4 + 144;                       // W3^T wq: 128 values in the block layout of conv3's input
     const f32x4* wg = wdense;
@@ -1179,14 +1163,14 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float*
             const int64_t qc = qv ? q : Q - 1;
             const float* row = mypark + qi * PN_ROWF;
             // per-lane (unreduced) online-softmax state; the parked left-over partials seed lane n == 0
-            f32x4 acc[16];
+            f32x4 acc[8];                             // 128 channels: the pooled conv2 output (conv3 follows in the tail)
             float mrun = -INFINITY, ssum = 0.f;
             if (pk.packed) {
                 mrun = row[256];
                 ssum = (n == 0) ? row[257] : 0.f;
             }
 #pragma unroll
-            for (int bb = 0; bb < 16; ++bb) {
+            for (int bb = 0; bb < 8; ++bb) {
                 const f32x4 a4 = pk.packed ? ((const f32x4*)row)[4 * bb + g] : f32x4{0.f, 0.f, 0.f, 0.f};
                 acc[bb] = (pk.packed && n == 0) ? a4 : f32x4{0.f, 0.f, 0.f, 0.f};
             }
@@ -1206,7 +1190,7 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float*
                     mrun = mnew;
                     ssum = ssum * scale + en;
 #pragma unroll
-                    for (int bb = 0; bb < 16; ++bb)
+                    for (int bb = 0; bb < 8; ++bb)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc[bb][r] *= scale;
                 };
@@ -1218,16 +1202,16 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float*
                 else feat_chain(coord, trans2, qc, Q, 1, 16, xyz_l, bias4, u4, s0, wg, cur, nxt, lane, on_logit, on_block);
             }
             const float inv = 1.f / row16_sum(ssum);
-            rows16_sum_transposed(acc, lane);             // lane (n,g): acc[0] = sum over the 16 lanes of block n
-            if (qv) ((f32x4*)(xbar + q * 256))[4 * n + g] = acc[0] * inv;
+            rows16_sum_transposed8(acc, lane);            // lane (n,g): acc[0] = sum over the 16 lanes of block n & 7
+            if (qv && n < 8) ((f32x4*)(xbar + q * 128))[4 * n + g] = acc[0] * inv;
         }
     }
     if (H) range_commit(amax, flag);
 }
 
 // =====================================================================================================
-// Tail: [pooled | xbar] -> 256 (ReLU) -> 256 (ReLU) -> 2
-// weights (floats): [Wa 65536][Wb 65536][L2 65536][L3 8192]   bias [256][256][32]
+// Tail: [pooled 256 | xbar 128] -> 256 (ReLU) -> 256 (ReLU) -> 2      (Wb carries conv3 of the PointNet branch, decoder.py)
+// weights (floats): [Wa 65536][Wb 32768][L2 65536][L3 8192]   bias [256][256][32]
 // =====================================================================================================
 #define TL_NBIAS (256 + 256 + 32)
 #define TL_LDS_BYTES (2 * CH4 * 16 + TL_NBIAS * 4)
@@ -1259,24 +1243,26 @@ __global__ __launch_bounds__(NT, 2) void decode_tail_kernel(const float* __restr
         const int64_t qi = (int64_t)(first + it * stride) * (NW * 16) + wave * 16 + n;
         const bool qv = qi < Q;
         const int64_t qc = qv ? qi : Q - 1;
-        f32x4 p[16], x[16], h[16];
+        f32x4 p[16], x[8], h[16];
         {
             const f32x4* sp = (const f32x4*)(pooled + qc * 256) + g;
-            const f32x4* sx = (const f32x4*)(xbar + qc * 256) + g;
+            const f32x4* sx = (const f32x4*)(xbar + qc * 128) + g;
 #pragma unroll
-            for (int bb = 0; bb < 16; ++bb) { p[bb] = sp[4 * bb]; x[bb] = sx[4 * bb]; }
+            for (int bb = 0; bb < 16; ++bb) p[bb] = sp[4 * bb];
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) x[bb] = sx[4 * bb];
         }
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
+        for (int c = 0; c < 8; ++c)                                  // Wa . pooled + bias: chunks 0..7 (two output blocks each)
             stream_step<CH4>(wg + (c + 1) * CH4, cur, nxt,
                            [&](const f32x4* w) { dense_blocks<16, 2, 0>(p, &h[2 * c], w, bias4 + 8 * c, lane); });
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
+        for (int c = 0; c < 4; ++c)                                  // + Wb . xbar (K = 128: four output blocks per 32 KiB chunk), ReLU: chunks 8..11
             stream_step<CH4>(wg + (c + 9) * CH4, cur, nxt,
-                           [&](const f32x4* w) { dense_blocks<16, 2, 1, 1>(x, &h[2 * c], w, bias4, lane); });
+                           [&](const f32x4* w) { dense_blocks<8, 4, 1, 1>(x, &h[4 * c], w, bias4, lane); });
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-            stream_step<CH4>(wg + (c + 17) * CH4, cur, nxt,
+        for (int c = 0; c < 8; ++c)                                  // L2: chunks 12..19, then L3 (chunk 20)
+            stream_step<CH4>(wg + (c + 13) * CH4, cur, nxt,
                            [&](const f32x4* w) { dense_blocks<16, 2, 1>(h, &p[2 * c], w, bias4 + 64 + 8 * c, lane); });
         f32x4 o[2];
         stream_step<CH4>(wg, cur, nxt, [&](const f32x4* w) { dense_blocks<16, 2, 0>(p, o, w, bias4 + 128, lane); });
@@ -1321,28 +1307,28 @@ __global__ __launch_bounds__(NT, 2) void decode_tail_h_kernel(const float* __res
         const int64_t qi = (int64_t)(first + it * stride) * (NW * 16) + wave * 16 + n;
         const bool qv = qi < Q;
         const int64_t qc = qv ? qi : Q - 1;
-        HiLo p[8], x[8];
+        HiLo p[8], x[4];
         {
             const f32x4* sp = (const f32x4*)(pooled + qc * 256) + g;
-            const f32x4* sx = (const f32x4*)(xbar + qc * 256) + g;
+            const f32x4* sx = (const f32x4*)(xbar + qc * 128) + g;
 #pragma unroll
-            for (int kb = 0; kb < 8; ++kb) {
-                p[kb] = split_f16_r(amax, sp[4 * (2 * kb)], sp[4 * (2 * kb + 1)]);
-                x[kb] = split_f16_r(amax, sx[4 * (2 * kb)], sx[4 * (2 * kb + 1)]);
-            }
+            for (int kb = 0; kb < 8; ++kb) p[kb] = split_f16_r(amax, sp[4 * (2 * kb)], sp[4 * (2 * kb + 1)]);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) x[kb] = split_f16_r(amax, sx[4 * (2 * kb)], sx[4 * (2 * kb + 1)]);
         }
         HiLo y[8];
+        // image: 8 x [Wa pair c: 2048 f32x4 | Wb pair c: 1024 f32x4], L2 at 24576 (8 x 2048), L3 at 40960
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {                                  // output blocks 2c, 2c+1 of the 512 -> 256 layer: the chunks of Wa and Wb alternate
+        for (int c = 0; c < 8; ++c) {                                  // output blocks 2c, 2c+1 of the (256 + 128) -> 256 layer: the chunks of Wa and Wb alternate
             f32x4 h[2];
-            stream_step<CH4>(wg + (2 * c + 1) * CH4, cur, nxt, [&](const f32x4* w) {             // Wa . pooled + bias, no activation yet
+            stream_step<CH4 / 2>(wg + c * 3072 + 2048, cur, nxt, [&](const f32x4* w) {           // Wa . pooled + bias, no activation yet; next: Wb pair c (16 KiB)
                 dense_blocks_f16x3<8, 2, 0>(p, (const half8*)w, bias4 + 8 * c, lane, [&](int, const f32x4& o0, const f32x4& o1) { h[0] = o0; h[1] = o1; }); });
-            stream_step<CH4>(wg + (2 * c + 2) * CH4, cur, nxt, [&](const f32x4* w) {             // + Wb . xbar, ReLU
-                dense_blocks_f16x3<8, 2, 1, true, true>(x, (const half8*)w, bias4, lane, [&](int, const f32x4& o0, const f32x4& o1) { y[c] = split_f16_r(amax, o0, o1); }, h); });
+            stream_step<CH4>(c + 1 < 8 ? wg + (c + 1) * 3072 : wg + 24576, cur, nxt, [&](const f32x4* w) {      // + Wb . xbar (K = 128), ReLU
+                dense_blocks_f16x3<4, 2, 1, true, true>(x, (const half8*)w, bias4, lane, [&](int, const f32x4& o0, const f32x4& o1) { y[c] = split_f16_r(amax, o0, o1); }, h); });
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c)
-            stream_step<CH4>(wg + (c + 17) * CH4, cur, nxt, [&](const f32x4* w) {
+            stream_step<CH4>(wg + 24576 + (c + 1) * 2048, cur, nxt, [&](const f32x4* w) {
                 dense_blocks_f16x3<8, 2, 1>(y, (const half8*)w, bias4 + 64 + 8 * c, lane, [&](int, const f32x4& o0, const f32x4& o1) { p[c] = split_f16_r(amax, o0, o1); }); });
         f32x4 o[2];
         stream_step<CH4>(wg, cur, nxt, [&](const f32x4* w) {
@@ -1437,7 +1423,7 @@ static int launch_feat_rows(const float* patches, const float* trans2, int64_t q
     if (q > sp.q_packed)
         hipLaunchKernelGGL(pointnet_feat_rows_kernel<H>, dim3(sp.grid_rest), dim3(PNT), PC_LDS_BYTES, (hipStream_t)stream,
                            patches + sp.q_packed * p * 3, trans2 + sp.q_packed * 4096, q - sp.q_packed, p, sp.rest_mode, wpack, (const f32x4*)wdense, bias,
-                           xbar + sp.q_packed * 256, flag);
+                           xbar + sp.q_packed * 128, flag);
     return PPS_LAUNCH_CHECK();
 }
 

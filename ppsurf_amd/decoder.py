@@ -131,7 +131,11 @@ class DecoderPlan:
         host['pa_b'] = f32(np.concatenate([c0a[1], c0b[1], s1[1], s2[1], s3[1]]))
         host['pb_w'] = np.concatenate([pack_dense(f1[0]), pack_dense(f2[0]), pack_dense(f3m)])
         host['pb_b'] = f32(np.concatenate([f1[1], f2[1], f3mb]))                                # identity (nn.py:187-188) and conv1 inside
-        host['pc_w'] = np.concatenate([pack_xyz(c0a[0]), pack_dense(c0b[0]), pack_dense(c1[0]), pack_dense(c2[0]), pack_dense(c3[0])])
+        # conv3 (+ bn3, no activation: nn.py:336) is followed by the attention pooling only, and both the attention logit and the value are
+        # linear in its output: sum_p w_p Wv (W3 y_p + b3) = Wv W3 (sum_p w_p y_p) + Wv b3 (weights sum to one).  The feature kernel therefore pools
+        # conv2's 128-channel output y and conv3 joins att.fc_value / the first MLP layer in the tail, evaluated once per QUERY instead of once per
+        # patch point (192 of the 288 MFMAs of a tile, 144 of the 192 KB of streamed weights per tile)
+        host['pc_w'] = np.concatenate([pack_xyz(c0a[0]), pack_dense(c0b[0]), pack_dense(c2[0])])
         # the attention logit of a patch point is linear in conv3's input: wq.(W3 y + b3) + bq = (W3^T wq).y + (wq.b3 + bq) (nn.py:88,336);
         # the kernels take u = W3^T wq and the constant, so the logit is known before conv3 runs (pps_decode.hip, feat_chain)
         u_att = c3[0].T @ aq_w.reshape(-1)
@@ -145,20 +149,20 @@ class DecoderPlan:
         if l3w.shape[0] != 2:
             raise NotImplementedError('occupancy head must have 2 outputs')
         wa = l1[0] @ w8 @ wv
-        wb = l1[0] @ av_w
-        ba = l1[0] @ (w8 @ bv + b8 + av_b) + l1[1]
+        wb = l1[0] @ av_w @ c3[0]                                                               # 256 x 128: acts on the pooled conv2 output
+        ba = l1[0] @ (w8 @ bv + b8 + av_w @ c3[1] + av_b) + l1[1]
         host['tl_w'] = np.concatenate([pack_dense(wa), pack_dense(wb), pack_dense(l2[0]), pack_dense(l3w)])
         host['tl_b'] = f32(np.concatenate([ba, l2[1], _pad(l3b, 32)]))
         expect = {'g_w': 65536, 'ip_w': 1024 + 65536 * 2 + 16384, 'ip_b': 576, 'pa_w': 256 + 4096 * 2 + 8192 + 32768,
-                  'pa_b': 576, 'pb_w': 32768 + 8192 + 262144, 'pb_b': 128 + 64 + 4096, 'pc_w': 256 + 4096 * 2 + 8192 + 32768,
-                  'pc_b': 576 + 256 + 4, 'tl_w': 65536 * 3 + 8192, 'tl_b': 544}
+                  'pa_b': 576, 'pb_w': 32768 + 8192 + 262144, 'pb_b': 128 + 64 + 4096, 'pc_w': 256 + 4096 + 8192,
+                  'pc_b': 576 + 256 + 4, 'tl_w': 65536 + 32768 + 65536 + 8192, 'tl_b': 544}
         for k, n in expect.items():
             assert host[k].shape == (n,), (k, host[k].shape, n)
         self.device = torch.device(device)
         self.w = {k: torch.from_numpy(v).to(self.device) for k, v in host.items()}
         self.w16 = None
         if self.dtype == 'f16x3':
-            split_layers = [w2, w3, wq, c0b[0], s1[0], s2[0], s3[0], f1[0], f2[0], f3m, c2[0], c3[0], wa, wb, l2[0], l3w]
+            split_layers = [w2, w3, wq, c0b[0], s1[0], s2[0], s3[0], f1[0], f2[0], f3m, c2[0], wa, wb, l2[0], l3w]
             wmax = max(float(np.abs(m_).max()) for m_ in split_layers)
             if not wmax < 65504.0:
                 # a weight that f16 cannot hold: the split W = hi + lo does not exist.  (Activations are guarded on the device, see decode().)
@@ -166,12 +170,15 @@ class DecoderPlan:
                 warnings.warn('decoder dtype f16x3 needs |weight| < 65504 (largest: {:.3g}); using the exact fp32 kernels'.format(wmax))
                 self.dtype = 'f32'
         if self.dtype == 'f16x3':
-            sets = [[w2, w3, wq], [c0b[0], s1[0], s2[0], s3[0]], [f1[0], f2[0], f3m], [c0b[0], c1[0], c2[0], c3[0]]]
+            sets = [[w2, w3, wq], [c0b[0], s1[0], s2[0], s3[0]], [f1[0], f2[0], f3m], [c0b[0], c2[0]]]
             imgs = [np.concatenate([pack_dense_f16x3(m) for m in ms]) for ms in sets]
-            # tail: the two halves of the 512 -> 256 layer alternate in 32 KiB chunks (two output blocks each), then L2, L3 (pps_decode_tail_f16x3)
-            ab = np.stack([pack_dense_f16x3(wa).reshape(8, -1), pack_dense_f16x3(wb).reshape(8, -1)], axis=1).reshape(-1)
+            # tail: the two parts of the (256 + 128) -> 256 layer alternate chunk by chunk (two output blocks each: 32 KiB of Wa, 16 KiB of Wb), then
+            # L2, L3 (pps_decode_tail_f16x3)
+            pa_, pb_ = pack_dense_f16x3(wa).reshape(8, -1), pack_dense_f16x3(wb).reshape(8, -1)
+            ab = np.concatenate([np.concatenate([pa_[c], pb_[c]]) for c in range(8)])
             imgs.append(np.concatenate([ab, pack_dense_f16x3(l2[0]), pack_dense_f16x3(l3w)]))
-            assert [i.shape[0] for i in imgs] == [2 * (65536 * 2 + 16384), 2 * 49152, 2 * (32768 + 8192 + 262144), 2 * 49152, 2 * (65536 * 3 + 8192)]
+            assert [i.shape[0] for i in imgs] == [2 * (65536 * 2 + 16384), 2 * 49152, 2 * (32768 + 8192 + 262144), 2 * (4096 + 8192),
+                                                  2 * (65536 + 32768 + 65536 + 8192)]
             self._w16_t = [torch.from_numpy(i.view(np.int16)).to(self.device) for i in imgs]
             self.w16 = (ctypes.c_void_p * 5)(*[t.data_ptr() for t in self._w16_t])
         self._scratch = {}
@@ -194,10 +201,10 @@ class DecoderPlan:
         trans2 [q,4096] (= conv1 @ trans2 of the reference, 64 x 64 row-major: conv1 is folded into the STN's last layer), xbar [q,256] -- for
         tests and debugging."""
         ws = self.scratch('decode_ws', (_lib.lib().pps_decode_ws_bytes(q) // 4,))
-        sizes = (('pooled', C), ('g', C), ('trans2', 4096), ('xbar', C))
+        sizes = (('pooled', C), ('g', C), ('trans2', 4096), ('xbar', C))       # xbar: the first q x 128 floats of its slot hold the pooled conv2 output
         out, off = {}, 16                                      # 64 bytes of range-guard words first
         for name, width in sizes:
-            out[name] = ws[off:off + q * width].view(q, width)
+            out[name] = ws[off:off + q * width].view(q, width) if name != 'xbar' else ws[off:off + q * 128].view(q, 128)
             off += q * width
         return out
 

@@ -73,7 +73,7 @@ def decode(w, latents_cn, pts, query, idx, patches):
     u = relu(gmax @ unpack_dense(f1, 128, 256).T + bb[0])
     u = relu(u @ unpack_dense(f2, 64, 128).T + bb[1])
     trans2 = (u @ unpack_dense(f3, 4096, 64).T + bb[2]).reshape(-1, 64, 64)
-    xc, c0b2, c1, c2, c3 = rows(w['pc_w'], None, None)
+    xc, c0b2, c2 = _split(w['pc_w'], [256, 4096, 8192])
     bc = _split(w['pc_b'].astype(np.float64), [64, 64, 64, 128, 256, 256, 4])
     y0 = relu(x @ unpack_xyz(xc, 64).T + bc[0])
     y1 = relu(y0 @ unpack_dense(c0b2, 64, 64).T + bc[1])
@@ -81,10 +81,9 @@ def decode(w, latents_cn, pts, query, idx, patches):
     y = relu(np.einsum('qab,qpb->qpa', trans2, y1) + bc[2])
     y = relu(y @ unpack_dense(c2, 128, 64).T + bc[3])
     wgt = softmax(y @ bc[5][:128] + bc[6][0], axis=1)          # attention logit from conv3's INPUT: u = W3^T wq, constant wq.b3 + bq
-    y = y @ unpack_dense(c3, 256, 128).T + bc[4]
-    xbar = (wgt[:, :, None] * y).sum(axis=1)
-    wa, wb, l2w, l3w = _split(w['tl_w'], [65536, 65536, 65536, 8192])
+    xbar = (wgt[:, :, None] * y).sum(axis=1)                   # conv3 is behind the pooling, composed into the tail's Wb (decoder.py)
+    wa, wb, l2w, l3w = _split(w['tl_w'], [65536, 32768, 65536, 8192])
     bt = _split(w['tl_b'].astype(np.float64), [256, 256, 32])
-    hh = relu(pooled @ unpack_dense(wa, 256, 256).T + xbar @ unpack_dense(wb, 256, 256).T + bt[0])
+    hh = relu(pooled @ unpack_dense(wa, 256, 256).T + xbar @ unpack_dense(wb, 256, 128).T + bt[0])
     hh = relu(hh @ unpack_dense(l2w, 256, 256).T + bt[1])
     return hh @ unpack_dense(l3w, 2, 256).T + bt[2][:2], trans2

@@ -215,8 +215,13 @@ def test_pointnet_branch_matches_reference_module_fixture(name, p, dtype):
         w1 = _fold_bn(*_wb(pn, pre + 'conv1'), pn, pre + 'bn1')[0]
         want = np.einsum('oa,qab->qob', w1, trans2.astype(np.float64))
         np.testing.assert_allclose(inter['trans2'][:trans2.shape[0]].cpu().numpy().reshape(-1, 64, 64), want, rtol=0, atol=5e-5)
+    # the kernels pool conv2's 128-channel output; conv3 (+ bn3) and att.fc_value follow once per query (composed into the tail by DecoderPlan):
+    # finish them here on the host to compare with the reference's pooled feature
+    from ppsurf_amd.decoder import _fold_bn, _wb
+    w3, b3 = _fold_bn(*_wb(pn, pre + 'conv3'), pn, pre + 'bn3')
     wv = pn[pre + 'att.fc_value.weight'].reshape(256, 256).double()
-    got = inter['xbar'].double().cpu() @ wv.t() + pn[pre + 'att.fc_value.bias'].double()
+    z = inter['xbar'].double().cpu() @ torch.from_numpy(w3).t() + torch.from_numpy(b3)
+    got = z @ wv.t() + pn[pre + 'att.fc_value.bias'].double()
     np.testing.assert_allclose(got.numpy(), feat, rtol=0, atol=5e-5)
 
 
