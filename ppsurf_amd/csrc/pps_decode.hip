@@ -941,270 +941,154 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_h_kernel(const float* _
 }
 
 // =====================================================================================================
-// PointNet phase C: conv0a, conv0b, x <- trans2 x, conv1, conv2 (+ReLU), conv3 (no ReLU), attention pooling
-// weights (floats): [xyz 256][c0b 4096][c2 8192]   bias [64][64][c1 64][128][c3 256: unused here][u = W3^T wq 128 | pad 128][wq.b3 + bq, 0, 0, 0]
+// PointNet phase C: conv0a, conv0b, x <- M x (M = conv1 . trans2 of phase B) + conv1's bias, ReLU, conv2 (+ReLU), attention pooling of conv2's output
+// weights (floats): [xyz 256][c0b 4096][c2 8192]   bias [64][64][c1 64][128][256 unused][u = W3^T wq 128 | pad 128][wq.b3 + bq, 0, 0, 0]
 // output xbar [q,128]: the attention-pooled conv2 features (conv1 lives in the per-query matrix, conv3 in the tail: decoder.py)
-// Row packing as in phase A; the left-over tile parks, per query, the softmax partials (max m, sum S, weighted sum A[256]).
+//
+// One wave = one query at a time.  With conv1 and conv3 composed away the layer weights are 48 KiB (both dtypes) and stay RESIDENT in LDS: no
+// weight stream, no barrier in the main loop, the waves of a workgroup are independent.  What bounds the kernel is the per-query matrix M (16 KiB per
+// query, written by phase B): a wave loads it ONCE into registers (64 VGPRs of A fragments) and applies it to all ceil(P/16) tiles of its query --
+// the round-3 kernel fetched it once per tile and once more for the packed left-over rows (4 x 16 KiB per query at P = 50).  Left-over rows are a
+// padded tile here (rows >= P repeat a valid point and get weight 0): 4 instead of 3.125 tiles per query at P = 50, 96 MFMAs each -- a quarter of the
+// matrix work the kernel did before conv3 moved, for a quarter of the fetch.
 // =====================================================================================================
 #define PC_W_XYZ 256
 #define PC_NBIAS (576 + 256 + 4)
-#define PC_LDS_BYTES (2 * PCH4 * 16 + (PC_W_XYZ + PC_NBIAS + PNW * PN_PARK_ROWS * PN_ROWF) * 4)
-
-// conv0a, conv0b, the per-query transform (with conv1 folded in) and conv2 on one 16-row tile, then the attention logit of each row.
-// rows_per_query = 16 and nq = 1 for a tile of one query; a left-over tile holds nq queries x rows_per_query rows
-// The attention logit of a row (nn.py:88) is linear in conv3's INPUT y (conv2's 128-channel output): s = wq.(W3 y + b3) + bq = (W3^T wq).y +
-// (wq.b3 + bq); the host packs u = W3^T wq and the constant.  `on_logit(s)` updates the softmax state, then the 8 blocks of y are handed to
-// `on_block(first_block, y0, y1)`: conv3 itself runs once per query on the pooled y, composed into the tail (decoder.py).
-template <class OnLogit, class OnBlock>
-__device__ __forceinline__ void feat_chain(float coord, const float* __restrict__ trans2, int64_t q0, int64_t Q, int nq, int rows_per_query,
-                                           const float* xyz_l, const f32x4* bias4, const f32x4* u4, float s0,
-                                           const f32x4* wg, f32x4*& cur, f32x4*& nxt, int lane, OnLogit&& on_logit, OnBlock&& on_block) {
-    const int n = lane & 15, g = lane >> 4;
-    f32x4 x0[4], x1[4], y[8];
-#pragma unroll
-    for (int bb = 0; bb < 4; ++bb) x0[bb] = bias4[4 * bb + g];
-    xyz_blocks<4>(coord, x0, xyz_l, lane);
-    relu_blocks<4>(x0);
-    __builtin_amdgcn_s_setprio(PPS_PRIO_PN);
-    stream_step<PCH4, PNT>(wg + 1024, cur, nxt, [&](const f32x4* w) { dense_blocks<4, 4, 1>(x0, x1, w, bias4 + 16, lane); });      // conv0b; next: conv2
-    // feature transform AND conv1 in one product: x0 = M[q] @ x1 with M = W1 (trans2[q]) (64x64, row-major; the host composes conv1 into the
-    // last STN layer, ppsurf_amd/decoder.py), then conv1's bias and ReLU.  A operand straight from global.  The A operand is shared by
-    // the 16 columns of an MFMA, so a tile holding rows of nq different queries is done as nq accumulating products with
-    // the columns of the other queries zeroed (nq = 1 for the full tiles: one product, no masking cost).
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob) x0[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int qi = 0; qi < nq; ++qi) {
-        const int64_t qq = (q0 + qi < Q) ? q0 + qi : Q - 1;
-        const f32x4* tq = (const f32x4*)(trans2 + qq * 4096);
-        const bool mine = (n / rows_per_query) == qi;
-        f32x4 xm[4];
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) xm[kb] = mine ? x1[kb] : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ob = 0; ob < 4; ++ob) {
-            f32x4 t[4];
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) t[kb] = tq[(16 * ob + n) * 16 + 4 * kb + g];
-            f32x4 o = x0[ob];
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                o = __builtin_amdgcn_mfma_f32_16x16x4f32(t[kb].x, xm[kb].x, o, 0, 0, 0);
-                o = __builtin_amdgcn_mfma_f32_16x16x4f32(t[kb].y, xm[kb].y, o, 0, 0, 0);
-                o = __builtin_amdgcn_mfma_f32_16x16x4f32(t[kb].z, xm[kb].z, o, 0, 0, 0);
-                o = __builtin_amdgcn_mfma_f32_16x16x4f32(t[kb].w, xm[kb].w, o, 0, 0, 0);
-            }
-            x0[ob] = o;
-        }
-    }
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob) {
-        const f32x4 b1 = bias4[32 + 4 * ob + g];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x1[ob][r] = fmaxf(x0[ob][r] + b1[r], 0.f);
-    }
-#pragma unroll
-    for (int h = 0; h < PN_C2N; ++h)                 // conv2 (64 -> 128, ReLU); its last chunk fetches conv0b for the next tile
-        stream_step<PCH4, PNT>(h + 1 < PN_C2N ? wg + 1024 + (h + 1) * PCH4 : wg, cur, nxt,
-                               [&](const f32x4* w) { dense_blocks<4, PN_C2OB, 1>(x1, &y[PN_C2OB * h], w, bias4 + 48 + 4 * PN_C2OB * h, lane); });
-    __builtin_amdgcn_s_setprio(0);
-    {
-        float s = 0.f;                               // attention logit of row n: linear in conv2's output (u = W3^T wq packed by the host)
-#pragma unroll
-        for (int bb = 0; bb < 8; ++bb) {
-            const f32x4 w4 = u4[4 * bb + g];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s += w4[r] * y[bb][r];
-        }
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        on_logit(s + s0);
-    }
-    // conv3 is not evaluated per row: it is linear and followed by the (sum-to-one) attention pooling only, so the POOLED conv2 output goes
-    // through it once per query, inside the tail (decoder.py).  The row's 128 channels are handed to the pooling as they are.
-#pragma unroll
-    for (int bb = 0; bb < 8; bb += 2) on_block(bb, y[bb], y[bb + 1]);
-}
-
-// split precision: `trans2` is the pre-split fragment image written by pointnet_stn_fc_h_kernel (A operands straight from global,
-// no conversion work here); wg -> f16x3 images of c0b, c1, c2, c3
-template <class OnLogit, class OnBlock>
-__device__ __forceinline__ void feat_chain_h(float coord, const float* __restrict__ trans2, int64_t q0, int64_t Q, int nq, int rows_per_query,
-                                             const float* xyz_l, const f32x4* bias4, const f32x4* u4, float s0,
-                                             const f32x4* wg, f32x4*& cur, f32x4*& nxt, int lane, float& amax, OnLogit&& on_logit, OnBlock&& on_block) {
-    const int n = lane & 15, g = lane >> 4;
-    HiLo a[2], b[2];
-    {
-        f32x4 x0[4];
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) x0[bb] = bias4[4 * bb + g];
-        xyz_blocks<4>(coord, x0, xyz_l, lane);
-        relu_blocks<4>(x0);
-        a[0] = split_f16_r(amax, x0[0], x0[1]);
-        a[1] = split_f16_r(amax, x0[2], x0[3]);
-    }
-    __builtin_amdgcn_s_setprio(PPS_PRIO_PN);
-    stream_step<PCH4, PNT>(wg + 1024, cur, nxt, [&](const f32x4* w) {            // conv0b; the next chunk is conv2's first
-        dense_blocks_f16x3<2, 4, 1>(a, (const half8*)w, bias4 + 16, lane, [&](int i, const f32x4& o0, const f32x4& o1) { b[i] = split_f16_r(amax, o0, o1); }); });
-    // feature transform + conv1 with the per-query 64 x 64 matrix M = W1 trans2: three f16 products per (output block, k-block)
-    f32x4 t0[4];
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob) t0[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 1
-    for (int qi = 0; qi < nq; ++qi) {
-        const int64_t qq = (q0 + qi < Q) ? q0 + qi : Q - 1;
-        const half8* tq = (const half8*)trans2 + qq * 1024 + 4 * n + g;       // slot 4 m + g of each 1 KiB fragment block
-        const bool mine = (n / rows_per_query) == qi;
-        HiLo xm[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) { xm[kb].hi = mine ? b[kb].hi : zero8; xm[kb].lo = mine ? b[kb].lo : zero8; }
-#pragma unroll
-        for (int ob = 0; ob < 4; ++ob) {
-            half8 th[2], tl[2];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) { th[kb] = tq[((ob * 2 + kb) * 2) * 64]; tl[kb] = tq[((ob * 2 + kb) * 2 + 1) * 64]; }
-            f32x4 o = t0[ob], c = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(th[kb], xm[kb].hi, o, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(th[kb], xm[kb].lo, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl[kb], xm[kb].hi, c, 0, 0, 0);
-            }
-            t0[ob] = o + c;
-        }
-    }
-#pragma unroll
-    for (int ob = 0; ob < 4; ++ob) {                 // conv1's bias and ReLU
-        const f32x4 b1 = bias4[32 + 4 * ob + g];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t0[ob][r] = fmaxf(t0[ob][r] + b1[r], 0.f);
-    }
-    b[0] = split_f16_r(amax, t0[0], t0[1]);
-    b[1] = split_f16_r(amax, t0[2], t0[3]);
-    float s = 0.f;                                   // attention logit, accumulated as conv2's output blocks arrive
-    f32x4 y[8];                                      // conv2's output stays fp32: nothing multiplies it any more (conv3 is behind the pooling)
-#pragma unroll
-    for (int h = 0; h < PN_C2N; ++h)
-        stream_step<PCH4, PNT>(h + 1 < PN_C2N ? wg + 1024 + (h + 1) * PCH4 : wg, cur, nxt, [&](const f32x4* w) {
-            dense_blocks_f16x3<2, PN_C2OB, 1>(b, (const half8*)w, bias4 + 48 + 4 * PN_C2OB * h, lane, [&](int i, const f32x4& o0, const f32x4& o1) {
-                const int bb = PN_C2OB * h + 2 * i;
-                const f32x4 w0 = u4[4 * bb + g], w1 = u4[4 * (bb + 1) + g];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s += w0[r] * o0[r] + w1[r] * o1[r];
-                y[bb] = o0;
-                y[bb + 1] = o1;
-            }); });
-    __builtin_amdgcn_s_setprio(0);
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    on_logit(s + s0);
-#pragma unroll
-    for (int bb = 0; bb < 8; bb += 2) on_block(bb, y[bb], y[bb + 1]);
-}
+#define PC_WFLOATS (4096 + 8192)       // conv0b + conv2 (fp32 floats; the f16x3 image has the same byte size)
+#define PC_LDS_BYTES ((PC_WFLOATS + PC_W_XYZ + PC_NBIAS) * 4)
 
 template <bool H>
 __global__ __launch_bounds__(PNT, 2) void pointnet_feat_rows_kernel(const float* __restrict__ patches, const float* __restrict__ trans2,
-                                                                    int64_t Q, int P, int pack, const float* __restrict__ wpack,
+                                                                    int64_t Q, int P, const float* __restrict__ wpack,
                                                                     const f32x4* __restrict__ wdense, const float* __restrict__ bias,
                                                                     float* __restrict__ xbar, int* __restrict__ flag) {
     if (!H && gate_closed(flag)) return;
     float amax = 0.f;
-    f32x4* buf0 = (f32x4*)pps_smem;
-    f32x4* buf1 = buf0 + PCH4;
-    float* xyz_l = (float*)(buf1 + PCH4);
+    f32x4* w_l = (f32x4*)pps_smem;                       // [conv0b 1024 f32x4][conv2 2048 f32x4], packed A fragments
+    float* xyz_l = (float*)(w_l + PC_WFLOATS / 4);
     float* bias_l = xyz_l + PC_W_XYZ;
-    float* park = bias_l + PC_NBIAS;                   // [PNW][PN_PARK_ROWS][PN_ROWF]: A[128] (+ 128 unused), m, S of the left-over rows
     const f32x4* bias4 = (const f32x4*)bias_l;
-    const f32x4* u4 = bias4 + 144;                       // W3^T wq: 128 values in the block layout of conv3's input
-    const f32x4* wg = wdense;
+    const f32x4* u4 = bias4 + 144;                       // W3^T wq: 128 values in the block layout of conv2's output
     const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
-    float* mypark = park + wave * PN_PARK_ROWS * PN_ROWF;
-
+    for (int i = threadIdx.x; i < PC_WFLOATS / 4; i += PNT) w_l[i] = wdense[i];
     lds_fill(xyz_l, wpack, PC_W_XYZ);
     lds_fill(bias_l, bias, PC_NBIAS);
-    stream_prologue<1024, PNT>(wg, buf0);
-    stream_wait();
     __syncthreads();
-    f32x4 *cur = buf0, *nxt = buf1;
     const float s0 = bias_l[576 + 256];                   // wq . b3 + bq
+    const f32x4* w_c0b = w_l;
+    const f32x4* w_c2 = w_l + 1024;
+    const int ntile_rows = (P + 15) / 16;
 
-    const PatchPacking pk = patch_packing(P, pack);
-    const int64_t ngroups = (Q + pk.qg - 1) / pk.qg;
-    const int ntiles = (int)((ngroups + PNW - 1) / PNW);
+    const int ntiles = (int)((Q + PNW - 1) / PNW);
     int first, count, stride;
     xcd_tile_range(ntiles, first, count, stride);
     for (int it = 0; it < count; ++it) {
-        const int64_t q0 = ((int64_t)(first + it * stride) * PNW + wave) * pk.qg;
-        if (pk.packed) {
-            const int ql = n / pk.lo;
-            const int64_t qq = (q0 + ql < Q) ? q0 + ql : Q - 1;
-            const float coord = (g < 3) ? patches[(qq * P + pk.fb * 16 + (n % pk.lo)) * 3 + g] : 0.f;
-            float* row = mypark + ql * PN_ROWF;
-            float e = 0.f;
-            auto on_logit = [&](float s) {
-                const float m = group_max(s, pk.lo);
-                e = __expf(s - m);
-                const float S = group_sum(e, pk.lo);
-                if ((n % pk.lo) == 0 && g == 0) { row[256] = m; row[257] = S; }
-            };
-            auto on_block = [&](int bb, const f32x4& z0, const f32x4& z1) {
-                f32x4 a0, a1;
+        const int64_t q = (int64_t)(first + it * stride) * PNW + wave;
+        if (q >= Q) continue;                            // no barrier below: a wave without a query just moves on
+        // the per-query matrix as A fragments, once
+        half8 th[4][2], tl[4][2];
+        f32x4 tf[4][4];
+        if (H) {
+            const half8* tq = (const half8*)trans2 + q * 1024 + 4 * n + g;       // slot 4 m + g of each 1 KiB fragment block (pointnet_stn_fc_h_kernel)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { a0[r] = group_sum(e * z0[r], pk.lo); a1[r] = group_sum(e * z1[r], pk.lo); }
-                if ((n % pk.lo) == 0) { ((f32x4*)row)[4 * bb + g] = a0; ((f32x4*)row)[4 * (bb + 1) + g] = a1; }
-            };
-            if (H) feat_chain_h(coord, trans2, q0, Q, pk.qg, pk.lo, xyz_l, bias4, u4, s0, wg, cur, nxt, lane, amax, on_logit, on_block);
-            else feat_chain(coord, trans2, q0, Q, pk.qg, pk.lo, xyz_l, bias4, u4, s0, wg, cur, nxt, lane, on_logit, on_block);
+            for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) { th[ob][kb] = tq[((ob * 2 + kb) * 2) * 64]; tl[ob][kb] = tq[((ob * 2 + kb) * 2 + 1) * 64]; }
+        } else {
+            const f32x4* tq = (const f32x4*)(trans2 + q * 4096);
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob)
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) tf[ob][kb] = tq[(16 * ob + n) * 16 + 4 * kb + g];
         }
-        for (int qi = 0; qi < pk.qg; ++qi) {
-            const int64_t q = q0 + qi;
-            const bool qv = q < Q;
-            const int64_t qc = qv ? q : Q - 1;
-            const float* row = mypark + qi * PN_ROWF;
-            // per-lane (unreduced) online-softmax state; the parked left-over partials seed lane n == 0
-            f32x4 acc[8];                             // 128 channels: the pooled conv2 output (conv3 follows in the tail)
-            float mrun = -INFINITY, ssum = 0.f;
-            if (pk.packed) {
-                mrun = row[256];
-                ssum = (n == 0) ? row[257] : 0.f;
+        // per-lane (unreduced) online-softmax state over the patch points (nn.py:91-93)
+        f32x4 acc[8];
+        float mrun = -INFINITY, ssum = 0.f;
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) acc[bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rb = 0; rb < ntile_rows; ++rb) {
+            const int rowi = rb * 16 + n;
+            const bool valid = rowi < P;
+            const int rowc = valid ? rowi : P - 1;
+            const float coord = (g < 3) ? patches[(q * P + rowc) * 3 + g] : 0.f;
+            f32x4 x0[4], y[8];
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) x0[bb] = bias4[4 * bb + g];
+            xyz_blocks<4>(coord, x0, xyz_l, lane);
+            relu_blocks<4>(x0);
+            __builtin_amdgcn_s_setprio(PPS_PRIO_PN);
+            float s = 0.f;                                   // attention logit of row n: linear in conv2's output (u = W3^T wq packed by the host)
+            if (H) {
+                HiLo a[2], b[2];
+                a[0] = split_f16_r(amax, x0[0], x0[1]);
+                a[1] = split_f16_r(amax, x0[2], x0[3]);
+                dense_blocks_f16x3<2, 4, 1>(a, (const half8*)w_c0b, bias4 + 16, lane, [&](int i, const f32x4& o0, const f32x4& o1) { b[i] = split_f16_r(amax, o0, o1); });
+                // x <- M x: three f16 products per (output block, k-block), A operands from registers
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob) {
+                    f32x4 o = bias4[32 + 4 * ob + g], c = {0.f, 0.f, 0.f, 0.f};           // conv1's bias seeds the sum
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        o = __builtin_amdgcn_mfma_f32_16x16x32_f16(th[ob][kb], b[kb].hi, o, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(th[ob][kb], b[kb].lo, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(tl[ob][kb], b[kb].hi, c, 0, 0, 0);
+                    }
+                    o += c;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x0[ob][r] = fmaxf(o[r], 0.f);
+                }
+                a[0] = split_f16_r(amax, x0[0], x0[1]);
+                a[1] = split_f16_r(amax, x0[2], x0[3]);
+                dense_blocks_f16x3<2, 8, 1>(a, (const half8*)w_c2, bias4 + 48, lane, [&](int i, const f32x4& o0, const f32x4& o1) {
+                    const f32x4 w0 = u4[4 * (2 * i) + g], w1 = u4[4 * (2 * i + 1) + g];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s += w0[r] * o0[r] + w1[r] * o1[r];
+                    y[2 * i] = o0;
+                    y[2 * i + 1] = o1;
+                });
+            } else {
+                f32x4 x1[4];
+                dense_blocks<4, 4, 1>(x0, x1, w_c0b, bias4 + 16, lane);
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob) {
+                    f32x4 o = bias4[32 + 4 * ob + g];
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) {
+                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(tf[ob][kb].x, x1[kb].x, o, 0, 0, 0);
+                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(tf[ob][kb].y, x1[kb].y, o, 0, 0, 0);
+                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(tf[ob][kb].z, x1[kb].z, o, 0, 0, 0);
+                        o = __builtin_amdgcn_mfma_f32_16x16x4f32(tf[ob][kb].w, x1[kb].w, o, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x0[ob][r] = fmaxf(o[r], 0.f);
+                }
+                dense_blocks<4, 8, 1>(x0, y, w_c2, bias4 + 48, lane);
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) {
+                    const f32x4 w4 = u4[4 * bb + g];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s += w4[r] * y[bb][r];
+                }
             }
+            __builtin_amdgcn_s_setprio(0);
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            s += s0;
+            // online softmax: advance the state with this tile's logits, then add its rows (conv3 acts on the pooled vector, in the tail)
+            const float mblk = row16_max(valid ? s : -INFINITY);
+            const float mnew = fmaxf(mrun, mblk);
+            const float scale = __expf(mrun - mnew);
+            const float en = valid ? __expf(s - mnew) : 0.f;
+            mrun = mnew;
+            ssum = ssum * scale + en;
 #pragma unroll
-            for (int bb = 0; bb < 8; ++bb) {
-                const f32x4 a4 = pk.packed ? ((const f32x4*)row)[4 * bb + g] : f32x4{0.f, 0.f, 0.f, 0.f};
-                acc[bb] = (pk.packed && n == 0) ? a4 : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            for (int rb = 0; rb < pk.fb; ++rb) {
-                const int rowi = rb * 16 + n;
-                const bool valid = rowi < P;
-                const int rowc = valid ? rowi : P - 1;
-                const float coord = (g < 3) ? patches[(qc * P + rowc) * 3 + g] : 0.f;
-                float en = 0.f;
-                // online softmax over the patch points (nn.py:91-93): the state is advanced as soon as the tile's logits are known,
-                // the accumulators take conv3's output blocks as they are produced
-                auto on_logit = [&](float s) {
-                    const float mblk = row16_max(valid ? s : -INFINITY);
-                    const float mnew = fmaxf(mrun, mblk);
-                    const float scale = __expf(mrun - mnew);
-                    en = valid ? __expf(s - mnew) : 0.f;
-                    mrun = mnew;
-                    ssum = ssum * scale + en;
+            for (int bb = 0; bb < 8; ++bb)
 #pragma unroll
-                    for (int bb = 0; bb < 8; ++bb)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[bb][r] *= scale;
-                };
-                auto on_block = [&](int bb, const f32x4& z0, const f32x4& z1) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { acc[bb][r] += en * z0[r]; acc[bb + 1][r] += en * z1[r]; }
-                };
-                if (H) feat_chain_h(coord, trans2, qc, Q, 1, 16, xyz_l, bias4, u4, s0, wg, cur, nxt, lane, amax, on_logit, on_block);
-                else feat_chain(coord, trans2, qc, Q, 1, 16, xyz_l, bias4, u4, s0, wg, cur, nxt, lane, on_logit, on_block);
-            }
-            const float inv = 1.f / row16_sum(ssum);
-            rows16_sum_transposed8(acc, lane);            // lane (n,g): acc[0] = sum over the 16 lanes of block n & 7
-            if (qv && n < 8) ((f32x4*)(xbar + q * 128))[4 * n + g] = acc[0] * inv;
+                for (int r = 0; r < 4; ++r) acc[bb][r] = acc[bb][r] * scale + en * y[bb][r];
         }
+        const float inv = 1.f / row16_sum(ssum);
+        rows16_sum_transposed8(acc, lane);            // lane (n,g): acc[0] = sum over the 16 lanes of block n & 7
+        if (n < 8) ((f32x4*)(xbar + q * 128))[4 * n + g] = acc[0] * inv;
     }
     if (H) range_commit(amax, flag);
 }
@@ -1416,14 +1300,11 @@ static int launch_feat_rows(const float* patches, const float* trans2, int64_t q
                             const float* bias, float* xbar, int* flag, void* stream) {
     static int once = set_lds(pointnet_feat_rows_kernel<H>, PC_LDS_BYTES);
     (void)once;
-    const PnSplit sp = pn_split(q, p);
-    if (sp.q_packed > 0)
-        hipLaunchKernelGGL(pointnet_feat_rows_kernel<H>, dim3(sp.grid_packed), dim3(PNT), PC_LDS_BYTES, (hipStream_t)stream, patches,
-                           trans2, sp.q_packed, p, 1, wpack, (const f32x4*)wdense, bias, xbar, flag);
-    if (q > sp.q_packed)
-        hipLaunchKernelGGL(pointnet_feat_rows_kernel<H>, dim3(sp.grid_rest), dim3(PNT), PC_LDS_BYTES, (hipStream_t)stream,
-                           patches + sp.q_packed * p * 3, trans2 + sp.q_packed * 4096, q - sp.q_packed, p, sp.rest_mode, wpack, (const f32x4*)wdense, bias,
-                           xbar + sp.q_packed * 128, flag);
+    int cus = cu_count();
+    if (cus <= 0) cus = 256;
+    const int64_t ntiles = (q + PNW - 1) / PNW, wgs = (int64_t)cus * PN_WG_PER_CU;
+    hipLaunchKernelGGL(pointnet_feat_rows_kernel<H>, dim3((unsigned)(ntiles < wgs ? ntiles : wgs)), dim3(PNT), PC_LDS_BYTES, (hipStream_t)stream, patches,
+                       trans2, q, p, wpack, (const f32x4*)wdense, bias, xbar, flag);
     return PPS_LAUNCH_CHECK();
 }
 
