@@ -54,7 +54,10 @@ INTERP_ALG_FLOP_PER_QUERY = 2.0 * (64 * 279_296 + 16_384)
 # work it EXECUTES per query: 2320 k-steps x 4 v_mfma_f32_16x16x4_f32 x 2048 flop (fc1 hoisted to the per-point table, fc_value
 # moved behind the pooling: DESIGN.md section 2)
 INTERP_EXEC_FLOP_PER_QUERY = 2320 * 4 * 2048.0
-STAGE_EXEC_MFMA_PER_QUERY = {'interp_pool': 9280, 'pointnet_stn_rows': 2413, 'pointnet_stn_fc': 296, 'pointnet_feat_rows': 2670, 'decode_tail': 200}
+# executed v_mfma_f32_16x16x4_f32-equivalents per query at P = 50 (f16x3: 3/8 as many v_mfma_f32_16x16x32_f16 per dense layer).  Round 4: conv1 lives in
+# the per-query matrix and conv3 behind the attention pooling (ppsurf_amd/decoder.py): the feature kernel runs 4 tiles x (4 + 64 + 64 + 128), the
+# tail (256 + 128) -> 256 -> 256 -> 2 on 16-query tiles
+STAGE_EXEC_MFMA_PER_QUERY = {'interp_pool': 9280, 'pointnet_stn_rows': 2413, 'pointnet_stn_fc': 296, 'pointnet_feat_rows': 1040, 'decode_tail': 168}
 PEAK_F32_MFMA_TFLOPS = 157.3                   # /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F16_MFMA_TFLOPS = 2500.0                  # dense f16 / bf16 matrix peak, same guide
 MEASURED_F16_MFMA_TFLOPS = 1800.0              # bare v_mfma_f32_16x16x32_f16 loop, random operands, measured (1797-1917; 2274 on zeros)
