@@ -360,7 +360,7 @@ def main():
                        'entry': 'ChunkPipeline.run -> pps_knn_blocked_f32, pps_patch_normalize_f32, pps_decode_fwd_events_f32'},
             'roofline': roofline_block(args.dtype, r['stage_ms']),
             'stage_ms': st['stage_ms'], 'stage_mfma_frac': st['stage_mfma_frac'], 'spatial_ms': st['spatial_ms'],
-            'whole_path_algorithmic_tflops': st['whole_path_algorithmic_tflops'],
+            'whole_path_algorithmic_tflops': st['whole_path_algorithmic_tflops'], 'whole_path_algorithmic_frac': st['whole_path_algorithmic_frac'],
             'whole_path_executed_mfma_frac': st['whole_path_executed_mfma_frac'],
         }
     if not args.quick:

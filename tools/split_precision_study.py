@@ -71,7 +71,7 @@ def decode(w, latents_cn, pts, query, idx, patches):
     u = E.relu(gmax @ E.unpack_dense(f1, 128, 256).T + bb[0])          # per-query small layers stay fp32
     u = E.relu(u @ E.unpack_dense(f2, 64, 128).T + bb[1])
     trans2 = (u @ E.unpack_dense(f3, 4096, 64).T + bb[2]).reshape(-1, 64, 64)
-    xc, c0b2, c1, c2, c3 = E._split(w['pc_w'], [256, 4096, 4096, 8192, 32768])
+    xc, c0b2, c2 = E._split(w['pc_w'], [256, 4096, 8192])      # round 4: conv1 lives in the per-query matrix, conv3 in the tail (decoder.py)
     bc = E._split(w['pc_b'].astype(np.float64), [64, 64, 64, 128, 256, 256, 4])
     y0 = E.relu(x @ E.unpack_xyz(xc, 64).T + bc[0])
     y1 = E.relu(mm(y0, E.unpack_dense(c0b2, 64, 64).T) + bc[1])
@@ -79,14 +79,13 @@ def decode(w, latents_cn, pts, query, idx, patches):
         y = np.einsum('qab,qpb->qpa', trans2, y1)
     else:
         y = np.stack([mm(y1[q], trans2[q].T) for q in range(y1.shape[0])])
-    y = E.relu(mm(y, E.unpack_dense(c1, 64, 64).T) + bc[2])
+    y = E.relu(y + bc[2])
     y = E.relu(mm(y, E.unpack_dense(c2, 128, 64).T) + bc[3])
     wgt = E.softmax(y @ bc[5][:128] + bc[6][0], axis=1)        # logit from conv3's input (u = W3^T wq), as the kernels compute it
-    y = mm(y, E.unpack_dense(c3, 256, 128).T) + bc[4]
     xbar = (wgt[:, :, None] * y).sum(axis=1)
-    wa, wb, l2w, l3w = E._split(w['tl_w'], [65536, 65536, 65536, 8192])
+    wa, wb, l2w, l3w = E._split(w['tl_w'], [65536, 32768, 65536, 8192])
     bt = E._split(w['tl_b'].astype(np.float64), [256, 256, 32])
-    hh = E.relu(pooled @ E.unpack_dense(wa, 256, 256).T + xbar @ E.unpack_dense(wb, 256, 256).T + bt[0])
+    hh = E.relu(pooled @ E.unpack_dense(wa, 256, 256).T + xbar @ E.unpack_dense(wb, 256, 128).T + bt[0])
     hh = E.relu(hh @ E.unpack_dense(l2w, 256, 256).T + bt[1])
     return hh @ E.unpack_dense(l3w, 2, 256).T + bt[2][:2]
 

@@ -49,7 +49,7 @@ t_pb = timeit('pointnet_stn_fc', lambda: L.pps_pointnet_stn_fc_f32(g.data_ptr(),
 t_pc = timeit('pointnet_feat_rows', lambda: L.pps_pointnet_feat_rows_f32(patches.data_ptr(), tr.data_ptr(), Q, 50, w['pc_w'].data_ptr(), w['pc_b'].data_ptr(), xb.data_ptr(), st))
 t_tl = timeit('decode_tail', lambda: L.pps_decode_tail_f32(pooled.data_ptr(), xb.data_ptr(), Q, w['tl_w'].data_ptr(), w['tl_b'].data_ptr(), logits.data_ptr(), occ.data_ptr(), st))
 t_all = timeit('knn+patch+decode (chunk)', lambda: pl.decode(table, pts, qd, ops.knn_point_major(pts, qd, 64), ops.patch_normalize(pts, qd, idx, 50)))
-mf = {'interp_pool': 2320 * 4, 'pointnet_stn_rows': 772 * 4, 'pointnet_stn_fc': 4736 / 16, 'pointnet_feat_rows': 836 * 4, 'decode_tail': 3200 / 16}
+mf = {'interp_pool': 2320 * 4, 'pointnet_stn_rows': 772 * 4, 'pointnet_stn_fc': 4736 / 16, 'pointnet_feat_rows': 1040, 'decode_tail': 2688 / 16}
 for name, t in (('interp_pool', t_ip), ('pointnet_stn_rows', t_pa), ('pointnet_stn_fc', t_pb), ('pointnet_feat_rows', t_pc), ('decode_tail', t_tl)):
     fl = mf[name] * 2048.0 * Q
     print('{:20s} executed {:7.1f} TFLOP/s ({:.1%} of 157.3)'.format(name, fl / t / 1e9, fl / t / 1e9 / 157.3))
