@@ -457,20 +457,25 @@ def main():
 
 
 def fit_roofline(ms_per_step):
-    """Executed matrix flops and HBM bytes of one fit step from the committed counter passes (profiles/round3_train_pmc.json, written by
-    tools/profile_train.sh) against the step time measured in THIS run.  Absent file -> no object."""
-    path = os.path.join(REPO, 'profiles', 'round3_train_pmc.json')
+    """Executed matrix flops and HBM bytes of one fit step from the committed counter passes of the REPLAYED step (tools/profile_train_pmc.sh ->
+    profiles/round4_train_pmc.json) against the step time measured in THIS run -- only if the file was measured on the same kernel sources and
+    training code (bench_workloads.fit_digest); otherwise no roofline is reported (the round-3 object mixed an eager step of an older
+    commit with the replayed step's time)."""
+    import bench_workloads as workloads
+    path = os.path.join(REPO, 'profiles', 'round4_train_pmc.json')
     if not os.path.isfile(path):
-        return {}
+        return {'roofline': None, 'roofline_note': 'no counter passes of the replayed fit step committed'}
     d = json.load(open(path))
+    if d.get('fit_digest') != workloads.fit_digest():
+        return {'roofline': None, 'roofline_note': 'profiles/round4_train_pmc.json was measured on other sources (digest {} at commit {}, now {}): not reported'.format(
+            d.get('fit_digest', 'unrecorded'), d.get('git_head', 'unrecorded'), workloads.fit_digest())}
     s = ms_per_step * 1e-3
-    out = {'roofline': {'source': 'profiles/round3_train_pmc.json (tools/profile_train_pmc.sh: rocprofv3 --pmc passes of the eager fit step, tools/time_train_step.py --bf16, at commit {}; per-step sums over all kernels '
-                                  'of the step incl. the data preparation on the second stream); step time from this run'.format(d.get('git_head', 'unrecorded')),
-                        'mfma_flops_per_step': d['mfma_flops_per_step'], 'hbm_bytes_per_step': d['hbm_bytes_per_step'],
-                        'achieved_tflops': d['mfma_flops_per_step'] / s / 1e12, 'mfma_frac_of_bf16_peak': d['mfma_flops_per_step'] / s / 1e12 / PEAK_F16_MFMA_TFLOPS,
-                        'achieved_hbm_tb_s': d['hbm_bytes_per_step'] / s / 1e12, 'hbm_frac': d['hbm_bytes_per_step'] / s / 8e12,
-                        'bound': d.get('bound', 'hbm')}}
-    return out
+    return {'roofline': {'source': 'profiles/round4_train_pmc.json (tools/profile_train_pmc.sh: rocprofv3 --pmc passes of {} at commit {}, same sources; per-step sums over all '
+                                   'kernels incl. the data preparation on the second stream); step time from this run'.format(d.get('command', '?'), d.get('git_head', 'unrecorded')),
+                         'mfma_flops_per_step': d['mfma_flops_per_step'], 'hbm_bytes_per_step': d['hbm_bytes_per_step'],
+                         'achieved_tflops': d['mfma_flops_per_step'] / s / 1e12, 'mfma_frac_of_bf16_peak': d['mfma_flops_per_step'] / s / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                         'achieved_hbm_tb_s': d['hbm_bytes_per_step'] / s / 1e12, 'hbm_frac': d['hbm_bytes_per_step'] / s / 8e12,
+                         'bound': d.get('bound', 'hbm')}}
 
 
 def strong(args, rank, world, dev, dist, red_dev):

@@ -107,6 +107,17 @@ def csrc_digest():
     return h.hexdigest()[:16]
 
 
+def fit_digest():
+    """csrc_digest() extended by the Python side of the fit step: ties profiles/*_train_pmc.json to the program it was measured on."""
+    import hashlib
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha1(csrc_digest().encode())
+    for name in ('train_graph.py', 'train_ops.py', 'fit.py', 'optim.py', 'modules.py', 'data.py'):
+        h.update(open(os.path.join(here, 'ppsurf_amd', name), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 class SteeredField(reconstruct.OccupancyField):
     norm = None                                     # (centre, scale) of the synthetic cloud, set by the caller
 

@@ -53,8 +53,10 @@ def main(src, steps, dst):
                                            stderr=subprocess.DEVNULL).strip()
         except Exception:
             head = 'unrecorded'
-    out = {'source': os.path.basename(src.rstrip('/')), 'git_head': head, 'steps_traced': steps,
-           'command': 'python tools/time_train_step.py --bf16 --steps {} (eager; B=10 x 10000 points x 2000 queries, P=50)'.format(steps - 2),
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    import bench_workloads
+    out = {'source': os.path.basename(src.rstrip('/')), 'git_head': head, 'steps_traced': steps, 'fit_digest': bench_workloads.fit_digest(),
+           'command': 'python tools/time_fit_graph.py ({} calls of the bench leg\'s FitStep: HIP-graph replay + loader thread; B=10 x 10000 points x 2000 queries, P=50, bf16-mixed)'.format(steps),
            'mfma_flops_per_step': mops * 512.0 / steps, 'mfma_mops_by_type_per_step': {t: tot.get('SQ_INSTS_VALU_MFMA_MOPS_' + t, 0.0) / steps for t in ('F32', 'F16', 'BF16')},
            'hbm_bytes_per_step': hbm / steps, 'fetch_kib_per_step': tot.get('FETCH_SIZE', 0.0) / steps, 'write_kib_per_step': tot.get('WRITE_SIZE', 0.0) / steps,
            'mfma_busy_share_of_kernel_time': busy / (gui / 8.0 * 1024.0) if gui else None,
