@@ -808,7 +808,10 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_stn_rows_kernel(const float* 
 // weights (floats): [fc1 32768][fc2 8192][fc3 262144]   bias [128][64][4096]
 // =====================================================================================================
 #define PB_NBIAS (128 + 64 + 4096)
-#define PB_LDS_BYTES (2 * CH4 * 16 + PB_NBIAS * 4)
+// LDS: the two 32 KiB weight buffers + the 16 KiB bias of the last layer = exactly 80 KiB, so that TWO workgroups fit a CU's 160 KiB.  (Rounds 1-3
+// also kept the 768 bytes of the first two layers' biases there: 165 376 bytes for two workgroups, 1.5 KiB too many -- the kernel ran ONE 4-wave
+// workgroup per CU.)  The small biases are read from global memory, five times per tile.
+#define PB_LDS_BYTES (2 * CH4 * 16 + 4096 * 4)
 #ifndef PB_T
 #define PB_T 1                 // 16-query tiles a wave carries through fc3 together (2: no gain, 3: slower -- measured)
 #endif
@@ -824,7 +827,8 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_kernel(const float* __r
     const f32x4* wg = (const f32x4*)wpack;
     const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
 
-    lds_fill(bias_l, bias, PB_NBIAS);
+    lds_fill(bias_l, bias + 192, 4096);
+    const f32x4* bias_g = (const f32x4*)bias;                  // biases of the first two layers: [128][64] floats
     stream_prologue<CH4>(wg, buf0);
     stream_wait();
     __syncthreads();
@@ -854,9 +858,9 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_kernel(const float* __r
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 stream_step<CH4>(wg + (c + 1) * CH4, cur, nxt,
-                               [&](const f32x4* w) { dense_blocks<16, 2, 1>(a, &h[2 * c], w, bias4 + 8 * c, lane); });
+                               [&](const f32x4* w) { dense_blocks<16, 2, 1>(a, &h[2 * c], w, bias_g + 8 * c, lane); });
             stream_step<CH4>(t + 1 < PB_T ? wg : wg + 5 * CH4, cur, nxt,
-                           [&](const f32x4* w) { dense_blocks<8, 4, 1>(h, u[t], w, bias4 + 32, lane); });
+                           [&](const f32x4* w) { dense_blocks<8, 4, 1>(h, u[t], w, bias_g + 32, lane); });
         }
 #pragma unroll 1
         for (int c = 0; c < 32; ++c) {
@@ -864,7 +868,7 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_kernel(const float* __r
             const f32x4* gn = (c + 1 < 32) ? wg + (6 + c) * CH4 : wg;
             stream_step<CH4>(gn, cur, nxt, [&](const f32x4* w) {
 #pragma unroll
-                for (int t = 0; t < PB_T; ++t) dense_blocks<4, 8, 0>(u[t], o[t], w, bias4 + 48 + 32 * c, lane);
+                for (int t = 0; t < PB_T; ++t) dense_blocks<4, 8, 0>(u[t], o[t], w, bias4 + 32 * c, lane);
             });
 #pragma unroll
             for (int t = 0; t < PB_T; ++t) {
@@ -893,7 +897,8 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_h_kernel(const float* _
     const f32x4* wg = w16;
     const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
 
-    lds_fill(bias_l, bias, PB_NBIAS);
+    lds_fill(bias_l, bias + 192, 4096);
+    const f32x4* bias_g = (const f32x4*)bias;                  // biases of the first two layers: [128][64] floats
     stream_prologue<CH4>(wg, buf0);
     stream_wait();
     __syncthreads();
@@ -917,15 +922,15 @@ __global__ __launch_bounds__(NT, 2) void pointnet_stn_fc_h_kernel(const float* _
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             stream_step<CH4>(wg + (c + 1) * CH4, cur, nxt, [&](const f32x4* w) {
-                dense_blocks_f16x3<8, 2, 1>(ah, (const half8*)w, bias4 + 8 * c, lane, [&](int, const f32x4& o0, const f32x4& o1) { h[c] = split_f16_r(amax, o0, o1); }); });
+                dense_blocks_f16x3<8, 2, 1>(ah, (const half8*)w, bias_g + 8 * c, lane, [&](int, const f32x4& o0, const f32x4& o1) { h[c] = split_f16_r(amax, o0, o1); }); });
         stream_step<CH4>(wg + 5 * CH4, cur, nxt, [&](const f32x4* w) {
-            dense_blocks_f16x3<4, 4, 1>(h, (const half8*)w, bias4 + 32, lane, [&](int i, const f32x4& o0, const f32x4& o1) { u[i] = split_f16_r(amax, o0, o1); }); });
+            dense_blocks_f16x3<4, 4, 1>(h, (const half8*)w, bias_g + 32, lane, [&](int i, const f32x4& o0, const f32x4& o1) { u[i] = split_f16_r(amax, o0, o1); }); });
         half8* dst = trans2h + qc * 1024 + g;                         // + ((ob*2 + kb)*2 + part)*64 + 4*m
 #pragma unroll 1
         for (int c = 0; c < 32; ++c) {
             const f32x4* gn = (c + 1 < 32) ? wg + (6 + c) * CH4 : wg;
             stream_step<CH4>(gn, cur, nxt, [&](const f32x4* w) {
-                dense_blocks_f16x3<2, 8, 0, false>(u, (const half8*)w, bias4 + 48 + 32 * c, lane, [&](int i, const f32x4& o0, const f32x4& o1) {
+                dense_blocks_f16x3<2, 8, 0, false>(u, (const half8*)w, bias4 + 32 * c, lane, [&](int i, const f32x4& o0, const f32x4& o1) {
                     // blocks 8c + 2i, 8c + 2i + 1: row a = 2c + (i >> 1), k-block kb = i & 1
                     const int a = 2 * c + (i >> 1), kb = i & 1;
                     const HiLo v = split_f16_r(amax, o0, o1);
@@ -1356,6 +1361,8 @@ int pps_debug_occupancy(int which) {
     int n = -1;
     if (which == 0) { set_lds(interp_pool_kernel, IP_LDS_BYTES); hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, interp_pool_kernel, NT, IP_LDS_BYTES); }
     if (which == 1) { set_lds(pointnet_stn_rows_kernel<false>, PA_LDS_BYTES); hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pointnet_stn_rows_kernel<false>, PNT, PA_LDS_BYTES); }
+    if (which == 3) { set_lds(pointnet_stn_fc_kernel, PB_LDS_BYTES); hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pointnet_stn_fc_kernel, NT, PB_LDS_BYTES); }
+    if (which == 4) { set_lds(pointnet_stn_fc_h_kernel, PB_LDS_BYTES); hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pointnet_stn_fc_h_kernel, NT, PB_LDS_BYTES); }
     if (which == 2) { set_lds(pointnet_feat_rows_kernel<false>, PC_LDS_BYTES); hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pointnet_feat_rows_kernel<false>, PNT, PC_LDS_BYTES); }
     return n;
 }
