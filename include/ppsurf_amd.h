@@ -149,6 +149,15 @@ int pps_interp_pool_f32(const float* G, const float* pts, const float* query, co
  * out f32 [q,nout], nout <= 8. */
 int pps_interp_small_f32(const float* G, const float* pts, const float* query, const int64_t* idx, int64_t q, int k, int c,
                          const float* wpack, const float* bias, const float* wtail, int nout, float* out, void* stream);
+/* The same head with fc2, fc3 and fc_query in split precision on the f16 matrix pipe (three f16 MFMA products per fp32 product, fp32 accumulation;
+ * the xyz part of fc1, softmax, pooling and the composed fc8.fc_value stay fp32).  w16 = concat(pps_pack_dense_f16x3 of fc2, fc3, fc_query);
+ * wpack / bias / wtail as above (the fp32 packs are the fall-back's operands).  guard: 2 device ints owned by the caller; guard[0] is cleared,
+ * raised by the split-precision kernel when an activation leaves the f16 range (|x| > 65504), and the fp32 kernel queued behind it on the same
+ * stream then recomputes the call (guard[1] counts those calls): the result is always finite-range safe, without a host round trip.
+ * replaces: the same lines as pps_interp_small_f32 (the reference runs them under fp16 autocast on the GPU, configs/poco.yaml:10). */
+int pps_interp_small_f16x3(const float* G, const float* pts, const float* query, const int64_t* idx, int64_t q, int k, int c,
+                           const float* wpack, const void* w16, const float* bias, const float* wtail, int nout, float* out, int* guard,
+                           void* stream);
 
 /* PointNet branch, phase A: per patch point conv0a, conv0b, STN conv1..3, max over the patch.
  * replaces: source/base/nn.py:323-324 and :164-170.   patches [q,p,3]; out g [q,256].

@@ -43,6 +43,7 @@ SIGNATURES = {
     'pps_rows_dense256_f32': (_I, [_P, _I64, _I64, _I64, _P, _P, _P, _P]),
     'pps_interp_pool_f32': (_I, [_P, _P, _P, _P, _I64, _I, _P, _P, _P, _P]),
     'pps_interp_small_f32': (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _P, _P, _I, _P, _P]),
+    'pps_interp_small_f16x3': (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     'pps_pointnet_stn_rows_f32': (_I, [_P, _I64, _I, _P, _P, _P, _P]),
     'pps_pointnet_stn_fc_f32': (_I, [_P, _I64, _P, _P, _P, _P]),
     'pps_pointnet_feat_rows_f32': (_I, [_P, _P, _I64, _I, _P, _P, _P, _P]),

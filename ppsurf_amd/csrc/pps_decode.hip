@@ -428,13 +428,21 @@ __global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float
 // =====================================================================================================
 #define IS_NT 256
 #define IS_MAX_OUT 8
-template <int CB>
+// H = true: fc2, fc3 and fc_query in split precision on the f16 matrix pipe (pps_common.h); `w16` = f16x3 packs of the three layers (as many bytes
+// as their fp32 packs: the LDS layout does not change), `guard[0]` receives the range flag.  H = false with a non-null `guard`: the fp32 fall-back
+// behind a split-precision launch -- nothing to do unless guard[0] was raised; guard[1] counts the chunks it recomputed.
+template <int CB, bool H>
 __global__ __launch_bounds__(IS_NT) void interp_small_kernel(const float* __restrict__ G, const float* __restrict__ pts,
                                                              const float* __restrict__ query, const int64_t* __restrict__ idx,
-                                                             int64_t Q, int k, const float* __restrict__ wpack,
+                                                             int64_t Q, int k, const float* __restrict__ wpack, const float* __restrict__ w16,
                                                              const float* __restrict__ bias, const float* __restrict__ wtail, int nout,
-                                                             float* __restrict__ out) {
-    constexpr int C = 16 * CB, NWX = 64 * CB, NW2 = 256 * CB * CB, NWQ = 1024 * CB, NB = 2 * C + 64;
+                                                             float* __restrict__ out, int* __restrict__ guard) {
+    constexpr int C = 16 * CB, NWX = 64 * CB, NW2 = 256 * CB * CB, NWQ = 1024 * CB, NB = 2 * C + 64, KB = CB / 2;
+    if (!H) {
+        if (gate_closed(guard)) return;
+        if (guard != nullptr && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(guard + 1, 1);
+    }
+    float amax = 0.f;
     __shared__ __attribute__((aligned(16))) float lds[NWX + 2 * NW2 + NWQ + NB + 4 * 64 * 3 + 4 * C + IS_MAX_OUT * (C + 1)];
     float* xyz_l = lds;
     const f32x4* w2 = (const f32x4*)(lds + NWX);
@@ -448,7 +456,11 @@ __global__ __launch_bounds__(IS_NT) void interp_small_kernel(const float* __rest
     float* tail_l = part + 4 * C;            // [nout][C] then [nout]
     const f32x4* bias4 = (const f32x4*)bias_l;
     const int lane = lane_id(), wave = threadIdx.x >> 6, n = lane & 15, g = lane >> 4;
-    for (int i = threadIdx.x; i < NWX + 2 * NW2 + NWQ; i += IS_NT) lds[i] = wpack[i];
+    for (int i = threadIdx.x; i < NWX; i += IS_NT) lds[i] = wpack[i];
+    {
+        const float* dense = H ? w16 : wpack + NWX;
+        for (int i = threadIdx.x; i < 2 * NW2 + NWQ; i += IS_NT) lds[NWX + i] = dense[i];
+    }
     for (int i = threadIdx.x; i < NB; i += IS_NT) bias_l[i] = bias[i];
     for (int i = threadIdx.x; i < nout * (C + 1); i += IS_NT) tail_l[i] = wtail[i];
     __syncthreads();
@@ -463,9 +475,24 @@ __global__ __launch_bounds__(IS_NT) void interp_small_kernel(const float* __rest
         const float coord = (g < 3) ? (query[qi * 3 + g] - pts[i * 3 + g]) : 0.f;
         xyz_blocks<CB>(coord, a, xyz_l, lane);
         relu_blocks<CB>(a);
-        dense_blocks<CB, CB, 1>(a, h, w2, bias4, lane);
-        dense_blocks<CB, CB, 1>(h, a, w3, bias4 + 4 * CB, lane);
-        dense_blocks<CB, 4, 0>(a, b, wq, bias4 + 8 * CB, lane);           // 64 heads
+        if constexpr (H) {
+            HiLo x[KB], y[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) x[kb] = split_f16_r(amax, a[2 * kb], a[2 * kb + 1]);
+            dense_blocks_f16x3<KB, CB, 1, false>(x, (const half8*)w2, bias4, lane,
+                                                 [&](int p, const f32x4& o0, const f32x4& o1) { y[p] = split_f16_r(amax, o0, o1); });
+            dense_blocks_f16x3<KB, CB, 1, false>(y, (const half8*)w3, bias4 + 4 * CB, lane, [&](int p, const f32x4& o0, const f32x4& o1) {
+                x[p] = split_f16_r(amax, o0, o1);
+                a[2 * p] = o0;                                            // the pooled feature keeps the fp32 output of fc3
+                a[2 * p + 1] = o1;
+            });
+            dense_blocks_f16x3<KB, 4, 0, false>(x, (const half8*)wq, bias4 + 8 * CB, lane,
+                                                [&](int p, const f32x4& o0, const f32x4& o1) { b[2 * p] = o0; b[2 * p + 1] = o1; });
+        } else {
+            dense_blocks<CB, CB, 1>(a, h, w2, bias4, lane);
+            dense_blocks<CB, CB, 1>(h, a, w3, bias4 + 4 * CB, lane);
+            dense_blocks<CB, 4, 0>(a, b, wq, bias4 + 8 * CB, lane);       // 64 heads
+        }
         float e[16];
         {
             f32x4 m4[4], s4[4];
@@ -522,6 +549,7 @@ __global__ __launch_bounds__(IS_NT) void interp_small_kernel(const float* __rest
             out[qi * nout + threadIdx.x] = acc;
         }
     }
+    if (H) range_commit(amax, guard);
 }
 
 // =====================================================================================================
@@ -1412,8 +1440,31 @@ int pps_interp_small_f32(const float* G, const float* pts, const float* query, c
     if (cus <= 0) cus = 256;
     const int grid = (int)(q < (int64_t)cus * 8 ? q : (int64_t)cus * 8);
     hipStream_t st = (hipStream_t)stream;
-    if (c == 32) hipLaunchKernelGGL(interp_small_kernel<2>, dim3(grid), dim3(IS_NT), 0, st, G, pts, query, idx, q, k, wpack, bias, wtail, nout, out);
-    else hipLaunchKernelGGL(interp_small_kernel<4>, dim3(grid), dim3(IS_NT), 0, st, G, pts, query, idx, q, k, wpack, bias, wtail, nout, out);
+    if (c == 32) hipLaunchKernelGGL((interp_small_kernel<2, false>), dim3(grid), dim3(IS_NT), 0, st, G, pts, query, idx, q, k, wpack, nullptr, bias, wtail, nout, out, nullptr);
+    else hipLaunchKernelGGL((interp_small_kernel<4, false>), dim3(grid), dim3(IS_NT), 0, st, G, pts, query, idx, q, k, wpack, nullptr, bias, wtail, nout, out, nullptr);
+    return PPS_LAUNCH_CHECK();
+}
+
+int pps_interp_small_f16x3(const float* G, const float* pts, const float* query, const int64_t* idx, int64_t q, int k, int c,
+                           const float* wpack, const void* w16, const float* bias, const float* wtail, int nout, float* out, int* guard,
+                           void* stream) {
+    if (q < 0 || k < 1 || k > 64 || (c != 32 && c != 64) || nout < 1 || nout > IS_MAX_OUT) return PPS_ERR_ARG;
+    if (q == 0) return PPS_OK;
+    if (!G || !pts || !query || !idx || !wpack || !w16 || !bias || !wtail || !out || !guard) return PPS_ERR_ARG;
+    int cus = cu_count();
+    if (cus <= 0) cus = 256;
+    const int grid = (int)(q < (int64_t)cus * 8 ? q : (int64_t)cus * 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(guard, 0, sizeof(int), st) != hipSuccess) return PPS_ERR_LAUNCH;
+    const float* wh = (const float*)w16;
+    // split precision first; the fp32 kernel behind it runs only if an activation left the f16 range (no host round trip)
+    if (c == 32) {
+        hipLaunchKernelGGL((interp_small_kernel<2, true>), dim3(grid), dim3(IS_NT), 0, st, G, pts, query, idx, q, k, wpack, wh, bias, wtail, nout, out, guard);
+        hipLaunchKernelGGL((interp_small_kernel<2, false>), dim3(grid), dim3(IS_NT), 0, st, G, pts, query, idx, q, k, wpack, nullptr, bias, wtail, nout, out, guard);
+    } else {
+        hipLaunchKernelGGL((interp_small_kernel<4, true>), dim3(grid), dim3(IS_NT), 0, st, G, pts, query, idx, q, k, wpack, wh, bias, wtail, nout, out, guard);
+        hipLaunchKernelGGL((interp_small_kernel<4, false>), dim3(grid), dim3(IS_NT), 0, st, G, pts, query, idx, q, k, wpack, nullptr, bias, wtail, nout, out, guard);
+    }
     return PPS_LAUNCH_CHECK();
 }
 

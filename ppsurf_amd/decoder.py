@@ -320,14 +320,17 @@ class PocoDecoderPlan:
     """Packed weights of POCO's projection head (source/poco_model.py:362-419; latent size 32 or 64, few output channels).
     fc1 is split like in DecoderPlan (per-point table G), fc8 . fc_value is composed on the host and applied after pooling."""
 
+    DTYPES = ('f32', 'f16x3')
+
     def __init__(self, sd, device, prefix='projection', dtype=None):
-        """dtype: None / 'f32'.  There is no split-precision ('f16x3') plan for this head -- its layers are 32 or 64 wide (2 x 2 or 4 x 4 MFMA
-        blocks, all weights resident in LDS, never the bottleneck of a POCO reconstruction): asking for one is refused instead of silently
-        running fp32.  The PPS_DECODER_DTYPE default of the PPSurf decoder is not consulted here."""
-        if dtype not in (None, 'f32'):
-            raise NotImplementedError("POCO's projection head has no {!r} plan (decoder dtypes: 'f32'); 'f16x3' exists for the PPSurf decoder "
-                                      '(DecoderPlan) only'.format(dtype))
-        self.dtype = 'f32'
+        """dtype 'f16x3' or 'f32'; None = the environment variable PPS_DECODER_DTYPE, else 'f16x3' -- the same default and the same meaning as
+        DecoderPlan: fc2, fc3 and fc_query carried as three f16 MFMA products per fp32 product with fp32 accumulation, behind the same device-side
+        range guard (an activation beyond +-65504 makes the fp32 kernel queued behind recompute the call).  The layers are 32 or 64 wide and all
+        weights sit in LDS either way; 'f16x3' is here so that one setting selects one arithmetic for both model classes."""
+        import os
+        self.dtype = dtype or os.environ.get('PPS_DECODER_DTYPE', 'f16x3')
+        if self.dtype not in self.DTYPES:
+            raise ValueError('decoder dtype must be one of {} (got {!r})'.format(self.DTYPES, self.dtype))
         p = prefix
         w1, b1 = _wb(sd, p + '.fc1')
         c = w1.shape[0]
@@ -346,6 +349,18 @@ class PocoDecoderPlan:
         self.w = f32(np.concatenate([pack_xyz(w1[:, c:]), pack_dense(w2), pack_dense(w3), pack_dense(wq)]))
         self.b = f32(np.concatenate([b2, b3, bq]))
         self.tail = f32(np.concatenate([(w8 @ wv).reshape(-1), w8 @ bv + b8]))
+        self.w16 = None
+        if self.dtype == 'f16x3':
+            wmax = max(float(np.abs(m_).max()) for m_ in (w2, w3, wq))
+            if not wmax < 65504.0:
+                import warnings
+                warnings.warn('decoder dtype f16x3 needs |weight| < 65504 (largest: {:.3g}); using the exact fp32 kernel'.format(wmax))
+                self.dtype = 'f32'
+        if self.dtype == 'f16x3':
+            img = np.concatenate([pack_dense_f16x3(m_) for m_ in (w2, w3, wq)])
+            assert img.shape[0] * 2 == (2 * c * c + HEADS * c) * 4                     # as many bytes as the fp32 packs it replaces in LDS
+            self.w16 = torch.from_numpy(img.view(np.int16)).to(self.device)
+            self._guard = torch.zeros(16, dtype=torch.int32, device=self.device)       # [0] range flag of the last call, [1] fall-back counter
 
     def point_table(self, latents_cn):
         """G [N,c] from latents of SHAPE [c,N] (any strides)."""
@@ -361,7 +376,16 @@ class PocoDecoderPlan:
         q, k = query.shape[0], idx.shape[1]
         out = torch.empty((q, self.nout), dtype=torch.float32, device=self.device)
         st = torch.cuda.current_stream(self.device).cuda_stream
+        if self.w16 is not None:
+            _lib.check(_lib.lib().pps_interp_small_f16x3(table.data_ptr(), pts.data_ptr(), query.data_ptr(), idx.data_ptr(), q, k, self.c,
+                                                         self.w.data_ptr(), self.w16.data_ptr(), self.b.data_ptr(), self.tail.data_ptr(), self.nout,
+                                                         out.data_ptr(), self._guard.data_ptr(), st), 'pps_interp_small_f16x3')
+            return out
         _lib.check(_lib.lib().pps_interp_small_f32(table.data_ptr(), pts.data_ptr(), query.data_ptr(), idx.data_ptr(), q, k, self.c,
                                                    self.w.data_ptr(), self.b.data_ptr(), self.tail.data_ptr(), self.nout, out.data_ptr(), st),
                    'pps_interp_small_f32')
         return out
+
+    def range_fallbacks(self):
+        """Calls the split-precision kernel handed to the fp32 kernel so far (an activation left the f16 range); 0 for dtype 'f32'.  Synchronises."""
+        return 0 if self.w16 is None else int(self._guard[1])

@@ -420,7 +420,7 @@ class PocoNetwork(_Base):
         ver = _params_version(self.projection) + (self.training, getattr(self, 'decoder_dtype', None))
         if self._dec is None or self._dec[0] != ver or self._dec[1].device != torch.device(device):
             self._dec = (ver, PocoDecoderPlan({'projection.' + k: v for k, v in _sd(self.projection).items()}, device,
-                                              dtype=getattr(self, 'decoder_dtype', None)))          # 'f16x3' is refused there
+                                              dtype=getattr(self, 'decoder_dtype', None)))
             self._table = None
         return self._dec[1]
 
