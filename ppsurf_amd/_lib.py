@@ -19,6 +19,7 @@ SIGNATURES = {
     'pps_device_cu_count': (_I, []),
     'pps_knn_f32': (_I, [_P, _I64, _P, _I64, _I, _P, _P, _P]),
     'pps_knn_blocked_f32': (_I, [_P, _P, _P, _I64, _I64, _P, _I64, _P, _I64, _I, _P, _P, _P]),
+    'pps_knn_blocked_groups_f32': (_I, [_P, _P, _P, _I64, _I64, _P, _I64, _P, _P, _I64, _I, _P, _P, _P]),
     'pps_knn_multi_f32': (_I, [_I, _P, _P, _P, _P, _P, _P, _P]),
     'pps_knn_blocked_batch_f32': (_I, [_I, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pps_voxel_sample_max_points': (_I, []),

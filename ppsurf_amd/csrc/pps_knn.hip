@@ -19,6 +19,12 @@
 #define KNN_QW 8            // queries per wave pass
 #define KNN_WAVES 4         // waves per workgroup
 #define KNN_CAP 128         // candidate buffer entries per query (flush threshold 64 + one step of 64)
+#ifndef KNN_BISECT
+#define KNN_BISECT 12        // halvings of the distance-bit range when the seed bound is bisected
+#endif
+#ifndef KNN_SEED
+#define KNN_SEED 4           // full blocks around the best window whose exact k-th distance seeds tau (knn_blocked_kernel; at least R are taken)
+#endif
 
 typedef unsigned long long u64;
 
@@ -174,9 +180,11 @@ template <int R>
 __global__ __launch_bounds__(KNN_WAVES * 64) void knn_blocked_kernel(const float* __restrict__ pts, const int* __restrict__ orig,
                                                                      const float* __restrict__ bbox, int nb,
                                                                      const float* __restrict__ win_bbox, int n_win,
+                                                                     const float* __restrict__ sbox /* boxes of 64 consecutive blocks, or null */,
                                                                      const float* __restrict__ query, int64_t m, int k,
                                                                      int64_t* __restrict__ out_idx, float* __restrict__ out_d2) {
     __shared__ u64 cand_all[KNN_WAVES][KNN_QW][KNN_CAP];
+    const int ngrp = (nb + 63) >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kr = (k - 1) >> 6, kl = (k - 1) & 63;          // register / lane of the k-th key
     const int64_t ntask = (m + KNN_QW - 1) / KNN_QW;
@@ -184,36 +192,152 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_blocked_kernel(const float
         const int64_t q0 = task * KNN_QW;
         float qx[KNN_QW], qy[KNN_QW], qz[KNN_QW], tau[KNN_QW];
         u64 list[KNN_QW][R];
-        int cnt[KNN_QW];
+        int cnt[KNN_QW], wbest[KNN_QW];
 #pragma unroll
         for (int j = 0; j < KNN_QW; ++j) {
             const int64_t qq = (q0 + j < m) ? q0 + j : m - 1;
             qx[j] = __shfl(query[qq * 3], 0); qy[j] = __shfl(query[qq * 3 + 1], 0); qz[j] = __shfl(query[qq * 3 + 2], 0);
             tau[j] = INFINITY;
+            wbest[j] = 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) list[j][r] = ~0ull;
             cnt[j] = 0;
         }
-        // ---- initial tau: min over windows of R full blocks (>= k points) of the farthest-corner distance ------------
-        for (int b0 = 0; b0 < n_win; b0 += 64) {
-            const int b = b0 + lane;
-            const bool bv = b < n_win;
-            const float* bb = win_bbox + (int64_t)(bv ? b : 0) * 6;
-            const float lx = bb[0], ly = bb[1], lz = bb[2], hx = bb[3], hy = bb[4], hz = bb[5];
+        // ---- initial tau: the farthest-corner distance of a window of R full blocks (>= k points) bounds the k-th distance -----------------
+        // Any window gives a valid bound; a good one is wanted.  With the boxes of 64-block groups at hand (`sbox`) only the windows of ONE group
+        // per query are looked at -- the group whose own farthest corner is nearest -- instead of all of them (1563 boxes for a 100k-point cloud,
+        // a third of this kernel's instructions); without, every window is, as in rounds 1-3.
+        if (sbox != nullptr && n_win > 0) {
 #pragma unroll
             for (int j = 0; j < KNN_QW; ++j) {
-                const float fx = fmaxf(fabsf(__fsub_rn(qx[j], lx)), fabsf(__fsub_rn(qx[j], hx)));
-                const float fy = fmaxf(fabsf(__fsub_rn(qy[j], ly)), fabsf(__fsub_rn(qy[j], hy)));
-                const float fz = fmaxf(fabsf(__fsub_rn(qz[j], lz)), fabsf(__fsub_rn(qz[j], hz)));
-                const float far2 = bv ? __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz)) : INFINITY;
-                tau[j] = fminf(tau[j], far2);                      // per lane: the minimum over its windows ...
+                float best = INFINITY;
+                int bw = 0;
+                for (int g0 = 0; g0 * 64 < n_win; g0 += 64) {                    // groups that hold at least one window
+                    const int g = g0 + lane;
+                    const bool gv = g * 64 < n_win;
+                    const float* gb = sbox + (int64_t)(gv ? g : 0) * 6;
+                    const float gx = fmaxf(fmaxf(__fsub_rn(gb[0], qx[j]), __fsub_rn(qx[j], gb[3])), 0.f);
+                    const float gy = fmaxf(fmaxf(__fsub_rn(gb[1], qy[j]), __fsub_rn(qy[j], gb[4])), 0.f);
+                    const float gz = fmaxf(fmaxf(__fsub_rn(gb[2], qz[j]), __fsub_rn(qz[j], gb[5])), 0.f);
+                    const float gnear = gv ? __fadd_rn(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)), __fmul_rn(gz, gz)) : INFINITY;
+                    // a window's farthest corner is not nearer than its group's box: only groups nearer than the best bound so far can improve it
+                    u64 pend = __ballot(gnear < best);
+                    while (pend != 0ull) {
+                        const bool mine = (pend >> lane) & 1ull;
+                        const float tn = wave_min_f32(mine ? gnear : INFINITY, lane);
+                        const int src = __builtin_ctzll(__ballot(mine && gnear == tn));          // the nearest pending group first
+                        const int b = (g0 + src) * 64 + lane;
+                        const bool bv = b < n_win;
+                        const float* bb = win_bbox + (int64_t)(bv ? b : 0) * 6;
+                        const float fx = fmaxf(fabsf(__fsub_rn(qx[j], bb[0])), fabsf(__fsub_rn(qx[j], bb[3])));
+                        const float fy = fmaxf(fabsf(__fsub_rn(qy[j], bb[1])), fabsf(__fsub_rn(qy[j], bb[4])));
+                        const float fz = fmaxf(fabsf(__fsub_rn(qz[j], bb[2])), fabsf(__fsub_rn(qz[j], bb[5])));
+                        const float far2 = bv ? __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz)) : INFINITY;
+                        const float tf = wave_min_f32(far2, lane);
+                        if (tf < best) {
+                            best = tf;
+                            bw = (g0 + src) * 64 + __builtin_ctzll(__ballot(far2 == tf));
+                        }
+                        pend &= ~(1ull << src);
+                        pend &= __ballot(gnear < best);
+                    }
+                }
+                tau[j] = best;                                                   // wave-uniform: the reduction below leaves both as they are
+                wbest[j] = bw;
+            }
+        } else {
+            for (int b0 = 0; b0 < n_win; b0 += 64) {
+                const int b = b0 + lane;
+                const bool bv = b < n_win;
+                const float* bb = win_bbox + (int64_t)(bv ? b : 0) * 6;
+                const float lx = bb[0], ly = bb[1], lz = bb[2], hx = bb[3], hy = bb[4], hz = bb[5];
+#pragma unroll
+                for (int j = 0; j < KNN_QW; ++j) {
+                    const float fx = fmaxf(fabsf(__fsub_rn(qx[j], lx)), fabsf(__fsub_rn(qx[j], hx)));
+                    const float fy = fmaxf(fabsf(__fsub_rn(qy[j], ly)), fabsf(__fsub_rn(qy[j], hy)));
+                    const float fz = fmaxf(fabsf(__fsub_rn(qz[j], lz)), fabsf(__fsub_rn(qz[j], hz)));
+                    const float far2 = bv ? __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz)) : INFINITY;
+                    if (far2 < tau[j]) { tau[j] = far2; wbest[j] = b; }   // per lane: the minimum over its windows (and which one) ...
+                }
             }
         }
+        // ... and ONE reduction over the lanes per query (it used to sit inside the window loop: 48 ds_bpermute per 64 windows)
+        // ---- seed: the farthest-corner bound of a window is about the distance of its LAST point, loose by the whole extent of a 64-point cell;
+        // with it the scan below buffered and sorted several hundred candidates per query before tau closed in.  The exact k-th smallest distance
+        // among the 64 * nseed points of the full blocks around the best window is a far tighter upper bound of the k-th distance and costs no sort:
+        // a 31-step bisection on the distance bits with wave ballots (distances are non-negative floats: their bit patterns order like the values).
+        const int nfull = n_win > 0 ? n_win + R - 1 : 0;                          // windows slide over the FULL blocks (ops.KnnBlocks._windows)
+        constexpr int SEEDS = KNN_SEED > R ? KNN_SEED : R;                        // 64 * SEEDS >= k
+        const int nseed = nfull < SEEDS ? nfull : SEEDS;                          // >= R whenever there is a window
 #pragma unroll
-        for (int j = 0; j < KNN_QW; ++j) tau[j] = wave_min_f32(tau[j], lane);      // ... and ONE reduction over the lanes per query (it used to sit
-                                                                                   // inside the window loop: 48 ds_bpermute per 64 windows)
-        // ---- scan: 64 boxes per culling step, surviving blocks point by point ---------------------------------------
-        for (int b0 = 0; b0 < nb; b0 += 64) {
+        for (int j = 0; j < KNN_QW; ++j) {
+            const float t = wave_min_f32(tau[j], lane);
+            const u64 who = __ballot(tau[j] == t);
+            tau[j] = t;
+            if (nseed > 0) {
+                const int w = __shfl(wbest[j], who != 0ull ? __builtin_ctzll(who) : 0);
+                int s0 = w - (nseed - R) / 2;
+                s0 = s0 < 0 ? 0 : s0;
+                s0 = s0 + nseed > nfull ? nfull - nseed : s0;
+                unsigned u[SEEDS];
+#pragma unroll
+                for (int rr = 0; rr < SEEDS; ++rr) {
+                    const int p = (s0 + (rr < nseed ? rr : 0)) * 64 + lane;
+                    const float dx = __fsub_rn(qx[j], pts[3 * p]), dy = __fsub_rn(qy[j], pts[3 * p + 1]), dz = __fsub_rn(qz[j], pts[3 * p + 2]);
+                    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                    u[rr] = rr < nseed ? __float_as_uint(d2) : 0xffffffffu;
+                }
+                // invariant: #{u <= hi} >= k (the window bound to start with: its >= k points are among the seeds or it is no better than them);
+                // KNN_BISECT halvings of the bit range leave hi within ~2^-6 of the exact k-th distance, and any hi is a valid bound
+                unsigned lo = 0u, hi = __float_as_uint(tau[j]);
+                {
+                    int c = 0;
+#pragma unroll
+                    for (int rr = 0; rr < SEEDS; ++rr) c += __popcll(__ballot(u[rr] <= hi));
+                    if (c < k) lo = hi;                                           // the seeds do not hold k points below the window bound: keep it
+                }
+#pragma unroll
+                for (int it = 0; it < KNN_BISECT; ++it) {
+                    const unsigned mid = lo + ((hi - lo) >> 1);
+                    int c = 0;
+#pragma unroll
+                    for (int rr = 0; rr < SEEDS; ++rr) c += __popcll(__ballot(u[rr] <= mid));
+                    if (c >= k) hi = mid; else lo = mid + (lo < hi ? 1u : 0u);
+                }
+                tau[j] = __uint_as_float(hi);
+            }
+        }
+        // ---- scan: groups of 64 blocks whose box a query's ball reaches (all groups without `sbox`), 64 block boxes per culling step inside a
+        // group, surviving blocks point by point.  The group test is the block test on a larger box: same rounding order, never above the lower
+        // bound of any block inside (the gaps to the union box are no larger, every operation is monotonic).
+        for (int g0 = 0; g0 < ngrp; g0 += 64) {
+          u64 gneed[KNN_QW];
+          u64 gany = 0ull;
+          {
+            const int g = g0 + lane;
+            const bool gv = g < ngrp;
+            if (sbox != nullptr) {
+                const float* bb = sbox + (int64_t)(gv ? g : 0) * 6;
+                const float lx = bb[0], ly = bb[1], lz = bb[2], hx = bb[3], hy = bb[4], hz = bb[5];
+#pragma unroll
+                for (int j = 0; j < KNN_QW; ++j) {
+                    const float gx = fmaxf(fmaxf(__fsub_rn(lx, qx[j]), __fsub_rn(qx[j], hx)), 0.f);
+                    const float gy = fmaxf(fmaxf(__fsub_rn(ly, qy[j]), __fsub_rn(qy[j], hy)), 0.f);
+                    const float gz = fmaxf(fmaxf(__fsub_rn(lz, qz[j]), __fsub_rn(qz[j], hz)), 0.f);
+                    const float near2 = __fadd_rn(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)), __fmul_rn(gz, gz));
+                    gneed[j] = __ballot(gv && near2 <= tau[j]);
+                    gany |= gneed[j];
+                }
+            } else {
+                gany = __ballot(gv);
+#pragma unroll
+                for (int j = 0; j < KNN_QW; ++j) gneed[j] = gany;
+            }
+          }
+          while (gany != 0ull) {
+            const int gbit = __builtin_ctzll(gany);
+            gany &= gany - 1ull;
+            const int b0 = (g0 + gbit) * 64;
             const int b = b0 + lane;
             const bool bv = b < nb;
             const float* bb = bbox + (int64_t)(bv ? b : 0) * 6;
@@ -222,6 +346,8 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_blocked_kernel(const float
             u64 any = 0ull;
 #pragma unroll
             for (int j = 0; j < KNN_QW; ++j) {
+                need[j] = 0ull;
+                if (((gneed[j] >> gbit) & 1ull) == 0ull) continue;
                 const float gx = fmaxf(fmaxf(__fsub_rn(lx, qx[j]), __fsub_rn(qx[j], hx)), 0.f);
                 const float gy = fmaxf(fmaxf(__fsub_rn(ly, qy[j]), __fsub_rn(qy[j], hy)), 0.f);
                 const float gz = fmaxf(fmaxf(__fsub_rn(lz, qz[j]), __fsub_rn(qz[j], hz)), 0.f);
@@ -249,13 +375,14 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_blocked_kernel(const float
                         if (pass) cand[pos] = ((u64)__float_as_uint(d2) << 32) | (unsigned)oi;
                         cnt[j] += __popcll(mask);
                         if (cnt[j] > KNN_CAP - 64) {
-                            knn_flush_r<R>(list[j], cand, cnt[j], lane);
-                            cnt[j] = 0;
+                            knn_flush_r<R>(list[j], cand + (cnt[j] - 64), 64, lane);      // the newest 64: one full sorting network; the rest waits
+                            cnt[j] -= 64;
                             tau[j] = fminf(tau[j], __uint_as_float((unsigned)(shfl_u64(list[j][kr < R ? kr : R - 1], kl) >> 32)));
                         }
                     }
                 }
             }
+          }
         }
 #pragma unroll
         for (int j = 0; j < KNN_QW; ++j) {
@@ -437,6 +564,12 @@ int pps_knn_f32(const float* pts, int64_t n, const float* query, int64_t m, int 
 int pps_knn_blocked_f32(const float* pts_blocked, const int32_t* orig_idx, const float* bbox, int64_t nb, int64_t n,
                         const float* win_bbox, int64_t n_win, const float* query, int64_t m, int k, int64_t* out_idx, float* out_d2,
                         void* stream) {
+    return pps_knn_blocked_groups_f32(pts_blocked, orig_idx, bbox, nb, n, win_bbox, n_win, nullptr, query, m, k, out_idx, out_d2, stream);
+}
+
+int pps_knn_blocked_groups_f32(const float* pts_blocked, const int32_t* orig_idx, const float* bbox, int64_t nb, int64_t n,
+                               const float* win_bbox, int64_t n_win, const float* group_bbox, const float* query, int64_t m, int k,
+                               int64_t* out_idx, float* out_d2, void* stream) {
     if (n < 1 || nb < 1 || nb * 64 < n || (nb - 1) * 64 >= n || m < 0 || k < 1 || k > 256 || k > n || nb > 0x1ffffff || n_win < 0)
         return PPS_ERR_ARG;
     if (m == 0) return PPS_OK;
@@ -450,7 +583,7 @@ int pps_knn_blocked_f32(const float* pts_blocked, const int32_t* orig_idx, const
     hipStream_t st = (hipStream_t)stream;
     const int r = (k + 63) / 64;
 #define PPS_KNN_LAUNCH(R) hipLaunchKernelGGL(knn_blocked_kernel<R>, grid, block, 0, st, pts_blocked, orig_idx, bbox, (int)nb, win_bbox, \
-                                             (int)n_win, query, m, k, out_idx, out_d2)
+                                             (int)n_win, group_bbox, query, m, k, out_idx, out_d2)
     if (r == 1) PPS_KNN_LAUNCH(1);
     else if (r == 2) PPS_KNN_LAUNCH(2);
     else if (r == 3) PPS_KNN_LAUNCH(3);

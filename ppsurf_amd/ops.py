@@ -146,7 +146,12 @@ class KnnBlocks:
         self.orig = torch.cat([order.to(torch.int32), torch.full((pad,), -1, dtype=torch.int32, device=pts.device)]).contiguous()
         blk = self.pts.view(nb, 64, 3)                   # padding repeats the last valid point: boxes stay tight
         self.bbox = torch.cat([blk.min(dim=1)[0], blk.max(dim=1)[0]], dim=1).contiguous()
+        # second level: boxes of 64 consecutive blocks (the last group padded with its own last box)
+        ng = (nb + 63) // 64
+        bb = torch.cat([self.bbox, self.bbox[-1:].expand(ng * 64 - nb, 6)], dim=0).view(ng, 64, 6)
+        self.gbox = torch.cat([bb[:, :, :3].min(dim=1)[0], bb[:, :, 3:].max(dim=1)[0]], dim=1).contiguous()
         self._win = {}
+        self.groups = True                                # tests switch the second level off to compare
 
     def _windows(self, r: int):
         """Boxes of r consecutive FULL blocks (>= 64*r points each): upper bounds of the k-th distance for k <= 64*r."""
@@ -168,10 +173,10 @@ class KnnBlocks:
         assert idx.dtype == torch.int64 and idx.is_contiguous() and tuple(idx.shape) == (m, k)
         d2 = torch.empty((m, k), dtype=torch.float32, device=query.device) if return_d2 else None
         win = self._windows((int(k) + 63) // 64) if 1 <= int(k) <= 256 else None
-        _lib.check(_lib.lib().pps_knn_blocked_f32(self.pts.data_ptr(), self.orig.data_ptr(), self.bbox.data_ptr(), self.nb, self.n,
-                                                  win.data_ptr() if win is not None else None, win.shape[0] if win is not None else 0,
-                                                  query.data_ptr(), m, int(k), idx.data_ptr(), d2.data_ptr() if return_d2 else None,
-                                                  _stream(query)), 'pps_knn_blocked_f32')
+        _lib.check(_lib.lib().pps_knn_blocked_groups_f32(self.pts.data_ptr(), self.orig.data_ptr(), self.bbox.data_ptr(), self.nb, self.n,
+                                                         win.data_ptr() if win is not None else None, win.shape[0] if win is not None else 0,
+                                                         self.gbox.data_ptr() if self.groups else None, query.data_ptr(), m, int(k), idx.data_ptr(),
+                                                         d2.data_ptr() if return_d2 else None, _stream(query)), 'pps_knn_blocked_groups_f32')
         return (idx, d2) if return_d2 else idx
 
 

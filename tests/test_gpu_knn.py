@@ -117,6 +117,25 @@ def test_blocked_knn_is_bit_identical_to_brute_force(n, m, k):
     assert np.array_equal(idx.cpu().numpy(), O.knn_point_major(pts, qry, k))
 
 
+@pytest.mark.parametrize('n,m,k', [(4097, 500, 64), (4160, 500, 16), (100_000, 4000, 64), (250_000, 2000, 200), (8192, 300, 130)])
+def test_blocked_knn_group_level_changes_nothing(n, m, k):
+    """The second level of boxes (groups of 64 blocks), the seed bound bisected from the blocks around the best window and the per-batch
+    flushes only prune: with and without the group boxes the search returns the brute-force result bit for bit -- also where the last group
+    holds a single (partial) block and for queries far outside the cloud."""
+    pts = make_cloud(n, seed=n + k)
+    qry = np.concatenate([make_band_queries(pts, m - 20, resolution=257, seed=m),
+                          np.random.default_rng(k).uniform(-4, 4, (20, 3)).astype(np.float32)])
+    dp, dq = torch.from_numpy(pts).to(DEV), torch.from_numpy(qry).to(DEV)
+    blocks = ops.KnnBlocks(dp)
+    assert blocks.gbox.shape == ((blocks.nb + 63) // 64, 6)
+    a_idx, a_d2 = blocks.query(dq, k, return_d2=True)
+    blocks.groups = False
+    b_idx, b_d2 = blocks.query(dq, k, return_d2=True)
+    assert torch.equal(a_idx, b_idx) and torch.equal(a_d2, b_d2)
+    ref_idx, ref_d2 = O.knn_point_major(pts, qry, k, return_d2=True)
+    assert np.array_equal(a_idx.cpu().numpy(), ref_idx) and np.array_equal(a_d2.cpu().numpy(), ref_d2)
+
+
 def test_blocked_knn_ties_and_far_queries():
     rng = np.random.default_rng(11)
     pts = (rng.integers(0, 6, (4000, 3)) / 8.0).astype(np.float32)          # lattice: many exact distance ties
