@@ -128,8 +128,8 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(const float* __rest
                     if (pass) cand[pos] = ((u64)__float_as_uint(d2) << 32) | (unsigned)p;
                     cnt[j] += __popcll(mask);
                     if (cnt[j] > KNN_CAP - 64) {
-                        list[j] = knn_flush(list[j], cand, cnt[j], lane);
-                        cnt[j] = 0;
+                        list[j] = knn_flush(list[j], cand + (cnt[j] - 64), 64, lane);      // the newest 64 only: one sorting network per flush.  tau then
+                        cnt[j] -= 64;                                                     // comes from a subset of the points seen: looser, still exact
                         tau[j] = __uint_as_float((unsigned)(shfl_u64(list[j], k - 1) >> 32));
                     }
                 }
@@ -497,8 +497,8 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_blocked_batch_kernel(const
                         if (pass) cand[pos] = ((u64)__float_as_uint(d2) << 32) | (unsigned)oi;
                         cnt[j] += __popcll(mask);
                         if (cnt[j] > KNN_CAP - 64) {
-                            list[j] = knn_flush(list[j], cand, cnt[j], lane);
-                            cnt[j] = 0;
+                            list[j] = knn_flush(list[j], cand + (cnt[j] - 64), 64, lane);      // the newest 64 only (one sorting network)
+                            cnt[j] -= 64;
                             tau[j] = fminf(tau[j], __uint_as_float((unsigned)(shfl_u64(list[j], k - 1) >> 32)));
                         }
                     }

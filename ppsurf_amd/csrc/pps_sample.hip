@@ -466,8 +466,8 @@ __global__ __launch_bounds__(KM_WAVES * 64) void knn_multi_kernel(const KnnMulti
                     if (pass) cand[pos] = ((u64)__float_as_uint(d2) << 32) | (unsigned)p;
                     cnt[j] += __popcll(mask);
                     if (cnt[j] > KM_CAP - 64) {
-                        list[j] = km_flush(list[j], cand, cnt[j], lane);
-                        cnt[j] = 0;
+                        list[j] = km_flush(list[j], cand + (cnt[j] - 64), 64, lane);      // the newest 64: ONE sorting network per flush (two on 65..128
+                        cnt[j] -= 64;                                                     // entries before); the older ones wait in the buffer
                         tau[j] = __uint_as_float((unsigned)(km_shfl(list[j], k - 1) >> 32));
                     }
                 }
