@@ -175,6 +175,7 @@ def chunk_loop(work, steps, warmup, rank, world, dist, red_dev, min_timed_s=MIN_
     Returns the max-over-ranks wall time, this rank's own time, repeats, per-stage HIP-event means (ms) and the last occupancy."""
     import bench_workloads as workloads
     from ppsurf_amd import sharding
+    from ppsurf_amd.fit import HostGcPacer
     torch.cuda.synchronize()
     tw = time.perf_counter()
     for pipe, c in work[:warmup]:
@@ -195,6 +196,7 @@ def chunk_loop(work, steps, warmup, rank, world, dist, red_dev, min_timed_s=MIN_
         repeats = max(1, int(math.ceil(min_timed_s / (est * steps))))
     repeats = int(round(sharding.max_over_ranks(float(repeats), red_dev)))
     ev = [workloads.HipEvents(6) for _ in range(steps * repeats)]
+    pacer = HostGcPacer().__enter__()                             # as the predict loop of ppsurf_amd.runner decodes the chunks of a shape
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -203,12 +205,14 @@ def chunk_loop(work, steps, warmup, rank, world, dist, red_dev, min_timed_s=MIN_
     for _ in range(repeats):
         for pipe, c in timed:                                     # `steps` distinct chunks of Q_CHUNK queries, `repeats` times
             res = pipe.run([c], want_occ=True, stage_events=[ev[i].arr])
+            pacer.tick()
             i += 1
     torch.cuda.synchronize()
     mine = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
     dt = sharding.max_over_ranks(time.perf_counter() - t0, red_dev)
+    pacer.close()
     occ = res[-1][1]
     assert bool(torch.isfinite(occ).all())
     stage_ms = {name: float(np.mean([e.elapsed_ms(j, j + 1) for e in ev])) for j, name in enumerate(STAGES)}
@@ -395,16 +399,22 @@ def main():
         model = workloads.make_model(RES, P_LOCAL, Q_CHUNK, dev)
         model.network.decoder_dtype = args.dtype
         first = workloads.reconstruct_steered(model, N_POINTS, seed=42 + 1000 * rank, device=dev)
-        if dist is not None:
+        from ppsurf_amd.fit import HostGcPacer
+        runs = []
+        pacer = HostGcPacer(every=1).__enter__()            # the predict loop of ppsurf_amd.runner: a young-generation collection between shapes,
+        if dist is not None:                                # the full one when the loop is over
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        runs = [workloads.reconstruct_steered(model, N_POINTS, seed=43 + 1000 * rank + i, device=dev) for i in range(args.shapes)]
+        for i in range(args.shapes):
+            runs.append(workloads.reconstruct_steered(model, N_POINTS, seed=43 + 1000 * rank + i, device=dev))
+            pacer.tick()
         torch.cuda.synchronize()
         mine = time.perf_counter() - t0
         if dist is not None:
             dist.barrier()
         dt_shapes = sharding.max_over_ranks(time.perf_counter() - t0, red_dev)
+        pacer.close()
         rank_sph = [3600.0 * args.shapes / t for t in rank_values(mine, rank, world, dist, red_dev)]
         if rank == 0:
             steady = min(x['total_s'] for x in runs)
@@ -434,12 +444,15 @@ def main():
         for _ in range(6):
             fit()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n_fit = 60
-        for _ in range(n_fit):
-            loss = fit()
-        torch.cuda.synchronize()
-        out['fit_ms_per_step'] = (time.perf_counter() - t0) / n_fit * 1e3
+        from ppsurf_amd.fit import HostGcPacer
+        n_fit = 120
+        with HostGcPacer() as pacer:                      # as the epoch loop of ppsurf_amd.fit runs its steps
+            t0 = time.perf_counter()
+            for _ in range(n_fit):
+                loss = fit()
+                pacer.tick()
+            torch.cuda.synchronize()
+            out['fit_ms_per_step'] = (time.perf_counter() - t0) / n_fit * 1e3
         out['fit'] = {'config': 'ppsurf_50nn fit step: B=10 shapes x 10000 points, 2000 queries/shape, P=50, bf16-mixed, AdamW; id tables + '
                                 'patches built on the device by the loader thread on a second stream, step replayed as a HIP graph (the defaults of pps.py fit)',
                       'steps_timed': n_fit, 'loss': float(loss),

@@ -472,6 +472,12 @@ int pps_rows_layer_bwd_pooled(const void* x, const void* y, const void* gval, co
  * not NULL.  grad_scale / found_inf (device floats, NULL = none) as torch.amp.GradScaler hands them to a fused optimizer: gradients are divided by
  * *grad_scale (and written back), and nothing at all happens when *found_inf != 0. */
 int pps_adamw_piece_bytes(void);
+/* 16-bit images (dtype 1 = bfloat16, 2 = IEEE half; round to nearest even) of many fp32 tensors in one launch: pieces = device array of n_pieces
+ * records of pps_cast_piece_bytes() = 24 bytes {const float* src, uint16* dst, int32 n, int32 pad}, one workgroup each (n <= 4096 elements).
+ * replaces: the per-weight `.to(dtype)` casts torch.autocast inserts in front of every conv / linear of a training forward pass
+ * (source/base/nn.py layers under trainer.precision 16-mixed / bf16-mixed). */
+int pps_cast_piece_bytes(void);
+int pps_cast_pieces(const void* pieces, int n_pieces, int dtype, void* stream);
 int pps_adamw_step(const void* pieces, int n_pieces, const void* steps, int n_steps, const float* lr_dev, float lr, float beta1, float beta2,
                    float eps, float weight_decay, const float* grad_scale, const float* found_inf, void* stream);
 

@@ -101,6 +101,8 @@ SIGNATURES = {
     'pps_bn_train_bwd': (_I, [_P, _P, _I64, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     'pps_col_sum': (_I, [_P, _I64, _I, _I, _P, _P, _P]),
     'pps_adamw_piece_bytes': (_I, []),
+    'pps_cast_piece_bytes': (_I, []),
+    'pps_cast_pieces': (_I, [_P, _I, _I, _P]),
     'pps_adamw_step': (_I, [_P, _I, _P, _I, _P, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _c.c_float, _P, _P, _P]),
 }
 

@@ -173,10 +173,13 @@ def main(argv=None):
         sharding.set_query_sharding(model.shard_queries)
     with torch.no_grad():
         if sub == 'predict':
-            for i, batch in enumerate(data.predict_dataloader()):
-                if world > 1 and shard == 'shapes' and i % world != rank:
-                    continue
-                model.predict_step(batch, i)
+            from .fit import HostGcPacer
+            with HostGcPacer(every=1) as pacer:                 # a young-generation collection between shapes, none inside one (fit.HostGcPacer)
+                for i, batch in enumerate(data.predict_dataloader()):
+                    if world > 1 and shard == 'shapes' and i % world != rank:
+                        continue
+                    model.predict_step(batch, i)
+                    pacer.tick()
             model.on_predict_epoch_end()
         else:
             for i, batch in enumerate(data.test_dataloader()):

@@ -53,11 +53,41 @@ def splitk_slabs(rows):
     return SPLITK_SLABS if rows >= SPLITK_MIN_ROWS else 0
 
 
-# bf16 images of the fp32 master parameters, refreshed once per forward pass by ONE multi-tensor copy (prepare_shadows): the library GEMMs
+# bf16 images of the fp32 master parameters, refreshed once per forward pass by ONE launch (prepare_shadows -> pps_cast_pieces): the library GEMMs
 # of the encoder otherwise cast every weight and bias with a launch of its own (~140 four-microsecond kernels per step)
 _shadow = {}                 # id(parameter) -> bf16 tensor of the same shape (persistent storage)
 _shadow_live = [False]
 _shadow_ver = {}             # id(parameter) -> parameter._version when its image was taken (an optimizer step in between makes the image stale)
+
+
+_cast_tables = {}            # (device, dtype) -> (key, device table of pieces, number of pieces)
+CAST_PIECE = 4096
+
+
+def _cast_all(params, dtype):
+    """All images in ONE launch (pps_cast_pieces) through a device table of (source, image, count) pieces; the table holds raw pointers and is
+    rebuilt when a parameter or an image moved.  False (the caller copies with torch): a table would have to be uploaded while a graph is being
+    captured, non-contiguous tensors, parameters on several devices."""
+    code = {torch.bfloat16: 1, torch.float16: 2}.get(dtype)
+    if code is None or len({p.device for p in params}) != 1:
+        return False
+    if any(not p.is_contiguous() or not _shadow[id(p)].is_contiguous() for p in params):
+        return False
+    from . import _lib
+    import numpy as np
+    dev = params[0].device
+    key = tuple((p.data_ptr(), _shadow[id(p)].data_ptr(), p.numel()) for p in params)
+    cached = _cast_tables.get((dev, dtype))
+    if cached is None or cached[0] != key:
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        assert _lib.lib().pps_cast_piece_bytes() == 24
+        rows = [(sp + 4 * off, dp + 2 * off, min(CAST_PIECE, n - off)) for sp, dp, n in key for off in range(0, n, CAST_PIECE)]
+        cached = (key, torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev), len(rows))
+        _cast_tables[(dev, dtype)] = cached
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().pps_cast_pieces(cached[1].data_ptr(), cached[2], code, torch.cuda.current_stream(dev).cuda_stream), 'pps_cast_pieces')
+    return True
 
 
 def prepare_shadows(module, dtype=torch.bfloat16):
@@ -70,7 +100,8 @@ def prepare_shadows(module, dtype=torch.bfloat16):
             t = _shadow.get(id(p))
             if t is None or t.shape != p.shape or t.device != p.device or t.dtype != dtype:
                 _shadow[id(p)] = torch.empty_like(p, dtype=dtype)
-        torch._foreach_copy_([_shadow[id(p)] for p in params], params)
+        if not _cast_all(params, dtype):
+            torch._foreach_copy_([_shadow[id(p)] for p in params], params)
     for p in params:
         _shadow_ver[id(p)] = p._version
     _shadow_live[0] = True

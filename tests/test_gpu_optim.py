@@ -272,3 +272,27 @@ def test_state_replaced_behind_the_optimizers_back_rebuilds_the_pointer_table():
         _set_grads(a, b, step)
         mine.step(); ref.step()
     _same(a, b, mine, ref)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_parameter_images_in_one_launch_equal_torch_casts(dtype):
+    """train_graph.prepare_shadows: the 16-bit images of all parameters by ONE launch (pps_cast_pieces) are torch's own conversions bit for bit --
+    odd sizes, several pieces per tensor, halfway cases of the rounding, denormals, infinities, NaN -- and follow parameters that move."""
+    from ppsurf_amd import train_graph
+    g = torch.Generator(device='cpu').manual_seed(5)
+    mod = torch.nn.Module()
+    sizes = [(1,), (3, 5), (4097,), (64, 129), (300, 300), (2,)]
+    for i, sz in enumerate(sizes):
+        mod.register_parameter('p{}'.format(i), torch.nn.Parameter((torch.randn(sz, generator=g) * 10.0 ** (i - 3)).to(DEV)))
+    special = torch.tensor([0.0, -0.0, float('inf'), -float('inf'), float('nan'), 1e-40, -1e-45, 65504.0, 65520.0, 1e38, 3.4e38,
+                            1.0 + 2.0 ** -8, 1.0 + 2.0 ** -9, 1.0 + 3 * 2.0 ** -9, 1.0 + 2.0 ** -11, 1.0 + 2.0 ** -12], device=DEV)
+    mod.register_parameter('special', torch.nn.Parameter(special))
+    for rep in range(2):
+        train_graph.prepare_shadows(mod, dtype)
+        for p in mod.parameters():
+            img = train_graph._shadow[id(p)]
+            want = p.detach().to(dtype)
+            assert img.dtype == dtype and torch.equal(img.view(torch.int16), want.view(torch.int16))
+        with torch.no_grad():                                             # a parameter that moves: the table follows
+            mod.p3.data = (mod.p3.data * 1.5).clone()
+    train_graph.release_step_caches()
