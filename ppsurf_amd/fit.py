@@ -109,8 +109,8 @@ class GraphedStep:
                 # of this step are already queued behind the previous replay when the host gets here.
                 if self._done is not None:
                     self._done.synchronize()
-                for k, v in static.items():
-                    v.copy_(batch[k], non_blocking=True)
+                # one multi-tensor copy per dtype instead of one memcpy per tensor (35 of them): the GPU idles while the host queues these
+                torch._foreach_copy_(list(static.values()), [batch[k] for k in static])
                 graph.replay()
                 self.replayed = True
                 if self._done is None:
