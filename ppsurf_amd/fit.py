@@ -349,21 +349,20 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
         model.train()
         train_loader.set_epoch(epoch)
         t0 = time.time()
-        pacer.__enter__()                                      # no stop-the-world collection inside the step loop (HostGcPacer)
-        for bi, batch in enumerate(train_loader):
-            stepper.run(batch, bi)
-            pacer.tick()
-            global_step += 1
-            # the step's logged values are still device tensors: they are read one step LATER (when they are long finished), so
-            # the host never waits for the GPU inside the loop and keeps queueing the next step's launches
+        with pacer:                                            # no stop-the-world collection inside the step loop (HostGcPacer); the full
+            for bi, batch in enumerate(train_loader):          # collection of the epoch runs when the block is left, also by an exception
+                stepper.run(batch, bi)
+                pacer.tick()
+                global_step += 1
+                # the step's logged values are still device tensors: they are read one step LATER (when they are long finished), so
+                # the host never waits for the GPU inside the loop and keeps queueing the next step's launches
+                flush(pending)
+                pending = (metrics.values, dict(epoch=epoch, step=global_step, lr=host_lr))
+                if 0 < max_steps <= global_step:
+                    done = True
+                    break
             flush(pending)
-            pending = (metrics.values, dict(epoch=epoch, step=global_step, lr=host_lr))
-            if 0 < max_steps <= global_step:
-                done = True
-                break
-        flush(pending)
-        pending = None
-        pacer.close()                                          # the full collection of the epoch, outside the step loop
+            pending = None
         stepper.touch(model)                                   # replays move no version counters: the eval() plans below are keyed on them
         if scheduler is not None:
             scheduler.step()
