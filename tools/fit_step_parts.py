@@ -44,3 +44,9 @@ def inline():
 
 
 print('(d) preparation inline + replay: {:.2f} ms per step'.format(timed(inline)))
+
+# (e) the recorded graph replayed back to back: no wait for the previous replay, no refill of the static inputs -- what the host round trip between
+# two steps costs
+sig = step.stepper.signature(batch)
+static, graph, logged, state = step.stepper.graphs[sig]
+print('(e) graph.replay() back to back: {:.2f} / {:.2f} ms per step'.format(timed(graph.replay), timed(graph.replay)))
