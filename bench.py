@@ -58,6 +58,12 @@ INTERP_EXEC_FLOP_PER_QUERY = 2320 * 4 * 2048.0
 # the per-query matrix and conv3 behind the attention pooling (ppsurf_amd/decoder.py): the feature kernel runs 4 tiles x (4 + 64 + 64 + 128), the
 # tail (256 + 128) -> 256 -> 256 -> 2 on 16-query tiles
 STAGE_EXEC_MFMA_PER_QUERY = {'interp_pool': 9280, 'pointnet_stn_rows': 2413, 'pointnet_stn_fc': 296, 'pointnet_feat_rows': 1040, 'decode_tail': 168}
+# ALGORITHMIC flops per query of the reference work each stage replaces at P = 50 (2 x MACs of the conv / matmul ops;
+# the stages sum to 53.2 MFLOP with fc8's 65 536 MAC, which the tail carries): STN rows = 50 x (conv0a 192 + conv0b 4096 + stn.conv1 4096 +
+# conv2 8192 + conv3 32768), STN head 256x128 + 128x64 + 64x4096, feature rows = 50 x (trans2 4096 + conv1 4096 + conv2 8192 + conv3 32768 +
+# att.fc_query 256 + att.fc_value 65536 + pooling 256), tail = fc8 65536 + MLP 131584 (nn.py:162-190,305-373,376-417)
+STAGE_ALG_FLOP_PER_QUERY = {'interp_pool': INTERP_ALG_FLOP_PER_QUERY, 'pointnet_stn_rows': 2.0 * 50 * 49_344, 'pointnet_stn_fc': 2.0 * 303_104,
+                            'pointnet_feat_rows': 2.0 * 50 * 115_200, 'decode_tail': 2.0 * (65_536 + 131_584)}
 PEAK_F32_MFMA_TFLOPS = 157.3                   # /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F16_MFMA_TFLOPS = 2500.0                  # dense f16 / bf16 matrix peak, same guide
 MEASURED_F16_MFMA_TFLOPS = 1800.0              # bare v_mfma_f32_16x16x32_f16 loop, random operands, measured (1797-1917; 2274 on zeros)
@@ -244,22 +250,25 @@ def roofline_block(dtype, stage_ms):
     k_ms = stage_ms['interp_pool']
     executed = mult * INTERP_EXEC_FLOP_PER_QUERY * Q_CHUNK / (k_ms * 1e-3) / 1e12
     traffic, traffic_src = pmc_traffic(dtype)
+    algorithmic = INTERP_ALG_FLOP_PER_QUERY * Q_CHUNK / (k_ms * 1e-3) / 1e12
     return {'kernel': ('interp_pool_f16x3_kernel' if f16 else 'interp_pool_kernel') + ' (inside pps_decode_fwd_events_f32)', 'bound': 'mfma',
-            'achieved': executed, 'peak': peak, 'unit': 'TFLOP/s', 'frac': executed / peak,
-            # SURVEY 8(d)'s quantity: the flops of the REFERENCE work this kernel replaces (35.78 MFLOP per query) / time / peak.  For f16x3 the
-            # executed figure counts the 3x of the split; for fp32 two exact identities remove 47 % of the reference's flops (so this can exceed 1)
-            'frac_algorithmic': INTERP_ALG_FLOP_PER_QUERY * Q_CHUNK / (k_ms * 1e-3) / 1e12 / peak,
+            # SURVEY 8(d)'s quantity: ALGORITHMIC flops -- the reference work this kernel replaces, 35.78 MFLOP per query (poco_model.py:400-414) x the
+            # 50 000 queries of a launch -- / the kernel's HIP-event duration / the guide's dense peak for the MFMA type the kernel issues.
+            # fp32: two exact identities remove 47 % of the reference's flops before the kernel runs, so this can exceed 1 there
+            'achieved': algorithmic, 'peak': peak, 'unit': 'TFLOP/s', 'frac': algorithmic / peak,
+            # what the kernel EXECUTES on the matrix pipe (f16x3: the 3 f16 products per fp32 product counted as work) -- a utilisation figure, not
+            # the contract's fraction
+            'executed_tflops': executed, 'frac_executed': executed / peak,
             # what a bare loop of the same MFMA instruction sustains on random operands on this chip (it clocks down under matrix load:
-            # tools/ubench/mfma_power_probe.hip, profiles/round4_mfma_power_probe.txt) -- the peak of the guide is reached on zero operands only
+            # tools/ubench/mfma_power_probe.hip, profiles/round4_mfma_power_probe.txt); NOT a roofline fraction
             'peak_sustained_random_operands': MEASURED_F16_MFMA_TFLOPS if f16 else None,
-            'frac_of_sustained': executed / MEASURED_F16_MFMA_TFLOPS if f16 else None,
+            'executed_over_sustained': executed / MEASURED_F16_MFMA_TFLOPS if f16 else None,
             'traffic': traffic, 'traffic_source': traffic_src, 'avg_kernel_ms': k_ms,
-            'algorithmic_tflops': INTERP_ALG_FLOP_PER_QUERY * Q_CHUNK / (k_ms * 1e-3) / 1e12,
-            'note': ('achieved / frac = f16 MFMA flops the split-precision kernel executes (3 f16 products per fp32 product of the 9280 x 2048 '
-                     'flop per query) / its HIP-event duration / the dense f16 matrix peak (DESIGN.md section 4.1b)' if f16 else
-                     'achieved / frac = MFMA flops the kernel EXECUTES (9280 v_mfma_f32_16x16x4_f32 per query x 2048) / its HIP-event '
-                     'duration / the fp32 matrix peak; algorithmic_tflops prices the reference work it replaces (two exact identities '
-                     'remove 47 % of it, DESIGN.md section 2) and is not a hardware fraction')}
+            'note': 'achieved / frac = algorithmic flops per launch (SURVEY 8d: 35.78 MFLOP x 50 000 queries) / HIP-event duration of the kernel / ' +
+                    ('the dense f16 matrix peak; executed_tflops counts the 3 f16 MFMAs per fp32 product of the 9280 x 2048 flop per query the '
+                     'kernel runs (DESIGN.md section 4.1)' if f16 else
+                     'the fp32 matrix peak; executed_tflops = the 9280 v_mfma_f32_16x16x4_f32 per query x 2048 flop the kernel runs (two exact '
+                     'identities remove 47 % of the reference work, DESIGN.md section 2: frac > 1 is possible, frac_executed is the hardware fraction)')}
 
 
 def dtype_stats(dtype, r, world):
@@ -270,7 +279,8 @@ def dtype_stats(dtype, r, world):
     ms_step = r['dt'] / r['chunks'] * 1e3
     sm = r['stage_ms']
     return {'value': value, 'unit': 'queries/s', 'ms_per_step': ms_step, 'repeats': r['repeats'], 'timed_s': r['dt'], 'stage_ms': sm,
-            'stage_mfma_frac': {n: mult * STAGE_EXEC_MFMA_PER_QUERY[n] * 2048.0 * Q_CHUNK / (sm[n] * 1e-3) / 1e12 / peak for n in STAGES},
+            'stage_mfma_frac': {n: STAGE_ALG_FLOP_PER_QUERY[n] * Q_CHUNK / (sm[n] * 1e-3) / 1e12 / peak for n in STAGES},      # algorithmic (8d)
+            'stage_mfma_frac_executed': {n: mult * STAGE_EXEC_MFMA_PER_QUERY[n] * 2048.0 * Q_CHUNK / (sm[n] * 1e-3) / 1e12 / peak for n in STAGES},
             'spatial_ms': ms_step - sum(sm.values()),
             'whole_path_algorithmic_tflops': ALG_MFLOP_PER_QUERY * 1e6 * value / world / 1e12,
             'whole_path_algorithmic_frac': ALG_MFLOP_PER_QUERY * 1e6 * value / world / 1e12 / peak,
@@ -363,7 +373,7 @@ def main():
                        'parallelism': 'query-block sharding x{}'.format(world), 'weights': 'formula-filled (no checkpoint offline)',
                        'entry': 'ChunkPipeline.run -> pps_knn_blocked_f32, pps_patch_normalize_f32, pps_decode_fwd_events_f32'},
             'roofline': roofline_block(args.dtype, r['stage_ms']),
-            'stage_ms': st['stage_ms'], 'stage_mfma_frac': st['stage_mfma_frac'], 'spatial_ms': st['spatial_ms'],
+            'stage_ms': st['stage_ms'], 'stage_mfma_frac': st['stage_mfma_frac'], 'stage_mfma_frac_executed': st['stage_mfma_frac_executed'], 'spatial_ms': st['spatial_ms'],
             'whole_path_algorithmic_tflops': st['whole_path_algorithmic_tflops'], 'whole_path_algorithmic_frac': st['whole_path_algorithmic_frac'],
             'whole_path_executed_mfma_frac': st['whole_path_executed_mfma_frac'],
         }
