@@ -177,7 +177,11 @@ def build_work(plan, n_chunks, rank, dev, queries='band'):
 
 
 def chunk_loop(work, steps, warmup, rank, world, dist, red_dev, min_timed_s=MIN_TIMED_S):
-    """`warmup` untimed chunks, then `repeats` passes over the next `steps` DISTINCT chunks between barrier + synchronize on both sides.
+    """`warmup` untimed chunks, then `repeats` passes over the next `steps` DISTINCT chunks between barrier + synchronize on both sides, handed to
+    the product's chunk loop the way reconstruct.OccupancyField hands it a growth round: ChunkPipeline.run(list of the shape's chunks), which deals
+    long lists to two HIP streams (ChunkPipeline lanes).  Per-kernel HIP events cannot be read under two lanes (a kernel's interval then contains
+    the moments it shares the chip), so the per-stage times and the roofline come from a SECOND, single-lane pass over the same chunks
+    (`single_lane`), timed the same way.
     Returns the max-over-ranks wall time, this rank's own time, repeats, per-stage HIP-event means (ms) and the last occupancy."""
     import bench_workloads as workloads
     from ppsurf_amd import sharding
@@ -189,40 +193,56 @@ def chunk_loop(work, steps, warmup, rank, world, dist, red_dev, min_timed_s=MIN_
     torch.cuda.synchronize()
     est = (time.perf_counter() - tw) / max(warmup, 1)              # s per chunk, first-call overheads included: an over-estimate
     timed = work[warmup:warmup + steps]
+    groups = []                                                   # consecutive chunks of one shape: one run() call each
+    for pipe, c in timed:
+        if groups and groups[-1][0] is pipe:
+            groups[-1][1].append(c)
+        else:
+            groups.append((pipe, [c]))
     repeats = 1
     if warmup > 0 and min_timed_s > 0:
-        # one more untimed pass over a few timed chunks gives a steady-state estimate
-        probe = timed[:min(len(timed), 4)]
+        # one more untimed pass over the timed chunks' first group gives a steady-state estimate (and allocates the second lane's buffers)
+        probe = groups[0]
         torch.cuda.synchronize()
         tw = time.perf_counter()
-        for pipe, c in probe:
-            pipe.run([c])
+        probe[0].run(probe[1])
         torch.cuda.synchronize()
-        est = (time.perf_counter() - tw) / len(probe)
+        est = (time.perf_counter() - tw) / len(probe[1])
+        for pipe, cs in groups[1:]:
+            pipe.run(cs[:min(len(cs), 4)])
         repeats = max(1, int(math.ceil(min_timed_s / (est * steps))))
     repeats = int(round(sharding.max_over_ranks(float(repeats), red_dev)))
-    ev = [workloads.HipEvents(6) for _ in range(steps * repeats)]
     pacer = HostGcPacer().__enter__()                             # as the predict loop of ppsurf_amd.runner decodes the chunks of a shape
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    i = 0
     for _ in range(repeats):
-        for pipe, c in timed:                                     # `steps` distinct chunks of Q_CHUNK queries, `repeats` times
-            res = pipe.run([c], want_occ=True, stage_events=[ev[i].arr])
+        for pipe, cs in groups:                                   # `steps` distinct chunks of Q_CHUNK queries, `repeats` times
+            res = pipe.run(cs, want_occ=True)
             pacer.tick()
-            i += 1
     torch.cuda.synchronize()
     mine = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
     dt = sharding.max_over_ranks(time.perf_counter() - t0, red_dev)
-    pacer.close()
     occ = res[-1][1]
     assert bool(torch.isfinite(occ).all())
+    lanes = max(min(pipe.lanes if pipe.lanes is not None else (2 if len(cs) >= pipe.LANE_MIN_CHUNKS else 1), len(cs)) for pipe, cs in groups)
+    # ---- single-lane pass with HIP events around every kernel inside the product call: stage times, roofline -----------------------------------
+    n_ev = min(len(timed), 100)
+    ev = [workloads.HipEvents(6) for _ in range(n_ev)]
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i, (pipe, c) in enumerate(timed[:n_ev]):
+        pipe.run([c], want_occ=True, stage_events=[ev[i].arr])
+        pacer.tick()
+    torch.cuda.synchronize()
+    single = (time.perf_counter() - t1) / n_ev
+    pacer.close()
     stage_ms = {name: float(np.mean([e.elapsed_ms(j, j + 1) for e in ev])) for j, name in enumerate(STAGES)}
-    return {'dt': dt, 'mine': mine, 'repeats': repeats, 'stage_ms': stage_ms, 'occ': occ, 'chunks': steps * repeats}
+    return {'dt': dt, 'mine': mine, 'repeats': repeats, 'stage_ms': stage_ms, 'occ': occ, 'chunks': steps * repeats, 'lanes': lanes,
+            'single_lane_ms_per_step': single * 1e3, 'single_lane_steps': n_ev}
 
 
 def pmc_traffic(dtype):
@@ -281,7 +301,11 @@ def dtype_stats(dtype, r, world):
     return {'value': value, 'unit': 'queries/s', 'ms_per_step': ms_step, 'repeats': r['repeats'], 'timed_s': r['dt'], 'stage_ms': sm,
             'stage_mfma_frac': {n: STAGE_ALG_FLOP_PER_QUERY[n] * Q_CHUNK / (sm[n] * 1e-3) / 1e12 / peak for n in STAGES},      # algorithmic (8d)
             'stage_mfma_frac_executed': {n: mult * STAGE_EXEC_MFMA_PER_QUERY[n] * 2048.0 * Q_CHUNK / (sm[n] * 1e-3) / 1e12 / peak for n in STAGES},
-            'spatial_ms': ms_step - sum(sm.values()),
+            'lanes': r.get('lanes', 1),
+            # the same chunks one at a time on ONE stream with HIP events around every kernel: what stage_ms / roofline / spatial_ms describe
+            'single_lane': {'ms_per_step': r['single_lane_ms_per_step'], 'value': world * Q_CHUNK / (r['single_lane_ms_per_step'] * 1e-3),
+                            'steps': r['single_lane_steps']},
+            'spatial_ms': r['single_lane_ms_per_step'] - sum(sm.values()),
             'whole_path_algorithmic_tflops': ALG_MFLOP_PER_QUERY * 1e6 * value / world / 1e12,
             'whole_path_algorithmic_frac': ALG_MFLOP_PER_QUERY * 1e6 * value / world / 1e12 / peak,
             'whole_path_executed_mfma_frac': mult * sum(STAGE_EXEC_MFMA_PER_QUERY.values()) * 2048.0 * value / world / 1e12 / peak}
@@ -373,6 +397,10 @@ def main():
                        'parallelism': 'query-block sharding x{}'.format(world), 'weights': 'formula-filled (no checkpoint offline)',
                        'entry': 'ChunkPipeline.run -> pps_knn_blocked_f32, pps_patch_normalize_f32, pps_decode_fwd_events_f32'},
             'roofline': roofline_block(args.dtype, r['stage_ms']),
+            'lanes': st['lanes'], 'single_lane': st['single_lane'],
+            'lanes_note': 'value / ms_per_step: the product chunk loop (ChunkPipeline.run on the chunk list of a shape; lists of >= 4 chunks are dealt to 2 HIP '
+                          'streams).  stage_ms, roofline, spatial_ms: a separate single-stream pass over the same chunks (single_lane), where a HIP-event '
+                          'interval is one kernel',
             'stage_ms': st['stage_ms'], 'stage_mfma_frac': st['stage_mfma_frac'], 'stage_mfma_frac_executed': st['stage_mfma_frac_executed'], 'spatial_ms': st['spatial_ms'],
             'whole_path_algorithmic_tflops': st['whole_path_algorithmic_tflops'], 'whole_path_algorithmic_frac': st['whole_path_algorithmic_frac'],
             'whole_path_executed_mfma_frac': st['whole_path_executed_mfma_frac'],

@@ -229,7 +229,9 @@ __device__ __forceinline__ void join_f16(const HiLo& x, f32x4& y0, f32x4& y1) {
 // the bias -- a layer whose input is the concatenation of two tensors is evaluated half by half.
 // `hook(ob, kb)` is called after the six MFMAs of every k-step have been issued: the place to issue ONE piece of the next weight chunk's copy
 // (see stream_step_spread in pps_decode.hip) -- the wave's own MFMAs are queued in the matrix pipe while the memory pipeline accepts the piece.
-template <int KB, int NOB, int ACT, bool FENCE = true, bool INIT = false, class Sink, class Hook>
+// NP: f16 products per fp32 product -- 3 (hi.hi + hi.lo + lo.hi, the product's arithmetic), 2 (the weight's low part dropped) or 1 (plain f16):
+// the reduced forms exist for ONE measured experiment on fc_query (tools/fcq_products.md); nothing in the product instantiates them.
+template <int KB, int NOB, int ACT, bool FENCE = true, bool INIT = false, int NP = 3, class Sink, class Hook>
 __device__ __forceinline__ void dense_blocks_f16x3_hook(const HiLo (&in)[KB], const half8* __restrict__ w, const f32x4* __restrict__ bias, int lane,
                                                         Sink&& sink, Hook&& hook, const f32x4* init = nullptr) {
     static_assert(NOB % 2 == 0, "output blocks are processed in pairs");
@@ -250,14 +252,18 @@ __device__ __forceinline__ void dense_blocks_f16x3_hook(const HiLo (&in)[KB], co
             }
             m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, in[kb].hi, m0, 0, 0, 0);
             m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, in[kb].hi, m1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, in[kb].lo, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, in[kb].lo, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, in[kb].hi, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, in[kb].hi, c1, 0, 0, 0);
+            if (NP >= 2) {
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, in[kb].lo, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, in[kb].lo, c1, 0, 0, 0);
+            }
+            if (NP >= 3) {
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, in[kb].hi, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, in[kb].hi, c1, 0, 0, 0);
+            }
             hook(ob, kb);
             if (FENCE) {
-                __builtin_amdgcn_sched_group_barrier(PPS_SG_DSREAD, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(PPS_SG_MFMA, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(PPS_SG_DSREAD, NP >= 3 ? 4 : 2, 0);
+                __builtin_amdgcn_sched_group_barrier(PPS_SG_MFMA, 2 * NP, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

@@ -339,9 +339,13 @@ __global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float
         }
         __builtin_amdgcn_s_setprio(PPS_PRIO);
         // the 4 (8-wave workgroup) pieces of the next chunk's copy go out after k-steps 0, 2, 4, 6 of the first output-block pair
-#define IH_STEP(GNEXT, IN, BIAS, ACTV, SINK)                                                                                          \
+#ifndef PPS_FCQ_PRODUCTS
+#define PPS_FCQ_PRODUCTS 3      // f16 products per fp32 product in fc_query (2, 1: experiment builds only, python -m ppsurf_amd.build --variant)
+#endif
+#define IH_STEP(GNEXT, IN, BIAS, ACTV, SINK) IH_STEP_NP(GNEXT, IN, BIAS, ACTV, SINK, 3)
+#define IH_STEP_NP(GNEXT, IN, BIAS, ACTV, SINK, NPR)                                                                                  \
         stream_step_spread<IH_CH4, IH_NT>(GNEXT, cur, nxt, [&](const f32x4* w, auto&& piece) {                                         \
-            dense_blocks_f16x3_hook<8, IH_OB, ACTV>(IN, (const half8*)w, BIAS, lane, SINK,                                             \
+            dense_blocks_f16x3_hook<8, IH_OB, ACTV, true, false, NPR>(IN, (const half8*)w, BIAS, lane, SINK,                           \
                                                     [&](int ob, int kb) { if (ob == 0 && (kb & 1) == 0) piece(kb >> 1); if (IH_CH4 / IH_NT > 4 && ob == 0 && (kb & 1)) piece(4 + (kb >> 1)); }); })
 #pragma unroll
         for (int c = 0; c < 16 / IH_OB; ++c)                           // fc2: output blocks IH_OB c .. = k-blocks IH_OB/2 c .. of fc3
@@ -352,9 +356,10 @@ __global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float
         f32x4 b[4];
 #pragma unroll
         for (int c = 0; c < 4 / IH_OB; ++c)                            // fc_query: 64 heads
-            IH_STEP(wg + ((c + 32 / IH_OB + 1) % IH_NCH) * IH_CH4, x, bias4 + 128 + 4 * IH_OB * c, 0,
-                    ([&](int p, const f32x4& o0, const f32x4& o1) { b[IH_OB * c + 2 * p] = o0; b[IH_OB * c + 2 * p + 1] = o1; }));
+            IH_STEP_NP(wg + ((c + 32 / IH_OB + 1) % IH_NCH) * IH_CH4, x, bias4 + 128 + 4 * IH_OB * c, 0,
+                       ([&](int p, const f32x4& o0, const f32x4& o1) { b[IH_OB * c + 2 * p] = o0; b[IH_OB * c + 2 * p + 1] = o1; }), PPS_FCQ_PRODUCTS);
 #undef IH_STEP
+#undef IH_STEP_NP
         __builtin_amdgcn_s_setprio(0);
         // ---- softmax over the 64 neighbours (4 waves x 16 rows) for each of the 64 heads: as in interp_pool_kernel -------------
         float e[16];
@@ -1502,6 +1507,24 @@ int pps_pointnet_f16x3(const float* patches, int64_t q, int p, const float* cons
     if (rc != PPS_OK) return rc;
     static int once = set_lds(pointnet_stn_fc_h_kernel, PB_LDS_BYTES);
     (void)once;
+    // The per-query matrix M (16 KiB per query) crosses memory between these two kernels.  `sub` > 0: the pair runs sub-chunk by sub-chunk
+    // (M of a sub-chunk = sub x 16 KiB, written and read back to back; with `reuse` every sub-chunk uses the SAME scratch addresses) --
+    // the measured answer to "does a cache-resident M help" (tools/time_pn_subchunks.py).  Results are bit-identical:
+    // both kernels treat queries independently.
+    static const int64_t sub = getenv("PPS_PN_SUB") ? atoll(getenv("PPS_PN_SUB")) : 0;
+    static const bool reuse = getenv("PPS_PN_SUB_REUSE") != nullptr;
+    if (sub > 0 && sub < q) {
+        for (int64_t off = 0; off < q && rc == PPS_OK; off += sub) {
+            const int64_t n = q - off < sub ? q - off : sub;
+            float* t2 = reuse ? trans2 : trans2 + off * 4096;
+            hipLaunchKernelGGL(pointnet_stn_fc_h_kernel, dim3(grid_for((n + NW * 16 - 1) / (NW * 16))), dim3(NT), PB_LDS_BYTES, st, g + off * 256, n,
+                               (const f32x4*)w16[1], weights[3], (half8*)t2, range);
+            rc = launch_feat_rows<true>(patches + off * p * 3, t2, n, p, weights[4], w16[2], weights[5], xbar + off * 128, range, stream);
+        }
+        if (events && events[1]) hipEventRecord((hipEvent_t)events[1], st);
+        if (events && events[2]) hipEventRecord((hipEvent_t)events[2], st);
+        return rc;
+    }
     hipLaunchKernelGGL(pointnet_stn_fc_h_kernel, dim3(grid_for((q + NW * 16 - 1) / (NW * 16))), dim3(NT), PB_LDS_BYTES, st, g, q,
                        (const f32x4*)w16[1], weights[3], (half8*)trans2, range);
     if (events && events[1]) hipEventRecord((hipEvent_t)events[1], st);

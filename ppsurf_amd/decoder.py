@@ -223,10 +223,11 @@ class DecoderPlan:
                                                     self.w['g_b'].data_ptr(), out.data_ptr(), st), 'pps_rows_dense256_f32')
         return out
 
-    def decode(self, table, pts, query, idx, patches, want_occ=True, stage_events=None):
+    def decode(self, table, pts, query, idx, patches, want_occ=True, stage_events=None, lane=0):
         """table G [N,256]; pts [N,3]; query [Q,3]; idx int64 [Q,k]; patches [Q,P,3] -> (logits [Q,2], occ [Q] | None): the whole
         chunk in one C call (pps_decode_fwd_f32).  stage_events: optional ctypes array of 6 hipEvent_t handles recorded around
-        the five kernels of that same call (pps_decode_fwd_events_f32; bench.py)."""
+        the five kernels of that same call (pps_decode_fwd_events_f32; bench.py).  lane: which scratch workspace the call uses -- calls that may
+        run concurrently on different streams (ChunkPipeline lanes) must not share one."""
         L = _lib.lib()
         q, k, p = query.shape[0], idx.shape[1], patches.shape[1]
         for t in (table, pts, query, idx, patches):
@@ -234,7 +235,7 @@ class DecoderPlan:
         st = torch.cuda.current_stream(self.device).cuda_stream
         logits = torch.empty((q, 2), dtype=torch.float32, device=self.device)
         occ = torch.empty((q,), dtype=torch.float32, device=self.device) if want_occ else None
-        ws = self.scratch('decode_ws', (L.pps_decode_ws_bytes(q) // 4,))
+        ws = self.scratch('decode_ws' if lane == 0 else 'decode_ws{}'.format(lane), (L.pps_decode_ws_bytes(q) // 4,))
         if getattr(self, '_wptrs', None) is None:
             self._wptrs = (ctypes.c_void_p * 10)(*[self.w[n].data_ptr() for n in ('ip_w', 'ip_b', 'pa_w', 'pa_b', 'pb_w', 'pb_b', 'pc_w',
                                                                                   'pc_b', 'tl_w', 'tl_b')])
@@ -251,30 +252,53 @@ class DecoderPlan:
     def range_fallbacks(self):
         """Number of chunks the split-precision path handed to the fp32 kernels so far because an activation left the f16 range (|x| > 65504);
         always 0 for dtype 'f32'.  Reads one device word (synchronises)."""
-        ws = self._scratch.get('decode_ws')
-        return 0 if ws is None or self.w16 is None else int(ws[:16].view(torch.int32)[1])
+        if self.w16 is None:
+            return 0
+        return sum(int(ws[:16].view(torch.int32)[1]) for name, ws in self._scratch.items() if name.startswith('decode_ws'))
 
 
 class ChunkPipeline:
-    """Decodes a sequence of query chunks of ONE shape with the spatial queries of chunk i+1 (kNN + patch gather: fp32 VALU,
-    L2-resident) running on a side HIP stream underneath the MFMA-bound decoder kernels of chunk i.  Double-buffered
-    neighbour tables / patches; events order the two streams.  replaces the chunk loops of source/poco_utils.py:218-223,146-153."""
+    """Decodes a sequence of query chunks of ONE shape; replaces the chunk loops of source/poco_utils.py:218-223,146-153.
 
-    def __init__(self, plan: DecoderPlan, table, pts, raw, k: int, p: int, same_cloud: bool, max_chunk: int, overlap: bool = False):
+    lanes: consecutive chunks of a run() call are dealt to `lanes` HIP streams, each with its own neighbour tables, patches and decoder
+    workspace.  A chunk's kernels are persistent grids that drain unevenly (the last tiles of the interpolation kernel leave most CUs idle, and
+    the store-bound PointNet kernels leave the matrix pipe idle); with two lanes the next chunk's kernels fill those gaps: +5 % on a long chunk
+    list (tools/time_chunk_overlap.py, profiles/NOTES_r5.md).  Results do not depend on the lane (chunks are independent, every lane runs the same
+    kernels on its own buffers).  Default `lanes=None`: 2 for run() calls of at least LANE_MIN_CHUNKS chunks, else 1 -- a short list has nothing
+    to overlap with and the second lane would only cost its scratch.
+    overlap (single lane only): the spatial queries of chunk i+1 (kNN + patch gather: fp32 VALU) on a side stream underneath the decoder kernels of
+    chunk i; double-buffered tables, events order the two streams."""
+
+    LANE_MIN_CHUNKS = 4
+
+    def __init__(self, plan: DecoderPlan, table, pts, raw, k: int, p: int, same_cloud: bool, max_chunk: int, overlap: bool = False, lanes=None):
         from . import ops
+        import os
         self.ops, self.plan, self.table, self.pts, self.raw = ops, plan, table, pts, raw
         self.k, self.p, self.same_cloud, self.overlap = int(k), int(p), bool(same_cloud), bool(overlap)
-        dev = plan.device
-        self.idx = [torch.empty((max_chunk, self.k), dtype=torch.int64, device=dev) for _ in range(2)]
-        self.pidx = None if (same_cloud and p <= k) else [torch.empty((max_chunk, self.p), dtype=torch.int64, device=dev) for _ in range(2)]
-        self.patches = [torch.empty((max_chunk, self.p, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+        env = os.environ.get('PPS_CHUNK_LANES')
+        self.lanes = int(env) if env else lanes                   # None: decided per run() call
+        self.max_chunk = int(max_chunk)
+        self.idx, self.patches = [], []
+        self.pidx = None if (same_cloud and self.p <= self.k) else []
+        self._grow_buffers(2)
         # the cloud is searched thousands of times per shape: arrange it once for the block-culling search
         self.blocks = self.ops.KnnBlocks(pts)
         self.raw_blocks = None if self.pidx is None else self.ops.KnnBlocks(raw)
+        dev = plan.device
         self.side = torch.cuda.Stream(device=dev) if overlap else None
+        self.lane_streams = []
         self.ready = [torch.cuda.Event() for _ in range(2)]
         self.free = [torch.cuda.Event() for _ in range(2)]
         self.n = 0
+
+    def _grow_buffers(self, count):
+        dev = self.plan.device
+        while len(self.idx) < count:
+            self.idx.append(torch.empty((self.max_chunk, self.k), dtype=torch.int64, device=dev))
+            self.patches.append(torch.empty((self.max_chunk, self.p, 3), dtype=torch.float32, device=dev))
+            if self.pidx is not None:
+                self.pidx.append(torch.empty((self.max_chunk, self.p), dtype=torch.int64, device=dev))
 
     def _spatial(self, q, b):
         m = q.shape[0]
@@ -293,8 +317,40 @@ class ChunkPipeline:
                 self.raw_blocks.query(q, self.p, out=src)
         self.ops.patch_normalize(self.raw, q, src, self.p, out=self.patches[b][:m])
 
+    def _run_lanes(self, chunks, want_occ, lanes):
+        """Chunk i on lane i % lanes: every lane stream waits for the caller's stream once, runs its chunks in order on its own buffers, and the
+        caller's stream waits for every lane at the end.  The result tensors are allocated here, on the caller's stream."""
+        dev = self.plan.device
+        main = torch.cuda.current_stream(dev)
+        while len(self.lane_streams) < lanes:
+            self.lane_streams.append(torch.cuda.Stream(device=dev))
+        self._grow_buffers(max(lanes, 2))
+        out = [None] * len(chunks)
+        for ln in range(lanes):
+            st = self.lane_streams[ln]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                for i in range(ln, len(chunks), lanes):
+                    q = chunks[i]
+                    m = q.shape[0]
+                    self._spatial(q, ln)
+                    out[i] = self.plan.decode(self.table, self.pts, q, self.idx[ln][:m], self.patches[ln][:m], want_occ=want_occ, lane=ln)
+        for ln in range(lanes):
+            main.wait_stream(self.lane_streams[ln])
+        for lg, oc in out:                                      # allocated on a lane stream, consumed on the caller's: tell the allocator
+            lg.record_stream(main)
+            if oc is not None:
+                oc.record_stream(main)
+        return out
+
     def run(self, chunks, want_occ=True, stage_events=None):
-        """chunks: list of contiguous float32 [q_i,3] device tensors -> list of (logits, occ)."""
+        """chunks: list of contiguous float32 [q_i,3] device tensors -> list of (logits, occ).  stage_events (per-kernel HIP events, bench.py)
+        forces a single lane: under two lanes a kernel's event time includes the moments it shares the chip."""
+        lanes = self.lanes if self.lanes is not None else (2 if len(chunks) >= self.LANE_MIN_CHUNKS else 1)
+        if stage_events is None and lanes > 1 and len(chunks) > 1 and self.side is None:
+            res = self._run_lanes(chunks, want_occ, min(lanes, len(chunks)))
+            self.n += len(chunks)
+            return res
         main = torch.cuda.current_stream(self.plan.device)
         out = []
         for i, q in enumerate(chunks):

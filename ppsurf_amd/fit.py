@@ -155,6 +155,10 @@ class HostGcPacer:
     `every` steps (sub-millisecond), the full collection happens when the loop ends (`close()` / leaving the `with`).
     Opt out with PPS_HOST_GC=auto."""
 
+    FULL_EVERY = 16                   # every FULL_EVERY young collections (1024 steps at the default) one full collection: objects promoted to the
+                                      # oldest generation (eager steps: autograd closures, tracebacks, loader dicts holding device tensors) would
+                                      # otherwise pile up until the epoch ends; ~150 ms per 1024 steps amortised (ADVICE r4)
+
     def __init__(self, every=64):
         self.every, self.n, self.active = int(every), 0, False
 
@@ -171,7 +175,7 @@ class HostGcPacer:
         self.n += 1
         if self.active and self.n % self.every == 0:
             import gc
-            gc.collect(1)
+            gc.collect(2 if (self.n // self.every) % self.FULL_EVERY == 0 else 1)
 
     def close(self):
         if self.active:
@@ -363,6 +367,8 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
                     break
             flush(pending)
             pending = None
+        buckets.check()                                        # world > 1: the set of parameters with gradients never changed (also for epochs shorter than
+                                                               # GradBuckets.CHECK_EVERY steps, and before the checkpoint below is written)
         stepper.touch(model)                                   # replays move no version counters: the eval() plans below are keyed on them
         if scheduler is not None:
             scheduler.step()

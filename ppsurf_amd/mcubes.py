@@ -379,7 +379,14 @@ def clean_mesh_torch(verts, faces, min_component_faces=6, digits=8, welded=False
                     keep[tf[drop]] = False
                     faces = faces[keep]
     elif welded:
-        skip = True                      # model space after refinement: see the docstring (the first clean-up has merged what could coincide)
+        # model space after refinement: see the docstring (the first clean-up has merged what could coincide).  The argument needs every refined
+        # vertex to stay off the end points of its edge; a vertex whose end-point values were NaN is left unrefined, and float32 midpoints can round
+        # onto an end point for tiny steps / many iterations.  Cheap guard: if any face has two corners at one rounded position, the
+        # general path below merges and drops as the reference's second clean-up does (source/base/mesh.py:7-20).
+        pos = torch.round(verts * scale)
+        p0, p1, p2 = pos[faces[:, 0]], pos[faces[:, 1]], pos[faces[:, 2]]
+        degenerate = ((p0 == p1).all(dim=1) | (p1 == p2).all(dim=1) | (p0 == p2).all(dim=1)).any()
+        skip = not bool(degenerate)
     if not skip:
         _, inv = torch.unique(torch.round(verts * scale), dim=0, return_inverse=True)
         first = torch.full((int(inv.max()) + 1,), verts.shape[0], dtype=torch.int64, device=dev)

@@ -325,7 +325,7 @@ class GradBuckets:
             # is issued on EVERY step, replayed or not, so that a rank whose capture failed (eager) and a rank that replays still run the same
             # sequence of collectives.  Only the first step reads the mask back (one host synchronisation per run); later steps
             # compare it with the first step's mask on the device and the flag is read every CHECK_EVERY steps.
-            mask = torch.tensor([1 if id(p) in touched else 0 for p in self.params], dtype=torch.int32, device=self.flat[0].device)
+            mask = self._touched_mask(touched)
             self.dist.all_reduce(mask, op=self.dist.ReduceOp.MAX)
             if self._static is None:
                 self._static = [bool(k) for k in (mask.cpu().numpy() > 0)]
@@ -348,6 +348,34 @@ class GradBuckets:
                 p.grad = None
 
     CHECK_EVERY = 64
+
+    def _touched_mask(self, touched):
+        """Per-parameter int32 "got a gradient" mask on the device WITHOUT a blocking upload per step (torch.tensor(list, device=cuda) is a
+        pageable copy followed by a stream synchronise, so every step waited for the replayed backward and all bucket collectives before the host
+        could queue the optimizer).  The local set is the same step after step (fixed at capture for a replayed step): its device image is cached
+        and only re-uploaded -- from a pinned staging buffer, asynchronously -- when the set differs from the previous step's.  The collective
+        reduces a device-to-device copy of it in place."""
+        key = tuple(id(p) in touched for p in self.params)
+        dev = self.flat[0].device
+        if getattr(self, '_mask_key', None) != key:
+            host = torch.tensor([1 if k else 0 for k in key], dtype=torch.int32)
+            if dev.type == 'cuda':
+                if getattr(self, '_mask_pin', None) is None:
+                    self._mask_pin = torch.empty(len(self.params), dtype=torch.int32).pin_memory()
+                    self._mask_src = torch.empty(len(self.params), dtype=torch.int32, device=dev)
+                    self._mask_work = torch.empty_like(self._mask_src)
+                    self._mask_uploaded = torch.cuda.Event()
+                else:
+                    self._mask_uploaded.synchronize()        # the previous upload has left the staging buffer (only when the set changed again)
+                self._mask_pin.copy_(host)
+                self._mask_src.copy_(self._mask_pin, non_blocking=True)
+                self._mask_uploaded.record()
+            else:
+                self._mask_src = host.to(dev)
+                self._mask_work = torch.empty_like(self._mask_src)
+            self._mask_key = key
+        self._mask_work.copy_(self._mask_src)
+        return self._mask_work
 
     def check(self):
         """Raises if the set of parameters with a gradient (on any rank) ever differed from the first step's (one host synchronisation)."""

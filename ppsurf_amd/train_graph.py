@@ -60,7 +60,9 @@ _shadow_live = [False]
 _shadow_ver = {}             # id(parameter) -> parameter._version when its image was taken (an optimizer step in between makes the image stale)
 
 
-_cast_tables = {}            # (device, dtype) -> (key, device table of pieces, number of pieces)
+_cast_tables = {}            # (device, dtype, pointers of every (parameter, image) pair) -> (key, device table of pieces, number of pieces).  Entries
+                             # are never replaced or dropped: a pps_cast_pieces launch recorded into a HIP graph reads its table by ADDRESS on every
+                             # replay, so a table must outlive every graph that may hold it (80 KB per parameter set)
 CAST_PIECE = 4096
 
 
@@ -77,14 +79,14 @@ def _cast_all(params, dtype):
     import numpy as np
     dev = params[0].device
     key = tuple((p.data_ptr(), _shadow[id(p)].data_ptr(), p.numel()) for p in params)
-    cached = _cast_tables.get((dev, dtype))
-    if cached is None or cached[0] != key:
+    cached = _cast_tables.get((dev, dtype, key))
+    if cached is None:
         if torch.cuda.is_current_stream_capturing():
             return False
         assert _lib.lib().pps_cast_piece_bytes() == 24
         rows = [(sp + 4 * off, dp + 2 * off, min(CAST_PIECE, n - off)) for sp, dp, n in key for off in range(0, n, CAST_PIECE)]
         cached = (key, torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev), len(rows))
-        _cast_tables[(dev, dtype)] = cached
+        _cast_tables[(dev, dtype, key)] = cached
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().pps_cast_pieces(cached[1].data_ptr(), cached[2], code, torch.cuda.current_stream(dev).cuda_stream), 'pps_cast_pieces')
     return True

@@ -322,3 +322,28 @@ def test_f16x3_full_chunk_against_fp32_path():
     err = float((a - b).abs().max())
     print('f16x3 vs fp32, 50000 queries, logits |max| {:.1f}: max diff {:.2e}'.format(float(a.abs().max()), err))
     assert torch.isfinite(b).all() and err < 1e-4
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_chunk_lanes_change_nothing(dtype):
+    """ChunkPipeline deals long chunk lists to two HIP streams (lanes), each with its own tables, patches and decoder workspace: the logits and
+    occupancies are bit-identical to the single-stream loop, whatever the lane count and the chunk sizes, and the range-guard counter still counts."""
+    from ppsurf_amd.decoder import ChunkPipeline
+    pl = plan(dtype)
+    cloud = make_cloud(20_000, seed=21)
+    qry = make_band_queries(cloud, 23_000, resolution=129, seed=4)
+    pts, qd = dev(cloud), dev(qry)
+    table = pl.point_table(dev(make_latents(256, cloud.shape[0], seed=6)[0]))
+    cuts = [0, 5000, 9000, 9001, 14000, 19000, 22500, 23000]                  # seven uneven chunks, one of a single query
+    chunks = [qd[a:b].contiguous() for a, b in zip(cuts[:-1], cuts[1:])]
+    ref = ChunkPipeline(pl, table, pts, pts, 64, 50, same_cloud=True, max_chunk=5000, lanes=1).run(chunks)
+    for lanes in (None, 2, 3):
+        pipe = ChunkPipeline(pl, table, pts, pts, 64, 50, same_cloud=True, max_chunk=5000, lanes=lanes)
+        for _ in range(2):                                                    # the second call reuses the lanes' buffers
+            got = pipe.run(chunks)
+            torch.cuda.synchronize()
+            assert len(got) == len(ref)
+            for (lg, oc), (lg0, oc0) in zip(got, ref):
+                assert torch.equal(lg, lg0) and torch.equal(oc, oc0), (dtype, lanes)
+    short = ChunkPipeline(pl, table, pts, pts, 64, 50, same_cloud=True, max_chunk=5000).run(chunks[:3])      # below LANE_MIN_CHUNKS: one lane
+    assert all(torch.equal(a[0], b[0]) for a, b in zip(short, ref[:3]))
