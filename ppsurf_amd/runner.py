@@ -128,6 +128,30 @@ class _Trainer:
     progress_bar_callback = _Bar()
 
 
+def cpu_refusal(sub, argv, accel):
+    """The one seam where this build differs from the reference's surface ("trainer.accelerator=cpu"): the reference's mini
+    flow (configs/ppsurf_mini.yaml, README "--trainer.accelerator cpu", pps.py:27-72) runs its PyTorch modules on the host; here every op of the
+    path is a HIP kernel and a CPU twin inside the product would be a second, unverified implementation.  The message names the command to run
+    instead: the same one on the GPU."""
+    args, skip = [], False
+    for a in argv[1:]:
+        if skip:
+            skip = False
+            continue
+        if a == '--trainer.accelerator':
+            skip = True
+            continue
+        if a.startswith('--trainer.accelerator='):
+            continue
+        args.append(a)
+    cmd = 'python pps.py ' + ' '.join(args + ['--trainer.accelerator', 'gpu', '--trainer.devices', '1'])
+    why = 'trainer.accelerator={}'.format(accel) if accel == 'cpu' else 'no GPU is visible (torch.cuda.is_available() is False)'
+    return ('ppsurf_amd `{}` refused: {}.  This build has no CPU path -- every operator of the occupancy path is a HIP kernel for MI355X (gfx950) '
+            'and the product never falls back to a host implementation (the CPU restatement under oracle/ is test infrastructure only).  '
+            'Run the same configuration on the GPU instead:\n    {}\n(the plumbing-only flow of configs/ppsurf_mini.yaml is covered in that form '
+            'by tests/test_gpu_configs.py::test_config1_*; see INTEGRATION.md, "trainer.accelerator=cpu")'.format(sub, why, cmd))
+
+
 def main(argv=None):
     argv = list(sys.argv if argv is None else argv)
     sub, cfg, ckpt = parse(argv)
@@ -139,7 +163,7 @@ def main(argv=None):
     cfg = _link_arguments(cfg)
     accel = str(cfg.get('trainer', {}).get('accelerator', 'gpu'))
     if accel == 'cpu' or not torch.cuda.is_available():
-        raise RuntimeError('ppsurf_amd runs on an MI355X (gfx950) only: there is no CPU path (trainer.accelerator={})'.format(accel))
+        raise RuntimeError(cpu_refusal(sub, argv, accel))
     # one process per GPU; more ranks than GPUs (2-rank rehearsals on a 1-GPU box) wrap around
     device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)) % torch.cuda.device_count())
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))

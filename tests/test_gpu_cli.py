@@ -68,7 +68,7 @@ def test_rec_rewrite_and_cpu_is_refused(tmp_path):
     assert rec[1] == 'predict' and 'configs/ppsurf_50nn.yaml' in rec and rec[-2:] == ['--model.init_args.rec_batch_size', '25000']
     with pytest.raises(ValueError):
         runner.handle_rec_subcommand(['pps.py', 'rec', str(tmp_path / 'missing.ply'), 'out'])
-    with pytest.raises(RuntimeError, match='no CPU path'):
+    with pytest.raises(RuntimeError, match='no CPU path.*\n.*--trainer.accelerator gpu'):
         runner.main(['pps.py', 'predict'] + _configs(tmp_path, 'x.txt') + ['--trainer.accelerator', 'cpu'])
 
 

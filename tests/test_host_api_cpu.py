@@ -193,3 +193,19 @@ def test_readers_on_the_reference_dataset_files():
         assert float(it["pts_ms"].abs().max()) < 1.0                       # dataset clouds are already normalised (noisy scans overshoot 0.5)
         assert tuple(it['pts_query_ms'].shape) == (2000, 3) and tuple(it['imp_surf_dist_ms'].shape) == (2000,)
         assert it['pc_file_in'].endswith(names[i] + '.xyz.ply')
+
+
+def test_accelerator_cpu_is_refused_with_the_replacement_command():
+    """BASELINE config 1 as written (`--trainer.accelerator cpu`, configs/ppsurf_mini.yaml + README mini flow, pps.py:27-72): this build has no host
+    implementation of the path, and says so BEFORE touching model or data -- naming the command to run instead."""
+    from ppsurf_amd import runner
+    cfgs = [os.path.join(GOLDEN, 'configs', n) for n in ('poco.yaml', 'ppsurf.yaml', 'ppsurf_mini.yaml')]
+    argv = ['pps.py', 'predict', '-c', cfgs[0], '-c', cfgs[1], '-c', cfgs[2], '--model.init_args.gen_resolution_global', '33',
+            '--trainer.accelerator', 'cpu', '--trainer.logger', 'False']
+    with pytest.raises(RuntimeError) as exc:
+        runner.main(argv)
+    msg = str(exc.value)
+    assert 'no CPU path' in msg and 'trainer.accelerator=cpu' in msg
+    want = 'python pps.py predict -c {} -c {} -c {} --model.init_args.gen_resolution_global 33 --trainer.logger False --trainer.accelerator gpu --trainer.devices 1'.format(*cfgs)
+    assert want in msg, msg                                   # the same command, on the GPU
+    assert 'oracle' in msg and 'INTEGRATION.md' in msg
