@@ -22,7 +22,7 @@
 //                     MFMA rows is free, so it is chosen for 32-byte stores); per-lane statistics in registers, reduced in a fixed order
 //   rows_dx_kernel    same shape with the roles of the channel axes swapped, W^T fragments in LDS
 //   rows_dw_kernel    contraction over the ROWS: tiles of 32 rows of G and act(x) are written row-major into LDS and read back as MFMA
-//                     operands with ds_read_b64_tr_b16 (the LDS transpose read of gfx950, tools/ubench/tr_probe.hip); a workgroup keeps
+//                     operands with ds_read_b64_tr_b16 (the LDS transpose read of gfx950, lane map measured by the round-2 probe ubench/tr_probe.hip, git history); a workgroup keeps
 //                     the whole [cout, cin] product in registers over its slab of rows; slab partials are summed in a fixed order
 // Everything is deterministic (no floating-point atomics).
 #include <hip/hip_runtime.h>

@@ -14,7 +14,7 @@
     (`GraphedStep`); the batch is copied into static buffers; the id tables, their flat forms and CSRs are inputs built by the loader
     (train_graph.table_extras), so the graph holds no sort (replays with the CSR radix sort inside faulted intermittently at the full
     config-3 batch size).  Replay is bit-identical to the eager step (tools/fit_graph_check.py) and ran 1500 consecutive full-size steps
-    clean (tools/fit_graph_matrix2.py); the eager loop spends ~24 ms of Python per step on ~1400 launches and is host-bound (37-40 ms per
+    clean (round-2 probe fit_graph_matrix2.py, git history before round 5); the eager loop spends ~24 ms of Python per step on ~1400 launches and is host-bound (37-40 ms per
     step), the replayed loop is GPU-bound (~30 ms);
   * validation every `check_val_every_n_epoch` epochs in eval() mode -- that is the fused HIP inference path;
   * ModelCheckpoint(save_last) -> models/<name>/version_0/checkpoints/last.ckpt with Lightning's key layout
@@ -105,7 +105,7 @@ class GraphedStep:
                 # The static inputs may only be overwritten once the previous replay has finished READING them.  Stream order should
                 # guarantee that, but with the host several steps ahead the copies were observed to race the tail of the previous
                 # replay (id tables changing under the CSR sort -> out-of-bounds scatter inside rocprim's onesweep kernel,
-                # tools/fit_graph_matrix2.py); waiting on an event recorded behind the replay costs nothing -- the id-table kernels
+                # round-2 probe fit_graph_matrix2.py, git history); waiting on an event recorded behind the replay costs nothing -- the id-table kernels
                 # of this step are already queued behind the previous replay when the host gets here.
                 if self._done is not None:
                     self._done.synchronize()

@@ -317,7 +317,7 @@ class PocoModel(_Base):
         consecutive subsets -- across the boundaries of the coverage rounds -- are drawn exactly like the reference draws them one
         after the other and then encoded as ONE batch (batched sampling / kNN tables / FKAConv geometry and aggregation kernels,
         MFMA GEMMs with the folded BatchNorm over the rows of all subsets at once): a 10k-point pass alone cannot fill 256 CUs
-        (tools/time_latent_batch.py: 106 / 93 / 89 / 91 ms per 100k-point cloud at 10 / 20 / 25 / 100 subsets per batch).
+        (round-3 probe time_latent_batch.py, git history: 106 / 93 / 89 / 91 ms per 100k-point cloud at 10 / 20 / 25 / 100 subsets per batch).
 
         With torch.distributed initialised and `shard_queries` set, the subsets of a batch are dealt round-robin to the ranks
         (the selection comes from a generator seeded identically on every rank) and the partial sums / counts are all-reduced

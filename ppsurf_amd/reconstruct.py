@@ -50,7 +50,7 @@ class OccupancyField:
         self.k = min(network.projection.k, self.pts.shape[0])
         # `num_pts` (rec_batch_size) exists in the reference to bound memory; queries are independent, so decoding CHUNK_MULT of them per
         # launch sequence gives identical results with fewer, better filled launches (16-query tiles over 2048 wave slots: 12.33 -> 12.03 ms
-        # per 50000 queries at 4x, tools/subchunk_probe.py; 3.3 GB of scratch instead of 0.8 GB)
+        # per 50000 queries at 4x, round-3 probe subchunk_probe.py (git history); 3.3 GB of scratch instead of 0.8 GB)
         self.chunk = int(num_pts) * CHUNK_MULT
         self.n_queries = 0
         self.ppsurf = hasattr(network, 'point_net')

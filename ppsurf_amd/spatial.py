@@ -177,7 +177,7 @@ def sampling_quantized(pts_batch, ratio=None, n_support=None, support_points=Non
 
 
 # Levels with at least this many points per cloud are searched with block culling.  Measured on 10 x 10 000-point clouds
-# (tools/time_id_tables.py): arranging levels 0 and 1 costs 0.81 ms of small torch launches and the culling search of their five tables
+# (round-2 probe time_id_tables.py, git history): arranging levels 0 and 1 costs 0.81 ms of small torch launches and the culling search of their five tables
 # 1.00 ms against 1.36 ms for the exhaustive search -- with k = 16 the per-query merge networks, not the distance tests, bound both
 # kernels, so culling only pays for larger clouds.  A 10k-point encoder pass therefore stays on the exhaustive kernel.
 BLOCKED_MIN_POINTS = 16384

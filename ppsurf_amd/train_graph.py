@@ -38,7 +38,7 @@ def _w2d(layer):
 SPLITK_MIN_ROWS = 32768
 SPLITK_SLABS = 64            # row slabs of the split-K weight gradient (64 / 128 / 256 measured within 3 % of each other).  NOT more than 64: with 128
                              # or 256 batches the library's strided-batched bf16 GEMM faults when the step is replayed as a HIP graph (memory
-                             # aperture violation on replay, tools/fit_graph_matrix.py; 32 and 64 replay correctly)
+                             # aperture violation on replay, round-2 probe fit_graph_matrix.py, git history; 32 and 64 replay correctly)
 SPLITK_EXACT = (64, 32, 16, 8, 50, 40, 25, 20, 10, 5, 4)      # slab counts tried in this order: the first that divides the rows into slabs of
 SPLITK_SLAB_ROWS = 1000                                        # at least this many rows (no ragged tail -> no second GEMM + add for it)
 
@@ -46,7 +46,7 @@ SPLITK_SLAB_ROWS = 1000                                        # at least this m
 def splitk_slabs(rows):
     """Slab count of the split-K weight gradient for `rows` rows, or 0 for one plain GEMM.  The encoder's levels (100 000 / 25 000 / 6 250 rows
     per batch of 10) and the 20 000 query rows of the MLP run 3-6x faster split than as ONE library GEMM with a 256 x 256 (or smaller)
-    result, which occupies a handful of CUs (tools/time_dw_small.py: 25 000 x 128 -> 64: 96 us whole, 16 us as 8 slabs)."""
+    result, which occupies a handful of CUs (round-2 probe time_dw_small.py, git history: 25 000 x 128 -> 64: 96 us whole, 16 us as 8 slabs)."""
     for s in SPLITK_EXACT:
         if rows % s == 0 and rows // s >= SPLITK_SLAB_ROWS:
             return s
