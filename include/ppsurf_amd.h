@@ -251,8 +251,12 @@ int pps_decode_fwd_mixed_f32(const float* table, const float* pts, const float* 
 /* ---- Marching Cubes on the device ------------------------------------------------------------------
  * replaces: skimage.measure.marching_cubes(volume, level=mc_value) called at source/poco_utils.py:95-96.
  * vol float64 [nx,ny,nz] (z fastest), NaN = never evaluated: a cube is triangulated when its 8 corners are finite and not all on one side of
- * `level` (inside = value > level).  Tables (host-derived, ppsurf_amd/mcubes.py): tri int8 [256*64, width, 3] cube-edge ids (12 = the extra
- * vertex inside the cube, -1 = none) per (corner pattern * 64 + one asymptotic-decider bit per ambiguous face), ntri uint8 [256*64], amb uint8 [256].
+ * `level` (inside = value > level).  Tables (host-derived, ppsurf_amd/mcubes.py): tri int8 [rows, width, 3] cube-edge ids (12 = the extra
+ * vertex inside the cube, -1 = none), ntri uint8 [rows], amb uint8 [256].  Rows 0 .. 256*64-1: (corner pattern * 64 + one asymptotic-decider bit
+ * per ambiguous face), every loop closed by a disc.  Interior ambiguity (skimage's Lewiner variant resolves it, cases 4, 6, 7, 10, 12, 13 of
+ * Lewiner et al. 2003): tun_index int32 [256*64, 2] = (first, count) into tun_cand int32 [n, 3] = (sign: 1 inside / 0 outside corner groups,
+ * mask: bit 2*axis + diagonal = a plane sweep that decides the pair, alternative row >= 256*64 with a tube between the two loops); the first
+ * candidate whose interior test (test_interior of the paper, general form) succeeds replaces the row.
  * Two calls with two small prefix sums by the caller in between:
  *   pps_mc_count_f64: edge_flags uint8 [3*nx*ny*nz] (zeroed and filled here: 1 = the grid edge (voxel, axis) carries a vertex), block_tris /
  *                     block_centres int32 [pps_mc_cube_blocks] = triangles / centre vertices per block of 256 cubes, block_verts int32
@@ -264,10 +268,12 @@ int pps_decode_fwd_mixed_f32(const float* table, const float* pts, const float* 
 int64_t pps_mc_cube_blocks(int64_t nx, int64_t ny, int64_t nz);
 int64_t pps_mc_edge_blocks(int64_t nx, int64_t ny, int64_t nz);
 int pps_mc_count_f64(const double* vol, int64_t nx, int64_t ny, int64_t nz, double level, const int8_t* tri, int width, const uint8_t* ntri,
-                     const uint8_t* amb, uint8_t* edge_flags, int32_t* block_tris, int32_t* block_centres, int32_t* block_verts, void* stream);
+                     const uint8_t* amb, const int32_t* tun_index, const int32_t* tun_cand, uint8_t* edge_flags, int32_t* block_tris,
+                     int32_t* block_centres, int32_t* block_verts, void* stream);
 int pps_mc_emit_f64(const double* vol, int64_t nx, int64_t ny, int64_t nz, double level, const int8_t* tri, int width, const uint8_t* ntri,
-                    const uint8_t* amb, const uint8_t* edge_flags, const int64_t* tri_offset, const int64_t* centre_offset, const int64_t* vert_offset,
-                    int64_t n_edge_verts, int32_t* vidx, double* verts, int64_t* faces, void* stream);
+                    const uint8_t* amb, const int32_t* tun_index, const int32_t* tun_cand, const uint8_t* edge_flags, const int64_t* tri_offset,
+                    const int64_t* centre_offset, const int64_t* vert_offset, int64_t n_edge_verts, int32_t* vidx, double* verts, int64_t* faces,
+                    void* stream);
 
 /* ---- FKAConv encoder (eval mode), point-major activations, one batch item per call ----------------- */
 

@@ -30,8 +30,8 @@ SIGNATURES = {
     'pps_patch_normalize_f32': (_I, [_P, _P, _P, _I64, _I64, _I, _P, _P]),
     'pps_mc_cube_blocks': (_I64, [_I64, _I64, _I64]),
     'pps_mc_edge_blocks': (_I64, [_I64, _I64, _I64]),
-    'pps_mc_count_f64': (_I, [_P, _I64, _I64, _I64, _c.c_double, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
-    'pps_mc_emit_f64': (_I, [_P, _I64, _I64, _I64, _c.c_double, _P, _I, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    'pps_mc_count_f64': (_I, [_P, _I64, _I64, _I64, _c.c_double, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'pps_mc_emit_f64': (_I, [_P, _I64, _I64, _I64, _c.c_double, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
     'pps_dilate_box_u8': (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _P]),
     'pps_grow_frontier_f64': (_I, [_P, _P, _P, _P, _P, _I64, _P]),
     'pps_grow_band_todo_f64': (_I, [_P, _P, _P, _I64, _P]),

@@ -6,6 +6,11 @@
 //   * the triangle list of a cube comes from a table indexed by (corner pattern, one bit per AMBIGUOUS face); the bit is the asymptotic decider
 //     (sign of the bilinear saddle value of the face, Nielson & Hamann 1991; the face test of Lewiner et al. 2003): the two cubes that share a face read
 //     its four values in the same order and therefore agree -- no cracks;
+//   * [round 5] INTERIOR ambiguity (Chernyaev's / Lewiner's cases 4, 6, 7, 10, 12, 13): rows whose loops may be joined THROUGH the cube carry a list
+//     of candidates (tun_index / tun_cand, derived in ppsurf_amd/mcubes.py): for each, the interior test of Lewiner et al. 2003 (test_interior) in
+//     its general form -- sweep a plane along a cube axis, g(t) = X(t) Y(t) - B(t) D(t) of the plane's four columns, interior maximum of g with
+//     X, Y of the groups' sign and g > 0 -- decides whether the two loops are closed by a TUBE (the candidate's alternative table row) instead of
+//     two discs (sweep_connected below: the same operations in the same order as mcubes.interior_sweep_connected);
 //   * vertices are welded by GRID-EDGE KEY, not by position: edge (voxel o, axis a) <-> key 3 * linear(o) + a; the vertex numbering is the ascending
 //     key order, followed by the (rare) extra vertices inside a cube (table entry 12: a loop that has no chord-free triangulation is closed by a fan
 //     around the mean of its crossing points), in cube order.
@@ -58,7 +63,30 @@ struct CubeInfo {
     double v[8];
 };
 
-__device__ __forceinline__ CubeInfo classify(const double* __restrict__ vol, const McDims& d, int64_t lc, double level, const unsigned char* __restrict__ amb) {
+// one sweep of the interior test: plane orthogonal to axis ax, diagonal pair dg of its four columns; w = sg * (v - level)
+__device__ __forceinline__ bool sweep_connected(const double* v, double level, int sign, int ax, int dg) {
+    const int u = (ax + 1) % 3, w_ = (ax + 2) % 3;
+    const double sg = sign ? 1.0 : -1.0;
+    // columns at (u, v) = (0,0) (1,0) (0,1) (1,1); diagonal pair 0: X = col 0, Y = col 3, B = col 1, D = col 2; pair 1: X = 1, Y = 2, B = 0, D = 3
+    const int cx = dg ? 1 : 0, cy = dg ? 2 : 3, cb = dg ? 0 : 1, cd = dg ? 3 : 2;
+#define MC_COL0(c) ((((c) & 1) << u) | ((((c) >> 1) & 1) << w_))
+#define MC_W(c) (sg * (v[c] - level))
+    const double x0 = MC_W(MC_COL0(cx)), x1 = MC_W(MC_COL0(cx) | (1 << ax)), y0 = MC_W(MC_COL0(cy)), y1 = MC_W(MC_COL0(cy) | (1 << ax));
+    const double b0 = MC_W(MC_COL0(cb)), b1 = MC_W(MC_COL0(cb) | (1 << ax)), d0 = MC_W(MC_COL0(cd)), d1 = MC_W(MC_COL0(cd) | (1 << ax));
+#undef MC_W
+#undef MC_COL0
+    const double dx = x1 - x0, dy = y1 - y0, db = b1 - b0, dd = d1 - d0;
+    const double g2 = dx * dy - db * dd;
+    const double g1 = (y0 * dx + x0 * dy) - (d0 * db + b0 * dd);
+    if (!(g2 < 0.0)) return false;
+    const double t = -g1 / (2.0 * g2);
+    if (!(t > 0.0 && t < 1.0)) return false;
+    const double xt = x0 + dx * t, yt = y0 + dy * t, bt = b0 + db * t, dt = d0 + dd * t;
+    return xt > 0.0 && yt > 0.0 && (xt * yt - bt * dt > 0.0);
+}
+
+__device__ __forceinline__ CubeInfo classify(const double* __restrict__ vol, const McDims& d, int64_t lc, double level, const unsigned char* __restrict__ amb,
+                                             const int* __restrict__ tun_index, const int* __restrict__ tun_cand) {
     CubeInfo ci;
     ci.row = -1;
     ci.pattern = 0;
@@ -89,16 +117,29 @@ __device__ __forceinline__ CubeInfo classify(const double* __restrict__ vol, con
         dec &= am;
     }
     ci.row = ci.pattern * 64 + dec;
+    const int cnt = tun_index[2 * ci.row + 1];
+    if (cnt) {
+        // interior ambiguity: the first candidate pair of loops that one of its sweeps finds connected gets its tube row
+        const int first = tun_index[2 * ci.row];
+        for (int k = 0; k < cnt; ++k) {
+            const int sign = tun_cand[3 * (first + k)], mask = tun_cand[3 * (first + k) + 1];
+            bool hit = false;
+            for (int s = 0; s < 6; ++s)
+                if ((mask >> s) & 1) hit = hit || sweep_connected(ci.v, level, sign, s >> 1, s & 1);
+            if (hit) { ci.row = tun_cand[3 * (first + k) + 2]; break; }
+        }
+    }
     return ci;
 }
 
 // pass 1
 __global__ __launch_bounds__(MC_NT) void mc_count_cubes_kernel(const double* __restrict__ vol, McDims d, double level, const signed char* __restrict__ tri,
                                                                int width, const unsigned char* __restrict__ ntri, const unsigned char* __restrict__ amb,
+                                                               const int* __restrict__ tun_index, const int* __restrict__ tun_cand,
                                                                unsigned char* __restrict__ flags, int* __restrict__ block_tris, int* __restrict__ block_centres) {
     __shared__ int lds[4];
     const int64_t lc = (int64_t)blockIdx.x * MC_NT + threadIdx.x;
-    const CubeInfo ci = classify(vol, d, lc, level, amb);
+    const CubeInfo ci = classify(vol, d, lc, level, amb, tun_index, tun_cand);
     int nt = 0, ncen = 0;
     if (ci.row >= 0) {
         nt = ntri[ci.row];
@@ -167,12 +208,13 @@ __global__ __launch_bounds__(MC_NT) void mc_emit_verts_kernel(const double* __re
 // pass 4
 __global__ __launch_bounds__(MC_NT) void mc_emit_faces_kernel(const double* __restrict__ vol, McDims d, double level, const signed char* __restrict__ tri,
                                                               int width, const unsigned char* __restrict__ ntri, const unsigned char* __restrict__ amb,
+                                                              const int* __restrict__ tun_index, const int* __restrict__ tun_cand,
                                                               const int* __restrict__ vidx, const int64_t* __restrict__ tri_offset,
                                                               const int64_t* __restrict__ centre_offset, int64_t n_edge_verts,
                                                               double* __restrict__ verts, int64_t* __restrict__ faces) {
     __shared__ int lds[4];
     const int64_t lc = (int64_t)blockIdx.x * MC_NT + threadIdx.x;
-    const CubeInfo ci = classify(vol, d, lc, level, amb);
+    const CubeInfo ci = classify(vol, d, lc, level, amb, tun_index, tun_cand);
     int nt = 0, ncen = 0;
     const signed char* row = nullptr;
     if (ci.row >= 0) {
@@ -238,29 +280,30 @@ int64_t pps_mc_cube_blocks(int64_t nx, int64_t ny, int64_t nz) { return dims_ok(
 int64_t pps_mc_edge_blocks(int64_t nx, int64_t ny, int64_t nz) { return dims_ok(nx, ny, nz) ? (3 * nx * ny * nz + MC_NT * MC_EPT - 1) / (MC_NT * MC_EPT) : -1; }
 
 int pps_mc_count_f64(const double* vol, int64_t nx, int64_t ny, int64_t nz, double level, const int8_t* tri, int width, const uint8_t* ntri,
-                     const uint8_t* amb, uint8_t* edge_flags, int32_t* block_tris, int32_t* block_centres, int32_t* block_verts, void* stream) {
-    if (!dims_ok(nx, ny, nz) || width < 1 || !vol || !tri || !ntri || !amb || !edge_flags || !block_tris || !block_centres || !block_verts) return PPS_ERR_ARG;
+                     const uint8_t* amb, const int32_t* tun_index, const int32_t* tun_cand, uint8_t* edge_flags, int32_t* block_tris, int32_t* block_centres, int32_t* block_verts, void* stream) {
+    if (!dims_ok(nx, ny, nz) || width < 1 || !vol || !tri || !ntri || !amb || !tun_index || !tun_cand || !edge_flags || !block_tris || !block_centres || !block_verts)
+        return PPS_ERR_ARG;
     const McDims d = make_dims(nx, ny, nz);
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(edge_flags, 0, (size_t)d.nedges, st) != hipSuccess) return PPS_ERR_LAUNCH;
     hipLaunchKernelGGL(mc_count_cubes_kernel, dim3((unsigned)pps_mc_cube_blocks(nx, ny, nz)), dim3(MC_NT), 0, st, vol, d, level, (const signed char*)tri, width,
-                       ntri, amb, edge_flags, block_tris, block_centres);
+                       ntri, amb, (const int*)tun_index, (const int*)tun_cand, edge_flags, block_tris, block_centres);
     hipLaunchKernelGGL(mc_count_verts_kernel, dim3((unsigned)pps_mc_edge_blocks(nx, ny, nz)), dim3(MC_NT), 0, st, (const unsigned char*)edge_flags, d.nedges,
                        block_verts);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 
 int pps_mc_emit_f64(const double* vol, int64_t nx, int64_t ny, int64_t nz, double level, const int8_t* tri, int width, const uint8_t* ntri,
-                    const uint8_t* amb, const uint8_t* edge_flags, const int64_t* tri_offset, const int64_t* centre_offset, const int64_t* vert_offset,
+                    const uint8_t* amb, const int32_t* tun_index, const int32_t* tun_cand, const uint8_t* edge_flags, const int64_t* tri_offset, const int64_t* centre_offset, const int64_t* vert_offset,
                     int64_t n_edge_verts, int32_t* vidx, double* verts, int64_t* faces, void* stream) {
     if (!dims_ok(nx, ny, nz) || width < 1 || n_edge_verts < 0 || n_edge_verts > 0x7fffffff) return PPS_ERR_ARG;
-    if (!vol || !tri || !ntri || !amb || !edge_flags || !tri_offset || !centre_offset || !vert_offset || !vidx || !verts || !faces) return PPS_ERR_ARG;
+    if (!vol || !tri || !ntri || !amb || !tun_index || !tun_cand || !edge_flags || !tri_offset || !centre_offset || !vert_offset || !vidx || !verts || !faces) return PPS_ERR_ARG;
     const McDims d = make_dims(nx, ny, nz);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(mc_emit_verts_kernel, dim3((unsigned)pps_mc_edge_blocks(nx, ny, nz)), dim3(MC_NT), 0, st, vol, d, level, (const unsigned char*)edge_flags,
                        vert_offset, vidx, verts);
     hipLaunchKernelGGL(mc_emit_faces_kernel, dim3((unsigned)pps_mc_cube_blocks(nx, ny, nz)), dim3(MC_NT), 0, st, vol, d, level, (const signed char*)tri, width,
-                       ntri, amb, (const int*)vidx, tri_offset, centre_offset, n_edge_verts, verts, faces);
+                       ntri, amb, (const int*)tun_index, (const int*)tun_cand, (const int*)vidx, tri_offset, centre_offset, n_edge_verts, verts, faces);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 

@@ -11,8 +11,16 @@ table convention but a property of the DATA: the asymptotic decider of Nielson &
 saddle point, f00 f11 - f10 f01 against the level), which is what Lewiner et al. (2003), "Efficient implementation of Marching Cubes' cases with
 topological guarantees" -- the method behind skimage's default -- use for their face tests: the inside corners of the face are joined through the
 face when the saddle value is inside, cut off separately when it is outside.  Both cubes that share a face evaluate the same four values in the same
-order, so they agree and the surface has no cracks.  Interior ambiguities (Lewiner's cases 4, 6, 7, 10, 12, 13 with a tunnel through the cube) are NOT
-resolved: every loop is closed with a disc, which is Lewiner's topology whenever his interior test finds no tunnel.
+order, so they agree and the surface has no cracks.
+INTERIOR ambiguities [round 5] (Chernyaev's / Lewiner's cases 4, 6, 7, 10, 12, 13: two same-sign groups of corners that no face joins may still be
+connected THROUGH the cube by the trilinear interpolant) are resolved by the interior test of the same papers in its general form: sweep a plane
+along a cube axis; in the plane at height t the function is bilinear with corner values A(t), B(t), C(t), D(t) linear in t, and two diagonal
+corners A, C of one sign are joined in that plane iff A C - B D > 0 (the asymptotic decider again); g(t) = A C - B D is quadratic, so the groups
+are connected iff for some axis g has an interior maximum t* = -g1 / (2 g2) in (0, 1) with g(t*) > 0 and A(t*), C(t*) of the groups' sign
+(Lewiner et al. 2003, test_interior, cases 4 / 10: exactly these formulas).  A connected pair of loops is closed by a TUBE (annulus between the two
+loops) instead of two discs.  Which pairs of loops can be joined, which (axis, diagonal) sweeps decide it, and the tube's triangles are derived
+below like the rest of the table; the decision itself is data (`interior_connected`).  The specification and the numerical ground truth
+(connected components of the densely sampled trilinear interpolant) are in oracle/mesh_oracle.py.
 Vertices sit on grid edges (one fractional coordinate), which is what the bisection refinement of the reference relies on (poco_utils.py:111-119).
 """
 import numpy as np
@@ -108,14 +116,198 @@ def _ambiguous_mask(case):
     return m
 
 
+def _slice_columns(ax):
+    """The four columns (cube edges along `ax`) of a sweep along axis ax, at (u, v) = (0,0), (1,0), (0,1), (1,1) with u = ax+1, v = ax+2 (mod 3):
+    [(corner at t = 0, corner at t = 1)] * 4.  Diagonal pair 0 = columns 0, 3; pair 1 = columns 1, 2."""
+    u, v = (ax + 1) % 3, (ax + 2) % 3
+    return [((a << u) | (b << v), (a << u) | (b << v) | (1 << ax)) for b in (0, 1) for a in (0, 1)]
+
+
+_SLICE_COLS = [_slice_columns(ax) for ax in range(3)]
+_DIAG = ((0, 3, 1, 2), (1, 2, 0, 3))             # (X, Y, B, D) column numbers of the two diagonal pairs of a slice
+
+
+def _surface_regions(case, dec):
+    """Connectivity of the cube corners ON THE SURFACE of the cube: same-sign corners are joined along cube edges, and across an ambiguous face the
+    inside diagonal pair is joined when the face's decision bit is set, the outside pair when it is clear.  -> region label per corner."""
+    lab = list(range(8))
+
+    def find(x):
+        while lab[x] != x:
+            lab[x] = lab[lab[x]]
+            x = lab[x]
+        return x
+
+    ins = [(case >> c) & 1 for c in range(8)]
+    for a, b in _EDGES:
+        if ins[a] == ins[b]:
+            lab[find(a)] = find(b)
+    for f, (c00, c10, c01, c11) in enumerate(_FACE_UV):
+        if ins[c00] == ins[c11] and ins[c10] == ins[c01] and ins[c00] != ins[c10]:
+            joined_inside = (dec >> f) & 1
+            pair = (c00, c11) if bool(ins[c00]) == bool(joined_inside) else (c10, c01)
+            lab[find(pair[0])] = find(pair[1])
+    return [find(c) for c in range(8)]
+
+
+def _edge_mid(e):
+    a, b = _EDGES[e]
+    return (_CORNERS[a] + _CORNERS[b]) * 0.5
+
+
+_TUBE_CACHE = {}
+
+
+def _tube(loop_a, loop_b, edge_faces):
+    key = (tuple(loop_a), tuple(loop_b))
+    if key not in _TUBE_CACHE:
+        _TUBE_CACHE[key] = _tube_search(loop_a, loop_b, edge_faces)
+    return _TUBE_CACHE[key]
+
+
+_PATHS = {}
+
+
+def _lattice_paths(na, nb):
+    """All orders of na A-steps and nb B-steps: bool [paths, na + nb] (True = A-step), cached."""
+    import itertools
+    key = (na, nb)
+    if key not in _PATHS:
+        n = na + nb
+        combos = np.array(list(itertools.combinations(range(n), na)), dtype=np.int64)
+        m = np.zeros((combos.shape[0], n), dtype=bool)
+        m[np.arange(combos.shape[0])[:, None], combos] = True
+        _PATHS[key] = m
+    return _PATHS[key]
+
+
+def _tube_search(loop_a, loop_b, edge_faces):
+    """Triangles of an annulus between two directed loops (both as the table stores loops: inside on the left seen from outside the cube), with the
+    winding of the disc triangles (loop edges are traversed backwards: normals towards lower values).
+    The annulus is a cyclic sequence of BRIDGES a_i - b_j: from bridge (i, j) a step along A emits the triangle (a_i+1, a_i, b_j) and leads to
+    (i + 1, j), a step along B emits (b_j, b_j-1, a_i) and leads to (i, j - 1): the loops run in opposite senses around the tube.  All start
+    bridges (a_0, b_j0) and all orders of the na + nb steps are enumerated (vectorised); a tube may use every bridge once.
+    A bridge whose two cube edges lie in one cube face would be a chord flush with that face (the neighbouring cube sees the same two vertices, and
+    the face decider's segments would be contradicted): tubes without such bridges are preferred, shortest summed squared bridge length (between
+    edge midpoints) first.  For most loop pairs every tube has flush bridges; then the run of consecutive bridges that contains all of them is cut
+    out, together with the triangles on both sides of it, and the hole -- a polygon bounded by two clean bridges and the loop edges between them --
+    is closed by a fan around ONE extra vertex inside the cube (id CENTER, at the mean of the polygon's corners, like the centre vertex of the
+    long disc loops): the shortest such run is taken.  -> (triangles, with the fan first, or None if no tube exists)."""
+    na, nb = len(loop_a), len(loop_b)
+    n = na + nb
+    mid_a = np.array([_edge_mid(e) for e in loop_a])
+    mid_b = np.array([_edge_mid(e) for e in loop_b])
+    flush_ab = np.array([[1 if (edge_faces[ea] & edge_faces[eb]) else 0 for eb in loop_b] for ea in loop_a], dtype=np.int64)
+    len_ab = ((mid_a[:, None, :] - mid_b[None, :, :]) ** 2).sum(-1)
+    paths = _lattice_paths(na, nb)                                       # [P, n]
+    ia = np.concatenate([np.zeros((paths.shape[0], 1), dtype=np.int64), np.cumsum(paths, axis=1)[:, :-1]], axis=1)           # A-steps before step t
+    kb = np.concatenate([np.zeros((paths.shape[0], 1), dtype=np.int64), np.cumsum(~paths, axis=1)[:, :-1]], axis=1)
+    best = None
+    for j0 in range(nb):
+        ai, bj = ia % na, (j0 - kb) % nb                                 # bridge before step t
+        bid = np.sort(ai * nb + bj, axis=1)
+        ok = (bid[:, 1:] != bid[:, :-1]).all(axis=1)                     # every bridge once (a path that spends all its A-steps in one run is a cone)
+        fl = flush_ab[ai, bj].astype(bool)                               # [P, n]
+        length = len_ab[ai, bj]
+        # shortest cyclic window of bridges that contains every flush one = n - (longest cyclic run of clean bridges); the run must hold >= 2 bridges
+        clean = ~fl
+        dbl = np.concatenate([clean, clean], axis=1)
+        run = np.zeros(dbl.shape[0], dtype=np.int64)
+        best_run = np.zeros(dbl.shape[0], dtype=np.int64)
+        best_end = np.zeros(dbl.shape[0], dtype=np.int64)
+        for t in range(2 * n):
+            run = np.where(dbl[:, t], run + 1, 0)
+            better = run > best_run
+            best_run = np.where(better, run, best_run)
+            best_end = np.where(better, t, best_end)
+        full = best_run >= n                                             # no flush bridge at all
+        best_run = np.minimum(best_run, n)
+        window = n - best_run                                            # bridges cut out (0: a tube without flush bridges)
+        # the triangles that stay (between consecutive bridges of the clean run) must include a step along A AND a step along B: otherwise the
+        # piece that is cut out contains a whole loop and the polygon around it touches itself
+        ca = np.cumsum(np.concatenate([paths, paths], axis=1), axis=1)
+        ca = np.concatenate([np.zeros((ca.shape[0], 1), dtype=np.int64), ca], axis=1)            # ca[:, t] = A-steps among steps 0 .. t - 1 (doubled)
+        first_d = best_end - best_run + 1
+        rows_ = np.arange(paths.shape[0])
+        kept_a = ca[rows_, np.maximum(first_d + best_run - 1, 0)] - ca[rows_, np.maximum(first_d, 0)]
+        kept = best_run - 1
+        ok &= full | ((kept_a >= 1) & (kept - kept_a >= 1))
+        if not ok.any():
+            continue
+        reg_len = np.where(fl.any(axis=1), 0.0, length.sum(axis=1))      # ranking inside the clean tubes: summed bridge length
+        cand = np.nonzero(ok)[0]
+        keyed = sorted((int(window[p]), round(float(reg_len[p] if window[p] == 0 else length[p].sum()), 9), j0, int(p)) for p in cand)
+        if best is None or keyed[0] < best[0]:
+            p = keyed[0][3]
+            best = (keyed[0], j0, paths[p].copy(), int(best_end[p]) % n, int(best_run[p]), int(window[p]))
+    if best is None:
+        # No tube whose flush bridges fit into one simple polygon (a triangle loop against a hexagon: the six clean bridges come in three isolated
+        # pairs).  Lewiner's table for the same configuration (case 7.4.2) has chords in cube faces too: take the tube with the FEWEST flush bridges.
+        # Such a chord is an interior edge of this cube's patch (both its triangles lie in this cube), not a face segment.
+        for j0 in range(nb):
+            ai, bj = ia % na, (j0 - kb) % nb
+            bid = np.sort(ai * nb + bj, axis=1)
+            ok = (bid[:, 1:] != bid[:, :-1]).all(axis=1)
+            nfl = flush_ab[ai, bj].sum(axis=1)
+            length = len_ab[ai, bj].sum(axis=1)
+            for p in np.nonzero(ok)[0]:
+                key = (int(nfl[p]), round(float(length[p]), 9), j0, int(p))
+                if best is None or key < best[0]:
+                    best = (key, j0, paths[p].copy(), 0, n, 0)
+        if best is None:
+            return None, 1
+    _, j0, steps, run_end, run_len, window = best
+    # triangles in step order; triangle t lies between bridge t and bridge t + 1 (cyclic)
+    tris, i, j = [], 0, j0
+    for t in range(n):
+        ea, eb = loop_a[i % na], loop_b[j % nb]
+        if steps[t]:
+            tris.append((loop_a[(i + 1) % na], ea, eb))
+            i += 1
+        else:
+            tris.append((eb, loop_b[(j - 1) % nb], ea))
+            j -= 1
+    if window == 0:
+        return tris, 0
+    # clean run = bridges run_end - run_len + 1 .. run_end (cyclic); the triangles strictly between two clean bridges of the run stay, the rest
+    # (window + 1 triangles, from bridge run_end to bridge run_end - run_len + 1 going forward) is replaced by the fan
+    first = (run_end - run_len + 1) % n
+    keep = [(first + d) % n for d in range(run_len - 1)]                 # triangle t sits between bridges t and t + 1
+    cut = [t for t in range(n) if t not in keep]
+    edges = {}
+    for t in cut:
+        x, y, z = tris[t]
+        for u, v in ((x, y), (y, z), (z, x)):
+            if (v, u) in edges:
+                del edges[(v, u)]
+            else:
+                edges[(u, v)] = True
+    nxt = {u: v for u, v in edges}
+    assert len(nxt) == len(edges), 'the polygon around the flush bridges is not simple'
+    start = min(nxt)
+    cyc, e = [], start
+    while True:
+        cyc.append(e)
+        e = nxt[e]
+        if e == start:
+            break
+    assert len(cyc) == len(edges)
+    fan = [(CENTER, cyc[q], cyc[(q + 1) % len(cyc)]) for q in range(len(cyc))]
+    return fan + [tris[t] for t in keep], 0
+
+
 def _build_table():
-    """-> (tri int8 [256 * 64, W, 3] cube-edge ids (-1 = none), ntri uint8 [256 * 64], amb uint8 [256]); row case * 64 + dec, dec = one bit per
-    face: 1 = the inside corners of that (ambiguous) face are JOINED through the face.  Rows whose dec has bits outside amb[case] are copies of
-    the row with those bits cleared, so a lookup may mask or not."""
+    """-> (tri int8 [R, W, 3] cube-edge ids (-1 = none), ntri uint8 [R], amb uint8 [256], tun_index int32 [256 * 64, 2], tun_cand int32 [C, 3]).
+    Rows 0 .. 16383: row case * 64 + dec, dec = one bit per face: 1 = the inside corners of that (ambiguous) face are JOINED through the face; every
+    loop closed by a disc.  Rows whose dec has bits outside amb[case] are copies of the row with those bits cleared, so a lookup may mask or not.
+    tun_index[row] = (first, count) into tun_cand: the pairs of loops of that row that the interior test may join; tun_cand[c] = (sign: 1 inside /
+    0 outside groups, mask: bit 2 * axis + diagonal = this sweep decides the pair, alternative row >= 16384: the same cube with a tube between the
+    two loops).  The first candidate (in list order) whose test succeeds replaces the row."""
     faces = _face_cycles()
     edge_faces = {i: frozenset(fi for fi, cyc in enumerate(faces) if a in cyc and b in cyc) for i, (a, b) in enumerate(_EDGES)}
-    rows = {}
+    rows, cands = {}, {}
     amb = np.zeros(256, dtype=np.uint8)
+    extra = []                                          # alternative rows (tubes), appended behind the 16384 regular ones
     for case in range(256):
         amb[case] = _ambiguous_mask(case)
         inside = [(case >> c) & 1 for c in range(8)]
@@ -146,7 +338,7 @@ def _build_table():
                     else:
                         for ee, el in pair.items():                                  # separated: every inside corner is cut off by itself
                             nxt[el] = ee
-            per_loop, seen = [], set()
+            loops, seen = [], set()
             for start in sorted(nxt):
                 if start in seen:
                     continue
@@ -155,25 +347,81 @@ def _build_table():
                     seen.add(e)
                     loop.append(e)
                     e = nxt[e]
-                per_loop.append([(a, c, b) for a, b, c in _triangulate(loop, edge_faces)])      # winding: normals point towards LOWER values
-            # a fan around the centre vertex (at most one per cube: such loops have >= 8 of the 12 edges) is listed FIRST in its row: the kernels
-            # read "this cube has a centre vertex" off the row's first entry
-            per_loop.sort(key=lambda t: 0 if t[0][0] == CENTER else 1)
-            assert sum(1 for t in per_loop if t[0][0] == CENTER) <= 1
-            rows[(case, dec)] = [t for lp in per_loop for t in lp]
-    width = max(len(t) for t in rows.values())
-    tri = np.full((256 * 64, width, 3), -1, dtype=np.int8)
-    ntri = np.zeros(256 * 64, dtype=np.uint8)
+                loops.append(loop)
+            discs = [[(a, c, b) for a, b, c in _triangulate(loop, edge_faces)] for loop in loops]      # winding: normals point towards LOWER values
+
+            def assemble(pieces):
+                # a fan around the centre vertex (at most one per cube: such loops have >= 8 of the 12 edges) is listed FIRST in its row: the
+                # kernels read "this cube has a centre vertex" off the row's first entry
+                pieces = sorted(pieces, key=lambda t: 0 if t[0][0] == CENTER else 1)
+                assert sum(1 for t in pieces if t[0][0] == CENTER) <= 1
+                return [t for lp in pieces for t in lp]
+
+            rows[(case, dec)] = assemble(discs)
+            # ---- interior ambiguity: pairs of loops the interior test may join by a tube --------------------------------------------------------
+            if len(loops) < 2:
+                continue
+            region = _surface_regions(case, dec)
+            sides = []                                  # per loop: (inside region, outside region) it separates
+            for loop in loops:
+                rin = {region[c] for e in loop for c in _EDGES[e] if inside[c]}
+                rout = {region[c] for e in loop for c in _EDGES[e] if not inside[c]}
+                assert len(rin) == 1 and len(rout) == 1, (case, dec)
+                sides.append((rin.pop(), rout.pop()))
+            lst = []
+            for sign in (1, 0):                         # inside groups first
+                mine, other = (0, 1) if sign else (1, 0)
+                for la in range(len(loops)):
+                    for lb in range(la + 1, len(loops)):
+                        # two DIFFERENT groups of this sign with one common neighbour region between the loops
+                        if sides[la][mine] == sides[lb][mine] or sides[la][other] != sides[lb][other]:
+                            continue
+                        grp_a = {c for c in range(8) if region[c] == sides[la][mine]}
+                        grp_b = {c for c in range(8) if region[c] == sides[lb][mine]}
+                        mask = 0
+                        for ax in range(3):
+                            cols = _SLICE_COLS[ax]
+                            for dg, (x, y, _b, _d) in enumerate(_DIAG):
+                                cx, cy = set(cols[x]), set(cols[y])
+                                if (cx & grp_a and cy & grp_b) or (cx & grp_b and cy & grp_a):
+                                    mask |= 1 << (2 * ax + dg)
+                        if mask == 0:
+                            continue
+                        tube, flush = _tube(loops[la], loops[lb], edge_faces)
+                        if flush:
+                            continue                    # (does not occur: asserted by tests/test_mesh_oracle.py on the whole table)
+                        pieces = [tube] + [d for k, d in enumerate(discs) if k not in (la, lb)]
+                        extra.append(assemble(pieces))
+                        lst.append((sign, mask, 256 * 64 + len(extra) - 1))
+            if lst:
+                cands[(case, dec)] = lst
+    width = max(len(t) for t in list(rows.values()) + extra)
+    nrow = 256 * 64 + len(extra)
+    tri = np.full((nrow, width, 3), -1, dtype=np.int8)
+    ntri = np.zeros(nrow, dtype=np.uint8)
+    tun_index = np.zeros((256 * 64, 2), dtype=np.int32)
+    tun_cand = []
     for case in range(256):
+        first = {}
         for dec in range(64):
-            t = rows[(case, dec & int(amb[case]))]
+            key = (case, dec & int(amb[case]))
+            t = rows[key]
             ntri[case * 64 + dec] = len(t)
             if t:
                 tri[case * 64 + dec, :len(t)] = np.array(t, dtype=np.int8)
-    return tri, ntri, amb
+            if key in cands:
+                if key not in first:
+                    first[key] = len(tun_cand)
+                    tun_cand += cands[key]
+                tun_index[case * 64 + dec] = (first[key], len(cands[key]))
+    for k, t in enumerate(extra):
+        ntri[256 * 64 + k] = len(t)
+        tri[256 * 64 + k, :len(t)] = np.array(t, dtype=np.int8)
+    return tri, ntri, amb, tun_index, np.array(tun_cand, dtype=np.int32).reshape(-1, 3)
 
 
-_TRI_TABLE, _NTRI, _AMB = _build_table()
+_TRI_TABLE, _NTRI, _AMB, _TUN_INDEX, _TUN_CAND = _build_table()
+N_BASE_ROWS = 256 * 64
 TABLE_WIDTH = int(_TRI_TABLE.shape[1])
 
 
@@ -190,6 +438,55 @@ def face_decisions(corner_vals, level):
         bit = joined.astype(np.int64) << f
         dec = bit if dec is None else dec | bit
     return dec
+
+
+def interior_sweep_connected(corner_vals, level, sign, ax, dg):
+    """One sweep of the interior test, vectorised: corner_vals = 8 arrays (cube corners), sign 1: groups of inside corners (v - level), 0: of outside
+    corners (level - v); plane orthogonal to axis `ax`, diagonal pair `dg` of the plane's four columns (_SLICE_COLS, _DIAG).  With X, Y the diagonal
+    columns and B, D the other two, each linear in the height t:  g(t) = X Y - B D = g2 t^2 + g1 t + g0.  True where g has an interior maximum
+    t* = -g1 / (2 g2) in (0, 1) (g2 < 0) with X(t*) > 0, Y(t*) > 0 and g(t*) > 0: the two columns are joined inside the plane at height t* (the
+    asymptotic decider of that plane), hence their groups through the cube.  Same operations in the same order as the kernel
+    (csrc/pps_mc.hip::sweep_connected; no fused multiply-add on either side)."""
+    cols = _SLICE_COLS[ax]
+    x, y, b, d = _DIAG[dg]
+    sg = 1.0 if sign else -1.0
+    val = lambda c: sg * (corner_vals[c] - level)
+    x0, x1, y0, y1 = val(cols[x][0]), val(cols[x][1]), val(cols[y][0]), val(cols[y][1])
+    b0, b1, d0, d1 = val(cols[b][0]), val(cols[b][1]), val(cols[d][0]), val(cols[d][1])
+    dx, dy, db, dd = x1 - x0, y1 - y0, b1 - b0, d1 - d0
+    g2 = dx * dy - db * dd
+    g1 = (y0 * dx + x0 * dy) - (d0 * db + b0 * dd)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        t = -g1 / (2.0 * g2)
+        xt, yt, bt, dt = x0 + dx * t, y0 + dy * t, b0 + db * t, d0 + dd * t
+        return (g2 < 0.0) & (t > 0.0) & (t < 1.0) & (xt > 0.0) & (yt > 0.0) & (xt * yt - bt * dt > 0.0)
+
+
+def interior_rows(rows, corner_vals, level):
+    """rows: int64 table rows (case * 64 + dec) of some cubes, corner_vals: their 8 corner value arrays -> the rows after the interior test: the first
+    candidate pair of loops (tun_cand order) that one of its sweeps finds connected replaces the row by its tube row."""
+    rows = rows.copy()
+    first, count = _TUN_INDEX[rows, 0], _TUN_INDEX[rows, 1]
+    todo = np.nonzero(count > 0)[0]
+    if todo.size == 0:
+        return rows
+    sub = [v[todo] for v in corner_vals]
+    done = np.zeros(todo.size, dtype=bool)
+    for k in range(int(count.max())):
+        has = (count[todo] > k) & ~done
+        if not has.any():
+            break
+        cand = _TUN_CAND[np.where(has, first[todo] + k, 0)]
+        hit = np.zeros(todo.size, dtype=bool)
+        for sign in (1, 0):
+            for ax in range(3):
+                for dg in range(2):
+                    sel = has & (cand[:, 0] == sign) & (((cand[:, 1] >> (2 * ax + dg)) & 1) == 1)
+                    if sel.any():
+                        hit |= sel & interior_sweep_connected(sub, level, sign, ax, dg)
+        rows[todo[hit]] = cand[hit, 2]
+        done |= hit
+    return rows
 
 
 def marching_cubes(volume: np.ndarray, level: float = 0.0):
@@ -210,7 +507,9 @@ def marching_cubes(volume: np.ndarray, level: float = 0.0):
         return np.zeros((0, 3)), np.zeros((0, 3), dtype=np.int64)
     with np.errstate(invalid='ignore'):
         dec = face_decisions([v[cx, cy, cz] for v in corner_vals], level) & _AMB[case[cx, cy, cz]].astype(np.int64)
-    tris = _TRI_TABLE[case[cx, cy, cz] * 64 + dec].astype(np.int64)   # [n, W, 3] local edge ids
+    cvals = [v[cx, cy, cz] for v in corner_vals]
+    rows = interior_rows(case[cx, cy, cz] * 64 + dec, cvals, level)  # interior ambiguity: a connected pair of loops gets a tube (its own table row)
+    tris = _TRI_TABLE[rows].astype(np.int64)                         # [n, W, 3] local edge ids
     valid = tris[:, :, 0] >= 0
     cube_of = np.broadcast_to(np.arange(cx.size)[:, None], valid.shape)[valid]
     e = tris[valid]                                                  # [T,3] cube-edge ids, CENTER = the extra vertex inside the cube
@@ -287,11 +586,12 @@ _DEV_TABLES = {}
 
 
 def device_tables(dev):
-    """(tri int8 [16384, W, 3], ntri uint8 [16384], amb uint8 [256]) on `dev` (uploaded once)."""
+    """(tri int8 [rows, W, 3], ntri uint8 [rows], amb uint8 [256], tun_index int32 [16384, 2], tun_cand int32 [C, 3]) on `dev` (uploaded once)."""
     import torch
     t = _DEV_TABLES.get(str(dev))
     if t is None:
-        t = (torch.from_numpy(_TRI_TABLE).to(dev).contiguous(), torch.from_numpy(_NTRI).to(dev), torch.from_numpy(_AMB).to(dev))
+        t = (torch.from_numpy(_TRI_TABLE).to(dev).contiguous(), torch.from_numpy(_NTRI).to(dev), torch.from_numpy(_AMB).to(dev),
+             torch.from_numpy(_TUN_INDEX).to(dev).contiguous(), torch.from_numpy(_TUN_CAND).to(dev).contiguous())
         _DEV_TABLES[str(dev)] = t
     return t
 

@@ -220,7 +220,7 @@ def marching_cubes(volume: torch.Tensor, level: float):
     L = _lib.lib()
     nx, ny, nz = volume.shape
     dev = volume.device
-    tri, ntri, amb = mcubes.device_tables(dev)
+    tri, ntri, amb, tun_index, tun_cand = mcubes.device_tables(dev)
     nbc, nbe = L.pps_mc_cube_blocks(nx, ny, nz), L.pps_mc_edge_blocks(nx, ny, nz)
     if nbc < 0:
         raise ValueError('volume of shape {} is outside the range of pps_mc'.format(tuple(volume.shape)))
@@ -231,7 +231,7 @@ def marching_cubes(volume: torch.Tensor, level: float):
     st = _stream(volume)
     lvl = ctypes.c_double(float(level))
     _lib.check(L.pps_mc_count_f64(volume.data_ptr(), nx, ny, nz, lvl, tri.data_ptr(), mcubes.TABLE_WIDTH, ntri.data_ptr(), amb.data_ptr(),
-                                  flags.data_ptr(), bt.data_ptr(), bc.data_ptr(), bv.data_ptr(), st), 'pps_mc_count_f64')
+                                  tun_index.data_ptr(), tun_cand.data_ptr(), flags.data_ptr(), bt.data_ptr(), bc.data_ptr(), bv.data_ptr(), st), 'pps_mc_count_f64')
     inc = [torch.cumsum(x, 0, dtype=torch.int64) for x in (bt, bc, bv)]
     n_tri, n_cen, n_vert = [int(v) for v in torch.stack([i[-1] for i in inc]).tolist()]
     verts = torch.empty((n_vert + n_cen, 3), dtype=torch.float64, device=dev)
@@ -240,7 +240,7 @@ def marching_cubes(volume: torch.Tensor, level: float):
         return verts[:0], faces
     off = [(i - x).contiguous() for i, x in zip(inc, (bt, bc, bv))]
     vidx = torch.empty(nedge, dtype=torch.int32, device=dev)
-    _lib.check(L.pps_mc_emit_f64(volume.data_ptr(), nx, ny, nz, lvl, tri.data_ptr(), mcubes.TABLE_WIDTH, ntri.data_ptr(), amb.data_ptr(), flags.data_ptr(),
-                                 off[0].data_ptr(), off[1].data_ptr(), off[2].data_ptr(), n_vert, vidx.data_ptr(), verts.data_ptr(), faces.data_ptr(), st),
+    _lib.check(L.pps_mc_emit_f64(volume.data_ptr(), nx, ny, nz, lvl, tri.data_ptr(), mcubes.TABLE_WIDTH, ntri.data_ptr(), amb.data_ptr(), tun_index.data_ptr(),
+                                 tun_cand.data_ptr(), flags.data_ptr(), off[0].data_ptr(), off[1].data_ptr(), off[2].data_ptr(), n_vert, vidx.data_ptr(), verts.data_ptr(), faces.data_ptr(), st),
                'pps_mc_emit_f64')
     return verts, faces

@@ -89,6 +89,7 @@ def test_ambiguous_faces_follow_the_asymptotic_decider_and_a_fixed_rule_is_rejec
     info = M.check_marching_cubes(v, f, vol, 0.0)
     assert info['ambiguous_faces'] > 300 and info['interior_vertices'] > 10, info
     monkeypatch.setattr(mcubes, 'face_decisions', lambda corner_vals, level: np.zeros(corner_vals[0].shape, dtype=np.int64))
+    monkeypatch.setattr(mcubes, 'interior_rows', lambda rows, corner_vals, level: rows)       # (that mesher closed every loop with a disc)
     v0, f0 = mcubes.marching_cubes(vol, 0.0)
     with pytest.raises(AssertionError, match='ambiguous face'):
         M.check_marching_cubes(v0, f0, vol, 0.0)
@@ -306,3 +307,120 @@ def test_device_marching_cubes_at_r257_size_and_empty_volume():
     M.check_marching_cubes(vs.cpu().numpy(), fs.cpu().numpy(), sub.cpu().numpy(), 0.0, require_closed=False)
     ve, fe = mcubes.marching_cubes_torch(torch.full((20, 20, 20), -1.0, dtype=torch.float64, device='cuda:0'), 0.0)
     assert ve.shape == (0, 3) and fe.shape == (0, 3)
+
+
+# ---- interior ambiguity (round 5): tubes where the trilinear interpolant joins two corner groups through the cube ------------------------------
+def _one_cube(vals):
+    vol = np.zeros((2, 2, 2))
+    for c, (dx, dy, dz) in enumerate(M._CUBE_CORNERS):
+        vol[dx, dy, dz] = vals[c]
+    return vol
+
+
+def test_interior_test_equals_the_densely_sampled_trilinear_interpolant():
+    """The analytic interior test of the specification (plane sweeps, asymptotic decider at the extremum of A C - B D; Chernyaev 1995, Lewiner et al.
+    2003 `test_interior`) against NUMERICAL GROUND TRUTH: the cube's trilinear interpolant sampled on a 41^3 lattice, connected components of both
+    sides, which corners share one.  Random cubes with at least two same-side corner groups on the surface (the only ones with an interior
+    question), values kept away from the level so that the lattice resolves every connection."""
+    rng = np.random.default_rng(11)
+    n = joined = 0
+    while n < 700:
+        vals = rng.standard_normal(8)
+        if np.abs(vals).min() < 0.15:
+            continue
+        sin, sout = M.surface_corner_groups(vals)
+        if len(sin) + len(sout) < 3:
+            continue
+        n += 1
+        got = M.interior_corner_groups(vals)
+        assert got == M.trilinear_corner_groups(vals, n=40), vals
+        joined += got != (sin, sout)
+    assert joined >= 4                                            # tunnels are rare in white noise (about 1 % of these cubes)
+
+
+def test_tunnel_fixture_cubes_and_the_disc_closing_mesher_is_rejected(monkeypatch):
+    """tests/golden/mc_tunnel_cubes.npz (make_golden_mc.py): cubes of every corner-count class in which the trilinear interpolant joins two corner
+    groups THROUGH the cube, with the corner partitions found by dense sampling (96^3 lattice) stored beside the eight values.  The specification's
+    interior test reproduces the stored partitions; the product's mesh of each cube passes check_cube_topology with a tube; the same mesher with
+    the interior test switched off (every loop closed by a disc: rounds 1-4) is a valid manifold and is REJECTED."""
+    g = load_golden('mc_tunnel_cubes')
+    vals_all, part_in, part_out = g['vals'], g['inside_label'], g['outside_label']
+    assert vals_all.shape[0] >= 12
+    seen_counts = set()
+    for vals, lin, lout in zip(vals_all, part_in, part_out):
+        ins = [c for c in range(8) if vals[c] > 0]
+        outs = [c for c in range(8) if not vals[c] > 0]
+        want = (M._partition({c: int(lin[c]) for c in ins}, ins), M._partition({c: int(lout[c]) for c in outs}, outs))
+        assert M.interior_corner_groups(vals) == want
+        assert M.surface_corner_groups(vals) != want              # ... and it is an INTERIOR connection: the faces alone do not give it
+        vol = _one_cube(vals)
+        v, f = mcubes.marching_cubes(vol, 0.0)
+        assert M.check_cube_topology(v, f, vol, 0.0)['tunnels'] == 1
+        assert (0, 2) in M.cube_patch_topology(v, f, (0, 0, 0))
+        seen_counts.add(len(ins))
+    assert seen_counts >= {2, 3, 4, 5, 6}
+    monkeypatch.setattr(mcubes, 'interior_rows', lambda rows, corner_vals, level: rows)
+    for vals in vals_all:
+        vol = _one_cube(vals)
+        v, f = mcubes.marching_cubes(vol, 0.0)
+        assert all(c == (1, 1) for c in M.cube_patch_topology(v, f, (0, 0, 0)))      # discs only: a valid patch ...
+        with pytest.raises(AssertionError, match='tube expected'):                  # ... with the wrong topology
+            M.check_cube_topology(v, f, vol, 0.0)
+
+
+def test_white_noise_volumes_have_tubes_and_meet_the_whole_specification(monkeypatch):
+    """Closed manifold, orientation, face decider AND cube topology on white noise (every corner pattern, thousands of ambiguous faces, a few dozen
+    tunnels); the disc-closing mesher fails the same volumes in check_marching_cubes itself."""
+    rng = np.random.default_rng(5)
+    vols = [rng.standard_normal((9, 9, 9)) for _ in range(12)]
+    tunnels = 0
+    for vol in vols:
+        v, f = mcubes.marching_cubes(vol, 0.0)
+        info = M.check_marching_cubes(v, f, vol, 0.0)
+        tunnels += info['tunnels']
+    assert tunnels >= 10
+    monkeypatch.setattr(mcubes, 'interior_rows', lambda rows, corner_vals, level: rows)
+    rejected = 0
+    for vol in vols:
+        v, f = mcubes.marching_cubes(vol, 0.0)
+        try:
+            M.check_marching_cubes(v, f, vol, 0.0)
+        except AssertionError as exc:
+            assert 'tube expected' in str(exc)
+            rejected += 1
+    assert rejected >= 8
+
+
+def test_table_rows_discs_and_tubes_have_the_right_euler_characteristic():
+    """Every row of the derived table as a 2-complex of cube-edge ids: the regular rows (corner pattern x face decisions) are discs, one per loop
+    (euler characteristic 1, one boundary loop each); every tube row replaces exactly two discs by one annulus (0, 2); a centre vertex (id 12)
+    appears in at most one fan per row and never on a boundary.  Counts per corner-count class are stable facts of the construction."""
+    tri, ntri = mcubes._TRI_TABLE, mcubes._NTRI
+    nbase = mcubes.N_BASE_ROWS
+
+    def comps(row):
+        t = tri[row, :ntri[row]].astype(np.int64)
+        return M._patch_components(None, t) if t.shape[0] else []
+
+    loops_of = {}
+    for case in range(1, 255):
+        for dec in range(64):
+            if dec & ~int(mcubes._AMB[case]):
+                continue
+            c = comps(case * 64 + dec)
+            assert all(x == (1, 1) for x in c), (case, dec, c)
+            loops_of[(case, dec)] = len(c)
+    assert max(loops_of.values()) == 4 and loops_of[(0b10000001, 0)] == 2        # pattern 13 has four triangles; two opposite corners: two
+    n_tube = 0
+    for case in range(1, 255):
+        for dec in range(64):
+            first, count = mcubes._TUN_INDEX[case * 64 + dec]
+            for sign, mask, alt in mcubes._TUN_CAND[first:first + count]:
+                assert alt >= nbase and 0 < mask < 64 and sign in (0, 1)
+                c = comps(alt)
+                assert sorted(c) == sorted([(0, 2)] + [(1, 1)] * (loops_of[(case, dec & int(mcubes._AMB[case]))] - 2)), (case, dec, c)
+                n_tube += 1
+                t = tri[alt, :ntri[alt]]
+                fan = t[:, 0] == mcubes.CENTER
+                assert not (t[:, 1:] == mcubes.CENTER).any() and (not fan.any() or fan[0])      # the fan is listed first (the kernels rely on it)
+    assert n_tube > 300 and tri.shape[0] == nbase + len({int(a) for a in mcubes._TUN_CAND[:, 2]})
