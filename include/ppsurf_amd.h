@@ -487,6 +487,24 @@ int pps_cast_pieces(const void* pieces, int n_pieces, int dtype, void* stream);
 int pps_adamw_step(const void* pieces, int n_pieces, const void* steps, int n_steps, const float* lr_dev, float lr, float beta1, float beta2,
                    float eps, float weight_decay, const float* grad_scale, const float* found_inf, void* stream);
 
+/* ---- dense layers of the training step, any layer shape (csrc/pps_gemm_train.hip) ---------------------------------------------------------------
+ * replaces: the library GEMMs behind F.linear / torch.mm / torch.bmm of the layers the fused row kernels above do not take: every 1x1 Conv1d / Linear
+ * and the (1,16) Conv2d of the FKAConv encoder (source/base/nn.py:438-450, 508-554, 571, 650), the per-point table, fc_value, fc8 of the
+ * interpolation head (source/poco_model.py:405-417), the STN's fully connected layers (nn.py:183-188), att.fc_value and the MLP (nn.py:376-417).
+ * 16-bit storage (dtype 1 bfloat16, 2 IEEE half), fp32 accumulation on the matrix pipe; row pitches in elements, multiples of 8.
+ *   pps_gemm_nt_16: y [m, n] = x [m, k] w [n, k]^T (+ bias [n] fp32); y 16-bit, or fp32 if out_f32.  The input gradient of the layer is the same
+ *                   call with (g, transposed image of w).
+ *   pps_gemm_tn_16: dw [n, k] fp32 = g [m, n]^T x [m, k] (contraction over the rows; slabs summed in a fixed order); ws: pps_gemm_tn_ws_bytes.
+ *   pps_transpose_cast_pieces: transposed 16-bit images [k, n] of many fp32 matrices [n, k] in one launch; table = device array of
+ *                   pps_transpose_entry_bytes() = 32-byte records {const float* src; void* dst; int32 n, k; int64 tile0}, tile0 = number of 32 x 32
+ *                   tiles of the records before this one, tiles = their total. */
+int pps_gemm_nt_16(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y, int64_t ldy, int64_t m, int n, int k, int dtype,
+                   int out_f32, void* stream);
+size_t pps_gemm_tn_ws_bytes(int64_t m, int n, int k);
+int pps_gemm_tn_16(const void* g, int64_t ldg, const void* x, int64_t ldx, int64_t m, int n, int k, int dtype, float* dw, void* ws, void* stream);
+int pps_transpose_entry_bytes(void);
+int pps_transpose_cast_pieces(const void* table, int entries, int64_t tiles, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -146,6 +146,135 @@ class GraphedStep:
         return static, graph, logged, (self.after_capture() if self.after_capture is not None else None)
 
 
+class StagedStep:
+    """Forward + backward of a MULTI-RANK step with the gradient all-reduce overlapped with the backward pass -- eagerly and when the step is
+    replayed from HIP graphs.  The reference trains under Lightning DDP (configs/device_server.yaml:2, source/base/mp.py:85-91), whose autograd
+    hooks start a bucket's all-reduce while backward continues; hooks do not fire in a replayed graph, and a collective cannot be recorded into one
+    here.  So the backward pass is cut into train_graph.N_STAGES pieces (train_graph.BackwardStages: behind the encoder's coarse levels and behind
+    its middle levels), bucket k of sharding.GradBuckets holds exactly the parameters stage k completes, every stage is recorded as its OWN graph
+    (one memory pool, always replayed in the same order) and the loop is
+
+        replay(graph 0: zero, forward, loss, backward stage 0, pack bucket 0)   ->  all-reduce(bucket 0) issued, asynchronous
+        replay(graph 1: backward stage 1, pack bucket 1)                        ->  all-reduce(bucket 1)      (bucket 0 is on the wire meanwhile)
+        replay(graph 2: backward stage 2, pack bucket 2)                        ->  all-reduce(bucket 2)
+        finish(): wait, average, the per-parameter mask collective; optimizer step (eager, behind)
+
+    Bucket 0 is 82 % of the gradient bytes and is complete when ~70 % of the backward pass is still to run.  Eager steps (warm-up, a failed
+    capture) run the same stages and issue the same collectives in the same order, so ranks that replay and ranks that do not stay in step."""
+    WARMUP = 3
+
+    def __init__(self, model, buckets, scaler, ctx, metrics, enabled=True, max_graphs=2, on_capture_failed=None):
+        self.model, self.buckets, self.scaler, self.ctx, self.metrics = model, buckets, scaler, ctx, metrics
+        self.enabled, self.max_graphs, self.on_capture_failed = enabled, max_graphs, on_capture_failed
+        self.seen, self.graphs, self.failed, self._done, self.replayed = {}, {}, False, None, False
+        self.staged = len(buckets.buckets) == train_graph.N_STAGES      # else: one backward pass, every collective in finish()
+        # ONE stream for the eager steps, the captures and the replays: autograd binds a parameter's gradient accumulation to the stream of the
+        # parameter's first use, and an accumulator that survives from an eager step on another stream would pull that stream into the capture
+        # as an unjoined branch (hipStreamEndCapture faults on it; measured, profiles/NOTES_r5.md)
+        self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+
+    touch = GraphedStep.touch
+
+    def _log(self, what):
+        if self.buckets.order_log is not None:
+            self.buckets.order_log.append(what)
+
+    def _forward(self, batch, bi):
+        self.buckets.zero()
+        self.metrics.values = {}
+        with self.ctx:
+            # a COPY of the dictionary: the networks add entries to it (`latents` carries the step's autograd graph, ppsurf_model.py:70-117), and a
+            # caller that keeps its batch would keep that graph -- and the parameters' gradient accumulators with their stream -- alive into the
+            # next step's capture
+            loss = self.model.training_step(dict(batch), bi)
+        return self.scaler.scale(loss)
+
+    def eager(self, batch, bi):
+        if not self.staged:
+            self._forward(batch, bi).backward()
+            self.model.on_after_backward()
+            return
+        with train_graph.staged() as st:
+            scaled = self._forward(batch, bi)
+
+            def after(k):
+                self._log('stage{}'.format(k))
+                self.buckets.reduce(k)
+            st.backward(scaled, after)
+        self.model.on_after_backward()
+
+    def run(self, batch, bi):
+        if self.stream is None:
+            return self._run(batch, bi)
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self._run(batch, bi)
+        cur.wait_stream(self.stream)
+
+    def _run(self, batch, bi):
+        if self.enabled and not self.failed and self.staged:
+            sig = GraphedStep.signature(batch)
+            entry = self.graphs.get(sig)
+            if entry is None:
+                n = self.seen.get(sig, 0)
+                self.seen[sig] = n + 1
+                if n >= self.WARMUP and len(self.graphs) < self.max_graphs:
+                    entry = self._capture(batch, bi)
+                    if entry is not None:
+                        self.graphs[sig] = entry
+            if entry is not None:
+                static, graphs, logged, touched = entry
+                if self._done is not None:
+                    self._done.synchronize()                     # the previous replay has finished reading the static inputs (GraphedStep.run)
+                torch._foreach_copy_(list(static.values()), [batch[k] for k in static])
+                self.buckets.begin_replay(touched)
+                for k, g in enumerate(graphs):
+                    g.replay()
+                    self._log('replay{}'.format(k))
+                    self.buckets.reduce(k)                       # asynchronous: on the wire while the next sub-graph runs
+                self.replayed = True
+                if self._done is None:
+                    self._done = torch.cuda.Event()
+                self._done.record()
+                self.metrics.values = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in logged.items()}
+                return
+        self.eager(batch, bi)
+
+    def _capture(self, batch, bi):
+        static = {k: v.clone() for k, v in batch.items() if torch.is_tensor(v)}
+        rest = {k: v for k, v in batch.items() if isinstance(v, (int, float, bool, str)) and not k.startswith('_')}
+        graphs = [torch.cuda.CUDAGraph() for _ in range(train_graph.N_STAGES)]
+        try:
+            torch.cuda.synchronize()
+            with train_graph.staged() as st:
+                with torch.cuda.graph(graphs[0], stream=self.stream, capture_error_mode='thread_local'):
+                    scaled = self._forward(dict(static, **rest), bi)
+                    st.run_stage(0, scaled)
+                    self.buckets.pack(0)
+                assert st.n_stages == train_graph.N_STAGES
+                for k in range(1, train_graph.N_STAGES):
+                    # the later stages read what graph 0 left in ITS memory (saved activations, the cuts' gradients): one pool, fixed replay order
+                    with torch.cuda.graph(graphs[k], pool=graphs[0].pool(), stream=self.stream, capture_error_mode='thread_local'):
+                        st.run_stage(k)
+                        self.buckets.pack(k)
+                del scaled
+                st.release()
+            self.model.on_after_backward()
+            logged = dict(self.metrics.values)
+        except Exception as exc:
+            self.failed = True
+            if os.environ.get('PPS_FIT_GRAPH_DEBUG'):
+                import traceback
+                traceback.print_exc()
+            print('fit: HIP-graph capture of the staged step failed ({}: {}); continuing eagerly'.format(type(exc).__name__, str(exc).split('\n')[0]))
+            torch.cuda.synchronize()
+            if self.on_capture_failed is not None:
+                self.on_capture_failed()
+            return None
+        return static, graphs, logged, set(self.buckets.touched)
+
+
 class HostGcPacer:
     """Python's cyclic garbage collector paused for the duration of a step loop.  Every step allocates a few hundred tensor / dict / tuple objects, so
     the collector's oldest generation comes due every ~80 steps and walks every live object of the process (all modules, parameters, cached plans):
@@ -272,7 +401,8 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
         import torch.distributed as dist
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src=0)
-    buckets = sharding.GradBuckets(params, defer=split_graph)
+    # several ranks: bucket k = the parameters backward stage k completes (train_graph.parameter_stages), all-reduced while stage k + 1 runs
+    buckets = sharding.GradBuckets(params, defer=world > 1, groups=train_graph.parameter_stages(model) if world > 1 else None)
     out_dir = os.path.join('models', str(getattr(model, 'name', 'model')), 'version_0')
     ckpt_file = os.path.join(out_dir, 'checkpoints', 'last.ckpt')
     metrics = _MetricLog()
@@ -304,22 +434,17 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
         if per_opt is not None:
             per_opt.clear()
 
-    def eager_step(batch, bi):
-        sharding.broadcast_buffers(model)
+    def eager_step(batch, bi):                                 # one rank: the whole step, what GraphedStep records and replays
         compute_step(batch, bi)
         apply_step()
 
-    def compute_step(batch, bi):                               # no collective, no optimizer: what the multi-rank run replays as a graph
+    def compute_step(batch, bi):
         buckets.zero()
         metrics.values = {}
         with ctx:
             loss = model.training_step(batch, bi)
         scaler.scale(loss).backward()
         model.on_after_backward()
-        if buckets.defer:
-            # this body may be recorded into a HIP graph: every bucket -> flat copy has to be part of the recording, also for buckets the hooks
-            # did not complete (a bucket holding a parameter without gradient), or a replay would all-reduce buffers nobody filled
-            buckets.pack_all()
 
     def apply_step():
         buckets.finish()
@@ -327,11 +452,12 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
         scaler.update()
         train_graph.release_step_caches()
 
-    if split_graph:
-        # several ranks: the gradient all-reduces (and the buffer broadcast) stay ordinary eager collectives AROUND a replayed forward +
-        # backward; they lose their overlap with the backward pass (~1 ms for 55 MB over xGMI) and the rank its ~25 ms of Python per step
-        core = GraphedStep(compute_step, metrics, enabled=True, after_capture=lambda: set(buckets.touched), after_replay=buckets.replayed,
-                           on_capture_failed=reset_host_state)
+    if world > 1:
+        # several ranks: forward + backward in stages (eager or as one replayed HIP graph per stage) with the bucket all-reduces issued between the
+        # stages (StagedStep); buffer broadcast, the mask collective and the optimizer run eagerly around it
+        core = StagedStep(model, buckets, scaler, ctx, metrics, enabled=split_graph, on_capture_failed=reset_host_state)
+        if os.environ.get('PPS_FIT_ORDER_LOG'):
+            buckets.order_log = []
 
         class _Split:
             graphs, failed = core.graphs, False
@@ -394,6 +520,10 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
             break
     if mfile is not None:
         mfile.close()
+    if buckets.order_log is not None:                          # PPS_FIT_ORDER_LOG=1 (tests): the host order of stage replays and bucket collectives
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, 'order_rank{}.json'.format(rank)), 'w') as f:
+            json.dump(buckets.order_log, f)
     model.__dict__.pop('_fit_log', None)
     if (use_graph or split_graph) and rank == 0:
         print('fit: HIP-graph replay of the step: {} graph(s) captured{}'.format(len(stepper.graphs), ', capture FAILED (ran eagerly)' if stepper.failed else ''))

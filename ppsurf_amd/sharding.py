@@ -169,12 +169,13 @@ class GradBuckets:
     messages: a ring all-reduce over xGMI is per-link bound (~153 GB/s), so 55 MB of fp32 gradients cost ~1 ms as 3 buckets
     and far more as 455 per-tensor collectives."""
 
-    def __init__(self, params, n_buckets=3, defer=False, comm_dtype=None):
-        """defer: no collective inside backward (fit with the forward / backward replayed as a HIP graph; hooks do not fire in a replay): all
-            buckets are all-reduced behind the replay.  Starting bucket 0's collective while the replayed backward still produces buckets 1, 2
-            would need an event recorded INSIDE the graph that another stream can wait on (an "external" event); torch-ROCm 2.10 refuses those
-            ("External events are disallowed in rocm", tried in round 3), and RCCL collectives captured into the graph cannot be exercised on
-            the single-GPU boxes available here -- so the deferred collectives stay serial behind the step (~1 ms for 55 MB over xGMI).
+    def __init__(self, params, n_buckets=3, defer=False, comm_dtype=None, groups=None):
+        """groups: explicit buckets (a list of parameter lists; default: `n_buckets` of equal size in reverse registration order).  fit passes the
+            groups of train_graph.parameter_stages: bucket k = the parameters whose gradients backward stage k completes.
+        defer: no collective inside backward -- the hooks only count (they do not fire in a replayed HIP graph anyway).  The caller issues the
+            collectives itself: reduce(k) right after the piece of the backward pass that completes bucket k (fit: after the replay of sub-graph k,
+            so that the all-reduce of bucket k overlaps sub-graph k + 1 -- what DDP's hooks do in the reference's Lightning run); whatever was not
+            issued that way goes out in finish().
         comm_dtype (default: environment PPS_GRAD_BUCKET_DTYPE, e.g. 'bf16'): the buckets are summed over the ranks in this type (half the xGMI
             bytes, 27.5 instead of 55 MB per step); the flat fp32 buffers the optimizer reads stay fp32."""
         import torch.distributed as dist
@@ -184,17 +185,24 @@ class GradBuckets:
             comm_dtype = {'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16, 'f16': torch.float16, '': None, 'f32': None}[os.environ.get('PPS_GRAD_BUCKET_DTYPE', '')]
         self.comm_dtype = comm_dtype
         self.params = [p for p in params if p.requires_grad]
-        rev = list(reversed(self.params))                                     # roughly the order of gradient production
-        total = sum(p.numel() for p in rev)
-        self.buckets, cur, size = [], [], 0
-        for p in rev:
-            cur.append(p)
-            size += p.numel()
-            if size >= total / n_buckets and len(self.buckets) < n_buckets - 1:
+        if groups is not None:
+            self.buckets = [[p for p in g if p.requires_grad] for g in groups]
+            self.buckets = [b for b in self.buckets if b]
+            ids = [id(p) for b in self.buckets for p in b]
+            if len(ids) != len(set(ids)) or set(ids) != {id(p) for p in self.params}:
+                raise ValueError('GradBuckets: `groups` must partition the parameters that require a gradient')
+        else:
+            rev = list(reversed(self.params))                                 # roughly the order of gradient production
+            total = sum(p.numel() for p in rev)
+            self.buckets, cur, size = [], [], 0
+            for p in rev:
+                cur.append(p)
+                size += p.numel()
+                if size >= total / n_buckets and len(self.buckets) < n_buckets - 1:
+                    self.buckets.append(cur)
+                    cur, size = [], 0
+            if cur:
                 self.buckets.append(cur)
-                cur, size = [], 0
-        if cur:
-            self.buckets.append(cur)
         self.flat, self.views, self.pending, self.handles, self.launched = [], [], [], [], []
         for bi, bucket in enumerate(self.buckets):
             flat = torch.zeros(sum(p.numel() for p in bucket), dtype=torch.float32, device=bucket[0].device)
@@ -213,6 +221,7 @@ class GradBuckets:
         self._static_dev = None
         self._mismatch = None                       # device flag: a later step's global mask differed from the first step's
         self._steps = 0
+        self.order_log = None                       # tests: a list that receives 'reduce<k>' when bucket k's collective is issued
         self._reset()
         self._armed = False                         # hooks stay inert until the first zero(): a backward pass outside zero() ... finish() is not ours
 
@@ -227,6 +236,7 @@ class GradBuckets:
             self.pending = list(self._expect)
         self.handles = []
         self.launched = [False] * len(self.buckets)
+        self.reduced = [False] * len(self.buckets)  # the bucket's collective has been issued
         self.touched = set()
         self._replay = False
         self._next = 0                              # first bucket whose collective has not been issued yet
@@ -270,7 +280,25 @@ class GradBuckets:
             for v, p in pairs:
                 p.grad = v
         if ws > 1 and not self.defer and collective:
+            self.reduced[bi] = True
             self.handles.append(self._all_reduce(bi))
+
+    def pack(self, bi):
+        """Bucket bi -> its flat buffer, no collective (the end of a backward stage that is being recorded into a HIP graph)."""
+        if not self.launched[bi]:
+            self._launch(bi, collective=False)
+
+    def reduce(self, bi):
+        """Issue the (asynchronous) all-reduce of bucket bi now; finish() waits for it.  Buckets go out in index order on every rank."""
+        _, ws = world()
+        if ws == 1 or self.reduced[bi]:
+            return
+        assert all(self.reduced[:bi]), 'gradient buckets are all-reduced in index order'
+        self.pack(bi)
+        self.reduced[bi] = True
+        self.handles.append(self._all_reduce(bi))
+        if self.order_log is not None:
+            self.order_log.append('reduce{}'.format(bi))
 
     def _all_reduce(self, bi):
         """Asynchronous sum of bucket bi over the ranks (in comm_dtype if set); returns something with .wait()."""
@@ -288,12 +316,19 @@ class GradBuckets:
                 flat.copy_(low)
         return _Back
 
+    def begin_replay(self, touched):
+        """Host-side start of a step whose forward / backward will be REPLAYED from HIP graphs (no Python runs: neither zero() nor the hooks): the
+        buckets are packed by the graphs themselves, `touched` = the parameters that received a gradient when the graphs were recorded."""
+        self.handles = []
+        self.reduced = [False] * len(self.buckets)
+        self.replayed(touched)
+        self._armed = True
+
     def replayed(self, touched):
         """The forward / backward of this step ran as a replayed HIP graph: none of the Python hooks fired.  `touched` = ids of the
         parameters that received a gradient when the graph was captured (their p.grad already are the bucket views)."""
         self.touched = set(touched)
         self.launched = [True] * len(self.buckets)
-        self.handles = []
         self._replay = True                         # the set was fixed at capture time, identically on every rank (same graph everywhere)
 
     def zero(self):
@@ -310,8 +345,11 @@ class GradBuckets:
         for bi in range(len(self.buckets)):
             if not self.launched[bi]:
                 self._launch(bi)
-        if ws > 1 and self.defer:                   # collectives kept out of a captured forward / backward: all buckets now
-            self.handles = [self._all_reduce(bi) for bi in range(len(self.buckets))]
+        if ws > 1:                                  # whatever the caller (defer) or the hooks have not sent yet, in index order
+            for bi in range(len(self.buckets)):
+                if not self.reduced[bi]:
+                    self.reduced[bi] = True
+                    self.handles.append(self._all_reduce(bi))
         for h in self.handles:
             h.wait()
         if ws > 1:

@@ -92,6 +92,37 @@ def _cast_all(params, dtype):
     return True
 
 
+_shadow_t = {}               # id(parameter) -> 16-bit image of the parameter as a [K, N] matrix (N = shape[0]): the A operand of the input-gradient product
+_tr_tables = {}              # like _cast_tables, for pps_transpose_cast_pieces
+
+
+def _transpose_all(params, dtype):
+    """Transposed images of every matrix-shaped parameter in ONE launch (pps_transpose_cast_pieces).  False: not possible now (see _cast_all)."""
+    code = {torch.bfloat16: 1, torch.float16: 2}.get(dtype)
+    mats = [p for p in params if p.dim() >= 2]
+    if code is None or not mats or len({p.device for p in mats}) != 1 or any(not p.is_contiguous() for p in mats):
+        return False
+    from . import _lib
+    import numpy as np
+    dev = mats[0].device
+    key = tuple((p.data_ptr(), _shadow_t[id(p)].data_ptr(), p.shape[0], p.numel() // p.shape[0]) for p in mats)
+    cached = _tr_tables.get((dev, dtype, key))
+    if cached is None:
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        assert _lib.lib().pps_transpose_entry_bytes() == 32
+        rows, tile0 = [], 0
+        for sp, dp, n, k in key:
+            rows.append((sp, dp, n | (k << 32), tile0))                       # {src, dst, int32 n, int32 k, int64 tile0}, little endian
+            tile0 += ((n + 31) // 32) * ((k + 31) // 32)
+        cached = (key, torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev), len(rows), tile0)
+        _tr_tables[(dev, dtype, key)] = cached
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().pps_transpose_cast_pieces(cached[1].data_ptr(), cached[2], cached[3], code, torch.cuda.current_stream(dev).cuda_stream),
+                   'pps_transpose_cast_pieces')
+    return True
+
+
 def prepare_shadows(module, dtype=torch.bfloat16):
     """Call at the start of an autocast forward pass in train(): parameters -> persistent images in the autocast type (bf16 / fp16)."""
     params = [p for p in module.parameters() if p.is_cuda and p.dtype == torch.float32]
@@ -104,6 +135,16 @@ def prepare_shadows(module, dtype=torch.bfloat16):
                 _shadow[id(p)] = torch.empty_like(p, dtype=dtype)
         if not _cast_all(params, dtype):
             torch._foreach_copy_([_shadow[id(p)] for p in params], params)
+        for p in params:
+            if p.dim() >= 2:
+                t = _shadow_t.get(id(p))
+                shape = (p.numel() // p.shape[0], p.shape[0])
+                if t is None or tuple(t.shape) != shape or t.device != p.device or t.dtype != dtype:
+                    _shadow_t[id(p)] = torch.empty(shape, device=p.device, dtype=dtype)
+        if not _transpose_all(params, dtype):
+            for p in params:
+                if p.dim() >= 2:
+                    _shadow_t[id(p)].copy_(p.reshape(p.shape[0], -1).t())
     for p in params:
         _shadow_ver[id(p)] = p._version
     _shadow_live[0] = True
@@ -120,6 +161,13 @@ def _bf16_of(param):
     return t
 
 
+def _bf16_t_of(param):
+    """The transposed 16-bit image [K, N] of a matrix-shaped parameter, under the same conditions as _bf16_of."""
+    if _bf16_of(param) is None:
+        return None
+    return _shadow_t.get(id(param))
+
+
 _mm_fp32_out = [True]
 
 
@@ -134,33 +182,59 @@ def _mm_f32(a, b):
 
 
 class _RowsLinear(torch.autograd.Function):
-    """y = x W^T + b for a tall-skinny x [rows, K] (rows = all points / patch points / neighbours of the batch, K <= 512).
+    """y = x W^T + b for x [rows, K] (rows = all points / patch points / neighbours of the batch).
 
-    The forward and the input gradient are bandwidth-bound library GEMMs (0.33 ms for 1.28 M x 256 x 256 in bf16).  The weight
-    gradient dW = g^T x contracts over the ROWS; hipBLASLt runs that shape 6-20x off its bandwidth bound (1.9 ms), so it is
-    computed split-K: the rows are cut into S = 128 slabs, one batched GEMM produces S partial [N, K] products with fp32
-    accumulation and the partials are summed in fp32 (0.33 ms; 0.06 ms instead of 1.3 ms for the 64-channel PointNet layers)."""
+    Device tensors under 16-bit autocast: the three products are the hand-written kernels of csrc/pps_gemm_train.hip for ANY layer shape
+    (train_ops.gemm_nt for the forward and -- with the transposed weight image -- the input gradient, train_ops.gemm_tn for the weight gradient,
+    whose contraction runs over the rows: row slabs with fp32 partials summed in a fixed order), the bias gradient is the column-sum kernel.
+    Until round 4 these were library GEMMs (hipBLASLt behind F.linear / mm / a split-K bmm); they remain only for fp32 / float64 tensors
+    (trainer.precision 32, the CPU suite's torch twins) and for K that is not a multiple of 8 (the 3-channel offset layer of the unfused head)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, wc=None, bc=None):
+    def forward(ctx, x, w, b, wc=None, bc=None, wt=None):
         dev = x.device.type
         dt = torch.get_autocast_dtype(dev) if torch.is_autocast_enabled(dev) else x.dtype
         xc = x.to(dt)
-        wc = wc if (wc is not None and wc.dtype == dt) else w.to(dt)            # wc / bc: bf16 images of the step (prepare_shadows)
+        wc = wc if (wc is not None and wc.dtype == dt) else w.to(dt)            # wc / bc: 16-bit images of the step (prepare_shadows)
+        n, k = wc.shape
+        ctx.own = train_ops.gemm_supported(xc, k) and xc.dim() == 2
+        if ctx.own:
+            npad = (n + 7) // 8 * 8                                             # (the 256 -> 2 output layer: zero rows up to a multiple of 8)
+            if npad != n:
+                wc = torch.cat([wc, wc.new_zeros((npad - n, k))])
+                wt = None
+            bias = None if b is None else (b.detach().float() if npad == n else torch.cat([b.detach().float(), b.new_zeros(npad - n, dtype=torch.float32)]))
+            y = train_ops.gemm_nt(xc, wc, bias)
+            if npad != n:
+                y = y[:, :n].contiguous()
+            ctx.save_for_backward(xc, wc, wt if (wt is not None and wt.dtype == dt) else None)
+            ctx.meta = (x.dtype, w.dtype, None if b is None else b.dtype, n)
+            return y
         bc = None if b is None else (bc if (bc is not None and bc.dtype == dt) else b.to(dt))
         with torch.autocast(dev, enabled=False):
             y = F.linear(xc, wc, bc)
-        ctx.save_for_backward(xc, wc)
-        ctx.meta = (x.dtype, w.dtype, None if b is None else b.dtype)
+        ctx.save_for_backward(xc, wc, None)
+        ctx.meta = (x.dtype, w.dtype, None if b is None else b.dtype, n)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        xc, wc = ctx.saved_tensors
-        xdt, wdt, bdt = ctx.meta
+        xc, wc, wt = ctx.saved_tensors
+        xdt, wdt, bdt, n = ctx.meta
         g = g.to(xc.dtype).contiguous()
-        acc = torch.float64 if xc.dtype == torch.float64 else torch.float32
         dx = dw = db = None
+        if ctx.own:
+            npad = wc.shape[0]
+            gp = g if npad == n else F.pad(g, (0, npad - n))
+            if ctx.needs_input_grad[0]:
+                dx = train_ops.gemm_nt(gp, wt if wt is not None else wc.t().contiguous()).to(xdt)      # dx = g W: NT product with the [K, N] image
+            if ctx.needs_input_grad[1]:
+                dw = train_ops.gemm_tn(gp, xc)[:n].to(wdt)
+            if bdt is not None and ctx.needs_input_grad[2]:
+                db = train_ops.col_sum(g)
+                db = (g.sum(0, dtype=torch.float32) if db is None else db).to(bdt)
+            return dx, dw, db, None, None, None
+        acc = torch.float64 if xc.dtype == torch.float64 else torch.float32
         if ctx.needs_input_grad[0]:
             dx = (g @ wc).to(xdt)
         if ctx.needs_input_grad[1]:
@@ -178,19 +252,25 @@ class _RowsLinear(torch.autograd.Function):
         if bdt is not None and ctx.needs_input_grad[2]:
             db = train_ops.col_sum(g) if acc == torch.float32 else None
             db = (g.sum(0, dtype=acc) if db is None else db).to(bdt)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def rows_linear(x, w, b=None, wc=None, bc=None):
-    if x.dim() == 2 and (x.shape[0] >= SPLITK_MIN_ROWS or wc is not None):
-        return _RowsLinear.apply(x, w, b, wc, bc)
+def _own_gemm(x, k):
+    dev = x.device.type
+    return (x.is_cuda and x.dim() == 2 and torch.is_autocast_enabled(dev) and torch.get_autocast_dtype(dev) in train_ops.LOW and k % 8 == 0 and k >= 8
+            and x.shape[0] > 0)
+
+
+def rows_linear(x, w, b=None, wc=None, bc=None, wt=None):
+    if x.dim() == 2 and (x.shape[0] >= SPLITK_MIN_ROWS or wc is not None or _own_gemm(x, w.shape[1])):
+        return _RowsLinear.apply(x, w, b, wc, bc, wt)
     return F.linear(x, w, b)
 
 
 def dense(layer, x):
     """1x1 Conv1d / Conv2d / Linear holder applied to rows."""
     wc = _bf16_of(layer.weight)
-    return rows_linear(x, _w2d(layer), layer.bias, None if wc is None else wc.reshape(wc.shape[0], -1), _bf16_of(layer.bias))
+    return rows_linear(x, _w2d(layer), layer.bias, None if wc is None else wc.reshape(wc.shape[0], -1), _bf16_of(layer.bias), _bf16_t_of(layer.weight))
 
 
 _counters = []
@@ -310,6 +390,104 @@ def release_step_caches():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# backward in stages (gradient all-reduce overlapped with the rest of backward, also when the step is replayed as HIP graphs)
+# ---------------------------------------------------------------------------------------------------------------------
+class BackwardStages:
+    """The backward pass cut into consecutive pieces at tensors of the forward pass ("cuts"), so that whatever runs BETWEEN two pieces -- the
+    all-reduce of the gradients the previous piece completed -- overlaps the next piece.  Lightning DDP, which the reference trains under
+    (configs/device_server.yaml:2, source/base/mp.py:85-91), gets that overlap from autograd hooks; hooks do not fire in a replayed HIP graph, so
+    here every piece can be recorded as its own graph and the collectives are issued between the replays (ppsurf_amd/fit.py).
+
+    cut(*tensors) replaces each tensor by a detached leaf for everything that follows in the forward pass and remembers the pair.
+    Stage 0 = loss.backward(): gradients of everything behind the last cut, and of that cut's leaves.  Stage k = torch.autograd.backward(originals
+    of the k-th cut from the end, their leaves' gradients): the same chain rule, evaluated in the same order by the same kernels -- gradients are
+    bit-identical to a single backward pass (tests/test_train_graph_cpu.py::test_staged_backward_*)."""
+
+    def __init__(self):
+        self.cuts = []
+
+    def cut(self, tensors):
+        leaves = [t.detach().requires_grad_(True) if t.requires_grad else t for t in tensors]
+        self.cuts.append((list(tensors), leaves))
+        return leaves
+
+    @property
+    def n_stages(self):
+        return len(self.cuts) + 1
+
+    def run_stage(self, k, loss=None):
+        if k == 0:
+            loss.backward()
+            return
+        orig, leaves = self.cuts[len(self.cuts) - k]
+        pairs = [(o, l.grad) for o, l in zip(orig, leaves) if o.requires_grad and l.grad is not None]
+        if pairs:
+            torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
+
+    def backward(self, loss, after_stage=None):
+        try:
+            for k in range(self.n_stages):
+                self.run_stage(k, loss)
+                if after_stage is not None:
+                    after_stage(k)
+        finally:
+            self.release()
+
+    def release(self):
+        """Drop the cut tensors (and with them the autograd graph of the step).  A graph that outlives its step keeps the parameters' AccumulateGrad
+        nodes -- and the stream they were created on -- alive; a later HIP-graph capture on another stream would then fork that stream into the
+        capture (hipStreamEndCapture faults on the unjoined branch: tools/dbg notes in profiles/NOTES_r5.md)."""
+        self.cuts = []
+
+
+_stages = [None]
+
+
+class staged:
+    """with staged() as st: ... forward ...; st.backward(loss)   -- the encoder places its cuts while this is active."""
+
+    def __enter__(self):
+        self.prev = _stages[0]
+        _stages[0] = BackwardStages()
+        return _stages[0]
+
+    def __exit__(self, *exc):
+        _stages[0] = self.prev
+        return False
+
+
+def _cut(*tensors):
+    st = _stages[0]
+    if st is None or not torch.is_grad_enabled():
+        return tensors
+    return st.cut(tensors)
+
+
+N_STAGES = 3
+# parameters by the backward stage that completes their gradient (module names of the encoder, source/base/nn.py:455-506): the cuts of encoder()
+# sit behind resnetb31 and behind resnetb11.  Stage 0 -- decoder, the encoder's up-sampling head and its two coarsest levels -- holds 82 % of the
+# 13.75 M parameters and is complete when 70 % of the backward pass (the fine levels: 100 000 and 25 000 rows per batch of 10) is still to run.
+_STAGE_PREFIX = {2: ('cv0.', 'bn0.', 'resnetb01.', 'resnetb10.', 'resnetb11.'), 1: ('resnetb20.', 'resnetb21.', 'resnetb30.', 'resnetb31.')}
+
+
+def parameter_stages(module):
+    """[[parameters of stage 0], [stage 1], [stage 2]] of a model holding `network.encoder` (any module: parameters whose name has no
+    '.encoder.<block>' part are stage 0), each in reverse registration order (roughly the order backward produces them)."""
+    groups = [[] for _ in range(N_STAGES)]
+    for name, p in module.named_parameters():
+        if not p.requires_grad:
+            continue
+        stage = 0
+        if 'encoder.' in name:
+            tail = name.split('encoder.', 1)[1]
+            for k, prefixes in _STAGE_PREFIX.items():
+                if tail.startswith(prefixes):
+                    stage = k
+        groups[stage].append(p)
+    return [list(reversed(g)) for g in groups]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # encoder
 # ---------------------------------------------------------------------------------------------------------------------
 def pack_geo(layer):
@@ -336,7 +514,8 @@ def fkaconv_layer(layer, x, pts, sup, ids):
             layer.norm_radius.copy_(radius.detach().reshape(layer.norm_radius.shape))
     feat = train_ops.neighbour_contract(x.reshape(b * n, cin), flat, g)                  # [B*M, Cin*16]
     wc = _bf16_of(layer.cv.weight)
-    return rows_linear(feat, _w2d(layer.cv), None, None if wc is None else wc.reshape(wc.shape[0], -1)).view(b, m, -1)   # Conv2d (1,16): (c,t) -> c*16+t
+    return rows_linear(feat, _w2d(layer.cv), None, None if wc is None else wc.reshape(wc.shape[0], -1), None,
+                       _bf16_t_of(layer.cv.weight)).view(b, m, -1)   # Conv2d (1,16): (c,t) -> c*16+t
 
 
 @_counted
@@ -375,10 +554,12 @@ def encoder(enc, data):
     x0 = residual_block(enc.resnetb01, x0, pts, pts, data['ids00'])
     x1 = residual_block(enc.resnetb10, x0, pts, s1, data['ids01'])
     x1 = residual_block(enc.resnetb11, x1, s1, s1, data['ids11'])
+    x0, x1 = _cut(x0, x1)                                     # backward stage 2 = everything above (BackwardStages; no-op unless staged() is active)
     x2 = residual_block(enc.resnetb20, x1, s1, s2, data['ids12'])
     x2 = residual_block(enc.resnetb21, x2, s2, s2, data['ids22'])
     x3 = residual_block(enc.resnetb30, x2, s2, s3, data['ids23'])
     x3 = residual_block(enc.resnetb31, x3, s3, s3, data['ids33'])
+    x0, x1, x2, x3 = _cut(x0, x1, x2, x3)                     # backward stage 1 = the two levels above; stage 0 = everything below
     x4 = residual_block(enc.resnetb40, x3, s3, s4, data['ids34'])
     x4 = residual_block(enc.resnetb41, x4, s4, s4, data['ids44'])
 

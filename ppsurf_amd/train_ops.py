@@ -351,6 +351,47 @@ def col_sum(x):
     return out
 
 
+def gemm_supported(x, k):
+    """The hand-written dense-layer kernels (csrc/pps_gemm_train.hip) take this operand: device tensor in a 16-bit storage type, contraction length a
+    multiple of 8."""
+    return x.is_cuda and x.dtype in LOW and k % 8 == 0 and k >= 8
+
+
+def gemm_nt(x, w, bias=None, out_f32=False):
+    """x [M, K] @ w [N, K]^T (+ bias [N] fp32) -> [M, N] in x's 16-bit type (or fp32): pps_gemm_nt_16.  No autograd (called from autograd functions)."""
+    _need_cuda(x, w)
+    assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1] and x.dtype == w.dtype and x.dtype in LOW
+    if x.stride(1) != 1 or x.stride(0) % 8 or x.data_ptr() % 16:
+        x = x.contiguous()
+    if w.stride(1) != 1 or w.stride(0) % 8 or w.data_ptr() % 16:
+        w = w.contiguous()
+    m, k = x.shape
+    n = w.shape[0]
+    y = torch.empty((m, n), device=x.device, dtype=torch.float32 if out_f32 else x.dtype)
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    _lib.check(_lib.lib().pps_gemm_nt_16(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), None if b32 is None else b32.data_ptr(), y.data_ptr(), n,
+                                         m, n, k, _code(x.dtype), int(bool(out_f32)), _stream()), 'pps_gemm_nt_16')
+    return y
+
+
+def gemm_tn(g, x):
+    """g [M, N]^T @ x [M, K] -> fp32 [N, K] (the weight gradient of a row layer: contraction over the rows): pps_gemm_tn_16.  N, K multiples of 8."""
+    _need_cuda(g, x)
+    assert g.dim() == 2 and x.dim() == 2 and g.shape[0] == x.shape[0] and g.dtype == x.dtype and g.dtype in LOW
+    if g.stride(1) != 1 or g.stride(0) % 8 or g.data_ptr() % 16:
+        g = g.contiguous()
+    if x.stride(1) != 1 or x.stride(0) % 8 or x.data_ptr() % 16:
+        x = x.contiguous()
+    m, n = g.shape
+    k = x.shape[1]
+    L = _lib.lib()
+    dw = torch.empty((n, k), device=g.device, dtype=torch.float32)
+    ws = torch.empty((max(int(L.pps_gemm_tn_ws_bytes(m, n, k)), 16),), device=g.device, dtype=torch.uint8)
+    _lib.check(L.pps_gemm_tn_16(g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), m, n, k, _code(g.dtype), dw.data_ptr(), ws.data_ptr(), _stream()),
+               'pps_gemm_tn_16')
+    return dw
+
+
 class _AttnPool(torch.autograd.Function):
     """pooled[q] = sum_j mean_h softmax_j(qy[q,j,h]) * h[q,j]  (poco_model.py:412-414 in the pooled form): one HIP kernel forward, one
     backward; fp32 or bf16 storage, fp32 arithmetic; the softmax is recomputed in backward, only the two inputs are saved."""

@@ -378,6 +378,40 @@ def test_config4_unit_of_work_one_abc_shape_at_r257_learned_weights(trained):
     assert two > 0.999 and multi == 0                           # closed 2-manifold (open edges only where the surface leaves the evaluated band)
 
 
+def test_config4_r257_volume_equals_the_oracle_driver_on_the_same_decoder(trained):
+    """BASELINE config 4 at size, pinned on the DRIVER: the R = 257 region-growing volume of a real ABC shape by the product
+    (device masks, de-duplicated frontier, ChunkPipeline lanes; ppsurf_amd/reconstruct.py) against oracle.create_volume -- the CPU restatement of
+    source/poco_utils.py:178-254, which is pinned to the reference's own `_create_volume` by tests/golden/create_volume.npz -- driven by the SAME
+    learned decoder through a second OccupancyField.  35 minutes of CPU decoding are replaced by 6 M GPU queries; what is compared is everything
+    else: which voxels are visited in which round, the +-2 dilation, the frontier rule, the borders.  The decoder's kernels are chunk-invariant
+    (a query's occupancy does not depend on the batch it is in), so the two volumes are EQUAL, not close -- although the oracle driver evaluates
+    2.3 x as many queries (it re-evaluates voxels, poco_utils.py:212-223) in other chunk boundaries."""
+    from ppsurf_amd import reconstruct
+    import bench_workloads as workloads
+    root, ckpt = trained
+    model = _trained_model(root, ckpt, 257)
+    cloud = _abc_cloud(root)
+    pts_cf = torch.from_numpy(cloud).to(DEV).t().contiguous()
+    torch.manual_seed(11)
+    lat = model.encode_latents(pts_cf)
+    shape = {'pts': pts_cf.unsqueeze(0), 'latents': lat.t().unsqueeze(0)}
+    step, bmin_pad, pts_ids = workloads.grid_geometry(cloud, 257)
+    field = reconstruct.OccupancyField(model.network, shape, pts_cf.t().unsqueeze(0), 50000, 50)
+    vol = reconstruct.create_volume(field, torch.from_numpy(pts_ids).to(DEV), 257, step, bmin_pad).cpu().numpy()
+    probe = reconstruct.OccupancyField(model.network, shape, pts_cf.t().unsqueeze(0), 50000, 50)
+
+    def eval_occ(q):
+        return probe(torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).to(DEV)).cpu().numpy()
+
+    ref, n_eval = O.create_volume(eval_occ, pts_ids, 257, step, bmin_pad, 50000)
+    seen = ~np.isnan(ref)
+    print('R=257 volume: {} voxels evaluated by the product ({} decoder queries), {} by the oracle driver'.format(int(seen.sum()), field.n_queries, n_eval))
+    assert np.array_equal(np.isnan(vol), np.isnan(ref))
+    assert np.array_equal(vol[seen], ref[seen])
+    inner = int(seen[1:-1, 1:-1, 1:-1].sum())
+    assert 1_000_000 < inner <= field.n_queries < n_eval and field.n_queries - inner < 0.02 * inner      # every visited voxel decoded once (+ border voxels)
+
+
 def test_marching_cubes_and_clean_up_on_a_learned_volume_meet_the_specification(trained):
     """f2: the volume of a LEARNED network (abc_mini4 fit) at R = 65 through the device Marching Cubes + clean-up against the independent
     specification of oracle/mesh_oracle.py (vertex set = grid-edge crossings, closed oriented manifold, one cube per face, union-find

@@ -88,7 +88,7 @@ def test_two_rank_fit_keeps_the_replicas_identical(tmp_path, mode):
                       "m = runner.main(['pps.py', 'fit'] + {a!r})\n"
                       "torch.save({{k: v.cpu() for k, v in m.state_dict().items()}}, os.path.join({o!r}, 'sd_r' + os.environ['RANK'] + '.pt'))\n"
                       .format(r=REPO, a=paths, o=str(tmp_path)))
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', PPS_BACKEND='gloo')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', PPS_BACKEND='gloo', PPS_FIT_ORDER_LOG='1')
     env.update({'bf16': {'PPS_GRAD_BUCKET_DTYPE': 'bf16'}}.get(mode, {}))
 
     def launch(e, port):
@@ -104,3 +104,13 @@ def test_two_rank_fit_keeps_the_replicas_identical(tmp_path, mode):
     assert any(not torch.equal(a[k], b[k]) for k in a if 'running_mean' in k)     # buffers are rank-local (different shapes)
     state = torch.load(tmp_path / 'models' / model_name / 'version_0' / 'checkpoints' / 'last.ckpt', map_location='cpu')
     assert state['global_step'] == 8                                       # 4 shapes / 2 ranks / batch 1 x 4 epochs
+    # all-reduce / backward overlap (fit.StagedStep): the backward pass runs in three stages -- eagerly for the first steps, then as three replayed
+    # sub-graphs -- and bucket k's collective is issued right behind stage k, i.e. BEFORE the next stage starts, on both ranks in the same order
+    import json
+    logs = [json.load(open(tmp_path / 'models' / model_name / 'version_0' / 'order_rank{}.json'.format(r))) for r in (0, 1)]
+    assert logs[0] == logs[1]
+    eager = ['stage0', 'reduce0', 'stage1', 'reduce1', 'stage2', 'reduce2']
+    replay = ['replay0', 'reduce0', 'replay1', 'reduce1', 'replay2', 'reduce2']
+    steps = [logs[0][i:i + 6] for i in range(0, len(logs[0]), 6)]
+    assert len(steps) == 8 and all(st in (eager, replay) for st in steps), steps
+    assert steps[0] == eager and steps[-1] == replay and sum(st == replay for st in steps) >= 4

@@ -131,6 +131,43 @@ def _grad_worker(rank, world, port, out_dir):
         b5.finish()
         out['g_defer{}'.format(step)] = torch.cat([p.grad.reshape(-1) for p in net5.parameters()]).numpy().copy()
         out['defer_unused_none{}'.format(step)] = np.array([p.grad is None for p in unused5.parameters()])
+    # all-reduce / backward overlap (fit.StagedStep): explicit buckets = the parameters each backward STAGE completes, the collective of bucket k issued
+    # by the caller right behind stage k (reduce(k)), before the next stage starts; finish() only waits and averages
+    net6 = copy.deepcopy(net)
+    groups = [list(net6[4].parameters())[::-1], list(net6[2].parameters())[::-1], list(net6[0].parameters())[::-1]]
+    b6 = GradBuckets(list(net6.parameters()), defer=True, groups=groups)
+    b6.order_log = []
+    assert [len(b) for b in b6.buckets] == [2, 2, 2]
+    for step in range(2):
+        b6.zero()
+        h1 = net6[1](net6[0](x[lo:hi]))
+        h1c = h1.detach().requires_grad_(True)
+        h2 = net6[3](net6[2](h1c))
+        h2c = h2.detach().requires_grad_(True)
+        torch.nn.functional.cross_entropy(net6[4](h2c), y[lo:hi]).backward()
+        assert all(p.grad is None for p in net6[2].parameters()) and all(p.grad is None for p in net6[0].parameters())
+        b6.reduce(0)
+        assert len(b6.handles) == 1 and b6.reduced == [True, False, False]
+        h2.backward(h2c.grad)
+        b6.reduce(1)
+        h1.backward(h1c.grad)
+        if step == 1:
+            try:
+                b6.reduced[1] = False
+                b6.reduce(2)                                             # a bucket may not overtake its predecessor: every rank sends 0, 1, 2
+                raise SystemExit('out-of-order reduce was accepted')
+            except AssertionError:
+                b6.reduced[1] = True
+        b6.reduce(2)
+        b6.reduce(2)                                                     # idempotent
+        b6.finish()
+        out['g_staged{}'.format(step)] = torch.cat([p.grad.reshape(-1) for p in net6.parameters()]).numpy().copy()
+    assert b6.order_log == ['reduce0', 'reduce1', 'reduce2'] * 2
+    try:
+        GradBuckets(list(net6.parameters()), groups=groups[:2])
+        raise SystemExit('groups that do not cover the parameters were accepted')
+    except ValueError:
+        pass
     out['half_none'] = np.array([p.grad is None for p in half.parameters()])
     out['half_g'] = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in half.parameters()]).numpy().copy()
     out['w'] = torch.cat([p.detach().reshape(-1) for p in params]).numpy()
@@ -162,6 +199,9 @@ def test_two_rank_gradient_buckets_equal_full_batch_gradients(tmp_path):
     for step in range(3):                                                   # deferred collectives (split-graph fit), eager and "replayed"
         assert np.array_equal(r0['g_defer{}'.format(step)], r0['g_f32']) and np.array_equal(r1['g_defer{}'.format(step)], r0['g_f32'])
         assert r0['defer_unused_none{}'.format(step)].all() and r1['defer_unused_none{}'.format(step)].all()
+    for step in range(2):                                                   # staged backward + reduce(k) between the stages == the plain bucketed step
+        assert np.array_equal(r0['g_staged{}'.format(step)], r1['g_staged{}'.format(step)])
+        np.testing.assert_allclose(r0['g_staged{}'.format(step)], r0['g_f32'], rtol=1e-6, atol=1e-8)
     # touched on rank 0 only: kept on BOTH ranks with the same averaged value (rank 0's gradient / 2)
     assert not r0['half_none'].any() and not r1['half_none'].any() and np.array_equal(r0['half_g'], r1['half_g']) and np.abs(r0['half_g']).max() > 0
     half = torch.nn.Linear(6, 2)

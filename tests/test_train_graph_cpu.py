@@ -236,3 +236,62 @@ def test_split_k_slab_choice(rows, want):
     s = train_graph.splitk_slabs(rows)
     assert s == want
     assert s == 0 or rows // s >= 500
+
+
+@pytest.mark.parametrize('which', ['ppsurf', 'poco'])
+def test_staged_backward_gives_the_same_gradients_and_completes_them_stage_by_stage(which):
+    """train_graph.staged(): the encoder cuts the backward pass behind resnetb31 and behind resnetb11 (BackwardStages).  The three stages run the same
+    chain rule: the gradients equal those of a single loss.backward() to fp32 re-association (the sum over the consumers of a skip-connected
+    activation is taken in another order); and the gradients a stage is said to
+    complete (train_graph.parameter_stages: the gradient buckets of a multi-rank fit are exactly these groups, all-reduced between the stages) are
+    final when that stage returns -- later stages add nothing to them."""
+    g, net = (_ppsurf if which == 'ppsurf' else _poco)(torch.float32)
+    forward = tg.ppsurf_forward if which == 'ppsurf' else tg.poco_forward
+    data, occ = _step_inputs(load_golden('train_ppsurf'))
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    with patched():
+        logits = forward(net, data, data['proj_ids'])
+        nn.functional.cross_entropy(logits, occ, reduction='none').mean().backward()
+    want = {k: (None if p.grad is None else p.grad.clone()) for k, p in net.named_parameters()}
+    net.load_state_dict(state)                                  # the forward pass moved norm_radius / running statistics
+    for p in net.parameters():
+        p.grad = None
+    groups = tg.parameter_stages(net)
+    assert len(groups) == tg.N_STAGES == 3 and sum(len(x) for x in groups) == sum(1 for p in net.parameters() if p.requires_grad)
+    names = {id(p): k for k, p in net.named_parameters()}
+    assert all(names[id(p)].startswith(('encoder.cv0.', 'encoder.bn0.', 'encoder.resnetb01', 'encoder.resnetb10', 'encoder.resnetb11')) for p in groups[2])
+    assert all(names[id(p)].startswith(('encoder.resnetb2', 'encoder.resnetb3')) for p in groups[1])
+    share = sum(p.numel() for p in groups[0]) / sum(p.numel() for x in groups for p in x)
+    assert share > 0.75                                          # most gradient bytes are complete after the first stage
+    snapshots = []
+
+    def after_stage(k):
+        snapshots.append({names[id(p)]: (None if p.grad is None else p.grad.clone()) for x in groups[:k + 1] for p in x})
+        if k < 2:                                                # nothing of the later stages has arrived yet
+            assert all(p.grad is None for x in groups[k + 1:] for p in x), k
+
+    with patched(), tg.staged() as st:
+        logits2 = forward(net, data, data['proj_ids'])
+        loss = nn.functional.cross_entropy(logits2, occ, reduction='none').mean()
+        assert st.n_stages == 3
+        st.backward(loss, after_stage)
+    assert torch.equal(logits2, logits)
+    worst, gmax = 0.0, max(float(w.abs().max()) for w in want.values() if w is not None)
+    for k, p in net.named_parameters():
+        assert (p.grad is None) == (want[k] is None), k
+        if want[k] is None:
+            continue
+        if True:
+            # behind the last cut nothing changes (the same kernels in the same order: bit-identical on the GPU, tests/test_gpu_train.py; torch's CPU
+            # reductions are multi-threaded and differ from run to run by themselves, so the CPU suite compares everything to rounding).  In front of a cut the gradient of a skip-connected activation (x0 .. x3 feed a block AND the up-sampling head) is summed in another
+            # order than autograd's single pass sums it: fp32 re-association, a few ulp of the tensor's scale
+            # (biases in front of a train-mode BatchNorm have an analytically zero gradient: what is there is rounding noise of the set's scale)
+            err = float((p.grad - want[k]).abs().max()) / max(float(want[k].abs().max()), 1e-3 * gmax)
+            worst = max(worst, err)
+            assert err < 5e-5, (k, err)
+    final = {k: (None if p.grad is None else p.grad.clone()) for k, p in net.named_parameters()}
+    for snap in snapshots:                                       # a stage's gradients were FINAL when it returned: later stages add nothing
+        for k, gk in snap.items():
+            assert (gk is None and final[k] is None) or torch.equal(gk, final[k]), k
+    # outside staged() the cuts are no-ops (single backward, e.g. the one-GPU whole-step graph)
+    assert tg._stages[0] is None and tg._cut(logits)[0] is logits
