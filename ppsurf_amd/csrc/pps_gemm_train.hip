@@ -12,9 +12,8 @@
 //   pps_transpose_cast_pieces   fp32 master weights [N, K] -> 16-bit images [K, N] of all layers in one launch (table of matrices)
 //
 // NT: both operands are K-contiguous, so MFMA fragments are read straight from global memory (16 bytes per lane: 8 consecutive k of one row /
-// one output channel); a wave owns 16 TN rows x 16 TM channels, a workgroup 4 such row tiles against the same channel block (the weights come from
-// L2), grid = (row tiles, channel blocks).  HBM-bound for the wide-row layers (the rows are read once per channel block of 64), latency-bound for the
-// coarse levels (a few hundred rows).
+// one output channel); a wave owns 16 TN rows x 16 TM channels, grid = (row tiles, channel blocks), the weights come from L2.  The waves of a
+// workgroup are stacked over the rows for the wide layers and split the contraction for the coarse encoder levels (see gemm_nt_kernel).
 // TN: the contraction index is the ROW, which neither operand has contiguous: 64-row tiles of g and x are staged in LDS row-major and fragments are
 // taken with ds_read_b64_tr_b16 (the LDS transpose read of gfx950), as in rows_dw_kernel; a workgroup owns a 64 x 64 block of dw over a slab of
 // rows, slab partials are summed in a fixed order (no atomics: bit-reproducible).
@@ -45,8 +44,16 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {                   
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// NT product.  D[m <-> output channel][n <-> row]: A = w (lane (m = l & 15, kg = l >> 4): 8 consecutive k of channel m), B = x (lane (n, kg): 8
-// consecutive k of row n); lane (n, g) of D holds channels 4 g .. 4 g + 3 of row n.
+// NT product.  D[m <-> output channel][n <-> row]: A = w (lane (m = l & 15, kg = l >> 4): 8 consecutive k of one channel), B = x (lane (n, kg): 8
+// consecutive k of row n).  A workgroup is 4 waves against one block of 16 TM channels:
+//   KSPLIT = 1   the waves are stacked over the rows (4 x 16 TN rows): the wide layers (10^4 ... 10^5 rows), bound by the row traffic;
+//   KSPLIT = 2/4 the waves (also) split the contraction -- wave kp takes the k-steps kp, kp + KSPLIT, ... -- and their accumulators are added
+//                through LDS in wave order: the coarse encoder levels (a few hundred rows against 2048 ... 8192 input channels), whose grid is a
+//                few dozen workgroups and whose time is the LENGTH of the dependent load chain, not bytes.
+// PF k-steps of fragments are in flight per wave (a ring of PF register sets).
+// With TM = 4 the A rows are taken in the order  MFMA row 4 g + r of block i  <->  channel 16 g + 4 i + r  of the 64-channel block, so that lane
+// (n, g) ends up with the 16 CONSECUTIVE channels 16 g .. 16 g + 15 of row n: a row's 64 channels leave as 128 contiguous bytes (with the plain
+// order a lane stores 8 bytes per block and a store instruction touches 16 rows x 32 bytes).
 // ---------------------------------------------------------------------------------------------------------------------
 struct NtArgs {
     const uint16_t* x; int64_t ldx;
@@ -57,12 +64,15 @@ struct NtArgs {
     int out_f32;
 };
 
-template <int TM, int TN, bool F16>
+template <int TM, int TN, int KSPLIT, int PF, bool F16>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs a) {
+    constexpr int RG = 4 / KSPLIT;                                          // row groups of a workgroup
+    constexpr bool PERM = TM == 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i16 = lane & 15, kg = lane >> 4;
-    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * TN);
+    const int rg = wave / KSPLIT, kp = wave % KSPLIT;
+    const int64_t r0 = ((int64_t)blockIdx.x * RG + rg) * (16 * TN);
     const int c0 = blockIdx.y * (16 * TM);
-    if (r0 >= a.m) return;
+    const bool rows_live = r0 < a.m;                                        // (no early return: the waves of a split contraction meet at a barrier)
     const uint16_t* xr[TN];
     const uint16_t* wr[TM];
 #pragma unroll
@@ -72,7 +82,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int ch = c0 + 16 * i + i16;
+        const int ch = c0 + (PERM ? 16 * (i16 >> 2) + 4 * i + (i16 & 3) : 16 * i + i16);
         wr[i] = a.w + (int64_t)(ch < a.n ? ch : a.n - 1) * a.ldw + 8 * kg;
     }
     f32x4 acc[TM][TN];
@@ -81,53 +91,105 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const NtArgs a) {
 #pragma unroll
         for (int t = 0; t < TN; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ksteps = (a.k + 31) / 32;
-    u32x4 fa[TM], fb[TN], na[TM], nb[TN];
+    const int mine = (ksteps - kp + KSPLIT - 1) / KSPLIT;                    // k-steps kp, kp + KSPLIT, ... of this wave
+    u32x4 fa[PF][TM], fb[PF][TN];
     const u32x4 zero = {0, 0, 0, 0};
-    auto load = [&](int s, u32x4 (&pa)[TM], u32x4 (&pb)[TN]) {
-        const bool in = 32 * s + 8 * kg < a.k;                               // K is a multiple of 8: a chunk is inside or outside as a whole
+    auto load = [&](int i, u32x4 (&pa)[TM], u32x4 (&pb)[TN]) {
+        const int s = kp + KSPLIT * i;
+        const bool in = rows_live && i < mine && 32 * s + 8 * kg < a.k;      // K is a multiple of 8: a chunk is inside or outside as a whole
 #pragma unroll
-        for (int i = 0; i < TM; ++i) pa[i] = in ? *(const u32x4*)(wr[i] + 32 * s) : zero;
+        for (int j = 0; j < TM; ++j) pa[j] = in ? *(const u32x4*)(wr[j] + 32 * s) : zero;
 #pragma unroll
         for (int t = 0; t < TN; ++t) pb[t] = in ? *(const u32x4*)(xr[t] + 32 * s) : zero;
     };
-    load(0, fa, fb);
-    for (int s = 0; s < ksteps; ++s) {
-        if (s + 1 < ksteps) load(s + 1, na, nb);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+    for (int p = 0; p < PF; ++p) load(p, fa[p], fb[p]);
+    for (int i0 = 0; i0 < mine; i0 += PF) {
 #pragma unroll
-            for (int t = 0; t < TN; ++t) acc[i][t] = mfma16<F16>(fa[i], fb[t], acc[i][t]);
-        if (s + 1 < ksteps) {
+        for (int p = 0; p < PF; ++p) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = na[i];
+            for (int j = 0; j < TM; ++j)
 #pragma unroll
-            for (int t = 0; t < TN; ++t) fb[t] = nb[t];
+                for (int t = 0; t < TN; ++t) acc[j][t] = mfma16<F16>(fa[p][j], fb[p][t], acc[j][t]);
+            load(i0 + p + PF, fa[p], fb[p]);
         }
     }
+    if constexpr (KSPLIT > 1) {
+        __shared__ float red[RG][KSPLIT - 1][TM * TN * 4][64];
+        if (kp > 0) {
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int t = 0; t < TN; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[rg][kp - 1][(j * TN + t) * 4 + r][lane] = acc[j][t][r];
+        }
+        __syncthreads();
+        if (kp > 0) return;
+#pragma unroll
+        for (int q = 0; q < KSPLIT - 1; ++q)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int t = 0; t < TN; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[j][t][r] += red[rg][q][(j * TN + t) * 4 + r][lane];
+    }
+    if (!rows_live) return;
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
         const int64_t row = r0 + 16 * t + i16;
         if (row >= a.m) continue;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int ch = c0 + 16 * i + 4 * kg;
+        if constexpr (PERM) {
+            const int ch = c0 + 16 * kg;                                     // this lane: channels ch .. ch + 15, value (i, r) = channel ch + 4 i + r
             if (ch >= a.n) continue;
-            f32x4 v = acc[i][t];
-            if (a.bias) {
+            float v[16];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (ch + r < a.n) ? a.bias[ch + r] : 0.f;
-            }
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][t][r] + ((a.bias && ch + 4 * i + r < a.n) ? a.bias[ch + 4 * i + r] : 0.f);
             if (a.out_f32) {
                 float* dst = (float*)a.y + row * a.ldy + ch;
-                if (ch + 3 < a.n) *(f32x4*)dst = v;
-                else for (int r = 0; r < 4 && ch + r < a.n; ++r) dst[r] = v[r];
+                if (ch + 15 < a.n && (a.ldy & 3) == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) *(f32x4*)(dst + 4 * i) = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+                } else {
+                    for (int e = 0; e < 16 && ch + e < a.n; ++e) dst[e] = v[e];
+                }
             } else {
                 uint16_t* dst = (uint16_t*)a.y + row * a.ldy + ch;
-                const unsigned p0 = pack2<F16>(v[0], v[1]), p1 = pack2<F16>(v[2], v[3]);
-                if (ch + 3 < a.n) *(u32x2*)dst = u32x2{p0, p1};
-                else {
-                    const uint16_t h[4] = {(uint16_t)(p0 & 0xffff), (uint16_t)(p0 >> 16), (uint16_t)(p1 & 0xffff), (uint16_t)(p1 >> 16)};
-                    for (int r = 0; r < 4 && ch + r < a.n; ++r) dst[r] = h[r];
+                unsigned p[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) p[e] = pack2<F16>(v[2 * e], v[2 * e + 1]);
+                if (ch + 15 < a.n && (a.ldy & 7) == 0) {
+                    *(u32x4*)dst = u32x4{p[0], p[1], p[2], p[3]};
+                    *(u32x4*)(dst + 8) = u32x4{p[4], p[5], p[6], p[7]};
+                } else {
+                    for (int e = 0; e < 16 && ch + e < a.n; ++e) dst[e] = (uint16_t)(e & 1 ? p[e >> 1] >> 16 : p[e >> 1] & 0xffff);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int ch = c0 + 16 * i + 4 * kg;
+                if (ch >= a.n) continue;
+                f32x4 v = acc[i][t];
+                if (a.bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (ch + r < a.n) ? a.bias[ch + r] : 0.f;
+                }
+                if (a.out_f32) {
+                    float* dst = (float*)a.y + row * a.ldy + ch;
+                    if (ch + 3 < a.n && (a.ldy & 3) == 0) *(f32x4*)dst = v;
+                    else for (int r = 0; r < 4 && ch + r < a.n; ++r) dst[r] = v[r];
+                } else {
+                    uint16_t* dst = (uint16_t*)a.y + row * a.ldy + ch;
+                    const unsigned p0 = pack2<F16>(v[0], v[1]), p1 = pack2<F16>(v[2], v[3]);
+                    if (ch + 3 < a.n && (a.ldy & 3) == 0) *(u32x2*)dst = u32x2{p0, p1};
+                    else {
+                        const uint16_t h[4] = {(uint16_t)(p0 & 0xffff), (uint16_t)(p0 >> 16), (uint16_t)(p1 & 0xffff), (uint16_t)(p1 >> 16)};
+                        for (int r = 0; r < 4 && ch + r < a.n; ++r) dst[r] = h[r];
+                    }
                 }
             }
         }
@@ -235,13 +297,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs a) {
             }
 }
 
-// out[i] = sum over the slabs, in slab order
+// out[i] = sum over the slabs: 16 threads share an element (slab = slice, slice + 16, ... in double), their sums are added in slice order -- the
+// result does not depend on scheduling.  (One thread per element walked all slabs alone: 390 dependent loads for the 100 000-row layers, 24 us.)
 __global__ __launch_bounds__(256) void tn_sum_kernel(const float* __restrict__ part, int slabs, int64_t n, float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    __shared__ double red[16][16];
+    const int e = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 16 + e;
     double s = 0.0;
-    for (int p = 0; p < slabs; ++p) s += (double)part[(int64_t)p * n + i];
-    out[i] = (float)s;
+    if (i < n) {
+#pragma unroll 4
+        for (int p = sl; p < slabs; p += 16) s += (double)part[(int64_t)p * n + i];
+    }
+    red[sl][e] = s;
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][e];
+        out[i] = (float)t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -274,20 +348,30 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const TrEntry* __re
 
 template <bool F16>
 int launch_nt(const NtArgs& a, hipStream_t st) {
-    // channel block: 64 channels when there are that many (4 fragments of w per 2 of x), else what there is; row tile 32 per wave
-    const int64_t row_tiles = (a.m + 127) / 128;
-    if (row_tiles > 0x7fffffff) return PPS_ERR_ARG;
-    if (a.n > 32) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, F16>), dim3((unsigned)row_tiles, (unsigned)((a.n + 63) / 64)), dim3(256), 0, st, a);
-    else if (a.n > 16) hipLaunchKernelGGL((gemm_nt_kernel<2, 2, F16>), dim3((unsigned)row_tiles, 1), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_nt_kernel<1, 2, F16>), dim3((unsigned)row_tiles, 1), dim3(256), 0, st, a);
+    if ((a.m + 31) / 32 > 0x7fffffff) return PPS_ERR_ARG;
+    const int ksteps = (a.k + 31) / 32;
+    if (a.n > 32) {
+        // 64-channel blocks.  The contraction is split between the waves while the grid would not fill the chip and every wave keeps >= 4 k-steps
+        const int64_t cb = (a.n + 63) / 64;
+        int ks = 1;
+        while (ks < 4 && ((a.m + 128 / ks - 1) / (128 / ks)) * cb < 512 && ksteps / (2 * ks) >= 4) ks *= 2;
+        const dim3 grid((unsigned)((a.m + 128 / ks - 1) / (128 / ks)), (unsigned)cb);
+        if (ks == 1) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 1, 2, F16>), grid, dim3(256), 0, st, a);
+        else if (ks == 2) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 2, 4, F16>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_nt_kernel<4, 2, 4, 4, F16>), grid, dim3(256), 0, st, a);
+    } else if (a.n > 16) {
+        hipLaunchKernelGGL((gemm_nt_kernel<2, 2, 1, 2, F16>), dim3((unsigned)((a.m + 127) / 128), 1), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((gemm_nt_kernel<1, 2, 1, 2, F16>), dim3((unsigned)((a.m + 127) / 128), 1), dim3(256), 0, st, a);
+    }
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 
 int tn_slabs(int64_t m, int n, int k) {
-    // enough workgroups to fill the chip, few enough that the partials stay small: tiles x slabs ~ 1024, at least 256 rows per slab, at most 64 MB
+    // enough workgroups to fill the chip, few enough that the partials stay small: tiles x slabs ~ 512, at least 512 rows per slab, at most 64 MB
     const int64_t tiles = (int64_t)((n + TN_T - 1) / TN_T) * ((k + TN_T - 1) / TN_T);
-    int64_t slabs = (1024 + tiles - 1) / tiles;
-    const int64_t by_rows = (m + 255) / 256;
+    int64_t slabs = (512 + tiles - 1) / tiles;
+    const int64_t by_rows = (m + 511) / 512;
     if (slabs > by_rows) slabs = by_rows;
     const int64_t by_bytes = ((int64_t)64 << 20) / ((int64_t)n * k * 4);
     if (slabs > by_bytes) slabs = by_bytes;
@@ -330,7 +414,7 @@ int pps_gemm_tn_16(const void* g, int64_t ldg, const void* x, int64_t ldx, int64
     else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, st, a);
     if (used > 1) {
         const int64_t nk = (int64_t)n * k;
-        hipLaunchKernelGGL(tn_sum_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, (const float*)ws, used, nk, dw);
+        hipLaunchKernelGGL(tn_sum_kernel, dim3((unsigned)((nk + 15) / 16)), dim3(256), 0, st, (const float*)ws, used, nk, dw);
     }
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }

@@ -350,6 +350,7 @@ class PPSurfNetwork(_Base):
     def forward(self, data):
         if self.training:
             train_graph._prepare(self, data)             # bf16 images of all parameters for this step (one multi-tensor copy)
+            train_graph.start_pointnet(self, data)       # PointNet needs only the patches: on its side stream, beside the encoder
         data['latents'] = self.encoder.forward(data, spectral_only=True)
         return self.from_latent(data)
 

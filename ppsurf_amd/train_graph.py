@@ -261,7 +261,14 @@ def _own_gemm(x, k):
             and x.shape[0] > 0)
 
 
+ROWS_LAYER_MIN = 16384       # rows from which a 64 / 128 / 256-channel dense layer goes through the LDS-resident-weight row kernels (pps_rows_train.hip)
+
+
 def rows_linear(x, w, b=None, wc=None, bc=None, wt=None):
+    if (x.dim() == 2 and x.shape[0] >= ROWS_LAYER_MIN and _own_gemm(x, w.shape[1]) and train_ops.rows_layer_supported(x.shape[0], w.shape[1], w.shape[0])):
+        # the whole weight matrix fits the LDS of a CU: rows stream past it once (forward), and the backward pass is ONE call (input gradient,
+        # weight gradient from row slabs, bias gradient) -- the generic NT kernel re-reads the rows once per 64-channel block
+        return train_ops.rows_layer(train_ops.Act(x), w, b).raw
     if x.dim() == 2 and (x.shape[0] >= SPLITK_MIN_ROWS or wc is not None or _own_gemm(x, w.shape[1])):
         return _RowsLinear.apply(x, w, b, wc, bc, wt)
     return F.linear(x, w, b)
@@ -387,6 +394,79 @@ def release_step_caches():
     _flat_cache.clear()
     train_ops.clear_cache()
     _shadow_live[0] = False
+    _early.clear()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# independent branches of the step on side streams
+# ---------------------------------------------------------------------------------------------------------------------
+# The step is a long chain of small kernels (the encoder: ~600 launches of 5-30 us on a few hundred workgroups) next to a few heavy streaming ones
+# (PointNet on 10^6 patch rows).  Two branches do not depend on the encoder's features at all:
+#   * PointNet (source/base/nn.py:305-373) reads only the patches;
+#   * the FKAConv geometry branch of every layer (nn.py:601-643) reads only positions, id tables and its 1140 small parameters.
+# Forked onto side streams they run beside the feature chain -- and so do their BACKWARD passes: autograd runs a node's backward on the stream of its
+# forward and orders the streams with events, so the three geometry backward passes of a layer (which nothing downstream waits for) and PointNet's
+# backward leave the critical path as well.  Recorded into a HIP graph the forks and joins become edges of the graph.
+# PPS_FIT_STREAMS=0 keeps everything on one stream.
+import os as _os
+
+_side_streams = {}
+
+
+def side_streams_on(t):
+    return t.is_cuda and _os.environ.get('PPS_FIT_STREAMS', '1') != '0' and torch.is_grad_enabled()
+
+
+def _side(dev, name):
+    key = (dev, name)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=dev)
+    return _side_streams[key]
+
+
+class Forked:
+    """with Forked(dev, 'pointnet') as f: ... ops on the side stream ...;  f.join(*outputs) on the consumer's stream before the first use."""
+
+    def __init__(self, dev, name):
+        self.side = _side(dev, name)
+        self.main = torch.cuda.current_stream(dev)
+        self.ctx = None
+
+    def __enter__(self):
+        self.side.wait_stream(self.main)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self.ctx.__exit__(*exc)
+        self.done = torch.cuda.Event()
+        self.done.record(self.side)
+        return False
+
+    def join(self, *tensors):
+        cur = torch.cuda.current_stream(self.side.device)
+        cur.wait_event(self.done)
+        for t in tensors:
+            if torch.is_tensor(t):
+                t.record_stream(cur)                 # allocated on the side stream, read here: not to be recycled under the reader
+        return tensors[0] if len(tensors) == 1 else tensors
+
+
+_early = {}
+
+
+def start_pointnet(net, data):
+    """PointNet's forward pass of this step on its side stream, BEFORE the encoder is queued (PPSurfNetwork.forward in train()): the result is
+    picked up by ppsurf_from_latent.  No-op on one stream."""
+    _early.clear()
+    pl = data.get('pts_local_ps')
+    if not (torch.is_tensor(pl) and side_streams_on(pl)) or pl.dim() != 4:
+        return
+    b, q = pl.shape[0], pl.shape[1]
+    with Forked(pl.device, 'pointnet') as f:
+        feat, _ = pointnet(net.point_net, pl.reshape(b * q, pl.shape[2], 3), need_trans=False)
+    _early['pn'] = (pl, f, feat)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -500,11 +580,10 @@ def pack_geo(layer):
     return torch.cat([p.to(layer.alpha.dtype) for p in parts])
 
 
-def fkaconv_layer(layer, x, pts, sup, ids):
-    """x [B,N,Cin], pts [B,N,3], sup [B,M,3], ids int64 [B,M,K] -> [B,M,Cout].
-    Geometry branch (nn.py:601-643, incl. the norm_radius EMA in train()) and feature aggregation (:647-649) are HIP ops with
-    hand-written backward; the (1,16) convolution is one GEMM over all support points of the batch."""
-    b, n, cin = x.shape
+def fka_geometry_of(layer, pts, sup, ids):
+    """The [B*M, K, 16] kernel-weighting matrix of one FKAConv layer (nn.py:601-643) incl. the norm_radius EMA of train(): positions, ids and the
+    layer's small parameters only -- no features."""
+    b, n = pts.shape[0], pts.shape[1]
     m, k = ids.shape[1], ids.shape[2]
     flat = _flat_ids(ids, n).view(b * m, k)
     momentum = layer.norm_radius_momentum if layer.training else 0.0
@@ -512,6 +591,18 @@ def fkaconv_layer(layer, x, pts, sup, ids):
     if layer.training:
         with torch.no_grad():                               # IN PLACE: a replayed HIP graph reads and writes the buffer's own storage
             layer.norm_radius.copy_(radius.detach().reshape(layer.norm_radius.shape))
+    return g
+
+
+def fkaconv_layer(layer, x, pts, sup, ids, geo=None):
+    """x [B,N,Cin], pts [B,N,3], sup [B,M,3], ids int64 [B,M,K] -> [B,M,Cout].
+    Geometry branch (nn.py:601-643, incl. the norm_radius EMA in train()) and feature aggregation (:647-649) are HIP ops with
+    hand-written backward; the (1,16) convolution is one GEMM over all support points of the batch.  geo: (Forked, g) of a geometry branch that
+    was started on the side stream (encoder()), else it is evaluated here."""
+    b, n, cin = x.shape
+    m, k = ids.shape[1], ids.shape[2]
+    flat = _flat_ids(ids, n).view(b * m, k)
+    g = fka_geometry_of(layer, pts, sup, ids) if geo is None else geo[0].join(geo[1])
     feat = train_ops.neighbour_contract(x.reshape(b * n, cin), flat, g)                  # [B*M, Cin*16]
     wc = _bf16_of(layer.cv.weight)
     return rows_linear(feat, _w2d(layer.cv), None, None if wc is None else wc.reshape(wc.shape[0], -1), None,
@@ -519,12 +610,12 @@ def fkaconv_layer(layer, x, pts, sup, ids):
 
 
 @_counted
-def residual_block(blk, x, pts, sup, ids):
+def residual_block(blk, x, pts, sup, ids, geo=None):
     """[B,N,Cin] -> [B,M,Cout]."""
     b, n, cin = x.shape
     m = ids.shape[1]
     h = batch_norm(blk.bn0, dense(blk.cv0, x.reshape(b * n, cin)), relu=True).view(b, n, -1)
-    h = fkaconv_layer(blk.cv1, h, pts, sup, ids)
+    h = fkaconv_layer(blk.cv1, h, pts, sup, ids, geo)
     h = batch_norm(blk.bn1, h.reshape(b * m, -1), relu=True)
     h = batch_norm(blk.bn2, dense(blk.cv2, h))
     sc = x.reshape(b * n, cin)
@@ -549,19 +640,30 @@ def encoder(enc, data):
     s1, s2, s3, s4 = (pm(data['support{}'.format(i)]) for i in (1, 2, 3, 4))
     b = pts.shape[0]
     x = torch.ones_like(pts)                                                             # input features are all-ones (:517)
-    x0 = fkaconv_layer(enc.cv0, x, pts, pts, data['ids00'])
+    # the geometry branches of all ten layers, one after the other on a side stream (they need no features); each layer joins its own
+    levels = {'cv0': (enc.cv0, pts, pts, 'ids00'), 'b01': (enc.resnetb01.cv1, pts, pts, 'ids00'), 'b10': (enc.resnetb10.cv1, pts, s1, 'ids01'),
+              'b11': (enc.resnetb11.cv1, s1, s1, 'ids11'), 'b20': (enc.resnetb20.cv1, s1, s2, 'ids12'), 'b21': (enc.resnetb21.cv1, s2, s2, 'ids22'),
+              'b30': (enc.resnetb30.cv1, s2, s3, 'ids23'), 'b31': (enc.resnetb31.cv1, s3, s3, 'ids33'), 'b40': (enc.resnetb40.cv1, s3, s4, 'ids34'),
+              'b41': (enc.resnetb41.cv1, s4, s4, 'ids44')}
+    geo = dict.fromkeys(levels)
+    if side_streams_on(pts):
+        for name, (layer, p_in, p_out, table) in levels.items():
+            with Forked(pts.device, 'geometry') as f:
+                g = fka_geometry_of(layer, p_in, p_out, data[table])
+            geo[name] = (f, g)
+    x0 = fkaconv_layer(enc.cv0, x, pts, pts, data['ids00'], geo['cv0'])
     x0 = batch_norm(enc.bn0, x0.reshape(b * pts.shape[1], -1), relu=True).view(b, pts.shape[1], -1)
-    x0 = residual_block(enc.resnetb01, x0, pts, pts, data['ids00'])
-    x1 = residual_block(enc.resnetb10, x0, pts, s1, data['ids01'])
-    x1 = residual_block(enc.resnetb11, x1, s1, s1, data['ids11'])
+    x0 = residual_block(enc.resnetb01, x0, pts, pts, data['ids00'], geo['b01'])
+    x1 = residual_block(enc.resnetb10, x0, pts, s1, data['ids01'], geo['b10'])
+    x1 = residual_block(enc.resnetb11, x1, s1, s1, data['ids11'], geo['b11'])
     x0, x1 = _cut(x0, x1)                                     # backward stage 2 = everything above (BackwardStages; no-op unless staged() is active)
-    x2 = residual_block(enc.resnetb20, x1, s1, s2, data['ids12'])
-    x2 = residual_block(enc.resnetb21, x2, s2, s2, data['ids22'])
-    x3 = residual_block(enc.resnetb30, x2, s2, s3, data['ids23'])
-    x3 = residual_block(enc.resnetb31, x3, s3, s3, data['ids33'])
+    x2 = residual_block(enc.resnetb20, x1, s1, s2, data['ids12'], geo['b20'])
+    x2 = residual_block(enc.resnetb21, x2, s2, s2, data['ids22'], geo['b21'])
+    x3 = residual_block(enc.resnetb30, x2, s2, s3, data['ids23'], geo['b30'])
+    x3 = residual_block(enc.resnetb31, x3, s3, s3, data['ids33'], geo['b31'])
     x0, x1, x2, x3 = _cut(x0, x1, x2, x3)                     # backward stage 1 = the two levels above; stage 0 = everything below
-    x4 = residual_block(enc.resnetb40, x3, s3, s4, data['ids34'])
-    x4 = residual_block(enc.resnetb41, x4, s4, s4, data['ids44'])
+    x4 = residual_block(enc.resnetb40, x3, s3, s4, data['ids34'], geo['b40'])
+    x4 = residual_block(enc.resnetb41, x4, s4, s4, data['ids44'], geo['b41'])
 
     def head(cv, bn, coarse, ids_up, skip):
         z = torch.cat([_upsample(coarse, ids_up, coarse.shape[1]), skip], dim=-1)
@@ -751,7 +853,11 @@ def ppsurf_from_latent(net, latents, data, proj_ids):
     b, q = query.shape[0], query.shape[1]
     feat_proj = interp_attention(net.projection, latents, pts, query, proj_ids)
     pl = data['pts_local_ps']
-    feat_pn, _ = pointnet(net.point_net, pl.reshape(b * q, pl.shape[2], 3), need_trans=False)
+    early = _early.pop('pn', None)
+    if early is not None and early[0] is pl:
+        feat_pn = early[1].join(early[2])                    # started before the encoder on its side stream (start_pointnet)
+    else:
+        feat_pn, _ = pointnet(net.point_net, pl.reshape(b * q, pl.shape[2], 3), need_trans=False)
     out = mlp(net.mlp, feat_proj.reshape(b * q, -1) + feat_pn)
     return out.view(b, q, -1).transpose(1, 2)
 
@@ -767,6 +873,7 @@ def _prepare(net, data):
 @_counted
 def ppsurf_forward(net, data, proj_ids):
     _prepare(net, data)
+    start_pointnet(net, data)
     return ppsurf_from_latent(net, encoder(net.encoder, data), data, proj_ids)
 
 
