@@ -275,6 +275,25 @@ int pps_mc_emit_f64(const double* vol, int64_t nx, int64_t ny, int64_t nz, doubl
                     const int64_t* centre_offset, const int64_t* vert_offset, int64_t n_edge_verts, int32_t* vidx, double* verts, int64_t* faces,
                     void* stream);
 
+/* ---- mesh clean-up (csrc/pps_mesh.hip) -------------------------------------------------------------
+ * replaces: source/base/mesh.py:7-38 (trimesh merge_vertices(digits_vertex = 8), remove_degenerate_faces, remove_duplicate_faces,
+ * remove_small_connected_components(num_faces = 6)) as called from source/poco_utils.py:98-107, 169-174.
+ *   pps_mesh_small_components   small uint8 [nf] = 1 for the faces of face-connected components (faces sharing an edge) of at most k faces
+ *                               (1 <= k <= 32); faces int64 [nf, 3], vertex ids below nv.
+ *   pps_mesh_corner_weld        for a mesh welded by grid-edge key (pps_mc_emit_f64) in index space: vertices within 10^-digits of a grid corner
+ *                               that share their position rounded to `digits` digits are merged into the smallest id of their class.  remap int64
+ *                               [nv] (identity elsewhere), hot uint8 [nv] = 1 where something was merged into the vertex, counters int32 [2] =
+ *                               {merged vertices, 1 if a coordinate left [0, 524287]}.
+ *   pps_mesh_face_filter        faces AFTER remapping: keep uint8 [nf] = 0 for degenerate faces and, among the faces touching a hot vertex, for all
+ *                               but the first face of every vertex triple.
+ * ws: the matching *_ws_bytes() bytes each; results do not depend on scheduling. */
+size_t pps_mesh_components_ws_bytes(int64_t nf);
+int pps_mesh_small_components(const int64_t* faces, int64_t nf, int64_t nv, int k, uint8_t* small, void* ws, void* stream);
+size_t pps_mesh_weld_ws_bytes(int64_t nv);
+int pps_mesh_corner_weld(const double* verts, int64_t nv, int digits, int64_t* remap, uint8_t* hot, int* counters, void* ws, void* stream);
+size_t pps_mesh_face_filter_ws_bytes(int64_t nf);
+int pps_mesh_face_filter(const int64_t* faces, int64_t nf, const uint8_t* hot, uint8_t* keep, void* ws, void* stream);
+
 /* ---- FKAConv encoder (eval mode), point-major activations, one batch item per call ----------------- */
 
 /* number of floats of the packed small parameters of one FKAConv layer:
@@ -426,6 +445,18 @@ int pps_head_input_fwd(const void* table, const int64_t* ids, const float* pts, 
                        void* h1, void* stream);
 int pps_head_input_dwx(const void* dh1, const int64_t* ids, const float* pts, const float* query, int64_t q, int k, int c, int dtype, float* dwx, void* ws,
                        void* stream);
+
+/* The dense chain of the interpolation head in train(), forward, in one launch (source/poco_model.py:400-409 on all (query, neighbour) rows of the
+ * batch):  h1 = table[ids] + wx (query - pts[ids]),  y2 = fc2(relu(h1)),  y3 = fc3(relu(y2)),  qy = fc_query(relu(y3)) -- a wave carries its rows
+ * through the three layers in registers; h1, y2, y3 [q*k, 256] and qy [q*k, 64] (16-bit, RAW layer outputs: what the backward entries
+ * pps_attn_pool_bwd / pps_rows_layer_bwd / pps_head_input_dwx read) are written once each.  table [n, 256] 16-bit, ids [q*k], pts [n, 3], query [q, 3]
+ * fp32; wx [256, 3], w2 / w3 [256, 256], wq [64, 256] fp32 master weights, b2 / b3 [256], bq [64] fp32 or NULL.  The four outputs must have room
+ * for q*k rounded UP to a multiple of 256 rows (whole row units are written; the rows past q*k hold copies of the last row's results).
+ * ws: pps_head_chain_ws_bytes() bytes, 16-byte aligned (the weights as MFMA fragments, rebuilt by every call: they change every step). */
+size_t pps_head_chain_ws_bytes(void);
+int pps_head_chain_fwd(const void* table, const int64_t* ids, const float* pts, const float* query, int64_t q, int k, int dtype, const float* wx,
+                       const float* w2, const float* b2, const float* w3, const float* b3, const float* wq, const float* bq, void* h1, void* y2, void* y3,
+                       void* qy, void* ws, void* stream);
 
 /* conv0a of PointNet in train() (3 coordinates -> 64 channels, source/base/nn.py:323): y [rows, 64] bf16 = x [rows, 3] w^T + bias with the batch
  * statistics of y -> out_affine / save / running statistics as in pps_rows_layer_fwd; backward: dw [64, 3], dbias [64] (NULL = skip), dgamma,

@@ -32,6 +32,12 @@ SIGNATURES = {
     'pps_mc_edge_blocks': (_I64, [_I64, _I64, _I64]),
     'pps_mc_count_f64': (_I, [_P, _I64, _I64, _I64, _c.c_double, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pps_mc_emit_f64': (_I, [_P, _I64, _I64, _I64, _c.c_double, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _P]),
+    'pps_mesh_components_ws_bytes': (_SZ, [_I64]),
+    'pps_mesh_small_components': (_I, [_P, _I64, _I64, _I, _P, _P, _P]),
+    'pps_mesh_weld_ws_bytes': (_SZ, [_I64]),
+    'pps_mesh_corner_weld': (_I, [_P, _I64, _I, _P, _P, _P, _P, _P]),
+    'pps_mesh_face_filter_ws_bytes': (_SZ, [_I64]),
+    'pps_mesh_face_filter': (_I, [_P, _I64, _P, _P, _P, _P]),
     'pps_dilate_box_u8': (_I, [_P, _P, _P, _I64, _I64, _I64, _I, _P]),
     'pps_grow_frontier_f64': (_I, [_P, _P, _P, _P, _P, _I64, _P]),
     'pps_grow_band_todo_f64': (_I, [_P, _P, _P, _I64, _P]),
@@ -83,6 +89,8 @@ SIGNATURES = {
     'pps_head_input_ws_bytes': (_SZ, [_I]),
     'pps_head_input_fwd': (_I, [_P, _P, _P, _P, _I64, _I, _I, _I, _P, _P, _P]),
     'pps_head_input_dwx': (_I, [_P, _P, _P, _P, _I64, _I, _I, _I, _P, _P, _P]),
+    'pps_head_chain_ws_bytes': (_SZ, []),
+    'pps_head_chain_fwd': (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pps_rows3_ws_bytes': (_SZ, []),
     'pps_rows3_fwd': (_I, [_P, _I64, _P, _P, _I, _P, _P, _P, _P, _P, _c.c_float, _c.c_float, _P, _P, _P, _P]),
     'pps_rows3_bwd': (_I, [_P, _P, _P, _I64, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pps_common.h"
 #include "../../include/ppsurf_amd.h"
 
 #define PPS_OK 0
@@ -95,6 +96,12 @@ int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t row
                        void* stream) {
     return PPS_BY_TYPE(pps_rows_layer_bwd(x, y, gy, rows, cin, cout, in_scale, in_shift, in_relu, w, gamma, save, d_affine, dx, dx_add, d_in_affine, dw, dbias,
                                           dgamma, dbeta, ws, stream));
+}
+size_t pps_head_chain_ws_bytes(void) { return rt_bf16::pps_head_chain_ws_bytes(); }
+int pps_head_chain_fwd(const void* table, const int64_t* ids, const float* pts, const float* query, int64_t q, int k, int dtype, const float* wx,
+                       const float* w2, const float* b2, const float* w3, const float* b3, const float* wq, const float* bq, void* h1, void* y2, void* y3,
+                       void* qy, void* ws, void* stream) {
+    return PPS_BY_TYPE(pps_head_chain_fwd(table, ids, pts, query, q, k, wx, w2, b2, w3, b3, wq, bq, h1, y2, y3, qy, ws, stream));
 }
 int pps_rows_layer_pooled_supported(int cin, int cout, int pool_p) { return rt_bf16::pps_rows_layer_pooled_supported(cin, cout, pool_p); }
 int pps_rows_layer_bwd_pooled(const void* x, const void* y, const void* gval, const uint8_t* garg, int pool_p, int64_t rows, int cin, int cout,

@@ -1358,6 +1358,8 @@ int pps_rows_layer_bwd_pooled(const void* x, const void* y, const void* gval, co
 int pps_rows_layer_pooled_supported(int cin, int cout, int pool_p) { return pooled_ok(cin, cout, true, pool_p, (int64_t)pool_p) ? 1 : 0; }
 
 
+#include "pps_head_chain_impl.h"
+
 #undef PPS_MFMA16
 #undef PPS_DISPATCH
 }  // namespace PPS_NS

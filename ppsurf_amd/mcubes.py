@@ -649,7 +649,16 @@ def clean_mesh_torch(verts, faces, min_component_faces=6, digits=8, welded=False
     scale = 10.0 ** digits
     nv = verts.shape[0]
     skip = False
-    if welded and grid_coords:
+    if welded and grid_coords and verts.is_cuda and verts.dtype == torch.float64 and faces.dtype == torch.int64:
+        # device meshes: the corner weld and the face filter are HIP kernels (csrc/pps_mesh.hip); same result as the torch form below, which host
+        # tensors (the CPU suite) still take
+        from . import ops
+        skip = True
+        remap, hot, merged = ops.mesh_corner_weld(verts, digits)
+        if merged:
+            faces = remap[faces]
+            faces = faces[ops.mesh_face_filter(faces, hot)]
+    elif welded and grid_coords:
         # the only vertices that can share a position: those that sit (after rounding) ON a grid corner -- a handful per mesh (float32 vertex
         # coordinates round a crossing within ~1e-5 of a corner onto it).  Merge exactly those, by position, and touch only the faces around them.
         skip = True
@@ -703,7 +712,10 @@ def clean_mesh_torch(verts, faces, min_component_faces=6, digits=8, welded=False
             keep = torch.full((int(finv.max()) + 1,), faces.shape[0], dtype=torch.int64, device=dev)
             keep.scatter_reduce_(0, finv, torch.arange(faces.shape[0], device=dev), reduce='amin')
             faces = faces[torch.sort(keep)[0]]
-    if faces.shape[0] and min_component_faces is not None:
+    if faces.shape[0] and min_component_faces is not None and faces.is_cuda and faces.dtype == torch.int64 and int(min_component_faces) <= 32:
+        from . import ops
+        faces = faces[~ops.mesh_small_components(faces, nv, int(min_component_faces))]       # HIP kernels (csrc/pps_mesh.hip)
+    elif faces.shape[0] and min_component_faces is not None:
         nf = faces.shape[0]
         e = torch.cat([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]])
         e = torch.sort(e, dim=1)[0]

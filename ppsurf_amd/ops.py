@@ -244,3 +244,54 @@ def marching_cubes(volume: torch.Tensor, level: float):
                                  tun_cand.data_ptr(), flags.data_ptr(), off[0].data_ptr(), off[1].data_ptr(), off[2].data_ptr(), n_vert, vidx.data_ptr(), verts.data_ptr(), faces.data_ptr(), st),
                'pps_mc_emit_f64')
     return verts, faces
+
+
+def mesh_small_components(faces: torch.Tensor, nv: int, k: int):
+    """bool [F]: faces of face-connected components with at most k faces (csrc/pps_mesh.hip: one hash-table pass over the edges + one bounded walk
+    per face; replaces trimesh's split + filter, source/base/mesh.py:22-38).  faces int64 [F,3] on the device."""
+    assert faces.is_cuda and faces.dtype == torch.int64 and faces.dim() == 2 and faces.shape[1] == 3
+    L = _lib.lib()
+    nf = faces.shape[0]
+    small = torch.empty(nf, dtype=torch.uint8, device=faces.device)
+    if nf == 0:
+        return small.bool()
+    faces = faces.contiguous()
+    ws = torch.empty(L.pps_mesh_components_ws_bytes(nf), dtype=torch.uint8, device=faces.device)
+    _lib.check(L.pps_mesh_small_components(faces.data_ptr(), nf, int(nv), int(k), small.data_ptr(), ws.data_ptr(), _stream(faces)), 'pps_mesh_small_components')
+    return small.bool()
+
+
+def mesh_corner_weld(verts: torch.Tensor, digits: int = 8):
+    """(remap int64 [V], hot bool [V], merged: int) of a mesh welded by grid-edge key, vertices float64 [V,3] in index space: the vertices that share
+    a rounded position on a grid corner are merged into the smallest id (trimesh merge_vertices, source/base/mesh.py:9, restricted to where it can
+    act).  One host read (the count decides whether the faces have to be touched at all)."""
+    assert verts.is_cuda and verts.dtype == torch.float64 and verts.dim() == 2 and verts.shape[1] == 3
+    L = _lib.lib()
+    nv = verts.shape[0]
+    dev = verts.device
+    verts = verts.contiguous()
+    remap = torch.empty(nv, dtype=torch.int64, device=dev)
+    hot = torch.empty(nv, dtype=torch.uint8, device=dev)
+    counters = torch.empty(2, dtype=torch.int32, device=dev)
+    ws = torch.empty(L.pps_mesh_weld_ws_bytes(nv), dtype=torch.uint8, device=dev)
+    _lib.check(L.pps_mesh_corner_weld(verts.data_ptr(), nv, int(digits), remap.data_ptr(), hot.data_ptr(), counters.data_ptr(), ws.data_ptr(), _stream(verts)),
+               'pps_mesh_corner_weld')
+    merged, out_of_range = counters.tolist()
+    if out_of_range:
+        raise _lib.PpsError('pps_mesh_corner_weld: vertex coordinates outside [0, 524287] (not a mesh in grid index space)')
+    return remap, hot, int(merged)
+
+
+def mesh_face_filter(faces: torch.Tensor, hot: torch.Tensor):
+    """bool [F] keep: not degenerate and, among the faces around a hot vertex, the first of its vertex triple (trimesh remove_degenerate_faces /
+    remove_duplicate_faces, source/base/mesh.py:12-17, after a corner weld)."""
+    assert faces.is_cuda and faces.dtype == torch.int64 and hot.dtype == torch.uint8
+    L = _lib.lib()
+    nf = faces.shape[0]
+    keep = torch.empty(nf, dtype=torch.uint8, device=faces.device)
+    if nf == 0:
+        return keep.bool()
+    faces = faces.contiguous()
+    ws = torch.empty(L.pps_mesh_face_filter_ws_bytes(nf), dtype=torch.uint8, device=faces.device)
+    _lib.check(L.pps_mesh_face_filter(faces.data_ptr(), nf, hot.data_ptr(), keep.data_ptr(), ws.data_ptr(), _stream(faces)), 'pps_mesh_face_filter')
+    return keep.bool()

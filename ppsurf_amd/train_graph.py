@@ -413,8 +413,10 @@ import os as _os
 _side_streams = {}
 
 
-def side_streams_on(t):
-    return t.is_cuda and _os.environ.get('PPS_FIT_STREAMS', '1') != '0' and torch.is_grad_enabled()
+def side_streams_on(t, branch='pointnet'):
+    """PPS_FIT_STREAMS: 1 (default) both branches, 0 none, or the name of one branch (pointnet | geometry)."""
+    mode = _os.environ.get('PPS_FIT_STREAMS', '1')
+    return t.is_cuda and torch.is_grad_enabled() and (mode == '1' or mode == branch)
 
 
 def _side(dev, name):
@@ -646,7 +648,7 @@ def encoder(enc, data):
               'b30': (enc.resnetb30.cv1, s2, s3, 'ids23'), 'b31': (enc.resnetb31.cv1, s3, s3, 'ids33'), 'b40': (enc.resnetb40.cv1, s3, s4, 'ids34'),
               'b41': (enc.resnetb41.cv1, s4, s4, 'ids44')}
     geo = dict.fromkeys(levels)
-    if side_streams_on(pts):
+    if side_streams_on(pts, 'geometry'):
         for name, (layer, p_in, p_out, table) in levels.items():
             with Forked(pts.device, 'geometry') as f:
                 g = fka_geometry_of(layer, p_in, p_out, data[table])
@@ -686,6 +688,7 @@ def encoder(enc, data):
     return dense(enc.fcout, xo.reshape(-1, xo.shape[-1])).view(b, pts.shape[1], -1)
 
 
+HEAD_CHAIN = _os.environ.get('PPS_HEAD_CHAIN', '1') != '0'      # the interpolation head's three layers as one kernel (else: one launch per layer)
 FUSED_ROWS = True            # False: every row layer through the separate ops (library GEMM + fused BatchNorm op), e.g. to compare
 
 
@@ -717,10 +720,15 @@ def interp_attention(proj, latents, pts, query, ids, last_layer=True):
             and train_ops.head_input_supported(w1.shape[0])):
         # fc2, fc3, fc_query as fused row layers (pps_rows_train.hip): each stores its RAW output once, the ReLU is applied by the consumer on
         # load (and masks the gradient on the way back), so no activated [B*Q*k, 256] tensor is written or read
-        h1 = train_ops.head_input(table, flat, pts.reshape(b * n, 3), query.reshape(b * q, 3), k, w1[:, c:])
-        y2 = train_ops.rows_layer(train_ops.Act(h1, None, True), _w2d(proj.fc2), proj.fc2.bias, None, True)
-        y3 = train_ops.rows_layer(y2, _w2d(proj.fc3), proj.fc3.bias, None, True)
-        pooled = train_ops.query_attn_pool(y3.raw, _w2d(proj.fc_query), proj.fc_query.bias, k)      # fc_query + attention pooling: one node
+        if HEAD_CHAIN and train_ops.head_chain_supported(w1.shape[0], _w2d(proj.fc_query).shape[0], k):
+            # the three layers in ONE kernel: a wave carries its rows through them in registers (csrc/pps_head_chain_impl.h)
+            pooled = train_ops.head_chain(table, flat, pts.reshape(b * n, 3), query.reshape(b * q, 3), k, w1[:, c:], (_w2d(proj.fc2), proj.fc2.bias),
+                                          (_w2d(proj.fc3), proj.fc3.bias), (_w2d(proj.fc_query), proj.fc_query.bias))
+        else:
+            h1 = train_ops.head_input(table, flat, pts.reshape(b * n, 3), query.reshape(b * q, 3), k, w1[:, c:])
+            y2 = train_ops.rows_layer(train_ops.Act(h1, None, True), _w2d(proj.fc2), proj.fc2.bias, None, True)
+            y3 = train_ops.rows_layer(y2, _w2d(proj.fc3), proj.fc3.bias, None, True)
+            pooled = train_ops.query_attn_pool(y3.raw, _w2d(proj.fc_query), proj.fc_query.bias, k)      # fc_query + attention pooling: one node
         out = dense(proj.fc_value, pooled)
         if last_layer:
             out = dense(proj.fc8, out)

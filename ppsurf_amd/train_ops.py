@@ -820,6 +820,99 @@ def query_attn_pool(y3, wq, bq, k):
     return _QueryAttnPool.apply(y3, wq, bq, k)
 
 
+class _HeadChain(torch.autograd.Function):
+    """head_input -> fc2 -> fc3 -> fc_query -> attention pooling of the interpolation head as ONE autograd node whose forward is the fused chain
+    kernel (pps_head_chain_fwd: the rows pass through the three layers in registers, the raw outputs the backward needs are written once) followed
+    by pps_attn_pool_fwd.  The backward pass is the sequence of backward entries the separate nodes (_QueryAttnPool, _RowsLayer x 2, _HeadInput)
+    run, on the same saved tensors."""
+
+    @staticmethod
+    def forward(ctx, table, ids, pts, query, k, wx, w2, b2, w3, b3, wq, bq):
+        _need_cuda(table, ids, pts, query, wx, w2, w3, wq)
+        L = _lib.lib()
+        table = _low(table)
+        ids = ids.contiguous()
+        f32 = lambda t: None if t is None else t.detach().float().contiguous()
+        pts32, q32, wx32, w2_32, w3_32, wq32 = f32(pts), f32(query), f32(wx), f32(w2), f32(w3), f32(wq)
+        b2_32, b3_32, bq32 = f32(b2), f32(b3), f32(bq)
+        nq, c, heads = q32.shape[0], table.shape[1], wq32.shape[0]
+        dev, dt = table.device, table.dtype
+        rows = nq * k
+        pad = (rows + 255) // 256 * 256               # the kernel writes whole 256-row units (unconditional stores): padded storage, views of the rows
+        h1, y2, y3 = (torch.empty((pad, c), device=dev, dtype=dt)[:rows] for _ in range(3))
+        qy = torch.empty((pad, heads), device=dev, dtype=dt)[:rows]
+        ws = torch.empty((L.pps_head_chain_ws_bytes(),), device=dev, dtype=torch.uint8)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        _lib.check(L.pps_head_chain_fwd(table.data_ptr(), ids.data_ptr(), pts32.data_ptr(), q32.data_ptr(), nq, k, _code(dt), wx32.data_ptr(), w2_32.data_ptr(),
+                                        ptr(b2_32), w3_32.data_ptr(), ptr(b3_32), wq32.data_ptr(), ptr(bq32), h1.data_ptr(), y2.data_ptr(), y3.data_ptr(),
+                                        qy.data_ptr(), ws.data_ptr(), _stream()), 'pps_head_chain_fwd')
+        pooled = torch.empty((nq, c), device=dev, dtype=dt)
+        _lib.check(L.pps_attn_pool_fwd(qy.data_ptr(), y3.data_ptr(), nq, k, heads, c, _code(dt), 1, pooled.data_ptr(), _stream()), 'pps_attn_pool_fwd')
+        ctx.save_for_backward(ids, pts32, q32, w2_32, w3_32, wq32, h1, y2, y3, qy)
+        ctx.meta = (table.shape[0], k, wx.dtype, tuple(wx.shape), w2.dtype, w3.dtype, wq.dtype, None if b2 is None else b2.dtype,
+                    None if b3 is None else b3.dtype, None if bq is None else bq.dtype)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        ids, pts32, q32, w2_32, w3_32, wq32, h1, y2, y3, qy = ctx.saved_tensors
+        n, k, wxdt, wxshape, w2dt, w3dt, wqdt, b2dt, b3dt, bqdt = ctx.meta
+        L = _lib.lib()
+        rows, c = y3.shape
+        heads = wq32.shape[0]
+        dev, dt = y3.device, y3.dtype
+        code = _code(dt)
+        st = _stream()
+        ptr = lambda t: None if t is None else t.data_ptr()
+        dpooled = dpooled.to(dt).contiguous()
+        # attention pooling + fc_query: the two gradients of y3 are summed inside fc_query's input-gradient kernel (dx_add)
+        dqy, dy3 = torch.empty_like(qy), torch.empty_like(y3)
+        _lib.check(L.pps_attn_pool_bwd(qy.data_ptr(), y3.data_ptr(), dpooled.data_ptr(), rows // k, k, heads, c, code, 1, dqy.data_ptr(), dy3.data_ptr(), st),
+                   'pps_attn_pool_bwd')
+        f32e = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+        dwq, dbq = f32e(heads, c), (f32e(heads) if bqdt is not None else None)
+        ws = torch.empty((L.pps_rows_layer_ws_bytes(c, c),), device=dev, dtype=torch.uint8)        # (the largest of the three layers)
+        _lib.check(L.pps_rows_layer_bwd(y3.data_ptr(), qy.data_ptr(), dqy.data_ptr(), rows, c, heads, code, None, None, 1, wq32.data_ptr(), None, None, None,
+                                        dy3.data_ptr(), dy3.data_ptr(), None, dwq.data_ptr(), ptr(dbq), None, None, ws.data_ptr(), st), 'pps_rows_layer_bwd')
+        del dqy
+        # fc3
+        dy2 = torch.empty_like(y2)
+        dw3, db3 = f32e(c, c), (f32e(c) if b3dt is not None else None)
+        _lib.check(L.pps_rows_layer_bwd(y2.data_ptr(), y3.data_ptr(), dy3.data_ptr(), rows, c, c, code, None, None, 1, w3_32.data_ptr(), None, None, None,
+                                        dy2.data_ptr(), None, None, dw3.data_ptr(), ptr(db3), None, None, ws.data_ptr(), st), 'pps_rows_layer_bwd')
+        del dy3
+        # fc2
+        dh1 = torch.empty_like(h1)
+        dw2, db2 = f32e(c, c), (f32e(c) if b2dt is not None else None)
+        _lib.check(L.pps_rows_layer_bwd(h1.data_ptr(), y2.data_ptr(), dy2.data_ptr(), rows, c, c, code, None, None, 1, w2_32.data_ptr(), None, None, None,
+                                        dh1.data_ptr(), None, None, dw2.data_ptr(), ptr(db2), None, None, ws.data_ptr(), st), 'pps_rows_layer_bwd')
+        del dy2
+        # head input: d table by the segmented sum of the gather, d wx
+        dtable = dwx = None
+        if ctx.needs_input_grad[0]:
+            order, offsets = csr(ids, n)
+            dt32 = f32e(n, c)
+            _lib.check(L.pps_segment_sum_rows_16(dh1.data_ptr(), order.data_ptr(), offsets.data_ptr(), n, c, code, dt32.data_ptr(), st), 'pps_segment_sum_rows_16')
+            dtable = dt32.to(dt)
+        if ctx.needs_input_grad[5]:
+            dwx = f32e(c, 3)
+            ws2 = torch.empty((L.pps_head_input_ws_bytes(c),), device=dev, dtype=torch.uint8)
+            _lib.check(L.pps_head_input_dwx(dh1.data_ptr(), ids.data_ptr(), pts32.data_ptr(), q32.data_ptr(), q32.shape[0], k, c, code, dwx.data_ptr(),
+                                            ws2.data_ptr(), st), 'pps_head_input_dwx')
+            dwx = dwx.reshape(wxshape).to(wxdt)
+        cast = lambda t, d: None if (t is None or d is None) else t.to(d)
+        return (dtable, None, None, None, None, dwx, dw2.to(w2dt), cast(db2, b2dt), dw3.to(w3dt), cast(db3, b3dt), dwq.to(wqdt), cast(dbq, bqdt))
+
+
+def head_chain_supported(c, heads, k):
+    return c == 256 and heads == 64 and 1 <= k <= 64
+
+
+def head_chain(table, ids, pts, query, k, wx, fc2, fc3, fc_query):
+    """pooled [Q, 256] of the interpolation head from the per-point table: fc2 / fc3 / fc_query are (weight [out, 256], bias or None) pairs."""
+    return _HeadChain.apply(table, ids, pts, query, k, wx, fc2[0], fc2[1], fc3[0], fc3[1], fc_query[0], fc_query[1])
+
+
 def attn_pool_supported(k, heads, c):
     return 1 <= k <= 64 and 1 <= heads <= 64 and c <= 256
 

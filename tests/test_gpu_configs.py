@@ -221,6 +221,99 @@ def test_config3_fit_step_at_full_batch_size(precision):
     assert float(np.median(list(rel.values()))) < {'32': 1e-4, 'bf16-mixed': 2e-2, '16-mixed': 1e-2}[precision]
 
 
+@pytest.mark.parametrize('precision', ['32', 'bf16-mixed'])
+def test_config3_fit_step_at_full_batch_size_against_the_reference(precision):
+    """BASELINE config 3 at its full batch size, pinned on the REFERENCE: tests/golden/train_ppsurf_full.npz holds logits, loss,
+    buffers and a seeded sample of every parameter gradient of ONE training step of the reference's PPSurfNetwork in train() on 10 shapes x 10 000
+    points x 2000 queries (tests/golden/make_golden_train_full.py; outputs from its fp32 run, gradients from its float64 run and -- as the
+    reference's own accuracy -- from its fp32 run).  The batch is rebuilt from seeds (tests/golden/cases_full.py) and the id tables checked by
+    digest.  fp32: the bars of the small fixture (tests/test_gpu_train.py::test_training_step_gpu).  bf16-mixed -- the dtype of the benched step,
+    head chain kernel, fused row layers and side streams included: logits within the 16-bit noise of a 60-layer network, and every gradient tensor
+    of significant size within a few per cent of the reference's float64 gradient in direction and length (sampled entries)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import cases_full as cf
+    from golden_util import load_golden
+    from test_train_graph_cpu import _check_sigs, _check_samples, _load
+    from ppsurf_amd import modules
+    import test_train_graph_cpu as T
+    g = load_golden('train_ppsurf_full')
+    data, occ = cf.full_fit_batch()
+    dig = cf.table_digests(data)
+    assert [str(k) for k in g['table_names']] == list(dig.keys()) and [str(v) for v in g['table_digests']] == list(dig.values())
+    assert cf.digest(occ) == str(g['occ_digest']) and cf.digest(data['pts_local_ps']) == str(g['patches_digest'])
+    net = _load(modules.PPSurfNetwork(in_channels=3, latent_size=256, out_channels=2, k=64, num_pts_local=cf.P, pointnet_latent_size=256), '', key='ppsurf',
+                digest=g['digest'])
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    net = net.to(DEV)
+    batch = {k: v.to(DEV) for k, v in data.items()}
+    want_ids = batch.pop('proj_ids')                                # PPSurf recomputes them (ppsurf_model.py:83)
+    occ = occ.to(DEV)
+    auto = {'32': None, 'bf16-mixed': torch.bfloat16}[precision]
+    with torch.autocast('cuda', dtype=auto or torch.bfloat16, enabled=auto is not None):
+        logits = net.forward(batch)
+        loss = torch.nn.functional.cross_entropy(logits.float(), occ, reduction='none').mean()
+    loss.backward()
+    assert torch.equal(batch['proj_ids'], want_ids)
+    grads = [(k, v.grad.float().cpu()) for k, v in net.named_parameters() if v.grad is not None]
+    assert [k for k, p in net.named_parameters() if p.grad is None] == [str(k) for k in g['unused']]
+    err_logits = float((logits.detach().float().cpu() - torch.from_numpy(g['logits'])).abs().max())
+    err_loss = abs(float(loss.detach()) - float(g['loss']))
+    if precision == '32':
+        assert err_logits <= 5e-5 * float(np.abs(g['logits']).max()) + 1e-5 and err_loss < 1e-5, (err_logits, err_loss)
+        _check_sigs(grads, g['gnames'], g['gsigs'], 1e-2, 'grad', sigs32=g['gsigs32'])
+        T_SAMPLE = 1024
+        worst = _check_samples_n(grads, g, 1e-2, T_SAMPLE)
+        print('fp32 at size: logits {:.2e}, loss {:.2e}; sampled gradient entries worst error / tolerance {:.3f} ({})'.format(err_logits, err_loss, *worst))
+        _check_sigs([(k, v.float().cpu()) for k, v in net.named_buffers()], g['bnames'], g['bsigs'], 2e-5, 'buffer')
+        return
+    # bf16-mixed: direction and length of every sampled gradient against the float64 reference
+    names, off = [str(k) for k in g['gnames']], g['gsamp_off']
+    named = dict(grads)
+    top = max(float(s[2]) for s in g['gsigs'])
+    stats = []
+    for i, k in enumerate(names):
+        sl = slice(int(off[i]), int(off[i + 1]))
+        ref = g['gsamp_val'][sl]
+        got = named[k].double().reshape(-1)[torch.from_numpy(g['gsamp_idx'][sl])].numpy()
+        if float(g['gsigs'][i][2]) < 1e-3 * top or np.linalg.norm(ref) == 0:
+            continue                                                # (biases in front of a train-mode BatchNorm: zero gradient, noise in both)
+        cos = float(got @ ref / (np.linalg.norm(got) * np.linalg.norm(ref) + 1e-300))
+        stats.append((cos, float(np.linalg.norm(got) / np.linalg.norm(ref)), k))
+    lo = min(stats)
+    ratio = sorted(s[1] for s in stats)
+    print('bf16-mixed at size: logits {:.3e} (scale {:.2f}), loss {:.2e}; {} gradient tensors: lowest cosine {:.4f} ({}), length ratio {:.3f} .. {:.3f}'.format(
+        err_logits, float(np.abs(g['logits']).max()), err_loss, len(stats), lo[0], lo[2], ratio[0], ratio[-1]))
+    assert err_logits <= 0.05 * float(np.abs(g['logits']).max()) and err_loss < 2e-2
+    assert len(stats) > 150 and lo[0] > 0.95 and 0.85 < ratio[0] and ratio[-1] < 1.15
+    assert float(np.median([s[0] for s in stats])) > 0.995
+
+
+def _check_samples_n(named, g, rtol, n_sample, noise=1e-6):
+    """test_train_graph_cpu._check_samples for a fixture with n_sample (not 4096) entries per tensor."""
+    named = dict(named)
+    names, off = [str(k) for k in g['gnames']], g['gsamp_off']
+    floor = noise * max(float(s[2]) for s in g['gsigs'])
+    worst = (0.0, None)
+    for i, k in enumerate(names):
+        sl = slice(int(off[i]), int(off[i + 1]))
+        idx, ref = g['gsamp_idx'][sl], g['gsamp_val'][sl]
+        t = named[k].detach().double().reshape(-1)
+        assert idx.shape[0] == min(n_sample, t.numel())
+        got = t[torch.from_numpy(idx)].numpy()
+        own = 3 * float(np.abs(g['gsamp_val32'][sl] - ref).max())
+        rms = float(g['gsigs'][i][2]) / np.sqrt(t.numel())
+        tol = 4 * rtol * max(float(np.abs(ref).max()), rms) + floor + own
+        err = float(np.abs(got - ref).max())
+        assert err <= tol, 'grad {}: sampled entries differ by {} (tolerance {})'.format(k, err, tol)
+        if tol > 0 and err / tol > worst[0]:
+            worst = (err / tol, k)
+    return worst
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'f16x3'])
 def test_config5_ppsurf_200nn_chunk_at_size(dtype):
     """BASELINE config 5 chunk: N = 250 000 points, P = 200, rec_batch_size = 25 000, k = 64 (configs/ppsurf_200nn.yaml) through the

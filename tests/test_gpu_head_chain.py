@@ -1,0 +1,119 @@
+"""The interpolation head's dense chain as one kernel (csrc/pps_head_chain_impl.h through train_ops.head_chain; source/poco_model.py:400-414 in
+train()) against (i) the same chain as separate launches (head_input, rows_layer x 2, query_attn_pool: the nodes it replaces -- same rounding
+points, so the stored tensors agree to the last bit except where the accumulation order inside an MFMA moves a value across a rounding boundary)
+and (ii) a float64 torch twin of the reference's formula on the 16-bit operands."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _case(nq, k, n, seed, dt):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, scale=1.0: (torch.randn(*s, generator=g) * scale)
+    table = r(n, 256).to(dt)
+    ids = torch.randint(0, n, (nq * k,), generator=g)
+    pts = torch.rand(n, 3, generator=g) - 0.5
+    query = torch.rand(nq, 3, generator=g) - 0.5
+    wx = r(256, 3, scale=0.5)
+    w2, w3, wq = r(256, 256, scale=1 / 16), r(256, 256, scale=1 / 16), r(64, 256, scale=1 / 8)
+    b2, b3, bq = r(256, scale=0.1), r(256, scale=0.1), r(64, scale=0.1)
+    dev = lambda t: t.to(DEV)
+    return [dev(t) for t in (table, ids, pts, query, wx, w2, b2, w3, b3, wq, bq)]
+
+
+def _separate(table, ids, pts, query, k, wx, w2, b2, w3, b3, wq, bq):
+    from ppsurf_amd import train_ops
+    h1 = train_ops.head_input(table, ids, pts, query, k, wx)
+    y2 = train_ops.rows_layer(train_ops.Act(h1, None, True), w2, b2, None, True)
+    y3 = train_ops.rows_layer(y2, w3, b3, None, True)
+    return train_ops.query_attn_pool(y3.raw, wq, bq, k)
+
+
+def _twin(table, ids, pts, query, k, wx, w2, b2, w3, b3, wq, bq, dt):
+    rd = lambda t: t.float().to(dt).double()                          # every stored tensor is rounded to the storage type
+    d = lambda t: t.double()
+    rel = (d(query).repeat_interleave(k, dim=0) - d(pts)[ids])
+    h1 = rd(d(table)[ids] + rel @ d(wx).t())
+    y2 = rd(torch.relu(h1) @ rd(w2).t() + d(b2))
+    y3 = rd(torch.relu(y2) @ rd(w3).t() + d(b3))
+    qy = rd(torch.relu(y3) @ rd(wq).t() + d(bq))
+    nq = query.shape[0]
+    att = torch.softmax(qy.view(nq, k, 64), dim=1).mean(dim=2)
+    return (att.unsqueeze(2) * torch.relu(y3).view(nq, k, 256)).sum(1)
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('nq,k,n', [(300, 64, 4000), (37, 64, 500), (41, 37, 700), (1, 64, 64), (2003, 64, 10000)])
+def test_head_chain_equals_the_separate_launches_and_the_formula(nq, k, n, dt):
+    from ppsurf_amd import train_ops
+    args = _case(nq, k, n, 7 + nq, dt)
+    table, ids, pts, query, wx, w2, b2, w3, b3, wq, bq = args
+    leaves = [table.clone().requires_grad_(True), wx.clone().requires_grad_(True)] + [t.clone().requires_grad_(True) for t in (w2, b2, w3, b3, wq, bq)]
+    leaves2 = [t.detach().clone().requires_grad_(True) for t in leaves]
+    with torch.autocast('cuda', dtype=dt):
+        fused = train_ops.head_chain(leaves[0], ids, pts, query, k, leaves[1], (leaves[2], leaves[3]), (leaves[4], leaves[5]), (leaves[6], leaves[7]))
+        sep = _separate(leaves2[0], ids, pts, query, k, leaves2[1], *leaves2[2:])
+    assert fused.dtype == dt and fused.shape == (nq, 256)
+    ref = _twin(table, ids, pts, query, k, wx, w2, b2, w3, b3, wq, bq, dt)
+    scale = float(ref.abs().max())
+    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    # (i) the nodes it replaces: values that cross a rounding boundary in one of the three stored layers move the pooled row by a few ulp
+    assert float((fused.double() - sep.double()).abs().max()) <= 4 * eps * scale
+    # (ii) the formula: storage rounding of three layers of 256-term sums + the pooled row itself
+    assert float((fused.double() - ref).abs().max()) <= 6 * eps * scale
+    gout = torch.randn(nq, 256, generator=torch.Generator().manual_seed(3)).to(DEV).to(dt)
+    gf = torch.autograd.grad(fused, leaves, gout)
+    gs = torch.autograd.grad(sep, leaves2, gout)
+    for name, a, b in zip(('table', 'wx', 'w2', 'b2', 'w3', 'b3', 'wq', 'bq'), gf, gs):
+        assert a.shape == b.shape and a.dtype == b.dtype
+        tol = 0.04 * float(b.double().abs().max()) + 1e-6           # (16-bit gradients of a ReLU network whose stored activations differ in a few ulp)
+        if name == 'bq':
+            # a softmax does not see a constant added to its logits: the exact gradient of fc_query's bias is ZERO, what both paths return is the
+            # rounding noise of a 19 200-term sum of 16-bit values that cancel -- compared against that noise level, not against itself
+            tol = 2e-4
+        d = a.double() - b.double()
+        # a stored activation that sits within an ulp of zero takes the other side of its ReLU in one of the two paths: single entries move by the
+        # whole contribution of a row, so entries are held to 3 x the bar and the tensor as a whole (l2) to the bar
+        if name == 'bq':
+            assert float(d.abs().max()) <= tol, name
+        else:
+            assert float(d.abs().max()) <= 3 * tol and float(d.norm()) <= 0.02 * float(b.double().norm()) + 1e-6, name
+
+
+def test_head_chain_is_what_the_training_graph_runs():
+    """interp_attention (train_graph) with the chain kernel and with the separate launches: same output and parameter gradients within bf16."""
+    from ppsurf_amd import modules, train_graph
+    import contextlib
+    import io
+    torch.manual_seed(5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        proj = modules.InterpAttentionKHeadsNet(256, 256, 64).to(DEV).train() if hasattr(modules, 'InterpAttentionKHeadsNet') else None
+    if proj is None:
+        pytest.skip('no standalone head module')
+    b, n, q, k = 2, 3000, 500, 64
+    lat = torch.randn(b, n, 256, device=DEV)
+    pts = torch.rand(b, n, 3, device=DEV) - 0.5
+    qry = torch.rand(b, q, 3, device=DEV) - 0.5
+    ids = torch.randint(0, n, (b, q, k), device=DEV)
+    outs = []
+    for flag in (True, False):
+        train_graph.HEAD_CHAIN = flag
+        try:
+            proj.zero_grad()
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                y = train_graph.interp_attention(proj, lat, pts, qry, ids)
+            y.float().square().mean().backward()
+            outs.append((y.detach().float(), {nme: p.grad.detach().clone() for nme, p in proj.named_parameters() if p.grad is not None}))
+        finally:
+            train_graph.HEAD_CHAIN = True
+            train_graph.release_step_caches()
+    (ya, ga), (yb, gb) = outs
+    assert float((ya - yb).abs().max()) <= 2.0 ** -6 * float(yb.abs().max())
+    assert ga.keys() == gb.keys() and len(ga) >= 10
+    for nme in ga:
+        if nme == 'fc_query.bias':                  # exactly zero in exact arithmetic (softmax is shift-invariant): both are cancellation noise
+            assert float(ga[nme].abs().max()) <= 1e-2 * float(ga['fc_query.weight'].abs().max()) + 1e-6
+            continue
+        assert float((ga[nme] - gb[nme]).abs().max()) <= 0.03 * float(gb[nme].abs().max()) + 1e-7, nme

@@ -424,3 +424,64 @@ def test_table_rows_discs_and_tubes_have_the_right_euler_characteristic():
                 fan = t[:, 0] == mcubes.CENTER
                 assert not (t[:, 1:] == mcubes.CENTER).any() and (not fan.any() or fan[0])      # the fan is listed first (the kernels rely on it)
     assert n_tube > 300 and tri.shape[0] == nbase + len({int(a) for a in mcubes._TUN_CAND[:, 2]})
+
+
+# ---- the clean-up kernels themselves (csrc/pps_mesh.hip) -----------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('k', [1, 2, 6, 7, 13, 32])
+def test_small_component_kernel_equals_union_find_also_on_non_manifold_edges(k):
+    """ops.mesh_small_components against the specification's union-find: strips and fans of known sizes, a random soup over few vertices (edges
+    shared by three and more faces: the kernel chains an edge's owners in arrival order) and a large closed surface, face order shuffled."""
+    from ppsurf_amd import ops
+    v, f = _strips_and_fans()
+    rng = np.random.default_rng(k)
+    soup = rng.integers(0, 40, size=(60, 3)) + v.shape[0]                      # 60 random triangles over 40 vertices: heavily non-manifold
+    soup = soup[(soup[:, 0] != soup[:, 1]) & (soup[:, 1] != soup[:, 2]) & (soup[:, 0] != soup[:, 2])]
+    book = np.array([[0, 1, 2 + i] for i in range(k + 3)]) + v.shape[0] + 40   # k + 3 faces around ONE edge: a single component of k + 3 faces
+    book2 = np.array([[0, 1, 2 + i] for i in range(max(k, 2))]) + v.shape[0] + 100    # and one of exactly k faces around an edge (k = 1: two)
+    vol, _ = _volumes()['blobs']
+    vb, fb = mcubes.marching_cubes(vol, 0.0)
+    faces = np.concatenate([f, soup, book, book2, fb + v.shape[0] + 200])
+    faces = faces[rng.permutation(faces.shape[0])]
+    nv = int(faces.max()) + 1
+    got = ops.mesh_small_components(torch.from_numpy(faces).to('cuda:0'), nv, k).cpu().numpy()
+    label = M.components_union_find(faces)
+    size = np.bincount(label, minlength=faces.shape[0])[label]
+    assert np.array_equal(got, size <= k)
+    assert got.any() and not got.all()
+
+
+@pytest.mark.gpu
+def test_corner_weld_and_face_filter_kernels_equal_the_host_form():
+    """clean_mesh_torch(welded=True, grid_coords=True) on the device (ops.mesh_corner_weld / mesh_face_filter) against the same call on host tensors
+    (torch form) and the specification: vertices exactly on a grid corner, within 10^-8 of it on either side of a rounding step of the 8th digit
+    (0.4e-8: same rounded position; 0.9e-8: the neighbouring one -- NOT merged, like trimesh), just outside the tolerance, faces that become
+    degenerate and faces that become duplicates."""
+    vol, _ = _volumes()['ties']
+    v, f = mcubes.marching_cubes(vol, 0.0)
+    v = v.astype(np.float32).astype(np.float64)
+    rng = np.random.default_rng(4)
+    extra_v, extra_f = [], []
+    base = v.shape[0]
+    for i, (corner, offs) in enumerate([((3.0, 4.0, 5.0), [0.0, 0.0, 0.4e-8, -0.4e-8, 0.9e-8, 2e-8]), ((7.0, 7.0, 2.0), [0.0, 0.3e-8, 0.0]),
+                                        ((0.0, 1.0, 0.0), [0.0, 0.45e-8, 0.0, 1.2e-8])]):
+        ids = []
+        for o in offs:
+            ids.append(base + len(extra_v))
+            extra_v.append([corner[0] + o, corner[1], corner[2] - o])
+        far = []
+        for j in range(4):
+            far.append(base + len(extra_v))
+            extra_v.append([corner[0] + 0.5 + 0.1 * j, corner[1] + 0.25, corner[2] + 0.125 * (j + 1)])
+        extra_f += [[ids[0], far[0], far[1]], [ids[1], far[0], far[1]],          # duplicates of each other once ids[0] and ids[1] are merged
+                    [ids[0], ids[1], far[2]],                                    # degenerate after the merge
+                    [ids[-1], far[2], far[3]], [ids[2 % len(ids)], far[1], far[3]]]
+    vv = np.concatenate([v, np.array(extra_v)])
+    ff = np.concatenate([f, np.array(extra_f, dtype=np.int64)])
+    ff = ff[rng.permutation(ff.shape[0])]
+    vd, fd = mcubes.clean_mesh_torch(torch.from_numpy(vv).to('cuda:0'), torch.from_numpy(ff).to('cuda:0'), min_component_faces=None, welded=True, grid_coords=True)
+    vh, fh = mcubes.clean_mesh_torch(torch.from_numpy(vv), torch.from_numpy(ff), min_component_faces=None, welded=True, grid_coords=True)
+    vd, fd = vd.cpu().numpy(), fd.cpu().numpy()
+    assert fd.shape == tuple(fh.shape) and vd.shape == tuple(vh.shape) and fd.shape[0] < ff.shape[0]
+    assert np.array_equal(vd, vh.numpy()) and np.array_equal(fd, fh.numpy())      # same vertices in the same order, same faces in the same order
+    M.check_clean_mesh(vv, ff, vd, fd, min_component_faces=None)
