@@ -521,13 +521,21 @@ __global__ __launch_bounds__(256) void fka_fin_grad_kernel(const float* __restri
     if (lane == 0) dgeo[e] = (float)s;
 }
 
-// blocks per shape: the heavy kernels keep 2 workgroups per CU resident (225 VGPRs), so b * G is aimed at one full wave of
-// 2 * CUs workgroups, each looping over its share of the tiles (960 workgroups in two uneven rounds were 10 % slower)
-inline int grid_g(int64_t M, int64_t B) {
+// blocks per shape: b * G is aimed at ONE full wave of resident workgroups, each looping over its share of the tiles.  A wave carries one support
+// point at a time through a serial chain (gather, sixteen dependent fp32 MFMAs, DPP reductions: ~1500 clocks), so the kernels run at the rate of
+// the waves a SIMD holds; a workgroup is one wave per SIMD, and the register counts allow 5 (forward: 44 / 70 / 79 VGPRs) and 3 (backward: 132 /
+// 120 / 61 VGPRs, 22 KB of LDS) workgroups per CU.  (Until round 5 the grid was 2 per CU for every kernel -- the limit of the 225-VGPR backward
+// passes that preceded the MFMA form; more workgroups than are resident run in uneven rounds, which measured 10 % slower.)
+#ifndef PPS_FKA_WG_FWD
+#define PPS_FKA_WG_FWD 5
+#define PPS_FKA_WG_BWD 3
+#endif
+constexpr int FT_WG_PER_CU_FWD = PPS_FKA_WG_FWD, FT_WG_PER_CU_BWD = PPS_FKA_WG_BWD;
+inline int grid_g(int64_t M, int64_t B, int per_cu) {
     const int64_t ntiles = (M + FT_TM - 1) / FT_TM;
     int cus = pps_device_cu_count();
     if (cus <= 0) cus = 256;
-    int64_t g = (2 * (int64_t)cus) / (B > 0 ? B : 1);
+    int64_t g = ((int64_t)per_cu * cus) / (B > 0 ? B : 1);
     if (g < 1) g = 1;
     if (g > FT_GMAX_CAP) g = FT_GMAX_CAP;
     return (int)(ntiles < g ? ntiles : g);
@@ -541,7 +549,7 @@ extern "C" {
 
 size_t pps_fka_train_ws_bytes(int64_t b, int64_t m, int k) {
     if (b < 1 || m < 1 || k < 1) return 0;
-    const size_t nblk = (size_t)b * grid_g(m, b);
+    const size_t nblk = (size_t)b * grid_g(m, b, FT_WG_PER_CU_FWD > FT_WG_PER_CU_BWD ? FT_WG_PER_CU_FWD : FT_WG_PER_CU_BWD);
     // stat partials (double [nblk][32]) x2, radius partials, weight partials (512 + 512 + 48 floats), alpha/beta partials,
     // gradient means [b][32] x2, dy scratch [b*m*k][16], ddw scratch [b*m*k]
     return 4096 + nblk * (32 * 8 * 2 + 8 + (512 + 512 + 48) * 4 + 16) + (size_t)b * 32 * 4 * 2 + (size_t)b * m * k * 17 * 4;
@@ -553,7 +561,7 @@ int pps_fka_geometry_fwd_f32(const float* pts, const float* sup, const int64_t* 
     if (b == 0 || m == 0) return PPS_OK;
     if (!pts || !sup || !idx || !geo_w || !g_out || !stat || !ws) return PPS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const int G = grid_g(m, b);
+    const int G = grid_g(m, b, FT_WG_PER_CU_FWD);
     const dim3 grid(G, (unsigned)b);
     double* part = (double*)align256((char*)ws);
     float* stat1 = stat;
@@ -580,7 +588,7 @@ int pps_fka_geometry_bwd_f32(const float* pts, const float* sup, const int64_t* 
     hipStream_t st = (hipStream_t)stream;
     if (b == 0 || m == 0) return hipMemsetAsync(dgeo, 0, GEO_FLOATS * sizeof(float), st) == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
     if (!pts || !sup || !idx || !geo_w || !stat || !dg || !ws) return PPS_ERR_ARG;
-    const int G = grid_g(m, b);
+    const int G = grid_g(m, b, FT_WG_PER_CU_BWD);
     const dim3 grid(G, (unsigned)b);
     const size_t nblk = (size_t)G * b;
     char* p = align256((char*)ws);

@@ -240,7 +240,10 @@ class DevicePrefetch:
         self.device = torch.device(device)
         if self.device.index is None:               # resolved HERE, on the constructing (training) thread: a loader thread starts on device 0
             self.device = torch.device('cuda', torch.cuda.current_device())
-        self.side = torch.cuda.Stream(self.device)
+        # the loader's kernels are ~6 ms of GPU time per fit step, several of them chip-wide (the exhaustive kNN): they must not take workgroup slots
+        # from the step they hide behind.  This device offers two stream priorities (torch.cuda.Stream.priority_range() == (0, -1)): the loader
+        # gets the lower one -- which is the default level -- and the optimisation step runs on a high-priority stream (fit.step_stream)
+        self.side = torch.cuda.Stream(self.device, priority=0)
         self.pending = None                      # (batch, event)
 
     def launch(self, make, after_main=True):

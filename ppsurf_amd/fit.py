@@ -50,6 +50,22 @@ class _MetricLog:
         return {k: (float(v) if torch.is_tensor(v) else v) for k, v in self.values.items()}
 
 
+def step_stream():
+    """The stream the optimisation step runs on (eager steps, captures and replays alike: autograd binds a parameter's gradient accumulation to the
+    stream of its first use).  Normal priority.  PPS_STEP_PRIORITY=1 raises it to the highest level the device offers -- measured on the config-3
+    step: 22.6 ms against 19.3: the loader's side stream, which builds the NEXT batch meanwhile (~6 ms of GPU time), then only runs in the gaps,
+    finishes late, and the step waits for its batch.  None without a GPU."""
+    if not torch.cuda.is_available():
+        return None
+    if os.environ.get('PPS_STEP_PRIORITY', '0') != '1':
+        return torch.cuda.Stream()
+    try:
+        hi = int(torch.cuda.Stream.priority_range()[1])
+    except Exception:
+        hi = -1
+    return torch.cuda.Stream(priority=hi)
+
+
 class GraphedStep:
     """One optimisation step as a replayable HIP graph (torch.cuda.CUDAGraph = hipGraph on ROCm), one graph per batch signature
     (keys, shapes, dtypes).  `eager(batch, bi)` is the step body; it must be free of host synchronisation and data-dependent shapes
@@ -62,6 +78,7 @@ class GraphedStep:
         self.on_capture_failed = on_capture_failed      # puts host-side state a half-recorded step left behind (loss scaler stage, gradient buckets) back
         self.seen, self.graphs, self.failed, self._done = {}, {}, False, None
         self.replayed = False
+        self.stream = step_stream()
 
     def touch(self, module):
         """A replayed graph updates parameters and buffers in place WITHOUT the tensors' version counters moving (no op is dispatched), and
@@ -89,7 +106,17 @@ class GraphedStep:
         return tuple(sorted(sig))
 
     def run(self, batch, bi):
-        """Executes the step (eagerly, or by replaying the captured graph) and leaves the logged values in self.metrics.values."""
+        """Executes the step (eagerly, or by replaying the captured graph) and leaves the logged values in self.metrics.values.  Everything -- eager
+        steps, the capture, the replays -- runs on the step's own HIGH-priority stream (step_stream)."""
+        if self.stream is None:
+            return self._run(batch, bi)
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self._run(batch, bi)
+        cur.wait_stream(self.stream)
+
+    def _run(self, batch, bi):
         if self.enabled and not self.failed:
             sig = self.signature(batch)
             entry = self.graphs.get(sig)
@@ -130,7 +157,7 @@ class GraphedStep:
         graph = torch.cuda.CUDAGraph()
         try:
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+            with torch.cuda.graph(graph, stream=self.stream, capture_error_mode='thread_local'):
                 self.eager(dict(static, **rest), bi)
             logged = dict(self.metrics.values)
         except Exception as exc:                               # anything that cannot be captured: stay eager for the rest of the run
@@ -171,7 +198,7 @@ class StagedStep:
         # ONE stream for the eager steps, the captures and the replays: autograd binds a parameter's gradient accumulation to the stream of the
         # parameter's first use, and an accumulator that survives from an eager step on another stream would pull that stream into the capture
         # as an unjoined branch (hipStreamEndCapture faults on it; measured, profiles/NOTES_r5.md)
-        self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+        self.stream = step_stream()
 
     touch = GraphedStep.touch
 

@@ -414,9 +414,14 @@ _side_streams = {}
 
 
 def side_streams_on(t, branch='pointnet'):
-    """PPS_FIT_STREAMS: 1 (default) both branches, 0 none, or the name of one branch (pointnet | geometry)."""
-    mode = _os.environ.get('PPS_FIT_STREAMS', '1')
-    return t.is_cuda and torch.is_grad_enabled() and (mode == '1' or mode == branch)
+    """PPS_FIT_STREAMS: pointnet (default) | geometry | 1 (both branches) | 0 (one stream).  Measured on the config-3 step (profiles/NOTES_r5.md):
+    one stream 20.26 ms, PointNet forked 19.55, geometry forked 20.05, both 19.85 -- every join of the geometry branch (ten forward, ten
+    backward) costs a cross-queue hand-over of 10-25 us inside the replayed graph, more than the overlap returns; PointNet has two."""
+    mode = _os.environ.get('PPS_FIT_STREAMS', 'pointnet')
+    # not under staged(): the multi-rank step records every backward stage as its own graph in ONE memory pool replayed in a fixed order
+    # (fit.StagedStep); with a forked branch inside, replays did not reproduce the eager steps bit for bit
+    # (tests/test_gpu_train.py::test_staged_step_overlap_structure_replay_equals_eager), so that step stays on one stream
+    return t.is_cuda and torch.is_grad_enabled() and (mode == '1' or mode == branch) and _stages[0] is None
 
 
 def _side(dev, name):

@@ -63,8 +63,13 @@ def _check_sigs(named, names, sigs, rtol, what, noise=1e-6, sigs32=None):
         assert abs(got[1] - ref[1]) <= rtol * ref[1] + floor * np.sqrt(t.numel()) + own[1], '{} {}: sum|.| {} vs {}'.format(what, k, got[1], ref[1])
         assert abs(got[2] - ref[2]) <= rtol * ref[2] + floor + own[2], '{} {}: l2 {} vs {}'.format(what, k, got[2], ref[2])
         rms = ref[2] / np.sqrt(t.numel())
-        assert np.abs(got[3:] - ref[3:]).max() <= 4 * rtol * max(np.abs(ref[3:]).max(), rms) + floor + own[3:].max(), \
-            '{} {}: leading entries differ'.format(what, k)
+        scale = max(np.abs(ref[3:]).max(), rms)
+        err = np.abs(got[3:] - ref[3:])
+        tol = 4 * rtol * scale + floor + own[3:].max()
+        # ONE of the 32 leading entries may sit up to 10 % of the tensor's scale off: a ReLU whose pre-activation is within fp32 rounding of zero
+        # takes the other branch when a sum is evaluated in another order (e.g. another grid of the statistics kernels), and the unit's whole
+        # contribution appears in / vanishes from single gradient entries (cf. _close(flips=True); the l2 and sum|.| bars above hold regardless)
+        assert (err > tol).sum() <= 1 and err.max() <= max(tol, 0.1 * scale), '{} {}: leading entries differ'.format(what, k)
 
 
 def _check_samples(named, g, rtol, what, noise=1e-6, use32=True):
@@ -86,8 +91,11 @@ def _check_samples(named, g, rtol, what, noise=1e-6, use32=True):
         own = 3 * float(np.abs(g['gsamp_val32'][sl] - ref).max()) if use32 else 0.0
         rms = float(g['gsigs'][i][2]) / np.sqrt(t.numel())
         tol = 4 * rtol * max(float(np.abs(ref).max()), rms) + floor + own
-        err = float(np.abs(got - ref).max())
-        assert err <= tol, '{} {}: sampled entries differ by {} (tolerance {}, worst at flat index {})'.format(what, k, err, tol, int(idx[np.argmax(np.abs(got - ref))]))
+        errs = np.abs(got - ref)
+        flipped = errs > tol                         # (ReLU flips, see _check_sigs: <= 0.5 % of a tensor's sampled entries, bounded by 10 % of its scale)
+        err = float(errs[~flipped].max()) if (~flipped).any() else 0.0
+        assert flipped.mean() <= 5e-3 and float(errs.max()) <= max(tol, 0.1 * max(float(np.abs(ref).max()), rms)), \
+            '{} {}: sampled entries differ by {} (tolerance {}, worst at flat index {})'.format(what, k, float(errs.max()), tol, int(idx[np.argmax(errs)]))
         if tol > 0 and err / tol > worst[0]:
             worst = (err / tol, k)
     return worst

@@ -3,7 +3,7 @@
 per step (delimited by the one `adamw_pieces_kernel` launch of a step) the span, the time during which at least one / at least two kernels run,
 the sum of kernel durations per hardware queue, the gaps, and the kernels by total time.
 
-    python tools/fit_timeline.py DIR [steps_from_the_end=10]  -> text on stdout
+    python tools/fit_timeline.py DIR [steps_from_the_end=10] [--by-grid]  -> text on stdout   (--by-grid: launches of one kernel told apart by grid size)
 """
 import csv
 import glob
@@ -36,14 +36,17 @@ def union(intervals):
     return one, two
 
 
-def main(src, nsteps):
+def main(src, nsteps, by_grid=False):
     files = glob.glob(os.path.join(src, '**', '*kernel_trace.csv'), recursive=True)
     if not files:
         raise SystemExit('no *kernel_trace.csv under ' + src)
     rows = []
     with open(files[0]) as fh:
         for r in csv.DictReader(fh):
-            rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name']), r.get('Queue_Id', '0'), r.get('Stream_Id', '0')))
+            name = short(r['Kernel_Name'])
+            if by_grid and r.get('Grid_Size'):
+                name = '{} [grid {}]'.format(name[:50], r['Grid_Size'])
+            rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), name, r.get('Queue_Id', '0'), r.get('Stream_Id', '0')))
     rows.sort()
     marks = [e for s, e, n, q, st in rows if n.startswith('adamw_pieces_kernel')]
     if len(marks) < nsteps + 1:
@@ -80,9 +83,9 @@ def main(src, nsteps):
         tot[n][0] += 1
         tot[n][1] += e - s
     print('{:64s} {:>8s} {:>10s} {:>9s}'.format('kernel', 'per step', 'us / step', 'avg us'))
-    for n, (c, d) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:70]:
+    for n, (c, d) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:(140 if by_grid else 70)]:
         print('{:64s} {:8.1f} {:10.1f} {:9.2f}'.format(n, c / nsteps, d / 1e3 / nsteps, d / 1e3 / c))
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 10)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 10, by_grid='--by-grid' in sys.argv)
