@@ -414,10 +414,13 @@ _side_streams = {}
 
 
 def side_streams_on(t, branch='pointnet'):
-    """PPS_FIT_STREAMS: pointnet (default) | geometry | 1 (both branches) | 0 (one stream).  Measured on the config-3 step (profiles/NOTES_r5.md):
-    one stream 20.26 ms, PointNet forked 19.55, geometry forked 20.05, both 19.85 -- every join of the geometry branch (ten forward, ten
-    backward) costs a cross-queue hand-over of 10-25 us inside the replayed graph, more than the overlap returns; PointNet has two."""
-    mode = _os.environ.get('PPS_FIT_STREAMS', 'pointnet')
+    """PPS_FIT_STREAMS: 1 (default: both branches forked) | 0 (one stream) | pointnet | geometry (one branch; experiments only).  Measured on the
+    config-3 step (profiles/NOTES_r5.md section 3): one stream 20.26 ms, both branches 19.85, geometry only 20.05 -- every join of the geometry branch
+    (ten forward, ten backward) is a cross-queue hand-over of 10-25 us inside the replayed graph.  PointNet ALONE was the fastest (19.55 ms) and is NOT
+    usable: a step recorded with only that fork replays differently from the eager step (bf16-mixed: loss off by 0.07 after four replays, the
+    config-1 fit learns visibly worse; fp32 and every other mode: equal to the eager step within its own run-to-run noise; unexplained --
+    tests/test_gpu_train.py::test_replayed_bf16_step_with_forked_branches_equals_the_eager_step guards the default)."""
+    mode = _os.environ.get('PPS_FIT_STREAMS', '1')
     # not under staged(): the multi-rank step records every backward stage as its own graph in ONE memory pool replayed in a fixed order
     # (fit.StagedStep); with a forked branch inside, replays did not reproduce the eager steps bit for bit
     # (tests/test_gpu_train.py::test_staged_step_overlap_structure_replay_equals_eager), so that step stays on one stream
@@ -694,7 +697,7 @@ def encoder(enc, data):
 
 
 HEAD_CHAIN = _os.environ.get('PPS_HEAD_CHAIN', '1') != '0'      # the interpolation head's three layers as one kernel (else: one launch per layer)
-FUSED_ROWS = True            # False: every row layer through the separate ops (library GEMM + fused BatchNorm op), e.g. to compare
+FUSED_ROWS = _os.environ.get('PPS_FUSED_ROWS', '1') != '0'            # False: every row layer through the separate ops (library GEMM + fused BatchNorm op), e.g. to compare
 
 
 def fused_rows_ok(x, *bns):

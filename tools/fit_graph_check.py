@@ -5,7 +5,7 @@ import random
 res = {}
 for graph in (False, True):
     random.seed(0); torch.manual_seed(0)
-    fit = workloads.FitStep(batch=4, n=2000, q=300, precision='32', graph=True, n_batches=2)
+    fit = workloads.FitStep(batch=4, n=2000, q=300, precision=(sys.argv[1] if len(sys.argv) > 1 else '32'), graph=True, n_batches=2)
     fit.stepper.enabled = graph                            # same fused / capturable AdamW in both runs
     for m in fit.net.modules():
         if isinstance(m, torch.nn.Dropout): m.p = 0.0
