@@ -194,7 +194,7 @@ inline char* al256(char* p) { return (char*)(((uintptr_t)p + 255) & ~(uintptr_t)
 extern "C" {
 
 size_t pps_mesh_components_ws_bytes(int64_t nf) {
-    if (nf < 1 || nf > 700000000) return 0;
+    if (nf < 1 || nf > 100000000) return 0;
     const size_t cap = capacity_for(3 * nf);
     return 1024 + cap * (sizeof(u64) + sizeof(int)) + (size_t)nf * 6 * sizeof(int);
 }
@@ -202,7 +202,7 @@ size_t pps_mesh_components_ws_bytes(int64_t nf) {
 /* small [nf] = 1 for the faces of face-connected components (faces sharing an edge) with at most k faces (1 <= k <= 32), else 0.
  * faces int64 [nf, 3] vertex ids below nv.  ws: pps_mesh_components_ws_bytes(nf) bytes. */
 int pps_mesh_small_components(const int64_t* faces, int64_t nf, int64_t nv, int k, uint8_t* small, void* ws, void* stream) {
-    if (nf < 0 || nv < 1 || k < 1 || k > MS_KMAX || nf > 700000000 || nv > 0x7fffffff) return PPS_ERR_ARG;
+    if (nf < 0 || nv < 1 || k < 1 || k > MS_KMAX || nf > 100000000 || nv > 0x7fffffff) return PPS_ERR_ARG;      // (capacity 4 x 3 nf < 2^31 slots)
     if (nf == 0) return PPS_OK;
     if (!faces || !small || !ws) return PPS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -218,7 +218,7 @@ int pps_mesh_small_components(const int64_t* faces, int64_t nf, int64_t nv, int 
 }
 
 size_t pps_mesh_weld_ws_bytes(int64_t nv) {
-    if (nv < 1 || nv > 500000000) return 0;
+    if (nv < 1 || nv > 400000000) return 0;
     const size_t cap = capacity_for(nv);
     return 1024 + cap * (sizeof(u64) + sizeof(int));
 }
@@ -228,7 +228,7 @@ size_t pps_mesh_weld_ws_bytes(int64_t nv) {
  * was merged into (zeroed here), counters int32 [2] = {number of merged vertices, 1 if a coordinate was outside the range}.  ws:
  * pps_mesh_weld_ws_bytes(nv) bytes. */
 int pps_mesh_corner_weld(const double* verts, int64_t nv, int digits, int64_t* remap, uint8_t* hot, int* counters, void* ws, void* stream) {
-    if (nv < 0 || nv > 500000000 || digits < 1 || digits > 12) return PPS_ERR_ARG;
+    if (nv < 0 || nv > 400000000 || digits < 1 || digits > 12) return PPS_ERR_ARG;
     if (nv == 0) return PPS_OK;
     if (!verts || !remap || !hot || !counters || !ws) return PPS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -249,14 +249,14 @@ int pps_mesh_corner_weld(const double* verts, int64_t nv, int digits, int64_t* r
 }
 
 size_t pps_mesh_face_filter_ws_bytes(int64_t nf) {
-    if (nf < 1 || nf > 500000000) return 0;
+    if (nf < 1 || nf > 400000000) return 0;
     return 1024 + (size_t)capacity_for(nf) * sizeof(int);
 }
 
 /* keep uint8 [nf]: 0 for degenerate faces (two equal vertex ids) and for every face that repeats the vertex set of a face with a smaller index, checked
  * among the faces that touch a `hot` vertex (uint8 [nv]); faces int64 [nf, 3] AFTER remapping.  ws: pps_mesh_face_filter_ws_bytes(nf) bytes. */
 int pps_mesh_face_filter(const int64_t* faces, int64_t nf, const uint8_t* hot, uint8_t* keep, void* ws, void* stream) {
-    if (nf < 0 || nf > 500000000) return PPS_ERR_ARG;
+    if (nf < 0 || nf > 400000000) return PPS_ERR_ARG;
     if (nf == 0) return PPS_OK;
     if (!faces || !hot || !keep || !ws) return PPS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;

@@ -398,7 +398,7 @@ def release_step_caches():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# independent branches of the step on side streams
+# independent branches of the step on side streams  [EXPERIMENT, off by default: PPS_FIT_STREAMS, see side_streams_on]
 # ---------------------------------------------------------------------------------------------------------------------
 # The step is a long chain of small kernels (the encoder: ~600 launches of 5-30 us on a few hundred workgroups) next to a few heavy streaming ones
 # (PointNet on 10^6 patch rows).  Two branches do not depend on the encoder's features at all:
@@ -407,20 +407,19 @@ def release_step_caches():
 # Forked onto side streams they run beside the feature chain -- and so do their BACKWARD passes: autograd runs a node's backward on the stream of its
 # forward and orders the streams with events, so the three geometry backward passes of a layer (which nothing downstream waits for) and PointNet's
 # backward leave the critical path as well.  Recorded into a HIP graph the forks and joins become edges of the graph.
-# PPS_FIT_STREAMS=0 keeps everything on one stream.
+# Measured and NOT adopted (side_streams_on): the product keeps the step on one stream.
 import os as _os
 
 _side_streams = {}
 
 
 def side_streams_on(t, branch='pointnet'):
-    """PPS_FIT_STREAMS: 1 (default: both branches forked) | 0 (one stream) | pointnet | geometry (one branch; experiments only).  Measured on the
-    config-3 step (profiles/NOTES_r5.md section 3): one stream 20.26 ms, both branches 19.85, geometry only 20.05 -- every join of the geometry branch
-    (ten forward, ten backward) is a cross-queue hand-over of 10-25 us inside the replayed graph.  PointNet ALONE was the fastest (19.55 ms) and is NOT
-    usable: a step recorded with only that fork replays differently from the eager step (bf16-mixed: loss off by 0.07 after four replays, the
-    config-1 fit learns visibly worse; fp32 and every other mode: equal to the eager step within its own run-to-run noise; unexplained --
-    tests/test_gpu_train.py::test_replayed_bf16_step_with_forked_branches_equals_the_eager_step guards the default)."""
-    mode = _os.environ.get('PPS_FIT_STREAMS', '1')
+    """PPS_FIT_STREAMS: 0 (default: one stream) | 1 (both branches forked) | pointnet | geometry.  The forks are an EXPERIMENT that stays switched off
+    (measurements in profiles/NOTES_r5.md section 3): with the geometry kernels at their resident occupancy (5 / 3 workgroups per CU) forking them
+    beside the feature chain makes the config-3 step SLOWER (21.4 ms against ~19.7 on one stream: they fill the chip and the twenty joins cost 10-25 us
+    each); PointNet alone was the fastest configuration (19.3 ms) but a bf16-mixed step recorded with only that fork does not replay like the eager
+    step (loss off by 0.07 after four replays; unexplained), so it is not usable."""
+    mode = _os.environ.get('PPS_FIT_STREAMS', '0')
     # not under staged(): the multi-rank step records every backward stage as its own graph in ONE memory pool replayed in a fixed order
     # (fit.StagedStep); with a forked branch inside, replays did not reproduce the eager steps bit for bit
     # (tests/test_gpu_train.py::test_staged_step_overlap_structure_replay_equals_eager), so that step stays on one stream

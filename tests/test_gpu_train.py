@@ -574,11 +574,11 @@ def test_staged_step_overlap_structure_replay_equals_eager():
     assert not bad, bad[:5]
 
 
-def test_replayed_bf16_step_with_forked_branches_equals_the_eager_step():
-    """The config-3 step body at a small size, bf16-mixed, with the side streams of train_graph (PointNet and the geometry branches forked inside
-    the recorded graph): eight optimisation steps replayed from the HIP graph against the same eight steps run eagerly.  bf16 steps are not
-    bit-reproducible from run to run (loss differences of 1e-3 .. 7e-3 between two identical runs, with or without graph); a fork that loses a
-    dependency in the recorded graph shows as 0.07 (measured with PPS_FIT_STREAMS=pointnet, see train_graph.side_streams_on)."""
+def test_replayed_bf16_step_equals_the_eager_step():
+    """The config-3 step body at a small size, bf16-mixed (the benched dtype: head chain kernel, fused row layers, hand-written dense layers): eight
+    optimisation steps replayed from the HIP graph against the same eight steps run eagerly.  bf16 steps are not bit-reproducible from run to run
+    (loss differences of 1e-3 .. 7e-3 between two identical runs, with or without graph; the fp32 step IS, tools/fit_graph_check.py); a recorded
+    graph that loses a dependency shows as 0.07 (measured with the experimental PPS_FIT_STREAMS=pointnet, see train_graph.side_streams_on)."""
     import random
     import bench_workloads as workloads
     res = {}
