@@ -251,7 +251,7 @@ def pmc_traffic(dtype):
     have changed since, the figure is NOT reported (traffic: null) instead of silently going stale."""
     import bench_workloads as workloads
     here = workloads.csrc_digest()
-    for tag in ('round4', 'round3', 'round2'):
+    for tag in ('round5', 'round4', 'round3', 'round2'):
         path = os.path.join(REPO, 'profiles', '{}_{}_pmc.json'.format(tag, dtype))
         if os.path.isfile(path):
             d = json.load(open(path))
@@ -509,20 +509,23 @@ def main():
 
 def fit_roofline(ms_per_step):
     """Executed matrix flops and HBM bytes of one fit step from the committed counter passes of the REPLAYED step (tools/profile_train_pmc.sh ->
-    profiles/round4_train_pmc.json) against the step time measured in THIS run -- only if the file was measured on the same kernel sources and
+    profiles/round5_train_pmc.json) against the step time measured in THIS run -- only if the file was measured on the same kernel sources and
     training code (bench_workloads.fit_digest); otherwise no roofline is reported (the round-3 object mixed an eager step of an older
     commit with the replayed step's time)."""
     import bench_workloads as workloads
-    path = os.path.join(REPO, 'profiles', 'round4_train_pmc.json')
-    if not os.path.isfile(path):
+    paths = [os.path.join(REPO, 'profiles', '{}_train_pmc.json'.format(tag)) for tag in ('round5', 'round4')]
+    paths = [q for q in paths if os.path.isfile(q)]
+    if not paths:
         return {'roofline': None, 'roofline_note': 'no counter passes of the replayed fit step committed'}
+    path = paths[0]
+    name = 'profiles/' + os.path.basename(path)
     d = json.load(open(path))
     if d.get('fit_digest') != workloads.fit_digest():
-        return {'roofline': None, 'roofline_note': 'profiles/round4_train_pmc.json was measured on other sources (digest {} at commit {}, now {}): not reported'.format(
-            d.get('fit_digest', 'unrecorded'), d.get('git_head', 'unrecorded'), workloads.fit_digest())}
+        return {'roofline': None, 'roofline_note': '{} was measured on other sources (digest {} at commit {}, now {}): not reported'.format(
+            name, d.get('fit_digest', 'unrecorded'), d.get('git_head', 'unrecorded'), workloads.fit_digest())}
     s = ms_per_step * 1e-3
-    return {'roofline': {'source': 'profiles/round4_train_pmc.json (tools/profile_train_pmc.sh: rocprofv3 --pmc passes of {} at commit {}, same sources; per-step sums over all '
-                                   'kernels incl. the data preparation on the second stream); step time from this run'.format(d.get('command', '?'), d.get('git_head', 'unrecorded')),
+    return {'roofline': {'source': '{} (tools/profile_train_pmc.sh: rocprofv3 --pmc passes of {} at commit {}, same sources; per-step sums over all '
+                                   'kernels incl. the data preparation on the second stream); step time from this run'.format(name, d.get('command', '?'), d.get('git_head', 'unrecorded')),
                          'mfma_flops_per_step': d['mfma_flops_per_step'], 'hbm_bytes_per_step': d['hbm_bytes_per_step'],
                          'achieved_tflops': d['mfma_flops_per_step'] / s / 1e12, 'mfma_frac_of_bf16_peak': d['mfma_flops_per_step'] / s / 1e12 / PEAK_F16_MFMA_TFLOPS,
                          'achieved_hbm_tb_s': d['hbm_bytes_per_step'] / s / 1e12, 'hbm_frac': d['hbm_bytes_per_step'] / s / 8e12,

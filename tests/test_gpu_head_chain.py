@@ -1,7 +1,9 @@
 """The interpolation head's dense chain as one kernel (csrc/pps_head_chain_impl.h through train_ops.head_chain; source/poco_model.py:400-414 in
 train()) against (i) the same chain as separate launches (head_input, rows_layer x 2, query_attn_pool: the nodes it replaces -- same rounding
 points, so the stored tensors agree to the last bit except where the accumulation order inside an MFMA moves a value across a rounding boundary)
-and (ii) a float64 torch twin of the reference's formula on the 16-bit operands."""
+and (ii) a float64 torch twin of the reference's formula on the 16-bit operands.
+The kernel is an opt-in experiment (PPS_HEAD_CHAIN=1; train_graph.HEAD_CHAIN): correct to these tolerances, not run-to-run identical
+(profiles/NOTES_r5.md section 3)."""
 import pytest
 import torch
 
