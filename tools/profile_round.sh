@@ -9,7 +9,9 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
 python bench.py --quick --dtype $DT > $OUT/bench.json 2> $OUT/bench.err
-BENCH="python $PWD/bench.py --steps 20 --warmup 3 --quick --dtype $DT"
+# [r5] the traced / counted command runs ONE chunk lane: with the product default of two lanes the kernels of two chunks overlap and a kernel's
+# traced duration contains its share of the other lane (the bench line's per-kernel times come from its own single-lane pass for the same reason)
+BENCH="env PPS_CHUNK_LANES=1 python $PWD/bench.py --steps 20 --warmup 3 --quick --dtype $DT"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1
