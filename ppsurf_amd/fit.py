@@ -51,11 +51,11 @@ class _MetricLog:
 
 
 def step_stream():
-    """The stream the optimisation step runs on (eager steps, captures and replays alike: autograd binds a parameter's gradient accumulation to the
-    stream of its first use).  Normal priority.  PPS_STEP_PRIORITY=1 raises it to the highest level the device offers -- measured on the config-3
-    step: 22.6 ms against 19.3: the loader's side stream, which builds the NEXT batch meanwhile (~6 ms of GPU time), then only runs in the gaps,
-    finishes late, and the step waits for its batch.  None without a GPU."""
-    if not torch.cuda.is_available():
+    """A stream of its own for the single-rank optimisation step -- an EXPERIMENT, off by default: `GraphedStep` runs eager steps, the capture and the
+    replays on the caller's current stream.  Measured on the config-3 step (profiles/NOTES_r5.md section 3): on a stream of its own 21.3 ms against
+    20.25 on the current stream, on a HIGH-priority stream of its own 22.6 (the loader's side stream, which builds the next batch meanwhile, then only
+    runs in the gaps and the step waits for its batch).  PPS_STEP_STREAM=1 (and PPS_STEP_PRIORITY=1) select those.  None = the current stream."""
+    if not torch.cuda.is_available() or os.environ.get('PPS_STEP_STREAM', '0') != '1':
         return None
     if os.environ.get('PPS_STEP_PRIORITY', '0') != '1':
         return torch.cuda.Stream()
@@ -106,8 +106,8 @@ class GraphedStep:
         return tuple(sorted(sig))
 
     def run(self, batch, bi):
-        """Executes the step (eagerly, or by replaying the captured graph) and leaves the logged values in self.metrics.values.  Everything -- eager
-        steps, the capture, the replays -- runs on the step's own HIGH-priority stream (step_stream)."""
+        """Executes the step (eagerly, or by replaying the captured graph) and leaves the logged values in self.metrics.values; on the caller's
+        current stream unless step_stream() hands out one of its own."""
         if self.stream is None:
             return self._run(batch, bi)
         cur = torch.cuda.current_stream()
@@ -198,7 +198,7 @@ class StagedStep:
         # ONE stream for the eager steps, the captures and the replays: autograd binds a parameter's gradient accumulation to the stream of the
         # parameter's first use, and an accumulator that survives from an eager step on another stream would pull that stream into the capture
         # as an unjoined branch (hipStreamEndCapture faults on it; measured, profiles/NOTES_r5.md)
-        self.stream = step_stream()
+        self.stream = torch.cuda.Stream() if torch.cuda.is_available() else None
 
     touch = GraphedStep.touch
 
