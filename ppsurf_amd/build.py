@@ -60,7 +60,7 @@ def build(force=False, verbose=False, variant=None, defines=()):
 
 if __name__ == '__main__':
     argv = sys.argv[1:]
-    variant, defines = None, [a for a in argv if a.startswith('-D')]
+    variant, defines = None, [a for a in argv if a.startswith(('-D', '-f', '-m'))]
     if '--variant' in argv:
         variant = argv[argv.index('--variant') + 1]
     print(build(force='--force' in argv, verbose=True, variant=variant, defines=defines))

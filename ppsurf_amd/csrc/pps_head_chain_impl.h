@@ -55,6 +55,9 @@ __global__ __launch_bounds__(256) void head_chain_pack_kernel(const float* __res
     img[i] = as_frag(p);
 }
 
+// floats of padding in front of channel c's row of the Wx table: the four lane groups of a wave read rows 16 channels apart -- 256 B, the same
+// banks, without it
+#define HC_WXPAD(c) (((c) >> 4) * 4)
 __global__ __launch_bounds__(512, 1) void head_chain_fwd_kernel(const HeadChainArgs a) {
     bf16x8* wbuf = (bf16x8*)smem;                                   // [HC_NBUF][HC_CHUNK_FRAGS]
     float* bs = (float*)(wbuf + HC_NBUF * HC_CHUNK_FRAGS);          // b2 [256], b3 [256], bq [64]
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(512, 1) void head_chain_fwd_kernel(const HeadChainA
 
     for (int i = threadIdx.x; i < HC_C; i += 512) { bs[i] = a.b2 ? a.b2[i] : 0.f; bs[HC_C + i] = a.b3 ? a.b3[i] : 0.f; }
     for (int i = threadIdx.x; i < HC_HEADS; i += 512) bs[2 * HC_C + i] = a.bq ? a.bq[i] : 0.f;
-    for (int i = threadIdx.x; i < HC_C * 4; i += 512) wxs[i] = (i & 3) < 3 ? a.wx[(i >> 2) * 3 + (i & 3)] : 0.f;
+    for (int i = threadIdx.x; i < HC_C * 4; i += 512) wxs[i + HC_WXPAD(i >> 2)] = (i & 3) < 3 ? a.wx[(i >> 2) * 3 + (i & 3)] : 0.f;
     // chunks 0, 1, 2 -> buffers 0, 1, 2.  Chunks travel L2 -> LDS without passing through registers (global_load_lds_dwordx4, pps_common.h)
 #pragma unroll
     for (int c = 0; c < HC_NBUF - 1; ++c)
@@ -113,10 +116,8 @@ __global__ __launch_bounds__(512, 1) void head_chain_fwd_kernel(const HeadChainA
         //      every wait it places also waits for the weight chunk requested last), together with the ids of the next unit
         bf16x8 fa[2][8], fb[2][8];
         u32x4 raw[2][8];
-        // No weight chunk may be in flight while this phase reads wxs: with L2 -> LDS copies outstanding here, one ds_read_b128 in ~10^5 returned
-        // the Wx row of ANOTHER channel to the 16 lanes that share it (a whole tile wrong in one channel, different from run to run; measured:
-        // tools/dbg/head_chain_check.py -- with this wait h1 is bit-identical to pps_head_input_fwd and every output is run-to-run identical).
-        // The chunks requested during the last three chunks of the previous unit are 1-3 chunk times old: the wait is for the last epilogue's stores.
+        // The wait is for the last epilogue's stores (the chunks requested during the last three chunks of the previous unit are 1-3 chunk times
+        // old): the table rows requested next are then the only loads the compiler's own waits in this phase have to count.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int s = 0; s < 8; ++s)
@@ -133,8 +134,16 @@ __global__ __launch_bounds__(512, 1) void head_chain_fwd_kernel(const HeadChainA
                 float e[8] = {lo16(q4.x), hi16(q4.x), lo16(q4.y), hi16(q4.y), lo16(q4.z), hi16(q4.z), lo16(q4.w), hi16(q4.w)};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const f32x4 w = *(const f32x4*)(wxs + (c0 + j) * 4);
+                    const f32x4 w = *(const f32x4*)(wxs + (c0 + j) * 4 + HC_WXPAD(c0 + j));
                     e[j] += w[0] * rel[t][0] + w[1] * rel[t][1] + w[2] * rel[t][2];
+                    // Opaque on purpose: it keeps the SLP vectoriser from pairing channels j, j + 1.  The paired form reads four Wx rows ahead
+                    // (ds_read_b128 x 4, partial lgkmcnt waits) and builds its operand pairs IN the rows' destination registers (v_pk_mov_b32 /
+                    // v_mov_b32 into them while later rows are still in flight) -- and, on gfx950, lanes 48-63 of the second wave of a SIMD then
+                    // sometimes saw a stale value in one channel: ~1 row unit in 10^4, different from run to run, 50 x more often after an
+                    // unrelated change of the epilogue's code.  Measured (profiles/NOTES_r5.md section 3): 165 of 300 launches at the fit batch's size
+                    // differed from the first with the paired code, 0 of 18 000 (9 x 10^7 row units) with this line -- also with that epilogue --, and
+                    // h1 is bit-identical to pps_head_input_fwd.
+                    asm volatile("" : "+v"(e[j]));
                 }
                 const u32x4 p = {pack2(e[0], e[1]), pack2(e[2], e[3]), pack2(e[4], e[5]), pack2(e[6], e[7])};
 #ifndef PPS_HC_NOSTORE
@@ -180,7 +189,10 @@ __global__ __launch_bounds__(512, 1) void head_chain_fwd_kernel(const HeadChainA
                 unsigned p[8];
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
-                    const f32x4 v = acc[t][o] + *(const f32x4*)(bias + 4 * o);
+                    f32x4 v = acc[t][o] + *(const f32x4*)(bias + 4 * o);
+#ifdef PPS_HC_EB        // (the perturbation of the note in the gather phase: scalar epilogue)
+                    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+#endif
                     p[2 * o] = pack2(v[0], v[1]);
                     p[2 * o + 1] = pack2(v[2], v[3]);
                 }
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(512, 1) void head_chain_fwd_kernel(const HeadChainA
     }
 }
 
-constexpr size_t head_chain_lds() { return (size_t)HC_NBUF * HC_CHUNK_FRAGS * 16 + (size_t)(2 * HC_C + HC_HEADS + 4 * HC_C) * 4; }
+constexpr size_t head_chain_lds() { return (size_t)HC_NBUF * HC_CHUNK_FRAGS * 16 + (size_t)(2 * HC_C + HC_HEADS + 4 * HC_C + 4 * (HC_C / 16)) * 4; }
 
 size_t pps_head_chain_ws_bytes() { return (size_t)HC_CHUNKS * HC_CHUNK_FRAGS * 16; }
 

@@ -695,11 +695,10 @@ def encoder(enc, data):
     return dense(enc.fcout, xo.reshape(-1, xo.shape[-1])).view(b, pts.shape[1], -1)
 
 
-# The interpolation head's three layers as ONE kernel (csrc/pps_head_chain_impl.h): built, 0.36 ms faster in the config-3 step (0.60 against 0.97 ms),
-# and NOT the default: its outputs are not run-to-run identical (rare wrong LDS reads in the gather phase of a workgroup's first row unit, in every
-# variant of the weight stream that was tried -- profiles/NOTES_r5.md section 3), which shows as a flaky bit-exact replay test of the staged step.
-# PPS_HEAD_CHAIN=1 switches it on (experiments); the product runs one launch per layer.
-HEAD_CHAIN = _os.environ.get('PPS_HEAD_CHAIN', '0') == '1'
+# The interpolation head's three layers as ONE kernel (csrc/pps_head_chain_impl.h): 0.36 ms off the config-3 step (0.60 against 0.97 ms for the
+# separate launches), same stored tensors (h1 bit-identical to pps_head_input_fwd, the layers to the tolerance of tests/test_gpu_head_chain.py) and
+# run-to-run identical.  PPS_HEAD_CHAIN=0: one launch per layer (the form it is compared with).
+HEAD_CHAIN = _os.environ.get('PPS_HEAD_CHAIN', '1') != '0'
 FUSED_ROWS = _os.environ.get('PPS_FUSED_ROWS', '1') != '0'            # False: every row layer through the separate ops (library GEMM + fused BatchNorm op), e.g. to compare
 
 
