@@ -3,7 +3,8 @@
 per step (delimited by the one `adamw_pieces_kernel` launch of a step) the span, the time during which at least one / at least two kernels run,
 the sum of kernel durations per hardware queue, the gaps, and the kernels by total time.
 
-    python tools/fit_timeline.py DIR [steps_from_the_end=10] [--by-grid]  -> text on stdout   (--by-grid: launches of one kernel told apart by grid size)
+    python tools/fit_timeline.py DIR [steps_from_the_end=10] [--by-grid] [--per-queue]  -> text on stdout   (--by-grid: launches of one kernel told apart by grid
+    size; --per-queue: the kernel table once more per hardware queue -- the step's queue and the loader's)
 """
 import csv
 import glob
@@ -36,7 +37,7 @@ def union(intervals):
     return one, two
 
 
-def main(src, nsteps, by_grid=False):
+def main(src, nsteps, by_grid=False, per_queue=False):
     files = glob.glob(os.path.join(src, '**', '*kernel_trace.csv'), recursive=True)
     if not files:
         raise SystemExit('no *kernel_trace.csv under ' + src)
@@ -85,7 +86,17 @@ def main(src, nsteps, by_grid=False):
     print('{:64s} {:>8s} {:>10s} {:>9s}'.format('kernel', 'per step', 'us / step', 'avg us'))
     for n, (c, d) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:(140 if by_grid else 70)]:
         print('{:64s} {:8.1f} {:10.1f} {:9.2f}'.format(n, c / nsteps, d / 1e3 / nsteps, d / 1e3 / c))
+    if per_queue:
+        for key in sorted(per_q, key=lambda k: -len(per_q[k])):
+            tq = defaultdict(lambda: [0, 0])
+            for s, e, n, q, st in win:
+                if (q, st) == key:
+                    tq[n][0] += 1
+                    tq[n][1] += e - s
+            print('--- queue {} stream {}: kernels by total time'.format(*key))
+            for n, (c, d) in sorted(tq.items(), key=lambda kv: -kv[1][1])[:90]:
+                print('{:64s} {:8.1f} {:10.1f} {:9.2f}'.format(n, c / nsteps, d / 1e3 / nsteps, d / 1e3 / c))
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 10, by_grid='--by-grid' in sys.argv)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 10, by_grid='--by-grid' in sys.argv, per_queue='--per-queue' in sys.argv)
