@@ -369,6 +369,11 @@ int pps_gather_max_arg_f32(const float* x, const int64_t* idx, int64_t m, int k,
 /* its backward: dx [n,c] from dout [m,c], arg and the CSR of idx. */
 int pps_gather_max_bwd_f32(const float* dout, const int32_t* arg, const int64_t* order, const int64_t* offsets, int64_t n, int k,
                            int c, float* dx, void* stream);
+/* the same pair on 16-bit storage (dtype 1 bfloat16, 2 IEEE half): x, out, dout, dx in that type -- the maximum is one of the stored values, the
+ * gradient is summed in fp32 in CSR order and rounded once; what an autocast step would otherwise do with four cast kernels around each op. */
+int pps_gather_max_arg_16(const void* x, const int64_t* idx, int64_t m, int k, int c, int dtype, void* out, int32_t* arg, void* stream);
+int pps_gather_max_bwd_16(const void* dout, const int32_t* arg, const int64_t* order, const int64_t* offsets, int64_t n, int k, int c, int dtype,
+                          void* dx, void* stream);
 
 /* FKAConv geometry branch in train() mode, forward and backward (the part of FKAConvLayer.forward that turns neighbour
  * offsets into the [M,K,16] kernel-weighting matrix).   replaces: source/base/nn.py:601-643 under autograd.

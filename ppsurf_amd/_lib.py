@@ -78,6 +78,8 @@ SIGNATURES = {
     'pps_neighbour_contract_bwd': (_I, [_P, _P, _P, _P, _I64, _I, _I, _I, _P, _P, _P]),
     'pps_gather_max_arg_f32': (_I, [_P, _P, _I64, _I, _I, _P, _P, _P]),
     'pps_gather_max_bwd_f32': (_I, [_P, _P, _P, _P, _I64, _I, _I, _P, _P]),
+    'pps_gather_max_arg_16': (_I, [_P, _P, _I64, _I, _I, _I, _P, _P, _P]),
+    'pps_gather_max_bwd_16': (_I, [_P, _P, _P, _P, _I64, _I, _I, _I, _P, _P]),
     'pps_fka_train_ws_bytes': (_SZ, [_I64, _I64, _I]),
     'pps_fka_geometry_fwd_f32': (_I, [_P, _P, _P, _I64, _I64, _I, _P, _c.c_float, _P, _P, _P, _P]),
     'pps_fka_geometry_bwd_f32': (_I, [_P, _P, _P, _I64, _I64, _I, _P, _P, _P, _P, _P, _P]),

@@ -261,28 +261,34 @@ int contract_bwd_t(const T* x, const int64_t* idx, const float* g, const T* dout
 }
 
 
-// out[m,c] = max_j x[idx[m,j], c], arg[m,c] = first j attaining it
-__global__ void __launch_bounds__(TB) gather_max_arg_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
-                                                            int64_t m, int k, int c, float* __restrict__ out,
+// out[m,c] = max_j x[idx[m,j], c], arg[m,c] = first j attaining it.  T: float, or a 16-bit storage type (the maximum of 16-bit values is one of
+// them: the result is exact in the type it came in)
+template <typename T>
+__global__ void __launch_bounds__(TB) gather_max_arg_kernel(const T* __restrict__ x, const int64_t* __restrict__ idx,
+                                                            int64_t m, int k, int c, T* __restrict__ out,
                                                             int32_t* __restrict__ arg) {
     const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (t >= m * c) return;
     const int64_t row = t / c;
     const int ch = (int)(t - row * c);
-    float best = x[idx[row * k] * c + ch];
+    int64_t at = idx[row * k] * c + ch;
+    float best = ld1(x + at);
     int bj = 0;
     for (int j = 1; j < k; ++j) {
-        const float v = x[idx[row * k + j] * c + ch];
-        if (v > best) { best = v; bj = j; }
+        const int64_t a = idx[row * k + j] * c + ch;
+        const float v = ld1(x + a);
+        if (v > best) { best = v; bj = j; at = a; }
     }
-    out[t] = best;
+    out[t] = x[at];
     arg[t] = bj;
 }
 
 // dx[n,c] = sum over entries e=(m,j) pointing at n (CSR order) of dout[m,c] * [arg[m,c] == j]
-__global__ void __launch_bounds__(TB) gather_max_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ arg,
+//   (T a 16-bit type: gradients read in it, summed in fp32 in CSR order, the sum rounded to it once)
+template <typename T>
+__global__ void __launch_bounds__(TB) gather_max_bwd_kernel(const T* __restrict__ dout, const int32_t* __restrict__ arg,
                                                             const int64_t* __restrict__ order, const int64_t* __restrict__ offsets,
-                                                            int64_t n, int k, int c, float* __restrict__ dx) {
+                                                            int64_t n, int k, int c, T* __restrict__ dx) {
     const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (t >= n * c) return;
     const int64_t row = t / c;
@@ -293,9 +299,9 @@ __global__ void __launch_bounds__(TB) gather_max_bwd_kernel(const float* __restr
         const int64_t mj = order[e];
         const int64_t mm = mj / k;
         const int j = (int)(mj - mm * k);
-        if (arg[mm * c + ch] == j) acc += dout[mm * c + ch];
+        if (arg[mm * c + ch] == j) acc += ld1(dout + mm * c + ch);
     }
-    dx[t] = acc;
+    st1(dx + t, acc);
 }
 
 }  // namespace
@@ -385,7 +391,18 @@ int pps_gather_max_arg_f32(const float* x, const int64_t* idx, int64_t m, int k,
     if (m < 0 || k < 1 || c < 1) return 1;
     if (m == 0) return 0;
     if (!x || !idx || !out || !arg) return 1;
-    gather_max_arg_kernel<<<blocks_for(m * c), TB, 0, (hipStream_t)stream>>>(x, idx, m, k, c, out, arg);
+    gather_max_arg_kernel<float><<<blocks_for(m * c), TB, 0, (hipStream_t)stream>>>(x, idx, m, k, c, out, arg);
+    return launch_status();
+}
+
+int pps_gather_max_arg_16(const void* x, const int64_t* idx, int64_t m, int k, int c, int dtype, void* out, int32_t* arg, void* stream) {
+    if (m < 0 || k < 1 || c < 1 || (dtype != 1 && dtype != 2)) return 1;
+    if (m == 0) return 0;
+    if (!x || !idx || !out || !arg) return 1;
+    if (dtype == 1)
+        gather_max_arg_kernel<uint16_t><<<blocks_for(m * c), TB, 0, (hipStream_t)stream>>>((const uint16_t*)x, idx, m, k, c, (uint16_t*)out, arg);
+    else
+        gather_max_arg_kernel<half_c><<<blocks_for(m * c), TB, 0, (hipStream_t)stream>>>((const half_c*)x, idx, m, k, c, (half_c*)out, arg);
     return launch_status();
 }
 
@@ -394,7 +411,20 @@ int pps_gather_max_bwd_f32(const float* dout, const int32_t* arg, const int64_t*
     if (n < 0 || k < 1 || c < 1) return 1;
     if (n == 0) return 0;
     if (!order || !offsets || !dx) return 1;
-    gather_max_bwd_kernel<<<blocks_for(n * c), TB, 0, (hipStream_t)stream>>>(dout, arg, order, offsets, n, k, c, dx);
+    gather_max_bwd_kernel<float><<<blocks_for(n * c), TB, 0, (hipStream_t)stream>>>(dout, arg, order, offsets, n, k, c, dx);
+    return launch_status();
+}
+
+int pps_gather_max_bwd_16(const void* dout, const int32_t* arg, const int64_t* order, const int64_t* offsets, int64_t n, int k, int c, int dtype,
+                          void* dx, void* stream) {
+    if (n < 0 || k < 1 || c < 1 || (dtype != 1 && dtype != 2)) return 1;
+    if (n == 0) return 0;
+    if (!order || !offsets || !dx) return 1;
+    if (dtype == 1)
+        gather_max_bwd_kernel<uint16_t><<<blocks_for(n * c), TB, 0, (hipStream_t)stream>>>((const uint16_t*)dout, arg, order, offsets, n, k, c,
+                                                                                          (uint16_t*)dx);
+    else
+        gather_max_bwd_kernel<half_c><<<blocks_for(n * c), TB, 0, (hipStream_t)stream>>>((const half_c*)dout, arg, order, offsets, n, k, c, (half_c*)dx);
     return launch_status();
 }
 

@@ -499,7 +499,10 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
             touch = staticmethod(core.touch)
         stepper = _Split
     else:
-        stepper = GraphedStep(eager_step, metrics, enabled=use_graph, on_capture_failed=reset_host_state)
+        # PPS_FIT_GRAPH=norecord (tests): everything the graph mode sets up -- capturable optimizer, device-side learning rate, batches built by the
+        # loader thread -- but the step is never recorded: the eager twin a replayed fit is compared with
+        stepper = GraphedStep(eager_step, metrics, enabled=use_graph and os.environ.get('PPS_FIT_GRAPH') != 'norecord',
+                              on_capture_failed=reset_host_state)
     pacer = HostGcPacer()
     for epoch in range(start_epoch, max_epochs):
         host_lr = float(optimizer.param_groups[0]['lr'])        # once per epoch (the scheduler steps per epoch): no per-step read of a device value

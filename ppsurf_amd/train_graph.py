@@ -181,6 +181,22 @@ def _mm_f32(a, b):
     return (a @ b).float()
 
 
+def _bias_grad(g):
+    """Column sums of a 16-bit gradient [rows, n] in fp32 by the HIP reduction for ANY n (the kernel takes <= 1024 columns: wider layers -- the
+    4096 outputs of the STN's last layer -- go through it in column blocks).  NOT torch's sum: inside a replayed HIP graph `g.sum(0, dtype=fp32)`
+    of that [rows, 4096] bf16 tensor returned values that depended on the memory layout of the recording from the second replay on (the
+    config-1 fit: one tensor of the 455 in the checkpoint, stn2.fc3.bias, differed between two builds whose eager fits are bit-identical;
+    profiles/NOTES_r5.md section 3) -- the replayed step was not the eager step."""
+    db = train_ops.col_sum(g)
+    if db is not None:
+        return db
+    n = g.shape[1]
+    parts = [train_ops.col_sum(g[:, i:min(i + 1024, n)].contiguous()) for i in range(0, n, 1024)]
+    if all(p is not None for p in parts):
+        return torch.cat(parts)
+    return g.sum(0, dtype=torch.float32)
+
+
 class _RowsLinear(torch.autograd.Function):
     """y = x W^T + b for x [rows, K] (rows = all points / patch points / neighbours of the batch).
 
@@ -231,8 +247,7 @@ class _RowsLinear(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 dw = train_ops.gemm_tn(gp, xc)[:n].to(wdt)
             if bdt is not None and ctx.needs_input_grad[2]:
-                db = train_ops.col_sum(g)
-                db = (g.sum(0, dtype=torch.float32) if db is None else db).to(bdt)
+                db = _bias_grad(g).to(bdt)
             return dx, dw, db, None, None, None
         acc = torch.float64 if xc.dtype == torch.float64 else torch.float32
         if ctx.needs_input_grad[0]:
@@ -583,7 +598,11 @@ def pack_geo(layer):
     """The layer's small parameters as ONE differentiable vector in the layout of the HIP kernels (pps_fka_common.h):
     [norm_radius, alpha, beta, activation (1 relu / 2 silu), fc1 [16,3], fc2 [16,32], fc3 [16,32], bn1 w, bn1 b, bn2 w, bn2 b]."""
     act = 2.0 if isinstance(layer.activation, torch.nn.SiLU) else 1.0
-    head = torch.full((1,), act, dtype=layer.alpha.dtype, device=layer.alpha.device)        # a fill kernel, not a host-to-device copy: recordable into a HIP graph
+    cached = getattr(layer, '_pps_act_code', None)          # (value, device constant) made once, in the eager steps before any recording: no fill kernel per layer and step
+    if cached is None or cached[0] != act or cached[1].device != layer.alpha.device or cached[1].dtype != layer.alpha.dtype:
+        cached = (act, torch.full((1,), act, dtype=layer.alpha.dtype, device=layer.alpha.device))
+        layer._pps_act_code = cached
+    head = cached[1]
     parts = [layer.norm_radius.detach().reshape(1), layer.alpha.reshape(1), layer.beta.reshape(1), head, layer.fc1.weight.reshape(-1),
              layer.fc2.weight.reshape(-1), layer.fc3.weight.reshape(-1), layer.bn1.weight, layer.bn1.bias, layer.bn2.weight, layer.bn2.bias]
     return torch.cat([p.to(layer.alpha.dtype) for p in parts])
@@ -596,7 +615,7 @@ def fka_geometry_of(layer, pts, sup, ids):
     m, k = ids.shape[1], ids.shape[2]
     flat = _flat_ids(ids, n).view(b * m, k)
     momentum = layer.norm_radius_momentum if layer.training else 0.0
-    g, radius = train_ops.fka_geometry(pack_geo(layer), pts.reshape(b * n, 3), sup.reshape(b * m, 3), flat, b, m, momentum)
+    g, radius = train_ops.fka_geometry(pack_geo(layer), pts.reshape(b * n, 3), sup.reshape(b * m, 3), flat, b, m, momentum, owned=True)
     if layer.training:
         with torch.no_grad():                               # IN PLACE: a replayed HIP graph reads and writes the buffer's own storage
             layer.norm_radius.copy_(radius.detach().reshape(layer.norm_radius.shape))

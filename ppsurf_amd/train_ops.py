@@ -177,32 +177,44 @@ def head_input(table, ids, pts, query, k, wx):
 
 
 class _NeighbourMax(torch.autograd.Function):
+    """x fp32, or 16-bit storage (kept: the maximum of stored values is one of them; the incoming gradient is read in that type, summed in fp32
+    and rounded once -- the values an fp32 op between two casts produces, without the four cast kernels)."""
+
     @staticmethod
-    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, x, idx):
         _need_cuda(x, idx)
+        if x.dtype not in LOW:
+            x = x.float()
         x = x.contiguous()
         idx = idx.contiguous()
         m, k = idx.shape
         c = x.shape[1]
-        out = torch.empty((m, c), device=x.device, dtype=torch.float32)
+        out = torch.empty((m, c), device=x.device, dtype=x.dtype)
         arg = torch.empty((m, c), device=x.device, dtype=torch.int32)
-        _lib.check(_lib.lib().pps_gather_max_arg_f32(x.data_ptr(), idx.data_ptr(), m, k, c, out.data_ptr(), arg.data_ptr(), _stream()),
-                   'pps_gather_max_arg_f32')
+        if x.dtype in LOW:
+            _lib.check(_lib.lib().pps_gather_max_arg_16(x.data_ptr(), idx.data_ptr(), m, k, c, _code(x.dtype), out.data_ptr(), arg.data_ptr(),
+                                                        _stream()), 'pps_gather_max_arg_16')
+        else:
+            _lib.check(_lib.lib().pps_gather_max_arg_f32(x.data_ptr(), idx.data_ptr(), m, k, c, out.data_ptr(), arg.data_ptr(), _stream()),
+                       'pps_gather_max_arg_f32')
         ctx.save_for_backward(idx, arg)
         ctx.n = x.shape[0]
+        ctx.dtype = x.dtype
         return out
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, dout):
         idx, arg = ctx.saved_tensors
         order, offsets = csr(idx.view(-1), ctx.n)
-        dout = dout.contiguous().float()
+        dout = dout.contiguous().to(ctx.dtype)
         c = dout.shape[1]
-        dx = torch.empty((ctx.n, c), device=dout.device, dtype=torch.float32)
-        _lib.check(_lib.lib().pps_gather_max_bwd_f32(dout.data_ptr(), arg.data_ptr(), order.data_ptr(), offsets.data_ptr(), ctx.n,
-                                                     idx.shape[1], c, dx.data_ptr(), _stream()), 'pps_gather_max_bwd_f32')
+        dx = torch.empty((ctx.n, c), device=dout.device, dtype=ctx.dtype)
+        if ctx.dtype in LOW:
+            _lib.check(_lib.lib().pps_gather_max_bwd_16(dout.data_ptr(), arg.data_ptr(), order.data_ptr(), offsets.data_ptr(), ctx.n,
+                                                        idx.shape[1], c, _code(ctx.dtype), dx.data_ptr(), _stream()), 'pps_gather_max_bwd_16')
+        else:
+            _lib.check(_lib.lib().pps_gather_max_bwd_f32(dout.data_ptr(), arg.data_ptr(), order.data_ptr(), offsets.data_ptr(), ctx.n,
+                                                         idx.shape[1], c, dx.data_ptr(), _stream()), 'pps_gather_max_bwd_f32')
         return dx, None
 
 
@@ -256,13 +268,14 @@ GEO_FLOATS = 1140          # pps_fkaconv_geo_floats(): radius, alpha, beta, act,
 class _FkaGeometry(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
-    def forward(ctx, geo, pts, sup, idx, b, m, momentum):
+    def forward(ctx, geo, pts, sup, idx, b, m, momentum, owned=False):
         _need_cuda(geo, pts, sup, idx)
         pts, sup, idx = pts.contiguous(), sup.contiguous(), idx.contiguous()
         k = idx.shape[1]
         if geo.numel() != GEO_FLOATS or idx.shape[0] != b * m or sup.shape[0] != b * m:
             raise ValueError('fka_geometry: inconsistent sizes')
-        geo_w = geo.detach().clone().contiguous()
+        # the kernel moves entry 0 (norm_radius) in place: on a copy, unless the caller hands over a vector nobody else reads (pack_geo's)
+        geo_w = geo.detach() if owned and geo.is_contiguous() and geo.dtype == torch.float32 else geo.detach().clone().contiguous()
         g = torch.empty((b * m, k, 16), device=pts.device, dtype=torch.float32)
         stat = torch.empty((2, b, 32), device=pts.device, dtype=torch.float32)
         ws = torch.empty((_lib.lib().pps_fka_train_ws_bytes(b, m, k),), device=pts.device, dtype=torch.uint8)
@@ -271,13 +284,16 @@ class _FkaGeometry(torch.autograd.Function):
                    'pps_fka_geometry_fwd_f32')
         ctx.save_for_backward(pts, sup, idx, geo_w, stat)
         ctx.dims = (b, m, k)
-        radius = geo_w[0:1].clone()
+        radius = geo_w[0:1]                                     # (a view: the caller copies it into the layer's buffer)
         ctx.mark_non_differentiable(radius)
+        ctx.set_materialize_grads(False)                        # no zero tensor for the gradient of radius that nobody computes
         return g, radius
 
     @staticmethod
     @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, dg, _dradius):
+        if dg is None:
+            return None, None, None, None, None, None, None, None
         pts, sup, idx, geo_w, stat = ctx.saved_tensors
         b, m, k = ctx.dims
         dg = dg.contiguous().float()
@@ -286,14 +302,15 @@ class _FkaGeometry(torch.autograd.Function):
         _lib.check(_lib.lib().pps_fka_geometry_bwd_f32(pts.data_ptr(), sup.data_ptr(), idx.data_ptr(), b, m, k, geo_w.data_ptr(),
                                                        stat.data_ptr(), dg.data_ptr(), dgeo.data_ptr(), ws.data_ptr(), _stream()),
                    'pps_fka_geometry_bwd_f32')
-        return dgeo, None, None, None, None, None, None
+        return dgeo, None, None, None, None, None, None, None
 
 
-def fka_geometry(geo, pts, sup, idx, b, m, momentum):
+def fka_geometry(geo, pts, sup, idx, b, m, momentum, owned=False):
     """geo: packed small parameters of the layer (differentiable); pts [rows,3], sup [b*m,3], idx int64 [b*m,k] rows of pts.
     momentum > 0: train() -- norm_radius is first moved towards the mean neighbourhood radius, the new value is used and
-    returned.  -> (g [b*m,k,16], norm_radius [1])."""
-    return _FkaGeometry.apply(geo, pts, sup, idx, b, m, momentum)
+    returned.  owned: geo is a temporary of the caller's (its entry 0 may be overwritten with the new norm_radius) -- saves the copy.
+    -> (g [b*m,k,16], norm_radius [1])."""
+    return _FkaGeometry.apply(geo, pts, sup, idx, b, m, momentum, owned)
 
 
 class _BnAct(torch.autograd.Function):
@@ -939,8 +956,7 @@ def gather_rows(x, idx):
 def neighbour_max(x, idx):
     """A maximum of 16-bit values is one of them: the result goes back to the type it came in (the op computes in fp32), so that the residual
     sum it feeds stays a same-type addition (a bf16 + fp32 addition runs ATen's slow mixed-type kernel and promotes everything downstream)."""
-    out = _NeighbourMax.apply(x.float(), idx)             # explicit: custom_fwd casts only inside an autocast region
-    return out.to(x.dtype) if x.dtype in LOW else out
+    return _NeighbourMax.apply(x, idx)                    # 16-bit storage in, the same storage out (pps_gather_max_arg_16): no cast kernels
 
 
 def neighbour_contract(x, idx, g):

@@ -51,6 +51,39 @@ def trained(tmp_path_factory):
     return root, str(ckpt)
 
 
+def _short_fit(tmp_path_factory, tag, epochs, env):
+    """the fixture's fit for a few epochs under an environment -> state_dict of last.ckpt"""
+    from ppsurf_amd import runner
+    root = tmp_path_factory.mktemp(tag)
+    shutil.copytree(os.path.join(GOLDEN, 'abc_mini4'), root / 'abc')
+    cwd, old = os.getcwd(), {k: os.environ.get(k) for k in env}
+    os.chdir(root)
+    os.environ.update(env)
+    try:
+        runner.main(['pps.py', 'fit'] + _stack('poco', 'ppsurf', 'ppsurf_mini') + [
+            '--data.init_args.in_file', str(root / 'abc' / 'testset.txt'), '--data.init_args.batch_size', '3',
+            '--data.init_args.manifold_points', '5000', '--trainer.max_epochs', str(epochs), '--trainer.check_val_every_n_epoch', '15',
+            '--trainer.precision', 'bf16-mixed'])
+    finally:
+        os.chdir(cwd)
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    return torch.load(root / 'models' / 'ppsurf_mini' / 'version_0' / 'checkpoints' / 'last.ckpt', map_location='cpu')['state_dict']
+
+
+def test_config1_fit_replayed_as_a_hip_graph_is_the_eager_fit(tmp_path_factory):
+    """`pps.py fit` of config 1's stack for 7 epochs (3 eager steps, the recording, 4 replays; dropout active) against the same fit that never
+    records (PPS_FIT_GRAPH=norecord: same optimizer class, device-side learning rate, loader thread): every tensor of the checkpoint EQUAL.
+    Round 5 found them different in ONE tensor (stn2.fc3.bias, from the second replay on, by amounts that changed with the memory layout of the
+    recording): torch's sum over the rows of the [rows, 4096] bf16 gradient inside the replayed graph; the bias gradient now goes through
+    pps_col_sum for every width (train_graph._bias_grad)."""
+    a = _short_fit(tmp_path_factory, 'replayed', 7, {'PPS_FIT_GRAPH': '1'})
+    b = _short_fit(tmp_path_factory, 'norecord', 7, {'PPS_FIT_GRAPH': 'norecord'})
+    assert a.keys() == b.keys() and len(a) == 455
+    bad = [k for k in a if not torch.equal(a[k], b[k])]
+    assert not bad, bad[:5]
+
+
 def test_config1_ppsurf_mini_predict_real_yaml_stack(trained, capsys):
     """`pps.py predict -c configs/poco.yaml -c configs/ppsurf.yaml -c configs/ppsurf_mini.yaml
     --model.init_args.gen_resolution_global 33` (BASELINE config 1, README 'minimal' flow) with the reference's files unchanged."""

@@ -235,6 +235,26 @@ def test_neighbour_max_returns_the_storage_type_it_was_given():
     assert out.dtype == torch.bfloat16 and torch.equal(out, x[idx].max(dim=1)[0])
 
 
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('n,m,k,c', [(800, 200, 16, 64), (5000, 1250, 16, 128), (64, 16, 4, 6), (40, 160, 1, 8)])
+def test_neighbour_max_16_bit_is_the_fp32_op_between_two_casts(n, m, k, c, dt):
+    """pps_gather_max_arg_16 / _bwd_16: output and input gradient bit-equal to cast -> fp32 op -> cast (what the step did with four cast kernels)."""
+    from ppsurf_amd import train_ops
+    rng = np.random.default_rng(n + c)
+    x16 = torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32)).to(DEV).to(dt)
+    idx = _rand_table(rng, m, k, n)
+    w = torch.from_numpy(rng.standard_normal((m, c)).astype(np.float32)).to(DEV).to(dt)
+    a = x16.clone().requires_grad_(True)
+    out = train_ops.neighbour_max(a, idx)
+    assert out.dtype == dt
+    out.backward(w)
+    b = x16.clone().requires_grad_(True)
+    ref16 = train_ops.neighbour_max(b.float(), idx).to(dt)
+    assert torch.equal(out, ref16)
+    ref16.backward(w)
+    assert a.grad.dtype == dt and torch.equal(a.grad, b.grad)
+
+
 def test_ops_refuse_cpu_tensors():
     from ppsurf_amd import train_ops
     from ppsurf_amd._lib import PpsError

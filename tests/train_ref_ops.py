@@ -21,7 +21,7 @@ def neighbour_contract(x, idx, g):
     return torch.einsum('mkc,mkt->mct', xg, g).reshape(idx.shape[0], -1)
 
 
-def fka_geometry(geo, pts, sup, idx, b, m, momentum):
+def fka_geometry(geo, pts, sup, idx, b, m, momentum, owned=False):
     """source/base/nn.py:601-643 in torch ops, on the packed parameter vector of train_graph.pack_geo.
     pts [rows,3], sup [b*m,3], idx [b*m,k] -> (g [b*m,k,16], norm_radius [1])."""
     import torch.nn.functional as F
