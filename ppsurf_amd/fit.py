@@ -157,8 +157,9 @@ class GraphedStep:
         graph = torch.cuda.CUDAGraph()
         try:
             torch.cuda.synchronize()
-            with torch.cuda.graph(graph, stream=self.stream, capture_error_mode='thread_local'):
-                self.eager(dict(static, **rest), bi)
+            with _no_gc_during_capture():
+                with torch.cuda.graph(graph, stream=self.stream, capture_error_mode='thread_local'):
+                    self.eager(dict(static, **rest), bi)
             logged = dict(self.metrics.values)
         except Exception as exc:                               # anything that cannot be captured: stay eager for the rest of the run
             self.failed = True
@@ -171,6 +172,26 @@ class GraphedStep:
                 self.on_capture_failed()                        # the eager re-run of this step starts from clean host-side state
             return None
         return static, graph, logged, (self.after_capture() if self.after_capture is not None else None)
+
+
+class _no_gc_during_capture:
+    """Old cyclic garbage is collected BEFORE a recording and the collector is off during it: what a collection frees in the middle of a stream
+    capture -- recorded graphs, streams, device tensors used on other streams, left behind by whatever ran in the process before (a validation pass,
+    a reconstruction, another fit) -- is destroyed with the capture open, and the recording then ended with `capturing stream has unjoined work`
+    (seen as the last test of the GPU suite falling back to the eager step after 470 other tests, never in a fresh process)."""
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        if self.was:
+            import gc
+            gc.enable()
+        return False
 
 
 class StagedStep:
@@ -274,7 +295,7 @@ class StagedStep:
         graphs = [torch.cuda.CUDAGraph() for _ in range(train_graph.N_STAGES)]
         try:
             torch.cuda.synchronize()
-            with train_graph.staged() as st:
+            with _no_gc_during_capture(), train_graph.staged() as st:
                 with torch.cuda.graph(graphs[0], stream=self.stream, capture_error_mode='thread_local'):
                     scaled = self._forward(dict(static, **rest), bi)
                     st.run_stage(0, scaled)
