@@ -303,3 +303,34 @@ def test_staged_backward_gives_the_same_gradients_and_completes_them_stage_by_st
             assert (gk is None and final[k] is None) or torch.equal(gk, final[k]), k
     # outside staged() the cuts are no-ops (single backward, e.g. the one-GPU whole-step graph)
     assert tg._stages[0] is None and tg._cut(logits)[0] is logits
+
+
+def test_bias_grad_of_a_host_tensor_is_the_column_sum():
+    """train_graph._bias_grad: the HIP reduction takes device tensors only; anything else is torch's sum in fp32 (the torch twins of this suite)."""
+    from ppsurf_amd import train_graph
+    g = torch.randn(37, 2050).to(torch.bfloat16)
+    out = train_graph._bias_grad(g)
+    assert out.dtype == torch.float32 and torch.equal(out, g.sum(0, dtype=torch.float32))
+
+
+def test_the_collector_is_off_during_a_recording_and_back_afterwards():
+    """fit._no_gc_during_capture: collects, disables, restores the state it found (also when the body raises)."""
+    import gc
+    from ppsurf_amd import fit
+    assert gc.isenabled()
+    with fit._no_gc_during_capture():
+        assert not gc.isenabled()
+    assert gc.isenabled()
+    try:
+        with fit._no_gc_during_capture():
+            raise RuntimeError('x')
+    except RuntimeError:
+        pass
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with fit._no_gc_during_capture():
+            assert not gc.isenabled()
+        assert not gc.isenabled()
+    finally:
+        gc.enable()
