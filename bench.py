@@ -14,10 +14,18 @@ pps_decode_fwd(_events)_f32.  The K chunks are DISTINCT: the first region-growin
 shapes as it takes (47 full chunks per shape at R = 257).  Inputs (clouds, query lists, per-point tables, weights) are resident
 in HBM before the timed region.
 
---scaling weak (default): every rank decodes its own chunks of its own shapes, no collective on the data path.
---scaling strong: ONE shape is reconstructed by all ranks together (PPS_SHARD=queries: growth and refinement rounds split
-into contiguous query ranges + one all-gather of 4 B/query per round, encoder passes dealt round-robin + one all-reduce of the
-latent sums per wave); value = the shape's decoder queries / wall time, plus shapes_per_hour and the collective time share.
+N > 1 (the driver's SCALE run is this one command per N) puts THREE measurements on the one JSON line:
+  * `value` -- shape-level replicas: every rank decodes its own chunks of its own shapes, no collective on the data path (what a test-set
+    reconstruction with PPS_SHARD=shapes does; `scaling: weak`);
+  * `strong` -- SURVEY 8(e)'s query-block sharding: ONE R = 257 shape reconstructed by all ranks together (PPS_SHARD=queries: every growth /
+    refinement round split into contiguous query ranges + one RCCL all-gather of 4 B/query, encoder passes dealt round-robin + one all-reduce
+    of the latent sums per wave): queries/s, shapes/hour, collectives per shape and their share of the wall time;
+  * `fit` -- BASELINE config 3 under data parallelism: B = 50 // N shapes per rank (source/base/mp.py:91), backward in three replayed stages with
+    the gradient bucket of stage k on the wire (RCCL all-reduce) while stage k + 1 runs: ms/step, the all-reduces alone, the same step with every
+    collective behind backward, and the share of the all-reduce time the overlap hides.
+--scaling strong prints the `strong` measurement as a line of its own (value = the shape's decoder queries / wall time).
+--single-rank-collectives (with --gpus 1): a ONE-rank process group runs the N > 1 code path -- every collective call site executes on the real
+backend (RCCL accepts a one-rank communicator) on a 1-GPU box.
 
 Extra keys on the same JSON line (skipped with --quick): `shapes_per_hour` (whole R=257 reconstructions by the product driver; N=1: first
 shape and steady state, N>1: every rank reconstructs its own shapes, the figure is all shapes of all ranks / the slowest rank's time),
@@ -335,6 +343,9 @@ def main():
                     help="band: the first region-growing round (what a reconstruction evaluates); dense: z-slab blocks of the whole (R+2)^3 grid "
                          "(SURVEY 8d(i): 'every voxel of the Marching-Cubes grid')")
     ap.add_argument('--shapes', type=int, default=2, help='timed whole reconstructions per rank of the shapes/hour leg')
+    ap.add_argument('--single-rank-collectives', action='store_true',
+                    help='--gpus 1 only: initialise a ONE-rank process group and run the N > 1 code path (strong + fit legs with every collective issued)')
+    ap.add_argument('--legs', default='replicas,strong,fit', help='N > 1: which measurements go on the line (comma list of replicas, strong, fit)')
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 200 if args.scaling == 'weak' else 3
@@ -355,22 +366,28 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if args.backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
-
     from ppsurf_amd import sharding
+    if args.single_rank_collectives:
+        if world != 1:
+            raise SystemExit('--single-rank-collectives is the one-rank rehearsal of the N > 1 path: use it with --gpus 1')
+        os.environ['PPS_SINGLE_RANK_COLLECTIVES'] = '1'
+    multi = world > 1 or args.single_rank_collectives
+    if multi:
+        import torch.distributed as dist
+        sharding.init_process_group(dev, backend=args.backend)     # nccl: communicator bound to this rank's GPU (device_id)
     import bench_workloads as workloads
     from ppsurf_amd.decoder import DecoderPlan
     from ppsurf_amd.synthetic import network_state_dict
 
     red_dev = dev if args.backend == 'nccl' else 'cpu'
     if args.scaling == 'strong':
-        return strong(args, rank, world, dev, dist, red_dev)
+        st = strong_leg(args, rank, world, dev, dist, red_dev, args.steps, args.warmup)
+        if rank == 0:
+            print(json.dumps(strong_line(args, world, st)), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    legs = set(args.legs.split(',')) if multi else {'replicas'}
 
     sd = network_state_dict('ppsurf')
     plan = DecoderPlan(sd, dev, dtype=args.dtype)
@@ -386,7 +403,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': st['ms_per_step'],
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'repeats': r['repeats'], 'timed_s': r['dt'], 'world_size_seen': world,
-            'backend': ('RCCL (torch.distributed nccl)' if args.backend == 'nccl' else args.backend) if world > 1 else None,
+            'backend': ('RCCL (torch.distributed nccl)' if args.backend == 'nccl' else args.backend) if multi else None,
             'per_rank_queries_per_s': {'min': min(per_rank), 'max': max(per_rank), 'all': per_rank},
             'dtype_note': DTYPE_NOTE[args.dtype],
             'config': {'workload': 'ppsurf_50nn predict, R=257: {} distinct {} chunks of {} queries '
@@ -394,7 +411,9 @@ def main():
                                        args.steps, 'first-growth-round band' if args.queries == 'band' else 'dense z-slab (every voxel of the (R+2)^3 grid)',
                                        Q_CHUNK, len(shapes)),
                        'queries': args.queries,
-                       'parallelism': 'query-block sharding x{}'.format(world), 'weights': 'formula-filled (no checkpoint offline)',
+                       'parallelism': 'shape-level replicas x{} (every rank its own shapes, no collective on the data path; the query-block sharding '
+                                      'of ONE shape over all ranks is the `strong` key of this line)'.format(world) if multi else 'one GPU',
+                       'weights': 'formula-filled (no checkpoint offline)',
                        'entry': 'ChunkPipeline.run -> pps_knn_blocked_f32, pps_patch_normalize_f32, pps_decode_fwd_events_f32'},
             'roofline': roofline_block(args.dtype, r['stage_ms']),
             'lanes': st['lanes'], 'single_lane': st['single_lane'],
@@ -407,7 +426,7 @@ def main():
         }
     if not args.quick:
         other = 'f16x3' if args.dtype == 'f32' else 'f32'
-        if world == 1:
+        if not multi:
             # ---- the other decoder dtype on the same chunks: an extra key, never `value` ----------------------------------------------
             plan2 = DecoderPlan(sd, dev, dtype=other)
             from ppsurf_amd.decoder import ChunkPipeline
@@ -423,7 +442,7 @@ def main():
             out[other] = dict(dtype_stats(other, r2, world), steps=n2, note=DTYPE_NOTE[other], roofline=roofline_block(other, r2['stage_ms']))
             out[other]['max_abs_occ_diff_vs_{}_last_chunk'.format(args.dtype)] = float((r2['occ'] - ref_occ).abs().max())
             del plan2, pipes2, work2, r2
-        if world == 1 and args.queries == 'band':
+        if not multi and args.queries == 'band':
             # ---- the north star's other reading of the workload: dense z-slab blocks of the whole grid, same step, same dtype ---------------
             _, workd = build_work(plan, 5 + 40, rank, dev, queries='dense')
             rd = chunk_loop(workd, 40, 5, rank, world, dist, red_dev, min_timed_s=0.5)
@@ -470,14 +489,27 @@ def main():
                                              'passes), region growing, Marching Cubes + clean-up, 10 refinement rounds; every query decoded by the real '
                                              'kernels, growth steered by the analytic shape (formula-filled weights describe no surface); N>1: shape-level '
                                              'sharding (PPS_SHARD=shapes), no collective on the data path'}
-        if world == 1:
+        if not multi:
             model.network.decoder_dtype = other
             runs2 = [workloads.reconstruct_steered(model, N_POINTS, seed=42 + i, device=dev) for i in range(3)]      # the first warms the other dtype's plan
             out[other]['shapes_per_hour'] = 3600.0 * len(runs2[1:]) / sum(x['total_s'] for x in runs2[1:])
             out[other]['reconstruction_steady_s'] = runs2[-1]['total_s']
         del model
         torch.cuda.empty_cache()
-    if world == 1 and not args.quick:
+    if multi and not args.quick:
+        # ---- the two measurements that need every rank at once -------------------------------------------------------------------
+        if 'strong' in legs:
+            st = strong_leg(args, rank, world, dev, dist, red_dev, steps=2, warm=1)
+            if rank == 0:
+                out['strong'] = strong_block(world, st)
+            torch.cuda.empty_cache()
+        if 'fit' in legs:
+            fb = ddp_fit_leg(rank, world, dev, dist, red_dev)
+            if rank == 0:
+                out['fit'] = fb
+                out['fit_ms_per_step'] = fb['ms_per_step']
+            torch.cuda.empty_cache()
+    if not multi and not args.quick:
         fit = workloads.FitStep(batch=10, precision='bf16-mixed', device=dev, graph=True)      # as `pps.py fit` runs it: replayed HIP graph, loader thread
         for _ in range(6):
             fit()
@@ -496,6 +528,16 @@ def main():
                       'steps_timed': n_fit, 'loss': float(loss),
                       'shapes_per_s': 10.0 / (out['fit_ms_per_step'] * 1e-3)}
         out['fit'].update(fit_roofline(out['fit_ms_per_step']))
+        # where a slow box loses its time: a second, instrumented pass of 60 steps -- HIP events on the step's stream and on the
+        # loader's, host time blocked on the loader thread.  Not part of fit_ms_per_step (the events cost a few microseconds per step).
+        fit.start_trace()
+        with HostGcPacer() as pacer:
+            for _ in range(60):
+                fit()
+                pacer.tick()
+        tr = fit.read_trace()
+        out['fit'].update({'queue_busy_ms': tr['queue_busy_ms'], 'loader_wait_ms': tr['loader_wait_ms'], 'batch_wait_ms': tr['batch_wait_ms'],
+                           'loader_host_ms': tr['loader_host_ms'], 'traced_call_ms': tr['call_ms'], 'trace_note': tr['note'], 'host_cores': os.cpu_count()})
         fit.close()
         del fit
         if not args.no_cpu_baseline:
@@ -532,48 +574,136 @@ def fit_roofline(ms_per_step):
                          'bound': d.get('bound', 'hbm')}}
 
 
-def strong(args, rank, world, dev, dist, red_dev):
-    """One shape, all ranks: PPS_SHARD=queries.  `steps` = reconstructions timed, `warmup` = untimed ones."""
+def strong_leg(args, rank, world, dev, dist, red_dev, steps, warm):
+    """One shape, all ranks: PPS_SHARD=queries (SURVEY.md 8e).  `steps` = reconstructions timed, `warm` = untimed ones.  Every rank calls this;
+    returns the measured figures (the same on every rank up to rank 0's own collective time)."""
     from ppsurf_amd import sharding
     import bench_workloads as workloads
-    sharding.set_query_sharding(world > 1)
+    on = sharding.multi()
+    sharding.set_query_sharding(on)
     model = workloads.make_model(RES, P_LOCAL, Q_CHUNK, dev)
     model.network.decoder_dtype = args.dtype
-    model.shard_queries = world > 1
-    steps, warm = args.steps, args.warmup
-    for i in range(warm):
-        workloads.reconstruct_steered(model, N_POINTS, seed=42, device=dev)
-    sharding.profile_collectives(True)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    runs = [workloads.reconstruct_steered(model, N_POINTS, seed=43 + i, device=dev) for i in range(steps)]
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = sharding.max_over_ranks(time.perf_counter() - t0, red_dev)
-    coll = sharding.collective_seconds()
+    model.shard_queries = on
+    try:
+        for i in range(warm):
+            workloads.reconstruct_steered(model, N_POINTS, seed=42, device=dev)
+        sharding.profile_collectives(True)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        runs = [workloads.reconstruct_steered(model, N_POINTS, seed=43 + i, device=dev) for i in range(steps)]
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = sharding.max_over_ranks(time.perf_counter() - t0, red_dev)
+        coll = sharding.collective_seconds()
+        calls, items = sharding.STATS['calls'], sharding.STATS['items']
+    finally:
+        sharding.profile_collectives(False)
+        sharding.set_query_sharding(False)
     mine = sum(r['decoder_queries'] for r in runs)
     total_q = mine
     if dist is not None:
         t = torch.tensor([float(mine)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t)
         total_q = int(t.item())
-    if rank == 0:
-        print(json.dumps({
-            'metric': 'occupancy query-points/sec @ res=257, 50NN', 'value': total_q / dt, 'unit': 'queries/s', 'n_gpus': world,
-            'steps': steps, 'warmup': warm, 'ms_per_step': dt / steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+    per_rank_q = rank_values(mine / steps, rank, world, dist, red_dev)
+    del model
+    return {'dt': dt, 'steps': steps, 'warm': warm, 'total_q': total_q, 'coll': coll, 'calls': calls, 'items': items, 'per_rank_q': per_rank_q,
+            'latent_s': runs[-1]['latent_s'], 'surface_s': runs[-1]['surface_s'], 'vertices': runs[-1]['vertices']}
+
+
+STRONG_PARALLELISM = ('PPS_SHARD=queries x{}: per growth / refinement round contiguous query ranges + one all-gather of 4 B/query '
+                      '(sharding.sharded_map); encoder passes round-robin + all-reduce of latent sums and counts per wave (sharding.allreduce_latents)')
+
+
+def strong_block(world, st):
+    """The `strong` key of the N > 1 line: SURVEY 8(e)'s query-block sharding of ONE shape over all ranks."""
+    dt, steps = st['dt'], st['steps']
+    return {'value': st['total_q'] / dt, 'unit': 'queries/s', 'scaling': 'strong', 'shapes_per_hour': 3600.0 * steps / dt,
+            's_per_shape': dt / steps, 'shapes_timed': steps, 'warmup_shapes': st['warm'],
+            'decoder_queries_per_shape': st['total_q'] / steps,
+            'per_rank_decoder_queries_per_shape': st['per_rank_q'],
+            'collectives_per_shape': st['calls'] / steps, 'gathered_queries_per_shape': st['items'] / steps,
+            'collective_s_per_shape_rank0': st['coll'] / steps, 'collective_share_rank0': st['coll'] / dt,
+            'latent_loop_s': st['latent_s'], 'surface_s': st['surface_s'], 'vertices': st['vertices'],
+            'parallelism': STRONG_PARALLELISM.format(world),
+            'note': 'ONE 100k-point synthetic shape at R=257 reconstructed by all ranks together (latent loop, region growing, Marching Cubes, 10 '
+                    'refinement rounds); collective_* = HIP-event time around the data-path collectives on rank 0 (includes waiting for the slowest '
+                    'rank of a round); collectives_per_shape counts the per-round all-gathers (the latent all-reduces are in the time, not the count)'}
+
+
+def strong_line(args, world, st):
+    """`--scaling strong`: the same measurement as a bench line of its own."""
+    b = strong_block(world, st)
+    return {'metric': 'occupancy query-points/sec @ res=257, 50NN', 'value': b['value'], 'unit': 'queries/s', 'n_gpus': world,
+            'steps': st['steps'], 'warmup': st['warm'], 'ms_per_step': st['dt'] / st['steps'] * 1e3, 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': args.dtype, 'dtype_note': DTYPE_NOTE[args.dtype], 'data': 'synthetic',
             'config': {'workload': 'ppsurf_50nn predict, ONE 100k-point synthetic shape at R=257 reconstructed by all ranks together '
                                    '(step = one whole reconstruction: latent loop, region growing, MC, 10 refinement rounds)',
-                       'parallelism': 'PPS_SHARD=queries x{}: per growth/refinement round contiguous query ranges + all-gather of 4 B/query; '
-                                      'encoder passes round-robin + all-reduce of latent sums'.format(world)},
-            'shapes_per_hour': 3600.0 * steps / dt, 'decoder_queries_per_shape': total_q / steps,
-            'collective_s_per_shape_rank0': coll / steps, 'collective_share_rank0': coll / dt,
-            'collectives_per_shape': sharding.STATS['calls'] / steps}), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+                       'parallelism': STRONG_PARALLELISM.format(world)},
+            'shapes_per_hour': b['shapes_per_hour'], 'decoder_queries_per_shape': b['decoder_queries_per_shape'],
+            'collective_s_per_shape_rank0': b['collective_s_per_shape_rank0'], 'collective_share_rank0': b['collective_share_rank0'],
+            'collectives_per_shape': b['collectives_per_shape']}
+
+
+DDP_GLOBAL_BATCH = int(os.environ.get('PPS_BENCH_DDP_BATCH', '50'))          # source/base/mp.py:91: `--data.init_args.batch_size 50 // num_gpus` (the env override: tests)
+
+
+def ddp_fit_leg(rank, world, dev, dist, red_dev, n_steps=40):
+    """BASELINE config 3 data-parallel: B = 50 // N shapes per rank (mp.py:91; configs/device_server.yaml:13 writes 12 for its 4 GPUs), the step of
+    ppsurf_amd.fit for several ranks (fit.StagedStep: backward in three replayed HIP graphs, bucket k's RCCL all-reduce issued between replays k
+    and k + 1; buffer broadcast, mask collective and AdamW behind).  Timed three ways, each between barrier + synchronize with the max over
+    ranks: (a) as the product runs it, (b) every bucket all-reduce held back until backward is over (no overlap), (c) the three bucket
+    all-reduces alone.  overlap_share = (b - a) / c: the part of the all-reduce time the staged issue hides behind backward."""
+    import bench_workloads as workloads
+    from ppsurf_amd import sharding
+    from ppsurf_amd.fit import HostGcPacer
+    b = max(1, DDP_GLOBAL_BATCH // world)
+    fit = workloads.FitStepDDP(batch=b, precision='bf16-mixed', device=dev, rank=rank)
+
+    def timed(n):
+        with HostGcPacer() as pacer:
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                loss = fit()
+                pacer.tick()
+            torch.cuda.synchronize()
+            mine = time.perf_counter() - t0
+            if dist is not None:
+                dist.barrier()
+        return sharding.max_over_ranks(mine, red_dev) / n * 1e3, float(loss)
+
+    for _ in range(fit.WARMUP_STEPS):                     # eager steps, the capture of the three stage graphs, first replays
+        fit()
+    t_overlap, loss = timed(n_steps)
+    fit.buckets.hold = True                               # reduce(k) between the replays does nothing: finish() sends every bucket behind backward
+    for _ in range(3):
+        fit()
+    t_serial, _ = timed(n_steps)
+    fit.buckets.hold = False
+    t_overlap2, _ = timed(n_steps)                        # (a) again after (b): the two orders bracket any drift of the box
+    t_ar = fit.allreduce_alone_ms(reps=10, dist=dist)
+    t_ar = sharding.max_over_ranks(t_ar, red_dev)
+    ta = min(t_overlap, t_overlap2)
+    out = {'config': 'ppsurf_50nn fit step, data-parallel: B = {} // {} = {} shapes per rank x 10000 points, 2000 queries/shape, P=50, bf16-mixed, AdamW; '
+                     'id tables + patches built on the device by the loader thread on a second stream; forward + backward replayed as {} HIP graphs per '
+                     'step with bucket k all-reduced between replays k and k+1 (fit.StagedStep), buffer broadcast / mask collective / optimizer eager '
+                     'behind (the defaults of pps.py fit under torch.distributed.run)'.format(DDP_GLOBAL_BATCH, world, b, fit.n_stage_graphs()),
+           'ranks': world, 'batch_per_rank': b, 'global_batch': b * world,
+           'ms_per_step': ta, 'ms_per_step_runs': [t_overlap, t_overlap2], 'shapes_per_s': b * world / (ta * 1e-3),
+           'ms_per_step_collectives_behind_backward': t_serial, 'allreduce_ms': t_ar,
+           'overlap_share': max(0.0, min(1.0, (t_serial - ta) / t_ar)) if t_ar > 0 else None,
+           'gradient_bytes_per_step': fit.bucket_bytes(), 'bucket_dtype': str(fit.buckets.comm_dtype or torch.float32),
+           'graphs_captured': fit.n_stage_graphs(), 'capture_failed': bool(fit.core.failed), 'steps_timed': n_steps, 'loss': loss,
+           'allreduce_note': 'allreduce_ms = the step\'s three bucket all-reduces issued back to back with nothing else on the GPU (max over ranks, mean '
+                             'of 10); overlap_share = (ms_per_step_collectives_behind_backward - ms_per_step) / allreduce_ms, clipped to [0, 1]'}
+    fit.close()
+    return out
 
 
 if __name__ == '__main__':

@@ -7,6 +7,7 @@
                          after one round; with the steering the query counts are those of a real shape of that geometry
   reconstruct_steered    one whole reconstruction (latent loop, region growing, Marching Cubes, clean-up, 10 refinement rounds)
   FitStep                one optimisation step at BASELINE config 3 (B shapes x 10k points, 2000 queries, P = 50)
+  FitStepDDP             the same step as ppsurf_amd.fit runs it with several ranks (staged backward, bucket all-reduces between the stage replays)
   HipEvents              hipEvent_t handles for timing kernels INSIDE a C-ABI call (pps_decode_fwd_events_f32)
 """
 import contextlib
@@ -196,6 +197,7 @@ class FitStep:
         self.batches = [self._raw_batch(batch, n, q, s) for s in range(n_batches)]
         self.i = 0
         self.loss = None
+        self.trace = None                    # start_trace(): per-step host wait for the loader + HIP events around the step / the loader's kernels
 
         class _Log:
             values = {}
@@ -248,19 +250,82 @@ class FitStep:
         return batch
 
     def _build(self, i):
-        return self.prefetch.launch(lambda: self._prepare(i), after_main=False)
+        tr = self.trace
+        if tr is None:
+            return self.prefetch.launch(lambda: self._prepare(i), after_main=False)
+
+        def make():                                   # the loader's kernels between two events on ITS stream
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            t0 = time.perf_counter()
+            batch = self._prepare(i)
+            tr['loader_host_ms'].append((time.perf_counter() - t0) * 1e3)
+            b.record()
+            tr['loader_ev'].append((a, b))
+            return batch
+        return self.prefetch.launch(make, after_main=False)
+
+    def start_trace(self):
+        """From now on every call records: how long the host waited for the loader thread (`loader_wait_ms`), the step's own queue between the
+        hand-over of the batch and the end of the step (`step_queue_ms`: static-input copy + graph replay, by HIP events on the step's stream), how
+        long the step's stream waited for the loader's last kernel (`batch_wait_ms`: event before the hand-over to event after it), and the
+        loader's kernels on its side stream (`loader_queue_ms`) with the host time of issuing them (`loader_host_ms`)."""
+        self.trace = {'loader_wait_ms': [], 'step_ev': [], 'loader_ev': [], 'loader_host_ms': [], 'call_ms': []}
+
+    def read_trace(self):
+        tr, self.trace = self.trace, None
+        torch.cuda.synchronize()
+        if self.fut is not None:                      # the batch built ahead by the traced _build: its events are complete now
+            self.fut.result()
+            torch.cuda.synchronize()
+        med = lambda v: float(np.median(v)) if len(v) else None
+        mean = lambda v: float(np.mean(v)) if len(v) else None
+        wait = [a.elapsed_time(b) for a, b, _ in tr['step_ev']]
+        busy = [b.elapsed_time(c) for _, b, c in tr['step_ev']]
+        loader = [a.elapsed_time(b) for a, b in tr['loader_ev']]
+        return {'steps': len(busy), 'call_ms': {'mean': mean(tr['call_ms']), 'median': med(tr['call_ms']), 'max': max(tr['call_ms'])},
+                'queue_busy_ms': {'step': {'mean': mean(busy), 'median': med(busy), 'max': max(busy)},
+                                  'loader': {'mean': mean(loader), 'median': med(loader), 'max': max(loader) if loader else None}},
+                'batch_wait_ms': {'mean': mean(wait), 'median': med(wait), 'max': max(wait)},
+                'loader_wait_ms': {'mean': mean(tr['loader_wait_ms']), 'median': med(tr['loader_wait_ms']), 'max': max(tr['loader_wait_ms'])},
+                'loader_host_ms': {'mean': mean(tr['loader_host_ms']), 'median': med(tr['loader_host_ms'])},
+                'note': 'per step: call_ms = host time of one FitStep call; queue_busy_ms.step = HIP events on the step\'s stream from the hand-over of '
+                        'the batch to the end of the replayed graph (the step\'s own kernels, back to back); batch_wait_ms = the step\'s stream waiting for '
+                        'the loader\'s last kernel; loader_wait_ms = the HOST blocked on the loader thread; queue_busy_ms.loader = the loader\'s kernels '
+                        'on the side stream (they share the GPU with the step), loader_host_ms = host time the loader thread needs to issue them'}
 
     def __call__(self):
+        tr = self.trace
+        t_call = time.perf_counter()
         if self.prefetch is None:
             batch = self._prepare(self.i)
         else:                                         # like data.DeviceBatchLoader: a loader thread builds the next batch on the side stream
             if self.fut is None:
                 self.fut = self.pool.submit(self._build, self.i)
+            t0 = time.perf_counter()
             batch, ev = self.fut.result()
+            if tr is not None:
+                tr['loader_wait_ms'].append((time.perf_counter() - t0) * 1e3)
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             self.fut = self.pool.submit(self._build, self.i + 1)
             batch = self.prefetch.hand_over(batch, ev)
         self.i += 1
+        if tr is not None and self.prefetch is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+        self._step(batch)
+        if tr is not None and self.prefetch is not None:
+            e2 = torch.cuda.Event(enable_timing=True)
+            e2.record()
+            tr['step_ev'].append((e0, e1, e2))
+            tr['call_ms'].append((time.perf_counter() - t_call) * 1e3)
+        return self._loss()
+
+    def _step(self, batch):
         self.stepper.run(batch, self.i)
+
+    def _loss(self):
         return self.stepper.metrics.values['loss']
 
     def close(self):
@@ -268,3 +333,73 @@ class FitStep:
             if self.fut is not None:
                 self.fut.result()
             self.pool.shutdown(wait=True)
+
+
+class FitStepDDP(FitStep):
+    """BASELINE config 3 as `pps.py fit` runs it under torch.distributed.run (one rank per GPU): the Lightning module's training_step, the backward
+    pass in train_graph.N_STAGES stages -- eager for the first steps, then one replayed HIP graph per stage -- with gradient bucket k all-reduced
+    (RCCL) between stage k and stage k + 1 (fit.StagedStep + sharding.GradBuckets(defer=True, groups=parameter_stages)), the buffer broadcast of
+    DDP before the step, the per-parameter mask collective and the fused AdamW behind it.  Every rank builds its own batches (rank-offset seeds)."""
+    WARMUP_STEPS = 8                                  # 3 eager + capture + first replays
+
+    def __init__(self, batch=10, n=10000, q=2000, p=50, precision='bf16-mixed', device='cuda:0', n_batches=2, rank=0):
+        from ppsurf_amd import fit, sharding, train_graph, optim, data
+        self.p, self.dev = p, torch.device(device)
+        self.model = make_model(257, p, 50000, device).train()
+        params = [t for t in self.model.parameters() if t.requires_grad]
+        self.opt = optim.AdamW(params, lr=1e-3, eps=1e-5, weight_decay=1e-2, fused=True, capturable=False)   # as fit() builds it for several ranks
+        if sharding.multi():
+            import torch.distributed as dist
+            for t in list(self.model.parameters()) + list(self.model.buffers()):
+                dist.broadcast(t.data, src=0)
+        self.buckets = sharding.GradBuckets(params, defer=True, groups=train_graph.parameter_stages(self.model))
+        ctx, use_scaler = fit.autocast_context(precision, 'cuda')
+        self.scaler = torch.amp.GradScaler('cuda', enabled=use_scaler)
+        self.metrics = fit._MetricLog()
+        self.model.__dict__['_fit_log'] = self.metrics
+        self.core = fit.StagedStep(self.model, self.buckets, self.scaler, ctx, self.metrics, enabled=True)
+        self.batches = [self._raw_batch(batch, n, q, 1000 * (rank + 1) + s) for s in range(n_batches)]
+        self.i, self.trace, self.fut = 0, None, None
+        self.prefetch = data.DevicePrefetch(self.dev)
+        import concurrent.futures
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+
+    def _step(self, batch):
+        from ppsurf_amd import sharding, train_graph
+        sharding.broadcast_buffers(self.model)        # DDP's broadcast_buffers=True: rank 0's BatchNorm statistics / norm_radius before the step
+        self.core.run(batch, self.i)
+        self.buckets.finish()                         # waits for the bucket all-reduces, averages, mask collective
+        self.scaler.step(self.opt)
+        self.scaler.update()
+        train_graph.release_step_caches()
+
+    def _loss(self):
+        return self.metrics.values['loss/train/00_all']
+
+    def n_stage_graphs(self):
+        return sum(len(e[1]) for e in self.core.graphs.values())
+
+    def bucket_bytes(self):
+        el = 4 if self.buckets.comm_dtype is None else torch.empty((), dtype=self.buckets.comm_dtype).element_size()
+        return [int(f.numel()) * el for f in self.buckets.flat]
+
+    def allreduce_alone_ms(self, reps=10, dist=None):
+        """The three bucket all-reduces of a step issued back to back with nothing else on the GPU (what sharding.GradBuckets._all_reduce issues)."""
+        if dist is None:
+            return 0.0
+        if self.fut is not None:                      # the loader's kernels of the batch built ahead are not part of this
+            self.fut.result()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            hs = [self.buckets._all_reduce(bi) for bi in range(len(self.buckets.flat))]
+            for h in hs:
+                h.wait()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    def close(self):
+        super().close()
+        self.model.__dict__.pop('_fit_log', None)

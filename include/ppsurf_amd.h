@@ -333,6 +333,17 @@ int pps_gather_max_f32(const float* x, const int64_t* idx, int64_t m, int k, int
  *   offsets int64 [n+1]      entries of target row i are order[offsets[i] .. offsets[i+1]),
  * and every target row adds its contributions in that fixed order (bit-reproducible gradients). */
 
+/* The CSR itself, built on the device by a stable counting sort (pps_csr.hip: count, scan, fill, rank; deterministic, no comparison sort):
+ *   ids      int64 [entries]  the id table, row-major [B, M, K] flattened (per_item = M*K > 0: entry e belongs to batch item e / per_item and points
+ *                             at row ids[e] + item * rows_per_item of the [B * rows_per_item, C] activations), or already flat rows (per_item = 0);
+ *   clamp_negative            -1 entries ("no neighbour" of the nearest up-sampling tables, nn.py:686-687) count as row 0;
+ *   flat     int64 [entries]  out, the flat row numbers (NULL to skip);   order / offsets as above (offsets [rows + 1]);
+ *   ws                        pps_csr_ws_bytes(entries, rows) bytes.  Ids must lie in [0, rows) after flattening (entries outside are left out).
+ * replaces: the index_add backward of source/base/nn.py:655-674 `batch_gather` under autograd (atomics in arbitrary order there). */
+size_t pps_csr_ws_bytes(int64_t entries, int64_t rows);
+int pps_csr_build(const int64_t* ids, int64_t entries, int64_t per_item, int64_t rows_per_item, int64_t rows, int clamp_negative,
+                  int64_t* flat, int64_t* order, int64_t* offsets, void* ws, size_t ws_bytes, void* stream);
+
 /* out[r,:] = x[idx[r],:].   replaces: source/base/nn.py:655-674 `batch_gather` for the latent gather of
  * source/poco_model.py:400 and the nearest-neighbour up-sampling of nn.py:684-697. */
 int pps_gather_rows_f32(const float* x, const int64_t* idx, int64_t r, int c, float* out, void* stream);

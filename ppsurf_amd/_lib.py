@@ -68,6 +68,8 @@ SIGNATURES = {
     'pps_rows_linear_f32': (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I64, _I, _P, _P]),
     'pps_rows_gemm_f32': (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _I, _I64, _I, _P, _P]),
     'pps_gather_max_f32': (_I, [_P, _P, _I64, _I, _I, _P, _P]),
+    'pps_csr_ws_bytes': (_SZ, [_I64, _I64]),
+    'pps_csr_build': (_I, [_P, _I64, _I64, _I64, _I64, _I, _P, _P, _P, _P, _SZ, _P]),
     'pps_gather_rows_f32': (_I, [_P, _P, _I64, _I, _P, _P]),
     'pps_segment_sum_rows_f32': (_I, [_P, _P, _P, _I64, _I, _P, _P]),
     'pps_segment_sum_rows_16': (_I, [_P, _P, _P, _I64, _I, _I, _P, _P]),

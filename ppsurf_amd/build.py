@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libppsurf_amd.so')
-SOURCES = ['pps_decode.hip', 'pps_knn.hip', 'pps_grow.hip', 'pps_mc.hip', 'pps_mesh.hip', 'pps_fkaconv.hip', 'pps_sample.hip', 'pps_train.hip', 'pps_fka_train.hip', 'pps_bn_train.hip',
+SOURCES = ['pps_decode.hip', 'pps_knn.hip', 'pps_grow.hip', 'pps_mc.hip', 'pps_mesh.hip', 'pps_fkaconv.hip', 'pps_sample.hip', 'pps_train.hip', 'pps_csr.hip', 'pps_fka_train.hip', 'pps_bn_train.hip',
            'pps_attn_train.hip', 'pps_rows_train.hip', 'pps_gemm_train.hip', 'pps_optim.hip', 'pps_pack.cpp']
 HEADERS = ['pps_common.h', 'pps_fka_common.h', 'pps_rows_train_impl.h', 'pps_head_chain_impl.h', os.path.join('..', '..', 'include', 'ppsurf_amd.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC']

@@ -216,6 +216,10 @@ class StagedStep:
         self.enabled, self.max_graphs, self.on_capture_failed = enabled, max_graphs, on_capture_failed
         self.seen, self.graphs, self.failed, self._done, self.replayed = {}, {}, False, None, False
         self.staged = len(buckets.buckets) == train_graph.N_STAGES      # else: one backward pass, every collective in finish()
+        if not self.staged and sharding.world()[0] == 0:
+            print('fit: {} gradient buckets for {} backward stages -- the step runs as ONE backward pass, eagerly, with every all-reduce behind it '
+                  '(no HIP-graph replay, no all-reduce / backward overlap); build the buckets from train_graph.parameter_stages(model)'.format(
+                      len(buckets.buckets), train_graph.N_STAGES))
         # ONE stream for the eager steps, the captures and the replays: autograd binds a parameter's gradient accumulation to the stream of the
         # parameter's first use, and an accumulator that survives from an eager step on another stream would pull that stream into the capture
         # as an unjoined branch (hipStreamEndCapture faults on it; measured, profiles/NOTES_r5.md)
@@ -407,6 +411,7 @@ def save_checkpoint(path, model, optimizer, scheduler, epoch, global_step):
 
 def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
     rank, world = sharding.world()
+    multi = sharding.multi()                                   # several ranks -- or one rank made to run the multi-rank step (PPS_SINGLE_RANK_COLLECTIVES)
     tcfg = cfg.get('trainer', {})
     max_epochs = int(tcfg.get('max_epochs', 150))
     max_steps = int(tcfg.get('max_steps', -1))
@@ -417,8 +422,8 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
         raise ValueError('fit needs an `optimizer:` section (class_path / init_args), as in configs/poco.yaml:60-69')
     on_gpu = torch.device(device).type == 'cuda'
     graph_on = on_gpu and os.environ.get('PPS_FIT_GRAPH', '1') != '0'
-    use_graph = graph_on and world == 1                        # the whole step (optimizer included) as one graph
-    split_graph = graph_on and world > 1                       # forward + backward as a graph; collectives and optimizer eager behind it
+    use_graph = graph_on and not multi                         # the whole step (optimizer included) as one graph
+    split_graph = graph_on and multi                           # forward + backward as a graph; collectives and optimizer eager behind it
     ospec = cfg['optimizer']
     if on_gpu and ospec.get('class_path', '').rsplit('.', 1)[-1] in ('AdamW', 'Adam') and 'fused' not in ospec.get('init_args', {}):
         # the fused implementation (one launch per dtype group instead of ~10 small foreach launches over 298 parameter tensors: 57.6 ->
@@ -445,12 +450,12 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
     if use_graph:
         for group in optimizer.param_groups:                   # a device-side learning rate: the scheduler's changes reach the replayed graph
             group['lr'] = torch.tensor(float(group['lr']), dtype=torch.float32, device=device)
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src=0)
     # several ranks: bucket k = the parameters backward stage k completes (train_graph.parameter_stages), all-reduced while stage k + 1 runs
-    buckets = sharding.GradBuckets(params, defer=world > 1, groups=train_graph.parameter_stages(model) if world > 1 else None)
+    buckets = sharding.GradBuckets(params, defer=multi, groups=train_graph.parameter_stages(model) if multi else None)
     out_dir = os.path.join('models', str(getattr(model, 'name', 'model')), 'version_0')
     ckpt_file = os.path.join(out_dir, 'checkpoints', 'last.ckpt')
     metrics = _MetricLog()
@@ -500,7 +505,7 @@ def fit(model, data, cfg, ckpt_path=None, device='cuda', log=print):
         scaler.update()
         train_graph.release_step_caches()
 
-    if world > 1:
+    if multi:
         # several ranks: forward + backward in stages (eager or as one replayed HIP graph per stage) with the bucket all-reduces issued between the
         # stages (StagedStep); buffer broadcast, the mask collective and the optimizer run eagerly around it
         core = StagedStep(model, buckets, scaler, ctx, metrics, enabled=split_graph, on_capture_failed=reset_host_state)

@@ -328,9 +328,10 @@ class PocoModel(_Base):
         latent = torch.zeros((n, self.network_latent_size), dtype=torch.float32, device=dev)
         counts = torch.zeros((n,), dtype=torch.float32, device=dev)
         m = self.gen_subsample_manifold
-        rank, world = sharding.world() if getattr(self, 'shard_queries', False) else (0, 1)
+        shard = bool(getattr(self, 'shard_queries', False)) and sharding.multi()      # several ranks (or one under PPS_SINGLE_RANK_COLLECTIVES)
+        rank, world = sharding.world() if shard else (0, 1)
         gen = None
-        if world > 1:
+        if shard:
             gen = torch.Generator(device='cpu')
             gen.manual_seed(int(n) * 1000003 + 12345)
         encode = encode_subsets if encode_subsets is not None else self._encode_subsets
@@ -338,7 +339,7 @@ class PocoModel(_Base):
         # 'reference': subsets follow torch's CPU generator like the reference (same seed -> same subsets; the parity tests);
         # 'device' (default on a GPU): the permutation is drawn where the counts live
         device_rng = getattr(self, 'latent_rng', 'device') == 'device' and dev.type == 'cuda'
-        if world > 1:
+        if shard:
             batch = -(-batch // world) * world                               # whole waves: every rank encodes batch / world subsets
         iteration = 0
         n_rounds = self.gen_subsample_manifold_iter
@@ -381,8 +382,8 @@ class PocoModel(_Base):
                 subsets = draw(counts, 1, state)                             # pass by pass: counts are up to date, nothing is simulated
             if not subsets:
                 break
-            mine = subsets[rank::world] if world > 1 else subsets
-            part, cnt = (torch.zeros_like(latent), torch.zeros_like(counts)) if world > 1 else (latent, counts)
+            mine = subsets[rank::world] if shard else subsets
+            part, cnt = (torch.zeros_like(latent), torch.zeros_like(counts)) if shard else (latent, counts)
             if mine:
                 lat_b = encode(pts_cf, mine)
                 i = 0
@@ -396,7 +397,7 @@ class PocoModel(_Base):
                     part[ids] += lat_b[i:j].reshape(ids.shape[0], -1).float()       # duplicate ids (top-up): one write wins, counted once, like the reference
                     cnt[ids] += 1
                     i = j
-            if world > 1:
+            if shard:
                 sharding.allreduce_latents(part, cnt)
                 latent += part
                 counts += cnt

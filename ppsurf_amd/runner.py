@@ -167,11 +167,10 @@ def main(argv=None):
     # one process per GPU; more ranks than GPUs (2-rank rehearsals on a 1-GPU box) wrap around
     device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)) % torch.cuda.device_count())
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
-    if world > 1:
-        import torch.distributed as dist
+    from . import sharding
+    if world > 1 or sharding.single_rank_collectives():
         torch.cuda.set_device(device)
-        if not dist.is_initialized():
-            dist.init_process_group(os.environ.get('PPS_BACKEND', 'nccl'), rank=rank, world_size=world)
+        sharding.init_process_group(device)                     # PPS_BACKEND (default nccl = RCCL), 127.0.0.1
     model = _instantiate(cfg['model']).to(device).eval()
     dspec = dict(cfg['data'])
     dspec['class_path'] = _DATA_CLASSES.get(dspec['class_path'], dspec['class_path'])
@@ -191,9 +190,8 @@ def main(argv=None):
     # shapes of the test set round-robin to the ranks, no communication; PPS_SHARD=queries shards the query blocks and the
     # encoder passes of every shape over all ranks (latent all-reduce + per-round all-gather of occupancies).
     shard = os.environ.get('PPS_SHARD', 'shapes')
-    if world > 1:
+    if sharding.multi():
         model.shard_queries = shard == 'queries'
-        from . import sharding
         sharding.set_query_sharding(model.shard_queries)
     with torch.no_grad():
         if sub == 'predict':

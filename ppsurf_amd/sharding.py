@@ -26,6 +26,47 @@ def world():
     return 0, 1
 
 
+def single_rank_collectives() -> bool:
+    """PPS_SINGLE_RANK_COLLECTIVES=1: a process group of ONE rank still runs every collective of the multi-rank code paths (query-sharded predict,
+    staged data-parallel fit).  RCCL accepts a one-rank communicator, so on a 1-GPU box every collective call site -- the padded all-gather of
+    sharded_map, the latent all-reduce, the bucket all-reduces issued between the replayed backward stages, the buffer broadcast, the mask MAX --
+    executes on the REAL backend with its dtype / stream semantics (tests/test_gpu_nccl_single_rank.py, `bench.py --single-rank-collectives`)."""
+    return os.environ.get('PPS_SINGLE_RANK_COLLECTIVES', '0') == '1'
+
+
+def multi() -> bool:
+    """True when the data path issues its collectives: an initialised process group of several ranks, or of one rank under
+    PPS_SINGLE_RANK_COLLECTIVES=1."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or single_rank_collectives()
+
+
+def init_process_group(device=None, backend=None):
+    """One process per GPU: the group of the launcher's RANK / WORLD_SIZE (torch.distributed.run) on 127.0.0.1 unless MASTER_ADDR says otherwise;
+    backend PPS_BACKEND (default 'nccl' = RCCL over xGMI; 'gloo' for rehearsals on one GPU).  With RCCL the communicator is bound to `device`
+    at once (device_id), so the first collective does not have to guess it.  No-op when a group exists; returns (rank, world)."""
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    rank, ws = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    backend = backend or os.environ.get('PPS_BACKEND', 'nccl')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if 'MASTER_PORT' not in os.environ:
+        if ws > 1:
+            raise RuntimeError('WORLD_SIZE > 1 without MASTER_PORT: launch the ranks with python -m torch.distributed.run')
+        import socket
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(('127.0.0.1', 0))
+            os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
+    if backend == 'nccl' and device is not None and torch.device(device).type == 'cuda':
+        dist.init_process_group('nccl', rank=rank, world_size=ws, device_id=torch.device(device))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=ws)
+    return rank, ws
+
+
 def shard_range(n: int, rank: int, world_size: int):
     """Contiguous, balanced [lo, hi) slice of n items for `rank` (sizes differ by at most one)."""
     base, rem = divmod(n, world_size)
@@ -81,7 +122,7 @@ def sharded_map(fn, items: torch.Tensor, min_shard: int = None) -> torch.Tensor:
     import torch.distributed as dist
     rank, ws = world()
     n = items.shape[0]
-    if ws == 1 or not _QUERY_SHARDING:
+    if not multi() or not _QUERY_SHARDING:
         return fn(items)
     ranges = shard_ranges(n, ws, min_shard)
     lo, hi = ranges[rank]
@@ -99,8 +140,7 @@ def sharded_map(fn, items: torch.Tensor, min_shard: int = None) -> torch.Tensor:
 
 def max_over_ranks(seconds: float, device) -> float:
     import torch.distributed as dist
-    rank, ws = world()
-    if ws == 1:
+    if not multi():
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -110,7 +150,7 @@ def max_over_ranks(seconds: float, device) -> float:
 def mean_over_ranks(value: float, device) -> float:
     import torch.distributed as dist
     _, ws = world()
-    if ws == 1:
+    if not multi():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -120,8 +160,7 @@ def mean_over_ranks(value: float, device) -> float:
 def weighted_mean_over_ranks(total: float, count: int, device) -> float:
     """sum(total over ranks) / sum(count over ranks): a rank without batches contributes nothing instead of a zero."""
     import torch.distributed as dist
-    _, ws = world()
-    if ws > 1:
+    if multi():
         t = torch.tensor([total, float(count)], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         total, count = float(t[0]), float(t[1])
@@ -131,8 +170,7 @@ def weighted_mean_over_ranks(total: float, count: int, device) -> float:
 def allreduce_latents(latent_sum: torch.Tensor, counts: torch.Tensor):
     """Sum the per-rank partial latent sums / counts of a latent loop whose encoder passes were dealt round-robin."""
     import torch.distributed as dist
-    _, ws = world()
-    if ws > 1:
+    if multi():
         with _timed_collective(latent_sum.device):
             dist.all_reduce(latent_sum, op=dist.ReduceOp.SUM)
             dist.all_reduce(counts, op=dist.ReduceOp.SUM)
@@ -146,7 +184,7 @@ def broadcast_buffers(module, src: int = 0):
     import torch.distributed as dist
     _, ws = world()
     bufs = [b for b in module.buffers() if b.is_floating_point()]
-    if ws == 1 or not bufs:
+    if not multi() or not bufs:
         return
     flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
     dist.broadcast(flat, src=src)
@@ -186,8 +224,8 @@ class GradBuckets:
         self.comm_dtype = comm_dtype
         self.params = [p for p in params if p.requires_grad]
         if groups is not None:
+            # an empty group stays an (empty) bucket: bucket k == backward stage k for fit.StagedStep, whatever is frozen
             self.buckets = [[p for p in g if p.requires_grad] for g in groups]
-            self.buckets = [b for b in self.buckets if b]
             ids = [id(p) for b in self.buckets for p in b]
             if len(ids) != len(set(ids)) or set(ids) != {id(p) for p in self.params}:
                 raise ValueError('GradBuckets: `groups` must partition the parameters that require a gradient')
@@ -205,7 +243,7 @@ class GradBuckets:
                 self.buckets.append(cur)
         self.flat, self.views, self.pending, self.handles, self.launched = [], [], [], [], []
         for bi, bucket in enumerate(self.buckets):
-            flat = torch.zeros(sum(p.numel() for p in bucket), dtype=torch.float32, device=bucket[0].device)
+            flat = torch.zeros(sum(p.numel() for p in bucket), dtype=torch.float32, device=(bucket[0] if bucket else self.params[0]).device)
             off, views = 0, []
             for p in bucket:
                 views.append(flat[off:off + p.numel()].view_as(p))
@@ -222,6 +260,8 @@ class GradBuckets:
         self._mismatch = None                       # device flag: a later step's global mask differed from the first step's
         self._steps = 0
         self.order_log = None                       # tests: a list that receives 'reduce<k>' when bucket k's collective is issued
+        self.hold = False                           # measurement (bench.py): reduce(k) does nothing, every collective goes out in finish() -- the
+                                                    # step WITHOUT all-reduce / backward overlap, to price the overlap against
         self._reset()
         self._armed = False                         # hooks stay inert until the first zero(): a backward pass outside zero() ... finish() is not ours
 
@@ -279,7 +319,7 @@ class GradBuckets:
             torch._foreach_copy_([v for v, _ in pairs], [p.grad for _, p in pairs])
             for v, p in pairs:
                 p.grad = v
-        if ws > 1 and not self.defer and collective:
+        if multi() and not self.defer and collective:
             self.reduced[bi] = True
             self.handles.append(self._all_reduce(bi))
 
@@ -290,8 +330,7 @@ class GradBuckets:
 
     def reduce(self, bi):
         """Issue the (asynchronous) all-reduce of bucket bi now; finish() waits for it.  Buckets go out in index order on every rank."""
-        _, ws = world()
-        if ws == 1 or self.reduced[bi]:
+        if not multi() or self.reduced[bi] or self.hold:
             return
         assert all(self.reduced[:bi]), 'gradient buckets are all-reduced in index order'
         self.pack(bi)
@@ -303,6 +342,12 @@ class GradBuckets:
     def _all_reduce(self, bi):
         """Asynchronous sum of bucket bi over the ranks (in comm_dtype if set); returns something with .wait()."""
         flat = self.flat[bi]
+        if flat.numel() == 0:                       # a stage without trainable parameters: nothing on the wire (the same decision on every rank)
+            class _Nothing:
+                @staticmethod
+                def wait():
+                    pass
+            return _Nothing
         if self.low is None:
             return self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, async_op=True)
         low = self.low[bi]
@@ -345,18 +390,19 @@ class GradBuckets:
         for bi in range(len(self.buckets)):
             if not self.launched[bi]:
                 self._launch(bi)
-        if ws > 1:                                  # whatever the caller (defer) or the hooks have not sent yet, in index order
+        on = multi()
+        if on:                                      # whatever the caller (defer) or the hooks have not sent yet, in index order
             for bi in range(len(self.buckets)):
                 if not self.reduced[bi]:
                     self.reduced[bi] = True
                     self.handles.append(self._all_reduce(bi))
         for h in self.handles:
             h.wait()
-        if ws > 1:
+        if on:
             for flat in self.flat:
                 flat.div_(ws)
         touched = self.touched
-        if ws > 1:
+        if on:
             # the decision "this parameter got a gradient" must be the same on every rank, or some replicas would step the parameter (averaged
             # gradient, weight decay, step count) and others skip it: one tiny MAX all-reduce of a per-parameter mask per step.  A
             # parameter touched on ANY rank keeps its averaged gradient everywhere (ranks that did not touch it contributed zeros).  The collective

@@ -383,9 +383,9 @@ def table_extras(data):
         if not torch.is_tensor(ids) or ids.dim() != 3:
             continue
         n = sizes[src]
-        t = torch.where(ids > -1, ids, torch.zeros_like(ids)) if name in UP_TABLES else ids
-        flat = (t + torch.arange(b, device=ids.device).view(b, 1, 1) * n).reshape(-1)
-        order, offsets = train_ops.csr_build(flat, b * n)
+        # flat row numbers (-1 -> row 0 for the up-sampling tables) and their CSR in one device call (a counting sort, pps_csr.hip): four
+        # elementwise torch launches, a stable sort and a searchsorted per table until round 5
+        flat, order, offsets = train_ops.csr_build_table(ids, ids.shape[1] * ids.shape[2], n, b * n, name in UP_TABLES)
         out['tables_flat_' + name], out['tables_order_' + name], out['tables_offsets_' + name] = flat, order, offsets
     return out
 
@@ -575,19 +575,22 @@ _STAGE_PREFIX = {2: ('cv0.', 'bn0.', 'resnetb01.', 'resnetb10.', 'resnetb11.'), 
 
 
 def parameter_stages(module):
-    """[[parameters of stage 0], [stage 1], [stage 2]] of a model holding `network.encoder` (any module: parameters whose name has no
-    '.encoder.<block>' part are stage 0), each in reverse registration order (roughly the order backward produces them)."""
+    """[[parameters of stage 0], [stage 1], [stage 2]] of a model holding the encoder as `network.encoder` (PocoModel / PPSurfModel) or
+    `encoder` (a network): the encoder's parameters are found through the MODULE (identity, not a substring of their names) and sorted by the
+    block they belong to; every other parameter is stage 0.  Each group in reverse registration order (roughly the order backward produces them).
+    A stage without trainable parameters (frozen encoder levels) stays in the list as an EMPTY group: sharding.GradBuckets keeps it as an empty
+    bucket, so the stage <-> bucket correspondence fit.StagedStep relies on survives."""
     groups = [[] for _ in range(N_STAGES)]
-    for name, p in module.named_parameters():
-        if not p.requires_grad:
-            continue
-        stage = 0
-        if 'encoder.' in name:
-            tail = name.split('encoder.', 1)[1]
+    enc = getattr(getattr(module, 'network', module), 'encoder', None)
+    stage_of = {}
+    if isinstance(enc, torch.nn.Module):
+        for name, p in enc.named_parameters():
             for k, prefixes in _STAGE_PREFIX.items():
-                if tail.startswith(prefixes):
-                    stage = k
-        groups[stage].append(p)
+                if name.startswith(prefixes):
+                    stage_of[id(p)] = k
+    for _, p in module.named_parameters():
+        if p.requires_grad:
+            groups[stage_of.get(id(p), 0)].append(p)
     return [list(reversed(g)) for g in groups]
 
 

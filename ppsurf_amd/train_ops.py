@@ -72,15 +72,31 @@ def csr_register(idx_flat, n, order, offsets):
 
 
 def csr_build(idx_flat: torch.Tensor, n: int):
-    """(order, offsets) of a flat id table, not cached."""
-    # 32-bit keys: the radix sort makes half the passes of the 64-bit one (row numbers fit easily)
-    small = n < 2 ** 31 - 1
-    keys, order = torch.sort(idx_flat.to(torch.int32) if small else idx_flat, stable=True)
-    order = order.contiguous()
-    # first entry of every target row by binary search in the sorted keys (torch.bincount would synchronise with the host
-    # in the middle of the backward pass)
-    offsets = torch.searchsorted(keys, torch.arange(n + 1, dtype=keys.dtype, device=idx_flat.device))
-    return order, offsets
+    """(order, offsets) of a flat id table, not cached: entries stably sorted by target row (ascending entry number inside a row), offsets int64
+    [n+1] -- a counting sort on the device (pps_csr_build: count, scan, fill, rank; csrc/pps_csr.hip), the same arrays torch.sort(stable) +
+    torch.searchsorted returned until round 5 (tests/test_gpu_train.py::test_csr_build_*)."""
+    return csr_build_table(idx_flat.reshape(-1), 0, 0, n, False, want_flat=False)[1:]
+
+
+def csr_build_table(ids: torch.Tensor, per_item: int, rows_per_item: int, rows: int, clamp_negative: bool, want_flat: bool = True):
+    """(flat, order, offsets) of an id table [B, M, K] of a fit batch in one call: flat row numbers ids + item * rows_per_item (per_item = M * K
+    entries per batch item; -1 -> row 0 with clamp_negative), and their CSR.  per_item = 0: `ids` are flat rows already."""
+    _need_cuda(ids)
+    if ids.dtype != torch.int64:
+        raise _lib.PpsError('csr_build: id tables are int64')
+    ids = ids.contiguous()
+    entries = ids.numel()
+    L = _lib.lib()
+    dev = ids.device
+    flat = torch.empty((entries,), dtype=torch.int64, device=dev) if want_flat else None
+    order = torch.empty((entries,), dtype=torch.int64, device=dev)
+    offsets = torch.empty((rows + 1,), dtype=torch.int64, device=dev)
+    nbytes = L.pps_csr_ws_bytes(entries, rows)
+    ws = torch.empty(((nbytes + 7) // 8,), dtype=torch.int64, device=dev)
+    _lib.check(L.pps_csr_build(ids.data_ptr(), entries, int(per_item), int(rows_per_item), int(rows), 1 if clamp_negative else 0,
+                               flat.data_ptr() if flat is not None else None, order.data_ptr(), offsets.data_ptr(), ws.data_ptr(), nbytes, _stream()),
+               'pps_csr_build')
+    return flat, order, offsets
 
 
 def clear_cache():

@@ -48,20 +48,33 @@ def test_a_mismatched_launcher_is_refused_not_ignored():
 
 
 @pytest.mark.gpu
-def test_plain_gpus_2_prints_one_line_with_per_rank_rates_and_shapes_per_hour():
+def test_plain_gpus_2_prints_one_line_with_replicas_strong_and_fit():
     """`python bench.py --gpus 2` exactly as the driver would type it (plus the single-GPU rehearsal switches): self-spawn, two ranks on
-    cuda:0 over gloo, ONE JSON line from rank 0 with n_gpus 2, per-rank rates and a shapes/hour figure."""
+    cuda:0 over gloo, ONE JSON line from rank 0 with n_gpus 2 carrying the three measurements of an N > 1 run: the replica
+    figure (`value`, per-rank rates, shapes/hour), `strong` (ONE shape by both ranks, PPS_SHARD=queries) and `fit` (the staged data-parallel
+    step with its all-reduce accounting)."""
+    env = dict(os.environ, PPS_BENCH_DDP_BATCH='4', PPS_MIN_SHARD='4096')
     p = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--same-gpu', '--steps', '2', '--warmup', '1',
-                        '--shapes', '1'], capture_output=True, text=True, timeout=1500, cwd=REPO)
+                        '--shapes', '1'], capture_output=True, text=True, timeout=1500, cwd=REPO, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['world_size_seen'] == 2 and d['steps'] == 2 and d['scaling'] == 'weak'
+    assert d['config']['parallelism'].startswith('shape-level replicas x2')          # not "query-block sharding": that is d['strong']
     assert len(d['per_rank_queries_per_s']['all']) == 2 and d['per_rank_queries_per_s']['min'] > 0
     assert d['value'] > 0 and d['repeats'] >= 1 and d['timed_s'] >= 1.0
     assert d['shapes_per_hour'] and d['shapes_per_hour'] > 0 and len(d['reconstruction']['per_rank_shapes_per_hour']['all']) == 2
-    assert 'cpu_baseline' not in d and 'fit_ms_per_step' not in d                    # rank 0 at N = 1 only
+    assert 'cpu_baseline' not in d                                                   # rank 0 at N = 1 only
+    st, ft = d['strong'], d['fit']
+    assert st['scaling'] == 'strong' and st['value'] > 0 and st['shapes_per_hour'] > 0 and 10 <= st['collectives_per_shape'] <= 40
+    assert 0 < st['collective_share_rank0'] < 1 and len(st['per_rank_decoder_queries_per_shape']) == 2
+    assert abs(sum(st['per_rank_decoder_queries_per_shape']) - st['decoder_queries_per_shape']) < 1
+    assert min(st['per_rank_decoder_queries_per_shape']) > 0.3 * st['decoder_queries_per_shape']      # both ranks decoded about half
+    assert ft['ranks'] == 2 and ft['batch_per_rank'] == 2 and ft['global_batch'] == 4 and ft['graphs_captured'] == 3 and not ft['capture_failed']
+    assert ft['ms_per_step'] > 0 and ft['allreduce_ms'] > 0 and ft['ms_per_step_collectives_behind_backward'] > 0
+    assert 0.0 <= ft['overlap_share'] <= 1.0 and sum(ft['gradient_bytes_per_step']) == 4 * 13_749_111
+    assert d['fit_ms_per_step'] == ft['ms_per_step']
 
 
 @pytest.mark.gpu

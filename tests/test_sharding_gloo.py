@@ -283,3 +283,100 @@ def test_dense_grid_blocks_shard_into_contiguous_z_slab_runs():
         for lo, hi in ranges:                                        # consecutive voxels: the z index advances by one, wrapping at n
             z = np.round((first[lo:hi, 2].numpy() - np.float32(bmin_pad)) / np.float32(step)).astype(np.int64)
             assert np.all((np.diff(z) == 1) | (np.diff(z) == -(n - 1)))
+
+
+def _single_worker(rank, world, port, out_dir):
+    """ONE rank, PPS_SINGLE_RANK_COLLECTIVES=1: the multi-rank code paths with their collectives (gloo here, RCCL in tests/test_gpu_nccl_single_rank.py)."""
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', PPS_BACKEND='gloo')
+    from ppsurf_amd import sharding
+    out = {}
+    os.environ['PPS_SINGLE_RANK_COLLECTIVES'] = '0'
+    assert sharding.init_process_group() == (0, 1) and sharding.init_process_group() == (0, 1)      # idempotent
+    out['multi_off'] = sharding.multi()
+    os.environ['PPS_SINGLE_RANK_COLLECTIVES'] = '1'
+    out['multi_on'] = sharding.multi()
+    sharding.set_query_sharding(True)
+    sharding.profile_collectives(True)
+    seen = []
+    g = sharding.sharded_map(lambda x: (seen.append(x.shape[0]), x * 3)[1], torch.arange(7, dtype=torch.float32))
+    out['gathered'], out['seen'], out['calls'] = g.numpy(), seen, sharding.STATS['calls']
+    lat, cnt = torch.full((4, 2), 2.0), torch.ones(4)
+    sharding.allreduce_latents(lat, cnt)
+    out['lat'] = lat.numpy()
+    # gradient buckets with an EMPTY middle group (a frozen backward stage): three buckets stay three, the empty one sends nothing
+    ps = [torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2, 2))]
+    b = sharding.GradBuckets(ps, defer=True, groups=[[ps[0]], [], [ps[1]]])
+    b.order_log = []
+    b.zero()
+    (ps[0].sum() * 2 + ps[1].sum() * 3).backward()
+    for k in range(3):
+        b.reduce(k)
+    b.finish()
+    out['n_buckets'], out['order'] = len(b.buckets), list(b.order_log)
+    out['g0'], out['g1'] = ps[0].grad.numpy().copy(), ps[1].grad.numpy().copy()
+    b.hold = True                                             # measurement switch: reduce(k) does nothing, finish() sends everything
+    b.order_log = []
+    b.zero()
+    (ps[0].sum() + ps[1].sum()).backward()
+    for k in range(3):
+        b.reduce(k)
+    out['held_order'] = list(b.order_log)
+    b.finish()
+    out['held_g0'] = ps[0].grad.numpy().copy()
+    torch.save(out, os.path.join(out_dir, 'single.pt'))
+    dist.destroy_process_group()
+
+
+def test_one_rank_group_runs_the_multi_rank_paths_when_asked(tmp_path):
+    port = 31000 + os.getpid() % 2000
+    mp.spawn(_single_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    out = torch.load(tmp_path / 'single.pt', weights_only=False)
+    assert out['multi_off'] is False and out['multi_on'] is True
+    assert np.array_equal(out['gathered'], np.arange(7) * 3.0) and out['seen'] == [7] and out['calls'] == 1
+    assert (out['lat'] == 2.0).all()
+    assert out['n_buckets'] == 3 and out['order'] == ['reduce0', 'reduce1', 'reduce2']
+    assert (out['g0'] == 2.0).all() and (out['g1'] == 3.0).all()
+    assert out['held_order'] == [] and (out['held_g0'] == 1.0).all()
+
+
+def test_parameter_stages_follow_the_encoder_module_not_a_name_substring():
+    """stages were keyed on the substring 'encoder.' of parameter names.  A module whose encoder is found through the attribute gets
+    its blocks sorted into stages; another module that merely has 'encoder.' inside a parameter name does not; empty stages stay in the list."""
+    sys.path.insert(0, REPO)
+    from ppsurf_amd import train_graph
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.cv0 = torch.nn.Linear(2, 2)
+            self.resnetb20 = torch.nn.Linear(2, 2)
+            self.fcout = torch.nn.Linear(2, 2)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder = Enc()
+            self.mlp = torch.nn.Linear(2, 2)
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.network = Net()
+
+    m = Model()
+    st = train_graph.parameter_stages(m)
+    ids = lambda ps: {id(p) for p in ps}
+    assert ids(st[2]) == ids(m.network.encoder.cv0.parameters()) and ids(st[1]) == ids(m.network.encoder.resnetb20.parameters())
+    assert ids(st[0]) == ids(m.network.encoder.fcout.parameters()) | ids(m.network.mlp.parameters())
+    assert train_graph.parameter_stages(m.network)[2] == st[2]                      # a network holding `.encoder` directly
+    for p in m.network.encoder.resnetb20.parameters():
+        p.requires_grad_(False)
+    assert [len(g) for g in train_graph.parameter_stages(m)] == [4, 0, 2]           # the frozen stage stays, empty
+
+    class Other(torch.nn.Module):                                                   # 'encoder.' in the name, no encoder module of ours
+        def __init__(self):
+            super().__init__()
+            self.my_encoder = torch.nn.ModuleDict({'cv0': torch.nn.Linear(2, 2)})
+
+    assert [len(g) for g in train_graph.parameter_stages(Other())] == [2, 0, 0]
