@@ -50,6 +50,29 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// The same reductions for FOUR values at once with the lane permutation folded INTO the arithmetic instruction (v_max_f32_dpp / v_add_f32_dpp: the
+// first source is read through the DPP permutation).  Written with dpp_mov the compiler keeps a separate v_mov_b32_dpp per step -- it pairs the
+// adds of two values into v_pk_add_f32, which has no DPP form, and puts a canonicalising v_max in front of every fmaxf -- 2.5-3 instructions
+// per step and value instead of 1 (profiles/round6_interp_isa_census.md).  Inline assembly is outside the compiler's hazard recogniser: a DPP
+// read of a VGPR needs 2 wait states after the VALU write of it.  Inside a block the four independent chains are interleaved (a dependent
+// instruction is 4 issues behind its producer) and the block starts with s_nop 1 for whatever the compiler scheduled right in front of it.
+#define PPS_DPP4(OP, CTRL)                                                    \
+    OP " %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      \
+    OP " %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      \
+    OP " %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      \
+    OP " %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+__device__ __forceinline__ void row16_max4(float& a, float& b, float& c, float& d) {
+    asm("s_nop 1\n\t" PPS_DPP4("v_max_f32_dpp", "quad_perm:[1,0,3,2]") PPS_DPP4("v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+        PPS_DPP4("v_max_f32_dpp", "row_half_mirror") PPS_DPP4("v_max_f32_dpp", "row_mirror")
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void row16_sum4(float& a, float& b, float& c, float& d) {
+    asm("s_nop 1\n\t" PPS_DPP4("v_add_f32_dpp", "quad_perm:[1,0,3,2]") PPS_DPP4("v_add_f32_dpp", "quad_perm:[2,3,0,1]")
+        PPS_DPP4("v_add_f32_dpp", "row_half_mirror") PPS_DPP4("v_add_f32_dpp", "row_mirror")
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+#undef PPS_DPP4
+
 // ---- value of lane (l ^ st) without the LDS crossbar -------------------------------------------------
 // A bitonic network over the 64 lanes is a chain of dependent exchanges; as ds_bpermute each costs an LDS round trip (the kNN kernels spend
 // more time in their merge networks than in the distance tests).  Strides 1 and 2 are quad permutations, 4 and 8 two DPP moves
@@ -176,15 +199,23 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct HiLo { half8 hi, lo; };
 
+// The low part comes from ONE mixed-precision fma per value: v_fma_mixlo_f16 / v_fma_mixhi_f16 read the f16 half of `hi` selected by op_sel as
+// its first operand, compute x - hi in fp32 (exact: hi is x truncated to 11 significant bits) and write the result, converted to f16 (round to
+// nearest even), into the low / high half of the destination -- 1.5 VALU instructions per value (half a v_cvt_pkrtz + one fma_mix) instead of 3
+// (v_cvt_pkrtz, v_cvt_f32_f16 back, v_sub_f32, v_cvt_pkrtz of the difference: rounds 2-5).  The split is 25 % of all vector instructions of
+// interp_pool_f16x3_kernel (profiles/round6_interp_isa_census.md).  As inline assembly: hipcc does not form the mix instructions from the
+// fptrunc(fsub(x, fpext(h))) pattern on its own.
 __device__ __forceinline__ HiLo split_f16(const f32x4& x0, const f32x4& x1) {
     u32x4 hp, lp;
     const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const auto h = __builtin_amdgcn_cvt_pkrtz(v[2 * p], v[2 * p + 1]);
-        const auto l = __builtin_amdgcn_cvt_pkrtz(v[2 * p] - (float)h[0], v[2 * p + 1] - (float)h[1]);
-        hp[p] = __builtin_bit_cast(unsigned, h);
-        lp[p] = __builtin_bit_cast(unsigned, l);
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[2 * p], v[2 * p + 1]));
+        unsigned l;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(v[2 * p]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(v[2 * p + 1]));
+        hp[p] = h;
+        lp[p] = l;
     }
     return HiLo{__builtin_bit_cast(half8, hp), __builtin_bit_cast(half8, lp)};
 }
@@ -209,12 +240,16 @@ __device__ __forceinline__ void range_commit(float amax, int* flag) {
 // gate of the fp32 fallback kernels: nothing to do unless a split-precision kernel of this chunk left the f16 range
 __device__ __forceinline__ bool gate_closed(const int* gate) { return gate != nullptr && __builtin_nontemporal_load(gate) == 0; }
 
-// back to fp32 (hi + lo), blocks 2 kb and 2 kb + 1
+// back to fp32 (hi + lo), blocks 2 kb and 2 kb + 1: one v_fma_mix_f32 per value (f16 half of hi x 1.0 + f16 half of lo, in fp32) instead of two
+// conversions and an add
 __device__ __forceinline__ void join_f16(const HiLo& x, f32x4& y0, f32x4& y1) {
+    const u32x4 hp = __builtin_bit_cast(u32x4, x.hi), lp = __builtin_bit_cast(u32x4, x.lo);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        y0[r] = (float)x.hi[r] + (float)x.lo[r];
-        y1[r] = (float)x.hi[4 + r] + (float)x.lo[4 + r];
+    for (int p = 0; p < 4; ++p) {
+        float a, b;
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(a) : "v"(hp[p]), "v"(lp[p]));
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(b) : "v"(hp[p]), "v"(lp[p]));
+        if (p < 2) { y0[2 * p] = a; y0[2 * p + 1] = b; } else { y1[2 * (p - 2)] = a; y1[2 * (p - 2) + 1] = b; }
     }
 }
 
@@ -383,6 +418,26 @@ __device__ __forceinline__ void chunk_copy_piece(const f32x4* __restrict__ src, 
     asm volatile("" : "+s"(piece));
     const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(dst + i * NTHREADS + wave_base));
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_addr), "v"(lane_off), "s"(piece) : "memory", "m0");
+}
+// The same piece with NO per-piece vector instruction: `voff` = this lane's byte offset INCLUDING the piece's (threadIdx.x * 16 + i * NTHREADS * 16),
+// one VGPR per piece index made by stream_lane_offsets() once per kernel, and `chunk` = the chunk's first byte (one SGPR pair for all pieces of a
+// chunk, advanced by the caller).  chunk_copy_piece builds its lane offset and its source pointer per piece: the opaque "+v" copy of the offset is
+// a v_mov per piece, and the 18 x 4 piece pointers of a pass over the weights, all loop invariant, were hoisted out of the persistent loop and
+// spilled -- v_writelane / v_readlane: 227 of the 2264 vector instructions of a trip of interp_pool_f16x3_kernel
+// (profiles/round6_interp_isa_census.md).
+template <int NTHREADS, int NPIECES>
+__device__ __forceinline__ void stream_lane_offsets(unsigned (&voff)[NPIECES]) {
+#pragma unroll
+    for (int i = 0; i < NPIECES; ++i) {
+        voff[i] = threadIdx.x * 16u + (unsigned)i * (NTHREADS * 16u);
+        asm volatile("" : "+v"(voff[i]));          // opaque: stays one live VGPR instead of being rebuilt (or folded into 64-bit addresses) per use
+    }
+}
+template <int NTHREADS>
+__device__ __forceinline__ void chunk_copy_piece_at(const char* chunk, f32x4* dst, int i, unsigned voff) {
+    const int wave_base = threadIdx.x & ~63;
+    const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(dst + i * NTHREADS + wave_base));
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_addr), "v"(voff), "s"(chunk) : "memory", "m0");
 }
 // all outstanding pieces of this wave have landed in LDS (call before the barrier that hands the chunk to the other waves)
 __device__ __forceinline__ void stream_wait() {

@@ -55,6 +55,17 @@ __device__ __forceinline__ void stream_step_spread(const f32x4* __restrict__ gne
     f32x4* t = cur; cur = nxt; nxt = t;
 }
 
+// stream_step_spread with the pieces addressed by chunk_copy_piece_at: `chunk` = first byte of the NEXT chunk (SGPR pair kept by the caller),
+// voff = the per-lane piece offsets of stream_lane_offsets (no vector instruction per piece)
+template <int CHUNK_F4_NEXT, int NTH = NT, class F>
+__device__ __forceinline__ void stream_step_spread_at(const char* chunk, const unsigned (&voff)[CHUNK_F4_NEXT / NTH], f32x4*& cur, f32x4*& nxt, F&& compute) {
+    f32x4* dst = nxt;
+    compute((const f32x4*)cur, [&](int i) { if (i < CHUNK_F4_NEXT / NTH) chunk_copy_piece_at<NTH>(chunk, dst, i, voff[i]); });
+    stream_wait();
+    __syncthreads();
+    f32x4* t = cur; cur = nxt; nxt = t;
+}
+
 template <int CHUNK_F4, int NTH = NT>
 __device__ __forceinline__ void stream_prologue(const f32x4* __restrict__ g, f32x4* buf) {
     chunk_copy_async<CHUNK_F4 / NTH, NTH>(g, buf);
@@ -312,6 +323,12 @@ __global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float
     stream_wait();
     __syncthreads();
     f32x4 *cur = buf0, *nxt = buf1;
+    // the weight stream: one SGPR pointer to the chunk being fetched (advanced after every step, back to the first chunk after the last one) and
+    // one VGPR byte offset per piece -- no vector instruction and no spilled pointer per piece (pps_common.h, chunk_copy_piece_at)
+    unsigned voff[IH_CH4 / IH_NT];
+    stream_lane_offsets<IH_NT>(voff);
+    const char* const wfirst = (const char*)wg;
+    const char* snext = wfirst + (size_t)IH_CH4 * 16;
 
     const int ntiles = (int)((Q + IH_NW / 4 - 1) / (IH_NW / 4));
     int first, count, stride;
@@ -342,21 +359,26 @@ __global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float
 #ifndef PPS_FCQ_PRODUCTS
 #define PPS_FCQ_PRODUCTS 3      // f16 products per fp32 product in fc_query (2, 1: experiment builds only, python -m ppsurf_amd.build --variant)
 #endif
-#define IH_STEP(GNEXT, IN, BIAS, ACTV, SINK) IH_STEP_NP(GNEXT, IN, BIAS, ACTV, SINK, 3)
-#define IH_STEP_NP(GNEXT, IN, BIAS, ACTV, SINK, NPR)                                                                                  \
-        stream_step_spread<IH_CH4, IH_NT>(GNEXT, cur, nxt, [&](const f32x4* w, auto&& piece) {                                         \
-            dense_blocks_f16x3_hook<8, IH_OB, ACTV, true, false, NPR>(IN, (const half8*)w, BIAS, lane, SINK,                           \
-                                                    [&](int ob, int kb) { if (ob == 0 && (kb & 1) == 0) piece(kb >> 1); if (IH_CH4 / IH_NT > 4 && ob == 0 && (kb & 1)) piece(4 + (kb >> 1)); }); })
+        // LAST: the step that fetches the last chunk of the pass -- the pointer wraps to the first chunk behind it
+#define IH_STEP(LAST, IN, BIAS, ACTV, SINK) IH_STEP_NP(LAST, IN, BIAS, ACTV, SINK, 3)
+#define IH_STEP_NP(LAST, IN, BIAS, ACTV, SINK, NPR)                                                                                   \
+        {                                                                                                                             \
+            stream_step_spread_at<IH_CH4, IH_NT>(snext, voff, cur, nxt, [&](const f32x4* w, auto&& piece) {                            \
+                dense_blocks_f16x3_hook<8, IH_OB, ACTV, true, false, NPR>(IN, (const half8*)w, BIAS, lane, SINK,                       \
+                                                    [&](int ob, int kb) { if (ob == 0 && (kb & 1) == 0) piece(kb >> 1); if (IH_CH4 / IH_NT > 4 && ob == 0 && (kb & 1)) piece(4 + (kb >> 1)); }); }); \
+            snext = (LAST) ? wfirst : snext + (size_t)IH_CH4 * 16;                                                                     \
+            asm volatile("" : "+s"(snext));      /* opaque: one running pointer, not 18 hoisted ones */                                \
+        }
 #pragma unroll
         for (int c = 0; c < 16 / IH_OB; ++c)                           // fc2: output blocks IH_OB c .. = k-blocks IH_OB/2 c .. of fc3
-            IH_STEP(wg + (c + 1) * IH_CH4, x, bias4 + 4 * IH_OB * c, 1, ([&](int p, const f32x4& o0, const f32x4& o1) { y[IH_OB / 2 * c + p] = split_f16_r(amax, o0, o1); }));
+            IH_STEP(false, x, bias4 + 4 * IH_OB * c, 1, ([&](int p, const f32x4& o0, const f32x4& o1) { y[IH_OB / 2 * c + p] = split_f16_r(amax, o0, o1); }));
 #pragma unroll
         for (int c = 0; c < 16 / IH_OB; ++c)                           // fc3
-            IH_STEP(wg + (c + 16 / IH_OB + 1) * IH_CH4, y, bias4 + 64 + 4 * IH_OB * c, 1, ([&](int p, const f32x4& o0, const f32x4& o1) { x[IH_OB / 2 * c + p] = split_f16_r(amax, o0, o1); }));
+            IH_STEP(false, y, bias4 + 64 + 4 * IH_OB * c, 1, ([&](int p, const f32x4& o0, const f32x4& o1) { x[IH_OB / 2 * c + p] = split_f16_r(amax, o0, o1); }));
         f32x4 b[4];
 #pragma unroll
         for (int c = 0; c < 4 / IH_OB; ++c)                            // fc_query: 64 heads
-            IH_STEP_NP(wg + ((c + 32 / IH_OB + 1) % IH_NCH) * IH_CH4, x, bias4 + 128 + 4 * IH_OB * c, 0,
+            IH_STEP_NP(c + 32 / IH_OB + 2 == IH_NCH, x, bias4 + 128 + 4 * IH_OB * c, 0,
                        ([&](int p, const f32x4& o0, const f32x4& o1) { b[IH_OB * c + 2 * p] = o0; b[IH_OB * c + 2 * p + 1] = o1; }), PPS_FCQ_PRODUCTS);
 #undef IH_STEP
 #undef IH_STEP_NP
@@ -366,16 +388,22 @@ __global__ __launch_bounds__(IH_NT, 2) void interp_pool_f16x3_kernel(const float
         {
             f32x4 m4[4], s4[4];
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb)
+            for (int bb = 0; bb < 4; ++bb) {
+                // row maxima and row sums of four heads at a time, the lane permutation folded into v_max_f32_dpp / v_add_f32_dpp (pps_common.h)
+                float v[4], mx[4], sm[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx[r] = v[r] = valid ? b[bb][r] : -INFINITY;
+                row16_max4(mx[0], mx[1], mx[2], mx[3]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = valid ? b[bb][r] : -INFINITY;
-                    const float mx = row16_max(v);
-                    const float ev = valid ? __expf(v - mx) : 0.f;
+                    const float ev = valid ? __expf(v[r] - mx[r]) : 0.f;
                     e[bb * 4 + r] = ev;
-                    m4[bb][r] = mx;
-                    s4[bb][r] = row16_sum(ev);
+                    sm[r] = ev;
                 }
+                row16_sum4(sm[0], sm[1], sm[2], sm[3]);
+                m4[bb] = f32x4{mx[0], mx[1], mx[2], mx[3]};
+                s4[bb] = f32x4{sm[0], sm[1], sm[2], sm[3]};
+            }
             if (n < 4) {
                 const f32x4 mm = (n == 0) ? m4[0] : (n == 1) ? m4[1] : (n == 2) ? m4[2] : m4[3];
                 const f32x4 ss = (n == 0) ? s4[0] : (n == 1) ? s4[1] : (n == 2) ? s4[2] : s4[3];

@@ -320,11 +320,38 @@ def test_config3_fit_step_at_full_batch_size_against_the_reference(precision):
     ratio = sorted(s[1] for s in stats)
     print('bf16-mixed at size: logits {:.3e} (scale {:.2f}), loss {:.2e}; {} gradient tensors: lowest cosine {:.4f} ({}), length ratio {:.3f} .. {:.3f}'.format(
         err_logits, float(np.abs(g['logits']).max()), err_loss, len(stats), lo[0], lo[2], ratio[0], ratio[-1]))
-    # measured on an MI355X: logits 0.164 of a scale of 3.35 (bf16 storage through ~60 layers), loss 5.8e-4; 114 gradient tensors above the size
-    # threshold, lowest cosine 0.954 (encoder.resnetb40.shortcut.weight: 390 rows), length ratio 0.941 .. 1.075
-    assert err_logits <= 0.08 * float(np.abs(g['logits']).max()) and err_loss < 5e-3
-    assert len(stats) >= 100 and lo[0] > 0.93 and 0.88 < ratio[0] and ratio[-1] < 1.15
-    assert float(np.median([s[0] for s in stats])) > 0.99
+    # The yardstick is the REFERENCE's own 16-bit step: tests/golden/train_ppsurf_full_bf16ref.npz holds what
+    # torch.autocast('cpu', dtype=torch.bfloat16) costs the reference's PPSurfNetwork on this very batch against its own fp32 logits / float64
+    # gradients (make_golden_train_full_bf16.py: logits 0.237 of the scale 3.35, loss 4.4e-4, lowest gradient cosine 0.917 -- the same tensor that
+    # is lowest here, encoder.resnetb40.shortcut.weight, 390 rows -- median 0.992, length ratio 0.902 .. 1.184).  The build's bf16-mixed step (fused
+    # row layers, hand-written dense layers, bf16 storage between layers) may lose at most 1.5 x as much, quantity by quantity; measured on an
+    # MI355X it loses LESS than the reference's autocast step: logits 0.164, lowest cosine 0.954, ratio 0.941 .. 1.075.
+    y = load_golden('train_ppsurf_full_bf16ref')
+    assert str(y['digest']) == str(g['digest'])
+    ynames = [str(k) for k in y['gnames']]
+    ref = {k: (float(y['cos'][i]), float(y['ratio'][i])) for i, k in enumerate(ynames)}
+    ref_used = [ref[k] for _, _, k in stats]                            # the same tensors (above the size threshold, non-zero reference gradient)
+    ref_lo = min(c for c, _ in ref_used)
+    ref_med = float(np.median([c for c, _ in ref_used]))
+    ref_ratio = max(abs(r - 1.0) for _, r in ref_used)
+    ours_med = float(np.median([s[0] for s in stats]))
+    ours_ratio = max(abs(r - 1.0) for r in ratio)
+    F = 1.5
+    print('  reference bf16 autocast on the same batch: logits {:.3e}, loss {:.2e}, lowest cosine {:.4f}, median {:.4f}, |ratio - 1| <= {:.3f}'.format(
+        float(y['err_logits']), float(y['err_loss']), ref_lo, ref_med, ref_ratio))
+    print('  ours / reference: logits {:.2f}, loss {:.2f}, 1 - lowest cosine {:.2f}, 1 - median cosine {:.2f}, |ratio - 1| {:.2f}'.format(
+        err_logits / float(y['err_logits']), err_loss / float(y['err_loss']), (1 - lo[0]) / (1 - ref_lo), (1 - ours_med) / (1 - ref_med),
+        ours_ratio / ref_ratio))
+    assert len(stats) >= 100
+    assert err_logits <= F * float(y['err_logits'])
+    assert err_loss <= F * float(y['err_loss'])
+    assert 1.0 - lo[0] <= F * (1.0 - ref_lo)
+    assert 1.0 - ours_med <= F * (1.0 - ref_med)
+    assert ours_ratio <= F * ref_ratio
+    # tensor by tensor: nowhere more than 1.5 x the reference's own loss of direction plus what two different bf16 roundings of a gradient with
+    # 0.92 .. 0.999 cosine to the truth can differ by (1e-2)
+    worse = [(k, c, ref[k][0]) for c, _, k in stats if 1.0 - c > F * (1.0 - ref[k][0]) + 1e-2]
+    assert not worse, worse
 
 
 def _check_samples_n(named, g, rtol, n_sample, noise=1e-6):
