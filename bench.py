@@ -259,7 +259,7 @@ def pmc_traffic(dtype):
     have changed since, the figure is NOT reported (traffic: null) instead of silently going stale."""
     import bench_workloads as workloads
     here = workloads.csrc_digest()
-    for tag in ('round5', 'round4', 'round3', 'round2'):
+    for tag in ('round6', 'round5', 'round4', 'round3', 'round2'):
         path = os.path.join(REPO, 'profiles', '{}_{}_pmc.json'.format(tag, dtype))
         if os.path.isfile(path):
             d = json.load(open(path))
@@ -345,6 +345,7 @@ def main():
     ap.add_argument('--shapes', type=int, default=2, help='timed whole reconstructions per rank of the shapes/hour leg')
     ap.add_argument('--single-rank-collectives', action='store_true',
                     help='--gpus 1 only: initialise a ONE-rank process group and run the N > 1 code path (strong + fit legs with every collective issued)')
+    ap.add_argument('--only', choices=['config2', 'config5'], default=None, help='run ONE extra leg and print its object (profiling: tools/profile_config5.sh)')
     ap.add_argument('--legs', default='replicas,strong,fit', help='N > 1: which measurements go on the line (comma list of replicas, strong, fit)')
     args = ap.parse_args()
     if args.steps is None:
@@ -380,6 +381,9 @@ def main():
     from ppsurf_amd.synthetic import network_state_dict
 
     red_dev = dev if args.backend == 'nccl' else 'cpu'
+    if args.only is not None:
+        print(json.dumps({'config2': config2_leg, 'config5': config5_leg}[args.only](dev, args.dtype)), flush=True)
+        return
     if args.scaling == 'strong':
         st = strong_leg(args, rank, world, dev, dist, red_dev, args.steps, args.warmup)
         if rank == 0:
@@ -510,6 +514,12 @@ def main():
                 out['fit_ms_per_step'] = fb['ms_per_step']
             torch.cuda.empty_cache()
     if not multi and not args.quick:
+        # ---- BASELINE.md section 3's other per-config report lines ---------------------------------------------------------
+        out['config2'] = config2_leg(dev, args.dtype)
+        torch.cuda.empty_cache()
+        out['config5'] = config5_leg(dev, args.dtype)
+        torch.cuda.empty_cache()
+    if not multi and not args.quick:
         fit = workloads.FitStep(batch=10, precision='bf16-mixed', device=dev, graph=True)      # as `pps.py fit` runs it: replayed HIP graph, loader thread
         for _ in range(6):
             fit()
@@ -555,7 +565,7 @@ def fit_roofline(ms_per_step):
     training code (bench_workloads.fit_digest); otherwise no roofline is reported (the round-3 object mixed an eager step of an older
     commit with the replayed step's time)."""
     import bench_workloads as workloads
-    paths = [os.path.join(REPO, 'profiles', '{}_train_pmc.json'.format(tag)) for tag in ('round5', 'round4')]
+    paths = [os.path.join(REPO, 'profiles', '{}_train_pmc.json'.format(tag)) for tag in ('round6', 'round5', 'round4')]
     paths = [q for q in paths if os.path.isfile(q)]
     if not paths:
         return {'roofline': None, 'roofline_note': 'no counter passes of the replayed fit step committed'}
@@ -572,6 +582,120 @@ def fit_roofline(ms_per_step):
                          'achieved_tflops': d['mfma_flops_per_step'] / s / 1e12, 'mfma_frac_of_bf16_peak': d['mfma_flops_per_step'] / s / 1e12 / PEAK_F16_MFMA_TFLOPS,
                          'achieved_hbm_tb_s': d['hbm_bytes_per_step'] / s / 1e12, 'hbm_frac': d['hbm_bytes_per_step'] / s / 8e12,
                          'bound': d.get('bound', 'hbm')}}
+
+
+def config2_leg(dev, dtype, shapes=2):
+    """BASELINE config 2 (ppsurf_50nn predict, ONE shape, gen_resolution_global = 129, 1 GPU; BASELINE.md section 3: q/s, s/shape): whole reconstructions
+    by the product driver at R = 129 -- latent loop, region growing, Marching Cubes + clean-up, 10 refinement rounds -- on the synthetic 100k-point
+    cloud (growth steered by the analytic shape like the R = 257 leg: formula-filled weights describe no surface; the real ABC shape of this config
+    runs in tests/test_gpu_configs.py::test_config2_* with learned toy weights)."""
+    import bench_workloads as workloads
+    model = workloads.make_model(129, P_LOCAL, Q_CHUNK, dev)
+    model.network.decoder_dtype = dtype
+    first = workloads.reconstruct_steered(model, N_POINTS, seed=42, device=dev)
+    runs = [workloads.reconstruct_steered(model, N_POINTS, seed=43 + i, device=dev) for i in range(shapes)]
+    best = min(runs, key=lambda r: r['total_s'])
+    tot_q, tot_s = sum(r['decoder_queries'] for r in runs), sum(r['total_s'] for r in runs)
+    del model
+    return {'config': 'ppsurf_50nn predict, one 100k-point synthetic shape, gen_resolution_global=129, rec_batch_size=50000, 1 GPU (BASELINE config 2)',
+            'queries_per_s': tot_q / tot_s, 's_per_shape': tot_s / shapes, 'best_s_per_shape': best['total_s'], 'first_shape_s': first['total_s'],
+            'decoder_queries_per_shape': tot_q / shapes, 'latent_loop_s': best['latent_s'], 'surface_s': best['surface_s'],
+            'vertices': best['vertices'], 'shapes_timed': shapes, 'decoder_dtype': dtype,
+            'surface_queries_per_s': best['decoder_queries'] / best['surface_s'],
+            'note': 'queries_per_s = decoder queries of the timed shapes / their whole wall time (latent loop, driver, Marching Cubes included); '
+                    'surface_queries_per_s = the same without the latent loop'}
+
+
+C5_N, C5_P, C5_Q, C5_RES = 250_000, 200, 25_000, 513          # configs/ppsurf_200nn.yaml:8 + BASELINE config 5
+# algorithmic bytes per query of the two gather kernels of config 5: the 200-NN search reads the query (12 B) and writes 200 int64 ids (the cloud,
+# 3 MB, is shared by all queries); the patch kernel reads those ids, gathers 200 points of 12 B and writes 200 normalised points
+C5_KNN_BYTES, C5_PATCH_BYTES = 12 + 200 * 8, 12 + 200 * 8 + 200 * 12 + 200 * 12
+
+
+def config5_pmc():
+    """HBM bytes per launch of the k = 200 search and the patch kernel from the committed counter passes of `python bench.py --only config5`
+    (profiles/round6_config5_pmc.json), only if measured on these kernel sources."""
+    import bench_workloads as workloads
+    path = os.path.join(REPO, 'profiles', 'round6_config5_pmc.json')
+    if not os.path.isfile(path):
+        return None, 'no counter passes of the config-5 leg committed'
+    d = json.load(open(path))
+    if d.get('csrc_digest') != workloads.csrc_digest():
+        return None, 'profiles/round6_config5_pmc.json was measured on other kernel sources (digest {} at commit {}, now {}): not reported'.format(
+            d.get('csrc_digest'), d.get('git_head'), workloads.csrc_digest())
+    return d, 'profiles/round6_config5_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE per launch, separate rocprofv3 --pmc passes of `python bench.py --only config5` at commit {}'.format(d.get('git_head'))
+
+
+def config5_leg(dev, dtype, steps=20, warmup=3):
+    """BASELINE config 5's chunk (ppsurf_200nn: P = 200 patch points, rec_batch_size = 25 000, N = 250 000-point synthetic cloud, R = 513 band): the same
+    step as the headline through the product's chunk loop -- ONE exact 200-NN search serves the patches and (its first 64 columns) the
+    interpolation ids -- with per-kernel times and the HBM rates BASELINE.md section 3 asks for of the k = 200 search and the patch gather."""
+    import bench_workloads as workloads
+    from ppsurf_amd import ops
+    from ppsurf_amd.decoder import DecoderPlan, ChunkPipeline
+    from ppsurf_amd.synthetic import make_cloud, make_latents, network_state_dict
+    plan = DecoderPlan(network_state_dict('ppsurf', num_pts_local=C5_P), dev, dtype=dtype)
+    cloud = make_cloud(C5_N, seed=5)
+    pts = torch.from_numpy(cloud).to(dev)
+    table = plan.point_table(torch.from_numpy(make_latents(256, C5_N, seed=6)[0]).to(dev))
+    chunks, n_band = workloads.band_chunks(cloud, C5_RES, C5_Q, dev)
+    chunks = chunks[::max(1, len(chunks) // (steps + warmup))][:steps + warmup]
+    pipe = ChunkPipeline(plan, table, pts, pts, K_PROJ, C5_P, same_cloud=True, max_chunk=C5_Q)
+    pipe.run(chunks[:warmup])
+    timed = chunks[warmup:]
+    pipe.run(timed[:4])                                            # allocates the second lane's buffers
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        res = pipe.run(timed, want_occ=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (reps * len(timed))
+    assert bool(torch.isfinite(res[-1][1]).all())
+    ev = [workloads.HipEvents(6) for _ in timed]
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i, c in enumerate(timed):
+        pipe.run([c], want_occ=True, stage_events=[ev[i].arr])
+    torch.cuda.synchronize()
+    single = (time.perf_counter() - t1) / len(timed)
+    stage_ms = {name: float(np.mean([e.elapsed_ms(j, j + 1) for e in ev])) for j, name in enumerate(STAGES)}
+
+    def timed_op(fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn(timed[0])
+        torch.cuda.synchronize()
+        a.record()
+        for c in timed:
+            fn(c)
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / len(timed)
+    ids = torch.empty((C5_Q, C5_P), dtype=torch.int64, device=dev)
+    patches = torch.empty((C5_Q, C5_P, 3), dtype=torch.float32, device=dev)
+    knn_ms = timed_op(lambda c: pipe.raw_blocks.query(c, C5_P, out=ids))
+    patch_ms = timed_op(lambda c: ops.patch_normalize(pts, c, ids, C5_P, out=patches))
+    pmc, src = config5_pmc()
+    gbs = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9
+    out = {'config': 'ppsurf_200nn predict chunk: N=250000-point synthetic cloud, P=200, k=64, rec_batch_size=25000, {} band chunks of the R=513 grid '
+                     '(BASELINE config 5; configs/ppsurf_200nn.yaml:8)'.format(len(timed)),
+           'queries_per_s': C5_Q / dt, 'ms_per_step': dt * 1e3, 'single_lane_ms_per_step': single * 1e3, 'steps': len(timed), 'repeats': reps,
+           'decoder_dtype': dtype, 'band_queries_of_the_shape': n_band, 'stage_ms': stage_ms,
+           'spatial_ms': single * 1e3 - sum(stage_ms.values()),
+           'kernel_ms': {'knn_blocked_k200': knn_ms, 'patch_normalize_p200': patch_ms},
+           'gather_kernels': {
+               'knn_blocked_k200': {'ms': knn_ms, 'algorithmic_bytes_per_launch': C5_KNN_BYTES * C5_Q, 'algorithmic_GB_s': gbs(C5_KNN_BYTES * C5_Q, knn_ms),
+                                    'hbm_bytes_per_launch': pmc and pmc.get('knn_hbm_bytes_per_launch'),
+                                    'hbm_GB_s': pmc and pmc.get('knn_hbm_bytes_per_launch') and gbs(pmc['knn_hbm_bytes_per_launch'], knn_ms)},
+               'patch_normalize_p200': {'ms': patch_ms, 'algorithmic_bytes_per_launch': C5_PATCH_BYTES * C5_Q, 'algorithmic_GB_s': gbs(C5_PATCH_BYTES * C5_Q, patch_ms),
+                                        'hbm_bytes_per_launch': pmc and pmc.get('patch_hbm_bytes_per_launch'),
+                                        'hbm_GB_s': pmc and pmc.get('patch_hbm_bytes_per_launch') and gbs(pmc['patch_hbm_bytes_per_launch'], patch_ms)},
+               'hbm_source': src,
+               'note': 'ms: the kernel alone on the stream (HIP events over the chunks); algorithmic bytes: query + 200 int64 ids (search), ids + 200 gathered '
+                       'points + 200 written points (patches), the 3 MB cloud is cache-resident; hbm_*: counted L2 <-> fabric traffic of a separate '
+                       'profiled run, reported only for matching kernel sources'}}
+    del pipe, plan, table
+    return out
 
 
 def strong_leg(args, rank, world, dev, dist, red_dev, steps, warm):

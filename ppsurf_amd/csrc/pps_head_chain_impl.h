@@ -20,6 +20,8 @@ constexpr int HC_HEADS = 64;            // attention heads = outputs of fc_query
 constexpr int HC_CHUNKS = 9;            // fc2: 4 groups of 64 output channels, fc3: 4, fc_query: 1
 constexpr int HC_CHUNK_FRAGS = 8 * 4 * 64;          // [k-step][block][lane] fragments of 16 bytes = 32 KB
 constexpr int HC_UNIT = 256;            // rows of a workgroup pass: 8 waves x 2 tiles x 16 rows
+constexpr int HC_REQ_OPS = HC_CHUNK_FRAGS * 16 / (512 * 16);   // global_load_lds_dwordx4 per wave and chunk (512 threads x 16 bytes per instruction)
+static_assert(HC_REQ_OPS == 4, "chunk_copy_async<4, 512> below");
 constexpr int HC_NBUF = 4;              // LDS weight buffers: a chunk is requested 3 chunks before it is used (a chunk's products take ~0.9 us of a
                                         // SIMD's matrix pipe, an L2 -> LDS copy ~2 us: with two buffers every chunk waited for the next one)
 
@@ -209,13 +211,19 @@ __global__ __launch_bounds__(512, 1) void head_chain_fwd_kernel(const HeadChainA
                     out[t][2 * gout + 1] = as_frag(relu_bf16x8(hi));
                 }
             }
-            // the NEXT chunk must have landed.  VMEM operations retire in order on gfx9; younger than its request are the requests of the two chunks
-            // after it (4 each) and the stores of three epilogues (4 each) = 20.  (vmcnt(0) here makes every chunk wait for its own stores.)
-#ifdef PPS_HC_VM0
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-            asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            // the NEXT chunk must have landed.  VMEM operations retire in order on gfx9; YOUNGER than its request are, at least, the requests of the
+            // two chunks after it: HC_REQ_OPS global_load_lds each, issued by inline assembly, so their number does not depend on the compiler.
+            // Waiting until at most 2 HC_REQ_OPS operations are outstanding is therefore safe WHATEVER the compiler makes of the epilogues' stores
+            // (rounds 4-5 waited for vmcnt(20) = 8 requests + 12 stores of three epilogues, hand counted -- a build that emitted fewer
+            // stores than assumed would have let a wave read a weight buffer before it had landed).  The price of the safe count is that a chunk
+            // also waits for the stores of the epilogue BEFORE its own (the youngest 8 operations are this chunk's 4 stores and the request issued
+            // at its head): measured 0.60x ms either way at the fit batch's size (profiles/NOTES_r6.md); PPS_HC_VMCNT selects another count for
+            // experiments (20: the old hand count; 0: every chunk waits for its own stores).
+#ifndef PPS_HC_VMCNT
+#define PPS_HC_VMCNT (2 * HC_REQ_OPS)
 #endif
+            static_assert(PPS_HC_VMCNT >= 0 && PPS_HC_VMCNT < 64, "vmcnt is a 6-bit field");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPS_HC_VMCNT) : "memory");
             __syncthreads();
             cur = (cur + 1) % HC_NBUF;
         };

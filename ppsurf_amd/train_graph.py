@@ -21,6 +21,8 @@ Semantics restated from the reference, train() mode:
 Parity: tests/test_train_graph_cpu.py and tests/test_gpu_train.py against tests/golden/train_*.npz (outputs, loss, updated
 buffers and parameter gradients recorded from the reference itself).
 """
+import weakref
+
 import torch
 import torch.nn.functional as F
 
@@ -123,6 +125,12 @@ def _transpose_all(params, dtype):
     return True
 
 
+def _drop_images(pid):
+    _shadow.pop(pid, None)
+    _shadow_t.pop(pid, None)
+    _shadow_ver.pop(pid, None)
+
+
 def prepare_shadows(module, dtype=torch.bfloat16):
     """Call at the start of an autocast forward pass in train(): parameters -> persistent images in the autocast type (bf16 / fp16)."""
     params = [p for p in module.parameters() if p.is_cuda and p.dtype == torch.float32]
@@ -132,6 +140,10 @@ def prepare_shadows(module, dtype=torch.bfloat16):
         for p in params:
             t = _shadow.get(id(p))
             if t is None or t.shape != p.shape or t.device != p.device or t.dtype != dtype:
+                if t is None:
+                    # the images die with their parameter (every model created in a process used to leave its 16-bit images -- 55 MB for
+                    # PPSurf with the transposed ones -- behind for good).  A recorded step reads images by address, but it also holds its model.
+                    weakref.finalize(p, _drop_images, id(p))
                 _shadow[id(p)] = torch.empty_like(p, dtype=dtype)
         if not _cast_all(params, dtype):
             torch._foreach_copy_([_shadow[id(p)] for p in params], params)
@@ -182,19 +194,12 @@ def _mm_f32(a, b):
 
 
 def _bias_grad(g):
-    """Column sums of a 16-bit gradient [rows, n] in fp32 by the HIP reduction for ANY n (the kernel takes <= 1024 columns: wider layers -- the
-    4096 outputs of the STN's last layer -- go through it in column blocks).  NOT torch's sum: inside a replayed HIP graph `g.sum(0, dtype=fp32)`
-    of that [rows, 4096] bf16 tensor returned values that depended on the memory layout of the recording from the second replay on (the
-    config-1 fit: one tensor of the 455 in the checkpoint, stn2.fc3.bias, differed between two builds whose eager fits are bit-identical;
-    profiles/NOTES_r5.md section 3) -- the replayed step was not the eager step."""
-    db = train_ops.col_sum(g)
-    if db is not None:
-        return db
-    n = g.shape[1]
-    parts = [train_ops.col_sum(g[:, i:min(i + 1024, n)].contiguous()) for i in range(0, n, 1024)]
-    if all(p is not None for p in parts):
-        return torch.cat(parts)
-    return g.sum(0, dtype=torch.float32)
+    """Column sums of a gradient [rows, n] in fp32 by the HIP reduction for ANY n (train_ops.sum_rows: the kernel takes <= 1024 columns, wider layers
+    -- the 4096 outputs of the STN's last layer -- go through it in column blocks, the 2-column output layer padded to 4).  NOT torch's sum: inside
+    a replayed HIP graph `g.sum(0, dtype=fp32)` of that [rows, 4096] bf16 tensor returned values that depended on the memory layout of the
+    recording from the second replay on (the config-1 fit: one tensor of the 455 in the checkpoint, stn2.fc3.bias, differed between two builds whose
+    eager fits are bit-identical; profiles/NOTES_r5.md section 3) -- the replayed step was not the eager step."""
+    return train_ops.sum_rows(g)
 
 
 class _RowsLinear(torch.autograd.Function):
@@ -213,7 +218,7 @@ class _RowsLinear(torch.autograd.Function):
         xc = x.to(dt)
         wc = wc if (wc is not None and wc.dtype == dt) else w.to(dt)            # wc / bc: 16-bit images of the step (prepare_shadows)
         n, k = wc.shape
-        ctx.own = train_ops.gemm_supported(xc, k) and xc.dim() == 2
+        ctx.own = train_ops.gemm_supported(xc, k) and xc.dim() == 2 and xc.shape[0] > 0      # (no rows: F.linear and its plain backward)
         if ctx.own:
             npad = (n + 7) // 8 * 8                                             # (the 256 -> 2 output layer: zero rows up to a multiple of 8)
             if npad != n:
@@ -247,7 +252,7 @@ class _RowsLinear(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 dw = train_ops.gemm_tn(gp, xc)[:n].to(wdt)
             if bdt is not None and ctx.needs_input_grad[2]:
-                db = _bias_grad(g).to(bdt)
+                db = _bias_grad(gp)[:n].to(bdt)
             return dx, dw, db, None, None, None
         acc = torch.float64 if xc.dtype == torch.float64 else torch.float32
         if ctx.needs_input_grad[0]:
@@ -752,7 +757,8 @@ def interp_attention(proj, latents, pts, query, ids, last_layer=True):
             and train_ops.head_input_supported(w1.shape[0])):
         # fc2, fc3, fc_query as fused row layers (pps_rows_train.hip): each stores its RAW output once, the ReLU is applied by the consumer on
         # load (and masks the gradient on the way back), so no activated [B*Q*k, 256] tensor is written or read
-        if HEAD_CHAIN and train_ops.head_chain_supported(w1.shape[0], _w2d(proj.fc_query).shape[0], k):
+        if (HEAD_CHAIN and train_ops.head_chain_supported(w1.shape[0], _w2d(proj.fc_query).shape[0], k)
+                and train_ops.head_chain_trusted(table.dtype if table.dtype in train_ops.LOW else torch.bfloat16)):
             # the three layers in ONE kernel: a wave carries its rows through them in registers (csrc/pps_head_chain_impl.h)
             pooled = train_ops.head_chain(table, flat, pts.reshape(b * n, 3), query.reshape(b * q, 3), k, w1[:, c:], (_w2d(proj.fc2), proj.fc2.bias),
                                           (_w2d(proj.fc3), proj.fc3.bias), (_w2d(proj.fc_query), proj.fc_query.bias))
@@ -842,7 +848,7 @@ def _pointnet_fused(pn, patches, need_trans=True):
     # (softmax ignores the constant w_q . shift + b_q; it stays in the graph with weight 0 so that fc_query.bias gets its zero gradient, not None)
     const = (wq * shift).sum() + pn.att.fc_query.bias.float().sum()
     pooled = train_ops.patch_attn(z.raw.view(nq, p, -1), (wq * scale).reshape(-1))
-    pooled = (pooled * scale + shift + 0.0 * const).to(z.raw.dtype)
+    pooled = (train_ops.affine_rows(pooled, scale, shift) + 0.0 * const).to(z.raw.dtype)      # (the row sums of its backward by the HIP reduction)
     return dense(pn.att.fc_value, pooled), trans2
 
 

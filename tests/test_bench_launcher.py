@@ -102,3 +102,21 @@ def test_strong_scaling_line_reports_the_dtype_it_ran_and_its_collectives(dtype)
     assert d['value'] > 0 and d['shapes_per_hour'] > 0
     assert 10 <= d['collectives_per_shape'] <= 40                                   # growth rounds + refinement rounds + the latent all-reduce
     assert 0 <= d['collective_share_rank0'] < 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('leg', ['config2', 'config5'])
+def test_extra_config_legs_report_what_baseline_md_asks_for(leg):
+    """config 2 (R = 129: q/s, s/shape) and config 5 (N = 250k, P = 200, Q = 25 000: q/s and the k = 200 search / patch gather
+    kernels' rates) are keys of the default line; `--only <leg>` prints the same object alone (what the counter passes profile)."""
+    p = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--only', leg], capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+    assert d['queries_per_s'] > 1e5 and d['decoder_dtype'] == 'f16x3'
+    if leg == 'config2':
+        assert 0 < d['s_per_shape'] < 10 and d['decoder_queries_per_shape'] > 5e5 and d['vertices'] > 10000
+    else:
+        assert d['ms_per_step'] > 0 and set(d['stage_ms']) == {'interp_pool', 'pointnet_stn_rows', 'pointnet_stn_fc', 'pointnet_feat_rows', 'decode_tail'}
+        g = d['gather_kernels']
+        assert g['knn_blocked_k200']['ms'] > 0 and g['patch_normalize_p200']['algorithmic_GB_s'] > 10
+        assert d['band_queries_of_the_shape'] > 5_000_000

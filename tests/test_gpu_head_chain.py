@@ -101,18 +101,21 @@ def _launch(args, nq, k, dt):
 
 
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
-def test_head_chain_is_run_to_run_identical_and_h1_is_head_input_to_the_bit(dt):
-    """60 launches at the fit batch's size (5000 row units each): every stored tensor equal to the first launch's, and h1 equal to the separate
-    head_input kernel's.  (The gather phase once lost this -- one channel of a 16-row tile in ~1 unit of 10^4, from the compiler's paired form of
-    the Wx products: the note in csrc/pps_head_chain_impl.h; that form differed in 165 of 300 such launches.)"""
+@pytest.mark.parametrize('nq,n,reps', [(20000, 100000, 60), (50000, 250000, 20), (24000, 120000, 20), (12000, 60000, 20), (2003, 10000, 40), (777, 3000, 40)])
+def test_head_chain_is_run_to_run_identical_and_h1_is_head_input_to_the_bit(dt, nq, n, reps):
+    """Repeated launches at the fit batch's size (20 000 queries: 5000 row units; and at the per-rank batches of a data-parallel fit, B = 25 / 12 / 6
+    shapes: 50 000 / 24 000 / 12 000 queries, and two small sizes with a partial last unit): every stored tensor equal to the first launch's, and
+    h1 equal to the separate head_input kernel's.  (The gather phase once lost this -- one channel of a 16-row tile in ~1 unit of 10^4, from the
+    compiler's paired form of the Wx products: the note in csrc/pps_head_chain_impl.h; that form differed in 165 of 300 launches at 20 000
+    queries.  ADVICE r5: one size is not a guard.)"""
     from ppsurf_amd import train_ops
-    nq, k = 20000, 64
-    args = _case(nq, k, 100000, 11, dt)
+    k = 64
+    args = _case(nq, k, n, 11, dt)
     first = [t.clone() for t in _launch(args, nq, k, dt)]
     with torch.no_grad():
         ref = train_ops.head_input(args[0], args[1], args[2], args[3], k, args[4])
     assert torch.equal(first[0], ref.view(nq * k, 256))
-    for rep in range(60):
+    for rep in range(reps):
         out = _launch(args, nq, k, dt)
         for name, a, b in zip(('h1', 'y2', 'y3', 'qy'), out, first):
             assert torch.equal(a, b), (name, rep)
@@ -153,3 +156,12 @@ def test_head_chain_is_what_the_training_graph_runs():
             assert float(ga[nme].abs().max()) <= 1e-2 * float(ga['fc_query.weight'].abs().max()) + 1e-6
             continue
         assert float((ga[nme] - gb[nme]).abs().max()) <= 0.03 * float(gb[nme].abs().max()) + 1e-7, nme
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+def test_first_use_self_check_passes_and_is_cached(dt):
+    """train_ops.head_chain_trusted (what train_graph asks before it uses the chain kernel): the synthetic case agrees with the separate launches."""
+    from ppsurf_amd import train_ops
+    train_ops._head_chain_checked.pop(dt, None)
+    assert train_ops.head_chain_trusted(dt) is True
+    assert train_ops._head_chain_checked[dt] is True and train_ops.head_chain_trusted(dt) is True

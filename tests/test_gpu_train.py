@@ -594,8 +594,11 @@ def test_staged_step_overlap_structure_replay_equals_eager():
     assert not bad, bad[:5]
 
 
-def test_replayed_bf16_step_equals_the_eager_step():
-    """The config-3 step body at a small size, bf16-mixed (the benched dtype: head chain kernel, fused row layers, hand-written dense layers): eight
+@pytest.mark.parametrize('size,dropout', [((4, 2000, 300), 0.0), ((10, 10000, 2000), 0.3)], ids=['small', 'config3-dropout'])
+def test_replayed_bf16_step_equals_the_eager_step(size, dropout):
+    """[config3-dropout, ADVICE r5: the never-recording twin at config 3's FULL batch (10 shapes x 10 000 points x 2000 queries) with the MLP's dropout
+    0.3 active -- every reduction of the step now runs the HIP reduction kernel (train_ops.sum_rows) eagerly and in the replay.]
+    The config-3 step body at a small size, bf16-mixed (the benched dtype: head chain kernel, fused row layers, hand-written dense layers): eight
     optimisation steps replayed from the HIP graph against the same eight steps run eagerly -- EQUAL losses and parameters (every kernel of the
     step is run-to-run identical; a recorded graph that loses a dependency showed as 0.07 in the loss, measured with the experimental
     PPS_FIT_STREAMS=pointnet, see train_graph.side_streams_on).  The batches are built inline (overlap_prep=False): with the loader thread the
@@ -607,11 +610,11 @@ def test_replayed_bf16_step_equals_the_eager_step():
     res = {}
     for graph in (False, True):
         random.seed(0); torch.manual_seed(0)
-        fit = workloads.FitStep(batch=4, n=2000, q=300, precision='bf16-mixed', graph=True, n_batches=2, overlap_prep=False)
+        fit = workloads.FitStep(batch=size[0], n=size[1], q=size[2], precision='bf16-mixed', graph=True, n_batches=2, overlap_prep=False)
         fit.stepper.enabled = graph
         for m in fit.net.modules():
             if isinstance(m, nn.Dropout):
-                m.p = 0.0
+                m.p = dropout
         losses = []
         for i in range(8):
             random.seed(100 + i); torch.manual_seed(100 + i)
@@ -619,6 +622,6 @@ def test_replayed_bf16_step_equals_the_eager_step():
         fit.close()
         res[graph] = (losses, {k: v.detach().clone() for k, v in fit.net.state_dict().items()})
         assert len(fit.stepper.graphs) == (1 if graph else 0)
-    assert all(np.isfinite(res[True][0])) and res[True][0][-1] < 0.5 * res[True][0][0]
+    assert all(np.isfinite(res[True][0])) and res[True][0][-1] < (0.5 if dropout == 0.0 else 0.9) * res[True][0][0]
     assert res[False][0] == res[True][0], (res[False][0], res[True][0])
     assert all(torch.equal(res[False][1][k], res[True][1][k]) for k in res[True][1])
