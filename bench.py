@@ -128,6 +128,24 @@ def cpu_baseline(sd, cloud, qry, lat, q_call=20_000, reps=3):
                       'median of {} s per call'.format(reps, q_call, cloud.shape[0], ', '.join('{:.1f}'.format(t) for t in times))}
 
 
+def gpu_state():
+    """Clocks / power / temperature of GPU 0 as rocm-smi reports them right now (None if the tool is missing): the fit step's kernels are HBM- and
+    fabric-bound, and the same step runs 19.9 ms on a chip that has just started and 21-22 ms after a minute of sustained load (power management);
+    the bench line carries the state next to `fit_ms_per_step` so that a slow box can be told from a slow program."""
+    try:
+        p = subprocess.run(['rocm-smi', '--showclocks', '--showpower', '--showtemp', '--json'], capture_output=True, text=True, timeout=20)
+        d = json.loads(p.stdout)
+        card = d.get('card0') or next(iter(d.values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ('sclk', 'mclk', 'fclk', 'socclk', 'power', 'temperature (sensor junction)', 'temperature (sensor memory)')):
+                keep[k] = v
+        return keep
+    except Exception as exc:                                # noqa: BLE001 (a diagnostic only)
+        return {'unavailable': type(exc).__name__}
+
+
 def free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(('127.0.0.1', 0))
@@ -236,6 +254,21 @@ def chunk_loop(work, steps, warmup, rank, world, dist, red_dev, min_timed_s=MIN_
     dt = sharding.max_over_ranks(time.perf_counter() - t0, red_dev)
     occ = res[-1][1]
     assert bool(torch.isfinite(occ).all())
+    # ---- the SAME loop with the chunk lanes switched off: what the second HIP stream is worth (the difference between `value`
+    #      and the per-kernel pass below is NOT the lanes' gain -- that pass issues one chunk per call with HIP events between the kernels)
+    saved = [(pipe, pipe.lanes) for pipe, _ in groups]
+    for pipe, _ in groups:
+        pipe.lanes = 1
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(repeats):
+        for pipe, cs in groups:
+            pipe.run(cs, want_occ=True)
+            pacer.tick()
+    torch.cuda.synchronize()
+    one_lane = (time.perf_counter() - t2) / (repeats * steps)
+    for pipe, ln in saved:
+        pipe.lanes = ln
     lanes = max(min(pipe.lanes if pipe.lanes is not None else (2 if len(cs) >= pipe.LANE_MIN_CHUNKS else 1), len(cs)) for pipe, cs in groups)
     # ---- single-lane pass with HIP events around every kernel inside the product call: stage times, roofline -----------------------------------
     n_ev = min(len(timed), 100)
@@ -250,7 +283,7 @@ def chunk_loop(work, steps, warmup, rank, world, dist, red_dev, min_timed_s=MIN_
     pacer.close()
     stage_ms = {name: float(np.mean([e.elapsed_ms(j, j + 1) for e in ev])) for j, name in enumerate(STAGES)}
     return {'dt': dt, 'mine': mine, 'repeats': repeats, 'stage_ms': stage_ms, 'occ': occ, 'chunks': steps * repeats, 'lanes': lanes,
-            'single_lane_ms_per_step': single * 1e3, 'single_lane_steps': n_ev}
+            'single_lane_ms_per_step': single * 1e3, 'single_lane_steps': n_ev, 'one_lane_loop_ms_per_step': one_lane * 1e3}
 
 
 def pmc_traffic(dtype):
@@ -310,6 +343,9 @@ def dtype_stats(dtype, r, world):
             'stage_mfma_frac': {n: STAGE_ALG_FLOP_PER_QUERY[n] * Q_CHUNK / (sm[n] * 1e-3) / 1e12 / peak for n in STAGES},      # algorithmic (8d)
             'stage_mfma_frac_executed': {n: mult * STAGE_EXEC_MFMA_PER_QUERY[n] * 2048.0 * Q_CHUNK / (sm[n] * 1e-3) / 1e12 / peak for n in STAGES},
             'lanes': r.get('lanes', 1),
+            # the timed loop again with ONE chunk lane (same calls, no events): value / this = what the second stream gains
+            'one_lane_loop': {'ms_per_step': r['one_lane_loop_ms_per_step'], 'value': world * Q_CHUNK / (r['one_lane_loop_ms_per_step'] * 1e-3),
+                              'lanes_gain': r['one_lane_loop_ms_per_step'] / ms_step - 1.0},
             # the same chunks one at a time on ONE stream with HIP events around every kernel: what stage_ms / roofline / spatial_ms describe
             'single_lane': {'ms_per_step': r['single_lane_ms_per_step'], 'value': world * Q_CHUNK / (r['single_lane_ms_per_step'] * 1e-3),
                             'steps': r['single_lane_steps']},
@@ -420,10 +456,11 @@ def main():
                        'weights': 'formula-filled (no checkpoint offline)',
                        'entry': 'ChunkPipeline.run -> pps_knn_blocked_f32, pps_patch_normalize_f32, pps_decode_fwd_events_f32'},
             'roofline': roofline_block(args.dtype, r['stage_ms']),
-            'lanes': st['lanes'], 'single_lane': st['single_lane'],
+            'lanes': st['lanes'], 'single_lane': st['single_lane'], 'one_lane_loop': st['one_lane_loop'],
             'lanes_note': 'value / ms_per_step: the product chunk loop (ChunkPipeline.run on the chunk list of a shape; lists of >= 4 chunks are dealt to 2 HIP '
-                          'streams).  stage_ms, roofline, spatial_ms: a separate single-stream pass over the same chunks (single_lane), where a HIP-event '
-                          'interval is one kernel',
+                          'streams).  one_lane_loop: the same calls with one lane -- the gain of the second stream is value / one_lane_loop.value - 1.  '
+                          'stage_ms, roofline, spatial_ms: a separate pass, ONE chunk per call with a HIP event between the kernels (single_lane): its '
+                          'step is longer than one_lane_loop by the per-call overhead, not by lanes',
             'stage_ms': st['stage_ms'], 'stage_mfma_frac': st['stage_mfma_frac'], 'stage_mfma_frac_executed': st['stage_mfma_frac_executed'], 'spatial_ms': st['spatial_ms'],
             'whole_path_algorithmic_tflops': st['whole_path_algorithmic_tflops'], 'whole_path_algorithmic_frac': st['whole_path_algorithmic_frac'],
             'whole_path_executed_mfma_frac': st['whole_path_executed_mfma_frac'],
@@ -525,6 +562,7 @@ def main():
             fit()
         torch.cuda.synchronize()
         from ppsurf_amd.fit import HostGcPacer
+        state0 = gpu_state()
         n_fit = 120
         with HostGcPacer() as pacer:                      # as the epoch loop of ppsurf_amd.fit runs its steps
             t0 = time.perf_counter()
@@ -537,6 +575,7 @@ def main():
                                 'patches built on the device by the loader thread on a second stream, step replayed as a HIP graph (the defaults of pps.py fit)',
                       'steps_timed': n_fit, 'loss': float(loss),
                       'shapes_per_s': 10.0 / (out['fit_ms_per_step'] * 1e-3)}
+        out['fit']['gpu_state'] = {'before': state0, 'after': gpu_state(), 'note': 'rocm-smi before / right after the timed steps'}
         out['fit'].update(fit_roofline(out['fit_ms_per_step']))
         # where a slow box loses its time: a second, instrumented pass of 60 steps -- HIP events on the step's stream and on the
         # loader's, host time blocked on the loader thread.  Not part of fit_ms_per_step (the events cost a few microseconds per step).

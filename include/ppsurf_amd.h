@@ -278,7 +278,8 @@ int pps_mc_emit_f64(const double* vol, int64_t nx, int64_t ny, int64_t nz, doubl
 /* ---- mesh clean-up (csrc/pps_mesh.hip) -------------------------------------------------------------
  * replaces: source/base/mesh.py:7-38 (trimesh merge_vertices(digits_vertex = 8), remove_degenerate_faces, remove_duplicate_faces,
  * remove_small_connected_components(num_faces = 6)) as called from source/poco_utils.py:98-107, 169-174.
- *   pps_mesh_small_components   small uint8 [nf] = 1 for the faces of face-connected components (faces sharing an edge) of at most k faces
+ *   pps_mesh_small_components   small uint8 [nf] = 1 for the faces of face-connected components (faces sharing an edge that belongs to exactly two
+ *                               faces: trimesh's face_adjacency; an edge of three or more faces joins nothing) of at most k faces
  *                               (1 <= k <= 32); faces int64 [nf, 3], vertex ids below nv.
  *   pps_mesh_corner_weld        for a mesh welded by grid-edge key (pps_mc_emit_f64) in index space: vertices within 10^-digits of a grid corner
  *                               that share their position rounded to `digits` digits are merged into the smallest id of their class.  remap int64

@@ -311,8 +311,11 @@ def _set(idx, u, cu, v, cv):
 
 
 def components_union_find(faces):
-    """Label of the connected component of every face, components joined across shared UNDIRECTED edges (trimesh face_adjacency,
-    source/base/mesh.py:27) -- sequential union-find with path halving, no sparse-graph library."""
+    """Label of the connected component of every face.  Two faces are adjacent iff they share an UNDIRECTED edge that belongs to EXACTLY TWO
+    faces: source/base/mesh.py:27 builds its components from trimesh's `face_adjacency`, which pairs the faces of the edges that occur twice
+    (`group_rows(edges_sorted, require_count=2)` [ext: trimesh is not in the image]) -- an edge shared by three or more faces (non-manifold)
+    joins nothing, so pieces that touch only along such an edge stay separate components (rounds 3-5 joined all owners of an edge).
+    Sequential union-find with path halving, no sparse-graph library."""
     faces = np.asarray(faces, dtype=np.int64)
     nf = faces.shape[0]
     parent = list(range(nf))
@@ -323,18 +326,17 @@ def components_union_find(faces):
             x = parent[x]
         return x
 
-    owner = {}
+    owners = {}
     for f in range(nf):
         a, b, c = faces[f]
         for u, v in ((a, b), (b, c), (c, a)):
-            k = (u, v) if u < v else (v, u)
-            g = owner.get(k)
-            if g is None:
-                owner[k] = f
-            else:
-                ra, rb = find(f), find(g)
-                if ra != rb:
-                    parent[max(ra, rb)] = min(ra, rb)
+            owners.setdefault((int(u), int(v)) if u < v else (int(v), int(u)), []).append(f)
+    for fs in owners.values():
+        if len(fs) != 2:
+            continue
+        ra, rb = find(fs[0]), find(fs[1])
+        if ra != rb:
+            parent[max(ra, rb)] = min(ra, rb)
     return np.array([find(f) for f in range(nf)], dtype=np.int64)
 
 

@@ -7,7 +7,8 @@
 //
 //   pps_mesh_small_components   faces of components with <= k faces.  One hash-table pass links every face to the faces across its three edges
 //                               (an edge's owners form a chain in arrival order: each (face, edge) gets the previous owner, and tells it about
-//                               itself -- exact for non-manifold edges too, no sort), then every face walks its own neighbourhood: a component of
+//                               itself; no sort) and counts the owners of every edge; a second pass cuts the links of the edges that do not
+//                               have exactly two (trimesh's face_adjacency joins across manifold edges only); then every face walks its own neighbourhood: a component of
 //                               <= k faces is exhausted after visiting <= k faces, anything larger is left as soon as the (k+1)-th face shows up.
 //                               No label propagation, no iteration to convergence, no atomics on floating point; the RESULT does not depend on
 //                               the arrival order (connectivity is order-free).
@@ -57,7 +58,7 @@ __device__ __forceinline__ int hash_find(const u64* keys, unsigned mask, u64 key
 // ---- components ------------------------------------------------------------------------------------------------------------------------
 // nbr[6 f + 2 e + 0] = the owner of edge e of face f that arrived before f (or -1), nbr[6 f + 2 e + 1] = the one that arrived after it (or -1)
 __global__ __launch_bounds__(256) void mesh_edge_link_kernel(const int64_t* __restrict__ faces, int64_t nf, int64_t nv, u64* __restrict__ keys,
-                                                            int* __restrict__ last, int* __restrict__ nbr, unsigned mask) {
+                                                            int* __restrict__ last, int* __restrict__ cnt, int* __restrict__ nbr, unsigned mask) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= 3 * nf) return;
     const int64_t f = i / 3;
@@ -65,9 +66,26 @@ __global__ __launch_bounds__(256) void mesh_edge_link_kernel(const int64_t* __re
     const int64_t a = faces[3 * f + e], b = faces[3 * f + (e == 2 ? 0 : e + 1)];
     const int64_t lo = a < b ? a : b, hi = a < b ? b : a;
     const unsigned s = hash_claim(keys, mask, (u64)lo * (u64)nv + (u64)hi + 1ull);
+    atomicAdd(&cnt[s], 1);
     const int p = atomicExch(&last[s], (int)i);
     nbr[6 * f + 2 * e] = p < 0 ? -1 : p / 3;
     if (p >= 0) nbr[6 * (int64_t)(p / 3) + 2 * (p % 3) + 1] = (int)f;
+}
+
+// An edge joins its owners only if it has EXACTLY two: trimesh's face_adjacency (source/base/mesh.py:27) pairs the faces of the edges that occur
+// twice; an edge shared by three or more faces (non-manifold: it can occur where centre fans and tubes of neighbouring cubes meet) joins nothing, so a
+// small piece that hangs on the surface only by such an edge is a component of its own and is dropped like in the reference (rounds 3-5
+// chained ALL owners).  The links of every other edge are cut again here.
+__global__ __launch_bounds__(256) void mesh_edge_prune_kernel(const int64_t* __restrict__ faces, int64_t nf, int64_t nv, const u64* __restrict__ keys,
+                                                             const int* __restrict__ cnt, int* __restrict__ nbr, unsigned mask) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 3 * nf) return;
+    const int64_t f = i / 3;
+    const int e = (int)(i - 3 * f);
+    const int64_t a = faces[3 * f + e], b = faces[3 * f + (e == 2 ? 0 : e + 1)];
+    const int64_t lo = a < b ? a : b, hi = a < b ? b : a;
+    const int s = hash_find(keys, mask, (u64)lo * (u64)nv + (u64)hi + 1ull);
+    if (s >= 0 && cnt[s] != 2) { nbr[6 * f + 2 * e] = -1; nbr[6 * f + 2 * e + 1] = -1; }
 }
 
 __global__ __launch_bounds__(256) void mesh_small_kernel(const int* __restrict__ nbr, int64_t nf, int k, uint8_t* __restrict__ small) {
@@ -196,10 +214,11 @@ extern "C" {
 size_t pps_mesh_components_ws_bytes(int64_t nf) {
     if (nf < 1 || nf > 100000000) return 0;
     const size_t cap = capacity_for(3 * nf);
-    return 1024 + cap * (sizeof(u64) + sizeof(int)) + (size_t)nf * 6 * sizeof(int);
+    return 1024 + cap * (sizeof(u64) + 2 * sizeof(int)) + (size_t)nf * 6 * sizeof(int);
 }
 
-/* small [nf] = 1 for the faces of face-connected components (faces sharing an edge) with at most k faces (1 <= k <= 32), else 0.
+/* small [nf] = 1 for the faces of face-connected components (faces sharing an edge that has exactly two owners) with at most k faces
+ * (1 <= k <= 32), else 0.
  * faces int64 [nf, 3] vertex ids below nv.  ws: pps_mesh_components_ws_bytes(nf) bytes. */
 int pps_mesh_small_components(const int64_t* faces, int64_t nf, int64_t nv, int k, uint8_t* small, void* ws, void* stream) {
     if (nf < 0 || nv < 1 || k < 1 || k > MS_KMAX || nf > 100000000 || nv > 0x7fffffff) return PPS_ERR_ARG;      // (capacity 4 x 3 nf < 2^31 slots)
@@ -208,11 +227,14 @@ int pps_mesh_small_components(const int64_t* faces, int64_t nf, int64_t nv, int 
     hipStream_t st = (hipStream_t)stream;
     const unsigned cap = capacity_for(3 * nf);
     u64* keys = (u64*)al256((char*)ws);
-    int* last = (int*)(keys + cap);
+    int* cnt = (int*)(keys + cap);                                        // owners per edge slot
+    int* last = cnt + cap;
     int* nbr = last + cap;
-    if (hipMemsetAsync(keys, 0, (size_t)cap * sizeof(u64), st) != hipSuccess) return PPS_ERR_LAUNCH;
+    if (hipMemsetAsync(keys, 0, (size_t)cap * (sizeof(u64) + sizeof(int)), st) != hipSuccess) return PPS_ERR_LAUNCH;                         // keys and cnt: 0
     if (hipMemsetAsync(last, 0xff, (size_t)cap * sizeof(int) + (size_t)nf * 6 * sizeof(int), st) != hipSuccess) return PPS_ERR_LAUNCH;     // last and nbr: -1
-    hipLaunchKernelGGL(mesh_edge_link_kernel, dim3((unsigned)((3 * nf + 255) / 256)), dim3(256), 0, st, faces, nf, nv, keys, last, nbr, cap - 1);
+    hipLaunchKernelGGL(mesh_edge_link_kernel, dim3((unsigned)((3 * nf + 255) / 256)), dim3(256), 0, st, faces, nf, nv, keys, last, cnt, nbr, cap - 1);
+    hipLaunchKernelGGL(mesh_edge_prune_kernel, dim3((unsigned)((3 * nf + 255) / 256)), dim3(256), 0, st, faces, nf, nv, (const u64*)keys, (const int*)cnt, nbr,
+                       cap - 1);
     hipLaunchKernelGGL(mesh_small_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, st, (const int*)nbr, nf, k, small);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }

@@ -569,8 +569,7 @@ def clean_mesh(verts: np.ndarray, faces: np.ndarray, min_component_faces=6, digi
         owner = np.tile(np.arange(nf), 3)
         order = np.lexsort((edges[:, 1], edges[:, 0]))
         es, ow = edges[order], owner[order]
-        same = (es[1:] == es[:-1]).all(axis=1)
-        a, b = ow[:-1][same], ow[1:][same]
+        a, b = _two_owner_pairs((es[1:] == es[:-1]).all(axis=1), ow, np)
         graph = coo_matrix((np.ones(a.shape[0]), (a, b)), shape=(nf, nf))
         _, label = connected_components(graph, directed=False)
         size = np.bincount(label)
@@ -606,6 +605,26 @@ def marching_cubes_torch(volume, level: float = 0.0):
         return ops.marching_cubes(volume.to(torch.float64).contiguous(), float(level))
     v, f = marching_cubes(volume.detach().numpy(), level)
     return torch.from_numpy(v), torch.from_numpy(f)
+
+
+def _two_owner_pairs(same, ow, xp):
+    """(a, b): the two faces of every edge that belongs to EXACTLY two faces.  `same[i]` = sorted edge i + 1 equals sorted edge i, `ow` = the owning
+    face of every sorted edge; xp = numpy or torch.  An edge with three or more owners (non-manifold) pairs nothing: trimesh's face_adjacency,
+    which source/base/mesh.py:27 builds its components from, keeps the edges that occur twice (`require_count=2`)."""
+    n = ow.shape[0]
+    if n < 2:
+        return ow[:0], ow[:0]
+    if xp is np:
+        f = np.zeros(1, dtype=bool)
+        prev, nxt = np.concatenate([f, same]), np.concatenate([same, f])             # edge i equals edge i - 1 / edge i + 1
+        after = np.concatenate([nxt[1:], f])                                          # edge i + 1 equals edge i + 2
+    else:
+        f = xp.zeros(1, dtype=xp.bool, device=same.device)
+        prev, nxt = xp.cat([f, same]), xp.cat([same, f])
+        after = xp.cat([nxt[1:], f])
+    first = ~prev & nxt & ~after                                                      # first edge of a run of exactly two
+    idx = xp.nonzero(first)[0] if xp is np else xp.nonzero(first)[:, 0]
+    return ow[idx], ow[idx + 1]
 
 
 def _small_component_faces(a, b, nf, k):
@@ -723,8 +742,7 @@ def clean_mesh_torch(verts, faces, min_component_faces=6, digits=8, welded=False
         owner = torch.arange(nf, device=dev).repeat(3)
         skey, order = torch.sort(ekey, stable=True)
         ow = owner[order]
-        same = skey[1:] == skey[:-1]
-        a, b = ow[:-1][same], ow[1:][same]
+        a, b = _two_owner_pairs(skey[1:] == skey[:-1], ow, torch)
         faces = faces[~_small_component_faces(a, b, nf, int(min_component_faces))]
     used = torch.zeros(verts.shape[0], dtype=torch.bool, device=dev)           # compaction of the referenced vertices, order kept
     used[faces.reshape(-1)] = True

@@ -431,7 +431,8 @@ def test_table_rows_discs_and_tubes_have_the_right_euler_characteristic():
 @pytest.mark.parametrize('k', [1, 2, 6, 7, 13, 32])
 def test_small_component_kernel_equals_union_find_also_on_non_manifold_edges(k):
     """ops.mesh_small_components against the specification's union-find: strips and fans of known sizes, a random soup over few vertices (edges
-    shared by three and more faces: the kernel chains an edge's owners in arrival order) and a large closed surface, face order shuffled."""
+    shared by three and more faces: they join NOTHING, like in trimesh's face_adjacency; the "books" of k + 3 and k pages around one edge are
+    therefore single faces) and a large closed surface, face order shuffled."""
     from ppsurf_amd import ops
     v, f = _strips_and_fans()
     rng = np.random.default_rng(k)
@@ -485,3 +486,43 @@ def test_corner_weld_and_face_filter_kernels_equal_the_host_form():
     assert fd.shape == tuple(fh.shape) and vd.shape == tuple(vh.shape) and fd.shape[0] < ff.shape[0]
     assert np.array_equal(vd, vh.numpy()) and np.array_equal(fd, fh.numpy())      # same vertices in the same order, same faces in the same order
     M.check_clean_mesh(vv, ff, vd, fd, min_component_faces=None)
+
+
+def _flag_on_a_sheet():
+    """A 12 x 12 sheet (288 faces) with a 4-face flag standing on one of its interior edges: that edge has three owners."""
+    n = 13
+    vid = lambda i, j: i * n + j
+    faces = []
+    for i in range(n - 1):
+        for j in range(n - 1):
+            faces += [[vid(i, j), vid(i + 1, j), vid(i, j + 1)], [vid(i + 1, j), vid(i + 1, j + 1), vid(i, j + 1)]]
+    a, b = vid(5, 5), vid(6, 5)                      # an interior edge of the sheet (two owners there)
+    p = n * n
+    flag = [[a, b, p], [b, p + 1, p], [p, p + 1, p + 2], [p + 1, p + 3, p + 2]]      # 4 faces, attached by the edge (a, b) only
+    return np.array(faces + flag, dtype=np.int64), len(faces)
+
+
+def test_a_piece_attached_by_a_non_manifold_edge_is_a_component_of_its_own():
+    """the reference's components come from trimesh.face_adjacency = pairs of faces across edges that occur exactly TWICE
+    (source/base/mesh.py:27); an edge with three owners joins nothing.  The specification, the numpy clean-up and the torch twin drop the flag."""
+    faces, n_sheet = _flag_on_a_sheet()
+    lab = M.components_union_find(faces)
+    assert len(set(lab[:n_sheet])) == 1 and len(set(lab[n_sheet:])) == 1 and lab[0] != lab[-1]
+    # the two sheet faces of the shared edge stay joined to the sheet through their other edges
+    verts = np.random.default_rng(0).random((int(faces.max()) + 1, 3))
+    v1, f1 = mcubes.clean_mesh(verts, faces, min_component_faces=6)
+    assert f1.shape[0] == n_sheet
+    v2, f2 = mcubes.clean_mesh_torch(torch.from_numpy(verts), torch.from_numpy(faces), min_component_faces=6)
+    assert f2.shape[0] == n_sheet
+    assert np.array_equal(M.clean_mesh_spec(verts, faces, 6)[0], M.clean_mesh_spec(v1, f1, None)[0])
+
+
+@pytest.mark.gpu
+def test_small_component_kernel_drops_a_piece_attached_by_a_non_manifold_edge():
+    from ppsurf_amd import ops
+    faces, n_sheet = _flag_on_a_sheet()
+    perm = np.random.default_rng(1).permutation(faces.shape[0])
+    got = ops.mesh_small_components(torch.from_numpy(faces[perm]).to('cuda:0'), int(faces.max()) + 1, 6).cpu().numpy()
+    want = np.zeros(faces.shape[0], dtype=bool)
+    want[n_sheet:] = True
+    assert np.array_equal(got, want[perm])
