@@ -377,7 +377,14 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_blocked_kernel(const float
                         if (cnt[j] > KNN_CAP - 64) {
                             knn_flush_r<R>(list[j], cand + (cnt[j] - 64), 64, lane);      // the newest 64: one full sorting network; the rest waits
                             cnt[j] -= 64;
-                            tau[j] = fminf(tau[j], __uint_as_float((unsigned)(shfl_u64(list[j][kr < R ? kr : R - 1], kl) >> 32)));
+                            // the register that holds the k-th key, picked by compile-time comparisons: indexing `list[j]` with the run-time kr put
+                            // the whole [KNN_QW][R] array into scratch memory for R >= 3 (208 / 272 bytes per lane; every merge network of the
+                            // k = 200 search of config 5 then went through memory: 415 MB written per 25 000-query launch for 40 MB of results,
+                            // profiles/round6_config5_pmc.json at commit 1b7b9f8)
+                            u64 kth = list[j][R - 1];
+#pragma unroll
+                            for (int r = 0; r + 1 < R; ++r) kth = (r == kr) ? list[j][r] : kth;
+                            tau[j] = fminf(tau[j], __uint_as_float((unsigned)(shfl_u64(kth, kl) >> 32)));
                         }
                     }
                 }
