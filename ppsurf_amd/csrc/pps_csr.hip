@@ -69,21 +69,26 @@ __global__ void __launch_bounds__(TB) csr_tile_sum_kernel(const int* __restrict_
     if (threadIdx.x == 0) tile_sum[blockIdx.x] = s;
 }
 
-// offsets[r] for the rows of this tile (+ offsets[rows] by the last tile)
+// offsets[r] for the rows of this tile (+ offsets[rows] by the last tile).  Counts and offsets pass through LDS so that global memory sees unit-stride
+// accesses (thread t owns the 8 CONSECUTIVE rows 8 t .. 8 t + 7 of the tile for the scan; read or written directly that is a 32- / 64-byte stride
+// between lanes: 27 us per table in the first version of this kernel, profiles/round6_train_rocprof_summary.txt at commit 1b7b9f8)
 __global__ void __launch_bounds__(TB) csr_scan_kernel(const int* __restrict__ cnt, int64_t rows, const int64_t* __restrict__ tile_sum,
                                                       int64_t* __restrict__ offsets) {
     __shared__ int64_t sh[TB / 64];
     __shared__ int64_t part[TB];
+    __shared__ int cs[TILE];
+    __shared__ int64_t os[TILE];
+    const int64_t base = (int64_t)blockIdx.x * TILE;
+    for (int i = threadIdx.x; i < TILE; i += TB) cs[i] = (base + i < rows) ? cnt[base + i] : 0;
     int64_t before = 0;
     for (int64_t t = threadIdx.x; t < (int64_t)blockIdx.x; t += TB) before += tile_sum[t];
-    before = block_sum(before, sh);
-    // thread t owns rows base + 8 t .. base + 8 t + 7 (contiguous: two 16-byte loads)
-    const int64_t r0 = (int64_t)blockIdx.x * TILE + (int64_t)threadIdx.x * (TILE / TB);
-    int c[TILE / TB];
+    before = block_sum(before, sh);                         // (its barriers also publish cs)
+    constexpr int PER = TILE / TB;
+    int c[PER];
     int64_t mine = 0;
 #pragma unroll
-    for (int i = 0; i < TILE / TB; ++i) {
-        c[i] = (r0 + i < rows) ? cnt[r0 + i] : 0;
+    for (int i = 0; i < PER; ++i) {
+        c[i] = cs[threadIdx.x * PER + i];
         mine += c[i];
     }
     part[threadIdx.x] = mine;
@@ -96,11 +101,14 @@ __global__ void __launch_bounds__(TB) csr_scan_kernel(const int* __restrict__ cn
     }
     int64_t run = before + part[threadIdx.x] - mine;
 #pragma unroll
-    for (int i = 0; i < TILE / TB; ++i) {
-        if (r0 + i < rows) offsets[r0 + i] = run;
+    for (int i = 0; i < PER; ++i) {
+        os[threadIdx.x * PER + i] = run;
         run += c[i];
-        if (r0 + i == rows - 1) offsets[rows] = run;
     }
+    if (threadIdx.x == TB - 1 && blockIdx.x == gridDim.x - 1) offsets[rows] = run;      // rows past the end count 0: the last thread ends at the total
+    __syncthreads();
+    for (int i = threadIdx.x; i < TILE; i += TB)
+        if (base + i < rows) offsets[base + i] = os[i];
 }
 
 __global__ void __launch_bounds__(TB) csr_fill_kernel(const int64_t* __restrict__ ids, int64_t entries, int64_t per_item, int64_t rows_per_item,
