@@ -416,6 +416,15 @@ int pps_bn_train_fwd(const void* x, int64_t rows, int c, int dtype, const float*
 int pps_bn_train_bwd(const void* x, const void* dy, int64_t rows, int c, int dtype, const float* gamma, const float* beta, const float* save,
                      int relu, void* dx, float* dgamma, float* dbeta, void* ws, void* stream);
 
+/* relu(BN(x) + res) in train() mode: the tail of a residual block (source/base/nn.py:448-450, `self.activation(x + shortcut)` behind bn2) inside the
+ * BatchNorm's own apply pass (the separate add and ReLU were two more passes over [rows, c] forward and one backward).  res [rows, c] in the
+ * storage type of x; statistics, save, ws and the running statistics as pps_bn_train_fwd.  Backward: dx as pps_bn_train_bwd with the ReLU mask
+ * taken behind the sum; dres [rows, c] = the masked upstream gradient (the shortcut's gradient). */
+int pps_bn_add_relu_fwd(const void* x, const void* res, int64_t rows, int c, int dtype, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, float momentum, float eps, void* y, float* save, void* ws, void* stream);
+int pps_bn_add_relu_bwd(const void* x, const void* res, const void* dy, int64_t rows, int c, int dtype, const float* gamma, const float* beta,
+                        const float* save, void* dx, void* dres, float* dgamma, float* dbeta, void* ws, void* stream);
+
 /* out[c] = sum over the rows of x [rows, c]: the bias gradient of a row layer (replaces the `grad_output.sum(0)` autograd runs for the bias of
  * every Conv1d(…,1) / Linear of source/base/nn.py).  Shapes and dtype codes as pps_bn_train_*; ws: pps_bn_train_ws_bytes(rows, c) bytes.
  * Deterministic (fixed-order fp32 per thread, double across threads and blocks). */

@@ -111,6 +111,8 @@ SIGNATURES = {
     'pps_bn_train_ws_bytes': (_SZ, [_I64, _I]),
     'pps_bn_train_fwd': (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _c.c_float, _c.c_float, _I, _P, _P, _P, _P]),
     'pps_bn_train_bwd': (_I, [_P, _P, _I64, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    'pps_bn_add_relu_fwd': (_I, [_P, _P, _I64, _I, _I, _P, _P, _P, _P, _c.c_float, _c.c_float, _P, _P, _P, _P]),
+    'pps_bn_add_relu_bwd': (_I, [_P, _P, _P, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pps_col_sum': (_I, [_P, _I64, _I, _I, _P, _P, _P]),
     'pps_gemm_nt_16': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I, _I, _I, _I, _P]),
     'pps_gemm_tn_ws_bytes': (_SZ, [_I64, _I, _I]),

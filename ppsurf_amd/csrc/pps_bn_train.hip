@@ -69,7 +69,7 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(BNT) void bn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t rows, int C,
                                                        const float* __restrict__ save /* mean[C], rstd[C] (MODE 1) */,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
-                                                       double* __restrict__ part) {
+                                                       double* __restrict__ part, const T* __restrict__ res = nullptr) {
     extern __shared__ double red[];                 // [rpb][C][2]
     const Map m = map_of(C);
     const int64_t slab = (rows + gridDim.x - 1) / gridDim.x;
@@ -100,10 +100,12 @@ __global__ __launch_bounds__(BNT) void bn_reduce_kernel(const T* __restrict__ x,
                 for (int i = 0; i < 4; ++i) { const float d = xv.v[i] - mu[i]; s1[i] += d; s2[i] += d * d; }
             } else {
                 const F4 gv = load4<T>(dy + r * C + 4 * m.cg);
+                F4 rv = {{0.f, 0.f, 0.f, 0.f}};
+                if (res) rv = load4<T>(res + r * C + 4 * m.cg);           // residual variant: the ReLU sits behind BN(x) + res
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float xh = (xv.v[i] - mu[i]) * rs[i];
-                    const float g = (relu && !(xh * a[i] + b[i] > 0.f)) ? 0.f : gv.v[i];
+                    const float g = (relu && !(xh * a[i] + b[i] + rv.v[i] > 0.f)) ? 0.f : gv.v[i];
                     s1[i] += g; s2[i] += g * xh;
                 }
             }
@@ -176,7 +178,7 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(BNT) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, int64_t rows, int C,
                                                       const float* __restrict__ save, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, const float* __restrict__ gmeans, int relu,
-                                                      T* __restrict__ out) {
+                                                      T* __restrict__ out, const T* __restrict__ res = nullptr, T* __restrict__ dres = nullptr) {
     const Map m = map_of(C);
     float mu[4], sc[4], sh[4], rs[4], m1[4], m2[4];
 #pragma unroll
@@ -189,20 +191,25 @@ __global__ __launch_bounds__(BNT) void bn_apply_kernel(const T* __restrict__ x, 
     for (int64_t r = (int64_t)blockIdx.x * m.rpb + m.rl; r < rows; r += (int64_t)gridDim.x * m.rpb) {
         const F4 xv = load4<T>(x + r * C + 4 * m.cg);
         F4 o;
+        F4 rv = {{0.f, 0.f, 0.f, 0.f}};
+        if (res) rv = load4<T>(res + r * C + 4 * m.cg);                   // residual variant: act(BN(x) + res), one pass instead of three
         if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float y = (xv.v[i] - mu[i]) * rs[i] * sc[i] + sh[i];
+                const float y = (xv.v[i] - mu[i]) * rs[i] * sc[i] + sh[i] + rv.v[i];
                 o.v[i] = (relu && !(y > 0.f)) ? 0.f : y;
             }
         } else {
             const F4 gv = load4<T>(dy + r * C + 4 * m.cg);
+            F4 gm;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float xh = (xv.v[i] - mu[i]) * rs[i];
-                const float g = (relu && !(xh * sc[i] + sh[i] > 0.f)) ? 0.f : gv.v[i];
+                const float g = (relu && !(xh * sc[i] + sh[i] + rv.v[i] > 0.f)) ? 0.f : gv.v[i];
+                gm.v[i] = g;
                 o.v[i] = sc[i] * rs[i] * (g - m1[i] - xh * m2[i]);
             }
+            if (dres) store4<T>(dres + r * C + 4 * m.cg, gm);             // the residual's gradient: the masked upstream gradient
         }
         store4<T>(out + r * C + 4 * m.cg, o);
     }
@@ -269,7 +276,7 @@ inline char* al(char* p) { return (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255
 
 template <typename T>
 int fwd_t(const T* x, int64_t rows, int c, const float* gamma, const float* beta, float* rm, float* rv, float momentum, float eps, int relu,
-          T* y, float* save, void* ws, hipStream_t st) {
+          T* y, float* save, void* ws, hipStream_t st, const T* res = nullptr) {
     const int nb = reduce_blocks(rows, c);
     double* part = (double*)al((char*)ws);
     const size_t lds = (size_t)(BNT / (c >> 2)) * c * 2 * sizeof(double);
@@ -279,22 +286,22 @@ int fwd_t(const T* x, int64_t rows, int c, const float* gamma, const float* beta
                        rm, rv, save, (float*)nullptr, (float*)nullptr);
     const int grid = apply_blocks(rows, c);
     hipLaunchKernelGGL((bn_apply_kernel<T, 0>), dim3(grid), dim3(BNT), 0, st, x, (const T*)nullptr, rows, c, (const float*)save, gamma, beta,
-                       (const float*)nullptr, relu, y);
+                       (const float*)nullptr, relu, y, res, (T*)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
 template <typename T>
 int bwd_t(const T* x, const T* dy, int64_t rows, int c, const float* gamma, const float* beta, const float* save, int relu, T* dx,
-          float* dgamma, float* dbeta, void* ws, hipStream_t st) {
+          float* dgamma, float* dbeta, void* ws, hipStream_t st, const T* res = nullptr, T* dres = nullptr) {
     const int nb = reduce_blocks(rows, c);
     double* part = (double*)al((char*)ws);
     float* gmeans = (float*)al((char*)(part + (size_t)nb * 2 * c));
     const size_t lds = (size_t)(BNT / (c >> 2)) * c * 2 * sizeof(double);
-    hipLaunchKernelGGL((bn_reduce_kernel<T, 1>), dim3(nb), dim3(BNT), lds, st, x, dy, rows, c, save, gamma, beta, relu, part);
+    hipLaunchKernelGGL((bn_reduce_kernel<T, 1>), dim3(nb), dim3(BNT), lds, st, x, dy, rows, c, save, gamma, beta, relu, part, res);
     hipLaunchKernelGGL((bn_finalize_kernel<T, 1>), dim3((c + 3) / 4), dim3(BNT), 0, st, (const double*)part, nb, rows, c, x, 0.f, 0.f,
                        (float*)nullptr, (float*)nullptr, gmeans, dgamma, dbeta);
     const int grid = apply_blocks(rows, c);
-    hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(grid), dim3(BNT), 0, st, x, dy, rows, c, save, gamma, beta, (const float*)gmeans, relu, dx);
+    hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(grid), dim3(BNT), 0, st, x, dy, rows, c, save, gamma, beta, (const float*)gmeans, relu, dx, res, dres);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
@@ -339,6 +346,35 @@ int pps_bn_train_bwd(const void* x, const void* dy, int64_t rows, int c, int dty
         return bwd_t<half_t>((const half_t*)x, (const half_t*)dy, rows, c, gamma, beta, save, relu, (half_t*)dx, dgamma, dbeta, ws, (hipStream_t)stream);
     return bwd_t<uint16_t>((const uint16_t*)x, (const uint16_t*)dy, rows, c, gamma, beta, save, relu, (uint16_t*)dx, dgamma, dbeta, ws,
                            (hipStream_t)stream);
+}
+
+/* relu(BN(x) + res) in train() mode: the tail of a residual block (source/base/nn.py:448-450 `self.activation(x + shortcut)` behind bn2) as the
+ * BatchNorm's own apply pass -- res [rows, c] in the storage type of x.  Backward: dx as pps_bn_train_bwd with the ReLU mask taken behind the sum,
+ * dres [rows, c] = the masked upstream gradient (the shortcut's gradient). */
+int pps_bn_add_relu_fwd(const void* x, const void* res, int64_t rows, int c, int dtype, const float* gamma, const float* beta, float* running_mean,
+                        float* running_var, float momentum, float eps, void* y, float* save, void* ws, void* stream) {
+    if (rows == 0) return 0;
+    if (!ok_shape(rows, c) || (dtype < 0 || dtype > 2) || !x || !res || !gamma || !beta || !y || !save || !ws) return 1;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0) return fwd_t<float>((const float*)x, rows, c, gamma, beta, running_mean, running_var, momentum, eps, 1, (float*)y, save, ws, st, (const float*)res);
+    if (dtype == 2)
+        return fwd_t<half_t>((const half_t*)x, rows, c, gamma, beta, running_mean, running_var, momentum, eps, 1, (half_t*)y, save, ws, st, (const half_t*)res);
+    return fwd_t<uint16_t>((const uint16_t*)x, rows, c, gamma, beta, running_mean, running_var, momentum, eps, 1, (uint16_t*)y, save, ws, st, (const uint16_t*)res);
+}
+
+int pps_bn_add_relu_bwd(const void* x, const void* res, const void* dy, int64_t rows, int c, int dtype, const float* gamma, const float* beta,
+                        const float* save, void* dx, void* dres, float* dgamma, float* dbeta, void* ws, void* stream) {
+    if (rows == 0) return 0;
+    if (!ok_shape(rows, c) || (dtype < 0 || dtype > 2) || !x || !res || !dy || !gamma || !beta || !save || !dx || !dres || !dgamma || !dbeta || !ws) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0)
+        return bwd_t<float>((const float*)x, (const float*)dy, rows, c, gamma, beta, save, 1, (float*)dx, dgamma, dbeta, ws, st, (const float*)res, (float*)dres);
+    if (dtype == 2)
+        return bwd_t<half_t>((const half_t*)x, (const half_t*)dy, rows, c, gamma, beta, save, 1, (half_t*)dx, dgamma, dbeta, ws, st, (const half_t*)res,
+                             (half_t*)dres);
+    return bwd_t<uint16_t>((const uint16_t*)x, (const uint16_t*)dy, rows, c, gamma, beta, save, 1, (uint16_t*)dx, dgamma, dbeta, ws, st,
+                           (const uint16_t*)res, (uint16_t*)dres);
 }
 
 }  // extern "C"

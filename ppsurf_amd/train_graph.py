@@ -346,6 +346,17 @@ def batch_norm(bn, x, relu=False):
     return F.relu(y) if relu else y
 
 
+def batch_norm_add_relu(bn, x, res):
+    """relu(bn(x) + res) on [rows, C]: the tail of a residual block (source/base/nn.py:448-450).  In train() on the device the sum and the ReLU ride
+    in the BatchNorm's apply pass (train_ops.bn_add_relu: two passes over the block's output less forward, one less backward, three launches
+    less per block); otherwise the three separate ops."""
+    if (bn.training and x.is_cuda and res.shape == x.shape and res.dtype == x.dtype and train_ops.bn_supported(x.shape[0], x.shape[1])
+            and x.dtype in (torch.float32,) + train_ops.LOW and _os.environ.get('PPS_BN_ADD_RELU', '1') != '0'):
+        _count_batch(bn)
+        return train_ops.bn_add_relu(x, res, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+    return F.relu(batch_norm(bn, x) + res)
+
+
 _flat_cache = {}
 
 
@@ -653,13 +664,13 @@ def residual_block(blk, x, pts, sup, ids, geo=None):
     h = batch_norm(blk.bn0, dense(blk.cv0, x.reshape(b * n, cin)), relu=True).view(b, n, -1)
     h = fkaconv_layer(blk.cv1, h, pts, sup, ids, geo)
     h = batch_norm(blk.bn1, h.reshape(b * m, -1), relu=True)
-    h = batch_norm(blk.bn2, dense(blk.cv2, h))
+    h = dense(blk.cv2, h)
     sc = x.reshape(b * n, cin)
     if not isinstance(blk.shortcut, torch.nn.Identity):
         sc = batch_norm(blk.bn_shortcut, dense(blk.shortcut, sc))
     if n != m:
         sc = train_ops.neighbour_max(sc, _flat_ids(ids, n).view(b * m, -1))
-    return F.relu(h + sc).view(b, m, -1)
+    return batch_norm_add_relu(blk.bn2, h, sc).view(b, m, -1)                     # relu(bn2(h) + shortcut): one op (nn.py:447-450)
 
 
 def _upsample(x, ids_up, n_coarse):

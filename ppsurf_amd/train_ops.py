@@ -368,6 +368,52 @@ class _BnAct(torch.autograd.Function):
         return dx, dgamma.to(ctx.dtypes[0]), dbeta.to(ctx.dtypes[1]), None, None, None, None, None
 
 
+class _BnAddRelu(torch.autograd.Function):
+    """relu(BatchNorm(x) + res) in train(): the tail of a residual block inside the BatchNorm's apply pass (pps_bn_add_relu_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, momentum, eps):
+        _need_cuda(x, res, weight, bias)
+        if x.dtype not in (torch.float32,) + LOW:
+            x = x.float()
+        x = x.contiguous()
+        res = res.to(x.dtype).contiguous()
+        rows, c = x.shape
+        w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        y = torch.empty_like(x)
+        save = torch.empty((2, c), device=x.device, dtype=torch.float32)
+        nbytes = _lib.lib().pps_bn_train_ws_bytes(rows, c)
+        if nbytes == 0 and rows > 0:
+            raise ValueError('bn_add_relu: unsupported shape [{}, {}]'.format(rows, c))
+        ws = torch.empty((max(nbytes, 1),), device=x.device, dtype=torch.uint8)
+        _lib.check(_lib.lib().pps_bn_add_relu_fwd(x.data_ptr(), res.data_ptr(), rows, c, _code(x.dtype) if x.dtype in LOW else 0, w32.data_ptr(), b32.data_ptr(),
+                                                  running_mean.data_ptr() if running_mean is not None else None,
+                                                  running_var.data_ptr() if running_var is not None else None, float(momentum), float(eps),
+                                                  y.data_ptr(), save.data_ptr(), ws.data_ptr(), _stream()), 'pps_bn_add_relu_fwd')
+        ctx.save_for_backward(x, res, w32, b32, save)
+        ctx.dtypes = (weight.dtype, bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, res, w32, b32, save = ctx.saved_tensors
+        rows, c = x.shape
+        dy = dy.to(x.dtype).contiguous()
+        dx, dres = torch.empty_like(x), torch.empty_like(x)
+        dgamma = torch.empty((c,), device=x.device, dtype=torch.float32)
+        dbeta = torch.empty((c,), device=x.device, dtype=torch.float32)
+        ws = torch.empty((max(_lib.lib().pps_bn_train_ws_bytes(rows, c), 1),), device=x.device, dtype=torch.uint8)
+        _lib.check(_lib.lib().pps_bn_add_relu_bwd(x.data_ptr(), res.data_ptr(), dy.data_ptr(), rows, c, _code(x.dtype) if x.dtype in LOW else 0,
+                                                  w32.data_ptr(), b32.data_ptr(), save.data_ptr(), dx.data_ptr(), dres.data_ptr(), dgamma.data_ptr(),
+                                                  dbeta.data_ptr(), ws.data_ptr(), _stream()), 'pps_bn_add_relu_bwd')
+        return dx, dres, dgamma.to(ctx.dtypes[0]), dbeta.to(ctx.dtypes[1]), None, None, None, None
+
+
+def bn_add_relu(x, res, weight, bias, running_mean, running_var, momentum, eps):
+    """relu(BatchNorm1d(x) + res) over the rows of x [rows, c] in train() mode (batch statistics, running statistics updated in place)."""
+    return _BnAddRelu.apply(x, res, weight, bias, running_mean, running_var, momentum, eps)
+
+
 def col_sum(x):
     """x [rows, c] -> fp32 [c] column sums (the bias gradient of a row layer) by the HIP reduction; None if the shape is not one it takes
     (the caller then uses torch's sum).  No autograd: called from backward passes."""

@@ -172,6 +172,40 @@ def test_bn_act_fwd_bwd(rows, c, relu, dt):
         assert float((a - b_).abs().max()) <= rel * scale, '{}: err {:.3e} of {:.3e}'.format(name, float((a - b_).abs().max()), scale)
 
 
+@pytest.mark.parametrize('rows,c,dt', [(5000, 64, torch.float32), (777, 256, torch.float32), (100000, 64, torch.bfloat16), (25000, 128, torch.bfloat16),
+                                       (390, 1024, torch.bfloat16), (3, 512, torch.float32), (6250, 256, torch.float16)])
+def test_bn_add_relu_fwd_bwd(rows, c, dt):
+    """relu(BatchNorm1d(x) + res) as one op (the tail of a residual block, nn.py:447-450) against torch in float64: output, running statistics, dx,
+    dres, dgamma, dbeta -- at the encoder's level sizes of a fit batch."""
+    from ppsurf_amd import train_ops
+    rng = np.random.default_rng(rows + c)
+    x0 = torch.from_numpy((rng.standard_normal((rows, c)) * rng.uniform(0.5, 2, c) + rng.uniform(-3, 3, c)).astype(np.float32)).to(DEV).to(dt)
+    s0 = torch.from_numpy(rng.standard_normal((rows, c)).astype(np.float32)).to(DEV).to(dt)
+    w0 = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32)).to(DEV)
+    b0 = torch.from_numpy(rng.uniform(-0.5, 0.5, c).astype(np.float32)).to(DEV)
+    r = torch.from_numpy(rng.standard_normal((rows, c)).astype(np.float32)).to(DEV)
+
+    def twin(x, res, w, b, rm, rv, mom, eps):
+        return torch.relu(torch.nn.functional.batch_norm(x, rm, rv, w, b, True, mom, eps) + res)
+    out = []
+    for fn, cdt in ((train_ops.bn_add_relu, dt), (twin, torch.float64)):
+        x = x0.detach().clone().to(cdt).requires_grad_(True)
+        sc = s0.detach().clone().to(cdt).requires_grad_(True)
+        pdt = torch.float64 if cdt == torch.float64 else torch.float32
+        w, b = w0.detach().clone().to(pdt).requires_grad_(True), b0.detach().clone().to(pdt).requires_grad_(True)
+        rm = torch.zeros(c, device=DEV, dtype=w.dtype); rv = torch.ones(c, device=DEV, dtype=w.dtype)
+        y = fn(x, sc, w, b, rm, rv, 0.1, 1e-5)
+        (y.double() * r.double()).sum().backward()
+        out.append([t.detach().double() for t in (y, rm, rv, x.grad, sc.grad, w.grad, b.grad)])
+    got, want = out
+    assert got[0].dtype == torch.float64 and (got[0] >= 0).all()
+    tol = {torch.bfloat16: 2e-2, torch.float16: 3e-3}.get(dt, 2e-4)
+    for name, a, b_ in zip(('y', 'running_mean', 'running_var', 'dx', 'dres', 'dgamma', 'dbeta'), got, want):
+        scale = float(b_.abs().max()) + 1e-6
+        rel = tol * (8 if name in ('dgamma', 'dbeta') and dt != torch.float32 else 1)
+        assert float((a - b_).abs().max()) <= rel * scale, '{}: err {:.3e} of {:.3e}'.format(name, float((a - b_).abs().max()), scale)
+
+
 @pytest.mark.parametrize('q,k,c,dt,heads', [(37, 64, 256, torch.float32, 64), (20, 64, 256, torch.bfloat16, 64), (9, 20, 256, torch.float32, 64),
                                             (21, 64, 256, torch.float16, 64), (13, 50, 256, torch.float16, 1),
                                             (5, 5, 64, torch.float32, 64), (3, 1, 32, torch.float32, 64), (33, 50, 256, torch.float32, 1),

@@ -21,12 +21,21 @@ def main():
     for _ in range(8):
         step()
     torch.cuda.synchronize()
-    for rep in range(3):
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            loss = step()
-        torch.cuda.synchronize()
-        print('{} {}: {:.2f} ms/step  loss {:.4f}'.format(a.precision, 'eager' if a.eager else 'graph', (time.perf_counter() - t0) / a.steps * 1e3, float(loss)))
+    from ppsurf_amd.fit import HostGcPacer
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    print('gpu state before:', bench.gpu_state())
+    # the collector paced like in ppsurf_amd.fit / bench.py's fit leg: without it a full collection (60-100 ms with everything a fit keeps alive)
+    # falls into every second or third block of 40-60 steps and reads as "the step got 1-2 ms slower after a while" (round 6 fell for it once)
+    with HostGcPacer() as pacer:
+        for rep in range(3):
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                loss = step()
+                pacer.tick()
+            torch.cuda.synchronize()
+            print('{} {}: {:.2f} ms/step  loss {:.4f}'.format(a.precision, 'eager' if a.eager else 'graph', (time.perf_counter() - t0) / a.steps * 1e3, float(loss)))
+    print('gpu state after:', bench.gpu_state())
     step.close()
 
 
