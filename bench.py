@@ -381,7 +381,8 @@ def main():
     ap.add_argument('--shapes', type=int, default=2, help='timed whole reconstructions per rank of the shapes/hour leg')
     ap.add_argument('--single-rank-collectives', action='store_true',
                     help='--gpus 1 only: initialise a ONE-rank process group and run the N > 1 code path (strong + fit legs with every collective issued)')
-    ap.add_argument('--only', choices=['config2', 'config5'], default=None, help='run ONE extra leg and print its object (profiling: tools/profile_config5.sh)')
+    ap.add_argument('--only', choices=['config2', 'config5', 'fit'], default=None, help='run ONE extra leg and print its object (profiling: tools/profile_config5.sh; the default line runs `fit` this way)')
+    ap.add_argument('--fit-in-process', action='store_true', help='N = 1: the fit leg at the end of this process instead of in a process of its own')
     ap.add_argument('--legs', default='replicas,strong,fit', help='N > 1: which measurements go on the line (comma list of replicas, strong, fit)')
     args = ap.parse_args()
     if args.steps is None:
@@ -418,7 +419,10 @@ def main():
 
     red_dev = dev if args.backend == 'nccl' else 'cpu'
     if args.only is not None:
-        print(json.dumps({'config2': config2_leg, 'config5': config5_leg}[args.only](dev, args.dtype)), flush=True)
+        if args.only == 'fit':
+            print(json.dumps(fit_leg(dev)), flush=True)
+        else:
+            print(json.dumps({'config2': config2_leg, 'config5': config5_leg}[args.only](dev, args.dtype)), flush=True)
         return
     if args.scaling == 'strong':
         st = strong_leg(args, rank, world, dev, dist, red_dev, args.steps, args.warmup)
@@ -557,38 +561,9 @@ def main():
         out['config5'] = config5_leg(dev, args.dtype)
         torch.cuda.empty_cache()
     if not multi and not args.quick:
-        fit = workloads.FitStep(batch=10, precision='bf16-mixed', device=dev, graph=True)      # as `pps.py fit` runs it: replayed HIP graph, loader thread
-        for _ in range(6):
-            fit()
-        torch.cuda.synchronize()
-        from ppsurf_amd.fit import HostGcPacer
-        state0 = gpu_state()
-        n_fit = 120
-        with HostGcPacer() as pacer:                      # as the epoch loop of ppsurf_amd.fit runs its steps
-            t0 = time.perf_counter()
-            for _ in range(n_fit):
-                loss = fit()
-                pacer.tick()
-            torch.cuda.synchronize()
-            out['fit_ms_per_step'] = (time.perf_counter() - t0) / n_fit * 1e3
-        out['fit'] = {'config': 'ppsurf_50nn fit step: B=10 shapes x 10000 points, 2000 queries/shape, P=50, bf16-mixed, AdamW; id tables + '
-                                'patches built on the device by the loader thread on a second stream, step replayed as a HIP graph (the defaults of pps.py fit)',
-                      'steps_timed': n_fit, 'loss': float(loss),
-                      'shapes_per_s': 10.0 / (out['fit_ms_per_step'] * 1e-3)}
-        out['fit']['gpu_state'] = {'before': state0, 'after': gpu_state(), 'note': 'rocm-smi before / right after the timed steps'}
-        out['fit'].update(fit_roofline(out['fit_ms_per_step']))
-        # where a slow box loses its time: a second, instrumented pass of 60 steps -- HIP events on the step's stream and on the
-        # loader's, host time blocked on the loader thread.  Not part of fit_ms_per_step (the events cost a few microseconds per step).
-        fit.start_trace()
-        with HostGcPacer() as pacer:
-            for _ in range(60):
-                fit()
-                pacer.tick()
-        tr = fit.read_trace()
-        out['fit'].update({'queue_busy_ms': tr['queue_busy_ms'], 'loader_wait_ms': tr['loader_wait_ms'], 'batch_wait_ms': tr['batch_wait_ms'],
-                           'loader_host_ms': tr['loader_host_ms'], 'traced_call_ms': tr['call_ms'], 'trace_note': tr['note'], 'host_cores': os.cpu_count()})
-        fit.close()
-        del fit
+        out.update(fit_leg(dev) if args.fit_in_process else fit_leg_fresh_process(args))
+        if args.fit_in_process:
+            out['fit']['process'] = 'at the end of the bench process (--fit-in-process)'
         if not args.no_cpu_baseline:
             qry = torch.cat(workloads.band_chunks(shapes[0]['cloud'], RES, Q_CHUNK, dev)[0][:2]).cpu().numpy()
             out['cpu_baseline'] = cpu_baseline(sd, shapes[0]['cloud'], qry, shapes[0]['lat'])
@@ -735,6 +710,60 @@ def config5_leg(dev, dtype, steps=20, warmup=3):
                        'profiled run, reported only for matching kernel sources'}}
     del pipe, plan, table
     return out
+
+
+def fit_leg(dev):
+    """BASELINE config 3 on one GPU as `pps.py fit` runs it -> {'fit_ms_per_step': ..., 'fit': {...}}."""
+    import bench_workloads as workloads
+    res = {}
+    fit = workloads.FitStep(batch=10, precision='bf16-mixed', device=dev, graph=True)      # as `pps.py fit` runs it: replayed HIP graph, loader thread
+    for _ in range(6):
+        fit()
+    torch.cuda.synchronize()
+    from ppsurf_amd.fit import HostGcPacer
+    state0 = gpu_state()
+    n_fit = 120
+    with HostGcPacer() as pacer:                      # as the epoch loop of ppsurf_amd.fit runs its steps
+        t0 = time.perf_counter()
+        for _ in range(n_fit):
+            loss = fit()
+            pacer.tick()
+        torch.cuda.synchronize()
+        res['fit_ms_per_step'] = (time.perf_counter() - t0) / n_fit * 1e3
+    res['fit'] = {'config': 'ppsurf_50nn fit step: B=10 shapes x 10000 points, 2000 queries/shape, P=50, bf16-mixed, AdamW; id tables + '
+                            'patches built on the device by the loader thread on a second stream, step replayed as a HIP graph (the defaults of pps.py fit)',
+                  'steps_timed': n_fit, 'loss': float(loss),
+                  'shapes_per_s': 10.0 / (res['fit_ms_per_step'] * 1e-3)}
+    res['fit']['gpu_state'] = {'before': state0, 'after': gpu_state(), 'note': 'rocm-smi before / right after the timed steps'}
+    res['fit'].update(fit_roofline(res['fit_ms_per_step']))
+    # where a slow box loses its time (VERDICT r5 item 2): a second, instrumented pass of 60 steps -- HIP events on the step's stream and on the
+    # loader's, host time blocked on the loader thread.  Not part of fit_ms_per_step (the events cost a few microseconds per step).
+    fit.start_trace()
+    with HostGcPacer() as pacer:
+        for _ in range(60):
+            fit()
+            pacer.tick()
+    tr = fit.read_trace()
+    res['fit'].update({'queue_busy_ms': tr['queue_busy_ms'], 'loader_wait_ms': tr['loader_wait_ms'], 'batch_wait_ms': tr['batch_wait_ms'],
+                       'loader_host_ms': tr['loader_host_ms'], 'traced_call_ms': tr['call_ms'], 'trace_note': tr['note'], 'host_cores': os.cpu_count()})
+    fit.close()
+    del fit
+    return res
+
+
+def fit_leg_fresh_process(args):
+    """The fit leg in a process of its own (`python bench.py --only fit`): `pps.py fit` IS a process of its own, and the step's time depends on what
+    the process did before -- the same box, the same clocks (fit.gpu_state): 19.7 ms after a 25-chunk inference leg, 21.5 ms after the default
+    200-chunk one (five shapes' tables, two decoder plans, a 250k-point config-5 cloud allocated and freed before the fit's tensors are placed),
+    19.9 ms in a fresh process (profiles/NOTES_r6.md section 2).  --fit-in-process measures it at the end of this process like rounds 1-5 did."""
+    cmd = [sys.executable, os.path.abspath(__file__), '--only', 'fit']
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1800)
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    if p.returncode != 0 or not lines:
+        raise RuntimeError('the fit leg failed in its own process (exit {}): {}'.format(p.returncode, p.stderr[-2000:]))
+    res = json.loads(lines[-1])
+    res['fit']['process'] = 'a process of its own (python bench.py --only fit), like pps.py fit; --fit-in-process runs it at the end of the bench process'
+    return res
 
 
 def strong_leg(args, rank, world, dev, dist, red_dev, steps, warm):

@@ -120,3 +120,17 @@ def test_extra_config_legs_report_what_baseline_md_asks_for(leg):
         g = d['gather_kernels']
         assert g['knn_blocked_k200']['ms'] > 0 and g['patch_normalize_p200']['algorithmic_GB_s'] > 10
         assert d['band_queries_of_the_shape'] > 5_000_000
+
+
+@pytest.mark.gpu
+def test_fit_leg_runs_in_a_process_of_its_own_and_says_where_the_time_goes():
+    """`python bench.py --only fit` = what the default line spawns for its fit leg (pps.py fit is a process of its own; at the end of the bench process
+    the same step measured 19.7 .. 21.5 ms on one box depending on what ran before): step time, per-queue busy time, loader waits, GPU state."""
+    p = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--only', 'fit'], capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+    f = d['fit']
+    assert 5 < d['fit_ms_per_step'] < 60 and f['steps_timed'] == 120 and np.isfinite(f['loss'])
+    assert f['queue_busy_ms']['step']['mean'] > 0.8 * d['fit_ms_per_step'] and f['queue_busy_ms']['loader']['mean'] > 0
+    assert f['loader_wait_ms']['mean'] < 2.0 and 'before' in f['gpu_state']
+    assert f.get('roofline') is not None or 'roofline_note' in f
