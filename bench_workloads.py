@@ -366,12 +366,29 @@ class FitStepDDP(FitStep):
 
     def _step(self, batch):
         from ppsurf_amd import sharding, train_graph
-        sharding.broadcast_buffers(self.model)        # DDP's broadcast_buffers=True: rank 0's BatchNorm statistics / norm_radius before the step
-        self.core.run(batch, self.i)
-        self.buckets.finish()                         # waits for the bucket all-reduces, averages, mask collective
-        self.scaler.step(self.opt)
-        self.scaler.update()
+        import os
+        if os.environ.get('PPS_BENCH_DDP_TRACE') != '1':
+            sharding.broadcast_buffers(self.model)    # DDP's broadcast_buffers=True: rank 0's BatchNorm statistics / norm_radius before the step
+            self.core.run(batch, self.i)
+            self.buckets.finish()                     # waits for the bucket all-reduces, averages, mask collective
+            self.scaler.step(self.opt)
+            self.scaler.update()
+            train_graph.release_step_caches()
+            return
+        # diagnostic: host time of every phase with a device synchronisation behind it (PPS_BENCH_DDP_TRACE=1; not a timing mode)
+        t = [time.perf_counter()]
+
+        def mark():
+            torch.cuda.synchronize()
+            t.append(time.perf_counter())
+        sharding.broadcast_buffers(self.model); mark()
+        self.core.run(batch, self.i); mark()
+        self.buckets.finish(); mark()
+        self.scaler.step(self.opt); self.scaler.update(); mark()
         train_graph.release_step_caches()
+        if sharding.world()[0] == 0:
+            print('ddp step {}: broadcast_buffers {:.1f} ms, staged forward/backward + reduce issue {:.1f} ms, finish {:.1f} ms, optimizer {:.1f} ms'.format(
+                self.i, *[(b - a) * 1e3 for a, b in zip(t[:-1], t[1:])]), flush=True)
 
     def _loss(self):
         return self.metrics.values['loss/train/00_all']

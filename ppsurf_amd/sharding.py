@@ -188,10 +188,11 @@ def broadcast_buffers(module, src: int = 0):
         return
     flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
     dist.broadcast(flat, src=src)
-    off = 0
+    views, off = [], 0
     for b in bufs:
-        b.data.copy_(flat[off:off + b.numel()].view_as(b))
+        views.append(flat[off:off + b.numel()].view_as(b))
         off += b.numel()
+    torch._foreach_copy_([b.data for b in bufs], views)        # one multi-tensor launch instead of one copy per buffer (~150 per step)
 
 
 class GradBuckets:
