@@ -50,6 +50,16 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// max(a, b) as ONE v_max_f32.  fmaxf of two values the compiler cannot prove canonical (loaded, or out of inline assembly) is three instructions
+// in IEEE mode -- a quieting v_max x, x per operand in front of the maximum -- and __builtin_amdgcn_fmed3f(a, b, inf) is folded back into the same
+// maxnum: 912 of the 1360 v_max_f32 of pointnet_stn_rows_kernel<true> were such quieting moves (its running maximum over the patch rows).
+// NaNs: v_max_f32 returns the other operand for a quiet NaN like fmaxf does.
+__device__ __forceinline__ float max_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // The same reductions for FOUR values at once with the lane permutation folded INTO the arithmetic instruction (v_max_f32_dpp / v_add_f32_dpp: the
 // first source is read through the DPP permutation).  Written with dpp_mov the compiler keeps a separate v_mov_b32_dpp per step -- it pairs the
 // adds of two values into v_pk_add_f32, which has no DPP form, and puts a canonicalising v_max in front of every fmaxf -- 2.5-3 instructions

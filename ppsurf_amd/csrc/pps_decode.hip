@@ -77,9 +77,9 @@ __device__ __forceinline__ void lds_fill(float* dst, const float* __restrict__ s
 
 // reductions over aligned groups of LO in {1,2,4,8} adjacent rows (lanes n): every lane of a group gets the result
 __device__ __forceinline__ float group_max(float v, int lo) {
-    if (lo >= 2) v = fmaxf(v, dpp_mov<0xB1>(v));
-    if (lo >= 4) v = fmaxf(v, dpp_mov<0x4E>(v));
-    if (lo >= 8) v = fmaxf(v, dpp_mov<0x141>(v));
+    if (lo >= 2) v = max_raw(v, dpp_mov<0xB1>(v));         // (max_raw: one v_max_f32, no quieting moves in front; pps_common.h)
+    if (lo >= 4) v = max_raw(v, dpp_mov<0x4E>(v));
+    if (lo >= 8) v = max_raw(v, dpp_mov<0x141>(v));
     return v;
 }
 __device__ __forceinline__ float group_sum(float v, int lo) {
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_stn_rows_kernel(const float* 
                     rmax[bb] = pk.packed ? ((const f32x4*)(mypark + qi * PN_ROWF))[4 * bb + g] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                 auto zmax = [&](int, int bb, const f32x4& o0, const f32x4& o1) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { rmax[bb][r] = fmaxf(rmax[bb][r], o0[r]); rmax[bb + 1][r] = fmaxf(rmax[bb + 1][r], o1[r]); }
+                    for (int r = 0; r < 4; ++r) { rmax[bb][r] = max_raw(rmax[bb][r], o0[r]); rmax[bb + 1][r] = max_raw(rmax[bb + 1][r], o1[r]); }
                 };
                 auto row_coord = [&](int rb) {
                     const int row = rb * 16 + n;
@@ -811,10 +811,9 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_stn_rows_kernel(const float* 
                 }
 #pragma unroll
                 for (int bb = 0; bb < 16; ++bb) {
-                    f32x4 p;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) p[r] = row16_max(rmax[bb][r]);
-                    if (n == 0 && qv) ((f32x4*)(gout + q * 256))[4 * bb + g] = p;
+                    float p0 = rmax[bb][0], p1 = rmax[bb][1], p2 = rmax[bb][2], p3 = rmax[bb][3];
+                    row16_max4(p0, p1, p2, p3);                   // (the lane permutation folded into v_max_f32_dpp, pps_common.h)
+                    if (n == 0 && qv) ((f32x4*)(gout + q * 256))[4 * bb + g] = f32x4{p0, p1, p2, p3};
                 }
             }
             continue;
@@ -850,13 +849,13 @@ __global__ __launch_bounds__(PNT, 2) void pointnet_stn_rows_kernel(const float* 
 #pragma unroll
                 for (int bb = 0; bb < 16; ++bb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) rmax[bb][r] = fmaxf(rmax[bb][r], z[bb][r]);
+                    for (int r = 0; r < 4; ++r) rmax[bb][r] = max_raw(rmax[bb][r], z[bb][r]);
             }
 #pragma unroll
             for (int bb = 0; bb < 16; ++bb) {
-                f32x4 p;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) p[r] = row16_max(rmax[bb][r]);
+                float p0 = rmax[bb][0], p1 = rmax[bb][1], p2 = rmax[bb][2], p3 = rmax[bb][3];
+                row16_max4(p0, p1, p2, p3);
+                const f32x4 p = {p0, p1, p2, p3};
                 if (n == 0 && qv) ((f32x4*)(gout + q * 256))[4 * bb + g] = p;
             }
         }
