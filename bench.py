@@ -752,10 +752,11 @@ def fit_leg(dev):
 
 
 def fit_leg_fresh_process(args):
-    """The fit leg in a process of its own (`python bench.py --only fit`): `pps.py fit` IS a process of its own, and the step's time depends on what
-    the process did before -- the same box, the same clocks (fit.gpu_state): 19.7 ms after a 25-chunk inference leg, 21.5 ms after the default
-    200-chunk one (five shapes' tables, two decoder plans, a 250k-point config-5 cloud allocated and freed before the fit's tensors are placed),
-    19.9 ms in a fresh process (profiles/NOTES_r6.md section 2).  --fit-in-process measures it at the end of this process like rounds 1-5 did."""
+    """The fit leg in a process of its own (`python bench.py --only fit`): `pps.py fit` IS a process of its own, and the step's time depends on which
+    stream of torch's pool the loader thread gets -- the same box, the same clocks (fit.gpu_state): 19.8 ms in a fresh process (the loader's stream
+    is the first one made), 21.6 ms when the legs in front have made 10, 14 or 18 streams before it (a period of four: in that mapping the
+    loader's kernels take an equal share of the chip instead of running in the step's shadow; profiles/NOTES_r6.md section 2).  --fit-in-process
+    measures it at the end of this process like rounds 1-5 did."""
     cmd = [sys.executable, os.path.abspath(__file__), '--only', 'fit']
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=1800)
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]

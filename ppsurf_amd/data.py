@@ -229,6 +229,26 @@ def _record_stream(obj, stream):
             _record_stream(v, stream)
 
 
+_LOADER_STREAMS = {}
+
+
+def _loader_stream(device):
+    """ONE side stream per device and process for the batch assembly, made at first use and kept.  How much the loader's kernels take from the
+    optimisation step depends on WHICH stream of torch's pool it got: measured on the config-3 step (profiles/NOTES_r6.md section 2,
+    tools/dbg/fit_after_legs.py), a loader stream that is the 11th, 15th or 19th stream made in the process runs its kernels at an equal share of
+    the chip (3.7 ms elapsed per batch) and the step takes 21.6 ms, any other of the first twenty leaves them in the step's shadow (5.9 ms elapsed)
+    and the step takes 19.8 ms -- a period of four in the stream index (the runtime's stream -> hardware queue map), same clocks, same box.  A
+    DevicePrefetch used to take a NEW pool stream per epoch (DeviceBatchLoader.__iter__), so a long fit walked through the pool and every fourth
+    epoch landed on the slow mapping; now the first choice -- in a `pps.py fit` process the first stream made, the fast regime -- holds for the
+    whole run."""
+    key = (device.type, device.index)
+    st = _LOADER_STREAMS.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device, priority=0)
+        _LOADER_STREAMS[key] = st
+    return st
+
+
 class DevicePrefetch:
     """Builds the device side of the NEXT batch (patch search, support sampling, the 13 + 1 id tables: ~4 ms of kernels of which the sampling
     runs on 10 workgroups) on a second HIP stream while the optimisation step of the current batch runs on the main stream -- what the
@@ -243,7 +263,7 @@ class DevicePrefetch:
         # the loader's kernels are ~6 ms of GPU time per fit step, several of them chip-wide (the exhaustive kNN): they must not take workgroup slots
         # from the step they hide behind.  This device offers two stream priorities (torch.cuda.Stream.priority_range() == (0, -1)): the loader
         # gets the lower one -- which is the default level -- and the optimisation step runs on a high-priority stream (fit.step_stream)
-        self.side = torch.cuda.Stream(self.device, priority=0)
+        self.side = _loader_stream(self.device)
         self.pending = None                      # (batch, event)
 
     def launch(self, make, after_main=True):
