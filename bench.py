@@ -561,9 +561,13 @@ def main():
         out['config5'] = config5_leg(dev, args.dtype)
         torch.cuda.empty_cache()
     if not multi and not args.quick:
-        out.update(fit_leg(dev) if args.fit_in_process else fit_leg_fresh_process(args))
-        if args.fit_in_process:
-            out['fit']['process'] = 'at the end of the bench process (--fit-in-process)'
+        try:
+            out.update(fit_leg(dev) if args.fit_in_process else fit_leg_fresh_process(args))
+            if args.fit_in_process:
+                out['fit']['process'] = 'at the end of the bench process (--fit-in-process)'
+        except Exception as exc:                            # noqa: BLE001 -- the headline line must not be lost to a failed extra leg
+            out['fit_ms_per_step'] = None
+            out['fit'] = {'error': '{}: {}'.format(type(exc).__name__, str(exc)[-1500:])}
         if not args.no_cpu_baseline:
             qry = torch.cat(workloads.band_chunks(shapes[0]['cloud'], RES, Q_CHUNK, dev)[0][:2]).cpu().numpy()
             out['cpu_baseline'] = cpu_baseline(sd, shapes[0]['cloud'], qry, shapes[0]['lat'])
