@@ -543,16 +543,26 @@ def main():
         torch.cuda.empty_cache()
     if multi and not args.quick:
         # ---- the two measurements that need every rank at once -------------------------------------------------------------------
+        # (an exception every rank raises alike -- a bug, an unsupported configuration -- is reported in the line; the replica figure is not lost)
         if 'strong' in legs:
-            st = strong_leg(args, rank, world, dev, dist, red_dev, steps=2, warm=1)
-            if rank == 0:
-                out['strong'] = strong_block(world, st)
+            try:
+                st = strong_leg(args, rank, world, dev, dist, red_dev, steps=2, warm=1)
+                if rank == 0:
+                    out['strong'] = strong_block(world, st)
+            except Exception as exc:                        # noqa: BLE001
+                if rank == 0:
+                    out['strong'] = {'error': '{}: {}'.format(type(exc).__name__, str(exc)[-1500:])}
             torch.cuda.empty_cache()
         if 'fit' in legs:
-            fb = ddp_fit_leg(rank, world, dev, dist, red_dev)
-            if rank == 0:
-                out['fit'] = fb
-                out['fit_ms_per_step'] = fb['ms_per_step']
+            try:
+                fb = ddp_fit_leg(rank, world, dev, dist, red_dev)
+                if rank == 0:
+                    out['fit'] = fb
+                    out['fit_ms_per_step'] = fb['ms_per_step']
+            except Exception as exc:                        # noqa: BLE001
+                if rank == 0:
+                    out['fit'] = {'error': '{}: {}'.format(type(exc).__name__, str(exc)[-1500:])}
+                    out['fit_ms_per_step'] = None
             torch.cuda.empty_cache()
     if not multi and not args.quick:
         # ---- BASELINE.md section 3's other per-config report lines ---------------------------------------------------------
