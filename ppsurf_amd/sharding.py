@@ -177,22 +177,41 @@ def allreduce_latents(latent_sum: torch.Tensor, counts: torch.Tensor):
     return latent_sum, counts
 
 
+_BUFFER_PLANS = {}
+
+
 def broadcast_buffers(module, src: int = 0):
     """torch DDP's `broadcast_buffers=True` (the Lightning default): at the start of every step the floating-point buffers
     (BatchNorm running statistics, FKAConv norm_radius -- the latter is read by the train-mode forward) are overwritten with
-    rank `src`'s values, coalesced into ONE broadcast."""
+    rank `src`'s values, coalesced into ONE broadcast.
+    Three launches per step: a persistent flat fp32 buffer with one view per module buffer is kept per module (rebuilt if a buffer moved); pack
+    (one multi-tensor copy), broadcast, unpack (one multi-tensor copy).  Until round 6 every step built the flat tensor anew -- ~150 reshape / cast
+    calls and a 150-input cat -- and copied back buffer by buffer: 3.3-5.0 ms of host time per multi-rank step.  (The host runs ahead of the
+    GPU, so the step time did not move: 24.4 ms per staged step at B = 10 on one rank before and after, against 19.8-20.1 for the single-graph
+    step -- the staged step's other 4 ms are not in this function; profiles/NOTES_r6.md section 2.)"""
     import torch.distributed as dist
-    _, ws = world()
-    bufs = [b for b in module.buffers() if b.is_floating_point()]
-    if not multi() or not bufs:
+    if not multi():
         return
-    flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+    bufs = [b for b in module.buffers() if b.is_floating_point()]
+    if not bufs:
+        return
+    key = tuple(b.data_ptr() for b in bufs)
+    plan = _BUFFER_PLANS.get(id(module))
+    if plan is None or plan[0] != key:
+        flat = torch.empty(sum(b.numel() for b in bufs), dtype=torch.float32, device=bufs[0].device)
+        views, off = [], 0
+        for b in bufs:
+            views.append(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+        plan = (key, flat, views)
+        if len(_BUFFER_PLANS) > 8:
+            _BUFFER_PLANS.clear()
+        _BUFFER_PLANS[id(module)] = plan
+    _, flat, views = plan
+    data = [b.data for b in bufs]
+    torch._foreach_copy_(views, data)
     dist.broadcast(flat, src=src)
-    views, off = [], 0
-    for b in bufs:
-        views.append(flat[off:off + b.numel()].view_as(b))
-        off += b.numel()
-    torch._foreach_copy_([b.data for b in bufs], views)        # one multi-tensor launch instead of one copy per buffer (~150 per step)
+    torch._foreach_copy_(data, views)
 
 
 class GradBuckets:
