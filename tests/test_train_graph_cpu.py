@@ -334,3 +334,37 @@ def test_the_collector_is_off_during_a_recording_and_back_afterwards():
         assert not gc.isenabled()
     finally:
         gc.enable()
+
+
+def test_affine_rows_and_sum_rows_on_the_host_are_plain_autograd():
+    """train_ops.affine_rows / sum_rows (round 6: the step's row reductions go through the HIP reduction on the device) keep torch semantics on host
+    tensors: same value, same gradients as x * scale + shift."""
+    from ppsurf_amd import train_ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(37, 12, generator=g, dtype=torch.float64, requires_grad=True)
+    sc = torch.randn(12, generator=g, dtype=torch.float64, requires_grad=True)
+    sh = torch.randn(12, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(37, 12, generator=g, dtype=torch.float64)
+    y = train_ops.affine_rows(x, sc, sh)
+    gx, gs, gh = torch.autograd.grad((y * w).sum(), (x, sc, sh))
+    x2, sc2, sh2 = (t.detach().clone().requires_grad_(True) for t in (x, sc, sh))
+    rx, rs, rh = torch.autograd.grad(((x2 * sc2 + sh2) * w).sum(), (x2, sc2, sh2))
+    assert torch.equal(y, x * sc + sh) and torch.allclose(gx, rx) and torch.allclose(gs, rs, atol=1e-12) and torch.allclose(gh, rh, atol=1e-12)
+    assert torch.allclose(train_ops.sum_rows(w.float()), w.float().sum(0)) and train_ops.sum_rows(w.float()).dtype == torch.float32
+
+
+def test_batch_norm_add_relu_off_the_device():
+    """train_graph.batch_norm_add_relu (the residual blocks' tail, nn.py:447-450) on host tensors: eval() mode = relu(bn(x) + res) by torch ops on
+    the running statistics; train() mode is refused like every train op (the product has no CPU path)."""
+    import pytest
+    from ppsurf_amd import train_graph, _lib
+    torch.manual_seed(0)
+    bn = torch.nn.BatchNorm1d(8)
+    bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+    x, res = torch.randn(50, 8), torch.randn(50, 8)
+    ref_bn = torch.nn.BatchNorm1d(8)
+    ref_bn.load_state_dict(bn.state_dict())
+    y = train_graph.batch_norm_add_relu(bn.eval(), x, res)
+    assert torch.allclose(y, torch.relu(ref_bn.eval()(x) + res)) and int(bn.num_batches_tracked) == 0
+    with pytest.raises(_lib.PpsError, match='no CPU path'):
+        train_graph.batch_norm_add_relu(bn.train(), x, res)
