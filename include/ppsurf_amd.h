@@ -429,6 +429,9 @@ int pps_bn_add_relu_bwd(const void* x, const void* res, const void* dy, int64_t 
  * every Conv1d(…,1) / Linear of source/base/nn.py).  Shapes and dtype codes as pps_bn_train_*; ws: pps_bn_train_ws_bytes(rows, c) bytes.
  * Deterministic (fixed-order fp32 per thread, double across threads and blocks). */
 int pps_col_sum(const void* x, int64_t rows, int c, int dtype, float* out, void* ws, void* stream);
+/* The same over c columns of a wider tensor: row r starts at x + r * ld elements (ld >= c, ld % 4 == 0, x aligned to 4 elements) -- the column
+ * blocks of a [rows, 4096] gradient are summed where they lie, without a contiguous copy of each block. */
+int pps_col_sum_strided(const void* x, int64_t rows, int c, int64_t ld, int dtype, float* out, void* ws, void* stream);
 
 /* Attention pooling of the interpolation head in train(): a[j] = mean_h softmax_j(qy[q,j,h]), pooled[q,c] = sum_j a[j] h[q,j,c]
  * (replaces source/poco_model.py:412-414 under autograd, in the pooled form where fc_value follows the pooling).  qy [q,k,heads], h [q,k,c],
@@ -438,6 +441,11 @@ int pps_col_sum(const void* x, int64_t rows, int c, int dtype, float* out, void*
 int pps_attn_pool_fwd(const void* qy, const void* h, int64_t q, int k, int heads, int c, int bf16, int relu_h, void* pooled, void* stream);
 int pps_attn_pool_bwd(const void* qy, const void* h, const void* dpooled, int64_t q, int k, int heads, int c, int bf16, int relu_h, void* dqy,
                       void* dh, void* stream);
+/* pps_attn_pool_bwd without dh: dh[q,j,c] = relu'(h[q,j,c]) * a[q,j] * dpooled[q,c] is one multiply per element, so the [q k, c] tensor is neither
+ * written here nor read back by its consumer -- `weights` [q, k] fp32 receives a (the softmax averaged over the heads) and
+ * pps_rows_layer_bwd_attn rebuilds the product where it adds the two gradients of h. */
+int pps_attn_pool_bwd_weights(const void* qy, const void* h, const void* dpooled, int64_t q, int k, int heads, int c, int bf16, int relu_h, void* dqy,
+                              float* weights, void* stream);
 
 /* The 16-bit tensors of the training-step entries below are bfloat16 (dtype = 1, trainer.precision bf16-mixed) or IEEE half (dtype = 2,
  * trainer.precision 16-mixed, the reference's default); "bf16" in the descriptions stands for either.
@@ -515,6 +523,13 @@ int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t row
                        const float* in_shift, int in_relu, const float* w, const float* gamma, const float* save, const float* d_affine,
                        void* dx, const void* dx_add, float* d_in_affine, float* dw, float* dbias, float* dgamma, float* dbeta, void* ws,
                        void* stream);
+
+/* pps_rows_layer_bwd for fc_query of the interpolation head (source/poco_model.py:404-409: no statistics, identity input affine, ReLU on the input
+ * x = the raw output of fc3), with the OTHER gradient of x -- the attention pooling's -- rebuilt in the epilogue instead of read as dx_add:
+ *   dx[r, c] = relu'(x[r, c]) * ((gy W)[r, c] + att_weights[r] * att_dpooled[r / att_k, c])
+ * att_weights [rows] fp32 (pps_attn_pool_bwd_weights), att_dpooled [rows / att_k, cin] in the storage type, rows % att_k == 0. */
+int pps_rows_layer_bwd_attn(const void* x, const void* gy, int64_t rows, int cin, int cout, int dtype, const float* w, const float* att_weights,
+                            const void* att_dpooled, int att_k, void* dx, float* dw, float* dbias, void* ws, void* stream);
 
 /* pps_rows_layer_bwd for a layer whose raw output only feeds a max over the p rows of every group (the last layer of PointNet's STN before
  * `torch.max(x, 2)`, source/base/nn.py:181): the incoming gradient is ONE value per (group, channel) -- gval [rows / pool_p, cout] in the storage type --

@@ -87,6 +87,7 @@ SIGNATURES = {
     'pps_fka_geometry_bwd_f32': (_I, [_P, _P, _P, _I64, _I64, _I, _P, _P, _P, _P, _P, _P]),
     'pps_attn_pool_fwd': (_I, [_P, _P, _I64, _I, _I, _I, _I, _I, _P, _P]),
     'pps_attn_pool_bwd': (_I, [_P, _P, _P, _I64, _I, _I, _I, _I, _I, _P, _P, _P]),
+    'pps_attn_pool_bwd_weights': (_I, [_P, _P, _P, _I64, _I, _I, _I, _I, _I, _P, _P, _P]),
     'pps_patch_attn_partials': (_I, [_I64]),
     'pps_patch_attn_fwd': (_I, [_P, _P, _I64, _I, _I, _I, _P, _P]),
     'pps_patch_attn_bwd': (_I, [_P, _P, _P, _I64, _I, _I, _I, _P, _P, _P]),
@@ -106,6 +107,7 @@ SIGNATURES = {
     'pps_rows_layer_ws_bytes': (_SZ, [_I, _I]),
     'pps_rows_layer_fwd': (_I, [_P, _I64, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _c.c_float, _c.c_float, _P, _P, _P, _P]),
     'pps_rows_layer_bwd': (_I, [_P, _P, _P, _I64, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'pps_rows_layer_bwd_attn': (_I, [_P, _P, _I64, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     'pps_rows_layer_pooled_supported': (_I, [_I, _I, _I]),
     'pps_rows_layer_bwd_pooled': (_I, [_P, _P, _P, _P, _I, _I64, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pps_bn_train_ws_bytes': (_SZ, [_I64, _I]),
@@ -114,6 +116,7 @@ SIGNATURES = {
     'pps_bn_add_relu_fwd': (_I, [_P, _P, _I64, _I, _I, _P, _P, _P, _P, _c.c_float, _c.c_float, _P, _P, _P, _P]),
     'pps_bn_add_relu_bwd': (_I, [_P, _P, _P, _I64, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pps_col_sum': (_I, [_P, _I64, _I, _I, _P, _P, _P]),
+    'pps_col_sum_strided': (_I, [_P, _I64, _I, _I64, _I, _P, _P, _P]),
     'pps_gemm_nt_16': (_I, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I, _I, _I, _I, _P]),
     'pps_gemm_tn_ws_bytes': (_SZ, [_I64, _I, _I]),
     'pps_gemm_tn_16': (_I, [_P, _I64, _P, _I64, _I64, _I, _I, _I, _P, _P, _P]),

@@ -152,9 +152,12 @@ __global__ __launch_bounds__(AT_NT) void attn_pool_fwd_kernel(const T* __restric
 }
 
 // d_h[q,j,c] = a[j] dP[c];   da[j] = sum_c dP[c] h[q,j,c];   d_qy[q,j,h] = s[j,h]/H * (da[j] - sum_j' s[j',h] da[j'])
+// dh == NULL: d_h is not stored -- the caller gets the weights a [Q, k] (a_out) and rebuilds mask * a[j] * dP[c] where it consumes the gradient
+// (the input-gradient kernel of fc_query, LayerArgs::att_a): [Q k, C] written here and read back there otherwise, for one multiply per element
 template <typename T>
 __global__ __launch_bounds__(AT_NT) void attn_pool_bwd_kernel(const T* __restrict__ qy, const T* __restrict__ h, const T* __restrict__ dpooled,
-                                                              int64_t Q, int k, int H, int C, int relu_h, T* __restrict__ dqy, T* __restrict__ dh) {
+                                                              int64_t Q, int k, int H, int C, int relu_h, T* __restrict__ dqy, T* __restrict__ dh,
+                                                              float* __restrict__ a_out) {
     const float hfloor = relu_h ? 0.f : -INFINITY;
     __shared__ float e[AT_KMAX][AT_H + 1];
     __shared__ float red[4 * 64], inv_s[64], a[AT_KMAX], da[AT_KMAX], dp[256], dsum[64];
@@ -167,11 +170,14 @@ __global__ __launch_bounds__(AT_NT) void attn_pool_bwd_kernel(const T* __restric
             const float s = lane < H ? e[j][lane] * inv_s[lane] : 0.f;
             e[j][lane] = s;                                                          // e now holds the softmax probabilities s[j][h]
             const float v = wave_sum(s);
-            if (lane == 0) a[j] = v * inv_h;
+            if (lane == 0) {
+                a[j] = v * inv_h;
+                if (a_out) a_out[q * (int64_t)k + j] = v * inv_h;
+            }
         }
         __syncthreads();
         const T* hq = h + q * (int64_t)k * C;
-        T* dhq = dh + q * (int64_t)k * C;
+        T* dhq = dh ? dh + q * (int64_t)k * C : nullptr;
         if (C == 256) {
             const float4 d4 = make_float4(dp[4 * lane], dp[4 * lane + 1], dp[4 * lane + 2], dp[4 * lane + 3]);
             // one neighbour row per wave pass, 4 channels per lane; the wave's 16 rows are requested four at a time (a row per iteration left
@@ -186,8 +192,9 @@ __global__ __launch_bounds__(AT_NT) void attn_pool_bwd_kernel(const T* __restric
                     if (j < k) {
                         const float aj = a[j];
                         // with relu_h the gradient goes to the stored pre-activation: masked where it was clipped
-                        st4(dhq, (int64_t)j * 256 + 4 * lane, make_float4(v[u].x > hfloor ? aj * d4.x : 0.f, v[u].y > hfloor ? aj * d4.y : 0.f,
-                                                                          v[u].z > hfloor ? aj * d4.z : 0.f, v[u].w > hfloor ? aj * d4.w : 0.f));
+                        if (dhq)
+                            st4(dhq, (int64_t)j * 256 + 4 * lane, make_float4(v[u].x > hfloor ? aj * d4.x : 0.f, v[u].y > hfloor ? aj * d4.y : 0.f,
+                                                                              v[u].z > hfloor ? aj * d4.z : 0.f, v[u].w > hfloor ? aj * d4.w : 0.f));
                         const float4 w = make_float4(fmaxf(v[u].x, hfloor), fmaxf(v[u].y, hfloor), fmaxf(v[u].z, hfloor), fmaxf(v[u].w, hfloor));
                         const float part = wave_sum((d4.x * w.x + d4.y * w.y) + (d4.z * w.z + d4.w * w.w));
                         if (lane == 0) da[j] = part;
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(AT_NT) void attn_pool_bwd_kernel(const T* __restric
                 for (int c = lane; c < C; c += 64) {
                     const float hv = ld(hq, (int64_t)j * C + c);
                     part += dp[c] * fmaxf(hv, hfloor);
-                    st(dhq, (int64_t)j * C + c, hv > hfloor ? aj * dp[c] : 0.f);
+                    if (dhq) st(dhq, (int64_t)j * C + c, hv > hfloor ? aj * dp[c] : 0.f);
                 }
                 part = wave_sum(part);
                 if (lane == 0) da[j] = part;
@@ -397,22 +404,34 @@ int pps_attn_pool_fwd(const void* qy, const void* h, int64_t q, int k, int heads
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 
-int pps_attn_pool_bwd(const void* qy, const void* h, const void* dpooled, int64_t q, int k, int heads, int c, int bf16, int relu_h, void* dqy,
-                      void* dh, void* stream) {
+static int attn_pool_bwd_any(const void* qy, const void* h, const void* dpooled, int64_t q, int k, int heads, int c, int bf16, int relu_h, void* dqy,
+                             void* dh, float* a_out, void* stream) {
     if (q < 0 || k < 1 || k > AT_KMAX || heads < 1 || heads > AT_H || c < 1 || c > 256) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
-    if (!qy || !h || !dpooled || !dqy || !dh) return PPS_ERR_ARG;
+    if (!qy || !h || !dpooled || !dqy || (!dh && !a_out)) return PPS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (bf16 == 2)
         hipLaunchKernelGGL(attn_pool_bwd_kernel<half_t>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const half_t*)qy, (const half_t*)h, (const half_t*)dpooled, q,
-                           k, heads, c, relu_h, (half_t*)dqy, (half_t*)dh);
+                           k, heads, c, relu_h, (half_t*)dqy, (half_t*)dh, a_out);
     else if (bf16)
         hipLaunchKernelGGL(attn_pool_bwd_kernel<uint16_t>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const uint16_t*)qy, (const uint16_t*)h,
-                           (const uint16_t*)dpooled, q, k, heads, c, relu_h, (uint16_t*)dqy, (uint16_t*)dh);
+                           (const uint16_t*)dpooled, q, k, heads, c, relu_h, (uint16_t*)dqy, (uint16_t*)dh, a_out);
     else
         hipLaunchKernelGGL(attn_pool_bwd_kernel<float>, dim3(grid_for(q)), dim3(AT_NT), 0, st, (const float*)qy, (const float*)h,
-                           (const float*)dpooled, q, k, heads, c, relu_h, (float*)dqy, (float*)dh);
+                           (const float*)dpooled, q, k, heads, c, relu_h, (float*)dqy, (float*)dh, a_out);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+int pps_attn_pool_bwd(const void* qy, const void* h, const void* dpooled, int64_t q, int k, int heads, int c, int bf16, int relu_h, void* dqy,
+                      void* dh, void* stream) {
+    if (q > 0 && !dh) return PPS_ERR_ARG;
+    return attn_pool_bwd_any(qy, h, dpooled, q, k, heads, c, bf16, relu_h, dqy, dh, nullptr, stream);
+}
+
+int pps_attn_pool_bwd_weights(const void* qy, const void* h, const void* dpooled, int64_t q, int k, int heads, int c, int bf16, int relu_h, void* dqy,
+                              float* weights, void* stream) {
+    if (q > 0 && !weights) return PPS_ERR_ARG;
+    return attn_pool_bwd_any(qy, h, dpooled, q, k, heads, c, bf16, relu_h, dqy, nullptr, weights, stream);
 }
 
 /* Single-head attention pooling with the logit computed inside: a = softmax_j(h[q,j,:] . v), pooled[q,:] = sum_j a_j h[q,j,:]

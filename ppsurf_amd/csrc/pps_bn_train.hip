@@ -228,7 +228,7 @@ inline int apply_blocks(int64_t rows, int C) {
 }
 // column sums of a [rows, C] tensor (bias gradient of a row layer): per-block partials over a slab of rows, then one wave per channel
 template <typename T>
-__global__ __launch_bounds__(BNT) void col_sum_kernel(const T* __restrict__ x, int64_t rows, int C, double* __restrict__ part) {
+__global__ __launch_bounds__(BNT) void col_sum_kernel(const T* __restrict__ x, int64_t rows, int C, int64_t ld, double* __restrict__ part) {
     extern __shared__ double red[];                 // [rpb][C]
     const Map m = map_of(C);
     const int64_t slab = (rows + gridDim.x - 1) / gridDim.x;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(BNT) void col_sum_kernel(const T* __restrict__ x, i
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     if (m.rl < m.rpb) {
         for (int64_t r = r0 + m.rl; r < r1; r += m.rpb) {
-            const F4 xv = load4<T>(x + r * C + 4 * m.cg);
+            const F4 xv = load4<T>(x + r * ld + 4 * m.cg);
 #pragma unroll
             for (int i = 0; i < 4; ++i) s[i] += xv.v[i];
         }
@@ -263,10 +263,10 @@ __global__ __launch_bounds__(BNT) void col_sum_finalize_kernel(const double* __r
 }
 
 template <typename T>
-int col_sum_t(const T* x, int64_t rows, int c, float* out, void* ws, hipStream_t st, int nb) {
+int col_sum_t(const T* x, int64_t rows, int c, int64_t ld, float* out, void* ws, hipStream_t st, int nb) {
     double* part = (double*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     const size_t lds = (size_t)(BNT / (c >> 2)) * c * sizeof(double);
-    hipLaunchKernelGGL((col_sum_kernel<T>), dim3(nb), dim3(BNT), lds, st, x, rows, c, part);
+    hipLaunchKernelGGL((col_sum_kernel<T>), dim3(nb), dim3(BNT), lds, st, x, rows, c, ld, part);
     hipLaunchKernelGGL(col_sum_finalize_kernel, dim3((c + 3) / 4), dim3(BNT), 0, st, (const double*)part, nb, c, out);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
@@ -314,13 +314,17 @@ size_t pps_bn_train_ws_bytes(int64_t rows, int c) {
     return 1024 + (size_t)reduce_blocks(rows, c) * 2 * c * sizeof(double) + 4 * (size_t)c * sizeof(float);        // partials | pivots or gradient means
 }
 
-int pps_col_sum(const void* x, int64_t rows, int c, int dtype, float* out, void* ws, void* stream) {
-    if (!ok_shape(rows, c) || (dtype < 0 || dtype > 2) || !x || !out || !ws) return 1;
+int pps_col_sum_strided(const void* x, int64_t rows, int c, int64_t ld, int dtype, float* out, void* ws, void* stream) {
+    if (!ok_shape(rows, c) || (dtype < 0 || dtype > 2) || !x || !out || !ws || ld < c || (ld & 3) || ((uintptr_t)x & (dtype == 0 ? 15 : 7))) return 1;
     int nb = reduce_blocks(rows, c);
     if (nb > 256) nb = 256;                              // one pass of <= 256 partial rows per channel in the second kernel
-    if (dtype == 0) return col_sum_t<float>((const float*)x, rows, c, out, ws, (hipStream_t)stream, nb);
-    if (dtype == 2) return col_sum_t<half_t>((const half_t*)x, rows, c, out, ws, (hipStream_t)stream, nb);
-    return col_sum_t<uint16_t>((const uint16_t*)x, rows, c, out, ws, (hipStream_t)stream, nb);
+    if (dtype == 0) return col_sum_t<float>((const float*)x, rows, c, ld, out, ws, (hipStream_t)stream, nb);
+    if (dtype == 2) return col_sum_t<half_t>((const half_t*)x, rows, c, ld, out, ws, (hipStream_t)stream, nb);
+    return col_sum_t<uint16_t>((const uint16_t*)x, rows, c, ld, out, ws, (hipStream_t)stream, nb);
+}
+
+int pps_col_sum(const void* x, int64_t rows, int c, int dtype, float* out, void* ws, void* stream) {
+    return pps_col_sum_strided(x, rows, c, (int64_t)c, dtype, out, ws, stream);
 }
 
 int pps_bn_train_fwd(const void* x, int64_t rows, int c, int dtype, const float* gamma, const float* beta, float* running_mean,

@@ -97,6 +97,10 @@ int pps_rows_layer_bwd(const void* x, const void* y, const void* gy, int64_t row
     return PPS_BY_TYPE(pps_rows_layer_bwd(x, y, gy, rows, cin, cout, in_scale, in_shift, in_relu, w, gamma, save, d_affine, dx, dx_add, d_in_affine, dw, dbias,
                                           dgamma, dbeta, ws, stream));
 }
+int pps_rows_layer_bwd_attn(const void* x, const void* gy, int64_t rows, int cin, int cout, int dtype, const float* w, const float* att_weights,
+                            const void* att_dpooled, int att_k, void* dx, float* dw, float* dbias, void* ws, void* stream) {
+    return PPS_BY_TYPE(pps_rows_layer_bwd_attn(x, gy, rows, cin, cout, w, att_weights, att_dpooled, att_k, dx, dw, dbias, ws, stream));
+}
 size_t pps_head_chain_ws_bytes(void) { return rt_bf16::pps_head_chain_ws_bytes(); }
 int pps_head_chain_fwd(const void* table, const int64_t* ids, const float* pts, const float* query, int64_t q, int k, int dtype, const float* wx,
                        const float* w2, const float* b2, const float* w3, const float* b3, const float* wq, const float* bq, void* h1, void* y2, void* y3,

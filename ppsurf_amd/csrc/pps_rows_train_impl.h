@@ -84,6 +84,12 @@ struct LayerArgs {
     const uint8_t* garg;          // dx, POOL: winning row of every (group, channel) [rows / pool_p, CK]; src is then the gradient per GROUP
     int pool_p;                   // dx, POOL: rows per group
     unsigned pool_magic;          // floor(2^32 / pool_p) + 1
+    // dx, second gradient of x rebuilt instead of read (attention pooling over the att_k rows of a group, pps_attn_pool_bwd_weights):
+    //   dx[row, c] += relu'(x[row, c]) * att_a[row] * att_dp[row / att_k, c]
+    const float* att_a;           // [rows] or NULL
+    const uint16_t* att_dp;       // [rows / att_k, CO]
+    int att_k;
+    unsigned att_magic;           // floor(2^32 / att_k) + 1 (att_k >= 2; one row per group needs no division)
 };
 
 // The incoming gradient of a layer whose output only feeds a max over the p rows of every group (the STN of PointNet, source/base/nn.py:181) is
@@ -270,6 +276,13 @@ __global__ __launch_bounds__(NT, 1) void rows_layer_kernel(const LayerArgs a) {
                         g0 = *(const u32x4*)(a.addend + row * CO + c0);
                         g1 = *(const u32x4*)(a.addend + row * CO + c0 + 8);
                     }
+                    float att = 0.f;
+                    if (a.att_a) {                    // (host: never together with addend)
+                        const uint16_t* dpq = a.att_dp + (int64_t)(a.att_k == 1 ? (unsigned)row : __umulhi((unsigned)row, a.att_magic)) * CO + c0;
+                        att = a.att_a[row];
+                        g0 = *(const u32x4*)dpq;
+                        g1 = *(const u32x4*)(dpq + 8);
+                    }
                     const unsigned gw[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
                     for (int o = 0; o < 4; ++o) {
@@ -284,7 +297,14 @@ __global__ __launch_bounds__(NT, 1) void rows_layer_kernel(const LayerArgs a) {
                             st1[4 * grp + o][r] += live * d[r];
                             d[r] *= sc[r];
                         }
-                        d[0] += lo16(gw[2 * o]); d[1] += hi16(gw[2 * o]); d[2] += lo16(gw[2 * o + 1]); d[3] += hi16(gw[2 * o + 1]);
+                        const float ad[4] = {lo16(gw[2 * o]), hi16(gw[2 * o]), lo16(gw[2 * o + 1]), hi16(gw[2 * o + 1])};
+                        if (a.att_a) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) d[r] += x4[r] > 0.f ? att * ad[r] : 0.f;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) d[r] += ad[r];
+                        }
                         out[2 * o] = pack2(d[0], d[1]);
                         out[2 * o + 1] = pack2(d[2], d[3]);
                     }
@@ -1259,8 +1279,9 @@ bool pooled_ok(int cin, int cout, bool bn, int pool_p, int64_t rows) {
 int rows_layer_bwd_any(const void* x, const void* y, const void* gy, const uint8_t* garg, int pool_p, int64_t rows, int cin, int cout,
                        const float* in_scale, const float* in_shift, int in_relu, const float* w, const float* gamma, const float* save,
                        const float* d_affine, void* dx, const void* dx_add, float* d_in_affine, float* dw, float* dbias, float* dgamma, float* dbeta,
-                       void* ws, void* stream) {
+                       void* ws, void* stream, const float* att_a = nullptr, const void* att_dp = nullptr, int att_k = 0) {
     if (rows < 1 || !dim_ok(cin) || !dim_ok(cout)) return PPS_ERR_ARG;
+    if (att_a && (!att_dp || dx_add || in_scale || !in_relu || att_k < 1 || rows % att_k || rows * att_k >= (int64_t)1 << 32)) return PPS_ERR_ARG;
     if (!x || !gy || !w || !ws || ((in_scale == nullptr) != (in_shift == nullptr))) return PPS_ERR_ARG;
     const bool bn = gamma != nullptr;
     if (bn && (!y || !save || !d_affine || !dgamma || !dbeta)) return PPS_ERR_ARG;
@@ -1292,6 +1313,10 @@ int rows_layer_bwd_any(const void* x, const void* y, const void* gy, const uint8
         a.in_relu = in_relu;
         a.dst = (uint16_t*)dx;
         a.addend = (const uint16_t*)dx_add;
+        a.att_a = att_a;
+        a.att_dp = (const uint16_t*)att_dp;
+        a.att_k = att_k;
+        a.att_magic = att_a ? (unsigned)(0x100000000ull / (unsigned)att_k) + 1u : 0u;
         a.partials = d_in_affine ? part_aff : nullptr;
         a.rows = rows;
         a.garg = garg;
@@ -1353,6 +1378,13 @@ int pps_rows_layer_bwd_pooled(const void* x, const void* y, const void* gval, co
     if (pool_p == 0) return PPS_ERR_ARG;
     return rows_layer_bwd_any(x, y, gval, garg, pool_p, rows, cin, cout, in_scale, in_shift, in_relu, w, gamma, save, d_affine, dx, nullptr, d_in_affine,
                               dw, dbias, dgamma, dbeta, ws, stream);
+}
+
+int pps_rows_layer_bwd_attn(const void* x, const void* gy, int64_t rows, int cin, int cout, const float* w, const float* att_weights, const void* att_dpooled,
+                            int att_k, void* dx, float* dw, float* dbias, void* ws, void* stream) {
+    if (!att_weights || !dx) return PPS_ERR_ARG;
+    return rows_layer_bwd_any(x, nullptr, gy, nullptr, 0, rows, cin, cout, nullptr, nullptr, 1, w, nullptr, nullptr, nullptr, dx, nullptr, nullptr, dw, dbias,
+                              nullptr, nullptr, ws, stream, att_weights, att_dpooled, att_k);
 }
 
 int pps_rows_layer_pooled_supported(int cin, int cout, int pool_p) { return pooled_ok(cin, cout, true, pool_p, (int64_t)pool_p) ? 1 : 0; }

@@ -66,6 +66,20 @@ def step_stream():
     return torch.cuda.Stream(priority=hi)
 
 
+def _refill(static, batch):
+    """The batch into the static input buffers of a recorded step: ONE multi-tensor copy per storage type.  torch._foreach_copy_ only takes its
+    one-kernel route for lists of a single dtype -- handed the batch's 68 tensors (int64 tables, fp32 points, uint8 / bool masks) as one list
+    it issues 68 device memcpys, 0.27 ms of the step's queue between the optimizer of one step and the replay of the next
+    (tools/dbg/copybuffer_queues.sh, profiles/NOTES_r6.md section 9)."""
+    groups = {}
+    for k, dst in static.items():
+        pair = groups.setdefault(dst.dtype, ([], []))
+        pair[0].append(dst)
+        pair[1].append(batch[k])
+    for dsts, srcs in groups.values():
+        torch._foreach_copy_(dsts, srcs)
+
+
 class GraphedStep:
     """One optimisation step as a replayable HIP graph (torch.cuda.CUDAGraph = hipGraph on ROCm), one graph per batch signature
     (keys, shapes, dtypes).  `eager(batch, bi)` is the step body; it must be free of host synchronisation and data-dependent shapes
@@ -136,8 +150,7 @@ class GraphedStep:
                 # of this step are already queued behind the previous replay when the host gets here.
                 if self._done is not None:
                     self._done.synchronize()
-                # one multi-tensor copy per dtype instead of one memcpy per tensor (35 of them): the GPU idles while the host queues these
-                torch._foreach_copy_(list(static.values()), [batch[k] for k in static])
+                _refill(static, batch)
                 graph.replay()
                 self.replayed = True
                 if self._done is None:
@@ -279,7 +292,7 @@ class StagedStep:
                 static, graphs, logged, touched = entry
                 if self._done is not None:
                     self._done.synchronize()                     # the previous replay has finished reading the static inputs (GraphedStep.run)
-                torch._foreach_copy_(list(static.values()), [batch[k] for k in static])
+                _refill(static, batch)
                 self.buckets.begin_replay(touched)
                 for k, g in enumerate(graphs):
                     g.replay()

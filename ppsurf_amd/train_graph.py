@@ -301,6 +301,7 @@ def dense(layer, x):
 
 
 _counters = []
+_radii = ([], [])            # (norm_radius buffers, their new values) of the FKAConv layers evaluated since the last flush
 
 
 def _count_batch(bn):
@@ -314,6 +315,24 @@ def flush_batch_counters():
     if _counters:
         torch._foreach_add_(list(_counters), 1)
         _counters.clear()
+    if _radii[0]:
+        with torch.no_grad():                                   # IN PLACE: a replayed HIP graph reads and writes the buffers' own storage
+            torch._foreach_copy_(list(_radii[0]), list(_radii[1]))
+        _radii[0].clear()
+        _radii[1].clear()
+
+
+def _store_radius(layer, radius):
+    """norm_radius <- the value the geometry kernel moved it to (nn.py:614-620, train()): collected like the BatchNorm counters and written by ONE
+    multi-tensor copy when the outermost graph function returns (a 4-byte device memcpy per FKAConv layer otherwise: 10 per step, 5 us each on
+    the step's queue); at once when called outside the graph functions."""
+    value = radius.detach().reshape(layer.norm_radius.shape)
+    if _depth[0] > 0:
+        _radii[0].append(layer.norm_radius)
+        _radii[1].append(value)
+    else:
+        with torch.no_grad():
+            layer.norm_radius.copy_(value)
 
 
 _depth = [0]
@@ -636,8 +655,7 @@ def fka_geometry_of(layer, pts, sup, ids):
     momentum = layer.norm_radius_momentum if layer.training else 0.0
     g, radius = train_ops.fka_geometry(pack_geo(layer), pts.reshape(b * n, 3), sup.reshape(b * m, 3), flat, b, m, momentum, owned=True)
     if layer.training:
-        with torch.no_grad():                               # IN PLACE: a replayed HIP graph reads and writes the buffer's own storage
-            layer.norm_radius.copy_(radius.detach().reshape(layer.norm_radius.shape))
+        _store_radius(layer, radius)
     return g
 
 

@@ -17,6 +17,8 @@ is sorted once (`csr`, cached per table and step) and each target row sums its c
 All ops compute in fp32; gather_rows, neighbour_contract (matrix-pipe shapes), bn_act and the attention ops read and write 16-bit activations as they
 are, the others up-cast them.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -416,17 +418,21 @@ def bn_add_relu(x, res, weight, bias, running_mean, running_var, momentum, eps):
 
 def col_sum(x):
     """x [rows, c] -> fp32 [c] column sums (the bias gradient of a row layer) by the HIP reduction; None if the shape is not one it takes
-    (the caller then uses torch's sum).  No autograd: called from backward passes."""
-    if not x.is_cuda or x.dim() != 2 or x.dtype not in (torch.float32,) + LOW or not x.is_contiguous():
+    (the caller then uses torch's sum).  x may be a block of columns of a wider contiguous tensor (unit column stride, row stride and first column
+    multiples of 4): summed where it lies.  No autograd: called from backward passes."""
+    if not x.is_cuda or x.dim() != 2 or x.dtype not in (torch.float32,) + LOW:
         return None
     rows, c = x.shape
+    ld = x.stride(0) if rows > 1 else c
+    if rows < 1 or (c > 1 and x.stride(1) != 1) or ld < c or ld % 4 or x.data_ptr() % (4 * x.element_size()):
+        return None
     nbytes = _lib.lib().pps_bn_train_ws_bytes(rows, c)
     if nbytes == 0:
         return None
     out = torch.empty((c,), device=x.device, dtype=torch.float32)
     ws = torch.empty((nbytes,), device=x.device, dtype=torch.uint8)
-    _lib.check(_lib.lib().pps_col_sum(x.data_ptr(), rows, c, _code(x.dtype) if x.dtype in LOW else 0, out.data_ptr(), ws.data_ptr(), _stream()),
-               'pps_col_sum')
+    _lib.check(_lib.lib().pps_col_sum_strided(x.data_ptr(), rows, c, ld, _code(x.dtype) if x.dtype in LOW else 0, out.data_ptr(), ws.data_ptr(),
+                                              _stream()), 'pps_col_sum_strided')
     return out
 
 
@@ -452,7 +458,7 @@ def sum_rows(x):
                 if width != c:
                     return sum_rows(torch.cat([x, x.new_zeros((rows, width - c))], dim=1))[:c]
         else:
-            parts = [col_sum(x[:, i:min(i + 1024, c)].contiguous()) for i in range(0, c, 1024)]
+            parts = [col_sum(x[:, i:min(i + 1024, c)]) for i in range(0, c, 1024)]        # column blocks summed where they lie
             if all(q is not None for q in parts):
                 return torch.cat(parts)
     return x.sum(0, dtype=torch.float32)
@@ -899,6 +905,31 @@ def rows_layer(act, w, b, bn=None, relu=False):
     return Act(y, aff, relu)
 
 
+def _query_attn_bwd(L, y3, qy, dpooled, wq32, k, dwq, dbq, ws, st):
+    """Backward of (fc_query, attention pooling) on the stored raw output y3 of fc3 -> d y3 [Q*k, 256]; dwq / dbq are filled.  y3 has two
+    consumers.  The pooling's gradient relu'(y3) * a[q, j] * dpooled[q, c] is one multiply per element, so it is NOT stored: pps_attn_pool_bwd_weights
+    returns a [Q, k] and the input-gradient kernel of fc_query rebuilds the product where it adds the two gradients (pps_rows_layer_bwd_attn) --
+    the [Q*k, 256] tensor (655 MB at 50 x 2000 x 64 rows) is neither written nor read.  PPS_ATTN_GRAD=stored: the pooling gradient goes through
+    memory (pps_attn_pool_bwd + dx_add; also taken when rows * k does not fit the kernel's 32-bit row / k)."""
+    rows, c = y3.shape
+    heads = wq32.shape[0]
+    code = _code(y3.dtype)
+    ptr = lambda t: None if t is None else t.data_ptr()
+    dqy, dy3 = torch.empty_like(qy), torch.empty_like(y3)
+    if os.environ.get('PPS_ATTN_GRAD', 'rebuilt') != 'stored' and rows * k < 1 << 32:
+        a = torch.empty((rows,), device=y3.device, dtype=torch.float32)
+        _lib.check(L.pps_attn_pool_bwd_weights(qy.data_ptr(), y3.data_ptr(), dpooled.data_ptr(), rows // k, k, heads, c, code, 1, dqy.data_ptr(), a.data_ptr(),
+                                               st), 'pps_attn_pool_bwd_weights')
+        _lib.check(L.pps_rows_layer_bwd_attn(y3.data_ptr(), dqy.data_ptr(), rows, c, heads, code, wq32.data_ptr(), a.data_ptr(), dpooled.data_ptr(), k,
+                                             dy3.data_ptr(), dwq.data_ptr(), ptr(dbq), ws.data_ptr(), st), 'pps_rows_layer_bwd_attn')
+        return dy3
+    _lib.check(L.pps_attn_pool_bwd(qy.data_ptr(), y3.data_ptr(), dpooled.data_ptr(), rows // k, k, heads, c, code, 1, dqy.data_ptr(), dy3.data_ptr(), st),
+               'pps_attn_pool_bwd')
+    _lib.check(L.pps_rows_layer_bwd(y3.data_ptr(), qy.data_ptr(), dqy.data_ptr(), rows, c, heads, code, None, None, 1, wq32.data_ptr(), None, None, None,
+                                    dy3.data_ptr(), dy3.data_ptr(), None, dwq.data_ptr(), ptr(dbq), None, None, ws.data_ptr(), st), 'pps_rows_layer_bwd')
+    return dy3
+
+
 class _QueryAttnPool(torch.autograd.Function):
     """The end of the interpolation head on the stored (pre-ReLU) output y3 of fc3 [Q*k, 256]:  qy = fc_query(relu(y3)),  pooled[q] = sum_j mean_h
     softmax_j(qy) relu(y3)[q, j]  as ONE autograd node: y3 has two consumers, and their two gradients are summed inside the input-gradient
@@ -933,15 +964,10 @@ class _QueryAttnPool(torch.autograd.Function):
         heads = w32.shape[0]
         dev = y3.device
         dpooled = dpooled.to(y3.dtype).contiguous()
-        dqy, dy3 = torch.empty_like(qy), torch.empty_like(y3)
-        _lib.check(L.pps_attn_pool_bwd(qy.data_ptr(), y3.data_ptr(), dpooled.data_ptr(), rows // k, k, heads, c, _code(y3.dtype), 1, dqy.data_ptr(), dy3.data_ptr(),
-                                       _stream()), 'pps_attn_pool_bwd')
         dw = torch.empty((heads, c), device=dev, dtype=torch.float32)
         db = torch.empty((heads,), device=dev, dtype=torch.float32) if has_b else None
         ws = torch.empty((L.pps_rows_layer_ws_bytes(c, heads),), device=dev, dtype=torch.uint8)
-        _lib.check(L.pps_rows_layer_bwd(y3.data_ptr(), qy.data_ptr(), dqy.data_ptr(), rows, c, heads, _code(y3.dtype), None, None, 1,
-                                        w32.data_ptr(), None, None, None, dy3.data_ptr(), dy3.data_ptr(), None, dw.data_ptr(),
-                                        None if db is None else db.data_ptr(), None, None, ws.data_ptr(), _stream()), 'pps_rows_layer_bwd')
+        dy3 = _query_attn_bwd(L, y3, qy, dpooled, w32, k, dw, db, ws, _stream())
         return dy3, dw.to(wdt), None if db is None else db.to(bdt), None
 
 
@@ -995,16 +1021,11 @@ class _HeadChain(torch.autograd.Function):
         st = _stream()
         ptr = lambda t: None if t is None else t.data_ptr()
         dpooled = dpooled.to(dt).contiguous()
-        # attention pooling + fc_query: the two gradients of y3 are summed inside fc_query's input-gradient kernel (dx_add)
-        dqy, dy3 = torch.empty_like(qy), torch.empty_like(y3)
-        _lib.check(L.pps_attn_pool_bwd(qy.data_ptr(), y3.data_ptr(), dpooled.data_ptr(), rows // k, k, heads, c, code, 1, dqy.data_ptr(), dy3.data_ptr(), st),
-                   'pps_attn_pool_bwd')
+        # attention pooling + fc_query: the two gradients of y3 are summed inside fc_query's input-gradient kernel
         f32e = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
         dwq, dbq = f32e(heads, c), (f32e(heads) if bqdt is not None else None)
         ws = torch.empty((L.pps_rows_layer_ws_bytes(c, c),), device=dev, dtype=torch.uint8)        # (the largest of the three layers)
-        _lib.check(L.pps_rows_layer_bwd(y3.data_ptr(), qy.data_ptr(), dqy.data_ptr(), rows, c, heads, code, None, None, 1, wq32.data_ptr(), None, None, None,
-                                        dy3.data_ptr(), dy3.data_ptr(), None, dwq.data_ptr(), ptr(dbq), None, None, ws.data_ptr(), st), 'pps_rows_layer_bwd')
-        del dqy
+        dy3 = _query_attn_bwd(L, y3, qy, dpooled, wq32, k, dwq, dbq, ws, st)
         # fc3
         dy2 = torch.empty_like(y2)
         dw3, db3 = f32e(c, c), (f32e(c) if b3dt is not None else None)
@@ -1048,7 +1069,6 @@ def head_chain_trusted(dtype):
     tensor's scale (the accumulation order inside an MFMA may move a value across a rounding boundary), the chain itself equal on a second launch.  False -> the
     caller keeps to the separate launches (also hand-written HIP kernels) and a warning says so once.  Not run while a stream is being captured
     (the eager warm-up steps of a fit come first); PPS_HEAD_CHAIN_CHECK=0 skips it."""
-    import os
     hit = _head_chain_checked.get(dtype)
     if hit is not None:
         return hit

@@ -165,3 +165,40 @@ def test_first_use_self_check_passes_and_is_cached(dt):
     train_ops._head_chain_checked.pop(dt, None)
     assert train_ops.head_chain_trusted(dt) is True
     assert train_ops._head_chain_checked[dt] is True and train_ops.head_chain_trusted(dt) is True
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('nq,k', [(300, 64), (41, 37), (1, 64), (2003, 64), (7, 1)])
+def test_rebuilt_attention_gradient_is_the_stored_one_without_its_rounding(nq, k, dt, monkeypatch):
+    """d y3 of (fc_query, attention pooling): the pooling's share relu'(y3) a[q, j] dpooled[q, c] rebuilt inside fc_query's input-gradient kernel
+    (pps_attn_pool_bwd_weights + pps_rows_layer_bwd_attn, the default) against the same share written to memory and read back (PPS_ATTN_GRAD=stored:
+    pps_attn_pool_bwd + dx_add) and against float64 autograd of the formula on the same 16-bit operands.  The two differ by ONE 16-bit rounding of
+    the share (the stored path rounds it before the add): d wq / d bq are EQUAL, d y3 agrees within that rounding and is no further from the
+    formula.  k = 37: row / k is a multiply-high in the kernel; 1517 / 7 rows: partial 32-row tiles."""
+    from ppsurf_amd import train_ops
+    g = torch.Generator().manual_seed(100 + nq + k)
+    y3 = (torch.randn(nq * k, 256, generator=g)).to(dt).to(DEV)
+    wq = (torch.randn(64, 256, generator=g) / 8).to(DEV)
+    bq = (torch.randn(64, generator=g) * 0.1).to(DEV)
+    gout = torch.randn(nq, 256, generator=g).to(dt).to(DEV)
+    res = {}
+    for mode in ('rebuilt', 'stored'):
+        monkeypatch.setenv('PPS_ATTN_GRAD', mode)
+        leaves = [y3.clone().requires_grad_(True), wq.clone().requires_grad_(True), bq.clone().requires_grad_(True)]
+        with torch.autocast('cuda', dtype=dt):
+            pooled = train_ops.query_attn_pool(leaves[0], leaves[1], leaves[2], k)
+        res[mode] = (pooled.detach(),) + torch.autograd.grad(pooled, leaves, gout)
+    assert all(torch.equal(a, b) for a, b in zip(res['rebuilt'][:1] + res['rebuilt'][2:], res['stored'][:1] + res['stored'][2:]))
+    # the formula in float64 on the stored operands (qy rounded to the storage type like the kernels' saved tensor)
+    yd = y3.double().requires_grad_(True)
+    qy = (torch.relu(yd) @ wq.to(dt).double().t() + bq.double())
+    qy = qy + (qy.detach().to(dt).double() - qy.detach())                    # value rounded, gradient straight through
+    att = torch.softmax(qy.view(nq, k, 64), dim=1).mean(dim=2)
+    ref = torch.autograd.grad((att.unsqueeze(2) * torch.relu(yd).view(nq, k, 256)).sum(1), yd, gout.double())[0]
+    a, b = res['rebuilt'][1].double(), res['stored'][1].double()
+    eps = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    scale = float(ref.abs().max())
+    assert float((a - b).abs().max()) <= 2 * eps * scale
+    ea, eb = float((a - ref).norm()), float((b - ref).norm())
+    assert ea <= 1.02 * eb + 1e-9, (ea, eb)
+    assert float((a - ref).abs().max()) <= 0.03 * scale

@@ -257,7 +257,32 @@ def test_col_sum_is_the_exact_sum_of_the_stored_values(rows, c, dt):
     want = x.double().sum(0)
     torch.testing.assert_close(got.double(), want, rtol=2e-6, atol=2e-6 * float(x.double().abs().sum(0).max()))
     assert torch.equal(got, train_ops.col_sum(x))                       # fixed summation order
-    assert train_ops.col_sum(x[:, :c // 2]) is None and train_ops.col_sum(torch.zeros(8, 6, device=DEV)) is None      # not contiguous / not a shape it takes
+    assert train_ops.col_sum(torch.zeros(8, 6, device=DEV)) is None and train_ops.col_sum(x[:, 1:5]) is None      # not a shape / not an alignment it takes
+    # a block of columns of the wider tensor, summed where it lies (pps_col_sum_strided): the same numbers as the sum of its contiguous copy
+    half = x[:, c // 2:]
+    assert not half.is_contiguous() or rows == 1
+    assert torch.equal(train_ops.col_sum(half), train_ops.col_sum(half.contiguous()))
+    torch.testing.assert_close(train_ops.col_sum(half), got[c // 2:], rtol=2e-6, atol=0)       # (another width: another row-to-thread map, another order)
+
+
+def test_sum_rows_of_a_wide_gradient_reads_it_once():
+    """[rows, 4096] (the bias gradient of the widest layer of the step): four strided column sums, no copies of the blocks -- equal to the sums of the
+    contiguous blocks, and no device memcpy / copy kernel is issued."""
+    from ppsurf_amd import train_ops
+    from torch.utils._python_dispatch import TorchDispatchMode
+    x = torch.randn(5000, 4096, device=DEV).to(torch.bfloat16)
+    seen = []
+
+    class Spy(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            seen.append(str(func))
+            return func(*args, **(kwargs or {}))
+    with Spy():
+        got = train_ops.sum_rows(x)
+    assert not any(name.startswith(('aten.clone', 'aten.copy_', 'aten.contiguous')) for name in seen), seen
+    want = torch.cat([train_ops.col_sum(x[:, i:i + 1024].contiguous()) for i in range(0, 4096, 1024)])
+    assert torch.equal(got, want)
+    torch.testing.assert_close(got.double(), x.double().sum(0), rtol=2e-6, atol=2e-6 * float(x.double().abs().sum(0).max()))
 
 
 def test_neighbour_max_returns_the_storage_type_it_was_given():
