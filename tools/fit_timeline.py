@@ -45,8 +45,8 @@ def main(src, nsteps, by_grid=False, per_queue=False):
     with open(files[0]) as fh:
         for r in csv.DictReader(fh):
             name = short(r['Kernel_Name'])
-            if by_grid and r.get('Grid_Size'):
-                name = '{} [grid {}]'.format(name[:50], r['Grid_Size'])
+            if by_grid and r.get('Grid_Size_X', r.get('Grid_Size')):
+                name = '{} [grid {}]'.format(name[:50], r.get('Grid_Size_X', r.get('Grid_Size')))
             rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), name, r.get('Queue_Id', '0'), r.get('Stream_Id', '0')))
     rows.sort()
     marks = [e for s, e, n, q, st in rows if n.startswith('adamw_pieces_kernel')]
