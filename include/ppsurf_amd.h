@@ -469,6 +469,11 @@ int pps_attn_pool_bwd_weights(const void* qy, const void* h, const void* dpooled
 int pps_patch_attn_partials(int64_t q);
 int pps_patch_attn_fwd(const void* h, const float* v, int64_t q, int k, int c, int dtype, float* pooled, void* stream);
 int pps_patch_attn_bwd(const void* h, const float* v, const float* dpooled, int64_t q, int k, int c, int dtype, void* dh, float* dv_part, void* stream);
+/* pps_patch_attn_bwd without dh: dh[q, j, :] = a[q, j] dpooled[q, :] + dl[q, j] v has rank two per group, so the [q k, 256] tensor is not written --
+ * `weights` and `dlogits` [q, k] fp32 receive a and dl (dl = a (dpooled . h_j - sum_i a_i dpooled . h_i)) and pps_rows_layer_bwd_rank2 rebuilds the
+ * rows where the producing layer's backward reads them. */
+int pps_patch_attn_bwd_weights(const void* h, const float* v, const float* dpooled, int64_t q, int k, int c, int dtype, float* weights, float* dlogits,
+                               float* dv_part, void* stream);
 
 /* Input of the interpolation head in train() (source/poco_model.py:400-404 with fc1 split into its latent and its offset part):
  * h1[(q,j),:] = table[ids[q,j],:] + wx (query[q] - pts[ids[q,j]]).  table [n, c] bf16, ids [q*k] (rows of table and pts), pts [n, 3] and
@@ -541,6 +546,16 @@ int pps_rows_layer_bwd_pooled(const void* x, const void* y, const void* gval, co
                               int dtype, const float* in_scale, const float* in_shift, int in_relu, const float* w, const float* gamma,
                               const float* save, const float* d_affine, void* dx, float* d_in_affine, float* dw, float* dbias, float* dgamma,
                               float* dbeta, void* ws, void* stream);
+
+/* pps_rows_layer_bwd for the layer whose raw output only feeds pps_patch_attn_fwd over the pool_p rows of every group (conv3 / bn3 of PointNet in
+ * front of AttentionPoco, source/base/nn.py:84-96,333-336): the incoming gradient gy[r, c] = g_a[r] g_dp[r / pool_p, c] + g_dl[r] g_v[c]
+ * (g_a, g_dl [rows] and g_dp [rows / pool_p, cout], g_v [cout] fp32: pps_patch_attn_bwd_weights) is rebuilt on load in the input-gradient and the
+ * weight-gradient kernel, rounded to the storage type like the tensor it replaces.  Shapes as pps_rows_layer_bwd_pooled (cin 128, cout 256,
+ * BatchNorm statistics on the output). */
+int pps_rows_layer_bwd_rank2(const void* x, const void* y, const float* g_a, const float* g_dl, const float* g_dp, const float* g_v, int pool_p, int64_t rows,
+                             int cin, int cout, int dtype, const float* in_scale, const float* in_shift, int in_relu, const float* w, const float* gamma,
+                             const float* save, const float* d_affine, void* dx, float* d_in_affine, float* dw, float* dbias, float* dgamma,
+                             float* dbeta, void* ws, void* stream);
 
 /* AdamW step over all parameter tensors of a group in one launch: replaces the optimizer step of the reference's trainer
  * (configs/poco.yaml:60-69 torch.optim.AdamW; arithmetic of torch's fused implementation, amsgrad and maximize off).

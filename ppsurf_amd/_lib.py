@@ -91,6 +91,7 @@ SIGNATURES = {
     'pps_patch_attn_partials': (_I, [_I64]),
     'pps_patch_attn_fwd': (_I, [_P, _P, _I64, _I, _I, _I, _P, _P]),
     'pps_patch_attn_bwd': (_I, [_P, _P, _P, _I64, _I, _I, _I, _P, _P, _P]),
+    'pps_patch_attn_bwd_weights': (_I, [_P, _P, _P, _I64, _I, _I, _I, _P, _P, _P, _P]),
     'pps_head_input_ws_bytes': (_SZ, [_I]),
     'pps_head_input_fwd': (_I, [_P, _P, _P, _P, _I64, _I, _I, _I, _P, _P, _P]),
     'pps_head_input_dwx': (_I, [_P, _P, _P, _P, _I64, _I, _I, _I, _P, _P, _P]),
@@ -110,6 +111,7 @@ SIGNATURES = {
     'pps_rows_layer_bwd_attn': (_I, [_P, _P, _I64, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     'pps_rows_layer_pooled_supported': (_I, [_I, _I, _I]),
     'pps_rows_layer_bwd_pooled': (_I, [_P, _P, _P, _P, _I, _I64, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'pps_rows_layer_bwd_rank2': (_I, [_P, _P, _P, _P, _P, _P, _I, _I64, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'pps_bn_train_ws_bytes': (_SZ, [_I64, _I]),
     'pps_bn_train_fwd': (_I, [_P, _I64, _I, _I, _P, _P, _P, _P, _c.c_float, _c.c_float, _I, _P, _P, _P, _P]),
     'pps_bn_train_bwd': (_I, [_P, _P, _I64, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P]),

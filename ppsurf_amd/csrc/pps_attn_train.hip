@@ -328,7 +328,8 @@ __global__ __launch_bounds__(PA_WAVES * 64, 2) void patch_attn_fwd_kernel(const 
 template <typename T, int KP>
 __global__ __launch_bounds__(PA_WAVES * 64, 2) void patch_attn_bwd_kernel(const T* __restrict__ h, const float* __restrict__ v,
                                                                          const float* __restrict__ dpooled, int64_t Q, int k, T* __restrict__ dh,
-                                                                         float* __restrict__ dv_part) {
+                                                                         float* __restrict__ dv_part, float* __restrict__ a_out = nullptr,
+                                                                         float* __restrict__ dl_out = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float4 v4 = *(const float4*)(v + 4 * lane);
     float4 dv = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -361,12 +362,18 @@ __global__ __launch_bounds__(PA_WAVES * 64, 2) void patch_attn_bwd_kernel(const 
         const float a = e / wave_sum(e);
         const float tbar = wave_sum(a * t);
         const float dl = a * (t - tbar);
-        T* dst = dh + q * (int64_t)k * 256 + 4 * lane;
+        // dh == NULL: dh[q, j, :] = a_j dP + dl_j v has rank two per group -- the caller gets (a, dl) per row and the consumers of dh rebuild it on
+        // load (pps_rows_layer_bwd_rank2); the [Q k, 256] tensor is neither written here nor read there
+        if (a_out && lane < k) {
+            a_out[q * (int64_t)k + lane] = a;
+            dl_out[q * (int64_t)k + lane] = dl;
+        }
+        T* dst = dh ? dh + q * (int64_t)k * 256 + 4 * lane : nullptr;
 #pragma unroll 8
         for (int j = 0; j < k; ++j) {
             const float aj = __shfl(a, j), dj = __shfl(dl, j);
             const float4 x = row4(src, j, lane);
-            st4(dst, (int64_t)j * 256, make_float4(aj * dp.x + dj * v4.x, aj * dp.y + dj * v4.y, aj * dp.z + dj * v4.z, aj * dp.w + dj * v4.w));
+            if (dst) st4(dst, (int64_t)j * 256, make_float4(aj * dp.x + dj * v4.x, aj * dp.y + dj * v4.y, aj * dp.z + dj * v4.z, aj * dp.w + dj * v4.w));
             dv.x += dj * x.x; dv.y += dj * x.y; dv.z += dj * x.z; dv.w += dj * x.w;
         }
     }
@@ -453,18 +460,30 @@ int pps_patch_attn_fwd(const void* h, const float* v, int64_t q, int k, int c, i
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
 
-int pps_patch_attn_bwd(const void* h, const float* v, const float* dpooled, int64_t q, int k, int c, int dtype, void* dh, float* dv_part, void* stream) {
+static int patch_attn_bwd_any(const void* h, const float* v, const float* dpooled, int64_t q, int k, int c, int dtype, void* dh, float* dv_part, float* a_out,
+                              float* dl_out, void* stream) {
     if (q < 0 || k < 1 || k > PA_K || c != 256 || (dtype != 1 && dtype != 2)) return PPS_ERR_ARG;
     if (q == 0) return PPS_OK;
-    if (!h || !v || !dpooled || !dh || !dv_part) return PPS_ERR_ARG;
+    if (!h || !v || !dpooled || !dv_part || (!dh && !(a_out && dl_out))) return PPS_ERR_ARG;
     const dim3 grid(patch_grid(q)), block(PA_WAVES * 64);
     hipStream_t st = (hipStream_t)stream;
-#define PPS_PA_BWD(T, KP) hipLaunchKernelGGL((patch_attn_bwd_kernel<T, KP>), grid, block, 0, st, (const T*)h, v, dpooled, q, k, (T*)dh, dv_part)
+#define PPS_PA_BWD(T, KP) hipLaunchKernelGGL((patch_attn_bwd_kernel<T, KP>), grid, block, 0, st, (const T*)h, v, dpooled, q, k, (T*)dh, dv_part, a_out, dl_out)
     if (dtype == 2) PPS_PA_BY_K(PPS_PA_BWD, half_t);
     else PPS_PA_BY_K(PPS_PA_BWD, uint16_t);
 #undef PPS_PA_BWD
 #undef PPS_PA_BY_K
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
+}
+
+int pps_patch_attn_bwd(const void* h, const float* v, const float* dpooled, int64_t q, int k, int c, int dtype, void* dh, float* dv_part, void* stream) {
+    if (q > 0 && !dh) return PPS_ERR_ARG;
+    return patch_attn_bwd_any(h, v, dpooled, q, k, c, dtype, dh, dv_part, nullptr, nullptr, stream);
+}
+
+int pps_patch_attn_bwd_weights(const void* h, const float* v, const float* dpooled, int64_t q, int k, int c, int dtype, float* weights, float* dlogits,
+                               float* dv_part, void* stream) {
+    if (q > 0 && (!weights || !dlogits)) return PPS_ERR_ARG;
+    return patch_attn_bwd_any(h, v, dpooled, q, k, c, dtype, nullptr, dv_part, weights, dlogits, stream);
 }
 
 }  // extern "C"

@@ -116,4 +116,12 @@ int pps_rows_layer_bwd_pooled(const void* x, const void* y, const void* gval, co
                                                  d_in_affine, dw, dbias, dgamma, dbeta, ws, stream));
 }
 
+int pps_rows_layer_bwd_rank2(const void* x, const void* y, const float* g_a, const float* g_dl, const float* g_dp, const float* g_v, int pool_p, int64_t rows,
+                             int cin, int cout, int dtype, const float* in_scale, const float* in_shift, int in_relu, const float* w, const float* gamma,
+                             const float* save, const float* d_affine, void* dx, float* d_in_affine, float* dw, float* dbias, float* dgamma,
+                             float* dbeta, void* ws, void* stream) {
+    return PPS_BY_TYPE(pps_rows_layer_bwd_rank2(x, y, g_a, g_dl, g_dp, g_v, pool_p, rows, cin, cout, in_scale, in_shift, in_relu, w, gamma, save, d_affine, dx,
+                                                d_in_affine, dw, dbias, dgamma, dbeta, ws, stream));
+}
+
 }  // extern "C"

@@ -84,6 +84,12 @@ struct LayerArgs {
     const uint8_t* garg;          // dx, POOL: winning row of every (group, channel) [rows / pool_p, CK]; src is then the gradient per GROUP
     int pool_p;                   // dx, POOL: rows per group
     unsigned pool_magic;          // floor(2^32 / pool_p) + 1
+    // dx, POOL == 2: src is not read -- the gradient of a layer whose raw output only feeds the single-head attention pooling over the pool_p rows
+    // of every group (PointNet's AttentionPoco, pps_patch_attn_bwd_weights) has rank two per group and is rebuilt on load (att_grad8)
+    const float* g_a;             // [rows]  softmax weight of the row
+    const float* g_dl;            // [rows]  gradient of the row's logit
+    const float* g_dp;            // [rows / pool_p, CK] fp32: gradient of the pooled row
+    const float* g_v;             // [CK] fp32: the logit's weight vector
     // dx, second gradient of x rebuilt instead of read (attention pooling over the att_k rows of a group, pps_attn_pool_bwd_weights):
     //   dx[row, c] += relu'(x[row, c]) * att_a[row] * att_dp[row / att_k, c]
     const float* att_a;           // [rows] or NULL
@@ -109,12 +115,28 @@ __device__ __forceinline__ u32x4 pooled_grad8(const uint16_t* gval, const uint8_
     return o;
 }
 
+// gy[row, c] = a[row] * dP[row / p, c] + dl[row] * v[c]  (pps_attn_train.hip patch_attn_bwd_kernel: the same two products and one sum in fp32, rounded
+// to the storage type like the tensor it used to store): 8 channels of one row from 2 floats of the row, 32 cached bytes of its group and of v
+__device__ __forceinline__ u32x4 att_grad8(const float* ga, const float* gdl, const float* gdp, const float* gv, unsigned magic, int64_t row, int c, int col8) {
+    const unsigned grp = __umulhi((unsigned)row, magic);
+    const float aj = ga[row], dj = gdl[row];
+    const float* dpq = gdp + (int64_t)grp * c + col8;
+    const f32x4 d0 = *(const f32x4*)dpq, d1 = *(const f32x4*)(dpq + 4);
+    const f32x4 v0 = *(const f32x4*)(gv + col8), v1 = *(const f32x4*)(gv + col8 + 4);
+    u32x4 o;
+    o.x = pack2(aj * d0[0] + dj * v0[0], aj * d0[1] + dj * v0[1]);
+    o.y = pack2(aj * d0[2] + dj * v0[2], aj * d0[3] + dj * v0[3]);
+    o.z = pack2(aj * d1[0] + dj * v1[0], aj * d1[1] + dj * v1[1]);
+    o.w = pack2(aj * d1[2] + dj * v1[2], aj * d1[3] + dj * v1[3]);
+    return o;
+}
+
 // R = 16-row tiles a wave carries through the weights together: 2, except 1 in the input-gradient kernel with 128 channels per wave,
 // whose epilogue (x, scale, shift, two sums per channel) would not fit the registers next to two tiles of accumulators
 template <int CO, bool DX>
 constexpr int tiles_of() { return (DX && CO >= 128) ? 1 : 2; }
 
-template <int CK, int CO, bool DX, bool POOL = false>
+template <int CK, int CO, bool DX, int POOL = 0>            // POOL: 0 gradient read from src, 1 pooled_grad8, 2 att_grad8
 __global__ __launch_bounds__(NT, 1) void rows_layer_kernel(const LayerArgs a) {
     constexpr int R = tiles_of<CO, DX>();
     constexpr int KS = CK / 32;                     // k-steps of 32 channels
@@ -194,7 +216,8 @@ __global__ __launch_bounds__(NT, 1) void rows_layer_kernel(const LayerArgs a) {
             for (int sc = 0; sc < KC; ++sc)
 #pragma unroll
                 for (int t = 0; t < R; ++t) {
-                    if constexpr (POOL) raw[sc][t] = pooled_grad8(a.src, a.garg, a.pool_p, a.pool_magic, rowc[t], CK, 32 * (s0 + sc) + 8 * g);
+                    if constexpr (POOL == 1) raw[sc][t] = pooled_grad8(a.src, a.garg, a.pool_p, a.pool_magic, rowc[t], CK, 32 * (s0 + sc) + 8 * g);
+                    else if constexpr (POOL == 2) raw[sc][t] = att_grad8(a.g_a, a.g_dl, a.g_dp, a.g_v, a.pool_magic, rowc[t], CK, 32 * (s0 + sc) + 8 * g);
                     else raw[sc][t] = *(const u32x4*)(a.src + rowc[t] * CK + 32 * (s0 + sc) + 8 * g);
                     if (dx_y) raw2[sc][t] = *(const u32x4*)(a.src2 + rowc[t] * CK + 32 * (s0 + sc) + 8 * g);
                 }
@@ -366,6 +389,10 @@ struct DwArgs {
     const uint8_t* garg;          // POOL: gy is the gradient per group [rows / pool_p, CO], garg the winning rows (see pooled_grad8)
     int pool_p;
     unsigned pool_magic;
+    const float* g_a;             // POOL == 2: gy is not read, see LayerArgs / att_grad8
+    const float* g_dl;
+    const float* g_dp;
+    const float* g_v;
 };
 
 __device__ __forceinline__ u32x2 lds_tr_read(const uint16_t* p) {
@@ -379,7 +406,7 @@ __device__ __forceinline__ void lds_tr_wait(u32x2& v) { asm volatile("s_waitcnt 
 template <int CI, int CO>
 constexpr int dw_ksteps() { return CI + CO <= 128 ? 4 : (CI + CO <= 384 ? 2 : 1); }
 
-template <int CI, int CO, bool HAS_Y, bool POOL = false>
+template <int CI, int CO, bool HAS_Y, int POOL = 0>
 __global__ __launch_bounds__(NT, 1) void rows_dw_kernel(const DwArgs a) {
     constexpr int KRS = dw_ksteps<CI, CO>();        // MFMA contraction steps (32 rows each) per staged tile: narrow layers stage more rows per barrier
     constexpr int KR = 32 * KRS;                    // rows per step
@@ -437,7 +464,10 @@ __global__ __launch_bounds__(NT, 1) void rows_dw_kernel(const DwArgs a) {
             const int row = id / (CO / 8), ch = id % (CO / 8);
             const int64_t rr = r0 + row < a.rows ? r0 + row : a.rows - 1;     // rows past the end re-read the last row (zeroed when staged): no
             if (id < GCH) {                                                  // lane-dependent branch around the loads, they all issue back to back
-                if constexpr (POOL) rg[it] = pooled_grad8(a.gy, a.garg, a.pool_p, a.pool_magic, rr, CO, 8 * ch);
+                if constexpr (POOL == 1) rg[it] = pooled_grad8(a.gy, a.garg, a.pool_p, a.pool_magic, rr, CO, 8 * ch);
+                // (POOL == 2, tried: the ingredients -- 2 floats of the row, 8 of its group -- carried in the registers and put together in stage(),
+                // so that no arithmetic waits for loads in front of the MFMA section: 107 spilled VGPRs, the kernel has 4 registers to spare)
+                else if constexpr (POOL == 2) rg[it] = att_grad8(a.g_a, a.g_dl, a.g_dp, a.g_v, a.pool_magic, rr, CO, 8 * ch);
                 else rg[it] = *(const u32x4*)(a.gy + rr * CO + 8 * ch);
                 if constexpr (HAS_Y) ry[it] = *(const u32x4*)(a.y + rr * CO + 8 * ch);
             }
@@ -1074,7 +1104,7 @@ int grid_for(int64_t units) {
 template <typename K>
 bool allow_lds(K kernel, size_t bytes) { return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess; }
 
-template <int CK, int CO, bool DX, bool POOL = false>
+template <int CK, int CO, bool DX, int POOL = 0>
 int launch_layer(const LayerArgs& a, int grid, hipStream_t st) {
     static bool ok = allow_lds(rows_layer_kernel<CK, CO, DX, POOL>, layer_lds<CK, CO>());
     if (!ok) return PPS_ERR_LAUNCH;
@@ -1082,7 +1112,7 @@ int launch_layer(const LayerArgs& a, int grid, hipStream_t st) {
     hipLaunchKernelGGL((rows_layer_kernel<CK, CO, DX, POOL>), dim3(grid), dim3(NT), lds, st, a);
     return hipGetLastError() == hipSuccess ? PPS_OK : PPS_ERR_LAUNCH;
 }
-template <int CI, int CO, bool HAS_Y, bool POOL = false>
+template <int CI, int CO, bool HAS_Y, int POOL = 0>
 int launch_dw_y(const DwArgs& a, int grid, hipStream_t st) {
     static bool ok = allow_lds(rows_dw_kernel<CI, CO, HAS_Y, POOL>, dw_lds<CI, CO>());
     if (!ok) return PPS_ERR_LAUNCH;
@@ -1279,14 +1309,16 @@ bool pooled_ok(int cin, int cout, bool bn, int pool_p, int64_t rows) {
 int rows_layer_bwd_any(const void* x, const void* y, const void* gy, const uint8_t* garg, int pool_p, int64_t rows, int cin, int cout,
                        const float* in_scale, const float* in_shift, int in_relu, const float* w, const float* gamma, const float* save,
                        const float* d_affine, void* dx, const void* dx_add, float* d_in_affine, float* dw, float* dbias, float* dgamma, float* dbeta,
-                       void* ws, void* stream, const float* att_a = nullptr, const void* att_dp = nullptr, int att_k = 0) {
+                       void* ws, void* stream, const float* att_a = nullptr, const void* att_dp = nullptr, int att_k = 0,
+                       const float* const* rank2 = nullptr /* {a, dl, dP, v}: the gradient rebuilt by att_grad8, gy and garg unused */) {
     if (rows < 1 || !dim_ok(cin) || !dim_ok(cout)) return PPS_ERR_ARG;
     if (att_a && (!att_dp || dx_add || in_scale || !in_relu || att_k < 1 || rows % att_k || rows * att_k >= (int64_t)1 << 32)) return PPS_ERR_ARG;
-    if (!x || !gy || !w || !ws || ((in_scale == nullptr) != (in_shift == nullptr))) return PPS_ERR_ARG;
+    if (!x || (!gy && !rank2) || !w || !ws || ((in_scale == nullptr) != (in_shift == nullptr))) return PPS_ERR_ARG;
     const bool bn = gamma != nullptr;
     if (bn && (!y || !save || !d_affine || !dgamma || !dbeta)) return PPS_ERR_ARG;
     const bool pool = pool_p != 0;
-    if (pool && (!garg || !pooled_ok(cin, cout, bn, pool_p, rows))) return PPS_ERR_ARG;
+    if (pool && ((!garg && !rank2) || !pooled_ok(cin, cout, bn, pool_p, rows))) return PPS_ERR_ARG;
+    if (rank2 && (!pool || !rank2[0] || !rank2[1] || !rank2[2] || !rank2[3])) return PPS_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const size_t big = (size_t)(cin > cout ? cin : cout);
     float* part_aff = (float*)ws;                                       // [MAXP][2][big]
@@ -1322,7 +1354,9 @@ int rows_layer_bwd_any(const void* x, const void* y, const void* gy, const uint8
         a.garg = garg;
         a.pool_p = pool_p;
         a.pool_magic = pool ? (unsigned)(0x100000000ull / (unsigned)pool_p) + 1u : 0u;
-        if (pool) rc = launch_layer<256, 128, true, true>(a, grid, st);
+        if (rank2) { a.g_a = rank2[0]; a.g_dl = rank2[1]; a.g_dp = rank2[2]; a.g_v = rank2[3]; }
+        if (rank2) rc = launch_layer<256, 128, true, 2>(a, grid, st);
+        else if (pool) rc = launch_layer<256, 128, true, 1>(a, grid, st);
         else PPS_DISPATCH(cin, cout, rc = (launch_layer<O, I, true>(a, grid, st)));
         if (rc != PPS_OK) return rc;
         if (d_in_affine) {
@@ -1352,7 +1386,9 @@ int rows_layer_bwd_any(const void* x, const void* y, const void* gy, const uint8
         a.garg = garg;
         a.pool_p = pool_p;
         a.pool_magic = pool ? (unsigned)(0x100000000ull / (unsigned)pool_p) + 1u : 0u;
-        if (pool) rc = launch_dw_y<128, 256, true, true>(a, grid, st);
+        if (rank2) { a.g_a = rank2[0]; a.g_dl = rank2[1]; a.g_dp = rank2[2]; a.g_v = rank2[3]; }
+        if (rank2) rc = launch_dw_y<128, 256, true, 2>(a, grid, st);
+        else if (pool) rc = launch_dw_y<128, 256, true, 1>(a, grid, st);
         else PPS_DISPATCH(cin, cout, rc = (launch_dw<I, O>(a, grid, st)));
         if (rc != PPS_OK) return rc;
         const int64_t nw = (int64_t)cin * cout;
@@ -1385,6 +1421,16 @@ int pps_rows_layer_bwd_attn(const void* x, const void* gy, int64_t rows, int cin
     if (!att_weights || !dx) return PPS_ERR_ARG;
     return rows_layer_bwd_any(x, nullptr, gy, nullptr, 0, rows, cin, cout, nullptr, nullptr, 1, w, nullptr, nullptr, nullptr, dx, nullptr, nullptr, dw, dbias,
                               nullptr, nullptr, ws, stream, att_weights, att_dpooled, att_k);
+}
+
+int pps_rows_layer_bwd_rank2(const void* x, const void* y, const float* g_a, const float* g_dl, const float* g_dp, const float* g_v, int pool_p, int64_t rows,
+                             int cin, int cout, const float* in_scale, const float* in_shift, int in_relu, const float* w, const float* gamma,
+                             const float* save, const float* d_affine, void* dx, float* d_in_affine, float* dw, float* dbias, float* dgamma, float* dbeta,
+                             void* ws, void* stream) {
+    if (pool_p == 0) return PPS_ERR_ARG;
+    const float* const rank2[4] = {g_a, g_dl, g_dp, g_v};
+    return rows_layer_bwd_any(x, y, nullptr, nullptr, pool_p, rows, cin, cout, in_scale, in_shift, in_relu, w, gamma, save, d_affine, dx, nullptr, d_in_affine,
+                              dw, dbias, dgamma, dbeta, ws, stream, nullptr, nullptr, 0, rank2);
 }
 
 int pps_rows_layer_pooled_supported(int cin, int cout, int pool_p) { return pooled_ok(cin, cout, true, pool_p, (int64_t)pool_p) ? 1 : 0; }

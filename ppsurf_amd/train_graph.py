@@ -869,14 +869,22 @@ def _pointnet_fused(pn, patches, need_trans=True):
     trans2 = t_raw.detach().float() + torch.eye(d, device=h.device).view(1, d, d) if need_trans else None
     z = _layer(train_ops.Act(h), pn.conv1, pn.bn1, True)
     z = _layer(z, pn.conv2, pn.bn2, True)
-    z = _layer(z, pn.conv3, pn.bn3, False)
     # AttentionPoco (nn.py:84-96) on h = raw * scale + shift (no ReLU after bn3): the logit is linear in raw, and the pooled row of h is the
     # affine image of the pooled raw row because the weights of a patch sum to 1
-    scale, shift = z.affine[0], z.affine[1]
     wq = _w2d(pn.att.fc_query).float()
+    w3 = _w2d(pn.conv3)
+    if (_os.environ.get('PPS_PATCH_ATTN_GRAD', 'rebuilt') != 'stored'
+            and train_ops.rows_layer_patch_attn_supported(w3.shape[1], w3.shape[0], p, nq * p)):
+        # conv3 / bn3 and the pooling as one node: the gradient of conv3's raw output has rank two per patch and is rebuilt where it is read
+        _count_batch(pn.bn3)
+        pooled, aff3 = train_ops.rows_layer_patch_attn(z, w3, pn.conv3.bias, pn.bn3, wq, nq, p)
+        scale, shift = aff3[0], aff3[1]
+    else:
+        z = _layer(z, pn.conv3, pn.bn3, False)
+        scale, shift = z.affine[0], z.affine[1]
+        pooled = train_ops.patch_attn(z.raw.view(nq, p, -1), (wq * scale).reshape(-1))
     # (softmax ignores the constant w_q . shift + b_q; it stays in the graph with weight 0 so that fc_query.bias gets its zero gradient, not None)
     const = (wq * shift).sum() + pn.att.fc_query.bias.float().sum()
-    pooled = train_ops.patch_attn(z.raw.view(nq, p, -1), (wq * scale).reshape(-1))
     pooled = (train_ops.affine_rows(pooled, scale, shift) + 0.0 * const).to(z.raw.dtype)      # (the row sums of its backward by the HIP reduction)
     return dense(pn.att.fc_value, pooled), trans2
 

@@ -905,6 +905,90 @@ def rows_layer(act, w, b, bn=None, relu=False):
     return Act(y, aff, relu)
 
 
+class _RowsLayerPatchAttn(torch.autograd.Function):
+    """rows_layer with BatchNorm statistics (conv3 / bn3 of PointNet) followed by the single-head attention pooling over the p rows of every group
+    (AttentionPoco, source/base/nn.py:84-96, on the RAW layer output: logit = raw . (w_q * scale) + const, and softmax ignores the constant) as
+    ONE node.  The raw output is stored (both backward passes need it), but its gradient -- a[q, j] dpooled[q, :] + dl[q, j] v, rank two per group
+    -- is never a tensor: pps_patch_attn_bwd_weights returns (a, dl) per row and pps_rows_layer_bwd_rank2 rebuilds the rows on load in the
+    input-gradient and the weight-gradient kernel (1 M x 256 bf16 = 512 MB per step: written once and read twice otherwise).
+    Returns (pooled raw rows [groups, cout] fp32, out_affine [2, cout]): the caller applies the BatchNorm's affine to the pooled rows (the
+    weights of a group sum to 1)."""
+
+    @staticmethod
+    def forward(ctx, x, in_affine, in_relu, w, b, gamma, beta, running_mean, running_var, momentum, eps, wq, groups, p):
+        _need_cuda(x, w, wq)
+        L = _lib.lib()
+        x = _low(x)
+        rows, cin = x.shape
+        cout = w.shape[0]
+        dev = x.device
+        w32 = w.detach().float().contiguous()
+        b32 = None if b is None else b.detach().float().contiguous()
+        aff = None if in_affine is None else in_affine.detach().float().contiguous()
+        g32, be32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        y = torch.empty((rows, cout), device=dev, dtype=x.dtype)
+        out_affine = torch.empty((2, cout), device=dev, dtype=torch.float32)
+        save = torch.empty((2, cout), device=dev, dtype=torch.float32)
+        ws = torch.empty((L.pps_rows_layer_ws_bytes(cin, cout),), device=dev, dtype=torch.uint8)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        _lib.check(L.pps_rows_layer_fwd(x.data_ptr(), rows, cin, _code(x.dtype), ptr(aff), None if aff is None else aff.data_ptr() + 4 * cin, int(bool(in_relu)),
+                                        w32.data_ptr(), ptr(b32), cout, y.data_ptr(), g32.data_ptr(), be32.data_ptr(), ptr(running_mean), ptr(running_var),
+                                        float(momentum or 0.0), float(eps or 0.0), out_affine.data_ptr(), save.data_ptr(), ws.data_ptr(), _stream()),
+                   'pps_rows_layer_fwd')
+        wq32 = wq.detach().float().reshape(-1).contiguous()
+        v = wq32 * out_affine[0]                                                     # the logit's weights on the raw output
+        pooled = torch.empty((groups, cout), device=dev, dtype=torch.float32)
+        _lib.check(L.pps_patch_attn_fwd(y.data_ptr(), v.data_ptr(), groups, p, cout, _code(y.dtype), pooled.data_ptr(), _stream()), 'pps_patch_attn_fwd')
+        ctx.save_for_backward(x, aff, w32, g32, save, y, v, wq32, out_affine)
+        ctx.meta = (bool(in_relu), b is not None, w.dtype, None if b is None else b.dtype, wq.dtype, tuple(wq.shape), groups, p)
+        return pooled, out_affine
+
+    @staticmethod
+    def backward(ctx, dpooled, g_affine):
+        x, aff, w32, g32, save, y, v, wq32, out_affine = ctx.saved_tensors
+        in_relu, has_b, wdt, bdt, qdt, qshape, groups, p = ctx.meta
+        L = _lib.lib()
+        rows, cin = x.shape
+        cout = w32.shape[0]
+        dev = x.device
+        st = _stream()
+        f32e = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
+        dpooled = torch.zeros((groups, cout), device=dev, dtype=torch.float32) if dpooled is None else dpooled.float().contiguous()
+        a, dl = f32e(rows), f32e(rows)
+        part = f32e(L.pps_patch_attn_partials(groups), cout)
+        _lib.check(L.pps_patch_attn_bwd_weights(y.data_ptr(), v.data_ptr(), dpooled.data_ptr(), groups, p, cout, _code(y.dtype), a.data_ptr(), dl.data_ptr(),
+                                                part.data_ptr(), st), 'pps_patch_attn_bwd_weights')
+        dv = sum_rows(part)
+        # v = w_q * scale: d w_q = dv * scale, and the scale of the layer's own BatchNorm gets dv * w_q on top of what its consumers hand back
+        dwq = (dv * out_affine[0]).reshape(qshape).to(qdt)
+        g_affine = torch.zeros((2, cout), device=dev, dtype=torch.float32) if g_affine is None else g_affine.float().clone()
+        g_affine[0] += dv * wq32
+        need_dx, need_daff = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and aff is not None
+        dx = torch.empty_like(x) if (need_dx or need_daff) else None
+        d_in = f32e(2, cin) if need_daff else None
+        dw = f32e(cout, cin)
+        db = f32e(cout) if has_b else None
+        dgamma, dbeta = f32e(cout), f32e(cout)
+        ws = torch.empty((L.pps_rows_layer_ws_bytes(cin, cout),), device=dev, dtype=torch.uint8)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        _lib.check(L.pps_rows_layer_bwd_rank2(x.data_ptr(), y.data_ptr(), a.data_ptr(), dl.data_ptr(), dpooled.data_ptr(), v.data_ptr(), p, rows, cin, cout,
+                                              _code(x.dtype), ptr(aff), None if aff is None else aff.data_ptr() + 4 * cin, int(in_relu), w32.data_ptr(),
+                                              g32.data_ptr(), save.data_ptr(), g_affine.data_ptr(), ptr(dx), ptr(d_in), dw.data_ptr(), ptr(db),
+                                              dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), st), 'pps_rows_layer_bwd_rank2')
+        return (dx if need_dx else None, d_in, None, dw.to(wdt), None if db is None else db.to(bdt), dgamma, dbeta, None, None, None, None, dwq, None, None)
+
+
+def rows_layer_patch_attn_supported(cin, cout, p, rows):
+    return bool(_lib.lib().pps_rows_layer_pooled_supported(cin, cout, p)) and patch_attn_supported(p, cout) and rows % p == 0 and rows * p < 1 << 32
+
+
+def rows_layer_patch_attn(act, w, b, bn, wq, groups, p):
+    """act: Act; w [cout, cin]; bn: BatchNorm1d holder (train() statistics on the output); wq: weight of the attention's fc_query [1, cout].
+    -> (pooled RAW rows [groups, cout] fp32, affine [2, cout] of bn)."""
+    return _RowsLayerPatchAttn.apply(act.raw, act.affine, act.relu, w, b, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, wq,
+                                     groups, p)
+
+
 def _query_attn_bwd(L, y3, qy, dpooled, wq32, k, dwq, dbq, ws, st):
     """Backward of (fc_query, attention pooling) on the stored raw output y3 of fc3 -> d y3 [Q*k, 256]; dwq / dbq are filled.  y3 has two
     consumers.  The pooling's gradient relu'(y3) * a[q, j] * dpooled[q, c] is one multiply per element, so it is NOT stored: pps_attn_pool_bwd_weights

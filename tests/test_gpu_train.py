@@ -684,3 +684,43 @@ def test_replayed_bf16_step_equals_the_eager_step(size, dropout):
     assert all(np.isfinite(res[True][0])) and res[True][0][-1] < (0.5 if dropout == 0.0 else 0.9) * res[True][0][0]
     assert res[False][0] == res[True][0], (res[False][0], res[True][0])
     assert all(torch.equal(res[False][1][k], res[True][1][k]) for k in res[True][1])
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('nq,p', [(700, 50), (33, 50), (129, 37), (64, 64)])
+def test_pointnet_with_the_rank_two_gradient_rebuilt_equals_the_stored_form(nq, p, dt, monkeypatch):
+    """PointNet in train() (train_graph.pointnet): conv3 / bn3 + the attention pooling as one node whose raw-output gradient a_j dP + dl_j v is
+    rebuilt on load by the layer's two backward kernels (pps_patch_attn_bwd_weights + pps_rows_layer_bwd_rank2, the default) against the same
+    gradient written to memory and read back (PPS_PATCH_ATTN_GRAD=stored: pps_patch_attn_bwd + pps_rows_layer_bwd).  The rebuilt rows are the stored
+    rows to the bit (same two products, one sum, one rounding), so the feature, the running statistics and EVERY parameter gradient are equal.
+    33 x 50 / 129 x 37 rows: partial 32-row tiles and a row / p that is not a shift."""
+    from ppsurf_amd import modules, train_graph
+    torch.manual_seed(3)
+    pn0 = modules.PointNetfeat(net_size_max=256, num_points=p, use_point_stn=False, use_feat_stn=True, output_size=256, sym_op='att', dim=3).to(DEV).train()
+    with torch.no_grad():
+        for name, prm in pn0.named_parameters():
+            if prm.dim() > 1:
+                prm.copy_(torch.randn_like(prm) / float(prm[0].numel()) ** 0.5)
+            elif name.endswith('weight'):
+                prm.copy_(1.0 + 0.2 * torch.randn_like(prm))            # BatchNorm scales (some end up negative after the step: both signs are covered)
+            else:
+                prm.copy_(0.1 * torch.randn_like(prm))
+    state = {k: v.clone() for k, v in pn0.state_dict().items()}
+    patches = (torch.rand(nq, p, 3, generator=torch.Generator().manual_seed(nq)) - 0.5).to(DEV)
+    gout = torch.randn(nq, 256, generator=torch.Generator().manual_seed(1)).to(DEV)
+    res = {}
+    for mode in ('rebuilt', 'stored'):
+        monkeypatch.setenv('PPS_PATCH_ATTN_GRAD', mode)
+        pn0.load_state_dict(state)
+        pn0.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=dt):
+            feat, _ = train_graph.pointnet(pn0, patches, need_trans=False)
+        (feat.float() * gout).sum().backward()
+        res[mode] = (feat.detach().clone(), {k: v.grad.clone() for k, v in pn0.named_parameters()}, {k: v.clone() for k, v in pn0.named_buffers()})
+    assert torch.isfinite(res['rebuilt'][0]).all() and float(res['rebuilt'][0].abs().max()) > 0
+    assert torch.equal(res['rebuilt'][0], res['stored'][0])
+    for k, g in res['stored'][1].items():
+        assert g is not None and torch.equal(res['rebuilt'][1][k], g), k
+    for k, b in res['stored'][2].items():
+        assert torch.equal(res['rebuilt'][2][k], b), k
+    assert float(res['stored'][1]['conv3.weight'].abs().max()) > 0 and float(res['stored'][1]['att.fc_query.weight'].abs().max()) > 0
